@@ -1,0 +1,260 @@
+"""Graph containers and the synthetic batch generator for the encode -> fuse -> score path.
+
+The reference feeds the model one nested dict batch built by its pandas collator
+(madrigal/data/data.py:948-974): per side ``{'drugs','strs','cv','tx','masks'}`` plus
+``batch_kg = {'data': HeteroData, 'drug_index_map'}``.  ``strs`` is a torchdrug
+``PackedMolecule`` and ``data`` a PyG ``HeteroData``; neither package is a dependency
+here.  :class:`MoleculeBatch` and :class:`KGData` carry exactly the attributes the path
+reads (``node_feature edge_list edge_feature node2graph batch_size edge_weight`` /
+``x_dict edge_index_dict metadata()``), so real torchdrug / PyG objects are accepted
+wherever these are (duck typing), and these are accepted by the reference's own model
+code.
+
+Everything random is drawn from numpy's PCG64 so that a (seed, size) pair names the
+same batch on every machine; golden fixtures store only the seed and the outputs.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+# madrigal/utils.py:25-37
+MOL_DIM = 67
+BOND_DIM = 18
+CELL_LINES = ['a375', 'a549', 'asc', 'ha1e', 'hcc515', 'hec108', 'hela', 'hepg2', 'ht29', 'huvec',
+              'mcf7', 'npc', 'pc3', 'thp1', 'vcap', 'yapc']
+NON_TX_MODALITIES = ["str", "kg", "cv"]
+NUM_NON_TX_MODALITIES = len(NON_TX_MODALITIES)
+NUM_MODALITIES = NUM_NON_TX_MODALITIES + len(CELL_LINES)
+CV_DIM = 559
+TX_DIM = 978
+
+_ATOM_BLOCKS = (18, 7, 7, 8, 7, 6, 7, 2, 5)     # one-hot groups, 67 in total
+_BOND_BLOCKS = (4, 3, 6, 2, 3)                  # one-hot groups, 18 in total
+assert sum(_ATOM_BLOCKS) == MOL_DIM and sum(_BOND_BLOCKS) == BOND_DIM
+
+
+@dataclass
+class MoleculeBatch:
+    """Packed batch of molecular graphs (the fields of torchdrug ``PackedMolecule`` the
+    structure encoder reads).  ``edge_list[:, 0]`` is the message source, ``[:, 1]`` the
+    destination, ``[:, 2]`` the bond type; both directions of every bond are present."""
+    node_feature: torch.Tensor      # [A, 67]
+    edge_list: torch.Tensor         # [E, 3] int64
+    edge_feature: torch.Tensor      # [E, 18]
+    node2graph: torch.Tensor        # [A] int64, non-decreasing
+    batch_size: int
+    edge_weight: Optional[torch.Tensor] = None   # [E]; None means all ones
+
+    def __post_init__(self):
+        if self.edge_weight is None:
+            self.edge_weight = torch.ones(self.edge_list.shape[0], dtype=torch.float32,
+                                          device=self.edge_list.device)
+
+    @property
+    def num_node(self) -> int:
+        return int(self.node_feature.shape[0])
+
+    @property
+    def num_edge(self) -> int:
+        return int(self.edge_list.shape[0])
+
+    def to(self, device):
+        return MoleculeBatch(self.node_feature.to(device), self.edge_list.to(device),
+                             self.edge_feature.to(device), self.node2graph.to(device),
+                             self.batch_size, self.edge_weight.to(device))
+
+    def cuda(self):
+        return self.to("cuda")
+
+
+@dataclass
+class KGData:
+    """Heterogeneous knowledge graph (the fields of PyG ``HeteroData`` the KG encoder reads)."""
+    x_dict: Dict[str, torch.Tensor]
+    edge_index_dict: Dict[Tuple[str, str, str], torch.Tensor]     # (src, rel, dst) -> [2, e] int64
+    node_types: List[str] = field(default_factory=list)
+    edge_types: List[Tuple[str, str, str]] = field(default_factory=list)
+
+    def __post_init__(self):
+        if not self.node_types:
+            self.node_types = list(self.x_dict.keys())
+        if not self.edge_types:
+            self.edge_types = list(self.edge_index_dict.keys())
+
+    def metadata(self):
+        return self.node_types, self.edge_types
+
+    def to(self, device):
+        return KGData({k: v.to(device) for k, v in self.x_dict.items()},
+                      {k: v.to(device) for k, v in self.edge_index_dict.items()},
+                      list(self.node_types), list(self.edge_types))
+
+
+def _one_hot_blocks(rng: np.random.Generator, n: int, blocks: Sequence[int]) -> np.ndarray:
+    out = np.zeros((n, sum(blocks)), dtype=np.float32)
+    off = 0
+    for b in blocks:
+        out[np.arange(n), off + rng.integers(0, b, size=n)] = 1.0
+        off += b
+    return out
+
+
+def make_molecules(n_mols: int, seed: int, mean_atoms: float = 26.0) -> MoleculeBatch:
+    """Random molecule-like graphs: atoms ~ clip(Poisson(mean),4,96), a random spanning
+    tree plus ~8 % ring-closure bonds, both directions of every bond."""
+    rng = np.random.default_rng([seed, 101])
+    n_atoms = np.clip(rng.poisson(mean_atoms, size=n_mols), 4, 96).astype(np.int64)
+    offsets = np.concatenate([[0], np.cumsum(n_atoms)])
+    src_l, dst_l = [], []
+    for g in range(n_mols):
+        a, o = int(n_atoms[g]), int(offsets[g])
+        parent = (rng.random(a - 1) * np.arange(1, a)).astype(np.int64)      # node i attaches to a node < i
+        u = np.arange(1, a, dtype=np.int64)
+        n_ring = int(round(0.08 * a))
+        ru = rng.integers(0, a, size=n_ring)
+        rv = rng.integers(0, a, size=n_ring)
+        keep = ru != rv
+        s = np.concatenate([u, ru[keep]]) + o
+        d = np.concatenate([parent, rv[keep]]) + o
+        src_l += [s, d]
+        dst_l += [d, s]
+    src = np.concatenate(src_l)
+    dst = np.concatenate(dst_l)
+    half_feat = None
+    E = src.shape[0]
+    # the two directions of a bond carry the same feature: draw per undirected bond
+    bond_feat_parts = []
+    pos = 0
+    for g in range(n_mols):
+        m = src_l[2 * g].shape[0]
+        f = _one_hot_blocks(rng, m, _BOND_BLOCKS)
+        bond_feat_parts += [f, f]
+        pos += 2 * m
+    edge_feature = np.concatenate(bond_feat_parts, axis=0)
+    bond_type = edge_feature[:, :4].argmax(1).astype(np.int64)
+    A = int(offsets[-1])
+    node_feature = _one_hot_blocks(rng, A, _ATOM_BLOCKS)
+    node2graph = np.repeat(np.arange(n_mols, dtype=np.int64), n_atoms)
+    del half_feat, E
+    return MoleculeBatch(torch.from_numpy(node_feature), torch.from_numpy(np.stack([src, dst, bond_type], 1)),
+                         torch.from_numpy(edge_feature), torch.from_numpy(node2graph), n_mols)
+
+
+def make_kg(n_kg_drugs: int, seed: int, n_nodes: int = 2000, n_edges: int = 20000, n_node_types: int = 10,
+            n_rel_pairs: int = 15, feat_dim: int = 128, zipf_a: float = 1.1) -> KGData:
+    """Synthetic PrimeKG-like heterogeneous graph.  ``n_node_types`` types (type 0 =
+    'drug' with ``n_kg_drugs`` nodes), ``n_rel_pairs`` relations each present in both
+    directions (``rel`` and ``rev_rel``) so every node type is a destination; Zipf-skewed
+    endpoint popularity."""
+    rng = np.random.default_rng([seed, 202])
+    types = ["drug"] + [f"t{i}" for i in range(1, n_node_types)]
+    rest = max(n_nodes - n_kg_drugs, n_node_types - 1)
+    w = rng.dirichlet(np.ones(n_node_types - 1) * 2.0)
+    counts = [n_kg_drugs] + [max(2, int(round(rest * x))) for x in w]
+    x_dict = {t: torch.from_numpy(rng.standard_normal((c, feat_dim)).astype(np.float32) * 0.5)
+              for t, c in zip(types, counts)}
+    # relation endpoints: make sure every type appears as a destination at least once
+    pairs = [(0, 0)] + [(0, i) for i in range(1, n_node_types)]
+    while len(pairs) < n_rel_pairs:
+        pairs.append((int(rng.integers(0, n_node_types)), int(rng.integers(0, n_node_types))))
+    pairs = pairs[:n_rel_pairs]
+    share = rng.dirichlet(np.ones(len(pairs)) * 1.5)
+    edge_index_dict = {}
+
+    def zipf_nodes(n, size):
+        r = rng.zipf(zipf_a, size=size) - 1 if zipf_a > 1.0 else rng.integers(0, n, size=size)
+        perm = rng.permutation(n)
+        return perm[np.minimum(r, n - 1) % n] if n > 0 else r
+
+    for k, (a, b) in enumerate(pairs):
+        e = max(1, int(round(n_edges / 2 * share[k])))
+        s = zipf_nodes(counts[a], e)
+        # mix skewed and uniform destinations so that degree is heavy tailed but not degenerate
+        d = np.where(rng.random(e) < 0.5, zipf_nodes(counts[b], e), rng.integers(0, counts[b], size=e))
+        ei = np.unique(np.stack([s, d], 0), axis=1).astype(np.int64)
+        edge_index_dict[(types[a], f"rel{k}", types[b])] = torch.from_numpy(ei)
+        edge_index_dict[(types[b], f"rev_rel{k}", types[a])] = torch.from_numpy(ei[::-1].copy())
+    return KGData(x_dict, edge_index_dict, types, list(edge_index_dict.keys()))
+
+
+def make_masks(n_drugs: int, seed: int, p_kg: float = 0.6, p_cv: float = 0.3, p_tx: float = 0.1) -> torch.Tensor:
+    """Modality-absence masks [n,19] (True = ABSENT): structure always present."""
+    rng = np.random.default_rng([seed, 303])
+    avail = np.zeros((n_drugs, NUM_MODALITIES), dtype=bool)
+    avail[:, 0] = True
+    avail[:, 1] = rng.random(n_drugs) < p_kg
+    avail[:, 2] = rng.random(n_drugs) < p_cv
+    avail[:, 3:] = rng.random((n_drugs, len(CELL_LINES))) < p_tx
+    return torch.from_numpy(~avail)
+
+
+def make_batch(n_drugs: int, seed: int, kg: Optional[KGData] = None, kg_nodes: int = 2000,
+               kg_edges: int = 20000, masks: Optional[torch.Tensor] = None, mean_atoms: float = 26.0):
+    """One full synthetic batch in the reference's boundary format.
+
+    Returns ``(batch, batch_kg)`` with ``batch = {'drugs','strs','cv','tx','masks'}``.
+    Drugs whose KG modality is present are the KG's drug nodes (``drug_index_map`` lists
+    their drug ids in KG-row order); tx rows of absent cell lines are zero
+    (madrigal/data/data.py:897-902)."""
+    rng = np.random.default_rng([seed, 404])
+    if masks is None:
+        masks = make_masks(n_drugs, seed)
+    drugs = torch.arange(n_drugs, dtype=torch.int64)
+    in_kg = (~masks[:, 1]).numpy()
+    kg_drug_ids = np.nonzero(in_kg)[0].astype(np.int64)
+    if kg_drug_ids.size == 0:                       # keep the KG encoder well defined
+        kg_drug_ids = np.array([0], dtype=np.int64)
+    drug_index_map = torch.from_numpy(rng.permutation(kg_drug_ids))
+    if kg is None:
+        kg = make_kg(int(drug_index_map.numel()), seed, n_nodes=kg_nodes, n_edges=kg_edges)
+    mols = make_molecules(n_drugs, seed, mean_atoms)
+    cv = torch.from_numpy(rng.standard_normal((n_drugs, CV_DIM)).astype(np.float32))
+    cv[masks[:, 2]] = 0.0
+    tx = {}
+    for c, name in enumerate(CELL_LINES):
+        sigs = torch.from_numpy(rng.standard_normal((n_drugs, TX_DIM)).astype(np.float32))
+        absent = masks[:, NUM_NON_TX_MODALITIES + c]
+        sigs[absent] = 0.0
+        tx[name] = {"sigs": sigs, "drugs": drugs.clone(),
+                    "dosages": torch.from_numpy(rng.uniform(0, 10, size=n_drugs).astype(np.float32)),
+                    "cell_lines": np.array([name] * n_drugs, dtype=np.str_)}
+    batch = {"drugs": drugs, "strs": mols, "cv": cv, "tx": tx, "masks": masks}
+    return batch, {"data": kg, "drug_index_map": drug_index_map}
+
+
+def make_labelled_triples(n_drugs: int, n_outcomes: int, n_pos: int, seed: int, neg_per_pos: int = 2):
+    """Labelled (outcome, head, tail) triples the way the reference's collator lays them
+    out: positives plus ``neg_per_pos`` fixed negatives each, doubled for direction
+    (madrigal/data/data.py:856-867).  Returns int64 label/head/tail and float32 targets."""
+    rng = np.random.default_rng([seed, 505])
+    lab = rng.integers(0, n_outcomes, size=n_pos)
+    h = rng.integers(0, n_drugs, size=n_pos)
+    t = (h + 1 + rng.integers(0, n_drugs - 1, size=n_pos)) % n_drugs
+    nl = np.repeat(lab, neg_per_pos)
+    nh = np.repeat(h, neg_per_pos)
+    nt = rng.integers(0, n_drugs, size=n_pos * neg_per_pos)
+    labels = np.concatenate([lab, nl])
+    heads = np.concatenate([h, nh])
+    tails = np.concatenate([t, nt])
+    y = np.concatenate([np.ones(n_pos), np.zeros(n_pos * neg_per_pos)]).astype(np.float32)
+    labels, heads, tails, y = (np.concatenate([labels, labels]), np.concatenate([heads, tails]),
+                               np.concatenate([tails, heads]), np.concatenate([y, y]))
+    return (torch.from_numpy(labels.astype(np.int64)), torch.from_numpy(heads.astype(np.int64)),
+            torch.from_numpy(tails.astype(np.int64)), torch.from_numpy(y))
+
+
+def batch_to(batch: dict, device) -> dict:
+    """Device move of a batch dict (numpy string arrays stay on the host)."""
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, dict):
+            out[k] = batch_to(v, device)
+        elif isinstance(v, torch.Tensor) or hasattr(v, "to") and not isinstance(v, np.ndarray):
+            out[k] = v.to(device)
+        else:
+            out[k] = v
+    return out

@@ -1,0 +1,593 @@
+"""CPU oracle for the encode -> fuse -> pairwise-score path of Madrigal.
+
+TEST INFRASTRUCTURE ONLY.  This module is a CPU restatement (torch-CPU fp32 and
+numpy) of the reference algorithm.  It is the *checker*: only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it.  Nothing under ``madrigal_amd/`` imports it, and the product path
+raises when the HIP extension is missing instead of falling back to this code.
+
+Every function cites the reference file:line it restates (paths relative to the
+reference checkout).  Parameters are passed as plain ``dict[str, Tensor]`` keyed
+by the reference's ``state_dict`` names, so the same function can be fed the
+weights of a reference module (golden generation, this container only) or of a
+``madrigal_amd`` module (parity tests).
+
+Pinning status
+  * pinned by golden vectors generated from the imported reference
+    (``oracle/gen_golden.py`` -> ``tests/golden/*.npz``): Symmetric + bilinear
+    head, MLPEncoder / MLPAdaptor, both position encodings, TransformerFusion
+    (all aggregations), TxAdaptingComPert.predict, the NovelDDIEncoder.encode
+    glue, NovelDDIMultilabel.forward, the InfoNCE loss, BCE-on-gathered-triples
+    and the rank normalisation.
+  * PARITY UNPINNED: ``gin_forward`` (torchdrug==0.2.1 GraphIsomorphismNetwork)
+    and ``hgt_conv_forward`` (torch-geometric==2.3.1 HGTConv).  Neither wheel nor
+    its source is in the container; both are restated from the published
+    algorithm and the parameter layout of ``GIN_256x4_muv.pt``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+NUM_NON_TX = 3           # madrigal/utils.py:34-36  (str, kg, cv)
+NUM_CELL_LINES = 16      # madrigal/utils.py:28
+NUM_MODALITIES = NUM_NON_TX + NUM_CELL_LINES
+
+
+def _sub(params: Params, prefix: str) -> Params:
+    """View of the entries of ``params`` below ``prefix`` with the prefix removed."""
+    n = len(prefix)
+    return {k[n:]: v for k, v in params.items() if k.startswith(prefix)}
+
+
+def _act(name: Optional[str], x: Tensor) -> Tensor:
+    # madrigal/models/models.py:31 (actn2actfunc)
+    if name is None or name == "none":
+        return x
+    if name == "relu":
+        return torch.clamp_min(x, 0.0)
+    if name == "gelu":
+        return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+    if name == "leakyrelu":
+        return torch.where(x >= 0, x, 0.01 * x)
+    if name == "tanh":
+        return torch.tanh(x)
+    if name == "sigmoid":
+        return torch.sigmoid(x)
+    if name == "softplus":
+        return torch.nn.functional.softplus(x)
+    if name == "selu":
+        return torch.selu(x)
+    raise ValueError(name)
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def batch_norm_eval(x: Tensor, p: Params, prefix: str, eps: float = 1e-5) -> Tensor:
+    """BatchNorm1d in eval mode (running statistics); affine is optional."""
+    y = (x - p[prefix + "running_mean"]) / torch.sqrt(p[prefix + "running_var"] + eps)
+    if prefix + "weight" in p:
+        y = y * p[prefix + "weight"] + p[prefix + "bias"]
+    return y
+
+
+# --------------------------------------------------------------------------- head
+def symmetric(w: Tensor) -> Tensor:
+    """Symmetric parametrisation: upper triangle mirrored, strict lower ignored.
+
+    madrigal/models/models.py:522-524."""
+    upper = torch.triu(w)
+    return upper + torch.triu(w, 1).transpose(-1, -2)
+
+
+def bilinear_scores(z_head: Tensor, z_tail: Tensor, w_original: Tensor,
+                    label_range: Optional[Tuple[int, int]] = None) -> Tensor:
+    """S[l,i,j] = z_head[i]^T W_sym[l] z_tail[j] -> [L', Nh, Nt] raw logits.
+
+    madrigal/models/models.py:537-547 (association order (z W) z^T kept)."""
+    w = symmetric(w_original)
+    if label_range is not None:
+        assert len(label_range) == 2
+        w = w[label_range[0]:label_range[1]]
+    t = torch.matmul(z_head, w)               # [L', Nh, D]
+    return torch.matmul(t, z_tail.t())        # [L', Nh, Nt]
+
+
+def gathered_bce_loss(scores: Tensor, labels: Tensor, heads: Tensor, tails: Tensor,
+                      pos_neg: Tensor) -> Tuple[Tensor, Tensor]:
+    """sigmoid -> gather labelled triples -> mean BCE on probabilities.
+
+    train_ddi_batch.py:285-288; loss_fn = nn.BCELoss (madrigal/utils.py:616-619).
+    BCELoss clamps log terms at -100."""
+    p = torch.sigmoid(scores)[labels, heads, tails]
+    logp = torch.clamp(torch.log(p), min=-100.0)
+    log1mp = torch.clamp(torch.log(1.0 - p), min=-100.0)
+    loss = -(pos_neg * logp + (1.0 - pos_neg) * log1mp).mean()
+    return p, loss
+
+
+# --------------------------------------------------------------------------- MLPs
+def mlp_encoder_forward(p: Params, x: Tensor, n_hidden: int, norm: Optional[str],
+                        actn: str, dropout_p: float, order: str = "nd") -> Tensor:
+    """MLPEncoder / MLPAdaptor in eval mode (identical structure).
+
+    madrigal/models/models.py:121-180 and :459-518.  ``fc`` is
+    [Linear, act] + per extra hidden layer [norm?, Dropout?, Linear, act] (order
+    'nd') or [Dropout?, norm?, Linear, act] ('dn') + [Linear].  Indices into the
+    Sequential therefore depend on whether norm / dropout modules exist; dropout
+    is the identity in eval mode but still occupies an index."""
+    idx = 0
+    h = _act(actn, linear(x, p[f"fc.{idx}.weight"], p[f"fc.{idx}.bias"]))
+    idx += 2
+    for _ in range(n_hidden - 1):
+        has_norm = norm not in (None, "None")
+        has_drop = dropout_p != 0
+        slots = (["n"] if has_norm else []) + (["d"] if has_drop else [])
+        if order == "dn":
+            slots = slots[::-1]
+        elif order != "nd":
+            raise NotImplementedError(order)
+        for s in slots:
+            if s == "n":
+                if norm == "ln":
+                    h = layer_norm(h, p[f"fc.{idx}.weight"], p[f"fc.{idx}.bias"])
+                elif norm == "bn":
+                    h = batch_norm_eval(h, p, f"fc.{idx}.")
+                else:
+                    raise NotImplementedError(norm)
+            idx += 1
+        h = _act(actn, linear(h, p[f"fc.{idx}.weight"], p[f"fc.{idx}.bias"]))
+        idx += 2
+    return linear(h, p[f"fc.{idx}.weight"], p[f"fc.{idx}.bias"])
+
+
+# --------------------------------------------------------------------------- chemCPA
+def chemcpa_mlp(p: Params, x: Tensor, n_linear: int) -> Tensor:
+    """chemCPA MLP: (Linear, BN, ReLU) x (n-1) + Linear, eval mode.
+
+    madrigal/chemcpa/chemCPA/model.py:161-231 (``network.{3k}`` Linear,
+    ``network.{3k+1}`` BatchNorm1d; last block is a bare Linear)."""
+    h = x
+    for k in range(n_linear):
+        h = linear(h, p[f"network.{3 * k}.weight"], p[f"network.{3 * k}.bias"])
+        if k < n_linear - 1:
+            h = batch_norm_eval(h, p, f"network.{3 * k + 1}.")
+            h = torch.clamp_min(h, 0.0)
+    return h
+
+
+def chemcpa_predict(p: Params, genes: Tensor, covariate_idx: Tensor, n_enc_linear: int,
+                    n_dec_linear: int, with_decoder: bool = True):
+    """TxAdaptingComPert.predict with ``use_drugs=False`` (the shipped setting).
+
+    madrigal/chemcpa/chemCPA/model.py:655-712.  ``covariate_idx`` is the argmax of
+    the one-hot covariate matrix (:693).  Returns (reconstruction | None,
+    cell_embedding, latent_basal, latent_treated)."""
+    latent_basal = chemcpa_mlp(_sub(p, "encoder."), genes, n_enc_linear)
+    emb = p["covariates_embeddings.0.weight"][covariate_idx]
+    latent_treated = latent_basal + emb
+    recon = None
+    if with_decoder:
+        g = chemcpa_mlp(_sub(p, "decoder."), latent_treated, n_dec_linear)
+        dim = g.shape[1] // 2
+        recon = torch.cat([g[:, :dim], torch.nn.functional.softplus(g[:, dim:])], dim=1)
+    return recon, emb, latent_basal, latent_treated
+
+
+# --------------------------------------------------------------------------- position encodings
+def sinusoidal_pe_table(d_model: int, max_len: int, num_tx_bottlenecks: int, agg: str) -> Tensor:
+    """Buffer ``pe`` of PositionEncodingSinusoidal, shape [1, S or max_len, d].
+
+    madrigal/models/models.py:551-579: with bottlenecks the table is zero-padded to
+    the full sequence length so only the first ``max_len`` tokens get an encoding."""
+    pos = torch.arange(max_len, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32) * (-math.log(10000.0) / d_model))
+    pe = torch.zeros(max_len, d_model)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    if num_tx_bottlenecks > 0:
+        seq = NUM_MODALITIES + num_tx_bottlenecks + (1 if agg == "cls" else 0)
+        full = torch.zeros(seq, d_model)
+        full[:max_len] = pe
+        pe = full
+    return pe.unsqueeze(0)
+
+
+def apply_pos_enc(x: Tensor, pe: Tensor, kind: str) -> Tensor:
+    """madrigal/models/models.py:581-587 (sinusoidal: x + pe, broadcast over the
+    whole sequence) and :597-603 (learnable: only the first max_len tokens)."""
+    if kind == "sinusoidal":
+        return x + pe
+    out = x.clone()
+    out[:, : pe.shape[1], :] += pe
+    return out
+
+
+# --------------------------------------------------------------------------- transformer fusion
+def multihead_attention(q_in: Tensor, kv_in: Tensor, p: Params, num_heads: int,
+                        key_padding_mask: Optional[Tensor], attn_mask: Optional[Tensor]):
+    """nn.MultiheadAttention forward (eval), batch-major: q_in [B,Tq,d], kv_in [B,Tk,d].
+
+    Masks are boolean with True = NOT allowed, as the reference passes them
+    (madrigal/models/models.py:412, 430-438).  Returns (out [B,Tq,d], probs [B,H,Tq,Tk])."""
+    d = q_in.shape[-1]
+    dh = d // num_heads
+    w, b = p["in_proj_weight"], p["in_proj_bias"]
+    q = linear(q_in, w[:d], b[:d])
+    k = linear(kv_in, w[d:2 * d], b[d:2 * d])
+    v = linear(kv_in, w[2 * d:], b[2 * d:])
+    B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
+    q = q.view(B, Tq, num_heads, dh).transpose(1, 2)
+    k = k.view(B, Tk, num_heads, dh).transpose(1, 2)
+    v = v.view(B, Tk, num_heads, dh).transpose(1, 2)
+    logits = (q / math.sqrt(dh)) @ k.transpose(-1, -2)            # [B,H,Tq,Tk]
+    neg = torch.zeros(B, 1, Tq, Tk)
+    if attn_mask is not None:
+        neg = neg.masked_fill(attn_mask.view(1, 1, Tq, Tk), float("-inf"))
+    if key_padding_mask is not None:
+        neg = neg.masked_fill(key_padding_mask.view(B, 1, 1, Tk), float("-inf"))
+    probs = torch.softmax(logits + neg, dim=-1)
+    out = (probs @ v).transpose(1, 2).reshape(B, Tq, d)
+    return linear(out, p["out_proj.weight"], p["out_proj.bias"]), probs
+
+
+def transformer_encoder_layer(x: Tensor, p: Params, num_heads: int, norm_first: bool, actn: str,
+                              key_padding_mask: Optional[Tensor], attn_mask: Optional[Tensor]):
+    """nn.TransformerEncoderLayer (eval) as configured at madrigal/models/models.py:366."""
+    sa = _sub(p, "self_attn.")
+    if norm_first:
+        a, probs = multihead_attention(*(2 * [layer_norm(x, p["norm1.weight"], p["norm1.bias"])]), sa,
+                                       num_heads, key_padding_mask, attn_mask)
+        x = x + a
+        h = layer_norm(x, p["norm2.weight"], p["norm2.bias"])
+        x = x + linear(_act(actn, linear(h, p["linear1.weight"], p["linear1.bias"])),
+                       p["linear2.weight"], p["linear2.bias"])
+    else:
+        a, probs = multihead_attention(x, x, sa, num_heads, key_padding_mask, attn_mask)
+        x = layer_norm(x + a, p["norm1.weight"], p["norm1.bias"])
+        f = linear(_act(actn, linear(x, p["linear1.weight"], p["linear1.bias"])),
+                   p["linear2.weight"], p["linear2.bias"])
+        x = layer_norm(x + f, p["norm2.weight"], p["norm2.bias"])
+    return x, probs
+
+
+def x_attn_key_mask(seq_len_no_cls: int, num_tx_bottlenecks: int) -> Tensor:
+    """Fixed key mask of the cross-attention pooling: only bottleneck tokens are keys.
+
+    madrigal/models/models.py:382-385 (ignores the per-drug availability mask)."""
+    m = torch.zeros(NUM_MODALITIES + num_tx_bottlenecks, dtype=torch.bool)
+    if num_tx_bottlenecks > 0:
+        m[:NUM_NON_TX] = True
+        m[-NUM_CELL_LINES:] = True
+    assert m.numel() == seq_len_no_cls
+    return m
+
+
+def transformer_fusion_forward(p: Params, seq: Tensor, key_padding_mask: Tensor,
+                               src_mask: Optional[Tensor], *, num_layers: int, num_heads: int,
+                               norm_first: bool, actn: str, agg: str, num_tx_bottlenecks: int,
+                               return_probs: bool = False):
+    """TransformerFusion.forward, eval mode.  seq [n,S,D] -> [n,D].
+
+    madrigal/models/models.py:401-455.  The reference runs sequence-major when
+    batch_first is False; per-drug math is identical, so this works batch-major."""
+    h = linear(seq, p["embed2latent.weight"], p["embed2latent.bias"])
+    probs = None
+    for i in range(num_layers):
+        h, probs = transformer_encoder_layer(h, _sub(p, f"transformer_encoder.layers.{i}."), num_heads,
+                                             norm_first, actn, key_padding_mask, src_mask)
+    if agg == "x-attn":
+        n = seq.shape[0]
+        q = p["x_attn_query"].view(1, 1, -1).expand(n, 1, -1)
+        kv = layer_norm(h, p["x_attn_kv_norm.weight"], p["x_attn_kv_norm.bias"])
+        if norm_first:
+            q = layer_norm(q, p["x_attn_query_norm.weight"], p["x_attn_query_norm.bias"])
+        kmask = x_attn_key_mask(seq.shape[1], num_tx_bottlenecks).view(1, -1).expand(n, -1)
+        o, _ = multihead_attention(q, kv, _sub(p, "x_attn_mha_layer."), num_heads, kmask, None)
+        o = o + q
+        if not norm_first:
+            o = layer_norm(o, p["x_attn_query_norm.weight"], p["x_attn_query_norm.bias"])
+        out = linear(o, p["latent2embed.weight"], p["latent2embed.bias"])[:, 0, :]
+    else:
+        e = linear(h, p["latent2embed.weight"], p["latent2embed.bias"])
+        if agg == "cls":
+            out = e[:, 0, :]
+        elif agg in ("mean", "max"):
+            # torch_scatter.scatter_mean / scatter_max over the non-masked tokens of
+            # each drug (:447, :451); bucket 0 collects the masked ones and is dropped.
+            keep = ~key_padding_mask
+            if agg == "mean":
+                out = (e * keep.unsqueeze(-1)).sum(1) / keep.sum(1, keepdim=True).clamp_min(1)
+            else:
+                out = e.masked_fill(~keep.unsqueeze(-1), float("-inf")).max(dim=1).values
+        else:
+            raise NotImplementedError(agg)
+    return (out, probs) if return_probs else out
+
+
+# --------------------------------------------------------------------------- GIN  (PARITY UNPINNED)
+def gin_forward(p: Params, node_feature: Tensor, edge_list: Tensor, edge_feature: Tensor,
+                node2graph: Tensor, num_graphs: int, *, num_layers: int, num_mlp_layer: int,
+                batch_norm: bool = True, readout: str = "mean",
+                edge_weight: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """torchdrug==0.2.1 GraphIsomorphismNetwork forward, eval mode.  PARITY UNPINNED.
+
+    Call site madrigal/models/models.py:217,720-721.  Restated from the GIN paper
+    and torchdrug's layer semantics: per layer, message = h_u + edge_linear(e_uv),
+    sum over incoming edges (edge_list[:,0] -> edge_list[:,1]) weighted by
+    edge_weight, combine = mlp((1+eps) h + agg) -> BatchNorm -> ReLU; no short cut,
+    no hidden concatenation; mean / sum read-out per molecule.  Parameter names
+    follow modality_pretraining/str/GIN_256x4_muv.pt."""
+    h = node_feature.float()
+    src, dst = edge_list[:, 0].long(), edge_list[:, 1].long()
+    ew = torch.ones(src.shape[0]) if edge_weight is None else edge_weight.float()
+    for k in range(num_layers):
+        pre = f"layers.{k}."
+        msg = h[src] + linear(edge_feature.float(), p[pre + "edge_linear.weight"], p[pre + "edge_linear.bias"])
+        agg = torch.zeros_like(h).index_add_(0, dst, msg * ew.unsqueeze(-1))
+        u = (1.0 + p[pre + "eps"]) * h + agg
+        for j in range(num_mlp_layer):
+            u = linear(u, p[pre + f"mlp.layers.{j}.weight"], p[pre + f"mlp.layers.{j}.bias"])
+            if j < num_mlp_layer - 1:
+                u = torch.clamp_min(u, 0.0)
+        if batch_norm:
+            u = batch_norm_eval(u, p, pre + "batch_norm.")
+        h = torch.clamp_min(u, 0.0)
+    g = torch.zeros(num_graphs, h.shape[1]).index_add_(0, node2graph.long(), h)
+    if readout == "mean":
+        cnt = torch.zeros(num_graphs).index_add_(0, node2graph.long(), torch.ones(h.shape[0]))
+        g = g / cnt.clamp_min(1).unsqueeze(-1)
+    elif readout != "sum":
+        raise NotImplementedError(readout)
+    return {"graph_feature": g, "node_feature": h}
+
+
+# --------------------------------------------------------------------------- HGT  (PARITY UNPINNED)
+def hgt_conv_forward(p: Params, x_dict: Dict[str, Tensor], edge_index_dict, node_types: Sequence[str],
+                     edge_types: Sequence[Tuple[str, str, str]], heads: int, out_channels: int):
+    """torch-geometric==2.3.1 HGTConv forward.  PARITY UNPINNED.
+
+    Call site madrigal/models/models.py:76-79, 90-94.  Restated from Hu et al. 2020
+    as laid out by PyG 2.3: per node type one Linear to K|Q|V; per (head, edge type)
+    relation matrices k_rel / v_rel applied to the SOURCE side; logit =
+    (q_i . k'_j) * p_rel[edge type][head] / sqrt(D); ONE softmax per destination
+    node over all incoming edges of all edge types; sum of alpha * v'; GELU ->
+    per-type output Linear -> sigmoid(skip)-gated residual when dims agree.
+    Parameter names: kqv_lin.lins.<type>.{weight,bias}, out_lin.lins.<type>.*,
+    k_rel.weight / v_rel.weight [heads*R, D, D] indexed h*R + r, skip.<type>,
+    p_rel.<src>__<rel>__<dst> [1, heads]."""
+    H, F = heads, out_channels
+    D = F // H
+    R = len(edge_types)
+    k_d, q_d, v_d = {}, {}, {}
+    for t, x in x_dict.items():
+        kqv = linear(x, p[f"kqv_lin.lins.{t}.weight"], p[f"kqv_lin.lins.{t}.bias"])
+        k_d[t], q_d[t], v_d[t] = (c.reshape(-1, H, D) for c in torch.tensor_split(kqv, 3, dim=1))
+    dst_types = {et[2] for et in edge_types}
+    out = {}
+    for t in node_types:
+        if t not in dst_types or t not in x_dict:
+            continue
+        n_t = x_dict[t].shape[0]
+        logit_parts, val_parts, dst_parts = [], [], []
+        for r, et in enumerate(edge_types):
+            if et[2] != t or et not in edge_index_dict:
+                continue
+            ei = edge_index_dict[et].long()
+            if ei.shape[1] == 0:
+                continue
+            rel_idx = torch.arange(H) * R + r
+            kp = torch.einsum("nhd,hde->nhe", k_d[et[0]], p["k_rel.weight"][rel_idx])
+            vp = torch.einsum("nhd,hde->nhe", v_d[et[0]], p["v_rel.weight"][rel_idx])
+            prel = p["p_rel." + "__".join(et)].view(1, H)
+            a = (q_d[t][ei[1]] * kp[ei[0]]).sum(-1) * prel / math.sqrt(D)     # [e,H]
+            logit_parts.append(a)
+            val_parts.append(vp[ei[0]])
+            dst_parts.append(ei[1])
+        agg = torch.zeros(n_t, H, D)
+        if logit_parts:
+            a = torch.cat(logit_parts)
+            v = torch.cat(val_parts)
+            d = torch.cat(dst_parts)
+            amax = torch.full((n_t, H), float("-inf")).scatter_reduce(0, d.view(-1, 1).expand(-1, H), a,
+                                                                       reduce="amax", include_self=True)
+            e = torch.exp(a - amax[d])
+            den = torch.zeros(n_t, H).index_add_(0, d, e)
+            alpha = e / (den[d] + 1e-16)      # torch_geometric.utils.softmax adds 1e-16
+            agg = agg.index_add_(0, d, v * alpha.unsqueeze(-1))
+        o = linear(_act("gelu", agg.reshape(n_t, F)), p[f"out_lin.lins.{t}.weight"], p[f"out_lin.lins.{t}.bias"])
+        if o.shape[-1] == x_dict[t].shape[-1]:
+            g = torch.sigmoid(p[f"skip.{t}"])
+            o = g * o + (1 - g) * x_dict[t]
+        out[t] = o
+    return out
+
+
+def hgt_forward(p: Params, x_dict, edge_index_dict, node_types, edge_types, *, num_layers: int,
+                heads: int, hidden: int):
+    """Madrigal's HGT wrapper: convs, ReLU only between convs i>=1 and the last, then
+    a per-type Linear.  madrigal/models/models.py:85-96."""
+    out = hgt_conv_forward(_sub(p, "convs.0."), x_dict, edge_index_dict, node_types, edge_types, heads, hidden)
+    for i in range(1, num_layers):
+        out = hgt_conv_forward(_sub(p, f"convs.{i}."), out, edge_index_dict, node_types, edge_types, heads, hidden)
+        if i < num_layers - 1:
+            out = {t: torch.clamp_min(x, 0.0) for t, x in out.items()}
+    return {t: linear(x, p[f"lin_dict.{t}.weight"], p[f"lin_dict.{t}.bias"]) for t, x in out.items()}
+
+
+# --------------------------------------------------------------------------- encode() glue
+def assemble_fusion_inputs(all_embeds: Tensor, masks: Tensor, bottleneck_tokens: Optional[Tensor],
+                           cls_token: Optional[Tensor]):
+    """Token sequence, key-padding mask and [S,S] source mask for the fusion transformer.
+
+    madrigal/models/models.py:799-842.  all_embeds [n,19,D], masks [n,19] (True =
+    modality absent)."""
+    n = all_embeds.shape[0]
+    seq, kpm, src = all_embeds, masks, None
+    nb = 0 if bottleneck_tokens is None else bottleneck_tokens.shape[0]
+    if nb > 0:
+        seq = torch.cat([all_embeds[:, :NUM_NON_TX], bottleneck_tokens.unsqueeze(0).expand(n, -1, -1),
+                         all_embeds[:, NUM_NON_TX:]], dim=1)
+        kpm = torch.cat([masks[:, :NUM_NON_TX], torch.zeros(n, nb, dtype=torch.bool), masks[:, NUM_NON_TX:]], dim=1)
+        S = seq.shape[1]
+        src = torch.zeros(S, S, dtype=torch.bool)
+        src[:NUM_NON_TX, -NUM_CELL_LINES:] = True
+        src[-NUM_CELL_LINES:, :NUM_NON_TX] = True
+    if cls_token is not None:
+        seq = torch.cat([cls_token.view(1, 1, -1).expand(n, 1, -1), seq], dim=1)
+        kpm = torch.cat([torch.zeros(n, 1, dtype=torch.bool), kpm], dim=1)
+        if src is not None:
+            S = src.shape[0]
+            full = torch.zeros(S + 1, S + 1, dtype=torch.bool)
+            full[1:, 1:] = src
+            src = full
+    return seq, kpm, src
+
+
+def l2_normalize(x: Tensor, eps: float = 1e-12) -> Tensor:
+    return x / x.norm(dim=-1, keepdim=True).clamp_min(eps)
+
+
+def fuse_modalities(p: Params, all_embeds: Tensor, masks: Tensor, cfg: dict,
+                    raw_encoder_output: bool = False) -> Tensor:
+    """Everything in NovelDDIEncoder.encode after the four encoders ran.
+
+    madrigal/models/models.py:775-896.  ``p`` holds the encoder's own parameters
+    (transformer.*, tx_bottleneck_tokens, cls, pos_encoder.pe, uni_projector.*,
+    uni_fuser.*).  cfg keys: fusion, normalize, adapt_before_fusion, pos_emb_type,
+    num_tx_bottlenecks, agg, num_layers, num_heads, norm_first, actn, proj (dict with
+    n_hidden, norm, actn, dropout, order)."""
+    proj = cfg["proj"]
+
+    def adaptor(prefix, x):
+        return mlp_encoder_forward(_sub(p, prefix), x, proj["n_hidden"], proj["norm"], proj["actn"],
+                                   proj["dropout"], proj["order"])
+
+    if raw_encoder_output:
+        uni = all_embeds[~masks]
+        if cfg["normalize"]:
+            uni = l2_normalize(uni)
+        return adaptor("uni_projector.", uni)
+    if cfg["adapt_before_fusion"]:
+        all_embeds = adaptor("uni_projector.", all_embeds)
+    fusion = cfg["fusion"]
+    if fusion in ("mean", "add"):
+        x = l2_normalize(all_embeds) if cfg["normalize"] else all_embeds
+        keep = (~masks).unsqueeze(-1)
+        s = (x * keep).sum(1)
+        return s / keep.sum(1).clamp_min(1) if fusion == "mean" else s
+    multi = torch.ones(all_embeds.shape[0], dtype=torch.bool)
+    if fusion == "transformer_uni_proj":
+        assert torch.all((~masks).sum(1) > 0)
+        multi = (~masks).sum(1) > 1
+    nb = cfg["num_tx_bottlenecks"]
+    seq, kpm, src = assemble_fusion_inputs(all_embeds[multi], masks[multi],
+                                           p["tx_bottleneck_tokens"] if nb > 0 else None,
+                                           p["cls"] if cfg["agg"] == "cls" else None)
+    if cfg["normalize"]:
+        seq = l2_normalize(seq)
+    seq = apply_pos_enc(seq, p["pos_encoder.pe"], cfg["pos_emb_type"])
+    z_f = transformer_fusion_forward(_sub(p, "transformer."), seq, kpm, src, num_layers=cfg["num_layers"],
+                                     num_heads=cfg["num_heads"], norm_first=cfg["norm_first"], actn=cfg["actn"],
+                                     agg=cfg["agg"], num_tx_bottlenecks=nb)
+    if fusion != "transformer_uni_proj":
+        return z_f
+    uni_rows = ~multi
+    col = torch.where(~masks[uni_rows])[1]
+    uni = all_embeds[uni_rows, col]
+    if cfg["normalize"]:
+        uni = l2_normalize(uni)
+    z = torch.empty(all_embeds.shape[0], all_embeds.shape[2])
+    z[multi] = z_f
+    z[uni_rows] = adaptor("uni_fuser.", uni)
+    return z
+
+
+def place_kg_rows(kg_out_valid: Tensor, drug_index_map: Tensor, batch_drugs: Tensor,
+                  filler: Tensor) -> Tensor:
+    """Rows of the KG encoder output re-indexed by drug id; drugs that are not in the KG
+    get ``filler`` rows (the reference draws torch.randn there; those rows are always
+    masked).  madrigal/models/models.py:734-736."""
+    table = filler.clone()
+    table[drug_index_map] = kg_out_valid
+    return table[batch_drugs]
+
+
+# --------------------------------------------------------------------------- InfoNCE
+def info_nce(aug1: Tensor, aug2: Tensor, too_hard_neg_mask: Optional[Tensor], temperature: float):
+    """SimCLR_NovelDDI.contrastive_loss.  madrigal/models/simclr.py:74-108.
+
+    Returns (logits [2B,2B-1], labels [2B,2B-1] float, loss) with the diagonal removed;
+    the loss is soft-label cross-entropy averaged over the 2B rows."""
+    B = aug1.shape[0]
+    f = torch.cat([aug1, aug2], dim=0)
+    f = f / f.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    sim = f @ f.t()
+    if too_hard_neg_mask is not None:
+        sim = sim.masked_fill(too_hard_neg_mask.repeat(2, 2), -1e9)
+    ids = torch.arange(B).repeat(2)
+    lab = (ids.view(-1, 1) == ids.view(1, -1)).float()
+    off = ~torch.eye(2 * B, dtype=torch.bool)
+    lab = lab[off].view(2 * B, -1)
+    logits = sim[off].view(2 * B, -1) / temperature
+    lse = torch.logsumexp(logits, dim=1, keepdim=True)
+    loss = -(lab * (logits - lse)).sum(1).mean()
+    return logits, lab, loss
+
+
+# --------------------------------------------------------------------------- rank normalisation
+def rank_normalize(scores: np.ndarray) -> np.ndarray:
+    """Per outcome: rank the strict lower triangle of an [N,N] score slice, divide by
+    N(N-1)/2, mirror.  notebooks/normalize_scores.py:33-70.
+
+    The reference overwrites the upper triangle + diagonal with 1e7 and ranks all N^2
+    entries with argsort(argsort()); for real scores < 1e7 every masked entry ranks
+    above every kept one, so the kept ranks equal the ranks among the kept entries.
+    numpy's default argsort is not stable, so the order of exactly tied scores is
+    implementation defined in the reference; this restatement (and the HIP path)
+    breaks ties by flat row-major index (stable).  Input/outputs: [L,N,N] float32."""
+    L, N, M = scores.shape
+    assert N == M
+    out = np.zeros((L, N, N), dtype=np.float32)
+    iu = np.triu_indices(N, k=0)
+    denom = N * (N - 1) / 2
+    for l in range(L):
+        s = scores[l].astype(np.float32).copy()
+        s[iu] = 1e7
+        order = np.argsort(s.reshape(-1), kind="stable")
+        rank = np.empty(N * N, dtype=np.int64)
+        rank[order] = np.arange(1, N * N + 1)
+        r = (rank / denom).reshape(N, N)
+        r[iu] = 0
+        out[l] = (r + r.T).astype(np.float32)
+    return out
+
+
+def lower_triangle_ranks(scores: np.ndarray) -> np.ndarray:
+    """Integer ranks (1-based, int64) of the strict-lower-triangle entries of each [N,N]
+    slice, in row-major order of the kept entries; stable in the flat index."""
+    L, N, _ = scores.shape
+    il = np.tril_indices(N, k=-1)
+    out = np.empty((L, il[0].size), dtype=np.int64)
+    for l in range(L):
+        v = scores[l][il].astype(np.float32)
+        order = np.argsort(v, kind="stable")
+        r = np.empty(v.size, dtype=np.int64)
+        r[order] = np.arange(1, v.size + 1)
+        out[l] = r
+    return out

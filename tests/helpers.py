@@ -1,0 +1,157 @@
+"""Shared helpers for the parity tests (CPU and GPU)."""
+import numpy as np
+import torch
+
+from oracle.params import det_state_dict
+
+# name, heads, head_dim, ffn, layers, norm_first, agg, nb, actn   (same list as oracle/gen_golden.py)
+FUSION_CASES = [
+    ("drugbank163", 8, 64, 256, 2, True, "x-attn", 4, "gelu"),
+    ("twosides105", 2, 256, 512, 2, True, "x-attn", 2, "gelu"),
+    ("twosides321", 8, 256, 1024, 2, True, "x-attn", 2, "gelu"),
+    ("cl_default", 4, 128, 512, 3, False, "x-attn", 0, "gelu"),
+    ("cls_small", 4, 32, 64, 1, True, "cls", 2, "relu"),
+    ("mean_small", 4, 32, 64, 2, False, "mean", 0, "gelu"),
+    ("max_small", 2, 64, 128, 1, True, "max", 2, "gelu"),
+]
+
+# name, fusion, nb, pos, heads, head_dim, ffn, layers, norm_first, agg, normalize, adapt
+ENCODE_CASES = [
+    ("drugbank163", "transformer", 4, "sinusoidal", 8, 64, 256, 2, True, "x-attn", False, False),
+    ("uniproj", "transformer_uni_proj", 2, "learnable", 2, 64, 128, 2, True, "x-attn", True, False),
+    ("cls_adapt", "transformer", 2, "learnable", 4, 32, 64, 1, False, "cls", False, True),
+    ("meanfuse", "mean", 0, "learnable", 4, 32, 64, 1, False, "x-attn", True, False),
+]
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def fusion_param_shapes(H, dh, ffn, nl, agg):
+    d = H * dh
+    s = {"embed2latent.weight": (d, 128), "embed2latent.bias": (d,), "latent2embed.weight": (128, d),
+         "latent2embed.bias": (128,)}
+    for i in range(nl):
+        p = f"transformer_encoder.layers.{i}."
+        s.update({p + "self_attn.in_proj_weight": (3 * d, d), p + "self_attn.in_proj_bias": (3 * d,),
+                  p + "self_attn.out_proj.weight": (d, d), p + "self_attn.out_proj.bias": (d,),
+                  p + "linear1.weight": (ffn, d), p + "linear1.bias": (ffn,), p + "linear2.weight": (d, ffn),
+                  p + "linear2.bias": (d,), p + "norm1.weight": (d,), p + "norm1.bias": (d,),
+                  p + "norm2.weight": (d,), p + "norm2.bias": (d,)})
+    if agg == "x-attn":
+        s.update({"x_attn_kv_norm.weight": (d,), "x_attn_kv_norm.bias": (d,), "x_attn_query_norm.weight": (d,),
+                  "x_attn_query_norm.bias": (d,), "x_attn_mha_layer.in_proj_weight": (3 * d, d),
+                  "x_attn_mha_layer.in_proj_bias": (3 * d,), "x_attn_mha_layer.out_proj.weight": (d, d),
+                  "x_attn_mha_layer.out_proj.bias": (d,), "x_attn_query": (1, d)})
+    return s
+
+
+def fusion_params(seed, H, dh, ffn, nl, agg):
+    return det_state_dict(seed, fusion_param_shapes(H, dh, ffn, nl, agg))
+
+
+def mlp_shapes(in_dim, hidden, out, p, norm, order="nd"):
+    """state_dict shapes of MLPEncoder / MLPAdaptor (madrigal/models/models.py:121-180)."""
+    s, idx = {}, 0
+    s[f"fc.{idx}.weight"], s[f"fc.{idx}.bias"] = (hidden[0], in_dim), (hidden[0],)
+    idx += 2
+    for i in range(len(hidden) - 1):
+        slots = (["n"] if norm not in (None, "None") else []) + (["d"] if p != 0 else [])
+        if order == "dn":
+            slots = slots[::-1]
+        for sl in slots:
+            if sl == "n":
+                s[f"fc.{idx}.weight"], s[f"fc.{idx}.bias"] = (hidden[i],), (hidden[i],)
+                if norm == "bn":
+                    s[f"fc.{idx}.running_mean"], s[f"fc.{idx}.running_var"] = (hidden[i],), (hidden[i],)
+                    s[f"fc.{idx}.num_batches_tracked"] = ()
+            idx += 1
+        s[f"fc.{idx}.weight"], s[f"fc.{idx}.bias"] = (hidden[i + 1], hidden[i]), (hidden[i + 1],)
+        idx += 2
+    s[f"fc.{idx}.weight"], s[f"fc.{idx}.bias"] = (out, hidden[-1]), (out,)
+    return s
+
+
+def chemcpa_shapes(num_genes=978, width=512, depth=2, dim=128, n_cov=16):
+    s = {}
+    for name, sizes in (("encoder", [num_genes] + [width] * depth + [dim]),
+                        ("decoder", [dim] + [width] * depth + [2 * num_genes])):
+        for k in range(len(sizes) - 1):
+            s[f"{name}.network.{3 * k}.weight"], s[f"{name}.network.{3 * k}.bias"] = (sizes[k + 1], sizes[k]), (sizes[k + 1],)
+            if k < len(sizes) - 2:
+                for leaf, shp in (("weight", (sizes[k + 1],)), ("bias", (sizes[k + 1],)), ("running_mean", (sizes[k + 1],)),
+                                  ("running_var", (sizes[k + 1],)), ("num_batches_tracked", ())):
+                    s[f"{name}.network.{3 * k + 1}.{leaf}"] = shp
+    s["covariates_embeddings.0.weight"] = (n_cov, dim)
+    return s
+
+
+def rel_err(a, b):
+    """Norm-wise relative error max|a-b| / max|b| (the 1e-4 bar of BASELINE.json is read this way:
+    relative to the score scale, since individual logits pass through zero)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def gin_shapes(input_dim=67, hidden=(128, 128, 128, 128), edge_dim=18, n_mlp=3, batch_norm=True):
+    s, dims = {}, [input_dim] + list(hidden)
+    for k in range(len(dims) - 1):
+        p = f"layers.{k}."
+        s[p + "eps"] = (1,)
+        if batch_norm:
+            for leaf, shp in (("weight", (dims[k + 1],)), ("bias", (dims[k + 1],)), ("running_mean", (dims[k + 1],)),
+                              ("running_var", (dims[k + 1],)), ("num_batches_tracked", ())):
+                s[p + "batch_norm." + leaf] = shp
+        md = [dims[k]] + [dims[k + 1]] * n_mlp
+        for j in range(n_mlp):
+            s[p + f"mlp.layers.{j}.weight"], s[p + f"mlp.layers.{j}.bias"] = (md[j + 1], md[j]), (md[j + 1],)
+        s[p + "edge_linear.weight"], s[p + "edge_linear.bias"] = (dims[k], edge_dim), (dims[k],)
+    return s
+
+
+def hgt_shapes(kg, in_dim=128, hidden=128, out=128, heads=4, n_layers=2):
+    s = {}
+    node_types, edge_types = kg.metadata()
+    for i in range(n_layers):
+        p, cin = f"convs.{i}.", in_dim if i == 0 else hidden
+        for tname in node_types:
+            s[p + f"kqv_lin.lins.{tname}.weight"], s[p + f"kqv_lin.lins.{tname}.bias"] = (3 * hidden, cin), (3 * hidden,)
+            s[p + f"out_lin.lins.{tname}.weight"], s[p + f"out_lin.lins.{tname}.bias"] = (hidden, hidden), (hidden,)
+            s[p + f"skip.{tname}"] = (1,)
+        dh = hidden // heads
+        s[p + "k_rel.weight"] = s[p + "v_rel.weight"] = (heads * len(edge_types), dh, dh)
+        for e in edge_types:
+            s[p + "p_rel." + "__".join(e)] = (1, heads)
+    for tname in node_types:
+        s[f"lin_dict.{tname}.weight"], s[f"lin_dict.{tname}.bias"] = (out, hidden), (out,)
+    return s
+
+
+def model_shapes_for_case(case, kg, L):
+    """state_dict shapes of NovelDDIMultilabel(NovelDDIEncoder(...)) for one ENCODE_CASES row, as the
+    reference lays it out (SURVEY.md 8b state-dict contract)."""
+    name, fusion, nb, pos, H, dh, ffn, nl, nf, agg, normalize, adapt = case
+    s = {"decoder.bias": (L,), "decoder.parametrizations.weight.original": (L, 128, 128)}
+
+    def add(prefix, d):
+        s.update({prefix + k: v for k, v in d.items()})
+    add("encoder.str_encoder.", gin_shapes())
+    add("encoder.kg_encoder.", hgt_shapes(kg))
+    add("encoder.cv_encoder.", mlp_shapes(559, [512, 256], 128, 0.2, None))
+    add("encoder.tx_encoder.", chemcpa_shapes())
+    add("encoder.transformer.", fusion_param_shapes(H, dh, ffn, nl, agg))
+    add("encoder.uni_projector.", mlp_shapes(128, [512, 512], 128, 0.2, "ln"))
+    if fusion == "transformer_uni_proj":
+        add("encoder.uni_fuser.", mlp_shapes(128, [512, 512], 128, 0.2, "ln"))
+    if nb > 0:
+        s["encoder.tx_bottleneck_tokens"] = (nb, 128)
+    if agg == "cls":
+        s["encoder.cls"] = (1, 128)
+    max_len = (19 if nb == 0 else 3) + (1 if agg == "cls" else 0)
+    if pos == "sinusoidal":
+        seq = 19 + nb + (1 if agg == "cls" else 0)
+        s["encoder.pos_encoder.pe"] = (1, seq if nb > 0 else max_len, 128)
+    else:
+        s["encoder.pos_encoder.pe"] = (1, max_len, 128)
+    return s
