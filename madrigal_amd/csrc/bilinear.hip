@@ -1,0 +1,427 @@
+// All-pairs symmetric bilinear DDI head for gfx950.
+//
+//   S[l,i,j] = z_head[i]^T W_sym[l] z_tail[j]        (madrigal/models/models.py:537-547)
+//
+// One workgroup (8 waves) owns a slab of 256 head rows of ONE outcome l and sweeps every tail
+// drug.  Prologue: T = z_head[rows] . W_sym[l] (the reference's inner matmul, rounded to fp32) is
+// formed on the matrix cores, bounced once through LDS so that each wave holds its 32 rows of T as
+// the MFMA *A* operand in registers for the whole sweep.  Main loop: 64 tail rows at a time are
+// staged into LDS (z_tail is 2 MB at N=4096: it lives in every XCD's L2), each wave multiplies its
+// resident T rows against the staged tile (2 accumulator tiles of 32x32) and the epilogue streams
+// the scores to HBM as full 128-byte lines (lane = column, so one store instruction writes two
+// complete rows segments).  Algorithmic traffic is 4 B written per score (STORE) and ~0 read, so the
+// kernel is bound by HBM writes for the bf16 products and by the fp32 matrix pipe for MDG_PREC_F32.
+//
+// LDS tile layout: [64 tail rows][D] with the 16-byte chunks of a row XOR-swizzled by (row & 15), so
+// the MFMA B-operand reads (lane = tail row, ds_read_b128) are bank-conflict free.
+// k ordering: fp32 MFMA consumes k = 8q+4h+e (q: 16-byte chunk pair, h: lane half, e: element) for
+// BOTH operands -- any permutation of k is legal as long as A and B agree -- which turns the
+// per-MFMA scalar operand into one ds_read_b128 per four MFMAs.
+#include "mdg_common.h"
+
+namespace {
+
+constexpr int D = 128;
+constexpr int BM = 256;            // head rows per workgroup
+constexpr int BN = 64;             // tail rows per stage
+constexpr int NTHREADS = 512;
+constexpr int STAGE_BYTES = BN * D * 4;   // fp32 tile, or bf16 hi (16 KB) + lo (16 KB)
+constexpr int LO_OFF = BN * D * 2;
+
+struct TileSrc {
+  const float* f32;
+  const __bf16* hi;
+  const __bf16* lo;
+  int64_t nrows;
+};
+
+struct BilinearArgs {
+  const float* z_head;
+  TileSrc zt;
+  TileSrc w;          // W_sym (all labels); nrows = D
+  float* out;
+  int64_t n_head, n_tail, n_labels;
+};
+
+template <int MODE> struct AFrag;
+template <> struct AFrag<MDG_PREC_F32> { float a[64]; };
+template <> struct AFrag<MDG_PREC_BF16X3> { bf16x8 hi[8]; bf16x8 lo[8]; };
+template <> struct AFrag<MDG_PREC_BF16> { bf16x8 hi[8]; };
+
+template <int ROWB>
+__device__ __forceinline__ int tile_off(int row, int chunk) {
+  return row * ROWB + ((chunk ^ (row & 15)) << 4);
+}
+
+// ---- global -> registers -> LDS staging of one 64-row tile ---------------------------------
+template <int MODE>
+__device__ __forceinline__ void stage_load(const TileSrc& s, int64_t row0, int tid, u32x4 (&regs)[4]) {
+  if constexpr (MODE == MDG_PREC_F32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g = tid + NTHREADS * i, row = g >> 5, c = g & 31;
+      int64_t gr = row0 + row;
+      gr = gr < s.nrows ? gr : s.nrows - 1;
+      regs[i] = *reinterpret_cast<const u32x4*>(s.f32 + gr * D + c * 4);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int g = tid + NTHREADS * i, row = g >> 4, c = g & 15;
+      int64_t gr = row0 + row;
+      gr = gr < s.nrows ? gr : s.nrows - 1;
+      regs[i] = *reinterpret_cast<const u32x4*>(s.hi + gr * D + c * 8);
+      if constexpr (MODE == MDG_PREC_BF16X3) regs[2 + i] = *reinterpret_cast<const u32x4*>(s.lo + gr * D + c * 8);
+    }
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ void stage_write(char* lds, int tid, const u32x4 (&regs)[4]) {
+  if constexpr (MODE == MDG_PREC_F32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g = tid + NTHREADS * i, row = g >> 5, c = g & 31;
+      *reinterpret_cast<u32x4*>(lds + tile_off<512>(row, c)) = regs[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int g = tid + NTHREADS * i, row = g >> 4, c = g & 15;
+      *reinterpret_cast<u32x4*>(lds + tile_off<256>(row, c)) = regs[i];
+      if constexpr (MODE == MDG_PREC_BF16X3) *reinterpret_cast<u32x4*>(lds + LO_OFF + tile_off<256>(row, c)) = regs[2 + i];
+    }
+  }
+}
+
+// ---- A fragment from 8 consecutive fp32 values --------------------------------------------
+__device__ __forceinline__ void split8(const float4& x0, const float4& x1, bf16x8& hi, bf16x8& lo) {
+  const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    __bf16 a, b;
+    mdg_split_bf16(v[j], a, b);
+    hi[j] = a;
+    lo[j] = b;
+  }
+}
+
+// rows of z_head straight from global memory (one-time, 512 B per lane)
+template <int MODE>
+__device__ __forceinline__ void afrag_from_global(AFrag<MODE>& A, const float* row, int h) {
+  if constexpr (MODE == MDG_PREC_F32) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(row + 8 * q + 4 * h);
+      A.a[4 * q + 0] = v.x; A.a[4 * q + 1] = v.y; A.a[4 * q + 2] = v.z; A.a[4 * q + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float4 v0 = *reinterpret_cast<const float4*>(row + 16 * s + 8 * h);
+      const float4 v1 = *reinterpret_cast<const float4*>(row + 16 * s + 8 * h + 4);
+      bf16x8 hi, lo;
+      split8(v0, v1, hi, lo);
+      A.hi[s] = hi;
+      if constexpr (MODE == MDG_PREC_BF16X3) A.lo[s] = lo;
+    }
+  }
+}
+
+// half of the T fragment (k in [64*st, 64*st+64)) from this wave's [32][64] fp32 slab in LDS
+template <int MODE>
+__device__ __forceinline__ void afrag_from_slab(AFrag<MODE>& A, const char* slab, int st, int r, int h) {
+  if constexpr (MODE == MDG_PREC_F32) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(slab + tile_off<256>(r, 2 * q + h));
+      const int o = 4 * (8 * st + q);
+      A.a[o + 0] = v.x; A.a[o + 1] = v.y; A.a[o + 2] = v.z; A.a[o + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float4 v0 = *reinterpret_cast<const float4*>(slab + tile_off<256>(r, 4 * s + 2 * h));
+      const float4 v1 = *reinterpret_cast<const float4*>(slab + tile_off<256>(r, 4 * s + 2 * h + 1));
+      bf16x8 hi, lo;
+      split8(v0, v1, hi, lo);
+      A.hi[4 * st + s] = hi;
+      if constexpr (MODE == MDG_PREC_BF16X3) A.lo[4 * st + s] = lo;
+    }
+  }
+}
+
+// ---- 32 rows (A, registers) x 64 staged tail rows (B, LDS) -> two 32x32 accumulators --------
+template <int MODE>
+__device__ __forceinline__ void compute_tile(const AFrag<MODE>& A, const char* lds, int r, int h, f32x16 (&acc)[2]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int j = 32 * t + r;
+    if constexpr (MODE == MDG_PREC_F32) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float4 b = *reinterpret_cast<const float4*>(lds + tile_off<512>(j, 2 * q + h));
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.a[4 * q + 0], b.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.a[4 * q + 1], b.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.a[4 * q + 2], b.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.a[4 * q + 3], b.w, acc[t], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(lds + tile_off<256>(j, 2 * s + h));
+        if constexpr (MODE == MDG_PREC_BF16X3) {
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(lds + LO_OFF + tile_off<256>(j, 2 * s + h));
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.lo[s], bh, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi[s], bl, acc[t], 0, 0, 0);
+        }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi[s], bh, acc[t], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// accumulator register v of lane (r,h) is element [row (v&3)+8(v>>2)+4h][col r] of the 32x32 tile
+__device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >> 2) + 4 * h; }
+
+template <int MODE, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void bilinear_allpairs_kernel(const BilinearArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const buf0 = smem;
+  char* const buf1 = smem + STAGE_BYTES;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int64_t l = blockIdx.y;
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * BM;
+
+  // ---------------- prologue: T = z_head[rows] . W_sym[l], kept as the A operand -------------
+  AFrag<MODE> At;
+  {
+    AFrag<MODE> Az;
+    int64_t zr = row0 + wave * 32 + r;
+    zr = zr < p.n_head ? zr : p.n_head - 1;
+    afrag_from_global<MODE>(Az, p.z_head + zr * D, h);
+    TileSrc ws = p.w;
+    if constexpr (MODE == MDG_PREC_F32) ws.f32 += l * D * D;
+    else { ws.hi += l * D * D; if constexpr (MODE == MDG_PREC_BF16X3) ws.lo += l * D * D; }
+    char* const slab = smem + wave * 8192;       // [32 rows][64 cols] fp32, chunk-swizzled
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      u32x4 regs[4];
+      stage_load<MODE>(ws, 64 * st, tid, regs);
+      __syncthreads();                            // slabs of the previous half are consumed
+      stage_write<MODE>(buf0, tid, regs);
+      __syncthreads();
+      f32x16 acc[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+      compute_tile<MODE>(Az, buf0, r, h, acc);
+      __syncthreads();                            // every wave is done reading buf0
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int row = acc_row(v, h), n = 32 * t + r;
+          *reinterpret_cast<float*>(slab + tile_off<256>(row, n >> 2) + (n & 3) * 4) = acc[t][v];
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      afrag_from_slab<MODE>(At, slab, st, r, h);
+    }
+    __syncthreads();
+  }
+
+  // ---------------- main sweep over the tail drugs -----------------------------------------
+  const int nst = static_cast<int>((p.n_tail + BN - 1) / BN);
+  const int64_t slab_rows = (p.n_head - row0) < BM ? (p.n_head - row0) : BM;
+  float* const out_slab = (EPI == MDG_EPI_ROWSTATS) ? nullptr : p.out + (l * p.n_head + row0) * p.n_tail;
+  __amdgpu_buffer_rsrc_t rsrc;
+  if constexpr (EPI != MDG_EPI_ROWSTATS)
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(out_slab, 0, static_cast<int>(slab_rows * p.n_tail * 4), 0x00020000);
+  f32x16 rsum, rmax;
+  if constexpr (EPI == MDG_EPI_ROWSTATS) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { rsum[v] = 0.f; rmax[v] = -INFINITY; }
+  }
+
+  u32x4 regs[4];
+  stage_load<MODE>(p.zt, 0, tid, regs);
+  stage_write<MODE>(buf0, tid, regs);
+  __syncthreads();
+  for (int s = 0; s < nst; ++s) {
+    char* const cur = (s & 1) ? buf1 : buf0;
+    char* const nxt = (s & 1) ? buf0 : buf1;
+    // prefetch of the next tile is unconditional: past the end the row index clamps to the last
+    // tail row and the tile is simply never consumed (a conditional here sends `regs` to scratch)
+    stage_load<MODE>(p.zt, static_cast<int64_t>(s + 1) * BN, tid, regs);
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+    compute_tile<MODE>(At, cur, r, h, acc);
+
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int64_t col = static_cast<int64_t>(s) * BN + 32 * t + r;
+      const bool col_ok = col < p.n_tail;
+      if constexpr (EPI == MDG_EPI_ROWSTATS) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          rsum[v] += col_ok ? acc[t][v] : 0.f;
+          rmax[v] = fmaxf(rmax[v], col_ok ? acc[t][v] : -INFINITY);
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int64_t e = static_cast<int64_t>(wave * 32 + acc_row(v, h)) * p.n_tail + col;
+          const unsigned off = col_ok ? static_cast<unsigned>(e * 4) : 0xFFFFFFFFu;   // out of range => dropped
+          float val = acc[t][v];
+          if constexpr (EPI == MDG_EPI_STORE_SIGMOID) val = 1.0f / (1.0f + expf(-val));
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsrc, off, 0, 0);
+        }
+      }
+    }
+    stage_write<MODE>(nxt, tid, regs);
+    __syncthreads();
+  }
+
+  if constexpr (EPI == MDG_EPI_ROWSTATS) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      float sv = rsum[v], mv = rmax[v];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        sv += __shfl_xor(sv, o, 64);
+        mv = fmaxf(mv, __shfl_xor(mv, o, 64));
+      }
+      const int64_t row = row0 + wave * 32 + acc_row(v, h);
+      if (r == 0 && row < p.n_head) {
+        float* o2 = p.out + (l * p.n_head + row) * 2;
+        o2[0] = sv;
+        o2[1] = mv;
+      }
+    }
+  }
+}
+
+// ---- pre-passes ---------------------------------------------------------------------------
+__global__ void symmetrize_kernel(const float* __restrict__ w, float* __restrict__ ws, int64_t L, int D_) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t per = static_cast<int64_t>(D_) * D_;
+  if (idx >= L * per) return;
+  const int64_t l = idx / per;
+  const int a = static_cast<int>((idx % per) / D_), b = static_cast<int>(idx % D_);
+  // read both before writing: in-place is allowed (each thread owns exactly one output element,
+  // and the element it may read besides its own, [b][a] with a > b, is an upper-triangle entry
+  // that its owner rewrites with the same value).
+  const float v = (a <= b) ? w[idx] : w[l * per + static_cast<int64_t>(b) * D_ + a];
+  ws[idx] = v;
+}
+
+__global__ void split_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ hi, __bf16* __restrict__ lo,
+                                  int64_t n4) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = reinterpret_cast<const float4*>(x)[i];
+  bf16x4 h, l;
+  __bf16 a, b;
+  mdg_split_bf16(v.x, a, b); h[0] = a; l[0] = b;
+  mdg_split_bf16(v.y, a, b); h[1] = a; l[1] = b;
+  mdg_split_bf16(v.z, a, b); h[2] = a; l[2] = b;
+  mdg_split_bf16(v.w, a, b); h[3] = a; l[3] = b;
+  reinterpret_cast<bf16x4*>(hi)[i] = h;
+  if (lo) reinterpret_cast<bf16x4*>(lo)[i] = l;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+
+template <int MODE>
+int launch_allpairs(const BilinearArgs& a, int epilogue, hipStream_t st) {
+  const dim3 grid(static_cast<unsigned>(mdg_cdiv(a.n_head, BM)), static_cast<unsigned>(a.n_labels));
+  const size_t lds = 2 * STAGE_BYTES;
+  switch (epilogue) {
+    case MDG_EPI_STORE:
+      hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE>), grid, dim3(NTHREADS), lds, st, a);
+      break;
+    case MDG_EPI_STORE_SIGMOID:
+      hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE_SIGMOID>), grid, dim3(NTHREADS), lds, st, a);
+      break;
+    case MDG_EPI_ROWSTATS:
+      hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_ROWSTATS>), grid, dim3(NTHREADS), lds, st, a);
+      break;
+    default:
+      mdg_set_error("mdg_bilinear_allpairs: unknown epilogue %d", epilogue);
+      return MDG_EINVAL;
+  }
+  MDG_CHECK_LAUNCH("mdg_bilinear_allpairs");
+  return MDG_OK;
+}
+
+}  // namespace
+
+extern "C" int mdg_symmetrize(const float* w_original, float* w_sym, int64_t L, int64_t D_, void* stream) {
+  MDG_CHECK_ARG(w_original && w_sym, "mdg_symmetrize: null pointer");
+  MDG_CHECK_ARG(L >= 0 && D_ > 0 && D_ <= 4096, "mdg_symmetrize: bad shape L=%lld D=%lld", (long long)L, (long long)D_);
+  const int64_t n = L * D_ * D_;
+  if (n == 0) return MDG_OK;
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), w_original, w_sym, L, static_cast<int>(D_));
+  MDG_CHECK_LAUNCH("mdg_symmetrize");
+  return MDG_OK;
+}
+
+extern "C" size_t mdg_bilinear_allpairs_workspace_bytes(int64_t n_head, int64_t n_tail, int64_t n_labels, int64_t D_,
+                                                        int precision) {
+  (void)n_head;
+  if (precision == MDG_PREC_F32 || n_tail <= 0 || n_labels <= 0) return 0;
+  const size_t z = align256(static_cast<size_t>(n_tail) * D_ * 2), w = align256(static_cast<size_t>(n_labels) * D_ * D_ * 2);
+  return precision == MDG_PREC_BF16X3 ? 2 * (z + w) : (z + w);
+}
+
+extern "C" int mdg_bilinear_allpairs(const float* z_head, const float* z_tail, const float* w_sym, float* out,
+                                     int64_t n_head, int64_t n_tail, int64_t n_labels, int64_t D_, int precision,
+                                     int epilogue, void* workspace, size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(D_ == D, "mdg_bilinear_allpairs: D must be %d (got %lld)", D, (long long)D_);
+  MDG_CHECK_ARG(n_head >= 0 && n_tail >= 0 && n_labels >= 0, "mdg_bilinear_allpairs: negative size");
+  MDG_CHECK_ARG(n_labels <= 65535, "mdg_bilinear_allpairs: n_labels %lld > 65535 per call", (long long)n_labels);
+  MDG_CHECK_ARG(n_tail * BM * 4 < (int64_t(1) << 31), "mdg_bilinear_allpairs: n_tail %lld too large", (long long)n_tail);
+  if (n_head == 0 || n_tail == 0 || n_labels == 0) return MDG_OK;
+  MDG_CHECK_ARG(z_head && z_tail && w_sym && out, "mdg_bilinear_allpairs: null pointer");
+  MDG_CHECK_ARG(mdg_aligned16(z_head) && mdg_aligned16(z_tail) && mdg_aligned16(w_sym),
+                "mdg_bilinear_allpairs: z_head, z_tail and w_sym must be 16-byte aligned");
+  MDG_CHECK_ARG(precision == MDG_PREC_F32 || precision == MDG_PREC_BF16X3 || precision == MDG_PREC_BF16,
+                "mdg_bilinear_allpairs: unknown precision %d", precision);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  BilinearArgs a{};
+  a.z_head = z_head;
+  a.out = out;
+  a.n_head = n_head; a.n_tail = n_tail; a.n_labels = n_labels;
+  a.zt.nrows = n_tail;
+  a.w.nrows = D;
+  if (precision == MDG_PREC_F32) {
+    a.zt.f32 = z_tail;
+    a.w.f32 = w_sym;
+    return launch_allpairs<MDG_PREC_F32>(a, epilogue, st);
+  }
+  const size_t need = mdg_bilinear_allpairs_workspace_bytes(n_head, n_tail, n_labels, D_, precision);
+  if (!workspace || workspace_bytes < need || !mdg_aligned16(workspace)) {
+    mdg_set_error("mdg_bilinear_allpairs: workspace of %zu bytes (16-byte aligned) required, got %zu", need, workspace_bytes);
+    return MDG_EWORKSPACE;
+  }
+  const bool x3 = precision == MDG_PREC_BF16X3;
+  char* ws = static_cast<char*>(workspace);
+  const size_t zb = align256(static_cast<size_t>(n_tail) * D * 2), wb = align256(static_cast<size_t>(n_labels) * D * D * 2);
+  __bf16* zhi = reinterpret_cast<__bf16*>(ws);
+  __bf16* whi = reinterpret_cast<__bf16*>(ws + zb);
+  __bf16* zlo = x3 ? reinterpret_cast<__bf16*>(ws + zb + wb) : nullptr;
+  __bf16* wlo = x3 ? reinterpret_cast<__bf16*>(ws + 2 * zb + wb) : nullptr;
+  const int64_t z4 = n_tail * D / 4, w4 = n_labels * D * D / 4;
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(static_cast<unsigned>(mdg_cdiv(z4, 256))), dim3(256), 0, st, z_tail, zhi, zlo, z4);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(static_cast<unsigned>(mdg_cdiv(w4, 256))), dim3(256), 0, st, w_sym, whi, wlo, w4);
+  MDG_CHECK_LAUNCH("mdg_bilinear_allpairs(split)");
+  a.zt.hi = zhi; a.zt.lo = zlo;
+  a.w.hi = whi; a.w.lo = wlo;
+  return x3 ? launch_allpairs<MDG_PREC_BF16X3>(a, epilogue, st) : launch_allpairs<MDG_PREC_BF16>(a, epilogue, st);
+}

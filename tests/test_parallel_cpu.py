@@ -1,0 +1,68 @@
+"""World-size-2 gloo tests of the multi-GPU sharding logic (CPU; the head itself needs the GPU, so
+the per-rank compute here is the oracle -- test infrastructure standing in for the kernel)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from madrigal_amd.parallel import shard_range, shard_sizes
+
+
+def test_shard_ranges_cover():
+    for n in (0, 1, 7, 8, 4096, 4003):
+        for w in (1, 2, 3, 8):
+            ranges = [shard_range(n, r, w) for r in range(w)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            assert max(shard_sizes(n, w)) - min(shard_sizes(n, w)) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from madrigal_amd.parallel import all_gather_rows
+    from oracle import madrigal_oracle as O
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(n, 128, generator=g)
+    lo, hi = shard_range(n, rank, world)
+    z_full = all_gather_rows(z[lo:hi].clone(), n, rank, world)
+    ok = torch.equal(z_full, z)
+    # outcome-sharded head: rank r scores its own outcomes against all pairs
+    L = 4
+    gw = torch.Generator().manual_seed(7)
+    w = torch.randn(L, 128, 128, generator=gw)
+    llo, lhi = shard_range(L, rank, world)
+    mine = O.bilinear_scores(z_full, z_full, w[llo:lhi])
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    full = torch.cat(parts, dim=0)
+    ok = ok and torch.allclose(full, O.bilinear_scores(z, z, w), rtol=1e-6, atol=1e-5)
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [64, 37])
+def test_gloo_world2_allgather_and_outcome_shards(n):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret[0] and ret[1]
