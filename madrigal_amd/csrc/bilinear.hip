@@ -18,13 +18,12 @@
 // BOTH operands -- any permutation of k is legal as long as A and B agree -- which turns the
 // per-MFMA scalar operand into one ds_read_b128 per four MFMAs.
 #include "mdg_common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int D = 128;
-constexpr int BM = 256;            // head rows per workgroup
 constexpr int BN = 64;             // tail rows per stage
-constexpr int NTHREADS = 512;
 constexpr int STAGE_BYTES = BN * D * 4;   // fp32 tile, or bf16 hi (16 KB) + lo (16 KB)
 constexpr int LO_OFF = BN * D * 2;
 
@@ -41,6 +40,7 @@ struct BilinearArgs {
   TileSrc w;          // W_sym (all labels); nrows = D
   float* out;
   int64_t n_head, n_tail, n_labels;
+  int stagger;
 };
 
 template <int MODE> struct AFrag;
@@ -54,11 +54,12 @@ __device__ __forceinline__ int tile_off(int row, int chunk) {
 }
 
 // ---- global -> registers -> LDS staging of one 64-row tile ---------------------------------
-template <int MODE>
-__device__ __forceinline__ void stage_load(const TileSrc& s, int64_t row0, int tid, u32x4 (&regs)[4]) {
+template <int MODE, int NW>
+__device__ __forceinline__ void stage_load(const TileSrc& s, int64_t row0, int tid, u32x4 (&regs)[32 / NW]) {
+  constexpr int NTHREADS = 64 * NW;
   if constexpr (MODE == MDG_PREC_F32) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 32 / NW; ++i) {
       const int g = tid + NTHREADS * i, row = g >> 5, c = g & 31;
       int64_t gr = row0 + row;
       gr = gr < s.nrows ? gr : s.nrows - 1;
@@ -66,30 +67,77 @@ __device__ __forceinline__ void stage_load(const TileSrc& s, int64_t row0, int t
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 16 / NW; ++i) {
       const int g = tid + NTHREADS * i, row = g >> 4, c = g & 15;
       int64_t gr = row0 + row;
       gr = gr < s.nrows ? gr : s.nrows - 1;
       regs[i] = *reinterpret_cast<const u32x4*>(s.hi + gr * D + c * 8);
-      if constexpr (MODE == MDG_PREC_BF16X3) regs[2 + i] = *reinterpret_cast<const u32x4*>(s.lo + gr * D + c * 8);
+      if constexpr (MODE == MDG_PREC_BF16X3) regs[16 / NW + i] = *reinterpret_cast<const u32x4*>(s.lo + gr * D + c * 8);
     }
   }
 }
 
-template <int MODE>
-__device__ __forceinline__ void stage_write(char* lds, int tid, const u32x4 (&regs)[4]) {
+template <int MODE, int NW>
+__device__ __forceinline__ void stage_write(char* lds, int tid, const u32x4 (&regs)[32 / NW]) {
+  constexpr int NTHREADS = 64 * NW;
   if constexpr (MODE == MDG_PREC_F32) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 32 / NW; ++i) {
       const int g = tid + NTHREADS * i, row = g >> 5, c = g & 31;
       *reinterpret_cast<u32x4*>(lds + tile_off<512>(row, c)) = regs[i];
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 16 / NW; ++i) {
       const int g = tid + NTHREADS * i, row = g >> 4, c = g & 15;
       *reinterpret_cast<u32x4*>(lds + tile_off<256>(row, c)) = regs[i];
-      if constexpr (MODE == MDG_PREC_BF16X3) *reinterpret_cast<u32x4*>(lds + LO_OFF + tile_off<256>(row, c)) = regs[2 + i];
+      if constexpr (MODE == MDG_PREC_BF16X3) *reinterpret_cast<u32x4*>(lds + LO_OFF + tile_off<256>(row, c)) = regs[16 / NW + i];
+    }
+  }
+}
+
+
+// ---- global -> LDS staging by LDS-DMA (no staging registers, asynchronous) ------------------
+// One wave-instruction moves 1 KiB: LDS destination = wave-uniform base + lane*16 (linear), the
+// per-lane SOURCE address carries the chunk swizzle (cdna guide rule 21: linear dest + swizzled
+// source + the same swizzle on the read).  Completion is tracked by the issuing wave's vmcnt.
+// Issued as inline asm so that hipcc's waitcnt pass does not see it (with the builtin it drains
+// vmcnt(0) -- i.e. every score store in flight -- before the next ds_read); the waits are counted
+// by hand in the kernel.  M0 carries the LDS base and is restored (cdna guide 5.7).
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return static_cast<unsigned>(reinterpret_cast<size_t>((lds_void*)p));
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst_uniform);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+
+template <int MODE, int NW>
+__device__ __forceinline__ void stage_dma(const TileSrc& s, int64_t row0, char* lds, int wave, int lane) {
+  if constexpr (MODE == MDG_PREC_F32) {
+#pragma unroll
+    for (int i = 0; i < 32 / NW; ++i) {
+      const int p = wave + NW * i, row = 2 * p + (lane >> 5), c = (lane & 31) ^ (row & 15);
+      int64_t gr = row0 + row;
+      gr = gr < s.nrows ? gr : s.nrows - 1;
+      glds16(s.f32 + gr * D + c * 4, lds_addr(lds + p * 1024));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16 / NW; ++i) {
+      const int p = wave + NW * i, row = 4 * p + (lane >> 4), c = (lane & 15) ^ (row & 15);
+      int64_t gr = row0 + row;
+      gr = gr < s.nrows ? gr : s.nrows - 1;
+      glds16(s.hi + gr * D + c * 8, lds_addr(lds + p * 1024));
+      if constexpr (MODE == MDG_PREC_BF16X3)
+        glds16(s.lo + gr * D + c * 8, lds_addr(lds + LO_OFF + p * 1024));
     }
   }
 }
@@ -184,8 +232,9 @@ __device__ __forceinline__ void compute_tile(const AFrag<MODE>& A, const char* l
 // accumulator register v of lane (r,h) is element [row (v&3)+8(v>>2)+4h][col r] of the 32x32 tile
 __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >> 2) + 4 * h; }
 
-template <int MODE, int EPI>
-__global__ __launch_bounds__(NTHREADS, 2) void bilinear_allpairs_kernel(const BilinearArgs p) {
+template <int MODE, int EPI, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const BilinearArgs p) {
+  constexpr int BM = 32 * NW;        // head rows per workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const buf0 = smem;
   char* const buf1 = smem + STAGE_BYTES;
@@ -206,10 +255,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void bilinear_allpairs_kernel(const Bi
     char* const slab = smem + wave * 8192;       // [32 rows][64 cols] fp32, chunk-swizzled
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-      u32x4 regs[4];
-      stage_load<MODE>(ws, 64 * st, tid, regs);
+      u32x4 regs[32 / NW];
+      stage_load<MODE, NW>(ws, 64 * st, tid, regs);
       __syncthreads();                            // slabs of the previous half are consumed
-      stage_write<MODE>(buf0, tid, regs);
+      stage_write<MODE, NW>(buf0, tid, regs);
       __syncthreads();
       f32x16 acc[2];
 #pragma unroll
@@ -245,16 +294,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void bilinear_allpairs_kernel(const Bi
     for (int v = 0; v < 16; ++v) { rsum[v] = 0.f; rmax[v] = -INFINITY; }
   }
 
-  u32x4 regs[4];
-  stage_load<MODE>(p.zt, 0, tid, regs);
-  stage_write<MODE>(buf0, tid, regs);
-  __syncthreads();
+  // Pipeline (one raw barrier per stage, counted waits only):
+  //   top of stage s : wait until this wave's DMA pieces of tile s have landed (all but the NST
+  //                    youngest vector-memory ops -- the score stores of stage s-1 -- are done),
+  //                    barrier => every wave's pieces of tile s are in LDS AND every wave has
+  //                    finished reading tile s-1, whose buffer the next DMA overwrites;
+  //   then           : issue DMA(tile s+1), MFMA on tile s, issue the stores of tile s.
+  // The stores are never waited for inside the loop.
+  // Each workgroup starts its sweep at a different tail tile (and wraps): co-resident workgroups
+  // otherwise write addresses that differ only by multiples of the row / slab strides (16 KB, 4 MB
+  // at N=4096) at the same instant, which piles them onto a few HBM channels.
+  constexpr int NST = (EPI == MDG_EPI_ROWSTATS) ? 0 : 32;
+  const int start = p.stagger ? static_cast<int>((blockIdx.x * 5u + blockIdx.y * 3u) % static_cast<unsigned>(nst)) : 0;
+  auto tile_of = [&](int s) { int t = s + start; return t >= nst ? t - nst : t; };
+  stage_dma<MODE, NW>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, buf0, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int s = 0; s < nst; ++s) {
+    const int64_t tcol0 = static_cast<int64_t>(tile_of(s)) * BN;
     char* const cur = (s & 1) ? buf1 : buf0;
     char* const nxt = (s & 1) ? buf0 : buf1;
-    // prefetch of the next tile is unconditional: past the end the row index clamps to the last
-    // tail row and the tile is simply never consumed (a conditional here sends `regs` to scratch)
-    stage_load<MODE>(p.zt, static_cast<int64_t>(s + 1) * BN, tid, regs);
+    if constexpr (NST == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // past the end the row index clamps to the last tail row; that tile is never consumed
+    stage_dma<MODE, NW>(p.zt, static_cast<int64_t>(tile_of(s + 1 < nst ? s + 1 : s)) * BN, nxt, wave, lane);
     f32x16 acc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -264,7 +327,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bilinear_allpairs_kernel(const Bi
 
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int64_t col = static_cast<int64_t>(s) * BN + 32 * t + r;
+      const int64_t col = tcol0 + 32 * t + r;
       const bool col_ok = col < p.n_tail;
       if constexpr (EPI == MDG_EPI_ROWSTATS) {
 #pragma unroll
@@ -283,9 +346,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void bilinear_allpairs_kernel(const Bi
         }
       }
     }
-    stage_write<MODE>(nxt, tid, regs);
-    __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the trailing (unused) DMA before LDS is released
 
   if constexpr (EPI == MDG_EPI_ROWSTATS) {
 #pragma unroll
@@ -337,19 +399,20 @@ __global__ void split_bf16_kernel(const float* __restrict__ x, __bf16* __restric
 
 inline size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
-template <int MODE>
-int launch_allpairs(const BilinearArgs& a, int epilogue, hipStream_t st) {
-  const dim3 grid(static_cast<unsigned>(mdg_cdiv(a.n_head, BM)), static_cast<unsigned>(a.n_labels));
+template <int MODE, int NW>
+int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
+  const dim3 grid(static_cast<unsigned>(mdg_cdiv(a.n_head, 32 * NW)), static_cast<unsigned>(a.n_labels));
+  const dim3 block(64 * NW);
   const size_t lds = 2 * STAGE_BYTES;
   switch (epilogue) {
     case MDG_EPI_STORE:
-      hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE>), grid, dim3(NTHREADS), lds, st, a);
+      hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE, NW>), grid, block, lds, st, a);
       break;
     case MDG_EPI_STORE_SIGMOID:
-      hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE_SIGMOID>), grid, dim3(NTHREADS), lds, st, a);
+      hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE_SIGMOID, NW>), grid, block, lds, st, a);
       break;
     case MDG_EPI_ROWSTATS:
-      hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_ROWSTATS>), grid, dim3(NTHREADS), lds, st, a);
+      hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_ROWSTATS, NW>), grid, block, lds, st, a);
       break;
     default:
       mdg_set_error("mdg_bilinear_allpairs: unknown epilogue %d", epilogue);
@@ -357,6 +420,17 @@ int launch_allpairs(const BilinearArgs& a, int epilogue, hipStream_t st) {
   }
   MDG_CHECK_LAUNCH("mdg_bilinear_allpairs");
   return MDG_OK;
+}
+
+// Workgroup shape.  4 waves x 128 rows lets two workgroups share a CU (2 x 64 KB LDS): they drift
+// out of lockstep, so one group's MFMA phase covers the other's store drain.  MDG_BILINEAR_WAVES
+// (4 or 8) overrides the choice for experiments; it is read per call and changes speed only.
+template <int MODE>
+int launch_allpairs(const BilinearArgs& a, int epilogue, hipStream_t st) {
+  int nw = 8;
+  if (const char* e = getenv("MDG_BILINEAR_WAVES")) nw = atoi(e);
+  if (nw == 8) return launch_allpairs_nw<MODE, 8>(a, epilogue, st);
+  return launch_allpairs_nw<MODE, 4>(a, epilogue, st);
 }
 
 }  // namespace
@@ -386,7 +460,7 @@ extern "C" int mdg_bilinear_allpairs(const float* z_head, const float* z_tail, c
   MDG_CHECK_ARG(D_ == D, "mdg_bilinear_allpairs: D must be %d (got %lld)", D, (long long)D_);
   MDG_CHECK_ARG(n_head >= 0 && n_tail >= 0 && n_labels >= 0, "mdg_bilinear_allpairs: negative size");
   MDG_CHECK_ARG(n_labels <= 65535, "mdg_bilinear_allpairs: n_labels %lld > 65535 per call", (long long)n_labels);
-  MDG_CHECK_ARG(n_tail * BM * 4 < (int64_t(1) << 31), "mdg_bilinear_allpairs: n_tail %lld too large", (long long)n_tail);
+  MDG_CHECK_ARG(n_tail * 256 * 4 < (int64_t(1) << 31), "mdg_bilinear_allpairs: n_tail %lld too large", (long long)n_tail);
   if (n_head == 0 || n_tail == 0 || n_labels == 0) return MDG_OK;
   MDG_CHECK_ARG(z_head && z_tail && w_sym && out, "mdg_bilinear_allpairs: null pointer");
   MDG_CHECK_ARG(mdg_aligned16(z_head) && mdg_aligned16(z_tail) && mdg_aligned16(w_sym),
@@ -399,6 +473,8 @@ extern "C" int mdg_bilinear_allpairs(const float* z_head, const float* z_tail, c
   a.out = out;
   a.n_head = n_head; a.n_tail = n_tail; a.n_labels = n_labels;
   a.zt.nrows = n_tail;
+  a.stagger = 1;
+  if (const char* e = getenv("MDG_BILINEAR_STAGGER")) a.stagger = atoi(e);
   a.w.nrows = D;
   if (precision == MDG_PREC_F32) {
     a.zt.f32 = z_tail;

@@ -58,7 +58,8 @@ def test_vs_oracle(ops, prec, nh, nt, L):
     ref = _oracle(zh, zt, w)
     got = ops.bilinear_allpairs(zh.cuda(), zt.cuda(), ops.symmetrize(w.cuda()), precision=prec).cpu()
     assert got.shape == ref.shape
-    assert rel_err(got, ref) < TOL[prec]
+    # scale floor sqrt(D): a lone score can sit near zero while its bf16 rounding error does not
+    assert float((got - ref).abs().max()) < TOL[prec] * max(float(ref.abs().max()), 128 ** 0.5)
 
 
 def test_asymmetric_operands_catch_transposes(ops):
