@@ -49,6 +49,12 @@ enum mdg_bilinear_epilogue {
                                 max_j S (roofline stress runs whose [L,N,N] cannot exist)        */
 };
 
+/* Activation fused into mdg_linear's epilogue (madrigal/models/models.py:31, actn2actfunc). */
+enum mdg_activation {
+  MDG_ACT_NONE = 0, MDG_ACT_RELU = 1, MDG_ACT_GELU = 2 /* exact erf form */, MDG_ACT_SIGMOID = 3, MDG_ACT_TANH = 4,
+  MDG_ACT_LEAKYRELU = 5, MDG_ACT_SOFTPLUS = 6, MDG_ACT_SELU = 7
+};
+
 const char* mdg_last_error(void);
 /* "gfx950" build tag, and the ABI version (bumped on any signature change). */
 const char* mdg_build_arch(void);
@@ -78,6 +84,82 @@ size_t mdg_bilinear_allpairs_workspace_bytes(int64_t n_head, int64_t n_tail, int
 int mdg_bilinear_allpairs(const float* z_head, const float* z_tail, const float* w_sym, float* out,
                           int64_t n_head, int64_t n_tail, int64_t n_labels, int64_t D, int precision,
                           int epilogue, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------ dense blocks ---- */
+
+/* Y = alpha * act( (X W^T + bias) * scale + shift ) + beta * R      X [M,K] ldx, W [N,K] ldw (nn.Linear
+ * layout), Y [M,N] ldy, R [M,N] ldr; bias/scale/shift [N]; any of bias, scale+shift, R may be NULL.
+ * Replaces every nn.Linear (+ eval BatchNorm1d folded into scale/shift, + activation, + residual) on
+ * the path: MLPEncoder/MLPAdaptor madrigal/models/models.py:178-180,516-518; chemCPA MLP
+ * madrigal/chemcpa/chemCPA/model.py:226-231; nn.TransformerEncoderLayer linears models.py:366;
+ * embed2latent / latent2embed models.py:411,443; GIN and HGT projections (third-party wheels).
+ * K, ldx, ldw multiples of 4 (zero-pad the inner dimension), x and w 16-byte aligned. */
+int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+               const float* bias, const float* scale, const float* shift, int activation, const float* residual, int64_t ldr,
+               float alpha, float beta, int precision, void* stream);
+
+/* Row-wise LayerNorm (nn.LayerNorm, biased variance): y = (x - mean) / sqrt(var + eps) * gamma + beta.
+ * norm1/norm2 and the x-attn norms of the fusion transformer, models.py:366,372-373; LayerNorm inside
+ * MLPAdaptor, models.py:492.  d multiple of 4, <= 2048. */
+int mdg_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy, int64_t rows,
+                  int64_t d, float eps, void* stream);
+
+/* ------------------------------------------------------------------- cross-modal fusion ---- */
+
+/* Token sequence of the fusion transformer: seq[i] = [cls?] str kg cv [bottleneck x nb] tx_0..tx_15
+ * (each a 128-float row), optional per-token L2 normalisation, then + pe[s] for s < pe_len.
+ * Replaces the stack / cat / repeat glue and PositionEncoding* of madrigal/models/models.py:772-775,
+ * 799-804,818-822,849-852,581-603.  tx_emb is [16 * n_src, 128], cell-line major.  rows (nullable) selects
+ * source drug rows (the multi-modal subset of fusion='transformer_uni_proj', models.py:784-790). */
+int mdg_assemble_tokens(const float* str_emb, const float* kg_emb, const float* cv_emb, const float* tx_emb,
+                        const float* bottleneck, const float* cls, const float* pe, const int64_t* rows, float* seq, int64_t n,
+                        int64_t n_src, int nb, int has_cls, int pe_len, int normalize, int64_t D, void* stream);
+
+/* Multi-head self-attention core for S <= 32 tokens per drug (scores, masks, softmax, PV) on the fp32
+ * matrix cores; projections are mdg_linear calls.  qkv [n*S, 3d] = q|k|v (in_proj output), out [n*S, d].
+ * kpm_bits[i] bit j = key j of drug i is padding (src_key_padding_mask), src_bits[s] bit j = query s
+ * may not attend key j (the [S,S] bottleneck mask, models.py:813-816); probs (nullable) receives the
+ * per-head attention weights [n,H,S,S] (need_weights=True, average_attn_weights=False, models.py:388-399).
+ * Replaces nn.MultiheadAttention inside nn.TransformerEncoderLayer, models.py:366-367,412. */
+int mdg_fusion_attention(const float* qkv, int64_t ld, float* out, int64_t ldo, const uint32_t* kpm_bits,
+                         const uint32_t* src_bits, float* probs, int64_t n, int S, int H, int dh, void* stream);
+
+/* Cross-attention pooling with one learned query shared by all drugs: out[i,h,:] = softmax_j(q_h . K_ijh / sqrt(dh)) V_ijh.
+ * q_proj [H*dh] (already projected), kv_proj [n*Tk, 2*H*dh] = K|V of the Tk allowed key tokens of each drug.
+ * Replaces x_attn_mha_layer, madrigal/models/models.py:430-438. */
+int mdg_xattn_pool(const float* q_proj, const float* kv_proj, int64_t ld, float* out, int64_t ldo, int64_t n, int Tk, int H, int dh,
+                   void* stream);
+
+/* y = x / max(||x||_2, 1e-12) per row (F.normalize; models.py:849-850,858-859,872,892-893,947-949). d % 4 == 0. */
+int mdg_l2_normalize(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t d, void* stream);
+
+/* Masked pooling over the S <= 32 tokens [n,S,128] of each drug; tokens whose bit is set in mask_bits[i] are
+ * skipped.  mode 0 = mean, 1 = sum, 2 = max.  Replaces the torch_scatter scatter_mean / scatter_add /
+ * scatter_max call sites madrigal/models/models.py:447,451,873,878. */
+int mdg_token_pool(const float* tokens, const uint32_t* mask_bits, float* out, int64_t n, int S, int64_t D, int mode, void* stream);
+
+/* ------------------------------------------------------------------- graph aggregations ---- */
+
+/* out[v] = (self_coef_add + *self_coef_dev) * x_self[v] + sum_{e in CSR row v} w[e] * x[col[e]]   (mean: sum / count)
+ * col == NULL: the row's neighbours are the contiguous rows [rowptr[v], rowptr[v+1]) of x (segment read-out).
+ * Replaces torchdrug GraphIsomorphismConv.message_and_aggregate (sparse.mm + scatter_add) and MeanReadout
+ * behind madrigal/models/models.py:217,720-721.  F multiple of 4, <= 256. */
+int mdg_csr_aggregate(const float* x, int64_t ldx, const int64_t* rowptr, const int64_t* col, const float* edge_weight,
+                      const float* x_self, int64_t ld_self, const float* self_coef_dev, float self_coef_add, int mean, float* out,
+                      int64_t ldo, int64_t n_dst, int64_t F, void* stream);
+
+size_t mdg_hgt_attention_workspace_bytes(int64_t n_items, int heads);
+
+/* HGT edge attention + aggregation for one destination node type: per-head softmax over ALL incoming edges
+ * of a node (every edge type), weighted sum of relation-transformed values, optional GELU.
+ * q [n_dst, ldq>=128]; kv [rows, ldkv>=256] = k'|v' (relation transforms and p_rel/sqrt(D) already applied);
+ * col[e] = kv row of edge e, edges sorted by destination; work items (item_dst, item_begin, item_end) split
+ * long destination rows, item_ptr [n_dst+1] = items of each destination.
+ * Replaces PyG HGTConv.propagate/message (edge softmax + scatter-add) behind models.py:76-79,90-94. */
+int mdg_hgt_attention(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const int64_t* col, const int64_t* item_dst,
+                      const int64_t* item_begin, const int64_t* item_end, int64_t n_items, const int64_t* item_ptr, float* out,
+                      int64_t ldo, int64_t n_dst, int heads, int64_t F, int apply_gelu, void* workspace, size_t workspace_bytes,
+                      void* stream);
 
 #ifdef __cplusplus
 }

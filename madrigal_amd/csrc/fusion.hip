@@ -1,0 +1,319 @@
+// Cross-modal fusion kernels for gfx950: token assembly, small-sequence self-attention on the fp32
+// matrix cores, and the one-query cross-attention pooling.  (madrigal/models/models.py:401-455,
+// 775-853; nn.TransformerEncoderLayer / nn.MultiheadAttention semantics, eval mode.)
+#include "mdg_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Token assembly: seq[n, S, D] = [cls?] str kg cv [bottleneck x nb] tx_0..tx_15, optional per-token
+// L2 normalisation, then + pe[s] for s < pe_len.  One 32-lane group (float4 per lane) per token.
+// ---------------------------------------------------------------------------------------------
+struct AssembleArgs {
+  const float* str; const float* kg; const float* cv; const float* tx;   // [n_src,128] x3, [16*n_src,128]
+  const float* bottleneck; const float* cls; const float* pe;            // [nb,128], [128], [pe_len,128]
+  const int64_t* rows;                                                   // [n] source row per output row, or null
+  float* seq;
+  int64_t n, n_src;
+  int nb, has_cls, pe_len, normalize;
+};
+
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const AssembleArgs p) {
+  const int S = p.has_cls + 3 + p.nb + 16;
+  const int64_t tok = static_cast<int64_t>(blockIdx.x) * 8 + (threadIdx.x >> 5);
+  const int sub = threadIdx.x & 31;
+  if (tok >= p.n * S) return;
+  const int64_t i = tok / S;
+  const int s = static_cast<int>(tok % S);
+  const int64_t src = p.rows ? p.rows[i] : i;
+  int t = s - p.has_cls;
+  const float* row;
+  bool learned = false;
+  if (t < 0) { row = p.cls; learned = true; }
+  else if (t == 0) row = p.str + src * 128;
+  else if (t == 1) row = p.kg + src * 128;
+  else if (t == 2) row = p.cv + src * 128;
+  else if (t < 3 + p.nb) { row = p.bottleneck + (t - 3) * 128; learned = true; }
+  else row = p.tx + (static_cast<int64_t>(t - 3 - p.nb) * p.n_src + src) * 128;
+  (void)learned;
+  f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * sub);
+  if (p.normalize) {
+    float q = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float inv = 1.0f / fmaxf(sqrtf(q), 1e-12f);      // F.normalize(p=2, eps=1e-12)
+    v *= inv;
+  }
+  if (s < p.pe_len) v += *reinterpret_cast<const f32x4*>(p.pe + s * 128 + 4 * sub);
+  *reinterpret_cast<f32x4*>(p.seq + tok * 128 + 4 * sub) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Self-attention over S <= 32 tokens, one wave per (drug, head), on v_mfma_f32_32x32x2_f32.
+//   P^T = softmax_keys( K (Q/sqrt(dh))^T + masks )   computed "swapped" so that the query sits on the
+//   lane and the 32 keys of a row sit in the accumulator registers of the two lane halves: the
+//   softmax is in-register plus one cross-half exchange.
+//   O^T = V^T P^T : the P^T accumulator is consumed as the B operand as it stands (the second product
+//   sums over P^T's row index), V is read with the lane on the feature column (coalesced).
+// k order of the first product is permuted (k = 8q+4h+e) identically for Q and K so that each lane
+// reads its row in 16-byte pieces.
+// ---------------------------------------------------------------------------------------------
+struct AttnArgs {
+  const float* qkv; int64_t ld;      // [n*S, 3d]: q | k | v
+  float* out; int64_t ldo;           // [n*S, d]
+  const uint32_t* kpm_bits;          // [n] bit j set = key j masked for this drug, or null
+  const uint32_t* src_bits;          // [S] bit j set = query i may not attend key j, or null
+  float* probs;                      // [n,H,S,S] or null
+  int64_t n;
+  int S, H, dh;
+  float qscale;
+};
+
+__global__ __launch_bounds__(256) void fusion_attention_kernel(const AttnArgs p) {
+  const int lane = threadIdx.x & 63, x = lane & 31, half = lane >> 5;
+  const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (gw >= p.n * p.H) return;
+  const int64_t drug = gw / p.H;
+  const int head = static_cast<int>(gw % p.H);
+  const int d = p.H * p.dh;
+  const int xr = x < p.S ? x : p.S - 1;
+  const float* qrow = p.qkv + (drug * p.S + xr) * p.ld + head * p.dh;
+  const float* krow = qrow + d;
+
+  f32x16 acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+  for (int k0 = 0; k0 < p.dh; k0 += 64) {
+    f32x4 qf[8], kf[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = k0 + 8 * q + 4 * half;
+      const bool ok = k < p.dh;
+      qf[q] = ok ? *reinterpret_cast<const f32x4*>(qrow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      kf[q] = ok ? *reinterpret_cast<const f32x4*>(krow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[q][e], qf[q][e] * p.qscale, acc, 0, 0, 0);
+  }
+
+  // acc[v] = score(query x, key j), j = (v&3) + 8(v>>2) + 4*half
+  const uint32_t blocked = (p.kpm_bits ? p.kpm_bits[drug] : 0u) | (p.src_bits ? p.src_bits[xr] : 0u);
+  float m = -INFINITY;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    const int j = (v & 3) + 8 * (v >> 2) + 4 * half;
+    if (j >= p.S || ((blocked >> j) & 1u)) acc[v] = -INFINITY;
+    m = fmaxf(m, acc[v]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    acc[v] = expf(acc[v] - m);         // a fully masked row gives exp(-inf - -inf) = NaN, as torch does
+    sum += acc[v];
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] *= inv;
+
+  if (p.probs && x < p.S) {
+    float* pr = p.probs + ((drug * p.H + head) * p.S + x) * p.S;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int j = (v & 3) + 8 * (v >> 2) + 4 * half;
+      if (j < p.S) pr[j] = acc[v];
+    }
+  }
+
+  const float* vbase = p.qkv + drug * p.S * p.ld + 2 * d + head * p.dh;
+  for (int c0 = 0; c0 < p.dh; c0 += 32) {
+    f32x16 o;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) o[v] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      int j = (s & 3) + 8 * (s >> 2) + 4 * half;
+      j = j < p.S ? j : p.S - 1;                    // clamped rows meet p == 0
+      const float vv = vbase[static_cast<int64_t>(j) * p.ld + c0 + x];
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, acc[s], o, 0, 0, 0);
+    }
+    if (x < p.S) {
+      float* orow = p.out + (drug * p.S + x) * p.ldo + head * p.dh + c0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(orow + 8 * g + 4 * half) = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cross-attention pooling with ONE query shared by every drug: out[i, head] = softmax_j(q.K_ij) V_ij.
+// One wave per (drug, head); lanes span the head dimension.  (models.py:422-438; the fixed key mask
+// is applied by the caller by passing only the allowed key tokens.)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xattn_pool_kernel(const float* __restrict__ q, const float* __restrict__ kv, int64_t ld,
+                                                         float* __restrict__ out, int64_t ldo, int64_t n, int Tk, int H, int dh,
+                                                         float qscale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (gw >= n * H) return;
+  const int64_t drug = gw / H;
+  const int head = static_cast<int>(gw % H);
+  const int d = H * dh;
+  const int per = (dh + 63) / 64;            // <= 4 for dh <= 256
+  float qv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = lane + 64 * u;
+    qv[u] = (u < per && c < dh) ? q[head * dh + c] * qscale : 0.f;
+  }
+  // online softmax over the Tk keys (running max m, running sum, running weighted V sum)
+  float m = -INFINITY, sum = 0.f;
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int j = 0; j < Tk; ++j) {
+    const float* kr = kv + (drug * Tk + j) * ld + head * dh;
+    const float* vr = kr + d;
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = lane + 64 * u;
+      if (u < per && c < dh) s += qv[u] * kr[c];
+    }
+    s = mdg_wave_sum(s);
+    const float mn = fmaxf(m, s);
+    const float f = expf(m - mn), e = expf(s - mn);
+    sum = sum * f + e;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = lane + 64 * u;
+      if (u < per && c < dh) o[u] = o[u] * f + e * vr[c];
+    }
+    m = mn;
+  }
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = lane + 64 * u;
+    if (u < per && c < dh) out[drug * ldo + head * dh + c] = o[u] * inv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-wise L2 normalisation (F.normalize, eps 1e-12): one wave per row, two passes over the row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
+                                                           int64_t rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  float q = 0.f;
+  for (int c = 4 * lane; c < d; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+    q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  const float inv = 1.0f / fmaxf(sqrtf(mdg_wave_sum(q)), 1e-12f);
+  float* yr = y + row * ldy;
+  for (int c = 4 * lane; c < d; c += 256) *reinterpret_cast<f32x4*>(yr + c) = *reinterpret_cast<const f32x4*>(xr + c) * inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Masked pooling over the tokens of a drug: mean / sum / max over tokens whose mask bit is clear
+// (the scatter_mean / scatter_add / scatter_max uses at madrigal/models/models.py:447,451,873,878).
+// One 32-lane group (float4 per lane, D = 128) per drug.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void token_pool_kernel(const float* __restrict__ e, const uint32_t* __restrict__ bits,
+                                                         float* __restrict__ out, int64_t n, int S, int mode) {
+  const int sub = threadIdx.x & 31;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 8 + (threadIdx.x >> 5);
+  if (i >= n) return;
+  const uint32_t b = bits ? bits[i] : 0u;
+  f32x4 acc = (mode == 2) ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
+  int cnt = 0;
+  for (int s = 0; s < S; ++s) {
+    if ((b >> s) & 1u) continue;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(e + (i * S + s) * 128 + 4 * sub);
+    if (mode == 2) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = fmaxf(acc[c], v[c]);
+    } else {
+      acc += v;
+    }
+    ++cnt;
+  }
+  if (mode == 0) acc = acc / static_cast<float>(cnt > 0 ? cnt : 1);
+  *reinterpret_cast<f32x4*>(out + i * 128 + 4 * sub) = acc;
+}
+
+}  // namespace
+
+extern "C" int mdg_assemble_tokens(const float* str_emb, const float* kg_emb, const float* cv_emb, const float* tx_emb,
+                                   const float* bottleneck, const float* cls, const float* pe, const int64_t* rows, float* seq,
+                                   int64_t n, int64_t n_src, int nb, int has_cls, int pe_len, int normalize, int64_t D,
+                                   void* stream) {
+  MDG_CHECK_ARG(D == 128, "mdg_assemble_tokens: D must be 128 (got %lld)", (long long)D);
+  MDG_CHECK_ARG(n >= 0 && n_src >= 0 && nb >= 0 && nb <= 8, "mdg_assemble_tokens: bad sizes");
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(str_emb && kg_emb && cv_emb && tx_emb && seq, "mdg_assemble_tokens: null pointer");
+  MDG_CHECK_ARG((nb == 0 || bottleneck) && (!has_cls || cls) && (pe_len == 0 || pe), "mdg_assemble_tokens: missing token table");
+  const int S = (has_cls ? 1 : 0) + 3 + nb + 16;
+  MDG_CHECK_ARG(S <= 32 && pe_len <= S, "mdg_assemble_tokens: sequence of %d tokens exceeds 32", S);
+  AssembleArgs a{str_emb, kg_emb, cv_emb, tx_emb, bottleneck, cls, pe, rows, seq, n, n_src, nb, has_cls ? 1 : 0, pe_len, normalize};
+  hipLaunchKernelGGL(assemble_tokens_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n * S, 8))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  MDG_CHECK_LAUNCH("mdg_assemble_tokens");
+  return MDG_OK;
+}
+
+extern "C" int mdg_fusion_attention(const float* qkv, int64_t ld, float* out, int64_t ldo, const uint32_t* kpm_bits,
+                                    const uint32_t* src_bits, float* probs, int64_t n, int S, int H, int dh, void* stream) {
+  MDG_CHECK_ARG(n >= 0 && S >= 1 && S <= 32, "mdg_fusion_attention: S must be in [1,32] (got %d)", S);
+  MDG_CHECK_ARG(H >= 1 && dh >= 8 && dh % 32 == 0 && dh <= 1024, "mdg_fusion_attention: head_dim must be a multiple of 32 (got %d)", dh);
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(qkv && out, "mdg_fusion_attention: null pointer");
+  MDG_CHECK_ARG(ld % 4 == 0 && ldo % 4 == 0 && ld >= 3 * H * dh && ldo >= H * dh && mdg_aligned16(qkv) && mdg_aligned16(out),
+                "mdg_fusion_attention: bad strides / alignment");
+  AttnArgs a{qkv, ld, out, ldo, kpm_bits, src_bits, probs, n, S, H, dh, 1.0f / sqrtf(static_cast<float>(dh))};
+  hipLaunchKernelGGL(fusion_attention_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n * H, 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  MDG_CHECK_LAUNCH("mdg_fusion_attention");
+  return MDG_OK;
+}
+
+extern "C" int mdg_xattn_pool(const float* q_proj, const float* kv_proj, int64_t ld, float* out, int64_t ldo, int64_t n, int Tk,
+                              int H, int dh, void* stream) {
+  MDG_CHECK_ARG(n >= 0 && Tk >= 1 && Tk <= 32 && H >= 1 && dh >= 1 && dh <= 256, "mdg_xattn_pool: bad shape (Tk=%d H=%d dh=%d)", Tk, H, dh);
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(q_proj && kv_proj && out && ld >= 2 * H * dh && ldo >= H * dh, "mdg_xattn_pool: bad pointers / strides");
+  hipLaunchKernelGGL(xattn_pool_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n * H, 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), q_proj, kv_proj, ld, out, ldo, n, Tk, H, dh,
+                     1.0f / sqrtf(static_cast<float>(dh)));
+  MDG_CHECK_LAUNCH("mdg_xattn_pool");
+  return MDG_OK;
+}
+
+extern "C" int mdg_l2_normalize(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t d, void* stream) {
+  MDG_CHECK_ARG(rows >= 0 && d > 0 && d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= d && ldy >= d, "mdg_l2_normalize: bad shape");
+  if (rows == 0) return MDG_OK;
+  MDG_CHECK_ARG(x && y && mdg_aligned16(x) && mdg_aligned16(y), "mdg_l2_normalize: bad pointers");
+  hipLaunchKernelGGL(l2_normalize_kernel, dim3(static_cast<unsigned>(mdg_cdiv(rows, 4))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     x, ldx, y, ldy, rows, static_cast<int>(d));
+  MDG_CHECK_LAUNCH("mdg_l2_normalize");
+  return MDG_OK;
+}
+
+extern "C" int mdg_token_pool(const float* tokens, const uint32_t* mask_bits, float* out, int64_t n, int S, int64_t D, int mode,
+                              void* stream) {
+  MDG_CHECK_ARG(D == 128 && S >= 1 && S <= 32 && n >= 0 && mode >= 0 && mode <= 2, "mdg_token_pool: bad arguments (D=%lld S=%d mode=%d)", (long long)D, S, mode);
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(tokens && out && mdg_aligned16(tokens) && mdg_aligned16(out), "mdg_token_pool: bad pointers");
+  hipLaunchKernelGGL(token_pool_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 8))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     tokens, mask_bits, out, n, S, mode);
+  MDG_CHECK_LAUNCH("mdg_token_pool");
+  return MDG_OK;
+}

@@ -1,0 +1,237 @@
+// GNN message-passing aggregations for gfx950 (structure GIN and knowledge-graph HGT encoders).
+//
+// Both are gather-bound (HBM / L2): per edge one F*4-byte neighbour row is read, per destination one
+// row is written.  Edges are pre-sorted by destination (CSR, built once per batch/graph by the host
+// glue), so every destination is owned by one lane group: no atomics, and the summation order is the
+// fixed CSR order => bitwise reproducible results.  Reductions inside a row use wavefront shuffles.
+#include "mdg_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// out[v] = self_coef * x_self[v] + sum_{e in [rowptr[v], rowptr[v+1])} w[e] * x[col[e]]      (mean: / count)
+//   GIN:      x = h, col = source atom of edge e, self_coef = 1 + eps  (torchdrug GraphIsomorphismConv;
+//             call site madrigal/models/models.py:720) and, with F=20, the per-destination sum of bond
+//             features that multiplies edge_linear once per layer (linearity of edge_linear);
+//   read-out: col == null => contiguous rows [rowptr[v], rowptr[v+1]) of x (node2graph is sorted), mean.
+// LPR lanes cooperate on one destination row (float4 per lane), 64/LPR rows per wave.
+// ---------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void csr_aggregate_kernel(const float* __restrict__ x, int64_t ldx,
+                                                            const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
+                                                            const float* __restrict__ w, const float* __restrict__ xself,
+                                                            int64_t ldself, const float* __restrict__ self_coef_dev,
+                                                            float self_coef_add, int mean, float* __restrict__ out, int64_t ldo,
+                                                            int64_t n_dst, int F) {
+  constexpr int RPB = 256 / LPR;
+  const int sub = threadIdx.x % LPR;
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * RPB + threadIdx.x / LPR;
+  if (v >= n_dst) return;
+  const int c = 4 * sub;
+  const bool act = c < F;
+  const int64_t e0 = rowptr[v], e1 = rowptr[v + 1];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int64_t e = e0;
+  for (; e + 4 <= e1; e += 4) {           // 4 independent gathers in flight
+    int64_t s[4];
+    float ww[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s[u] = col ? col[e + u] : e + u;
+      ww[u] = w ? w[e + u] : 1.f;
+    }
+    f32x4 r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = act ? *reinterpret_cast<const f32x4*>(x + s[u] * ldx + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += ww[u] * r[u];
+  }
+  for (; e < e1; ++e) {
+    const int64_t s = col ? col[e] : e;
+    const float ww = w ? w[e] : 1.f;
+    if (act) acc += ww * *reinterpret_cast<const f32x4*>(x + s * ldx + c);
+  }
+  if (mean) {
+    const float cnt = static_cast<float>(e1 - e0);
+    acc = acc / fmaxf(cnt, 1.f);
+  }
+  if (xself && act) {
+    const float coef = self_coef_add + (self_coef_dev ? self_coef_dev[0] : 0.f);
+    acc += coef * *reinterpret_cast<const f32x4*>(xself + v * ldself + c);
+  }
+  if (act) *reinterpret_cast<f32x4*>(out + v * ldo + c) = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// HGT edge attention (PyG HGTConv message/aggregate; call site madrigal/models/models.py:76-79,
+// 90-94).  For destination node i with query q_i [H,D] and incoming edges e -> (row c_e of the
+// relation-transformed source table kv = [k' | v'], F = H*D = 128 floats each):
+//     a_e[h] = q_i[h] . k'_{c_e}[h]          (p_rel / sqrt(D) is folded into k' by the host glue)
+//     alpha  = softmax over ALL incoming edges of i (every edge type), per head
+//     out_i  = gelu( sum_e alpha_e[h] v'_{c_e}[h] )
+// Work item = (destination, chunk of <= CHUNK edges): heavy-tailed KG degrees are split so that no
+// wave owns more than CHUNK edges; each item produces an online-softmax partial (m, l, acc) and a
+// second kernel merges the partials of a destination in item order (deterministic).
+// A half-wave (32 lanes x float4 = 128 floats) handles one edge; the two halves of a wave walk
+// alternate edges with 2 edges each in flight, and are merged at the end.
+// ---------------------------------------------------------------------------------------------
+struct HgtArgs {
+  const float* q; int64_t ldq;          // [n_dst, >=128]
+  const float* kv; int64_t ldkv;        // [n_rows, >=256]: k' at +0, v' at +128
+  const int64_t* col;                   // [nnz] row of kv per edge, sorted by destination
+  const int64_t* item_dst; const int64_t* item_begin; const int64_t* item_end;   // [n_items]
+  float* part_acc;                      // [n_items,128]
+  float* part_ml;                       // [n_items,H,2]
+  int64_t n_items;
+  int H;
+};
+
+__device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]); }
+
+__global__ __launch_bounds__(256) void hgt_attention_kernel(const HgtArgs p) {
+  const int lane = threadIdx.x & 63, sub = lane & 31, half = lane >> 5;
+  const int64_t item = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (item >= p.n_items) return;
+  const int lph = 32 / p.H;                       // lanes per head
+  const int64_t dst = p.item_dst[item], e0 = p.item_begin[item], e1 = p.item_end[item];
+  const f32x4 q = *reinterpret_cast<const f32x4*>(p.q + dst * p.ldq + 4 * sub);
+  float m = -INFINITY, l = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // this half takes edges e0+half, e0+half+2, ...; two of them per iteration
+  for (int64_t e = e0 + half; e < e1; e += 4) {
+    const bool two = (e + 2) < e1;
+    const int64_t c0 = p.col[e], c1 = two ? p.col[e + 2] : c0;
+    const float* r0 = p.kv + c0 * p.ldkv + 4 * sub;
+    const float* r1 = p.kv + c1 * p.ldkv + 4 * sub;
+    const f32x4 k0 = *reinterpret_cast<const f32x4*>(r0), v0 = *reinterpret_cast<const f32x4*>(r0 + 128);
+    const f32x4 k1 = *reinterpret_cast<const f32x4*>(r1), v1 = *reinterpret_cast<const f32x4*>(r1 + 128);
+    float a0 = dot4(q, k0), a1 = dot4(q, k1);
+    for (int o = lph >> 1; o > 0; o >>= 1) {
+      a0 += __shfl_xor(a0, o, 64);
+      a1 += __shfl_xor(a1, o, 64);
+    }
+    if (!two) a1 = -INFINITY;
+    const float mn = fmaxf(m, fmaxf(a0, a1));
+    const float f = expf(m - mn), w0 = expf(a0 - mn), w1 = expf(a1 - mn);
+    l = l * f + w0 + w1;
+    acc = acc * f + w0 * v0 + w1 * v1;
+    m = mn;
+  }
+  // merge the two halves (each lane pairs with lane ^ 32, same feature columns)
+  {
+    const float mo = __shfl_xor(m, 32, 64), lo = __shfl_xor(l, 32, 64);
+    f32x4 ao;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ao[c] = __shfl_xor(acc[c], 32, 64);
+    const float mn = fmaxf(m, mo);
+    const float f0 = (m == -INFINITY) ? 0.f : expf(m - mn), f1 = (mo == -INFINITY) ? 0.f : expf(mo - mn);
+    // fixed order (half 0 first) so that both halves compute bit-identical sums
+    const float la = half ? lo : l, lb = half ? l : lo;
+    const float fa = half ? f1 : f0, fb = half ? f0 : f1;
+    const f32x4 xa = half ? ao : acc, xb = half ? acc : ao;
+    l = la * fa + lb * fb;
+    acc = xa * fa + xb * fb;
+    m = mn;
+  }
+  if (half == 0) {
+    *reinterpret_cast<f32x4*>(p.part_acc + item * 128 + 4 * sub) = acc;
+    if (sub % lph == 0) {
+      const int h = sub / lph;
+      p.part_ml[(item * p.H + h) * 2 + 0] = m;
+      p.part_ml[(item * p.H + h) * 2 + 1] = l;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void hgt_combine_kernel(const float* __restrict__ part_acc, const float* __restrict__ part_ml,
+                                                          const int64_t* __restrict__ item_ptr, float* __restrict__ out, int64_t ldo,
+                                                          int64_t n_dst, int H, int apply_gelu) {
+  const int sub = threadIdx.x & 31;
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * 8 + (threadIdx.x >> 5);
+  if (v >= n_dst) return;
+  const int h = sub / (32 / H);
+  const int64_t i0 = item_ptr[v], i1 = item_ptr[v + 1];
+  float m = -INFINITY, l = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t it = i0; it < i1; ++it) {
+    const float mi = part_ml[(it * H + h) * 2], li = part_ml[(it * H + h) * 2 + 1];
+    if (mi == -INFINITY) continue;
+    const f32x4 ai = *reinterpret_cast<const f32x4*>(part_acc + it * 128 + 4 * sub);
+    const float mn = fmaxf(m, mi);
+    const float f = (m == -INFINITY) ? 0.f : expf(m - mn), g = expf(mi - mn);
+    l = l * f + li * g;
+    acc = acc * f + ai * g;
+    m = mn;
+  }
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  if (l > 0.f) o = acc / (l + 1e-16f);          // torch_geometric.utils.softmax: exp / (sum + 1e-16)
+  if (apply_gelu) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = mdg_gelu(o[c]);
+  }
+  *reinterpret_cast<f32x4*>(out + v * ldo + 4 * sub) = o;
+}
+
+template <int LPR>
+void launch_csr(const float* x, int64_t ldx, const int64_t* rowptr, const int64_t* col, const float* w, const float* xself,
+                int64_t ldself, const float* coef_dev, float coef_add, int mean, float* out, int64_t ldo, int64_t n_dst, int F,
+                hipStream_t st) {
+  const int rpb = 256 / LPR;
+  hipLaunchKernelGGL(csr_aggregate_kernel<LPR>, dim3(static_cast<unsigned>(mdg_cdiv(n_dst, rpb))), dim3(256), 0, st, x, ldx, rowptr,
+                     col, w, xself, ldself, coef_dev, coef_add, mean, out, ldo, n_dst, F);
+}
+
+}  // namespace
+
+extern "C" int mdg_csr_aggregate(const float* x, int64_t ldx, const int64_t* rowptr, const int64_t* col, const float* edge_weight,
+                                 const float* x_self, int64_t ld_self, const float* self_coef_dev, float self_coef_add, int mean,
+                                 float* out, int64_t ldo, int64_t n_dst, int64_t F, void* stream) {
+  MDG_CHECK_ARG(n_dst >= 0 && F > 0 && F % 4 == 0 && F <= 256, "mdg_csr_aggregate: F must be a multiple of 4 and <= 256 (got %lld)", (long long)F);
+  if (n_dst == 0) return MDG_OK;
+  MDG_CHECK_ARG(x && rowptr && out, "mdg_csr_aggregate: null pointer");
+  MDG_CHECK_ARG(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= F && ldo >= F && (!x_self || (ld_self % 4 == 0 && ld_self >= F)),
+                "mdg_csr_aggregate: row strides must be multiples of 4 and >= F");
+  MDG_CHECK_ARG(mdg_aligned16(x) && mdg_aligned16(out) && (!x_self || mdg_aligned16(x_self)), "mdg_csr_aggregate: 16-byte alignment");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int Fi = static_cast<int>(F);
+  if (F <= 32) launch_csr<8>(x, ldx, rowptr, col, edge_weight, x_self, ld_self, self_coef_dev, self_coef_add, mean, out, ldo, n_dst, Fi, st);
+  else if (F <= 64) launch_csr<16>(x, ldx, rowptr, col, edge_weight, x_self, ld_self, self_coef_dev, self_coef_add, mean, out, ldo, n_dst, Fi, st);
+  else if (F <= 128) launch_csr<32>(x, ldx, rowptr, col, edge_weight, x_self, ld_self, self_coef_dev, self_coef_add, mean, out, ldo, n_dst, Fi, st);
+  else launch_csr<64>(x, ldx, rowptr, col, edge_weight, x_self, ld_self, self_coef_dev, self_coef_add, mean, out, ldo, n_dst, Fi, st);
+  MDG_CHECK_LAUNCH("mdg_csr_aggregate");
+  return MDG_OK;
+}
+
+extern "C" size_t mdg_hgt_attention_workspace_bytes(int64_t n_items, int heads) {
+  if (n_items <= 0) return 0;
+  return static_cast<size_t>(n_items) * (128 + 2 * static_cast<size_t>(heads)) * sizeof(float);
+}
+
+extern "C" int mdg_hgt_attention(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const int64_t* col,
+                                 const int64_t* item_dst, const int64_t* item_begin, const int64_t* item_end, int64_t n_items,
+                                 const int64_t* item_ptr, float* out, int64_t ldo, int64_t n_dst, int heads, int64_t F,
+                                 int apply_gelu, void* workspace, size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(F == 128, "mdg_hgt_attention: hidden size must be 128 (got %lld)", (long long)F);
+  MDG_CHECK_ARG(heads == 1 || heads == 2 || heads == 4 || heads == 8, "mdg_hgt_attention: heads must be 1, 2, 4 or 8 (got %d)", heads);
+  MDG_CHECK_ARG(n_dst >= 0 && n_items >= 0, "mdg_hgt_attention: negative size");
+  if (n_dst == 0) return MDG_OK;
+  MDG_CHECK_ARG(q && out && item_ptr && (n_items == 0 || (kv && col && item_dst && item_begin && item_end)), "mdg_hgt_attention: null pointer");
+  MDG_CHECK_ARG(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && ldq >= 128 && ldkv >= 256 && ldo >= 128, "mdg_hgt_attention: bad strides");
+  MDG_CHECK_ARG(mdg_aligned16(q) && mdg_aligned16(out) && (!kv || mdg_aligned16(kv)), "mdg_hgt_attention: 16-byte alignment");
+  const size_t need = mdg_hgt_attention_workspace_bytes(n_items, heads);
+  if (need && (!workspace || workspace_bytes < need || !mdg_aligned16(workspace))) {
+    mdg_set_error("mdg_hgt_attention: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return MDG_EWORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* part_acc = static_cast<float*>(workspace);
+  float* part_ml = part_acc ? part_acc + n_items * 128 : nullptr;
+  if (n_items > 0) {
+    HgtArgs a{q, ldq, kv, ldkv, col, item_dst, item_begin, item_end, part_acc, part_ml, n_items, heads};
+    hipLaunchKernelGGL(hgt_attention_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_items, 4))), dim3(256), 0, st, a);
+  }
+  hipLaunchKernelGGL(hgt_combine_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_dst, 8))), dim3(256), 0, st, part_acc, part_ml, item_ptr,
+                     out, ldo, n_dst, heads, apply_gelu);
+  MDG_CHECK_LAUNCH("mdg_hgt_attention");
+  return MDG_OK;
+}

@@ -1,0 +1,100 @@
+"""Destination-sorted (CSR) plans for the two GNN aggregations.
+
+Host-side glue (torch ops on the device, no arithmetic of the model): the reference hands the
+encoders COO edge lists (torchdrug ``edge_list`` [E,3], PyG ``edge_index_dict``); the HIP
+aggregation kernels want edges grouped by destination so that one lane group owns one output row
+(no atomics, fixed summation order).  Plans are built once per graph object and cached on it: the
+KG is static across steps and the molecule batch is the single full batch of the run
+(train_ddi_batch.py:116).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+
+HGT_CHUNK = 512       # edges per work item: bounds the work of one wave for heavy-tailed KG degrees
+
+
+def _rowptr(sorted_dst: torch.Tensor, n: int) -> torch.Tensor:
+    deg = torch.bincount(sorted_dst, minlength=n)
+    rp = torch.zeros(n + 1, dtype=torch.int64, device=sorted_dst.device)
+    torch.cumsum(deg, 0, out=rp[1:])
+    return rp
+
+
+def molecule_plan(graph) -> dict:
+    """CSR-by-destination view of a packed molecule batch (duck-typed torchdrug PackedMolecule)."""
+    dev = graph.node_feature.device
+    cached = getattr(graph, "_mdg_plan", None)
+    if cached is not None and cached["device"] == dev:
+        return cached
+    el = graph.edge_list
+    src, dst = el[:, 0].long(), el[:, 1].long()
+    A = int(graph.node_feature.shape[0])
+    order = torch.argsort(dst, stable=True)
+    ew = getattr(graph, "edge_weight", None)
+    w_sorted = None
+    if ew is not None:
+        ew = ew.float()
+        if not bool(torch.all(ew == 1.0)):
+            w_sorted = ew[order].contiguous()
+    ef = graph.edge_feature.float()[order]
+    E = ef.shape[0]
+    # bond features + a ones column (weighted in-degree) + zero pad to a multiple of 4
+    width = ef.shape[1] + 1
+    pad = (-width) % 4
+    ef_aug = torch.cat([ef, torch.ones(E, 1, device=dev), torch.zeros(E, pad, device=dev)], dim=1).contiguous()
+    n2g = graph.node2graph.long()
+    n_graphs = int(getattr(graph, "batch_size", int(n2g.max()) + 1 if n2g.numel() else 0))
+    if n2g.numel() > 1 and not bool(torch.all(n2g[1:] >= n2g[:-1])):
+        raise ValueError("node2graph must be non-decreasing (packed graphs)")
+    plan = {"device": dev, "rowptr": _rowptr(dst[order], A), "col": src[order].contiguous(), "w": w_sorted,
+            "edge_feat_aug": ef_aug, "edge_feat_dim": int(ef.shape[1]), "graph_rowptr": _rowptr(n2g, n_graphs),
+            "n_graphs": n_graphs}
+    try:
+        graph._mdg_plan = plan
+    except Exception:       # objects that refuse new attributes: rebuild every call
+        pass
+    return plan
+
+
+def hgt_plan(edge_index_dict, edge_types: Sequence[Tuple[str, str, str]], sizes: Dict[str, int], device) -> dict:
+    """Per destination node type: concatenated incoming edges of every edge type, sorted by
+    destination, pointing into ONE relation-transformed source table whose rows are laid out edge
+    type after edge type (offset[r] + source index), plus the chunked work-item lists."""
+    present = [et for et in edge_types if et in edge_index_dict]
+    offset, total = {}, 0
+    for et in present:
+        offset[et] = total
+        total += sizes[et[0]]
+    per_dst = {}
+    for t, n_t in sizes.items():
+        cols, dsts = [], []
+        for et in present:
+            if et[2] != t:
+                continue
+            ei = edge_index_dict[et].to(device).long()
+            if ei.shape[1] == 0:
+                continue
+            cols.append(ei[0] + offset[et])
+            dsts.append(ei[1])
+        if cols:
+            col, dst = torch.cat(cols), torch.cat(dsts)
+            order = torch.argsort(dst, stable=True)
+            col, dst = col[order].contiguous(), dst[order]
+        else:
+            col = torch.zeros(0, dtype=torch.int64, device=device)
+            dst = col
+        rowptr = _rowptr(dst, n_t)
+        deg = rowptr[1:] - rowptr[:-1]
+        chunks = (deg + HGT_CHUNK - 1) // HGT_CHUNK
+        item_ptr = torch.zeros(n_t + 1, dtype=torch.int64, device=device)
+        torch.cumsum(chunks, 0, out=item_ptr[1:])
+        item_dst = torch.repeat_interleave(torch.arange(n_t, device=device), chunks)
+        k = torch.arange(item_dst.numel(), device=device) - item_ptr[item_dst]
+        item_begin = rowptr[item_dst] + k * HGT_CHUNK
+        item_end = torch.minimum(item_begin + HGT_CHUNK, rowptr[item_dst + 1])
+        per_dst[t] = {"col": col, "rowptr": rowptr, "item_ptr": item_ptr, "item_dst": item_dst.contiguous(),
+                      "item_begin": item_begin.contiguous(), "item_end": item_end.contiguous()}
+    return {"present": present, "offset": offset, "total_rows": total, "per_dst": per_dst}

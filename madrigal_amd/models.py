@@ -1,0 +1,936 @@
+"""MI355X-native drop-in for ``madrigal.models.models`` (+ the torchdrug GIN, PyG HGTConv and
+chemCPA ``TxAdaptingComPert.predict`` pieces it calls): same class names, constructor and
+``forward`` signatures, attribute names and ``state_dict`` keys as the reference, so that
+``madrigal/utils.py:get_model`` / ``create_optimizer`` and checkpoints keep working; the arithmetic
+runs in hand-written HIP kernels behind the C ABI of ``include/madrigal_hip.h`` (no PyTorch
+arithmetic on the hot path, no CPU fallback: the ops raise if the library is missing).
+
+Forward-only this release: modules must be in ``eval()`` mode and called under
+``torch.no_grad()``; training-mode statefulness (dropout, BatchNorm batch statistics) raises.
+
+Reference lines cited per class (paths relative to the reference checkout).
+"""
+from __future__ import annotations
+
+import math
+import os
+from contextlib import contextmanager
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .data import CELL_LINES, MOL_DIM, NON_TX_MODALITIES, NUM_MODALITIES, NUM_NON_TX_MODALITIES
+from .graph_plans import hgt_plan, molecule_plan
+
+TX_INPUT_DIM = 978
+CELL_LINES_CAPITALIZED = [c.upper() for c in CELL_LINES]
+
+_state = {"precision": "bf16x3"}
+
+
+def set_precision(p: str) -> None:
+    """Arithmetic of every matrix product on the path: 'f32' (exact fp32 MFMA), 'bf16x3'
+    (split-bf16, fp32-grade; default) or 'bf16'."""
+    if p not in ops.PRECISIONS:
+        raise ValueError(f"unknown precision {p!r}")
+    _state["precision"] = p
+
+
+def get_precision() -> str:
+    return _state["precision"]
+
+
+@contextmanager
+def precision(p: str):
+    old = get_precision()
+    set_precision(p)
+    try:
+        yield
+    finally:
+        set_precision(old)
+
+
+def _lin(x, w, b=None, **kw):
+    return ops.linear(x, w, b, precision=_state["precision"], **kw)
+
+
+def _require_eval(m: nn.Module) -> None:
+    if m.training:
+        raise RuntimeError(f"{type(m).__name__}: the HIP path is forward-only; call .eval() first "
+                           "(dropout / BatchNorm batch statistics of training mode are not implemented)")
+
+
+# madrigal/models/models.py:31.  Fresh instances per use; only the type matters for the fused epilogue.
+def _make_act(name):
+    table = {'relu': nn.ReLU, 'leakyrelu': nn.LeakyReLU, 'tanh': nn.Tanh, 'sigmoid': nn.Sigmoid, 'selu': nn.SELU,
+             'softplus': nn.Softplus, 'gelu': nn.GELU, None: nn.Identity}
+    if name not in table:
+        raise NotImplementedError(name)
+    return table[name]()
+
+
+_ACT_OF = {nn.ReLU: "relu", nn.LeakyReLU: "leakyrelu", nn.Tanh: "tanh", nn.Sigmoid: "sigmoid", nn.SELU: "selu",
+           nn.Softplus: "softplus", nn.GELU: "gelu", nn.Identity: None}
+
+
+def _bn_scale_shift(bn: nn.BatchNorm1d):
+    """Eval-mode BatchNorm as y = x * scale + shift."""
+    scale = torch.rsqrt(bn.running_var + bn.eps)
+    if bn.weight is not None:
+        scale = scale * bn.weight.detach()
+    shift = -bn.running_mean * scale
+    if bn.bias is not None:
+        shift = shift + bn.bias.detach()
+    return scale.contiguous(), shift.contiguous()
+
+
+def _run_sequential(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """Execute an nn.Sequential of Linear / activation / LayerNorm / BatchNorm1d / Dropout (eval) with
+    the fused kernels: every Linear absorbs the BatchNorm and activation that FOLLOW it; a BatchNorm
+    that PRECEDES a Linear (MLPEncoder's 'nd' order) is folded into that Linear's weights."""
+    mods = list(seq)
+    i = 0
+    pre_affine = None          # (scale, shift) of an eval BatchNorm waiting for the next Linear
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Dropout) or isinstance(m, nn.Identity):
+            i += 1
+        elif isinstance(m, nn.LayerNorm):
+            x = ops.layernorm(x, m.weight, m.bias, m.eps)
+            i += 1
+        elif isinstance(m, nn.BatchNorm1d):
+            pre_affine = _bn_scale_shift(m)
+            i += 1
+        elif isinstance(m, nn.Linear):
+            w, b = m.weight.detach(), None if m.bias is None else m.bias.detach()
+            if pre_affine is not None:          # W (s*x + t) + b = (W*s) x + (W t + b)
+                s, t = pre_affine
+                b = (w @ t) if b is None else b + w @ t
+                w = w * s.unsqueeze(0)
+                pre_affine = None
+            j, scale, shift, act = i + 1, None, None, None
+            if j < len(mods) and isinstance(mods[j], nn.BatchNorm1d):
+                scale, shift = _bn_scale_shift(mods[j])
+                j += 1
+            if j < len(mods) and type(mods[j]) in _ACT_OF and not isinstance(mods[j], nn.Identity):
+                act = _ACT_OF[type(mods[j])]
+                j += 1
+            x = _lin(x, w, b, scale=scale, shift=shift, act=act)
+            i = j
+        elif type(m) in _ACT_OF:
+            raise NotImplementedError("activation without a preceding Linear")
+        else:
+            raise NotImplementedError(type(m).__name__)
+    if pre_affine is not None:
+        raise NotImplementedError("trailing BatchNorm without a Linear")
+    return x
+
+
+# ------------------------------------------------------------------------------------- MLPs
+class MLPEncoder(nn.Module):
+    """madrigal/models/models.py:121-180 (cv encoder; also tx_encoder='mlp')."""
+
+    def __init__(self, in_dim: int, hidden_dims: list, output_dim: int, p: float, norm: str, actn: str, order: str = 'nd'):
+        super().__init__()
+        self.n_layer = len(hidden_dims) - 1
+        self.in_dim = in_dim
+        layers = [nn.Linear(in_dim, hidden_dims[0]), _make_act(actn)]
+        for i in range(self.n_layer):
+            layers += self.compose_layer(hidden_dims[i], hidden_dims[i + 1], norm, actn, p, order)
+        layers.append(nn.Linear(hidden_dims[-1], output_dim))
+        self.fc = nn.Sequential(*layers)
+
+    @staticmethod
+    def compose_layer(in_dim, out_dim, norm, actn, p=0.0, order='nd'):
+        if norm in (None, 'None'):
+            nl = None
+        elif norm == 'bn':
+            nl = nn.BatchNorm1d(in_dim)
+        elif norm == 'ln':
+            nl = nn.LayerNorm(in_dim)
+        else:
+            raise NotImplementedError(norm)
+        if order == 'nd':
+            layers = ([nl] if nl is not None else []) + ([nn.Dropout(p)] if p != 0 else [])
+        elif order == 'dn':
+            layers = ([nn.Dropout(p)] if p != 0 else []) + ([nl] if nl is not None else [])
+        else:
+            raise NotImplementedError(order)
+        layers.append(nn.Linear(in_dim, out_dim))
+        if actn is not None:
+            layers.append(_make_act(actn))
+        return layers
+
+    def forward(self, x):
+        _require_eval(self)
+        lead = x.shape[:-1]
+        return _run_sequential(self.fc, x.reshape(-1, x.shape[-1])).reshape(*lead, -1)
+
+
+class MLPAdaptor(MLPEncoder):
+    """madrigal/models/models.py:459-518 (uni_projector / uni_fuser); same structure as MLPEncoder."""
+
+
+class VAE(nn.Module):
+    """madrigal/models/models.py:183-208 is not on the encode -> fuse -> score path."""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+        raise NotImplementedError("VAE is outside the encode -> fuse -> score path")
+
+
+# ------------------------------------------------------------------------------------- structure encoder
+class GraphIsomorphismNetwork(nn.Module):
+    """torchdrug==0.2.1 ``models.GraphIsomorphismNetwork`` as used at madrigal/models/models.py:217,720
+    (parameter layout = modality_pretraining/str/GIN_256x4_muv.pt).  PARITY UNPINNED against the real
+    wheel (absent from the image): restated from the GIN paper + torchdrug's layer semantics.
+
+    Per layer: agg_v = (1+eps) h_v + sum_{u->v} w_uv (h_u + edge_linear(e_uv)); h' = ReLU(BN(MLP(agg))).
+    ``edge_linear`` is applied once per destination to the summed bond features (linearity), so the
+    per-edge work is a pure row gather (mdg_csr_aggregate); the MLP runs through mdg_linear with the
+    eval BatchNorm and ReLU fused into the last layer's epilogue; read-out = segment mean / sum."""
+
+    def __init__(self, input_dim=None, hidden_dims=None, edge_input_dim=None, num_mlp_layer=2, eps=0, learn_eps=False,
+                 short_cut=False, batch_norm=False, activation="relu", concat_hidden=False, readout="sum"):
+        super().__init__()
+        if short_cut or concat_hidden:
+            raise NotImplementedError("short_cut / concat_hidden are not used by Madrigal")
+        if readout not in ("sum", "mean"):
+            raise NotImplementedError(readout)
+        self.input_dim, self.output_dim = input_dim, hidden_dims[-1]
+        self.dims = [input_dim] + list(hidden_dims)
+        self.num_mlp_layer, self.readout_kind, self.activation = num_mlp_layer, readout, activation
+        self.layers = nn.ModuleList()
+        for i in range(len(self.dims) - 1):
+            layer = nn.Module()
+            e = torch.tensor([float(eps)], dtype=torch.float32)
+            if learn_eps:
+                layer.eps = nn.Parameter(e)
+            else:
+                layer.register_buffer("eps", e)
+            if batch_norm:
+                layer.batch_norm = nn.BatchNorm1d(self.dims[i + 1])
+            layer.mlp = nn.Module()
+            md = [self.dims[i]] + [self.dims[i + 1]] * num_mlp_layer
+            layer.mlp.layers = nn.ModuleList([nn.Linear(md[j], md[j + 1]) for j in range(num_mlp_layer)])
+            layer.edge_linear = nn.Linear(edge_input_dim, self.dims[i]) if edge_input_dim else None
+            self.layers.append(layer)
+
+    def forward(self, graph, input, all_loss=None, metric=None):
+        _require_eval(self)
+        plan = molecule_plan(graph)
+        h = ops._pad_last(input.float()).contiguous()          # 67 atom features -> 68 (zero column)
+        esum = None
+        for layer in self.layers:
+            k_in = layer.mlp.layers[0].weight.shape[1]
+            agg = ops.csr_aggregate(h, plan["rowptr"], plan["col"], edge_weight=plan["w"], x_self=h,
+                                    self_coef_dev=layer.eps.detach(), self_coef_add=1.0)        # [A, pad4(k_in)]
+            if layer.edge_linear is not None:
+                if esum is None:       # per-atom sum of (weighted) bond features + weighted in-degree: layer independent
+                    esum = ops.csr_aggregate(plan["edge_feat_aug"], plan["rowptr"], None, edge_weight=plan["w"])
+                fe = plan["edge_feat_dim"]
+                we = torch.zeros(agg.shape[1], esum.shape[1], device=h.device)
+                we[:k_in, :fe] = layer.edge_linear.weight.detach()
+                we[:k_in, fe] = layer.edge_linear.bias.detach()
+                agg = _lin(esum, we, None, residual=agg)                 # + W_e sum_e(e_uv) + deg_v * b_e
+            u = agg
+            n_mlp = len(layer.mlp.layers)
+            for j, lin in enumerate(layer.mlp.layers):
+                scale = shift = None
+                if j == n_mlp - 1 and hasattr(layer, "batch_norm"):      # BatchNorm(eval) + the conv's activation
+                    scale, shift = _bn_scale_shift(layer.batch_norm)
+                u = _lin(u, lin.weight, lin.bias, scale=scale, shift=shift, act=self.activation)
+            h = u
+        g = ops.csr_aggregate(h, plan["graph_rowptr"], None, mean=(self.readout_kind == "mean"))
+        return {"graph_feature": g[:, : self.output_dim], "node_feature": h}
+
+
+# ------------------------------------------------------------------------------------- KG encoder
+class HGTConv(nn.Module):
+    """torch-geometric==2.3.1 ``HGTConv`` as used at madrigal/models/models.py:76-79,90-94 (parameter
+    layout of PyG 2.3: kqv_lin.lins.<type>, out_lin.lins.<type>, k_rel/v_rel.weight [H*R,D,D] indexed
+    h*R + r, skip.<type>, p_rel.<src>__<rel>__<dst>).  PARITY UNPINNED against the real wheel.
+
+    K|Q|V projections and the per-relation transforms run through mdg_linear (the per-head relation
+    matrices as one block-diagonal 128x128 weight, with p_rel/sqrt(D) folded into the key transform);
+    the edge softmax over ALL incoming edges of a node fused with the weighted value sum is
+    mdg_hgt_attention; output projection, GELU and the sigmoid(skip)-gated residual are fused epilogues."""
+
+    def __init__(self, in_channels, out_channels, metadata, heads=1, group="sum", **kwargs):
+        super().__init__()
+        if out_channels % heads != 0:
+            raise ValueError("out_channels must be divisible by heads")
+        if out_channels != 128:
+            raise NotImplementedError("the HIP HGT kernels are built for hidden size 128 (all shipped configs)")
+        self.node_types = list(metadata[0])
+        self.edge_types = [tuple(e) for e in metadata[1]]
+        if not isinstance(in_channels, dict):
+            in_channels = {t: in_channels for t in self.node_types}
+        self.in_channels, self.out_channels, self.heads, self.group = in_channels, out_channels, heads, group
+        self.dst_node_types = {e[2] for e in self.edge_types}
+        D = out_channels // heads
+        self.kqv_lin = nn.Module()
+        self.kqv_lin.lins = nn.ModuleDict({t: nn.Linear(in_channels[t], 3 * out_channels) for t in self.node_types})
+        self.out_lin = nn.Module()
+        self.out_lin.lins = nn.ModuleDict({t: nn.Linear(out_channels, out_channels) for t in self.node_types})
+        R = len(self.edge_types)
+        self.k_rel = nn.Module()
+        self.k_rel.weight = nn.Parameter(torch.empty(heads * R, D, D))
+        self.v_rel = nn.Module()
+        self.v_rel.weight = nn.Parameter(torch.empty(heads * R, D, D))
+        self.skip = nn.ParameterDict({t: nn.Parameter(torch.ones(1)) for t in self.node_types})
+        self.p_rel = nn.ParameterDict({"__".join(e): nn.Parameter(torch.ones(1, heads)) for e in self.edge_types})
+        for w in (self.k_rel.weight, self.v_rel.weight):
+            nn.init.xavier_uniform_(w.view(heads * R * D, D))
+        self._plan_cache = {}
+        self._host_cache = {}
+
+    def _plan(self, edge_index_dict, sizes, device):
+        key = (id(edge_index_dict), str(device), tuple(sorted(sizes.items())))
+        hit = self._plan_cache.get("p")
+        if hit is None or hit[0] != key:
+            hit = (key, hgt_plan(edge_index_dict, self.edge_types, sizes, device))
+            self._plan_cache["p"] = hit
+        return hit[1]
+
+    def _skip_alpha(self, t: str) -> float:
+        p = self.skip[t]
+        key = (p.data_ptr(), p._version)
+        hit = self._host_cache.get(t)
+        if hit is None or hit[0] != key:
+            hit = (key, float(torch.sigmoid(p.detach()).item()))       # one sync per parameter version
+            self._host_cache[t] = hit
+        return hit[1]
+
+    def _relation_weights(self, r: int, et) -> Tuple[torch.Tensor, torch.Tensor]:
+        """nn.Linear-layout [128,128] weights applying the per-head [D,D] relation matrices of edge type r
+        to K (scaled by p_rel[h]/sqrt(D)) and to V:  k' = k @ blockdiag(A_h)  ==  linear(k, blockdiag(A_h)^T)."""
+        H, R = self.heads, len(self.edge_types)
+        D = self.out_channels // H
+        idx = torch.arange(H, device=self.k_rel.weight.device) * R + r
+        pr = self.p_rel["__".join(et)].detach().view(H, 1, 1) / math.sqrt(D)
+        wk = torch.block_diag(*(self.k_rel.weight.detach()[idx] * pr).unbind(0)).t().contiguous()
+        wv = torch.block_diag(*self.v_rel.weight.detach()[idx].unbind(0)).t().contiguous()
+        return wk, wv
+
+    def forward(self, x_dict, edge_index_dict):
+        _require_eval(self)
+        F = self.out_channels
+        dev = next(iter(x_dict.values())).device
+        sizes = {t: int(x.shape[0]) for t, x in x_dict.items()}
+        plan = self._plan(edge_index_dict, sizes, dev)
+        kqv = {t: _lin(x.float(), self.kqv_lin.lins[t].weight, self.kqv_lin.lins[t].bias) for t, x in x_dict.items()}
+        kv = torch.empty((max(plan["total_rows"], 1), 2 * F), dtype=torch.float32, device=dev)
+        for et in plan["present"]:
+            r = self.edge_types.index(et)
+            wk, wv = self._relation_weights(r, et)
+            o, n_s = plan["offset"][et], sizes[et[0]]
+            src = kqv[et[0]]
+            _lin(src[:, 0:F], wk, None, out=kv[o:o + n_s, 0:F])
+            _lin(src[:, 2 * F:3 * F], wv, None, out=kv[o:o + n_s, F:2 * F])
+        out = {}
+        for t in self.node_types:
+            if t not in self.dst_node_types or t not in x_dict:
+                continue
+            agg = ops.hgt_attention(kqv[t][:, F:2 * F], kv, plan["per_dst"][t], self.heads, apply_gelu=True)
+            lin = self.out_lin.lins[t]
+            if x_dict[t].shape[-1] == F:
+                a = self._skip_alpha(t)
+                out[t] = _lin(agg, lin.weight, lin.bias, alpha=a, residual=x_dict[t].float(), beta=1.0 - a)
+            else:
+                out[t] = _lin(agg, lin.weight, lin.bias)
+        return out
+
+
+class HGT(nn.Module):
+    """madrigal/models/models.py:71-96: HGTConv stack (ReLU only between convs i >= 1 and the last) + per-type Linear."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, num_heads, metadata, group='sum'):
+        super().__init__()
+        self.convs = nn.ModuleList([HGTConv(in_channels, hidden_channels, metadata, num_heads, group=group)])
+        for _ in range(num_layers - 1):
+            self.convs.append(HGTConv(hidden_channels, hidden_channels, metadata, num_heads, group=group))
+        self.lin_dict = nn.ModuleDict({t: nn.Linear(hidden_channels, out_channels) for t in metadata[0]})
+
+    def forward(self, x_dict, edge_index_dict):
+        out = self.convs[0](x_dict, edge_index_dict)
+        for i in range(1, len(self.convs)):
+            out = self.convs[i](out, edge_index_dict)
+            if i < len(self.convs) - 1:
+                out = {t: torch.relu_(x) for t, x in out.items()}
+        return {t: _lin(x, self.lin_dict[t].weight, self.lin_dict[t].bias) for t, x in out.items()}
+
+
+class HAN(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+        raise NotImplementedError("HAN (madrigal/models/models.py:41-67) is not used by any shipped config")
+
+
+class RGCN(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+        raise NotImplementedError("RGCN (madrigal/models/models.py:99-117) is not used by any shipped config")
+
+
+# ------------------------------------------------------------------------------------- chemCPA tx encoder
+class ChemCPAMLP(nn.Module):
+    """chemCPA ``MLP`` (madrigal/chemcpa/chemCPA/model.py:161-231): (Linear, BatchNorm1d, ReLU) x (n-1) + Linear."""
+
+    def __init__(self, sizes, batch_norm=True, last_layer_act="linear", append_layer_width=None, append_layer_position=None):
+        super().__init__()
+        if append_layer_width:
+            raise NotImplementedError("append_layer_width is not used by Madrigal (models.py:285,324)")
+        if last_layer_act != "linear":
+            raise NotImplementedError(last_layer_act)
+        layers = []
+        for s in range(len(sizes) - 1):
+            layers.append(nn.Linear(sizes[s], sizes[s + 1]))
+            if batch_norm and s < len(sizes) - 2:
+                layers.append(nn.BatchNorm1d(sizes[s + 1]))
+            layers.append(nn.ReLU())
+        layers = layers[:-1]
+        # indices must match the reference's Sequential (Linear 3k, BN 3k+1, ReLU 3k+2)
+        self.network = nn.Sequential(*layers)
+        self.activation = last_layer_act
+
+    def forward(self, x, residual=None):
+        _require_eval(self)
+        mods = list(self.network)
+        if residual is None:
+            return _run_sequential(self.network, x)
+        # fuse `+ residual` into the last Linear
+        x = _run_sequential(nn.Sequential(*mods[:-1]), x) if len(mods) > 1 else x
+        return _lin(x, mods[-1].weight, mods[-1].bias, residual=residual)
+
+
+class TxAdaptingComPert(nn.Module):
+    """Forward (``predict``) part of chemCPA's ComPert autoencoder as Madrigal uses it
+    (madrigal/chemcpa/chemCPA/model.py:290-519 constructor, :655-712 predict).  ``use_drugs=False`` only
+    (configs/chemcpa/chemcpa_finetune_configs.yaml:18); training (``update``), adversaries, dosers and
+    optimisers are outside the path."""
+
+    def __init__(self, num_genes: int, num_drugs: int, covariate_names_unique: Dict[str, List[str]], seed=0, patience=5,
+                 doser_type="logsigm", decoder_activation="linear", hparams="", drug_embeddings=None,
+                 append_layer_width=None, use_drugs=True, disable_adv=False, **kwargs):
+        super().__init__()
+        if use_drugs:
+            raise NotImplementedError("use_drugs=True (drug-embedding term of chemCPA) is not used by Madrigal's shipped configs")
+        if not isinstance(hparams, dict):
+            raise ValueError("hparams must be a dict (autoencoder_width, autoencoder_depth, dim)")
+        self.num_genes, self.num_drugs, self.covariate_names_unique = num_genes, num_drugs, covariate_names_unique
+        self.num_covariates = [len(v) for v in covariate_names_unique.values()]
+        assert 0 not in self.num_covariates
+        self.hparams, self.use_drugs, self.disable_adv = hparams, use_drugs, disable_adv
+        w, dpt, dim = hparams["autoencoder_width"], hparams["autoencoder_depth"], hparams["dim"]
+        self.encoder = ChemCPAMLP([num_genes] + [w] * dpt + [dim])
+        self.decoder = ChemCPAMLP([dim] + [w] * dpt + [num_genes * 2], last_layer_act=decoder_activation)
+        self.adversary_drugs = self.drug_embeddings = self.drug_embedding_encoder = self.dosers = None
+        self.covariates_embeddings = nn.ModuleList([nn.Embedding(n, dim) for n in self.num_covariates])
+
+    def predict(self, genes, drugs=None, drugs_idx=None, dosages=None, covariates=None, return_latent_basal=False,
+                return_latent_treated=False, compute_reconstruction=True, covariate_indices=None):
+        """Same outputs as the reference.  ``compute_reconstruction=False`` skips the decoder (62 % of
+        this block's flops) whose output Madrigal discards (models.py:761) and returns None in its slot;
+        ``covariate_indices`` may replace the one-hot ``covariates`` (the reference only takes argmax)."""
+        _require_eval(self)
+        assert (drugs is not None) or (drugs_idx is not None and dosages is not None)
+        if covariate_indices is None:
+            covariate_indices = [c.argmax(1) for c in covariates]
+        emb_sum = None
+        for emb, idx in zip(self.covariates_embeddings, covariate_indices):
+            e = emb.weight.detach().index_select(0, idx.to(emb.weight.device))
+            emb_sum = e if emb_sum is None else emb_sum + e
+        last_emb = e
+        need_basal = return_latent_basal or emb_sum is None
+        if need_basal:
+            latent_basal = self.encoder(genes)
+            latent_treated = latent_basal if emb_sum is None else self._add(latent_basal, emb_sum)
+        else:
+            latent_basal = None
+            latent_treated = self.encoder(genes, residual=emb_sum)          # + cov embedding fused in the epilogue
+        recon = None
+        if compute_reconstruction:
+            g = self.decoder(latent_treated)
+            dim = g.size(1) // 2
+            recon = torch.cat([g[:, :dim], torch.nn.functional.softplus(g[:, dim:])], dim=1)
+        out = (recon, last_emb)
+        if return_latent_basal:
+            out += (latent_basal,)
+        if return_latent_treated:
+            out += (latent_treated,)
+        return out
+
+    @staticmethod
+    def _add(a, b):
+        return a + b
+
+
+# ------------------------------------------------------------------------------------- encoder factories
+def _ckpt_dir():
+    return os.getenv("ENCODER_CKPT_DIR", "")
+
+
+def get_str_encoder(str_encoder_name, str_encoder_hparams, embed_dim, atom_dim, use_modality_pretrain=True):
+    """madrigal/models/models.py:213-232."""
+    if str_encoder_name != 'gin':
+        raise NotImplementedError(f"str encoder {str_encoder_name!r}: only 'gin' is on the path (GAT is unused by shipped configs)")
+    hp = str_encoder_hparams
+    enc = GraphIsomorphismNetwork(input_dim=atom_dim, hidden_dims=hp['gin_hidden_dims'] + [embed_dim],
+                                  edge_input_dim=hp['gin_edge_input_dim'], num_mlp_layer=hp['gin_num_mlp_layer'],
+                                  eps=hp['gin_eps'], batch_norm=hp['gin_batch_norm'], activation=hp['gin_actn'],
+                                  readout=hp['gin_readout'])
+    if use_modality_pretrain:
+        sd = torch.load(_ckpt_dir() + 'str/GIN_256x4_muv.pt', map_location='cpu')
+        clean = {}
+        for k, v in sd.items():
+            if k.startswith('model.'):
+                clean[k[len('model.'):]] = v
+            elif k.startswith('layer'):
+                clean[k] = v
+        enc.load_state_dict(clean)
+    return enc
+
+
+def get_kg_encoder(kg_encoder_name, kg_encoder_hparams, embed_dim, all_kg_data, use_modality_pretrain=True):
+    """madrigal/models/models.py:235-247."""
+    if 'hgt' not in kg_encoder_name:
+        raise NotImplementedError(f"kg encoder {kg_encoder_name!r}: only HGT is on the path")
+    hp = kg_encoder_hparams
+    enc = HGT(in_channels=all_kg_data.x_dict['drug'].shape[1], hidden_channels=hp['hgt_hidden_dim'], out_channels=embed_dim,
+              num_layers=hp['hgt_num_layers'], num_heads=hp['hgt_att_heads'], metadata=all_kg_data.metadata(),
+              group=hp['hgt_group'])
+    if use_modality_pretrain:
+        enc.load_state_dict(torch.load(_ckpt_dir() + 'kg/hgt_best.pt', map_location='cpu'))
+    return enc
+
+
+def get_tabular_mod_encoder(mod_encoder_name, mod_encoder_hparams, embed_dim, use_modality_pretrain=True, mod="cv"):
+    """madrigal/models/models.py:250-259."""
+    assert mod_encoder_name == 'mlp'
+    hp = mod_encoder_hparams
+    enc = MLPEncoder(hp['cv_input_dim'], hp['cv_mlp_hidden_dims'], embed_dim, hp['cv_mlp_dropout'], hp['cv_mlp_norm'],
+                     hp['cv_mlp_actn'], hp['cv_mlp_order'])
+    if use_modality_pretrain:
+        enc.load_state_dict(torch.load(_ckpt_dir() + f'{mod}/{mod}_model_ae.pt', map_location='cpu'))
+    return enc
+
+
+def get_tx_encoder(tx_encoder_name, tx_encoder_hparams, embed_dim, use_modality_pretrain=True):
+    """madrigal/models/models.py:262-348.  With ``use_drugs=False`` the frozen drug-embedding table the
+    reference builds from two external data files (:271-275) is never used, so it is not read here."""
+    if tx_encoder_name == 'mlp':
+        hp = tx_encoder_hparams
+        return MLPEncoder(hp['tx_input_dim'], hp['tx_mlp_hidden_dims'], embed_dim, hp['tx_mlp_dropout'], hp['tx_mlp_norm'],
+                          hp['tx_mlp_actn'], hp['tx_mlp_order'])
+    if tx_encoder_name != 'chemcpa':
+        raise NotImplementedError(tx_encoder_name)
+    m = tx_encoder_hparams["model"]
+    hparams, additional, use_drugs = m["hparams"], dict(m.get("additional_params", {})), m["use_drugs"]
+    num_drugs = int(m.get("num_drugs", 0))
+    if not use_modality_pretrain:
+        enc = TxAdaptingComPert(num_genes=TX_INPUT_DIM, num_drugs=num_drugs, covariate_names_unique={"cell_iname": CELL_LINES_CAPITALIZED},
+                                **additional, hparams=hparams, drug_embeddings=None, append_layer_width=None,
+                                use_drugs=use_drugs, disable_adv=True)
+        cell_lines = np.array([c.lower() for c in CELL_LINES_CAPITALIZED])
+        return enc, cell_lines
+    state_dict, _, cov_sds, model_config, _history = torch.load(_ckpt_dir() + f"tx/{m['pretrained_model_ckpt']}",
+                                                                map_location='cpu', weights_only=False)
+    assert model_config['use_drugs'] == use_drugs
+    assert len(cov_sds) == 1
+    for key in list(state_dict.keys()):
+        if key.startswith("adversary_") or key == "drug_embeddings.weight":
+            state_dict.pop(key)
+    for k in list(additional):
+        if k in model_config:
+            additional[k] = model_config[k]
+    enc = TxAdaptingComPert(num_genes=TX_INPUT_DIM, num_drugs=num_drugs, covariate_names_unique=model_config["covariate_names_unique"],
+                            **additional, hparams=model_config["hparams"], drug_embeddings=None, append_layer_width=None,
+                            use_drugs=use_drugs, disable_adv=True)
+    enc.load_state_dict(state_dict, strict=False)
+    for emb, sd in zip(enc.covariates_embeddings, cov_sds):
+        emb.load_state_dict(sd)
+    cell_lines = np.array([c.lower() for c in model_config["covariate_names_unique"]["cell_iname"]])
+    return enc, cell_lines
+
+
+# ------------------------------------------------------------------------------------- fusion
+class TransformerFusion(nn.Module):
+    """madrigal/models/models.py:352-455.  Holds a stock ``nn.TransformerEncoder`` / ``nn.MultiheadAttention``
+    ONLY for their parameters (identical state_dict keys; ``transformer_encoder.layers[-1].self_attn`` stays
+    a hook target, predict.py:643); the forward pass is mdg_linear / mdg_layernorm / mdg_fusion_attention /
+    mdg_xattn_pool.  Works batch-major internally; per-drug results do not depend on ``batch_first``."""
+
+    def __init__(self, embed_dim, num_tx_bottlenecks, transformer_num_layers, transformer_att_heads, transformer_head_dim,
+                 transformer_ffn_dim, transformer_dropout=0.1, transformer_actn='relu', transformer_norm_first=False,
+                 transformer_batch_first=True, transformer_agg='mean'):
+        super().__init__()
+        self.batch_first = transformer_batch_first
+        self.norm_first = transformer_norm_first
+        self.num_heads, self.head_dim = transformer_att_heads, transformer_head_dim
+        self.latent_dim = transformer_head_dim * transformer_att_heads
+        self.actn = transformer_actn
+        self.num_tx_bottlenecks = num_tx_bottlenecks
+        self.embed2latent = nn.Linear(embed_dim, self.latent_dim)
+        layer = nn.TransformerEncoderLayer(d_model=self.latent_dim, nhead=transformer_att_heads, dim_feedforward=transformer_ffn_dim,
+                                           dropout=transformer_dropout, activation=transformer_actn,
+                                           norm_first=transformer_norm_first, batch_first=transformer_batch_first)
+        self.transformer_encoder = nn.TransformerEncoder(layer, num_layers=transformer_num_layers, enable_nested_tensor=False)
+        self.latent2embed = nn.Linear(self.latent_dim, embed_dim)
+        self.transformer_agg = transformer_agg
+        if transformer_agg == 'x-attn':
+            self.x_attn_kv_norm = nn.LayerNorm(self.latent_dim)
+            self.x_attn_query_norm = nn.LayerNorm(self.latent_dim)
+            self.x_attn_mha_layer = nn.MultiheadAttention(embed_dim=self.latent_dim, num_heads=transformer_att_heads,
+                                                          dropout=transformer_dropout, batch_first=transformer_batch_first)
+            self.x_attn_dropout = nn.Dropout(transformer_dropout)
+            self.x_attn_query = nn.Parameter(torch.randn(1, self.latent_dim))
+            kpm = torch.zeros(1, NUM_MODALITIES + num_tx_bottlenecks, dtype=torch.bool)
+            if num_tx_bottlenecks > 0:           # only the bottleneck tokens are keys (models.py:382-385)
+                kpm[:, :NUM_NON_TX_MODALITIES] = True
+                kpm[:, -len(CELL_LINES):] = True
+            self.x_attn_key_padding_mask = kpm
+        self.last_attention_weights = None
+
+    def forward(self, fusion_sequence, fusion_mask, src_mask=None):
+        """fusion_sequence [n,S,D] (batch-major, as the encoder passes it), fusion_mask bool [n,S]
+        (True = padding), src_mask bool [S,S] (True = not allowed) -> [n,D]."""
+        _require_eval(self)
+        n, S, D = fusion_sequence.shape
+        d, H, dh = self.latent_dim, self.num_heads, self.head_dim
+        kbits = None if fusion_mask is None else ops.mask_bits(fusion_mask)
+        sbits = None if src_mask is None else ops.mask_bits(src_mask)
+        h = _lin(fusion_sequence.reshape(n * S, D), self.embed2latent.weight, self.embed2latent.bias)
+        layers = self.transformer_encoder.layers
+        probs = None
+        for li, L in enumerate(layers):
+            want = li == len(layers) - 1
+            sa = L.self_attn
+            if self.norm_first:
+                a = ops.layernorm(h, L.norm1.weight, L.norm1.bias, L.norm1.eps)
+                qkv = _lin(a, sa.in_proj_weight, sa.in_proj_bias)
+                att, pr = ops.fusion_attention(qkv, n, S, H, dh, kbits, sbits, want_probs=want)
+                h = _lin(att, sa.out_proj.weight, sa.out_proj.bias, residual=h)
+                f = ops.layernorm(h, L.norm2.weight, L.norm2.bias, L.norm2.eps)
+                u = _lin(f, L.linear1.weight, L.linear1.bias, act=self.actn)
+                h = _lin(u, L.linear2.weight, L.linear2.bias, residual=h)
+            else:
+                qkv = _lin(h, sa.in_proj_weight, sa.in_proj_bias)
+                att, pr = ops.fusion_attention(qkv, n, S, H, dh, kbits, sbits, want_probs=want)
+                t = _lin(att, sa.out_proj.weight, sa.out_proj.bias, residual=h)
+                h = ops.layernorm(t, L.norm1.weight, L.norm1.bias, L.norm1.eps)
+                u = _lin(h, L.linear1.weight, L.linear1.bias, act=self.actn)
+                t = _lin(u, L.linear2.weight, L.linear2.bias, residual=h)
+                h = ops.layernorm(t, L.norm2.weight, L.norm2.bias, L.norm2.eps)
+            if want:
+                probs = pr
+                for hook in list(sa._forward_hooks.values()):       # analysis hooks expect (attn_out, weights)
+                    hook(sa, (a if self.norm_first else h,), (att, pr))
+        self.last_attention_weights = probs
+        agg = self.transformer_agg
+        if agg == 'x-attn':
+            mha = self.x_attn_mha_layer
+            keys = (~self.x_attn_key_padding_mask[0]).nonzero().flatten().tolist()
+            Tk = len(keys)
+            h3 = h.view(n, S * d)
+            kvn = torch.empty((n, Tk * d), dtype=torch.float32, device=h.device)
+            for t, s in enumerate(keys):                             # LayerNorm of the key tokens only
+                ops.layernorm(h3[:, s * d:(s + 1) * d], self.x_attn_kv_norm.weight, self.x_attn_kv_norm.bias,
+                              self.x_attn_kv_norm.eps, out=kvn[:, t * d:(t + 1) * d])
+            w, b = mha.in_proj_weight.detach(), mha.in_proj_bias.detach()
+            kvp = _lin(kvn.view(n * Tk, d), w[d:], b[d:])            # [n*Tk, 2d] = K|V
+            q = self.x_attn_query.detach()
+            if self.norm_first:
+                q = ops.layernorm(q, self.x_attn_query_norm.weight, self.x_attn_query_norm.bias, self.x_attn_query_norm.eps)
+            qp = _lin(q, w[:d], b[:d])
+            pooled = ops.xattn_pool(qp, kvp, n, Tk, H, dh)
+            o = _lin(pooled, mha.out_proj.weight, mha.out_proj.bias, residual=q.reshape(-1))      # + query (broadcast)
+            if not self.norm_first:
+                o = ops.layernorm(o, self.x_attn_query_norm.weight, self.x_attn_query_norm.bias, self.x_attn_query_norm.eps)
+            return _lin(o, self.latent2embed.weight, self.latent2embed.bias)
+        if agg == 'cls':
+            return _lin(h.view(n, S * d)[:, :d], self.latent2embed.weight, self.latent2embed.bias)
+        if agg in ('mean', 'max'):
+            e = _lin(h, self.latent2embed.weight, self.latent2embed.bias).view(n, S, -1)
+            return ops.token_pool(e, kbits, agg)
+        raise NotImplementedError(agg)
+
+
+# ------------------------------------------------------------------------------------- decoder
+class Symmetric(nn.Module):
+    """madrigal/models/models.py:522-524 (parametrisation registered at :922)."""
+
+    def forward(self, W):
+        if W.is_cuda and not (torch.is_grad_enabled() and W.requires_grad):
+            return ops.symmetrize(W if W.dim() == 3 else W.unsqueeze(0)).view_as(W)
+        return W.triu() + W.triu(1).transpose(-1, -2)      # parameter materialisation off the GPU (state_dict tools)
+
+
+class BilinearDDIScorer(nn.Bilinear):
+    """madrigal/models/models.py:526-547: S[l,i,j] = input1[i]^T W[l] input2[j] -> [L', n1, n2] raw logits,
+    optional ``label_range`` slice of the outcomes.  ``bias`` exists in the state_dict and is unused, as in
+    the reference."""
+
+    def __init__(self, input_dim1: int, input_dim2: int, output_dim: int):
+        super().__init__(in1_features=input_dim1, in2_features=input_dim2, out_features=output_dim)
+        self._sym_cache = None
+
+    def symmetric_weight(self) -> torch.Tensor:
+        """W_sym on the device, recomputed only when the underlying parameter changes (the reference
+        re-runs triu/transpose on every forward)."""
+        if hasattr(self, "parametrizations") and "weight" in self.parametrizations:
+            w = self.parametrizations.weight.original
+            key = (w.data_ptr(), w._version, str(w.device))
+            if self._sym_cache is None or self._sym_cache[0] != key:
+                self._sym_cache = (key, ops.symmetrize(w.detach()))
+            return self._sym_cache[1]
+        return self.weight.detach()
+
+    def bilinear(self, input1, input2, weight, epilogue=ops.EPI_STORE, out=None):
+        ops.forward_only(input1, input2)
+        return ops.bilinear_allpairs(input1, input2, weight, precision=_state["precision"], epilogue=epilogue, out=out)
+
+    def forward(self, input1, input2, label_range: tuple = None, epilogue=ops.EPI_STORE, out=None):
+        w = self.symmetric_weight()
+        if label_range is not None:
+            assert len(label_range) == 2
+            w = w[label_range[0]:label_range[1]]
+        return self.bilinear(input1, input2, w, epilogue, out)
+
+
+# ------------------------------------------------------------------------------------- position encodings
+class PositionEncodingSinusoidal(nn.Module):
+    """madrigal/models/models.py:551-587.  Inside NovelDDIEncoder the table is added by mdg_assemble_tokens."""
+
+    def __init__(self, d_model: int, dropout: float = 0.1, max_len: int = 19, num_tx_bottlenecks: int = 0, transformer_agg: str = 'cls'):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        position = torch.arange(max_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+        pe = torch.zeros(1, max_len, d_model)
+        pe[0, :, 0::2] = torch.sin(position * div_term)
+        pe[0, :, 1::2] = torch.cos(position * div_term)
+        if num_tx_bottlenecks > 0:
+            seq = NUM_MODALITIES + num_tx_bottlenecks + (1 if transformer_agg == 'cls' else 0)
+            full = torch.zeros(1, seq, d_model)
+            full[:, :max_len] = pe
+            pe = full
+        self.register_buffer('pe', pe)
+
+    def table(self):
+        return self.pe[0]
+
+    def forward(self, x):
+        _require_eval(self)
+        return x + self.pe
+
+
+class PositionEncodingLearnable(nn.Module):
+    """madrigal/models/models.py:590-603."""
+
+    def __init__(self, d_model: int, dropout: float = 0.1, max_len: int = 19, num_tx_bottlenecks: int = 0, transformer_agg: str = 'cls'):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        self.max_len = max_len
+        self.pe = nn.Parameter(torch.randn(1, max_len, d_model))
+
+    def table(self):
+        return self.pe.detach()[0]
+
+    def forward(self, x):
+        _require_eval(self)
+        x = x.clone()
+        x[:, :self.max_len, :] += self.pe.detach()
+        return x
+
+
+# ------------------------------------------------------------------------------------- the encoder
+class NovelDDIEncoder(nn.Module):
+    """madrigal/models/models.py:607-899: four modality encoders -> token assembly (bottleneck tokens,
+    masks, position encoding) -> transformer fusion (+ the uni-modal projector branch)."""
+
+    def __init__(self, all_kg_data, feat_dim, str_encoder_name, str_encoder_hparams, kg_encoder_name, kg_encoder_hparams,
+                 cv_encoder_name, cv_encoder_hparams, tx_encoder_name, tx_encoder_hparams, num_tx_bottlenecks, pos_emb_dropout,
+                 transformer_fusion_hparams, proj_hparams, fusion='transformer_uni_proj', str_node_feat_dim=MOL_DIM,
+                 use_modality_pretrain=True, normalize=False, pos_emb_type='learnable', adapt_before_fusion=False, **kwargs):
+        super().__init__()
+        if NUM_NON_TX_MODALITIES != 3:
+            raise NotImplementedError("extra tabular modalities (NON_TX_MODALITIES env override) are outside the path")
+        self.embed_dim, self.fusion, self.normalize = feat_dim, fusion, normalize
+        self.adapt_before_fusion = adapt_before_fusion
+        self.use_tx_basal = kwargs.get('use_tx_basal', False)
+        self.str_encoder = get_str_encoder(str_encoder_name, str_encoder_hparams, feat_dim, str_node_feat_dim, use_modality_pretrain)
+        self.kg_encoder_name = kg_encoder_name
+        self.kg_encoder = get_kg_encoder(kg_encoder_name, kg_encoder_hparams, feat_dim, all_kg_data, use_modality_pretrain)
+        self.cv_encoder = get_tabular_mod_encoder(cv_encoder_name, cv_encoder_hparams, feat_dim, use_modality_pretrain, mod="cv")
+        self.tabular_mod_encoders = nn.ModuleDict()
+        if tx_encoder_name == 'mlp':
+            self.tx_encoder_dict = nn.ModuleDict({c: get_tx_encoder(tx_encoder_name, tx_encoder_hparams, feat_dim, False) for c in CELL_LINES})
+        elif tx_encoder_name == 'chemcpa':
+            self.tx_encoder_dict = None
+            self.tx_encoder, cell_lines = get_tx_encoder(tx_encoder_name, tx_encoder_hparams, feat_dim, use_modality_pretrain)
+            self.set_cell_line_categories(cell_lines)
+        else:
+            raise NotImplementedError(tx_encoder_name)
+        self.num_tx_bottlenecks = num_tx_bottlenecks
+        self.transformer_agg = transformer_fusion_hparams['transformer_agg']
+        self.transformer_att_heads = transformer_fusion_hparams['transformer_att_heads']
+        pos_emb_max_len = NUM_MODALITIES if num_tx_bottlenecks == 0 else NUM_NON_TX_MODALITIES
+        if self.transformer_agg == 'cls':
+            pos_emb_max_len += 1
+        if num_tx_bottlenecks > 0:
+            self.tx_bottleneck_tokens = nn.Parameter(torch.randn(num_tx_bottlenecks, feat_dim))
+        cls_ = {'learnable': PositionEncodingLearnable, 'sinusoidal': PositionEncodingSinusoidal}.get(pos_emb_type)
+        if cls_ is None:
+            raise NotImplementedError(pos_emb_type)
+        self.pos_encoder = cls_(d_model=feat_dim, dropout=pos_emb_dropout, max_len=pos_emb_max_len,
+                                num_tx_bottlenecks=num_tx_bottlenecks, transformer_agg=self.transformer_agg)
+        self.transformer = TransformerFusion(feat_dim, num_tx_bottlenecks, **transformer_fusion_hparams)
+        if self.transformer_agg == 'cls':
+            self.cls = nn.Parameter(torch.randn(1, feat_dim))
+        ph = proj_hparams
+        self.uni_projector = MLPAdaptor(feat_dim, ph['proj_hidden_dims'], feat_dim, ph['proj_dropout'], ph['proj_norm'], ph['proj_actn'], ph['proj_order'])
+        if fusion == 'transformer_uni_proj':
+            self.uni_fuser = MLPAdaptor(feat_dim, ph['proj_hidden_dims'], feat_dim, ph['proj_dropout'], ph['proj_norm'], ph['proj_actn'], ph['proj_order'])
+
+    def set_cell_line_categories(self, cell_lines_lowercase) -> None:
+        """Category order of the reference's sklearn OneHotEncoder (sorted unique names, models.py:648-649)."""
+        cats = sorted(set(str(c) for c in cell_lines_lowercase))
+        self._cell_line_index = {c: i for i, c in enumerate(cats)}
+
+    # -- encoders ---------------------------------------------------------------------------
+    def _encode_tx(self, batch_tx_dict, n: int, device) -> torch.Tensor:
+        """[16*n, D] cell-line-major tx embeddings (models.py:753-769)."""
+        if self.tx_encoder_dict is not None:
+            return torch.cat([self.tx_encoder_dict[c](batch_tx_dict[c]['sigs']) for c in CELL_LINES], dim=0)
+        sigs = torch.cat([batch_tx_dict[c]['sigs'] for c in CELL_LINES], dim=0)
+        drugs = torch.cat([batch_tx_dict[c]['drugs'] for c in CELL_LINES], dim=0)
+        dos = torch.cat([batch_tx_dict[c]['dosages'] for c in CELL_LINES], dim=0)
+        idx = []
+        for c in CELL_LINES:
+            names = np.asarray(batch_tx_dict[c]['cell_lines'])
+            first = str(names[0]) if names.size else c
+            if names.size and not np.all(names == names[0]):
+                idx.append(torch.tensor([self._cell_line_index[str(s)] for s in names], dtype=torch.int64))
+            else:
+                idx.append(torch.full((names.size,), self._cell_line_index[first], dtype=torch.int64))
+        cov = torch.cat(idx).to(device)
+        out = self.tx_encoder.predict(genes=sigs, drugs_idx=drugs, dosages=dos, covariates=None, covariate_indices=[cov],
+                                      return_latent_basal=self.use_tx_basal, return_latent_treated=(not self.use_tx_basal),
+                                      compute_reconstruction=False)
+        return out[2]
+
+    def encode(self, batch_drugs, batch_masks, batch_mols, batch_kg, batch_cv, batch_tx_dict, raw_encoder_output=False, **kwargs):
+        _require_eval(self)
+        dev = batch_cv.device
+        n, Dm = batch_drugs.shape[0], self.embed_dim
+        str_out = self.str_encoder(batch_mols, batch_mols.node_feature.float())["graph_feature"]
+        kg_data, kg_map = batch_kg['data'], batch_kg['drug_index_map']
+        kg_valid = self.kg_encoder(kg_data.x_dict, kg_data.edge_index_dict)['drug']
+        # drugs absent from the KG get filler rows that are always masked (models.py:734-736); the size of the
+        # table needs the largest drug id (the reference's .item() syncs here as well)
+        filler = kwargs.get('kg_filler')
+        if filler is None:
+            rows = max(int(batch_drugs.max().item()) + 1, int(kg_map.max().item()) + 1)
+            filler = torch.randn((rows, Dm), device=dev)
+        kg_table = filler.to(dev).clone()
+        kg_table[kg_map] = kg_valid
+        kg_out = kg_table[batch_drugs]
+        cv_out = self.cv_encoder(batch_cv)
+        tx_out = self._encode_tx(batch_tx_dict, n, dev)                                    # [16n, D]
+        if raw_encoder_output:
+            all_embeds = torch.stack([str_out, kg_out, cv_out] + list(tx_out.split(n)), dim=1)
+            uni = all_embeds[~batch_masks]
+            if self.normalize:
+                uni = ops.l2_normalize(uni)
+            return self.uni_projector(uni)
+        if self.adapt_before_fusion:
+            str_out, kg_out, cv_out, tx_out = (self.uni_projector(t) for t in (str_out, kg_out, cv_out, tx_out))
+        if self.fusion in ('mean', 'add'):
+            all_embeds = torch.stack([str_out, kg_out, cv_out] + list(tx_out.split(n)), dim=1)
+            if self.normalize:
+                all_embeds = ops.l2_normalize(all_embeds)
+            return ops.token_pool(all_embeds, ops.mask_bits(batch_masks), 'mean' if self.fusion == 'mean' else 'sum')
+        if self.fusion not in ('transformer', 'transformer_uni_proj'):
+            raise NotImplementedError(self.fusion)
+        rows, uni_rows = None, None
+        masks_f = batch_masks
+        if self.fusion == 'transformer_uni_proj':
+            avail = (~batch_masks).sum(dim=1)
+            assert bool(torch.all(avail > 0))
+            multi = avail > 1
+            rows = multi.nonzero().flatten()
+            uni_rows = (~multi).nonzero().flatten()
+            masks_f = batch_masks[rows]
+        nb = self.num_tx_bottlenecks
+        has_cls = self.transformer_agg == 'cls'
+        seq = ops.assemble_tokens(str_out, kg_out, cv_out, tx_out, bottleneck=self.tx_bottleneck_tokens if nb > 0 else None,
+                                  cls=self.cls if has_cls else None, pe=self.pos_encoder.table(), rows=rows,
+                                  normalize=self.normalize)
+        nf = seq.shape[0]
+        parts = []
+        if has_cls:
+            parts.append(torch.zeros(nf, 1, dtype=torch.bool, device=dev))
+        parts.append(masks_f[:, :NUM_NON_TX_MODALITIES])
+        if nb > 0:
+            parts.append(torch.zeros(nf, nb, dtype=torch.bool, device=dev))
+        parts.append(masks_f[:, NUM_NON_TX_MODALITIES:])
+        kpm = torch.cat(parts, dim=1)
+        src = None
+        if nb > 0:                                       # non-TX tokens and TX tokens only meet through the bottleneck
+            S0 = NUM_MODALITIES + nb
+            src = torch.zeros(S0, S0, dtype=torch.bool, device=dev)
+            src[:NUM_NON_TX_MODALITIES, -len(CELL_LINES):] = True
+            src[-len(CELL_LINES):, :NUM_NON_TX_MODALITIES] = True
+            if has_cls:
+                full = torch.zeros(S0 + 1, S0 + 1, dtype=torch.bool, device=dev)
+                full[1:, 1:] = src
+                src = full
+        z_f = self.transformer(seq, fusion_mask=kpm, src_mask=src) if nf > 0 else torch.zeros(0, Dm, device=dev)
+        if self.fusion != 'transformer_uni_proj':
+            return z_f
+        z = torch.empty((n, Dm), dtype=torch.float32, device=dev)
+        z[rows] = z_f
+        if uni_rows.numel() > 0:
+            col = (~batch_masks[uni_rows]).to(torch.int64).argmax(dim=1)      # the single available modality
+            all_embeds = torch.stack([str_out, kg_out, cv_out] + list(tx_out.split(n)), dim=1)
+            uni = all_embeds[uni_rows, col]
+            if self.normalize:
+                uni = ops.l2_normalize(uni)
+            z[uni_rows] = self.uni_fuser(uni)
+        return z
+
+    def forward(self, batch_drugs, batch_masks, batch_mols, batch_kg, batch_cv, batch_tx_dict, raw_encoder_output=False, **kwargs):
+        return self.encode(batch_drugs, batch_masks, batch_mols, batch_kg, batch_cv, batch_tx_dict, raw_encoder_output, **kwargs)
+
+
+class NovelDDIMultilabel(nn.Module):
+    """madrigal/models/models.py:914-953: encoder on both sides + symmetric bilinear head -> raw logits [L,Nh,Nt]."""
+
+    def __init__(self, encoder, feat_dim, prediction_dim, prediction_dim_single_drug=None, normalize=False, use_single_drug=False):
+        super().__init__()
+        self.encoder = encoder
+        self.embed_dim = feat_dim
+        self.normalize = normalize
+        self.use_single_drug = use_single_drug
+        self.decoder = BilinearDDIScorer(feat_dim, feat_dim, prediction_dim)
+        nn.utils.parametrize.register_parametrization(self.decoder, 'weight', Symmetric())
+        # the reference encodes head and tail separately even when they are the same object (full-batch mode,
+        # train_ddi_batch.py:285); in eval mode the two results are identical, so one pass is reused.
+        self.reuse_identical_sides = True
+
+    def forward(self, batch_head, batch_tail, batch_head_mod_masks, batch_tail_mod_masks, batch_kg, label_range=None,
+                single_drug=False, **kwargs):
+        def enc(b, m):
+            return self.encoder(b['drugs'], m, b['strs'], batch_kg, b['cv'], b['tx'], **kwargs)
+        z_head = enc(batch_head, batch_head_mod_masks)
+        same = self.reuse_identical_sides and batch_head is batch_tail and (
+            batch_head_mod_masks is batch_tail_mod_masks or torch.equal(batch_head_mod_masks, batch_tail_mod_masks))
+        z_tail = z_head if same else enc(batch_tail, batch_tail_mod_masks)
+        if self.normalize:
+            z_head = ops.l2_normalize(z_head)
+            z_tail = z_head if same else ops.l2_normalize(z_tail)
+        return self.decoder(z_head, z_tail, label_range)

@@ -109,3 +109,234 @@ def bilinear_allpairs(z_head: torch.Tensor, z_tail: torch.Tensor, w_sym: torch.T
                                        _c64(D), prec, int(epilogue), _ptr(ws), ctypes.c_size_t(nbytes), _stream(zh)),
               "mdg_bilinear_allpairs")
     return out
+
+
+# ------------------------------------------------------------------------------- dense blocks
+ACTS = {None: 0, "none": 0, "relu": 1, "gelu": 2, "sigmoid": 3, "tanh": 4, "leakyrelu": 5, "softplus": 6, "selu": 7}
+_c = ctypes.c_int
+_f = ctypes.c_float
+
+_pad_cache = {}
+
+
+def forward_only(*tensors) -> None:
+    """The HIP ops are forward-only in this release: refuse to run under autograd rather than
+    silently return tensors that do not carry gradients."""
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
+        raise RuntimeError("madrigal_amd HIP ops are forward-only: call the model under torch.no_grad() "
+                           "(backward kernels are not part of this release)")
+
+
+def _pad_last(t: torch.Tensor, mult: int = 4) -> torch.Tensor:
+    k = t.shape[-1]
+    if k % mult == 0:
+        return t
+    return torch.nn.functional.pad(t, (0, mult - k % mult))
+
+
+def padded_weight(w: torch.Tensor) -> torch.Tensor:
+    """nn.Linear weight [N,K] with K zero-padded to a multiple of 4; cached per (storage, version)."""
+    if w.shape[-1] % 4 == 0 and w.is_contiguous():
+        return w.detach()
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = _pad_cache.get(id(w))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    p = _pad_last(w.detach()).contiguous()
+    _pad_cache[id(w)] = (key, p)
+    return p
+
+
+def _rows2d(x: torch.Tensor, name: str):
+    """[..., K] fp32 cuda tensor -> (2-D view/copy with unit inner stride and ld % 4 == 0, leading shape)."""
+    x = _f32_cuda(x, name)
+    lead = tuple(x.shape[:-1])
+    return x.reshape(-1, x.shape[-1]), lead
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, scale=None, shift=None,
+           act=None, residual: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 1.0,
+           precision="bf16x3", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = alpha * act((x W^T + b) * scale + shift) + beta * residual   (nn.Linear layout W [N,K]).
+
+    ``x`` may be a strided 2-D view (row stride a multiple of 4); ``residual`` may be [N] / [1,N]
+    (broadcast over rows) or [M,N]."""
+    forward_only(x, weight, bias, residual)
+    if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.shape[1] % 4 == 0 and x.data_ptr() % 16 == 0 \
+            and x.is_cuda and x.dtype == torch.float32:
+        x2, lead = x, (x.shape[0],)
+    else:
+        x2, lead = _rows2d(x, "x")
+        if x2.shape[1] % 4:
+            x2 = _pad_last(x2)
+    w = padded_weight(_f32_cuda(weight, "weight", 2))
+    M, K, N = x2.shape[0], x2.shape[1], w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"linear: x has inner dim {x.shape[-1]} but weight is {tuple(weight.shape)}")
+    if act not in ACTS:
+        raise ValueError(f"unknown activation {act!r}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+    elif out.dim() != 2 or out.shape != (M, N) or out.stride(1) != 1 or out.dtype != torch.float32 or not out.is_cuda:
+        raise ValueError(f"out: expected fp32 cuda [{M},{N}] with unit inner stride")
+    ldr = 0
+    if residual is not None:
+        residual = _f32_cuda(residual, "residual") if residual.is_contiguous() else residual
+        if residual.numel() == N:
+            ldr = 0
+        else:
+            if residual.dim() != 2:
+                residual = residual.reshape(-1, N)
+            if residual.shape != (M, N) or residual.stride(1) != 1:
+                raise ValueError(f"residual: expected [{M},{N}] or [{N}], got {tuple(residual.shape)}")
+            ldr = residual.stride(0)
+    for nm, t in (("bias", bias), ("scale", scale), ("shift", shift)):
+        if t is not None and (t.numel() != N or not t.is_cuda or t.dtype != torch.float32):
+            raise ValueError(f"{nm}: expected fp32 cuda [{N}]")
+    check(lib().mdg_linear(_ptr(x2), _c64(x2.stride(0)), _ptr(w), _c64(w.stride(0)), _ptr(out), _c64(out.stride(0)),
+                           _c64(M), _c64(N), _c64(K), _ptr(None if bias is None else bias.detach().contiguous()),
+                           _ptr(None if scale is None else scale.contiguous()), _ptr(None if shift is None else shift.contiguous()),
+                           _c(ACTS[act]), _ptr(residual), _c64(ldr), _f(alpha), _f(beta), _c(_prec(precision)), _stream(x2)),
+          "mdg_linear")
+    return out.view(*lead, N) if len(lead) != 1 or lead[0] != M else out
+
+
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Row-wise LayerNorm over the last dim; ``x`` / ``out`` may be strided 2-D views (row stride % 4 == 0)."""
+    forward_only(x, weight, bias)
+    if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.is_cuda and x.dtype == torch.float32:
+        x2, lead = x, None
+    else:
+        x2, lead = _rows2d(x, "x")
+    R, d = x2.shape
+    if out is None:
+        out = torch.empty((R, d), dtype=torch.float32, device=x2.device)
+    check(lib().mdg_layernorm(_ptr(x2), _c64(x2.stride(0)), _ptr(weight.detach().contiguous()), _ptr(bias.detach().contiguous()),
+                              _ptr(out), _c64(out.stride(0)), _c64(R), _c64(d), _f(eps), _stream(x2)), "mdg_layernorm")
+    return out.view(*lead, d) if lead is not None and out.is_contiguous() else out
+
+
+# ------------------------------------------------------------------------------- fusion
+def mask_bits(mask: torch.Tensor) -> torch.Tensor:
+    """bool [..., S] (True = masked) -> uint32-valued int32 [...] bit field, bit j = mask[..., j]."""
+    S = mask.shape[-1]
+    if S > 32:
+        raise ValueError("at most 32 tokens")
+    w = (torch.ones(S, dtype=torch.int64, device=mask.device) << torch.arange(S, device=mask.device))
+    return (mask.to(torch.int64) * w).sum(-1).to(torch.int32).contiguous()     # two's complement keeps bit 31
+
+
+def assemble_tokens(str_emb, kg_emb, cv_emb, tx_emb, *, bottleneck=None, cls=None, pe=None, rows=None,
+                    normalize=False) -> torch.Tensor:
+    """[n, S, 128] token sequence (see mdg_assemble_tokens).  tx_emb is [16*n_src,128], cell-line major."""
+    forward_only(str_emb, kg_emb, cv_emb, tx_emb, bottleneck, cls, pe)
+    s, k, c, t = (_f32_cuda(a, nm, 2) for a, nm in ((str_emb, "str"), (kg_emb, "kg"), (cv_emb, "cv"), (tx_emb, "tx")))
+    n_src = s.shape[0]
+    if k.shape != s.shape or c.shape != s.shape or t.shape != (16 * n_src, s.shape[1]):
+        raise ValueError("assemble_tokens: modality embeddings disagree in shape")
+    n = n_src if rows is None else int(rows.numel())
+    nb = 0 if bottleneck is None else int(bottleneck.shape[0])
+    pe2 = None if pe is None else _f32_cuda(pe.detach().reshape(-1, pe.shape[-1]), "pe")
+    S = (1 if cls is not None else 0) + 3 + nb + 16
+    seq = torch.empty((n, S, s.shape[1]), dtype=torch.float32, device=s.device)
+    check(lib().mdg_assemble_tokens(_ptr(s), _ptr(k), _ptr(c), _ptr(t),
+                                    _ptr(None if bottleneck is None else bottleneck.detach().contiguous()),
+                                    _ptr(None if cls is None else cls.detach().contiguous()), _ptr(pe2),
+                                    _ptr(None if rows is None else rows.contiguous()), _ptr(seq), _c64(n), _c64(n_src), _c(nb),
+                                    _c(0 if cls is None else 1), _c(0 if pe2 is None else pe2.shape[0]), _c(1 if normalize else 0),
+                                    _c64(s.shape[1]), _stream(s)), "mdg_assemble_tokens")
+    return seq
+
+
+def fusion_attention(qkv: torch.Tensor, n: int, S: int, H: int, dh: int, kpm_bits=None, src_bits=None,
+                     want_probs: bool = False):
+    """Self-attention core over [n*S, 3*H*dh] q|k|v rows -> ([n*S, H*dh], probs [n,H,S,S] | None)."""
+    qkv = _f32_cuda(qkv, "qkv", 2)
+    d = H * dh
+    if qkv.shape != (n * S, 3 * d):
+        raise ValueError(f"qkv: expected [{n * S},{3 * d}], got {tuple(qkv.shape)}")
+    out = torch.empty((n * S, d), dtype=torch.float32, device=qkv.device)
+    probs = torch.empty((n, H, S, S), dtype=torch.float32, device=qkv.device) if want_probs else None
+    check(lib().mdg_fusion_attention(_ptr(qkv), _c64(qkv.stride(0)), _ptr(out), _c64(d), _ptr(kpm_bits), _ptr(src_bits), _ptr(probs),
+                                     _c64(n), _c(S), _c(H), _c(dh), _stream(qkv)), "mdg_fusion_attention")
+    return out, probs
+
+
+def xattn_pool(q_proj: torch.Tensor, kv_proj: torch.Tensor, n: int, Tk: int, H: int, dh: int) -> torch.Tensor:
+    q = _f32_cuda(q_proj.reshape(-1), "q_proj", 1)
+    kv = _f32_cuda(kv_proj, "kv_proj", 2)
+    d = H * dh
+    if q.numel() != d or kv.shape != (n * Tk, 2 * d):
+        raise ValueError(f"xattn_pool: expected q [{d}] and kv [{n * Tk},{2 * d}]")
+    out = torch.empty((n, d), dtype=torch.float32, device=kv.device)
+    check(lib().mdg_xattn_pool(_ptr(q), _ptr(kv), _c64(kv.stride(0)), _ptr(out), _c64(d), _c64(n), _c(Tk), _c(H), _c(dh), _stream(kv)),
+          "mdg_xattn_pool")
+    return out
+
+
+# ------------------------------------------------------------------------------- graphs
+def csr_aggregate(x: torch.Tensor, rowptr: torch.Tensor, col: Optional[torch.Tensor] = None, *, edge_weight=None,
+                  x_self: Optional[torch.Tensor] = None, self_coef_dev: Optional[torch.Tensor] = None,
+                  self_coef_add: float = 0.0, mean: bool = False) -> torch.Tensor:
+    """out[v] = (self_coef_add + self_coef_dev[0]) * x_self[v] + sum_{e in row v} w[e] * x[col[e]]  (see the C header)."""
+    forward_only(x, x_self)
+    x = _f32_cuda(x, "x", 2)
+    if x.shape[1] % 4:
+        x = _pad_last(x)
+    F = x.shape[1]
+    n_dst = int(rowptr.numel()) - 1
+    if rowptr.dtype != torch.int64 or (col is not None and col.dtype != torch.int64):
+        raise ValueError("rowptr / col must be int64")
+    if x_self is not None:
+        x_self = _f32_cuda(x_self, "x_self", 2)
+        if x_self.shape[1] % 4:
+            x_self = _pad_last(x_self)
+        if x_self.shape != (n_dst, F):
+            raise ValueError("x_self: shape mismatch")
+    out = torch.empty((n_dst, F), dtype=torch.float32, device=x.device)
+    check(lib().mdg_csr_aggregate(_ptr(x), _c64(x.stride(0)), _ptr(rowptr.contiguous()), _ptr(None if col is None else col.contiguous()),
+                                  _ptr(None if edge_weight is None else edge_weight.contiguous()), _ptr(x_self),
+                                  _c64(0 if x_self is None else x_self.stride(0)), _ptr(self_coef_dev), _f(self_coef_add),
+                                  _c(1 if mean else 0), _ptr(out), _c64(F), _c64(n_dst), _c64(F), _stream(x)), "mdg_csr_aggregate")
+    return out
+
+
+def hgt_attention(q: torch.Tensor, kv: torch.Tensor, plan: dict, heads: int, apply_gelu: bool = True) -> torch.Tensor:
+    """Edge softmax + aggregation for one destination node type.  ``q`` may be a column-slice view
+    [n_dst,128] of the k|q|v projection; ``plan`` holds col / item_* / item_ptr (see graph_plans)."""
+    n_dst = q.shape[0]
+    if q.dim() != 2 or q.shape[1] != 128 or q.stride(1) != 1 or not q.is_cuda or q.dtype != torch.float32:
+        raise ValueError("q: expected fp32 cuda [n_dst,128] with unit inner stride")
+    out = torch.empty((n_dst, 128), dtype=torch.float32, device=q.device)
+    n_items = int(plan["item_dst"].numel())
+    nbytes = lib().mdg_hgt_attention_workspace_bytes(_c64(n_items), _c(heads))
+    ws = _workspace(nbytes, q.device)
+    check(lib().mdg_hgt_attention(_ptr(q), _c64(q.stride(0)), _ptr(kv), _c64(0 if kv is None else kv.stride(0)), _ptr(plan["col"]),
+                                  _ptr(plan["item_dst"]), _ptr(plan["item_begin"]), _ptr(plan["item_end"]), _c64(n_items),
+                                  _ptr(plan["item_ptr"]), _ptr(out), _c64(128), _c64(n_dst), _c(heads), _c64(128),
+                                  _c(1 if apply_gelu else 0), _ptr(ws), ctypes.c_size_t(nbytes), _stream(q)), "mdg_hgt_attention")
+    return out
+
+
+def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+    """F.normalize(x, p=2, dim=-1)."""
+    forward_only(x)
+    x2, lead = _rows2d(x, "x")
+    if x2.shape[1] % 4:
+        raise ValueError("l2_normalize: last dim must be a multiple of 4")
+    y = torch.empty_like(x2)
+    check(lib().mdg_l2_normalize(_ptr(x2), _c64(x2.stride(0)), _ptr(y), _c64(y.stride(0)), _c64(x2.shape[0]), _c64(x2.shape[1]),
+                                 _stream(x2)), "mdg_l2_normalize")
+    return y.view(*lead, x2.shape[1])
+
+
+def token_pool(tokens: torch.Tensor, bits: Optional[torch.Tensor], mode: str) -> torch.Tensor:
+    """Masked mean / sum / max over the token axis of [n,S,128]."""
+    forward_only(tokens)
+    t = _f32_cuda(tokens, "tokens", 3)
+    n, S, D = t.shape
+    out = torch.empty((n, D), dtype=torch.float32, device=t.device)
+    check(lib().mdg_token_pool(_ptr(t), _ptr(bits), _ptr(out), _c64(n), _c(S), _c64(D), _c({"mean": 0, "sum": 1, "max": 2}[mode]),
+                               _stream(t)), "mdg_token_pool")
+    return out

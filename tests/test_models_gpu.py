@@ -1,0 +1,156 @@
+"""madrigal_amd model classes (HIP path) against the reference golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import ENCODE_CASES, FUSION_CASES, rel_err, t
+
+pytestmark = pytest.mark.gpu
+TOL = {"f32": 3e-5, "bf16x3": 1e-4}
+
+
+@pytest.fixture(scope="module")
+def M():
+    import madrigal_amd.models as _m
+    return _m
+
+
+def _fill(module, seed, skip=()):
+    from oracle.params import fill_module
+    fill_module(module, seed, skip)
+    return module.cuda().eval()
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("name,cls,in_dim,hidden,out,p,norm,actn,order", [
+    ("cv", "MLPEncoder", 559, [512, 256], 128, 0.2, None, "relu", "nd"),
+    ("proj", "MLPAdaptor", 128, [512, 512], 128, 0.2, "ln", "relu", "nd"),
+    ("bn_dn", "MLPEncoder", 40, [64, 48, 32], 16, 0.1, "bn", "gelu", "dn"),
+    ("one_hidden", "MLPAdaptor", 32, [64], 8, 0.0, "ln", "tanh", "nd"),
+])
+def test_mlps_golden(M, golden, prec, name, cls, in_dim, hidden, out, p, norm, actn, order):
+    g = golden("mlps")
+    m = getattr(M, cls)(in_dim, hidden, out, p, norm, actn, order)
+    assert sorted(m.state_dict().keys()) == list(g[name + "_keys"])
+    _fill(m, 21)
+    with torch.no_grad(), M.precision(prec):
+        y = m(t(g[name + "_x"]).cuda()).cpu()
+    assert rel_err(y, g[name + "_y"]) < TOL[prec]
+
+
+def test_training_mode_and_autograd_are_refused(M):
+    m = M.MLPEncoder(8, [8], 4, 0.0, None, "relu").cuda()
+    with pytest.raises(RuntimeError, match="eval"):
+        m(torch.zeros(2, 8, device="cuda"))
+    m.eval()
+    with pytest.raises(RuntimeError, match="forward-only"):
+        m(torch.zeros(2, 8, device="cuda"))
+    with torch.no_grad():
+        assert m(torch.zeros(2, 8, device="cuda")).shape == (2, 4)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("case", FUSION_CASES, ids=[c[0] for c in FUSION_CASES])
+def test_fusion_golden(M, golden, case, prec):
+    name, H, dh, ffn, nl, nf, agg, nb, actn = case
+    g = golden("fusion_" + name)
+    m = M.TransformerFusion(128, nb, nl, H, dh, ffn, 0.3, actn, nf, False, agg)
+    _fill(m, 41)
+    src = t(g["src"]).cuda() if g["src"].size else None
+    seen = {}
+    hook = m.transformer_encoder.layers[-1].self_attn.register_forward_hook(lambda mod, i, o: seen.__setitem__("w", o[1]))
+    with torch.no_grad(), M.precision(prec):
+        y = m(t(g["seq"]).cuda(), t(g["kpm"]).cuda(), src).cpu()
+    hook.remove()
+    assert rel_err(y, g["out"]) < TOL[prec]
+    assert rel_err(seen["w"].cpu(), g["attn_last"]) < TOL[prec]      # the forward-hook target still sees the weights
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_chemcpa_golden(M, golden, prec):
+    g = golden("chemcpa")
+    hp = {"dim": 128, "autoencoder_width": 512, "autoencoder_depth": 2}
+    m = M.TxAdaptingComPert(num_genes=978, num_drugs=50, covariate_names_unique={"cell_iname": M.CELL_LINES_CAPITALIZED},
+                            hparams=hp, use_drugs=False, disable_adv=True)
+    assert sorted(m.state_dict().keys()) == list(g["keys"])
+    _fill(m, 51)
+    genes, cov = t(g["genes"]).cuda(), t(g["cov_idx"]).cuda()
+    onehot = torch.nn.functional.one_hot(cov, 16).long()
+    with torch.no_grad(), M.precision(prec):
+        rec, emb, basal, treated = m.predict(genes=genes, drugs_idx=torch.zeros_like(cov), dosages=torch.ones(cov.shape[0], device="cuda"),
+                                             covariates=[onehot], return_latent_basal=True, return_latent_treated=True)
+        out2 = m.predict(genes=genes, drugs_idx=torch.zeros_like(cov), dosages=torch.ones(cov.shape[0], device="cuda"),
+                         covariates=[onehot], return_latent_treated=True, compute_reconstruction=False)
+    for a, k in ((rec, "recon"), (emb, "cell_emb"), (basal, "basal"), (treated, "treated"), (out2[2], "treated")):
+        assert rel_err(a.cpu(), g[k]) < TOL[prec], k
+    assert out2[0] is None
+
+
+def build_model(M, case, kg, L):
+    name, fusion, nb, pos, H, dh, ffn, nl, nf, agg, normalize, adapt = case
+    enc = M.NovelDDIEncoder(
+        all_kg_data=kg, feat_dim=128, str_encoder_name="gin",
+        str_encoder_hparams=dict(gin_hidden_dims=[128, 128, 128], gin_edge_input_dim=18, gin_num_mlp_layer=3, gin_eps=0,
+                                 gin_batch_norm=True, gin_actn="relu", gin_readout="mean"),
+        kg_encoder_name="hgt", kg_encoder_hparams=dict(hgt_hidden_dim=128, hgt_num_layers=2, hgt_att_heads=4, hgt_group="sum"),
+        cv_encoder_name="mlp", cv_encoder_hparams=dict(cv_input_dim=559, cv_mlp_hidden_dims=[512, 256], cv_mlp_dropout=0.2,
+                                                      cv_mlp_norm=None, cv_mlp_actn="relu", cv_mlp_order="nd"),
+        tx_encoder_name="chemcpa",
+        tx_encoder_hparams={"model": {"hparams": {"dim": 128, "autoencoder_width": 512, "autoencoder_depth": 2},
+                                      "additional_params": {}, "append_ae_layer": False, "pretrained_model_ckpt": None,
+                                      "use_drugs": False}},
+        num_tx_bottlenecks=nb, pos_emb_dropout=0.2,
+        transformer_fusion_hparams=dict(transformer_num_layers=nl, transformer_att_heads=H, transformer_head_dim=dh,
+                                        transformer_ffn_dim=ffn, transformer_dropout=0.3, transformer_actn="gelu",
+                                        transformer_norm_first=nf, transformer_batch_first=False, transformer_agg=agg),
+        proj_hparams=dict(proj_hidden_dims=[512, 512], proj_dropout=0.2, proj_norm="ln", proj_actn="relu", proj_order="nd"),
+        fusion=fusion, use_modality_pretrain=False, normalize=normalize, pos_emb_type=pos, adapt_before_fusion=adapt)
+    return M.NovelDDIMultilabel(enc, 128, L, normalize=False)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("case", ENCODE_CASES, ids=[c[0] for c in ENCODE_CASES])
+def test_encode_and_score_golden(M, golden, case, prec):
+    """Whole path (GIN + HGT + cv + chemCPA -> tokens -> fusion -> head) against the reference's outputs."""
+    from madrigal_amd import data as D
+    g = golden("encode_" + case[0])
+    n, L, seed = (int(v) for v in g["meta"])
+    masks = t(g["masks"])
+    batch, bkg = D.make_batch(n, seed, kg_nodes=300, kg_edges=2500, masks=masks)
+    model = build_model(M, case, bkg["data"], L)
+    assert sorted(model.state_dict().keys()) == list(g["keys"])              # checkpoint-compatible key set
+    skip = [k for k in model.state_dict() if k.endswith("pos_encoder.pe") and case[3] == "sinusoidal"]
+    _fill(model, seed, skip)
+    b = D.batch_to(batch, "cuda")
+    kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
+    filler = t(g["kg_filler"]).cuda()
+    enc = model.encoder
+    with torch.no_grad(), M.precision(prec):
+        str_out = enc.str_encoder(b["strs"], b["strs"].node_feature.float())["graph_feature"]
+        kg_out = enc.kg_encoder(kgc["data"].x_dict, kgc["data"].edge_index_dict)["drug"]
+        cv_out = enc.cv_encoder(b["cv"])
+        z = enc(b["drugs"], b["masks"], b["strs"], kgc, b["cv"], b["tx"], kg_filler=filler)
+        z_raw = enc(b["drugs"], b["masks"], b["strs"], kgc, b["cv"], b["tx"], raw_encoder_output=True, kg_filler=filler)
+        scores = model(b, b, b["masks"], b["masks"], kgc, kg_filler=filler)
+        scores25 = model.decoder(z, z, (2, 5))
+    for a, k in ((str_out, "str_out"), (kg_out, "kg_out"), (cv_out, "cv_out"), (z, "z"), (z_raw, "z_raw"), (scores, "scores"),
+                 (scores25, "scores_2_5")):
+        assert rel_err(a.cpu(), g[k]) < 2 * TOL[prec], k
+
+
+def test_head_module_matches_golden_and_caches_symmetric_weight(M, golden):
+    g = golden("head")
+    dec = M.BilinearDDIScorer(128, 128, 5)
+    torch.nn.utils.parametrize.register_parametrization(dec, "weight", M.Symmetric())
+    dec = dec.cuda().eval()
+    with torch.no_grad():
+        dec.parametrizations.weight.original.copy_(t(g["w_original"]).cuda())
+        with M.precision("f32"):
+            s = dec(t(g["z_head"]).cuda(), t(g["z_tail"]).cuda())
+            s14 = dec(t(g["z_head"]).cuda(), t(g["z_tail"]).cuda(), (1, 4))
+        assert rel_err(s.cpu(), g["scores"]) < 2e-5 and rel_err(s14.cpu(), g["scores_1_4"]) < 2e-5
+        first = dec.symmetric_weight()
+        assert dec.symmetric_weight() is first                     # no re-symmetrisation while W is unchanged
+        dec.parametrizations.weight.original.mul_(2.0)
+        assert dec.symmetric_weight() is not first
+    assert sorted(dec.state_dict().keys()) == ["bias", "parametrizations.weight.original"]

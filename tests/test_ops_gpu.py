@@ -1,0 +1,202 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against the CPU oracle's building blocks."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = {"f32": 2e-5, "bf16x3": 1e-4, "bf16": 3e-2}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from madrigal_amd import ops as _ops
+    return _ops
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(300, 128, 128), (1, 5, 4), (129, 257, 68), (1000, 512, 560), (77, 1536, 512), (515, 128, 980)])
+def test_linear_plain(ops, prec, M, N, K):
+    x, w, b = _rand((M, K), 1), _rand((N, K), 2, 1 / math.sqrt(K)), _rand((N,), 3)
+    ref = x @ w.t() + b
+    got = ops.linear(x.cuda(), w.cuda(), b.cuda(), precision=prec).cpu()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) < TOL[prec] * max(float(ref.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("act", ["relu", "gelu", "tanh", "sigmoid", "leakyrelu", "softplus", "selu", None])
+def test_linear_epilogue(ops, act):
+    from oracle import madrigal_oracle as O
+    M, N, K = 200, 96, 64
+    x, w, b = _rand((M, K), 4), _rand((N, K), 5, 0.2), _rand((N,), 6)
+    scale, shift, res = _rand((N,), 7).abs() + 0.5, _rand((N,), 8), _rand((M, N), 9)
+    ref = 0.7 * O._act(act, (x @ w.t() + b) * scale + shift) + 0.3 * res
+    got = ops.linear(x.cuda(), w.cuda(), b.cuda(), scale=scale.cuda(), shift=shift.cuda(), act=act, residual=res.cuda(),
+                     alpha=0.7, beta=0.3, precision="f32").cpu()
+    assert rel_err(got, ref) < 2e-5
+
+
+def test_linear_unpadded_k_strided_views_and_broadcast_residual(ops):
+    x, w = _rand((50, 559), 10), _rand((40, 559), 11, 0.05)
+    got = ops.linear(x.cuda(), w.cuda(), None, precision="f32").cpu()          # K = 559 is zero-padded to 560
+    assert rel_err(got, x @ w.t()) < 2e-5
+    big = _rand((30, 384), 12).cuda()
+    w2 = _rand((128, 128), 13, 0.1)
+    out = torch.zeros(30, 256, device="cuda")
+    ops.linear(big[:, 128:256], w2.cuda(), None, precision="f32", out=out[:, 128:])
+    assert rel_err(out[:, 128:].cpu(), big[:, 128:256].cpu() @ w2.t()) < 2e-5
+    assert float(out[:, :128].abs().max()) == 0.0
+    r = _rand((128,), 14)
+    got = ops.linear(big[:, :128], w2.cuda(), None, residual=r.cuda(), precision="f32").cpu()
+    assert rel_err(got, big[:, :128].cpu() @ w2.t() + r) < 2e-5
+
+
+def test_linear_errors(ops):
+    x, w = torch.zeros(4, 8, device="cuda"), torch.zeros(3, 12, device="cuda")
+    with pytest.raises(ValueError):
+        ops.linear(x, w)
+    with pytest.raises(ValueError):
+        ops.linear(x, torch.zeros(3, 8, device="cuda"), act="swish")
+    with pytest.raises(RuntimeError, match="forward-only"):
+        ops.linear(x.requires_grad_(), torch.zeros(3, 8, device="cuda"))
+
+
+@pytest.mark.parametrize("rows,d", [(37, 128), (5, 512), (3, 2048), (1000, 256), (9, 36)])
+def test_layernorm(ops, rows, d):
+    from oracle import madrigal_oracle as O
+    x, g, b = _rand((rows, d), 20, 3.0) + 1.5, _rand((d,), 21).abs() + 0.5, _rand((d,), 22)
+    got = ops.layernorm(x.cuda(), g.cuda(), b.cuda()).cpu()
+    assert float((got - O.layer_norm(x, g, b)).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("S,H,dh", [(23, 8, 64), (21, 2, 256), (19, 4, 128), (22, 4, 32), (32, 1, 32), (1, 2, 64)])
+def test_fusion_attention(ops, S, H, dh):
+    n, d = 9, H * dh
+    qkv = _rand((n * S, 3 * d), 30)
+    kpm = torch.rand(n, S, generator=torch.Generator().manual_seed(31)) < 0.3
+    kpm[:, min(3, S - 1)] = False                        # at least one key everyone may attend
+    src = torch.zeros(S, S, dtype=torch.bool)
+    if S > 4:
+        src[:2, -2:] = True
+        src[-2:, :2] = True
+    q, k, v = (t.view(n, S, H, dh).transpose(1, 2) for t in qkv.view(n, S, 3 * d).split(d, dim=2))
+    logits = (q / math.sqrt(dh)) @ k.transpose(-1, -2)
+    logits = logits.masked_fill(src.view(1, 1, S, S), float("-inf")).masked_fill(kpm.view(n, 1, 1, S), float("-inf"))
+    p = torch.softmax(logits, dim=-1)
+    ref = (p @ v).transpose(1, 2).reshape(n * S, d)
+    out, probs = ops.fusion_attention(qkv.cuda(), n, S, H, dh, ops.mask_bits(kpm.cuda()), ops.mask_bits(src.cuda()), want_probs=True)
+    assert rel_err(probs.cpu(), p) < 2e-5
+    assert rel_err(out.cpu(), ref) < 2e-5
+    out2, none = ops.fusion_attention(qkv.cuda(), n, S, H, dh)          # no masks
+    p2 = torch.softmax((q / math.sqrt(dh)) @ k.transpose(-1, -2), dim=-1)
+    assert none is None and rel_err(out2.cpu(), (p2 @ v).transpose(1, 2).reshape(n * S, d)) < 2e-5
+
+
+def test_fusion_attention_fully_masked_row_is_nan_like_torch(ops):
+    n, S, H, dh = 2, 5, 1, 32
+    qkv = _rand((n * S, 3 * H * dh), 33)
+    kpm = torch.zeros(n, S, dtype=torch.bool)
+    kpm[1, :] = True
+    out, _ = ops.fusion_attention(qkv.cuda(), n, S, H, dh, ops.mask_bits(kpm.cuda()), None)
+    out = out.cpu().view(n, S, -1)
+    assert torch.isfinite(out[0]).all() and torch.isnan(out[1]).all()
+
+
+@pytest.mark.parametrize("Tk,H,dh", [(4, 8, 64), (2, 2, 256), (19, 4, 128), (1, 4, 32)])
+def test_xattn_pool(ops, Tk, H, dh):
+    n, d = 11, H * dh
+    q, kv = _rand((d,), 40), _rand((n * Tk, 2 * d), 41)
+    k, v = (t.view(n, Tk, H, dh) for t in kv.split(d, dim=1))
+    lg = torch.einsum("hd,nthd->nht", q.view(H, dh) / math.sqrt(dh), k)
+    ref = torch.einsum("nht,nthd->nhd", torch.softmax(lg, -1), v).reshape(n, d)
+    assert rel_err(ops.xattn_pool(q.cuda(), kv.cuda(), n, Tk, H, dh).cpu(), ref) < 2e-5
+
+
+def test_assemble_tokens_and_pools(ops):
+    from oracle import madrigal_oracle as O
+    n, D = 7, 128
+    s, k, c = _rand((n, D), 50), _rand((n, D), 51), _rand((n, D), 52)
+    tx = _rand((16 * n, D), 53)
+    bt, cls = _rand((4, D), 54), _rand((1, D), 55)
+    all_embeds = torch.stack([s, k, c] + list(tx.split(n)), dim=1)
+    masks = torch.rand(n, 19, generator=torch.Generator().manual_seed(56)) < 0.4
+    masks[:, 0] = False
+    for nb, use_cls, norm in [(4, False, False), (2, True, True), (0, False, True)]:
+        seq, kpm, src = O.assemble_fusion_inputs(all_embeds, masks, bt[:nb] if nb else None, cls if use_cls else None)
+        pe = _rand((seq.shape[1] - 5, D), 57)
+        ref = O.l2_normalize(seq) if norm else seq.clone()
+        ref[:, :pe.shape[0]] += pe
+        got = ops.assemble_tokens(s.cuda(), k.cuda(), c.cuda(), tx.cuda(), bottleneck=bt[:nb].cuda() if nb else None,
+                                  cls=cls.cuda() if use_cls else None, pe=pe.cuda(), normalize=norm).cpu()
+        assert float((got - ref).abs().max()) < 2e-6
+    rows = torch.tensor([5, 0, 3])
+    got = ops.assemble_tokens(s.cuda(), k.cuda(), c.cuda(), tx.cuda(), rows=rows.cuda()).cpu()
+    assert torch.equal(got, all_embeds[rows])
+    bits = ops.mask_bits(masks.cuda())
+    keep = (~masks).unsqueeze(-1)
+    assert float((ops.token_pool(all_embeds.cuda(), bits, "sum").cpu() - (all_embeds * keep).sum(1)).abs().max()) < 1e-5
+    assert float((ops.token_pool(all_embeds.cuda(), bits, "mean").cpu() - (all_embeds * keep).sum(1) / keep.sum(1)).abs().max()) < 1e-5
+    mx = all_embeds.masked_fill(~keep, float("-inf")).max(1).values
+    assert torch.equal(ops.token_pool(all_embeds.cuda(), bits, "max").cpu(), mx)
+    assert float((ops.l2_normalize(all_embeds.cuda()).cpu() - O.l2_normalize(all_embeds)).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("F", [128, 68, 20, 256])
+def test_csr_aggregate(ops, F):
+    g = torch.Generator().manual_seed(60)
+    n_src, n_dst, E = 500, 300, 4000
+    x = _rand((n_src, F), 61)
+    dst = torch.randint(0, n_dst, (E,), generator=g).sort().values
+    dst[dst == 7] = 8                                    # an empty row
+    dst = dst.sort().values
+    col = torch.randint(0, n_src, (E,), generator=g)
+    w = torch.rand(E, generator=g)
+    rowptr = torch.zeros(n_dst + 1, dtype=torch.int64)
+    rowptr[1:] = torch.bincount(dst, minlength=n_dst).cumsum(0)
+    xs = _rand((n_dst, F), 62)
+    eps = torch.tensor([0.25])
+    ref = torch.zeros(n_dst, F).index_add_(0, dst, x[col] * w[:, None]) + 1.25 * xs
+    got = ops.csr_aggregate(x.cuda(), rowptr.cuda(), col.cuda(), edge_weight=w.cuda(), x_self=xs.cuda(), self_coef_dev=eps.cuda(),
+                            self_coef_add=1.0).cpu()
+    assert float((got - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    # contiguous segments + mean (molecule read-out)
+    seg = torch.tensor([0, 3, 3, 10, 500])
+    ref2 = torch.stack([x[a:b].mean(0) if b > a else torch.zeros(F) for a, b in zip(seg[:-1], seg[1:])])
+    got2 = ops.csr_aggregate(x.cuda(), seg.cuda(), None, mean=True).cpu()
+    assert float((got2 - ref2).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("heads", [4, 1, 8])
+def test_hgt_attention_heavy_tail(ops, heads):
+    """Edge softmax + aggregation incl. a destination with > CHUNK edges (split into work items), an
+    isolated destination and single-edge destinations."""
+    from madrigal_amd.graph_plans import HGT_CHUNK, hgt_plan
+    g = torch.Generator().manual_seed(70)
+    n_src, n_dst = 900, 40
+    e_heavy = 3 * HGT_CHUNK + 17
+    dst = torch.cat([torch.zeros(e_heavy, dtype=torch.int64), torch.randint(2, n_dst, (600,), generator=g), torch.tensor([1])])
+    src = torch.randint(0, n_src, (dst.numel(),), generator=g)
+    dst[dst == 5] = 6                                    # destination 5 has no edges
+    ei = {("a", "r", "b"): torch.stack([src, dst])}
+    plan = hgt_plan({k: v.cuda() for k, v in ei.items()}, [("a", "r", "b")], {"a": n_src, "b": n_dst}, torch.device("cuda"))
+    q, kv = _rand((n_dst, 128), 71), _rand((n_src, 256), 72)
+    D = 128 // heads
+    a = (q[dst].view(-1, heads, D) * kv[src, :128].view(-1, heads, D)).sum(-1)
+    amax = torch.full((n_dst, heads), float("-inf")).scatter_reduce(0, dst[:, None].expand(-1, heads), a, reduce="amax")
+    e = torch.exp(a - amax[dst])
+    den = torch.zeros(n_dst, heads).index_add_(0, dst, e)
+    alpha = e / (den[dst] + 1e-16)
+    agg = torch.zeros(n_dst, heads, D).index_add_(0, dst, kv[src, 128:].view(-1, heads, D) * alpha[..., None]).reshape(n_dst, 128)
+    from oracle import madrigal_oracle as O
+    got = ops.hgt_attention(q.cuda(), kv.cuda(), plan["per_dst"]["b"], heads, apply_gelu=False).cpu()
+    assert float((got - agg).abs().max()) < 2e-5
+    got_g = ops.hgt_attention(q.cuda(), kv.cuda(), plan["per_dst"]["b"], heads, apply_gelu=True).cpu()
+    assert float((got_g - O._act("gelu", agg)).abs().max()) < 2e-5
+    assert float(got[5].abs().max()) == 0.0
