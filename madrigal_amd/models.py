@@ -61,6 +61,9 @@ def _require_eval(m: nn.Module) -> None:
     if m.training:
         raise RuntimeError(f"{type(m).__name__}: the HIP path is forward-only; call .eval() first "
                            "(dropout / BatchNorm batch statistics of training mode are not implemented)")
+    if torch.is_grad_enabled() and any(p.requires_grad for p in m.parameters()):
+        raise RuntimeError(f"{type(m).__name__}: the HIP path is forward-only: call it under torch.no_grad() "
+                           "(the kernels do not record an autograd graph; backward is not part of this release)")
 
 
 # madrigal/models/models.py:31.  Fresh instances per use; only the type matters for the fused epilogue.
