@@ -161,6 +161,36 @@ int mdg_hgt_attention(const float* q, int64_t ldq, const float* kv, int64_t ldkv
                       int64_t ldo, int64_t n_dst, int heads, int64_t F, int apply_gelu, void* workspace, size_t workspace_bytes,
                       void* stream);
 
+/* ------------------------------------------------------------------------------ losses ---- */
+
+/* InfoNCE finish of SimCLR_NovelDDI.contrastive_loss (madrigal/models/simclr.py:74-108): given
+ * sim = F F^T [2B,2B] of the 2B L2-normalised features, apply the too-hard-negative mask ([B,B] bytes,
+ * nullable; tiled 2x2, filled with -1e9), drop the diagonal, divide by the temperature -> logits
+ * [2B,2B-1] (nullable), labels [2B,2B-1] (nullable, 1 at the other view of the same drug),
+ * row_loss [2B] and loss [1] = mean soft-label cross entropy. */
+int mdg_infonce_finish(const float* sim, const uint8_t* too_hard_neg, float* logits, float* labels, float* row_loss, float* loss,
+                       int64_t B, float temperature, void* stream);
+
+/* pred[e] = f(scores[label[e], head[e], tail[e]]) with f = sigmoid (apply_sigmoid) or identity, and the
+ * mean BCE of pred against target with nn.BCELoss's -100 clamp: term [n] and loss [1] (both nullable
+ * together).  Replaces the advanced-index gather + BCELoss of train_ddi_batch.py:285-288. */
+int mdg_gather_bce(const float* scores, int64_t n_labels, int64_t n_head, int64_t n_tail, const int64_t* label, const int64_t* head,
+                   const int64_t* tail, const float* target, float* pred, float* term, float* loss, int64_t n, int apply_sigmoid,
+                   void* stream);
+
+/* ---------------------------------------------------------------------- rank normalisation ---- */
+
+size_t mdg_rank_normalize_workspace_bytes(int64_t n_outcomes, int64_t N);
+
+/* Per outcome l: out[l,i,j] = out[l,j,i] = rank(scores[l,i,j] among the strict lower triangle i > j, ascending,
+ * 1-based, ties by flat index) / (N(N-1)/2), diagonal 0; the division is done in double and rounded to fp32
+ * like numpy's int64 / float -> float32 store.  Replaces classwise_normalized_rank_3d_numpy + run_slice,
+ * notebooks/normalize_scores.py:36-74 (two CPU argsorts of N^2 keys per outcome).  scores, out [n_outcomes,N,N];
+ * out may alias scores only if n_outcomes fits one call.  Scores must be finite and < 1e7 (the reference's
+ * mask value). */
+int mdg_rank_normalize(const float* scores, float* out, int64_t n_outcomes, int64_t N, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -165,17 +165,25 @@ def make_kg(n_kg_drugs: int, seed: int, n_nodes: int = 2000, n_edges: int = 2000
     share = rng.dirichlet(np.ones(len(pairs)) * 1.5)
     edge_index_dict = {}
 
-    def zipf_nodes(n, size):
-        r = rng.zipf(zipf_a, size=size) - 1 if zipf_a > 1.0 else rng.integers(0, n, size=size)
+    def skewed_nodes(n, size):
+        """Half the endpoints uniform, half Zipf(a)-popular (heavy-tailed degrees without collapsing
+        onto a handful of nodes)."""
+        uni = rng.integers(0, n, size=size)
+        if zipf_a <= 1.0:
+            return uni
         perm = rng.permutation(n)
-        return perm[np.minimum(r, n - 1) % n] if n > 0 else r
+        z = perm[(rng.zipf(zipf_a, size=size) - 1) % n]
+        return np.where(rng.random(size) < 0.5, z, uni)
 
     for k, (a, b) in enumerate(pairs):
         e = max(1, int(round(n_edges / 2 * share[k])))
-        s = zipf_nodes(counts[a], e)
-        # mix skewed and uniform destinations so that degree is heavy tailed but not degenerate
-        d = np.where(rng.random(e) < 0.5, zipf_nodes(counts[b], e), rng.integers(0, counts[b], size=e))
-        ei = np.unique(np.stack([s, d], 0), axis=1).astype(np.int64)
+        cap = counts[a] * counts[b]
+        e = min(e, max(1, cap // 2))
+        draw = int(e * 1.6) + 8                           # oversample, de-duplicate, trim to the target
+        ei = np.unique(np.stack([skewed_nodes(counts[a], draw), skewed_nodes(counts[b], draw)], 0), axis=1)
+        if ei.shape[1] > e:
+            ei = ei[:, np.sort(rng.choice(ei.shape[1], size=e, replace=False))]
+        ei = ei.astype(np.int64)
         edge_index_dict[(types[a], f"rel{k}", types[b])] = torch.from_numpy(ei)
         edge_index_dict[(types[b], f"rev_rel{k}", types[a])] = torch.from_numpy(ei[::-1].copy())
     return KGData(x_dict, edge_index_dict, types, list(edge_index_dict.keys()))

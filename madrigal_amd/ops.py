@@ -340,3 +340,73 @@ def token_pool(tokens: torch.Tensor, bits: Optional[torch.Tensor], mode: str) ->
     check(lib().mdg_token_pool(_ptr(t), _ptr(bits), _ptr(out), _c64(n), _c(S), _c64(D), _c({"mean": 0, "sum": 1, "max": 2}[mode]),
                                _stream(t)), "mdg_token_pool")
     return out
+
+
+# ------------------------------------------------------------------------------- losses
+def info_nce(aug1: torch.Tensor, aug2: torch.Tensor, too_hard_neg: Optional[torch.Tensor], temperature: float,
+             precision="bf16x3", want_logits: bool = True):
+    """(logits [2B,2B-1], labels [2B,2B-1], loss) of SimCLR_NovelDDI.contrastive_loss (simclr.py:74-108)."""
+    forward_only(aug1, aug2)
+    a1, a2 = _f32_cuda(aug1, "aug1", 2), _f32_cuda(aug2, "aug2", 2)
+    if a1.shape != a2.shape:
+        raise ValueError("aug1 / aug2 shapes differ")
+    B = a1.shape[0]
+    f = l2_normalize(torch.cat([a1, a2], dim=0))
+    sim = linear(f, f, None, precision=precision)
+    hard = None
+    if too_hard_neg is not None:
+        if too_hard_neg.shape != (B, B):
+            raise ValueError("too_hard_neg: expected [B,B]")
+        hard = too_hard_neg.to(device=a1.device, dtype=torch.uint8).contiguous()
+    logits = torch.empty((2 * B, 2 * B - 1), dtype=torch.float32, device=a1.device) if want_logits else None
+    labels = torch.empty_like(logits) if want_logits else None
+    row = torch.empty(2 * B, dtype=torch.float32, device=a1.device)
+    loss = torch.empty(1, dtype=torch.float32, device=a1.device)
+    check(lib().mdg_infonce_finish(_ptr(sim), _ptr(hard), _ptr(logits), _ptr(labels), _ptr(row), _ptr(loss), _c64(B),
+                                   _f(temperature), _stream(a1)), "mdg_infonce_finish")
+    return logits, labels, loss[0]
+
+
+def gather_bce(scores: torch.Tensor, labels: torch.Tensor, heads: torch.Tensor, tails: torch.Tensor,
+               target: Optional[torch.Tensor] = None, apply_sigmoid: bool = True):
+    """pred = sigmoid?(scores)[labels, heads, tails]; loss = BCELoss(pred, target)  (train_ddi_batch.py:285-288)."""
+    s = _f32_cuda(scores, "scores", 3)
+    n = int(labels.numel())
+    for nm, t in (("labels", labels), ("heads", heads), ("tails", tails)):
+        if t.dtype != torch.int64 or not t.is_cuda or t.numel() != n:
+            raise ValueError(f"{nm}: expected int64 cuda [{n}]")
+    pred = torch.empty(n, dtype=torch.float32, device=s.device)
+    term = loss = None
+    if target is not None:
+        target = _f32_cuda(target, "target", 1)
+        term = torch.empty(n, dtype=torch.float32, device=s.device)
+        loss = torch.zeros(1, dtype=torch.float32, device=s.device)
+    check(lib().mdg_gather_bce(_ptr(s), _c64(s.shape[0]), _c64(s.shape[1]), _c64(s.shape[2]), _ptr(labels.contiguous()),
+                               _ptr(heads.contiguous()), _ptr(tails.contiguous()), _ptr(target), _ptr(pred), _ptr(term), _ptr(loss),
+                               _c64(n), _c(1 if apply_sigmoid else 0), _stream(s)), "mdg_gather_bce")
+    return pred, (None if loss is None else loss[0])
+
+
+# ------------------------------------------------------------------------------- rank normalisation
+def rank_normalize(scores: torch.Tensor, out: Optional[torch.Tensor] = None, max_workspace_bytes: int = 8 << 30) -> torch.Tensor:
+    """Normalised ranks per outcome (notebooks/normalize_scores.py:36-74): [L,N,N] fp32 -> [L,N,N] fp32.
+    Outcomes are processed in chunks sized to ``max_workspace_bytes`` of sort scratch."""
+    s = _f32_cuda(scores, "scores", 3)
+    L, N, N2 = s.shape
+    if N != N2:
+        raise ValueError("scores: expected [L,N,N]")
+    out = torch.empty_like(s) if out is None else _f32_cuda(out, "out", 3)
+    if out.shape != s.shape or out.data_ptr() == s.data_ptr():
+        raise ValueError("out: same shape as scores, and not aliasing it")
+    if L == 0 or N == 0:
+        return out
+    lb = lib()
+    per = max(lb.mdg_rank_normalize_workspace_bytes(_c64(1), _c64(N)), 1)
+    chunk = int(max(1, min(L, 65535, max_workspace_bytes // per)))
+    for lo in range(0, L, chunk):
+        hi = min(L, lo + chunk)
+        nbytes = lb.mdg_rank_normalize_workspace_bytes(_c64(hi - lo), _c64(N))
+        ws = _workspace(nbytes, s.device)
+        check(lb.mdg_rank_normalize(_vp(s.data_ptr() + lo * N * N * 4), _vp(out.data_ptr() + lo * N * N * 4), _c64(hi - lo), _c64(N),
+                                    _ptr(ws), ctypes.c_size_t(nbytes), _stream(s)), "mdg_rank_normalize")
+    return out

@@ -1,0 +1,61 @@
+"""MI355X-native drop-in for ``madrigal.models.simclr`` (second-stage contrastive wrapper).
+
+``SimCLR_NovelDDI`` keeps the reference's constructor, attribute names (``base_encoder``, ``predictor_1``,
+``predictor_2`` / ``predictor``) and return value ``(aug_1, aug_2, (logits, labels, loss))``
+(madrigal/models/simclr.py:11-140).  Forward-only this release: eval-mode BatchNorm in the predictor MLPs.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .models import _require_eval, _run_sequential, get_precision
+
+
+class SimCLR_NovelDDI(nn.Module):
+    def __init__(self, base_encoder, dim=256, mlp_dim=1024, T=1.0, raw_encoder_output=False, shared_predictor=False):
+        super().__init__()
+        self.base_encoder = base_encoder
+        self.T = T
+        self.raw_encoder_output = raw_encoder_output
+        self.shared_predictor = shared_predictor
+        hidden_dim = self.base_encoder.uni_projector.fc[-1].weight.shape[0]
+        assert hidden_dim == dim, f"Hidden dim of the encoder ({hidden_dim}) should be the same as the dim of the projection head ({dim})."
+        if shared_predictor:
+            self.predictor = self._build_mlp(2, dim, mlp_dim, dim)
+        else:
+            self.predictor_1 = self._build_mlp(2, dim, mlp_dim, dim)
+            self.predictor_2 = self._build_mlp(2, dim, mlp_dim, dim)
+
+    @staticmethod
+    def _build_mlp(num_layers, input_dim, mlp_dim, output_dim, last_bn=True):
+        """simclr.py:46-62: Linear(no bias) + BN + ReLU, ..., Linear(no bias) + BN(affine=False)."""
+        mlp = []
+        for l in range(num_layers):
+            d1 = input_dim if l == 0 else mlp_dim
+            d2 = output_dim if l == num_layers - 1 else mlp_dim
+            mlp.append(nn.Linear(d1, d2, bias=False))
+            if l < num_layers - 1:
+                mlp.append(nn.BatchNorm1d(d2))
+                mlp.append(nn.ReLU(inplace=True))
+            elif last_bn:
+                mlp.append(nn.BatchNorm1d(d2, affine=False))
+        return nn.Sequential(*mlp)
+
+    def contrastive_loss(self, aug1, aug2, batch_too_hard_neg_mask):
+        """simclr.py:74-108 -> (logits [2B,2B-1], labels [2B,2B-1], loss)."""
+        return ops.info_nce(aug1, aug2, batch_too_hard_neg_mask, float(self.T), precision=get_precision())
+
+    def forward(self, drug_indices, batch_mask_1, batch_mask_2, batch_too_hard_neg_mask, batch_data, batch_extra_mols=None,
+                batch_extra_masks=None):
+        _require_eval(self)
+        batch_mols, batch_kg, batch_cv, batch_tx_dict = batch_data
+        p1 = self.predictor if self.shared_predictor else self.predictor_1
+        p2 = self.predictor if self.shared_predictor else self.predictor_2
+        e1 = self.base_encoder(drug_indices, batch_mask_1, batch_mols, batch_kg, batch_cv, batch_tx_dict,
+                               raw_encoder_output=self.raw_encoder_output)
+        e2 = self.base_encoder(drug_indices, batch_mask_2, batch_mols, batch_kg, batch_cv, batch_tx_dict,
+                               raw_encoder_output=self.raw_encoder_output)
+        aug_1, aug_2 = _run_sequential(p1, e1), _run_sequential(p2, e2)
+        return aug_1, aug_2, self.contrastive_loss(aug_1, aug_2, batch_too_hard_neg_mask)
