@@ -93,10 +93,13 @@ int mdg_bilinear_allpairs(const float* z_head, const float* z_tail, const float*
  * the path: MLPEncoder/MLPAdaptor madrigal/models/models.py:178-180,516-518; chemCPA MLP
  * madrigal/chemcpa/chemCPA/model.py:226-231; nn.TransformerEncoderLayer linears models.py:366;
  * embed2latent / latent2embed models.py:411,443; GIN and HGT projections (third-party wheels).
- * K, ldx, ldw multiples of 4 (zero-pad the inner dimension), x and w 16-byte aligned. */
+ * K, ldx, ldw multiples of 4 (zero-pad the inner dimension), x and w 16-byte aligned.  ldr == 0 broadcasts one
+ * residual row.  workspace: scratch for the operand images (K padded to 32, hi/lo bf16 split), sized by
+ * mdg_linear_workspace_bytes (0 for MDG_PREC_F32 with K % 32 == 0). */
+size_t mdg_linear_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision);
 int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K,
                const float* bias, const float* scale, const float* shift, int activation, const float* residual, int64_t ldr,
-               float alpha, float beta, int precision, void* stream);
+               float alpha, float beta, int precision, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Row-wise LayerNorm (nn.LayerNorm, biased variance): y = (x - mean) / sqrt(var + eps) * gamma + beta.
  * norm1/norm2 and the x-attn norms of the fusion transformer, models.py:366,372-373; LayerNorm inside
@@ -110,19 +113,26 @@ int mdg_layernorm(const float* x, int64_t ldx, const float* gamma, const float* 
  * (each a 128-float row), optional per-token L2 normalisation, then + pe[s] for s < pe_len.
  * Replaces the stack / cat / repeat glue and PositionEncoding* of madrigal/models/models.py:772-775,
  * 799-804,818-822,849-852,581-603.  tx_emb is [16 * n_src, 128], cell-line major.  rows (nullable) selects
- * source drug rows (the multi-modal subset of fusion='transformer_uni_proj', models.py:784-790). */
+ * source drug rows (the multi-modal subset of fusion='transformer_uni_proj', models.py:784-790).
+ * token_index (nullable, [n_tok] values i*S+s): emit only those tokens, densely packed -> seq [n_tok,128]. */
 int mdg_assemble_tokens(const float* str_emb, const float* kg_emb, const float* cv_emb, const float* tx_emb,
-                        const float* bottleneck, const float* cls, const float* pe, const int64_t* rows, float* seq, int64_t n,
-                        int64_t n_src, int nb, int has_cls, int pe_len, int normalize, int64_t D, void* stream);
+                        const float* bottleneck, const float* cls, const float* pe, const int64_t* rows, const int64_t* token_index,
+                        int64_t n_tok, float* seq, int64_t n, int64_t n_src, int nb, int has_cls, int pe_len, int normalize,
+                        int64_t D, void* stream);
 
 /* Multi-head self-attention core for S <= 32 tokens per drug (scores, masks, softmax, PV) on the fp32
  * matrix cores; projections are mdg_linear calls.  qkv [n*S, 3d] = q|k|v (in_proj output), out [n*S, d].
  * kpm_bits[i] bit j = key j of drug i is padding (src_key_padding_mask), src_bits[s] bit j = query s
  * may not attend key j (the [S,S] bottleneck mask, models.py:813-816); probs (nullable) receives the
  * per-head attention weights [n,H,S,S] (need_weights=True, average_attn_weights=False, models.py:388-399).
+ * Compact mode (row_start != NULL): padded tokens are not stored at all -- qkv / out hold only each drug's
+ * live tokens, rows row_start[i] .. row_start[i+1]-1 (at most 32), and row_bits[r] bit j says that query row r
+ * may not attend its drug's j-th live key (kpm_bits / src_bits are ignored, probs must be NULL).  Padded
+ * tokens never influence live ones, so the live rows equal the dense result.
  * Replaces nn.MultiheadAttention inside nn.TransformerEncoderLayer, models.py:366-367,412. */
 int mdg_fusion_attention(const float* qkv, int64_t ld, float* out, int64_t ldo, const uint32_t* kpm_bits,
-                         const uint32_t* src_bits, float* probs, int64_t n, int S, int H, int dh, void* stream);
+                         const uint32_t* src_bits, float* probs, const int64_t* row_start, const uint32_t* row_bits, int64_t n,
+                         int S, int H, int dh, void* stream);
 
 /* Cross-attention pooling with one learned query shared by all drugs: out[i,h,:] = softmax_j(q_h . K_ijh / sqrt(dh)) V_ijh.
  * q_proj [H*dh] (already projected), kv_proj [n*Tk, 2*H*dh] = K|V of the Tk allowed key tokens of each drug.

@@ -13,6 +13,8 @@ struct AssembleArgs {
   const float* str; const float* kg; const float* cv; const float* tx;   // [n_src,128] x3, [16*n_src,128]
   const float* bottleneck; const float* cls; const float* pe;            // [nb,128], [128], [pe_len,128]
   const int64_t* rows;                                                   // [n] source row per output row, or null
+  const int64_t* token_index;                                            // [n_tok] drug*S+s of the tokens to emit, or null (= all)
+  int64_t n_tok;
   float* seq;
   int64_t n, n_src;
   int nb, has_cls, pe_len, normalize;
@@ -20,9 +22,10 @@ struct AssembleArgs {
 
 __global__ __launch_bounds__(256) void assemble_tokens_kernel(const AssembleArgs p) {
   const int S = p.has_cls + 3 + p.nb + 16;
-  const int64_t tok = static_cast<int64_t>(blockIdx.x) * 8 + (threadIdx.x >> 5);
+  const int64_t slot = static_cast<int64_t>(blockIdx.x) * 8 + (threadIdx.x >> 5);
   const int sub = threadIdx.x & 31;
-  if (tok >= p.n * S) return;
+  if (slot >= (p.token_index ? p.n_tok : p.n * S)) return;
+  const int64_t tok = p.token_index ? p.token_index[slot] : slot;
   const int64_t i = tok / S;
   const int s = static_cast<int>(tok % S);
   const int64_t src = p.rows ? p.rows[i] : i;
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(const AssembleArgs
     v *= inv;
   }
   if (s < p.pe_len) v += *reinterpret_cast<const f32x4*>(p.pe + s * 128 + 4 * sub);
-  *reinterpret_cast<f32x4*>(p.seq + tok * 128 + 4 * sub) = v;
+  *reinterpret_cast<f32x4*>(p.seq + slot * 128 + 4 * sub) = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -64,6 +67,8 @@ struct AttnArgs {
   const uint32_t* kpm_bits;          // [n] bit j set = key j masked for this drug, or null
   const uint32_t* src_bits;          // [S] bit j set = query i may not attend key j, or null
   float* probs;                      // [n,H,S,S] or null
+  const int64_t* row_start;          // compact mode: [n+1] first row of each drug's LIVE tokens (null = dense [n,S])
+  const uint32_t* row_bits;          // compact mode: [R] per query row, bit j = its j-th live key is not allowed
   int64_t n;
   int S, H, dh;
   float qscale;
@@ -76,8 +81,12 @@ __global__ __launch_bounds__(256) void fusion_attention_kernel(const AttnArgs p)
   const int64_t drug = gw / p.H;
   const int head = static_cast<int>(gw % p.H);
   const int d = p.H * p.dh;
-  const int xr = x < p.S ? x : p.S - 1;
-  const float* qrow = p.qkv + (drug * p.S + xr) * p.ld + head * p.dh;
+  // dense: the drug's S tokens are rows drug*S ..; compact: only its live tokens, rows row_start[drug] ..
+  const int64_t base = p.row_start ? p.row_start[drug] : drug * p.S;
+  const int T = p.row_start ? static_cast<int>(p.row_start[drug + 1] - base) : p.S;
+  if (T <= 0) return;
+  const int xr = x < T ? x : T - 1;
+  const float* qrow = p.qkv + (base + xr) * p.ld + head * p.dh;
   const float* krow = qrow + d;
 
   f32x16 acc;
@@ -100,12 +109,13 @@ __global__ __launch_bounds__(256) void fusion_attention_kernel(const AttnArgs p)
   }
 
   // acc[v] = score(query x, key j), j = (v&3) + 8(v>>2) + 4*half
-  const uint32_t blocked = (p.kpm_bits ? p.kpm_bits[drug] : 0u) | (p.src_bits ? p.src_bits[xr] : 0u);
+  const uint32_t blocked = p.row_start ? (p.row_bits ? p.row_bits[base + xr] : 0u)
+                                       : ((p.kpm_bits ? p.kpm_bits[drug] : 0u) | (p.src_bits ? p.src_bits[xr] : 0u));
   float m = -INFINITY;
 #pragma unroll
   for (int v = 0; v < 16; ++v) {
     const int j = (v & 3) + 8 * (v >> 2) + 4 * half;
-    if (j >= p.S || ((blocked >> j) & 1u)) acc[v] = -INFINITY;
+    if (j >= T || ((blocked >> j) & 1u)) acc[v] = -INFINITY;
     m = fmaxf(m, acc[v]);
   }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -120,16 +130,16 @@ __global__ __launch_bounds__(256) void fusion_attention_kernel(const AttnArgs p)
 #pragma unroll
   for (int v = 0; v < 16; ++v) acc[v] *= inv;
 
-  if (p.probs && x < p.S) {
+  if (p.probs && x < T) {
     float* pr = p.probs + ((drug * p.H + head) * p.S + x) * p.S;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
       const int j = (v & 3) + 8 * (v >> 2) + 4 * half;
-      if (j < p.S) pr[j] = acc[v];
+      if (j < T) pr[j] = acc[v];
     }
   }
 
-  const float* vbase = p.qkv + drug * p.S * p.ld + 2 * d + head * p.dh;
+  const float* vbase = p.qkv + base * p.ld + 2 * d + head * p.dh;
   for (int c0 = 0; c0 < p.dh; c0 += 32) {
     f32x16 o;
 #pragma unroll
@@ -137,12 +147,12 @@ __global__ __launch_bounds__(256) void fusion_attention_kernel(const AttnArgs p)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       int j = (s & 3) + 8 * (s >> 2) + 4 * half;
-      j = j < p.S ? j : p.S - 1;                    // clamped rows meet p == 0
+      j = j < T ? j : T - 1;                        // clamped rows meet p == 0
       const float vv = vbase[static_cast<int64_t>(j) * p.ld + c0 + x];
       o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, acc[s], o, 0, 0, 0);
     }
-    if (x < p.S) {
-      float* orow = p.out + (drug * p.S + x) * p.ldo + head * p.dh + c0;
+    if (x < T) {
+      float* orow = p.out + (base + x) * p.ldo + head * p.dh + c0;
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<f32x4*>(orow + 8 * g + 4 * half) = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
@@ -253,9 +263,9 @@ __global__ __launch_bounds__(256) void token_pool_kernel(const float* __restrict
 }  // namespace
 
 extern "C" int mdg_assemble_tokens(const float* str_emb, const float* kg_emb, const float* cv_emb, const float* tx_emb,
-                                   const float* bottleneck, const float* cls, const float* pe, const int64_t* rows, float* seq,
-                                   int64_t n, int64_t n_src, int nb, int has_cls, int pe_len, int normalize, int64_t D,
-                                   void* stream) {
+                                   const float* bottleneck, const float* cls, const float* pe, const int64_t* rows,
+                                   const int64_t* token_index, int64_t n_tok, float* seq, int64_t n, int64_t n_src, int nb,
+                                   int has_cls, int pe_len, int normalize, int64_t D, void* stream) {
   MDG_CHECK_ARG(D == 128, "mdg_assemble_tokens: D must be 128 (got %lld)", (long long)D);
   MDG_CHECK_ARG(n >= 0 && n_src >= 0 && nb >= 0 && nb <= 8, "mdg_assemble_tokens: bad sizes");
   if (n == 0) return MDG_OK;
@@ -263,22 +273,26 @@ extern "C" int mdg_assemble_tokens(const float* str_emb, const float* kg_emb, co
   MDG_CHECK_ARG((nb == 0 || bottleneck) && (!has_cls || cls) && (pe_len == 0 || pe), "mdg_assemble_tokens: missing token table");
   const int S = (has_cls ? 1 : 0) + 3 + nb + 16;
   MDG_CHECK_ARG(S <= 32 && pe_len <= S, "mdg_assemble_tokens: sequence of %d tokens exceeds 32", S);
-  AssembleArgs a{str_emb, kg_emb, cv_emb, tx_emb, bottleneck, cls, pe, rows, seq, n, n_src, nb, has_cls ? 1 : 0, pe_len, normalize};
-  hipLaunchKernelGGL(assemble_tokens_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n * S, 8))), dim3(256), 0,
+  AssembleArgs a{str_emb, kg_emb, cv_emb, tx_emb, bottleneck, cls, pe, rows, token_index, n_tok, seq, n, n_src, nb, has_cls ? 1 : 0, pe_len, normalize};
+  const int64_t slots = token_index ? n_tok : n * S;
+  if (slots == 0) return MDG_OK;
+  hipLaunchKernelGGL(assemble_tokens_kernel, dim3(static_cast<unsigned>(mdg_cdiv(slots, 8))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   MDG_CHECK_LAUNCH("mdg_assemble_tokens");
   return MDG_OK;
 }
 
 extern "C" int mdg_fusion_attention(const float* qkv, int64_t ld, float* out, int64_t ldo, const uint32_t* kpm_bits,
-                                    const uint32_t* src_bits, float* probs, int64_t n, int S, int H, int dh, void* stream) {
+                                    const uint32_t* src_bits, float* probs, const int64_t* row_start, const uint32_t* row_bits,
+                                    int64_t n, int S, int H, int dh, void* stream) {
   MDG_CHECK_ARG(n >= 0 && S >= 1 && S <= 32, "mdg_fusion_attention: S must be in [1,32] (got %d)", S);
   MDG_CHECK_ARG(H >= 1 && dh >= 8 && dh % 32 == 0 && dh <= 1024, "mdg_fusion_attention: head_dim must be a multiple of 32 (got %d)", dh);
   if (n == 0) return MDG_OK;
   MDG_CHECK_ARG(qkv && out, "mdg_fusion_attention: null pointer");
   MDG_CHECK_ARG(ld % 4 == 0 && ldo % 4 == 0 && ld >= 3 * H * dh && ldo >= H * dh && mdg_aligned16(qkv) && mdg_aligned16(out),
                 "mdg_fusion_attention: bad strides / alignment");
-  AttnArgs a{qkv, ld, out, ldo, kpm_bits, src_bits, probs, n, S, H, dh, 1.0f / sqrtf(static_cast<float>(dh))};
+  MDG_CHECK_ARG(!(row_start && probs), "mdg_fusion_attention: attention weights are only produced in dense mode");
+  AttnArgs a{qkv, ld, out, ldo, kpm_bits, src_bits, probs, row_start, row_bits, n, S, H, dh, 1.0f / sqrtf(static_cast<float>(dh))};
   hipLaunchKernelGGL(fusion_attention_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n * H, 4))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   MDG_CHECK_LAUNCH("mdg_fusion_attention");

@@ -7,9 +7,10 @@
 // residual add (nn.TransformerEncoderLayer, models.py:366), the GIN MLPs and the HGT projections.
 //
 // 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles of
-// 32x32), BK = 32.  Tiles are staged global -> registers -> LDS (double buffered, prefetch issued
-// before the MFMA phase); in the bf16 modes the fp32 operands are split hi/lo while they sit in
-// registers, so LDS holds ready-made MFMA fragments (ds_read_b128, XOR-swizzled => conflict free).
+// 32x32), BK = 32, two workgroups per CU.  A fused pre-pass writes both operands into the caller's
+// workspace with K zero-padded to a multiple of 32 and, in the bf16 modes, already split into hi/lo bf16
+// images, so the main loop is pure LDS-DMA (global_load_lds, swizzle on the source address) + ds_read_b128
+// + MFMA: no conversion VALU, no ds_write, one raw barrier and one vmcnt wait per k-tile.
 // Arithmetic modes as in the head: exact fp32 MFMA, bf16x3 (fp32-grade), bf16.
 #include "mdg_common.h"
 
@@ -18,17 +19,6 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
 constexpr int TILE_BYTES = BM * BK * 4;     // one operand, one stage: 16 KB (fp32) == hi 8 KB + lo 8 KB
 constexpr int LO_OFF = BM * BK * 2;
-
-struct LinearArgs {
-  const float* x; int64_t ldx;
-  const float* w; int64_t ldw;
-  float* y; int64_t ldy;
-  const float* bias; const float* scale; const float* shift;
-  const float* res; int64_t ldr;
-  float alpha, beta;
-  int act;
-  int64_t M, N, K;
-};
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
@@ -43,44 +33,61 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-// fp32 tile [128][32]: 128-B rows, 8 chunks; bf16 tile [128][32]: 64-B rows, 4 chunks.
+// fp32 tile [128][32]: 128-B rows, 8 chunks; bf16 tile [128][32]: 64-B rows, 4 chunks.  XOR swizzles chosen so
+// that the 16 lanes of a ds_read_b128 group (16 consecutive rows, same chunk) hit 16 distinct 16-B slots.
 __device__ __forceinline__ int off_f32(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int off_bf16(int row, int cb) { return row * 64 + ((cb ^ ((row >> 2) & 3)) << 4); }
 
-__device__ __forceinline__ void load_tile(const float* base, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, int64_t K,
-                                          int tid, f32x4 (&regs)[4]) {
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return static_cast<unsigned>(reinterpret_cast<size_t>((lds_void*)p)); }
+
+// LDS-DMA, 16 B per lane, LDS destination = wave-uniform base + lane*16 (inline asm: see bilinear.hip)
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst_uniform);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+
+// One operand tile (128 rows x 32 k) of stage k0 into LDS.  `base` is the operand image (fp32 [rows,ld] or one
+// bf16 hi/lo image [rows,ld]); rows past the end clamp to the last row (their results are never stored).
+template <int ESIZE>   // 4 = fp32 tile (8 rows per 1-KiB piece), 2 = bf16 tile (16 rows per piece)
+__device__ __forceinline__ void dma_tile(const char* base, int64_t ld_bytes, int64_t row0, int64_t nrows, int64_t k0, char* lds,
+                                         int wave, int lane) {
+  constexpr int PIECES = (ESIZE == 4) ? 16 : 8;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int g = tid + NT * i, row = g >> 3, c = g & 7;
+  for (int i = 0; i < PIECES / 4; ++i) {
+    const int p = wave + 4 * i;
+    int row, c;
+    if constexpr (ESIZE == 4) { row = 8 * p + (lane >> 3); c = (lane & 7) ^ ((row >> 1) & 7); }
+    else { row = 16 * p + (lane >> 2); c = (lane & 3) ^ ((row >> 2) & 3); }
     int64_t gr = row0 + row;
     gr = gr < nrows ? gr : nrows - 1;
-    const int64_t k = k0 + 4 * c;
-    const int64_t kk = k < K ? k : 0;             // keep the address in range; value is zeroed below
-    f32x4 v = *reinterpret_cast<const f32x4*>(base + gr * ld + kk);
-    if (k >= K) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    regs[i] = v;
+    glds16(base + gr * ld_bytes + k0 * ESIZE + c * 16, lds_addr(lds + p * 1024));
   }
 }
 
+struct Operand {          // fp32: p0 = image; bf16 modes: p0 = hi image, p1 = lo image
+  const char* p0;
+  const char* p1;
+  int64_t ld_bytes;
+  int64_t nrows;
+};
+
 template <int MODE>
-__device__ __forceinline__ void write_tile(char* lds, int tid, const f32x4 (&regs)[4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int g = tid + NT * i, row = g >> 3, c = g & 7;
-    if constexpr (MODE == MDG_PREC_F32) {
-      *reinterpret_cast<f32x4*>(lds + off_f32(row, c)) = regs[i];
-    } else {
-      bf16x4 hi, lo;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        __bf16 a, b;
-        mdg_split_bf16(regs[i][e], a, b);
-        hi[e] = a;
-        lo[e] = b;
-      }
-      const int o = off_bf16(row, c >> 1) + (c & 1) * 8;
-      *reinterpret_cast<bf16x4*>(lds + o) = hi;
-      if constexpr (MODE == MDG_PREC_BF16X3) *reinterpret_cast<bf16x4*>(lds + LO_OFF + o) = lo;
+__device__ __forceinline__ void dma_stage(const Operand& A, const Operand& B, int64_t row0, int64_t col0, int64_t k0, char* lds,
+                                          int wave, int lane) {
+  if constexpr (MODE == MDG_PREC_F32) {
+    dma_tile<4>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane);
+    dma_tile<4>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + TILE_BYTES, wave, lane);
+  } else {
+    dma_tile<2>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane);
+    dma_tile<2>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + TILE_BYTES, wave, lane);
+    if constexpr (MODE == MDG_PREC_BF16X3) {
+      dma_tile<2>(A.p1, A.ld_bytes, row0, A.nrows, k0, lds + LO_OFF, wave, lane);
+      dma_tile<2>(B.p1, B.ld_bytes, col0, B.nrows, k0, lds + TILE_BYTES + LO_OFF, wave, lane);
     }
   }
 }
@@ -132,6 +139,19 @@ __device__ __forceinline__ void mma_stage(const char* la, const char* lb, int wr
   }
 }
 
+struct LinearArgs {
+  Operand A, B;            // K is a multiple of 32 in both images (zero padded by the pre-pass when needed)
+  float* y; int64_t ldy;
+  const float* bias; const float* scale; const float* shift;
+  const float* res; int64_t ldr;
+  float alpha, beta;
+  int act;
+  int64_t M, N, K;
+};
+
+// Pipeline: one raw barrier per k-tile.  Top of tile kt: wait for this wave's DMA pieces of tile kt (the only
+// vector-memory ops in flight), barrier (=> every wave's pieces landed, every wave finished reading tile kt-1),
+// issue the DMA of tile kt+1 into the other buffer, then the MFMAs of tile kt run under that DMA.
 template <int MODE>
 __global__ __launch_bounds__(NT, 2) void linear_kernel(const LinearArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A tile | B tile]
@@ -147,23 +167,15 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(const LinearArgs p) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
 
-  const int nk = static_cast<int>((p.K + BK - 1) / BK);
-  f32x4 ra[4], rb[4];
-  load_tile(p.x, p.ldx, row0, p.M, 0, p.K, tid, ra);
-  load_tile(p.w, p.ldw, col0, p.N, 0, p.K, tid, rb);
-  write_tile<MODE>(smem, tid, ra);
-  write_tile<MODE>(smem + TILE_BYTES, tid, rb);
-  __syncthreads();
+  const int nk = static_cast<int>(p.K / BK);
+  dma_stage<MODE>(p.A, p.B, row0, col0, 0, smem, wave, lane);
   for (int kt = 0; kt < nk; ++kt) {
     char* const cur = smem + (kt & 1) * 2 * TILE_BYTES;
     char* const nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-    // unconditional prefetch (past the end k >= K zero-fills; the tile is never consumed)
-    load_tile(p.x, p.ldx, row0, p.M, static_cast<int64_t>(kt + 1) * BK, p.K, tid, ra);
-    load_tile(p.w, p.ldw, col0, p.N, static_cast<int64_t>(kt + 1) * BK, p.K, tid, rb);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) dma_stage<MODE>(p.A, p.B, row0, col0, static_cast<int64_t>(kt + 1) * BK, nxt, wave, lane);
     mma_stage<MODE>(cur, cur + TILE_BYTES, wr, wc, r, h, acc);
-    write_tile<MODE>(nxt, tid, ra);
-    write_tile<MODE>(nxt + TILE_BYTES, tid, rb);
-    __syncthreads();
   }
 
   // ---- epilogue: lane = output column, accumulator registers = rows ---------------------
@@ -191,6 +203,42 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(const LinearArgs p) {
     }
   }
 }
+
+// ---- pre-pass: both operands -> K padded to a multiple of 32 (zeros), split hi/lo bf16 or copied as fp32 ------
+// grid.y = 0: x rows, 1: w rows.  One thread per 4 consecutive k.
+struct PrepArgs {
+  const float* src[2]; int64_t ld[2]; int64_t rows[2];
+  char* dst0[2]; char* dst1[2];       // fp32 copy / bf16 hi ; bf16 lo (or null)
+  int64_t K, Kp;
+  int bf16;
+};
+
+__global__ __launch_bounds__(256) void prep_operands_kernel(const PrepArgs p) {
+  const int which = blockIdx.y;
+  const int64_t q = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;       // index of a 4-element group
+  const int64_t per_row = p.Kp / 4;
+  if (q >= p.rows[which] * per_row) return;
+  const int64_t row = q / per_row, k = (q % per_row) * 4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (k < p.K) v = *reinterpret_cast<const f32x4*>(p.src[which] + row * p.ld[which] + k);
+  if (p.bf16) {
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      __bf16 a, b;
+      mdg_split_bf16(v[e], a, b);
+      hi[e] = a;
+      lo[e] = b;
+    }
+    *reinterpret_cast<bf16x4*>(p.dst0[which] + (row * p.Kp + k) * 2) = hi;
+    if (p.dst1[which]) *reinterpret_cast<bf16x4*>(p.dst1[which] + (row * p.Kp + k) * 2) = lo;
+  } else {
+    *reinterpret_cast<f32x4*>(p.dst0[which] + (row * p.Kp + k) * 4) = v;
+  }
+}
+
+inline size_t al256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+inline int64_t pad32(int64_t k) { return (k + 31) / 32 * 32; }
 
 // ---- LayerNorm: one wave per row -------------------------------------------------------------
 template <int VEC>   // floats per lane = 4*VEC, d <= 256*VEC
@@ -239,9 +287,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 }  // namespace
 
+extern "C" size_t mdg_linear_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const size_t Kp = static_cast<size_t>(pad32(K));
+  if (precision == MDG_PREC_F32) return (K % 32 == 0) ? 0 : al256(static_cast<size_t>(M) * Kp * 4) + al256(static_cast<size_t>(N) * Kp * 4);
+  const size_t images = precision == MDG_PREC_BF16X3 ? 2 : 1;
+  return images * (al256(static_cast<size_t>(M) * Kp * 2) + al256(static_cast<size_t>(N) * Kp * 2));
+}
+
 extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, float* y, int64_t ldy, int64_t M, int64_t N,
                           int64_t K, const float* bias, const float* scale, const float* shift, int act, const float* residual,
-                          int64_t ldr, float alpha, float beta, int precision, void* stream) {
+                          int64_t ldr, float alpha, float beta, int precision, void* workspace, size_t workspace_bytes,
+                          void* stream) {
   MDG_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "mdg_linear: negative size");
   if (M == 0 || N == 0) return MDG_OK;
   MDG_CHECK_ARG(x && w && y, "mdg_linear: null pointer");
@@ -253,15 +310,42 @@ extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t l
   MDG_CHECK_ARG((scale == nullptr) == (shift == nullptr), "mdg_linear: scale and shift come together");
   MDG_CHECK_ARG(act >= MDG_ACT_NONE && act <= MDG_ACT_SELU, "mdg_linear: unknown activation %d", act);
   MDG_CHECK_ARG(mdg_cdiv(M, BM) <= 65535, "mdg_linear: M too large for one launch");
-  LinearArgs a{x, ldx, w, ldw, y, ldy, bias, scale, shift, residual, ldr, alpha, beta, act, M, N, K};
-  const dim3 grid(static_cast<unsigned>(mdg_cdiv(N, BN)), static_cast<unsigned>(mdg_cdiv(M, BM)));
+  MDG_CHECK_ARG(precision == MDG_PREC_F32 || precision == MDG_PREC_BF16X3 || precision == MDG_PREC_BF16, "mdg_linear: unknown precision %d", precision);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t need = mdg_linear_workspace_bytes(M, N, K, precision);
+  if (need && (!workspace || workspace_bytes < need || !mdg_aligned16(workspace))) {
+    mdg_set_error("mdg_linear: workspace of %zu bytes (16-byte aligned) required, got %zu", need, workspace_bytes);
+    return MDG_EWORKSPACE;
+  }
+  const int64_t Kp = pad32(K);
+  LinearArgs a{};
+  a.y = y; a.ldy = ldy; a.bias = bias; a.scale = scale; a.shift = shift; a.res = residual; a.ldr = ldr;
+  a.alpha = alpha; a.beta = beta; a.act = act; a.M = M; a.N = N; a.K = Kp;
+  a.A.nrows = M; a.B.nrows = N;
+  if (need == 0) {            // fp32, K already a multiple of 32: stage straight from the caller's tensors
+    a.A.p0 = reinterpret_cast<const char*>(x); a.A.ld_bytes = ldx * 4;
+    a.B.p0 = reinterpret_cast<const char*>(w); a.B.ld_bytes = ldw * 4;
+  } else {
+    char* ws = static_cast<char*>(workspace);
+    const bool bf = precision != MDG_PREC_F32, x3 = precision == MDG_PREC_BF16X3;
+    const size_t es = bf ? 2 : 4;
+    const size_t ab = al256(static_cast<size_t>(M) * Kp * es), bb = al256(static_cast<size_t>(N) * Kp * es);
+    PrepArgs pa{};
+    pa.src[0] = x; pa.ld[0] = ldx; pa.rows[0] = M; pa.src[1] = w; pa.ld[1] = ldw; pa.rows[1] = N;
+    pa.dst0[0] = ws; pa.dst0[1] = ws + ab;
+    pa.dst1[0] = x3 ? ws + ab + bb : nullptr; pa.dst1[1] = x3 ? ws + 2 * ab + bb : nullptr;
+    pa.K = K; pa.Kp = Kp; pa.bf16 = bf ? 1 : 0;
+    const int64_t groups = (M > N ? M : N) * (Kp / 4);
+    hipLaunchKernelGGL(prep_operands_kernel, dim3(static_cast<unsigned>(mdg_cdiv(groups, 256)), 2), dim3(256), 0, st, pa);
+    a.A.p0 = pa.dst0[0]; a.A.p1 = pa.dst1[0]; a.A.ld_bytes = Kp * static_cast<int64_t>(es);
+    a.B.p0 = pa.dst0[1]; a.B.p1 = pa.dst1[1]; a.B.ld_bytes = Kp * static_cast<int64_t>(es);
+  }
+  const dim3 grid(static_cast<unsigned>(mdg_cdiv(N, BN)), static_cast<unsigned>(mdg_cdiv(M, BM)));
   const size_t lds = 4 * TILE_BYTES;
   switch (precision) {
     case MDG_PREC_F32: hipLaunchKernelGGL(linear_kernel<MDG_PREC_F32>, grid, dim3(NT), lds, st, a); break;
     case MDG_PREC_BF16X3: hipLaunchKernelGGL(linear_kernel<MDG_PREC_BF16X3>, grid, dim3(NT), lds, st, a); break;
-    case MDG_PREC_BF16: hipLaunchKernelGGL(linear_kernel<MDG_PREC_BF16>, grid, dim3(NT), lds, st, a); break;
-    default: mdg_set_error("mdg_linear: unknown precision %d", precision); return MDG_EINVAL;
+    default: hipLaunchKernelGGL(linear_kernel<MDG_PREC_BF16>, grid, dim3(NT), lds, st, a); break;
   }
   MDG_CHECK_LAUNCH("mdg_linear");
   return MDG_OK;

@@ -79,15 +79,32 @@ _ACT_OF = {nn.ReLU: "relu", nn.LeakyReLU: "leakyrelu", nn.Tanh: "tanh", nn.Sigmo
            nn.Softplus: "softplus", nn.GELU: "gelu", nn.Identity: None}
 
 
+_derived = {}
+
+
+def _cached(owner, tag, tensors, build):
+    """Weights derived from parameters (folded BatchNorm, block-diagonal relation matrices, padded / augmented
+    matrices) are rebuilt only when one of the source tensors changed (data pointer or in-place version)."""
+    key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors if t is not None)
+    slot = _derived.setdefault(id(owner), {})
+    hit = slot.get(tag)
+    if hit is None or hit[0] != key:
+        hit = (key, build())
+        slot[tag] = hit
+    return hit[1]
+
+
 def _bn_scale_shift(bn: nn.BatchNorm1d):
     """Eval-mode BatchNorm as y = x * scale + shift."""
-    scale = torch.rsqrt(bn.running_var + bn.eps)
-    if bn.weight is not None:
-        scale = scale * bn.weight.detach()
-    shift = -bn.running_mean * scale
-    if bn.bias is not None:
-        shift = shift + bn.bias.detach()
-    return scale.contiguous(), shift.contiguous()
+    def build():
+        scale = torch.rsqrt(bn.running_var + bn.eps)
+        if bn.weight is not None:
+            scale = scale * bn.weight.detach()
+        shift = -bn.running_mean * scale
+        if bn.bias is not None:
+            shift = shift + bn.bias.detach()
+        return scale.contiguous(), shift.contiguous()
+    return _cached(bn, "affine", (bn.running_var, bn.running_mean, bn.weight, bn.bias), build)
 
 
 def _run_sequential(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
@@ -110,9 +127,11 @@ def _run_sequential(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
         elif isinstance(m, nn.Linear):
             w, b = m.weight.detach(), None if m.bias is None else m.bias.detach()
             if pre_affine is not None:          # W (s*x + t) + b = (W*s) x + (W t + b)
-                s, t = pre_affine
-                b = (w @ t) if b is None else b + w @ t
-                w = w * s.unsqueeze(0)
+                sc, sh = pre_affine
+
+                def fold(w=w, b=b, sc=sc, sh=sh):
+                    return (w * sc.unsqueeze(0)).contiguous(), ((w @ sh) if b is None else b + w @ sh).contiguous()
+                w, b = _cached(m, "prefold", (m.weight, m.bias, sc, sh), fold)
                 pre_affine = None
             j, scale, shift, act = i + 1, None, None, None
             if j < len(mods) and isinstance(mods[j], nn.BatchNorm1d):
@@ -235,9 +254,13 @@ class GraphIsomorphismNetwork(nn.Module):
                 if esum is None:       # per-atom sum of (weighted) bond features + weighted in-degree: layer independent
                     esum = ops.csr_aggregate(plan["edge_feat_aug"], plan["rowptr"], None, edge_weight=plan["w"])
                 fe = plan["edge_feat_dim"]
-                we = torch.zeros(agg.shape[1], esum.shape[1], device=h.device)
-                we[:k_in, :fe] = layer.edge_linear.weight.detach()
-                we[:k_in, fe] = layer.edge_linear.bias.detach()
+
+                def build(layer=layer, rows=agg.shape[1], cols=esum.shape[1], fe=fe, k_in=k_in, dev=h.device):
+                    we = torch.zeros(rows, cols, device=dev)
+                    we[:k_in, :fe] = layer.edge_linear.weight.detach()
+                    we[:k_in, fe] = layer.edge_linear.bias.detach()
+                    return we
+                we = _cached(layer.edge_linear, ("aug", agg.shape[1], esum.shape[1]), (layer.edge_linear.weight, layer.edge_linear.bias), build)
                 agg = _lin(esum, we, None, residual=agg)                 # + W_e sum_e(e_uv) + deg_v * b_e
             u = agg
             n_mlp = len(layer.mlp.layers)
@@ -313,21 +336,30 @@ class HGTConv(nn.Module):
         to K (scaled by p_rel[h]/sqrt(D)) and to V:  k' = k @ blockdiag(A_h)  ==  linear(k, blockdiag(A_h)^T)."""
         H, R = self.heads, len(self.edge_types)
         D = self.out_channels // H
-        idx = torch.arange(H, device=self.k_rel.weight.device) * R + r
-        pr = self.p_rel["__".join(et)].detach().view(H, 1, 1) / math.sqrt(D)
-        wk = torch.block_diag(*(self.k_rel.weight.detach()[idx] * pr).unbind(0)).t().contiguous()
-        wv = torch.block_diag(*self.v_rel.weight.detach()[idx].unbind(0)).t().contiguous()
-        return wk, wv
+        prel = self.p_rel["__".join(et)]
 
-    def forward(self, x_dict, edge_index_dict):
+        def build():
+            idx = torch.arange(H, device=self.k_rel.weight.device) * R + r
+            pr = prel.detach().view(H, 1, 1) / math.sqrt(D)
+            wk = torch.block_diag(*(self.k_rel.weight.detach()[idx] * pr).unbind(0)).t().contiguous()
+            wv = torch.block_diag(*self.v_rel.weight.detach()[idx].unbind(0)).t().contiguous()
+            return wk, wv
+        return _cached(self, ("rel", r), (self.k_rel.weight, self.v_rel.weight, prel), build)
+
+    def forward(self, x_dict, edge_index_dict, needed_types=None):
+        """``needed_types`` (extension): compute only these destination node types (the encoder reads
+        ['drug'] of the LAST conv only, models.py:729); default = every destination type, as PyG does."""
         _require_eval(self)
         F = self.out_channels
         dev = next(iter(x_dict.values())).device
         sizes = {t: int(x.shape[0]) for t, x in x_dict.items()}
         plan = self._plan(edge_index_dict, sizes, dev)
-        kqv = {t: _lin(x.float(), self.kqv_lin.lins[t].weight, self.kqv_lin.lins[t].bias) for t, x in x_dict.items()}
+        want = set(self.dst_node_types if needed_types is None else needed_types)
+        used = [et for et in plan["present"] if et[2] in want]
+        proj_types = want | {et[0] for et in used}
+        kqv = {t: _lin(x.float(), self.kqv_lin.lins[t].weight, self.kqv_lin.lins[t].bias) for t, x in x_dict.items() if t in proj_types}
         kv = torch.empty((max(plan["total_rows"], 1), 2 * F), dtype=torch.float32, device=dev)
-        for et in plan["present"]:
+        for et in used:
             r = self.edge_types.index(et)
             wk, wv = self._relation_weights(r, et)
             o, n_s = plan["offset"][et], sizes[et[0]]
@@ -336,7 +368,7 @@ class HGTConv(nn.Module):
             _lin(src[:, 2 * F:3 * F], wv, None, out=kv[o:o + n_s, F:2 * F])
         out = {}
         for t in self.node_types:
-            if t not in self.dst_node_types or t not in x_dict:
+            if t not in self.dst_node_types or t not in x_dict or t not in want:
                 continue
             agg = ops.hgt_attention(kqv[t][:, F:2 * F], kv, plan["per_dst"][t], self.heads, apply_gelu=True)
             lin = self.out_lin.lins[t]
@@ -358,11 +390,14 @@ class HGT(nn.Module):
             self.convs.append(HGTConv(hidden_channels, hidden_channels, metadata, num_heads, group=group))
         self.lin_dict = nn.ModuleDict({t: nn.Linear(hidden_channels, out_channels) for t in metadata[0]})
 
-    def forward(self, x_dict, edge_index_dict):
-        out = self.convs[0](x_dict, edge_index_dict)
+    def forward(self, x_dict, edge_index_dict, only_types=None):
+        """``only_types`` (extension): node types whose output the caller reads; the last conv and the final
+        Linear are then restricted to them (same values for those types)."""
+        last = len(self.convs) - 1
+        out = self.convs[0](x_dict, edge_index_dict, needed_types=only_types if last == 0 else None)
         for i in range(1, len(self.convs)):
-            out = self.convs[i](out, edge_index_dict)
-            if i < len(self.convs) - 1:
+            out = self.convs[i](out, edge_index_dict, needed_types=only_types if i == last else None)
+            if i < last:
                 out = {t: torch.relu_(x) for t, x in out.items()}
         return {t: _lin(x, self.lin_dict[t].weight, self.lin_dict[t].bias) for t, x in out.items()}
 
@@ -598,9 +633,53 @@ class TransformerFusion(nn.Module):
             self.x_attn_key_padding_mask = kpm
         self.last_attention_weights = None
 
+    # ---- one transformer layer on a set of token rows (dense or compact) --------------------
+    def _layer(self, L, h, attend, keep_rows=None):
+        """``attend(qkv) -> attention output rows``; ``keep_rows`` (int64 index) prunes the rows that
+        continue after the attention (last layer: only the pooled key tokens are ever read again)."""
+        sa = L.self_attn
+        if self.norm_first:
+            a = ops.layernorm(h, L.norm1.weight, L.norm1.bias, L.norm1.eps)
+            att = attend(_lin(a, sa.in_proj_weight, sa.in_proj_bias), a)
+            if keep_rows is not None:
+                att, h = att.index_select(0, keep_rows), h.index_select(0, keep_rows)
+            h = _lin(att, sa.out_proj.weight, sa.out_proj.bias, residual=h)
+            f = ops.layernorm(h, L.norm2.weight, L.norm2.bias, L.norm2.eps)
+            u = _lin(f, L.linear1.weight, L.linear1.bias, act=self.actn)
+            return _lin(u, L.linear2.weight, L.linear2.bias, residual=h)
+        att = attend(_lin(h, sa.in_proj_weight, sa.in_proj_bias), h)
+        if keep_rows is not None:
+            att, h = att.index_select(0, keep_rows), h.index_select(0, keep_rows)
+        t = _lin(att, sa.out_proj.weight, sa.out_proj.bias, residual=h)
+        h = ops.layernorm(t, L.norm1.weight, L.norm1.bias, L.norm1.eps)
+        u = _lin(h, L.linear1.weight, L.linear1.bias, act=self.actn)
+        t = _lin(u, L.linear2.weight, L.linear2.bias, residual=h)
+        return ops.layernorm(t, L.norm2.weight, L.norm2.bias, L.norm2.eps)
+
+    def _x_attn_pool(self, h_keys, n, Tk):
+        """Cross-attention pooling over the (already selected) key tokens h_keys [n*Tk, d] (models.py:422-443)."""
+        d, H, dh = self.latent_dim, self.num_heads, self.head_dim
+        mha = self.x_attn_mha_layer
+        kvn = ops.layernorm(h_keys, self.x_attn_kv_norm.weight, self.x_attn_kv_norm.bias, self.x_attn_kv_norm.eps)
+        w, b = mha.in_proj_weight.detach(), mha.in_proj_bias.detach()
+        kvp = _lin(kvn, w[d:], b[d:])                              # [n*Tk, 2d] = K|V
+        q = self.x_attn_query.detach()
+        if self.norm_first:
+            q = ops.layernorm(q, self.x_attn_query_norm.weight, self.x_attn_query_norm.bias, self.x_attn_query_norm.eps)
+        qp = _lin(q, w[:d], b[:d])
+        pooled = ops.xattn_pool(qp, kvp, n, Tk, H, dh)
+        o = _lin(pooled, mha.out_proj.weight, mha.out_proj.bias, residual=q.reshape(-1))        # + query (broadcast)
+        if not self.norm_first:
+            o = ops.layernorm(o, self.x_attn_query_norm.weight, self.x_attn_query_norm.bias, self.x_attn_query_norm.eps)
+        return _lin(o, self.latent2embed.weight, self.latent2embed.bias)
+
+    def _key_positions(self):
+        return (~self.x_attn_key_padding_mask[0]).nonzero().flatten().tolist()
+
     def forward(self, fusion_sequence, fusion_mask, src_mask=None):
-        """fusion_sequence [n,S,D] (batch-major, as the encoder passes it), fusion_mask bool [n,S]
-        (True = padding), src_mask bool [S,S] (True = not allowed) -> [n,D]."""
+        """Dense path, the reference's signature: fusion_sequence [n,S,D] (batch-major, as the encoder passes
+        it), fusion_mask bool [n,S] (True = padding), src_mask bool [S,S] (True = not allowed) -> [n,D].
+        Also produces the last layer's attention weights for forward hooks on ``layers[-1].self_attn``."""
         _require_eval(self)
         n, S, D = fusion_sequence.shape
         d, H, dh = self.latent_dim, self.num_heads, self.head_dim
@@ -608,57 +687,91 @@ class TransformerFusion(nn.Module):
         sbits = None if src_mask is None else ops.mask_bits(src_mask)
         h = _lin(fusion_sequence.reshape(n * S, D), self.embed2latent.weight, self.embed2latent.bias)
         layers = self.transformer_encoder.layers
-        probs = None
         for li, L in enumerate(layers):
             want = li == len(layers) - 1
-            sa = L.self_attn
-            if self.norm_first:
-                a = ops.layernorm(h, L.norm1.weight, L.norm1.bias, L.norm1.eps)
-                qkv = _lin(a, sa.in_proj_weight, sa.in_proj_bias)
+            seen = {}
+
+            def attend(qkv, x_in, want=want, seen=seen):
                 att, pr = ops.fusion_attention(qkv, n, S, H, dh, kbits, sbits, want_probs=want)
-                h = _lin(att, sa.out_proj.weight, sa.out_proj.bias, residual=h)
-                f = ops.layernorm(h, L.norm2.weight, L.norm2.bias, L.norm2.eps)
-                u = _lin(f, L.linear1.weight, L.linear1.bias, act=self.actn)
-                h = _lin(u, L.linear2.weight, L.linear2.bias, residual=h)
-            else:
-                qkv = _lin(h, sa.in_proj_weight, sa.in_proj_bias)
-                att, pr = ops.fusion_attention(qkv, n, S, H, dh, kbits, sbits, want_probs=want)
-                t = _lin(att, sa.out_proj.weight, sa.out_proj.bias, residual=h)
-                h = ops.layernorm(t, L.norm1.weight, L.norm1.bias, L.norm1.eps)
-                u = _lin(h, L.linear1.weight, L.linear1.bias, act=self.actn)
-                t = _lin(u, L.linear2.weight, L.linear2.bias, residual=h)
-                h = ops.layernorm(t, L.norm2.weight, L.norm2.bias, L.norm2.eps)
+                seen["att"], seen["pr"], seen["in"] = att, pr, x_in
+                return att
+            h = self._layer(L, h, attend)
             if want:
-                probs = pr
-                for hook in list(sa._forward_hooks.values()):       # analysis hooks expect (attn_out, weights)
-                    hook(sa, (a if self.norm_first else h,), (att, pr))
-        self.last_attention_weights = probs
+                self.last_attention_weights = seen["pr"]
+                for hook in list(L.self_attn._forward_hooks.values()):      # analysis hooks expect (attn_out, weights)
+                    hook(L.self_attn, (seen["in"],), (seen["att"], seen["pr"]))
         agg = self.transformer_agg
         if agg == 'x-attn':
-            mha = self.x_attn_mha_layer
-            keys = (~self.x_attn_key_padding_mask[0]).nonzero().flatten().tolist()
-            Tk = len(keys)
-            h3 = h.view(n, S * d)
-            kvn = torch.empty((n, Tk * d), dtype=torch.float32, device=h.device)
-            for t, s in enumerate(keys):                             # LayerNorm of the key tokens only
-                ops.layernorm(h3[:, s * d:(s + 1) * d], self.x_attn_kv_norm.weight, self.x_attn_kv_norm.bias,
-                              self.x_attn_kv_norm.eps, out=kvn[:, t * d:(t + 1) * d])
-            w, b = mha.in_proj_weight.detach(), mha.in_proj_bias.detach()
-            kvp = _lin(kvn.view(n * Tk, d), w[d:], b[d:])            # [n*Tk, 2d] = K|V
-            q = self.x_attn_query.detach()
-            if self.norm_first:
-                q = ops.layernorm(q, self.x_attn_query_norm.weight, self.x_attn_query_norm.bias, self.x_attn_query_norm.eps)
-            qp = _lin(q, w[:d], b[:d])
-            pooled = ops.xattn_pool(qp, kvp, n, Tk, H, dh)
-            o = _lin(pooled, mha.out_proj.weight, mha.out_proj.bias, residual=q.reshape(-1))      # + query (broadcast)
-            if not self.norm_first:
-                o = ops.layernorm(o, self.x_attn_query_norm.weight, self.x_attn_query_norm.bias, self.x_attn_query_norm.eps)
-            return _lin(o, self.latent2embed.weight, self.latent2embed.bias)
+            keys = self._key_positions()
+            h3 = h.view(n, S, d)
+            h_keys = h3[:, keys, :].reshape(n * len(keys), d) if len(keys) != S else h
+            return self._x_attn_pool(h_keys, n, len(keys))
         if agg == 'cls':
             return _lin(h.view(n, S * d)[:, :d], self.latent2embed.weight, self.latent2embed.bias)
         if agg in ('mean', 'max'):
             e = _lin(h, self.latent2embed.weight, self.latent2embed.bias).view(n, S, -1)
             return ops.token_pool(e, kbits, agg)
+        raise NotImplementedError(agg)
+
+    # ---- compact path: padded tokens are never materialised ----------------------------------
+    def supports_live_tokens(self) -> bool:
+        """Padded tokens cannot influence the result (they are masked as keys and never pooled) except when the
+        cross-attention pooling has no bottleneck: then its fixed key mask lets every token in, padding included
+        (models.py:382-385).  Forward hooks on the last attention need the dense [n,H,S,S] weights."""
+        if self.transformer_agg == 'x-attn' and self.num_tx_bottlenecks == 0:
+            return False
+        if self.transformer_agg == 'max':
+            return False
+        return len(self.transformer_encoder.layers[-1].self_attn._forward_hooks) == 0
+
+    def live_token_plan(self, fusion_mask: torch.Tensor, src_mask: Optional[torch.Tensor]) -> dict:
+        """Index plumbing for the compact path (torch ops on the device; one host sync for the row count)."""
+        n, S = fusion_mask.shape
+        live = ~fusion_mask
+        dev = live.device
+        counts = live.sum(1)
+        row_start = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(counts, 0, out=row_start[1:])
+        token_index = live.flatten().nonzero().flatten()
+        cidx = torch.cumsum(live.to(torch.int64), 1) - 1                                   # compact index inside the drug
+        row_bits = None
+        if src_mask is not None:
+            blocked = live.unsqueeze(1) & src_mask.unsqueeze(0)                            # [n, query, key]
+            bits = (blocked.to(torch.int64) << cidx.clamp_min(0).unsqueeze(1)).sum(-1)     # [n, S]
+            row_bits = bits.flatten().index_select(0, token_index).to(torch.int32).contiguous()
+        plan = {"n": n, "S": S, "row_start": row_start, "token_index": token_index, "row_bits": row_bits}
+        if self.transformer_agg == 'x-attn':
+            off = S - (NUM_MODALITIES + self.num_tx_bottlenecks)                           # 1 if a cls token leads
+            keys = torch.tensor([k + off for k in self._key_positions()], device=dev)
+            plan["key_rows"] = (row_start[:-1].unsqueeze(1) + cidx[:, keys]).flatten().contiguous()
+            plan["Tk"] = int(keys.numel())
+        elif self.transformer_agg == 'cls':
+            plan["key_rows"] = row_start[:-1].contiguous()
+        return plan
+
+    def forward_tokens(self, tokens: torch.Tensor, plan: dict) -> torch.Tensor:
+        """Same result as ``forward`` on the dense sequence, computed on the live token rows only
+        (tokens [R,D] in plan['token_index'] order)."""
+        _require_eval(self)
+        n, S, H, dh = plan["n"], plan["S"], self.num_heads, self.head_dim
+        h = _lin(tokens, self.embed2latent.weight, self.embed2latent.bias)
+        layers = self.transformer_encoder.layers
+        agg = self.transformer_agg
+
+        def attend(qkv, _x):
+            return ops.fusion_attention(qkv, n, S, H, dh, row_start=plan["row_start"], row_bits=plan["row_bits"])[0]
+        for li, L in enumerate(layers):
+            last = li == len(layers) - 1
+            keep = plan.get("key_rows") if (last and agg in ('x-attn', 'cls')) else None
+            h = self._layer(L, h, attend, keep_rows=keep)
+        self.last_attention_weights = None
+        if agg == 'x-attn':
+            return self._x_attn_pool(h, n, plan["Tk"])
+        if agg == 'cls':
+            return _lin(h, self.latent2embed.weight, self.latent2embed.bias)
+        if agg == 'mean':
+            e = _lin(h, self.latent2embed.weight, self.latent2embed.bias)
+            return ops.csr_aggregate(e, plan["row_start"], None, mean=True)
         raise NotImplementedError(agg)
 
 
@@ -798,6 +911,8 @@ class NovelDDIEncoder(nn.Module):
         self.uni_projector = MLPAdaptor(feat_dim, ph['proj_hidden_dims'], feat_dim, ph['proj_dropout'], ph['proj_norm'], ph['proj_actn'], ph['proj_order'])
         if fusion == 'transformer_uni_proj':
             self.uni_fuser = MLPAdaptor(feat_dim, ph['proj_hidden_dims'], feat_dim, ph['proj_dropout'], ph['proj_norm'], ph['proj_actn'], ph['proj_order'])
+        # run the fusion transformer on live (unmasked) tokens only: identical z, a fraction of the rows
+        self.live_tokens_only = True
 
     def set_cell_line_categories(self, cell_lines_lowercase) -> None:
         """Category order of the reference's sklearn OneHotEncoder (sorted unique names, models.py:648-649)."""
@@ -832,7 +947,7 @@ class NovelDDIEncoder(nn.Module):
         n, Dm = batch_drugs.shape[0], self.embed_dim
         str_out = self.str_encoder(batch_mols, batch_mols.node_feature.float())["graph_feature"]
         kg_data, kg_map = batch_kg['data'], batch_kg['drug_index_map']
-        kg_valid = self.kg_encoder(kg_data.x_dict, kg_data.edge_index_dict)['drug']
+        kg_valid = self.kg_encoder(kg_data.x_dict, kg_data.edge_index_dict, only_types=('drug',))['drug']
         # drugs absent from the KG get filler rows that are always masked (models.py:734-736); the size of the
         # table needs the largest drug id (the reference's .item() syncs here as well)
         filler = kwargs.get('kg_filler')
@@ -870,10 +985,7 @@ class NovelDDIEncoder(nn.Module):
             masks_f = batch_masks[rows]
         nb = self.num_tx_bottlenecks
         has_cls = self.transformer_agg == 'cls'
-        seq = ops.assemble_tokens(str_out, kg_out, cv_out, tx_out, bottleneck=self.tx_bottleneck_tokens if nb > 0 else None,
-                                  cls=self.cls if has_cls else None, pe=self.pos_encoder.table(), rows=rows,
-                                  normalize=self.normalize)
-        nf = seq.shape[0]
+        nf = n if rows is None else int(rows.numel())
         parts = []
         if has_cls:
             parts.append(torch.zeros(nf, 1, dtype=torch.bool, device=dev))
@@ -892,7 +1004,17 @@ class NovelDDIEncoder(nn.Module):
                 full = torch.zeros(S0 + 1, S0 + 1, dtype=torch.bool, device=dev)
                 full[1:, 1:] = src
                 src = full
-        z_f = self.transformer(seq, fusion_mask=kpm, src_mask=src) if nf > 0 else torch.zeros(0, Dm, device=dev)
+        tok_args = dict(bottleneck=self.tx_bottleneck_tokens if nb > 0 else None, cls=self.cls if has_cls else None,
+                        pe=self.pos_encoder.table(), rows=rows, normalize=self.normalize)
+        if nf == 0:
+            z_f = torch.zeros(0, Dm, device=dev)
+        elif self.live_tokens_only and self.transformer.supports_live_tokens():
+            plan = self.transformer.live_token_plan(kpm, src)
+            tokens = ops.assemble_tokens(str_out, kg_out, cv_out, tx_out, token_index=plan["token_index"], **tok_args)
+            z_f = self.transformer.forward_tokens(tokens, plan)
+        else:
+            seq = ops.assemble_tokens(str_out, kg_out, cv_out, tx_out, **tok_args)
+            z_f = self.transformer(seq, fusion_mask=kpm, src_mask=src)
         if self.fusion != 'transformer_uni_proj':
             return z_f
         z = torch.empty((n, Dm), dtype=torch.float32, device=dev)

@@ -193,11 +193,14 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     for nm, t in (("bias", bias), ("scale", scale), ("shift", shift)):
         if t is not None and (t.numel() != N or not t.is_cuda or t.dtype != torch.float32):
             raise ValueError(f"{nm}: expected fp32 cuda [{N}]")
+    prec = _prec(precision)
+    nbytes = lib().mdg_linear_workspace_bytes(_c64(M), _c64(N), _c64(K), _c(prec))
+    ws = _workspace(nbytes, x2.device)
     check(lib().mdg_linear(_ptr(x2), _c64(x2.stride(0)), _ptr(w), _c64(w.stride(0)), _ptr(out), _c64(out.stride(0)),
                            _c64(M), _c64(N), _c64(K), _ptr(None if bias is None else bias.detach().contiguous()),
                            _ptr(None if scale is None else scale.contiguous()), _ptr(None if shift is None else shift.contiguous()),
-                           _c(ACTS[act]), _ptr(residual), _c64(ldr), _f(alpha), _f(beta), _c(_prec(precision)), _stream(x2)),
-          "mdg_linear")
+                           _c(ACTS[act]), _ptr(residual), _c64(ldr), _f(alpha), _f(beta), _c(prec), _ptr(ws),
+                           ctypes.c_size_t(nbytes), _stream(x2)), "mdg_linear")
     return out.view(*lead, N) if len(lead) != 1 or lead[0] != M else out
 
 
@@ -228,8 +231,9 @@ def mask_bits(mask: torch.Tensor) -> torch.Tensor:
 
 
 def assemble_tokens(str_emb, kg_emb, cv_emb, tx_emb, *, bottleneck=None, cls=None, pe=None, rows=None,
-                    normalize=False) -> torch.Tensor:
-    """[n, S, 128] token sequence (see mdg_assemble_tokens).  tx_emb is [16*n_src,128], cell-line major."""
+                    normalize=False, token_index=None) -> torch.Tensor:
+    """[n, S, 128] token sequence (see mdg_assemble_tokens).  tx_emb is [16*n_src,128], cell-line major.
+    ``token_index`` (int64 [R], values drug*S + s of the live tokens): emit only those rows -> [R,128]."""
     forward_only(str_emb, kg_emb, cv_emb, tx_emb, bottleneck, cls, pe)
     s, k, c, t = (_f32_cuda(a, nm, 2) for a, nm in ((str_emb, "str"), (kg_emb, "kg"), (cv_emb, "cv"), (tx_emb, "tx")))
     n_src = s.shape[0]
@@ -239,27 +243,41 @@ def assemble_tokens(str_emb, kg_emb, cv_emb, tx_emb, *, bottleneck=None, cls=Non
     nb = 0 if bottleneck is None else int(bottleneck.shape[0])
     pe2 = None if pe is None else _f32_cuda(pe.detach().reshape(-1, pe.shape[-1]), "pe")
     S = (1 if cls is not None else 0) + 3 + nb + 16
-    seq = torch.empty((n, S, s.shape[1]), dtype=torch.float32, device=s.device)
+    if token_index is None:
+        seq = torch.empty((n, S, s.shape[1]), dtype=torch.float32, device=s.device)
+        n_tok = 0
+    else:
+        if token_index.dtype != torch.int64 or not token_index.is_cuda:
+            raise ValueError("token_index: int64 cuda tensor")
+        n_tok = int(token_index.numel())
+        seq = torch.empty((n_tok, s.shape[1]), dtype=torch.float32, device=s.device)
     check(lib().mdg_assemble_tokens(_ptr(s), _ptr(k), _ptr(c), _ptr(t),
                                     _ptr(None if bottleneck is None else bottleneck.detach().contiguous()),
                                     _ptr(None if cls is None else cls.detach().contiguous()), _ptr(pe2),
-                                    _ptr(None if rows is None else rows.contiguous()), _ptr(seq), _c64(n), _c64(n_src), _c(nb),
-                                    _c(0 if cls is None else 1), _c(0 if pe2 is None else pe2.shape[0]), _c(1 if normalize else 0),
-                                    _c64(s.shape[1]), _stream(s)), "mdg_assemble_tokens")
+                                    _ptr(None if rows is None else rows.contiguous()),
+                                    _ptr(None if token_index is None else token_index.contiguous()), _c64(n_tok), _ptr(seq), _c64(n),
+                                    _c64(n_src), _c(nb), _c(0 if cls is None else 1), _c(0 if pe2 is None else pe2.shape[0]),
+                                    _c(1 if normalize else 0), _c64(s.shape[1]), _stream(s)), "mdg_assemble_tokens")
     return seq
 
 
 def fusion_attention(qkv: torch.Tensor, n: int, S: int, H: int, dh: int, kpm_bits=None, src_bits=None,
-                     want_probs: bool = False):
-    """Self-attention core over [n*S, 3*H*dh] q|k|v rows -> ([n*S, H*dh], probs [n,H,S,S] | None)."""
+                     want_probs: bool = False, row_start: Optional[torch.Tensor] = None,
+                     row_bits: Optional[torch.Tensor] = None):
+    """Self-attention core over q|k|v rows -> (attention output rows, probs [n,H,S,S] | None).
+    Dense: qkv [n*S, 3*H*dh].  Compact (``row_start`` [n+1] int64): qkv holds only live token rows."""
     qkv = _f32_cuda(qkv, "qkv", 2)
     d = H * dh
-    if qkv.shape != (n * S, 3 * d):
-        raise ValueError(f"qkv: expected [{n * S},{3 * d}], got {tuple(qkv.shape)}")
-    out = torch.empty((n * S, d), dtype=torch.float32, device=qkv.device)
+    rows = n * S if row_start is None else qkv.shape[0]
+    if qkv.shape != (rows, 3 * d):
+        raise ValueError(f"qkv: expected [{rows},{3 * d}], got {tuple(qkv.shape)}")
+    if row_start is not None and (row_start.dtype != torch.int64 or row_start.numel() != n + 1 or want_probs):
+        raise ValueError("row_start: int64 [n+1]; attention weights need the dense layout")
+    out = torch.empty((rows, d), dtype=torch.float32, device=qkv.device)
     probs = torch.empty((n, H, S, S), dtype=torch.float32, device=qkv.device) if want_probs else None
     check(lib().mdg_fusion_attention(_ptr(qkv), _c64(qkv.stride(0)), _ptr(out), _c64(d), _ptr(kpm_bits), _ptr(src_bits), _ptr(probs),
-                                     _c64(n), _c(S), _c(H), _c(dh), _stream(qkv)), "mdg_fusion_attention")
+                                     _ptr(row_start), _ptr(row_bits), _c64(n), _c(S), _c(H), _c(dh), _stream(qkv)),
+          "mdg_fusion_attention")
     return out, probs
 
 

@@ -133,6 +133,15 @@ def test_encode_and_score_golden(M, golden, case, prec):
         z_raw = enc(b["drugs"], b["masks"], b["strs"], kgc, b["cv"], b["tx"], raw_encoder_output=True, kg_filler=filler)
         scores = model(b, b, b["masks"], b["masks"], kgc, kg_filler=filler)
         scores25 = model.decoder(z, z, (2, 5))
+        # the live-token (compact) fusion path and the dense path give the same embeddings
+        enc.live_tokens_only = False
+        z_dense = enc(b["drugs"], b["masks"], b["strs"], kgc, b["cv"], b["tx"], kg_filler=filler)
+        enc.live_tokens_only = True
+        kg_all = enc.kg_encoder(kgc["data"].x_dict, kgc["data"].edge_index_dict)           # un-pruned last conv
+    assert rel_err(z.cpu(), z_dense.cpu()) < (1e-6 if prec == "f32" else 2e-5)
+    assert rel_err(kg_all["drug"].cpu(), kg_out.cpu()) < 1e-6 and len(kg_all) == len(kgc["data"].x_dict)
+    with torch.no_grad():
+        pass
     for a, k in ((str_out, "str_out"), (kg_out, "kg_out"), (cv_out, "cv_out"), (z, "z"), (z_raw, "z_raw"), (scores, "scores"),
                  (scores25, "scores_2_5")):
         assert rel_err(a.cpu(), g[k]) < 2 * TOL[prec], k
