@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
 """Headline benchmark: drug-pair x outcome scores/sec for all-pairs scoring (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--drugs 4096] [--outcomes 896] [--precision bf16x3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--drugs 4096] [--outcomes 896]
+                    [--config twosides321] [--precision bf16x3] [--head-only]
 
-One "step" = one pass of the all-pairs bilinear head over every (head, tail, outcome) triple of the
-synthetic drug set, scores materialised as the reference does ([L, N, N] fp32, raw logits), with the
-inputs (z, W) already resident in HBM.  N GPUs: one process per GPU (torch.distributed over RCCL);
-the drug embeddings are sharded by rank and all-gathered over xGMI (the path's one exchange step),
-then every rank scores ITS OWN `--outcomes` outcomes against all N x N pairs (outcome-sharded head,
-SURVEY.md 8e): per-GPU work is fixed, so scaling is "weak" and the global outcome count is
-outcomes x n_gpus.  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path over one synthetic drug set, inputs resident in HBM:
+    encode + fuse every drug (GIN structure encoder, HGT over the whole KG, cv MLP, chemCPA tx encoder,
+    token assembly, fusion transformer)  ->  [all-gather of the embedding shards]  ->  symmetrise W  ->
+    all-pairs bilinear head, scores materialised as the reference does ([L, N, N] fp32 raw logits).
+This is BASELINE configs[1]/[3]: 4-modality model (TWOSIDES hyper-parameters, hardy_sweep_321), ~4k drugs,
+~900 outcomes, KG of 1.3e5 nodes / 8e6 directed edges.  value = scores produced per second.
+
+N GPUs: one process per GPU (torch.distributed over RCCL).  Drugs are sharded by rank for encode+fuse (the KG
+encoder is per-graph and replicated), the [N/G,128] embedding blocks are all-gathered over xGMI (the path's one
+exchange step), then every rank scores ITS OWN `--outcomes` outcomes against all N x N pairs (outcome-sharded
+head).  Per-GPU work is fixed => "scaling": "weak"; global outcomes = outcomes x n_gpus.
+Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -27,6 +33,25 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 FLOP_PER_SCORE = 256.0         # 2*D at D=128
 BYTES_PER_SCORE = 4.0          # fp32 score stored
+HEAD_KERNEL = {"f32": "bilinear_allpairs_kernel<0, 0, 8>", "bf16x3": "bilinear_allpairs_kernel<1, 0, 8>",
+               "bf16": "bilinear_allpairs_kernel<2, 0, 8>"}
+
+
+def pmc_traffic(n_drugs: int, n_outcomes: int, precision: str):
+    """HBM bytes per launch of the head kernel from the committed rocprofv3 PMC passes (WRITE_SIZE + 2 x
+    FETCH_SIZE, gfx950 correction), if a profile of exactly this workload exists under profiles/."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if w.get("drugs") == n_drugs and w.get("outcomes") == n_outcomes and w.get("precision") == precision:
+            for name, k in d.get("kernels", {}).items():
+                if "bilinear_allpairs_kernel" in name:
+                    return k.get("hbm_bytes_per_launch_corrected"), os.path.basename(f)
+    return None, None
 
 
 def cpu_baseline(n_drugs: int, n_outcomes: int, seconds: float = 12.0):
@@ -52,8 +77,9 @@ def cpu_baseline(n_drugs: int, n_outcomes: int, seconds: float = 12.0):
         times.append(time.perf_counter() - t0)
     med = sorted(times)[1]
     return {"value": rows * n_drugs * n_outcomes / med, "unit": "scores/s", "cores": cores, "kind": "port",
-            "sample": f"oracle bilinear_scores on {rows} head rows x {n_drugs} tail drugs x {n_outcomes} outcomes "
-                      f"(fp32 torch CPU, {cores} threads), median of 3, extrapolated linearly in rows"}
+            "sample": f"oracle bilinear_scores (the scoring stage only: encode is amortised over N^2 L scores) on {rows} head "
+                      f"rows x {n_drugs} tail drugs x {n_outcomes} outcomes, fp32 torch CPU, {cores} threads, median of 3, "
+                      f"extrapolated linearly in rows"}
 
 
 def main():
@@ -63,14 +89,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--drugs", type=int, default=4096)
     ap.add_argument("--outcomes", type=int, default=896)
+    ap.add_argument("--config", default="twosides321", choices=["twosides321", "twosides105", "drugbank163"])
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
+    ap.add_argument("--kg-nodes", type=int, default=130000)
+    ap.add_argument("--kg-edges", type=int, default=8000000)
+    ap.add_argument("--head-only", action="store_true", help="time the scoring stage alone (embeddings given)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from madrigal_amd import ops
-    from madrigal_amd.parallel import shard_range
+    from madrigal_amd import configs, data as D, models as M, ops
+    from madrigal_amd.parallel import all_gather_rows, shard_range
+    from madrigal_amd.pipeline import generate_embeddings
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -84,28 +115,48 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     N, L = args.drugs, args.outcomes
-    g = torch.Generator().manual_seed(0)
-    z_all = torch.randn(N, 128, generator=g)
-    lo, hi = shard_range(N, rank, world)
-    z_shard = z_all[lo:hi].to(dev)                                     # this rank's drug embeddings
-    gw = torch.Generator().manual_seed(1000 + rank)
-    w_orig = (torch.randn(L, 128, 128, generator=gw) / 128 ** 0.5).to(dev)   # this rank's outcomes
+    M.set_precision(args.precision)
     out = torch.empty(L, N, N, dtype=torch.float32, device=dev)
-    w_sym = torch.empty_like(w_orig)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if args.head_only:
+        g = torch.Generator().manual_seed(0)
+        z_all = torch.randn(N, 128, generator=g)
+        lo, hi = shard_range(N, rank, world)
+        z_shard = z_all[lo:hi].to(dev)
+        w_orig = (torch.randn(L, 128, 128, generator=torch.Generator().manual_seed(1000 + rank)) / 128 ** 0.5).to(dev)
+        w_sym = torch.empty_like(w_orig)
+        model = None
+    else:
+        # same synthetic batch on every rank (seeded); each rank encodes only its drug block
+        batch, bkg = D.make_batch(N, 0, kg_nodes=args.kg_nodes, kg_edges=args.kg_edges)
+        torch.manual_seed(1234)                       # identical encoder weights on every rank
+        model = configs.build_model(args.config, bkg["data"], L)
+        with torch.no_grad():                         # this rank's own outcomes
+            model.decoder.parametrizations.weight.original.copy_(
+                torch.randn(L, 128, 128, generator=torch.Generator().manual_seed(1000 + rank)) / 128 ** 0.5)
+        model = model.to(dev).eval()
+        batch = D.batch_to(batch, dev)
+        bkg = {"data": bkg["data"].to(dev), "drug_index_map": bkg["drug_index_map"].to(dev)}
+        filler = torch.randn(N, 128, device=dev)       # rows of drugs absent from the KG (always masked)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
 
+    @torch.no_grad()
     def step(i=None):
-        if world > 1:
-            from madrigal_amd.parallel import all_gather_rows
-            z = all_gather_rows(z_shard, N, rank, world)
-        else:
-            z = z_shard
-        ops.symmetrize(w_orig, out=w_sym)
         if i is not None:
             ev[i][0].record()
-        ops.bilinear_allpairs(z, z, w_sym, precision=args.precision, out=out)
+        if args.head_only:
+            z = all_gather_rows(z_shard, N, rank, world) if world > 1 else z_shard
+            ops.symmetrize(w_orig, out=w_sym)
+            if i is not None:
+                ev[i][1].record()
+            ops.bilinear_allpairs(z, z, w_sym, precision=args.precision, out=out)
+        else:
+            z = generate_embeddings(model, batch, bkg, rank=rank, world=world, kg_filler=filler)
+            model.decoder.symmetric_weight()          # W_sym (cached until the parameter changes)
+            if i is not None:
+                ev[i][1].record()
+            model.decoder(z, z, out=out)
         if i is not None:
-            ev[i][1].record()
+            ev[i][2].record()
 
     for _ in range(args.warmup):
         step()
@@ -125,32 +176,38 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    scores_per_step = float(L) * N * N * world
-    value = scores_per_step * args.steps / dt
+    enc_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+    head_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps     # head launch (+ its two operand-split pre-passes)
+    value = float(L) * N * N * world * args.steps / dt
     if rank == 0:
-        per_launch_scores = float(L) * N * N
+        per_launch = float(L) * N * N
+        traffic, traffic_src = pmc_traffic(N, L, args.precision)
         if args.precision == "f32":
-            achieved = per_launch_scores * FLOP_PER_SCORE / (kern_ms * 1e-3) / 1e12
+            achieved = per_launch * FLOP_PER_SCORE / (head_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                    "kernel": "bilinear_allpairs_kernel<f32,store>", "kernel_ms": kern_ms}
+                    "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic}
         else:
-            achieved = per_launch_scores * BYTES_PER_SCORE / (kern_ms * 1e-3) / 1e9
+            achieved = per_launch * BYTES_PER_SCORE / (head_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": f"bilinear_allpairs_kernel<{args.precision},store>", "kernel_ms": kern_ms,
-                    "mfma_frac_bf16": per_launch_scores * FLOP_PER_SCORE * (3 if args.precision == 'bf16x3' else 1)
-                    / (kern_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
-        line = {"metric": "drug-pair x outcome scores/sec (all-pairs)", "value": value, "unit": "scores/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else
-                ("bf16x3(f32-grade)" if args.precision == "bf16x3" else "bf16"), "data": "synthetic",
-                "config": {"workload": f"all-pairs bilinear head, {N} drugs x {N} drugs x {L} outcomes per GPU "
-                                       f"([L,N,N] fp32 logits materialised in HBM); BASELINE configs[1]/[3] shape",
-                           "drugs": N, "outcomes_per_gpu": L, "outcomes_total": L * world, "feature_dim": 128,
-                           "precision": args.precision,
-                           "parallelism": "single GPU" if world == 1 else f"drug-sharded encode + all-gather(z) over RCCL, outcome-sharded head x{world}"},
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "mfma_frac_bf16": per_launch * FLOP_PER_SCORE * (3 if args.precision == "bf16x3" else 1)
+                    / (head_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+        roof.update({"kernel": HEAD_KERNEL[args.precision], "kernel_ms": head_ms, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": per_launch * BYTES_PER_SCORE,
+                     "head_only_scores_per_s": per_launch / (head_ms * 1e-3), "encode_fuse_ms": enc_ms})
+        wl = (f"all-pairs bilinear head only, {N} x {N} drugs x {L} outcomes per GPU" if args.head_only else
+              f"all-pairs inference, whole job per step: encode+fuse {N} drugs (4 modalities, {args.config}: GIN + HGT over a "
+              f"{args.kg_nodes}-node / {args.kg_edges}-edge KG + cv MLP + chemCPA tx, fusion transformer) then score {N} x {N} "
+              f"pairs x {L} outcomes per GPU, [L,N,N] fp32 logits materialised in HBM; BASELINE configs[1]/[3]")
+        line = {"metric": "drug-pair x outcome scores/sec (all-pairs)", "value": value, "unit": "scores/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None,
+                "dtype": {"f32": "f32", "bf16x3": "f32 via split-bf16 (bf16x3) MFMA", "bf16": "bf16"}[args.precision],
+                "data": "synthetic",
+                "config": {"workload": wl, "drugs": N, "outcomes_per_gpu": L, "outcomes_total": L * world, "feature_dim": 128,
+                           "model": None if args.head_only else args.config, "precision": args.precision,
+                           "parallelism": "single GPU" if world == 1 else
+                           f"drug-sharded encode+fuse, all-gather(z) over RCCL, outcome-sharded head x{world}"},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, L)

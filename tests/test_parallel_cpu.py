@@ -66,3 +66,47 @@ def test_gloo_world2_allgather_and_outcome_shards(n):
         p.join(120)
         assert p.exitcode == 0
     assert ret[0] and ret[1]
+
+
+def _enc_worker(rank, world, port, n, ret):
+    """Drug-sharded generate_embeddings == full-batch result.  The per-drug 'encoder' here is the oracle's GIN
+    read-out (CPU test infrastructure standing in for the HIP encoder): it exercises slice_batch /
+    slice_molecules re-indexing and the uneven all-gather."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from madrigal_amd import data as D
+    from madrigal_amd.pipeline import generate_embeddings
+    from oracle import madrigal_oracle as O
+    from oracle.params import det_state_dict
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__)))
+    from helpers import gin_shapes
+    p = det_state_dict(3, gin_shapes())
+
+    class Enc(torch.nn.Module):
+        def forward(self, drugs, masks, mols, kg, cv, tx, kg_filler=None):
+            g = O.gin_forward(p, mols.node_feature, mols.edge_list, mols.edge_feature, mols.node2graph, mols.batch_size,
+                              num_layers=4, num_mlp_layer=3)["graph_feature"]
+            return g + cv[:, :128] + tx["a375"]["sigs"][:, :128] + drugs.float().unsqueeze(1) * 1e-3
+
+    class Model:
+        encoder = Enc()
+    batch, bkg = D.make_batch(n, 5, kg_nodes=100, kg_edges=300)
+    full = Model.encoder(batch["drugs"], batch["masks"], batch["strs"], bkg, batch["cv"], batch["tx"])
+    z = generate_embeddings(Model, batch, bkg, rank=rank, world=world)
+    ret[rank] = bool(torch.allclose(z, full, rtol=1e-5, atol=1e-5)) and z.shape == full.shape
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [10, 7])
+def test_gloo_world2_sharded_encode_matches_full_batch(n):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_enc_worker, args=(r, 2, port, n, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert ret[0] and ret[1]
