@@ -94,12 +94,17 @@ int mdg_bilinear_allpairs(const float* z_head, const float* z_tail, const float*
  * madrigal/chemcpa/chemCPA/model.py:226-231; nn.TransformerEncoderLayer linears models.py:366;
  * embed2latent / latent2embed models.py:411,443; GIN and HGT projections (third-party wheels).
  * K, ldx, ldw multiples of 4 (zero-pad the inner dimension), x and w 16-byte aligned.  ldr == 0 broadcasts one
- * residual row.  workspace: scratch for the operand images (K padded to 32, hi/lo bf16 split), sized by
- * mdg_linear_workspace_bytes (0 for MDG_PREC_F32 with K % 32 == 0). */
-size_t mdg_linear_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision);
-int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K,
-               const float* bias, const float* scale, const float* shift, int activation, const float* residual, int64_t ldr,
-               float alpha, float beta, int precision, void* workspace, size_t workspace_bytes, void* stream);
+ * residual row.  The kernel stages "operand images" (K zero-padded to 32; bf16 modes: hi [+ lo] bf16 planes): the
+ * image of x (and of w unless w_packed is given) is written into `workspace` by a fused pre-pass; a weight that is
+ * reused can be packed once with mdg_pack_operand and passed as w_packed (w may then be NULL). */
+size_t mdg_pack_operand_bytes(int64_t rows, int64_t K, int precision);        /* 0: the raw fp32 tensor is used as is */
+int mdg_pack_operand(const float* src, int64_t ld, int64_t rows, int64_t K, int precision, void* dst, size_t dst_bytes,
+                     void* stream);
+size_t mdg_linear_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision, int w_is_packed);
+int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const void* w_packed, float* y, int64_t ldy, int64_t M,
+               int64_t N, int64_t K, const float* bias, const float* scale, const float* shift, int activation,
+               const float* residual, int64_t ldr, float alpha, float beta, int precision, void* workspace,
+               size_t workspace_bytes, void* stream);
 
 /* Row-wise LayerNorm (nn.LayerNorm, biased variance): y = (x - mean) / sqrt(var + eps) * gamma + beta.
  * norm1/norm2 and the x-attn norms of the fusion transformer, models.py:366,372-373; LayerNorm inside
@@ -162,7 +167,8 @@ size_t mdg_hgt_attention_workspace_bytes(int64_t n_items, int heads);
 
 /* HGT edge attention + aggregation for one destination node type: per-head softmax over ALL incoming edges
  * of a node (every edge type), weighted sum of relation-transformed values, optional GELU.
- * q [n_dst, ldq>=128]; kv [rows, ldkv>=256] = k'|v' (relation transforms and p_rel/sqrt(D) already applied);
+ * q [n_dst, ldq>=128]; edge e reads k' at kv + col[e]*ldkv and v' 128 floats later (relation transforms and
+ * p_rel/sqrt(D) already applied; ldkv >= 128, with ldkv == 128 the value is simply the next row);
  * col[e] = kv row of edge e, edges sorted by destination; work items (item_dst, item_begin, item_end) split
  * long destination rows, item_ptr [n_dst+1] = items of each destination.
  * Replaces PyG HGTConv.propagate/message (edge softmax + scatter-add) behind models.py:76-79,90-94. */

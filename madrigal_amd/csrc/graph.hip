@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void csr_aggregate_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------
 struct HgtArgs {
   const float* q; int64_t ldq;          // [n_dst, >=128]
-  const float* kv; int64_t ldkv;        // [n_rows, >=256]: k' at +0, v' at +128
+  const float* kv; int64_t ldkv;        // row col[e]: k' at +0 and v' at +128 floats (ldkv 128: v' is the next row)
   const int64_t* col;                   // [nnz] row of kv per edge, sorted by destination
   const int64_t* item_dst; const int64_t* item_begin; const int64_t* item_end;   // [n_items]
   float* part_acc;                      // [n_items,128]
@@ -216,7 +216,7 @@ extern "C" int mdg_hgt_attention(const float* q, int64_t ldq, const float* kv, i
   MDG_CHECK_ARG(n_dst >= 0 && n_items >= 0, "mdg_hgt_attention: negative size");
   if (n_dst == 0) return MDG_OK;
   MDG_CHECK_ARG(q && out && item_ptr && (n_items == 0 || (kv && col && item_dst && item_begin && item_end)), "mdg_hgt_attention: null pointer");
-  MDG_CHECK_ARG(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && ldq >= 128 && ldkv >= 256 && ldo >= 128, "mdg_hgt_attention: bad strides");
+  MDG_CHECK_ARG(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && ldq >= 128 && ldkv >= 128 && ldo >= 128, "mdg_hgt_attention: bad strides");
   MDG_CHECK_ARG(mdg_aligned16(q) && mdg_aligned16(out) && (!kv || mdg_aligned16(kv)), "mdg_hgt_attention: 16-byte alignment");
   const size_t need = mdg_hgt_attention_workspace_bytes(n_items, heads);
   if (need && (!workspace || workspace_bytes < need || !mdg_aligned16(workspace))) {

@@ -287,59 +287,97 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" size_t mdg_linear_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision) {
-  if (M <= 0 || N <= 0 || K <= 0) return 0;
+static size_t image_bytes(int64_t rows, int64_t K, int precision) {
+  if (rows <= 0 || K <= 0) return 0;
   const size_t Kp = static_cast<size_t>(pad32(K));
-  if (precision == MDG_PREC_F32) return (K % 32 == 0) ? 0 : al256(static_cast<size_t>(M) * Kp * 4) + al256(static_cast<size_t>(N) * Kp * 4);
-  const size_t images = precision == MDG_PREC_BF16X3 ? 2 : 1;
-  return images * (al256(static_cast<size_t>(M) * Kp * 2) + al256(static_cast<size_t>(N) * Kp * 2));
+  if (precision == MDG_PREC_F32) return (K % 32 == 0) ? 0 : al256(static_cast<size_t>(rows) * Kp * 4);
+  return (precision == MDG_PREC_BF16X3 ? 2 : 1) * al256(static_cast<size_t>(rows) * Kp * 2);
 }
 
-extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, float* y, int64_t ldy, int64_t M, int64_t N,
-                          int64_t K, const float* bias, const float* scale, const float* shift, int act, const float* residual,
-                          int64_t ldr, float alpha, float beta, int precision, void* workspace, size_t workspace_bytes,
-                          void* stream) {
+static void launch_prep(const float* s0, int64_t ld0, int64_t rows0, char* dst0, const float* s1, int64_t ld1, int64_t rows1,
+                        char* dst1, int64_t K, int precision, hipStream_t st) {
+  const int64_t Kp = pad32(K);
+  const bool bf = precision != MDG_PREC_F32, x3 = precision == MDG_PREC_BF16X3;
+  const size_t es = bf ? 2 : 4;
+  PrepArgs pa{};
+  pa.src[0] = s0; pa.ld[0] = ld0; pa.rows[0] = rows0; pa.dst0[0] = dst0;
+  pa.dst1[0] = (x3 && dst0) ? dst0 + al256(static_cast<size_t>(rows0) * Kp * es) : nullptr;
+  pa.src[1] = s1; pa.ld[1] = ld1; pa.rows[1] = s1 ? rows1 : 0; pa.dst0[1] = dst1;
+  pa.dst1[1] = (x3 && dst1) ? dst1 + al256(static_cast<size_t>(rows1) * Kp * es) : nullptr;
+  pa.K = K; pa.Kp = Kp; pa.bf16 = bf ? 1 : 0;
+  const int64_t groups = (rows0 > pa.rows[1] ? rows0 : pa.rows[1]) * (Kp / 4);
+  hipLaunchKernelGGL(prep_operands_kernel, dim3(static_cast<unsigned>(mdg_cdiv(groups, 256)), s1 ? 2 : 1), dim3(256), 0, st, pa);
+}
+
+static void set_operand(Operand& o, const float* raw, int64_t ld, const char* image, int64_t rows, int64_t K, int precision) {
+  const int64_t Kp = pad32(K);
+  o.nrows = rows;
+  if (!image) { o.p0 = reinterpret_cast<const char*>(raw); o.p1 = nullptr; o.ld_bytes = ld * 4; return; }
+  const size_t es = precision == MDG_PREC_F32 ? 4 : 2;
+  o.p0 = image;
+  o.p1 = precision == MDG_PREC_BF16X3 ? image + al256(static_cast<size_t>(rows) * Kp * es) : nullptr;
+  o.ld_bytes = Kp * static_cast<int64_t>(es);
+}
+
+extern "C" size_t mdg_pack_operand_bytes(int64_t rows, int64_t K, int precision) { return image_bytes(rows, K, precision); }
+
+extern "C" int mdg_pack_operand(const float* src, int64_t ld, int64_t rows, int64_t K, int precision, void* dst, size_t dst_bytes,
+                                void* stream) {
+  MDG_CHECK_ARG(rows >= 0 && K > 0 && K % 4 == 0 && ld % 4 == 0 && ld >= K, "mdg_pack_operand: K and ld must be multiples of 4, ld >= K");
+  const size_t need = image_bytes(rows, K, precision);
+  if (need == 0) return MDG_OK;
+  MDG_CHECK_ARG(src && mdg_aligned16(src), "mdg_pack_operand: src must be 16-byte aligned");
+  if (!dst || dst_bytes < need || !mdg_aligned16(dst)) {
+    mdg_set_error("mdg_pack_operand: destination of %zu bytes required, got %zu", need, dst_bytes);
+    return MDG_EWORKSPACE;
+  }
+  launch_prep(src, ld, rows, static_cast<char*>(dst), nullptr, 0, 0, nullptr, K, precision, static_cast<hipStream_t>(stream));
+  MDG_CHECK_LAUNCH("mdg_pack_operand");
+  return MDG_OK;
+}
+
+extern "C" size_t mdg_linear_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision, int w_is_packed) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return image_bytes(M, K, precision) + (w_is_packed ? 0 : image_bytes(N, K, precision));
+}
+
+extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const void* w_packed, float* y, int64_t ldy,
+                          int64_t M, int64_t N, int64_t K, const float* bias, const float* scale, const float* shift, int act,
+                          const float* residual, int64_t ldr, float alpha, float beta, int precision, void* workspace,
+                          size_t workspace_bytes, void* stream) {
   MDG_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "mdg_linear: negative size");
   if (M == 0 || N == 0) return MDG_OK;
-  MDG_CHECK_ARG(x && w && y, "mdg_linear: null pointer");
-  MDG_CHECK_ARG(K > 0 && K % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0 && ldx >= K && ldw >= K,
+  MDG_CHECK_ARG(x && (w || w_packed) && y, "mdg_linear: null pointer");
+  MDG_CHECK_ARG(K > 0 && K % 4 == 0 && ldx % 4 == 0 && ldx >= K && (w_packed || (ldw % 4 == 0 && ldw >= K)),
                 "mdg_linear: K, ldx, ldw must be multiples of 4 with ld >= K (K=%lld ldx=%lld ldw=%lld); zero-pad the inner dimension",
                 (long long)K, (long long)ldx, (long long)ldw);
-  MDG_CHECK_ARG(mdg_aligned16(x) && mdg_aligned16(w), "mdg_linear: x and w must be 16-byte aligned");
+  MDG_CHECK_ARG(mdg_aligned16(x) && (!w || mdg_aligned16(w)) && (!w_packed || mdg_aligned16(w_packed)), "mdg_linear: x, w, w_packed must be 16-byte aligned");
   MDG_CHECK_ARG(ldy >= N && (!residual || ldr >= N || ldr == 0), "mdg_linear: ldy/ldr smaller than N (ldr == 0 broadcasts one row)");
   MDG_CHECK_ARG((scale == nullptr) == (shift == nullptr), "mdg_linear: scale and shift come together");
   MDG_CHECK_ARG(act >= MDG_ACT_NONE && act <= MDG_ACT_SELU, "mdg_linear: unknown activation %d", act);
   MDG_CHECK_ARG(mdg_cdiv(M, BM) <= 65535, "mdg_linear: M too large for one launch");
   MDG_CHECK_ARG(precision == MDG_PREC_F32 || precision == MDG_PREC_BF16X3 || precision == MDG_PREC_BF16, "mdg_linear: unknown precision %d", precision);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const size_t need = mdg_linear_workspace_bytes(M, N, K, precision);
+  const size_t xb = image_bytes(M, K, precision), wb = image_bytes(N, K, precision);
+  const bool w_ready = w_packed != nullptr || wb == 0;      // fp32 with K % 32 == 0 needs no image at all
+  MDG_CHECK_ARG(w || w_ready, "mdg_linear: raw w missing");
+  const size_t need = xb + (w_ready ? 0 : wb);
   if (need && (!workspace || workspace_bytes < need || !mdg_aligned16(workspace))) {
     mdg_set_error("mdg_linear: workspace of %zu bytes (16-byte aligned) required, got %zu", need, workspace_bytes);
     return MDG_EWORKSPACE;
   }
-  const int64_t Kp = pad32(K);
+  char* ws = static_cast<char*>(workspace);
+  char* ximg = xb ? ws : nullptr;
+  char* wimg = w_ready ? nullptr : ws + xb;
+  if (ximg || wimg) {
+    if (ximg) launch_prep(x, ldx, M, ximg, wimg ? w : nullptr, ldw, N, wimg, K, precision, st);
+    else launch_prep(w, ldw, N, wimg, nullptr, 0, 0, nullptr, K, precision, st);
+  }
   LinearArgs a{};
   a.y = y; a.ldy = ldy; a.bias = bias; a.scale = scale; a.shift = shift; a.res = residual; a.ldr = ldr;
-  a.alpha = alpha; a.beta = beta; a.act = act; a.M = M; a.N = N; a.K = Kp;
-  a.A.nrows = M; a.B.nrows = N;
-  if (need == 0) {            // fp32, K already a multiple of 32: stage straight from the caller's tensors
-    a.A.p0 = reinterpret_cast<const char*>(x); a.A.ld_bytes = ldx * 4;
-    a.B.p0 = reinterpret_cast<const char*>(w); a.B.ld_bytes = ldw * 4;
-  } else {
-    char* ws = static_cast<char*>(workspace);
-    const bool bf = precision != MDG_PREC_F32, x3 = precision == MDG_PREC_BF16X3;
-    const size_t es = bf ? 2 : 4;
-    const size_t ab = al256(static_cast<size_t>(M) * Kp * es), bb = al256(static_cast<size_t>(N) * Kp * es);
-    PrepArgs pa{};
-    pa.src[0] = x; pa.ld[0] = ldx; pa.rows[0] = M; pa.src[1] = w; pa.ld[1] = ldw; pa.rows[1] = N;
-    pa.dst0[0] = ws; pa.dst0[1] = ws + ab;
-    pa.dst1[0] = x3 ? ws + ab + bb : nullptr; pa.dst1[1] = x3 ? ws + 2 * ab + bb : nullptr;
-    pa.K = K; pa.Kp = Kp; pa.bf16 = bf ? 1 : 0;
-    const int64_t groups = (M > N ? M : N) * (Kp / 4);
-    hipLaunchKernelGGL(prep_operands_kernel, dim3(static_cast<unsigned>(mdg_cdiv(groups, 256)), 2), dim3(256), 0, st, pa);
-    a.A.p0 = pa.dst0[0]; a.A.p1 = pa.dst1[0]; a.A.ld_bytes = Kp * static_cast<int64_t>(es);
-    a.B.p0 = pa.dst0[1]; a.B.p1 = pa.dst1[1]; a.B.ld_bytes = Kp * static_cast<int64_t>(es);
-  }
+  a.alpha = alpha; a.beta = beta; a.act = act; a.M = M; a.N = N; a.K = pad32(K);
+  set_operand(a.A, x, ldx, ximg, M, K, precision);
+  set_operand(a.B, w, ldw, wb == 0 ? nullptr : (w_packed ? static_cast<const char*>(w_packed) : wimg), N, K, precision);
   const dim3 grid(static_cast<unsigned>(mdg_cdiv(N, BN)), static_cast<unsigned>(mdg_cdiv(M, BM)));
   const size_t lds = 4 * TILE_BYTES;
   switch (precision) {

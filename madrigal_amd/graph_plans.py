@@ -59,25 +59,38 @@ def molecule_plan(graph) -> dict:
     return plan
 
 
-def hgt_plan(edge_index_dict, edge_types: Sequence[Tuple[str, str, str]], sizes: Dict[str, int], device) -> dict:
-    """Per destination node type: concatenated incoming edges of every edge type, sorted by
-    destination, pointing into ONE relation-transformed source table whose rows are laid out edge
-    type after edge type (offset[r] + source index), plus the chunked work-item lists."""
+def hgt_plan(edge_index_dict, edge_types: Sequence[Tuple[str, str, str]], sizes: Dict[str, int], device, used=None) -> dict:
+    """Layout + CSR plan of one HGTConv call.
+
+    Projection layout: node type t owns rows of ``width[t] = 128 + 256 * R_t`` floats in one flat buffer starting at
+    float offset ``base[t]``: [ q (128) | k'_0 v'_0 | k'_1 v'_1 | ... ] where slot i belongs to the i-th USED edge
+    type whose source is t (one GEMM per node type writes the whole row).  Viewed as [*,128] the relation-transformed
+    key of source node j under slot i is row (base[t] + j*width[t] + 128 + 256*i) / 128 and its value the next row.
+
+    Per destination type: the incoming edges of every used edge type concatenated, stably sorted by destination,
+    ``col[e]`` = that key row; rows longer than HGT_CHUNK are split into work items."""
     present = [et for et in edge_types if et in edge_index_dict]
-    offset, total = {}, 0
-    for et in present:
-        offset[et] = total
-        total += sizes[et[0]]
+    used = present if used is None else [et for et in present if et in set(used)]
+    slot, nrel = {}, {t: 0 for t in sizes}
+    for et in used:
+        slot[et] = nrel[et[0]]
+        nrel[et[0]] += 1
+    width = {t: 128 + 256 * nrel[t] for t in sizes}
+    base, total = {}, 0
+    for t in sizes:
+        base[t] = total
+        total += sizes[t] * width[t]
     per_dst = {}
     for t, n_t in sizes.items():
         cols, dsts = [], []
-        for et in present:
+        for et in used:
             if et[2] != t:
                 continue
             ei = edge_index_dict[et].to(device).long()
             if ei.shape[1] == 0:
                 continue
-            cols.append(ei[0] + offset[et])
+            s = et[0]
+            cols.append((base[s] + 128 + 256 * slot[et]) // 128 + ei[0] * (width[s] // 128))
             dsts.append(ei[1])
         if cols:
             col, dst = torch.cat(cols), torch.cat(dsts)
@@ -97,4 +110,4 @@ def hgt_plan(edge_index_dict, edge_types: Sequence[Tuple[str, str, str]], sizes:
         item_end = torch.minimum(item_begin + HGT_CHUNK, rowptr[item_dst + 1])
         per_dst[t] = {"col": col, "rowptr": rowptr, "item_ptr": item_ptr, "item_dst": item_dst.contiguous(),
                       "item_begin": item_begin.contiguous(), "item_end": item_end.contiguous()}
-    return {"present": present, "offset": offset, "total_rows": total, "per_dst": per_dst}
+    return {"used": used, "slot": slot, "nrel": nrel, "width": width, "base": base, "total_floats": total, "per_dst": per_dst}

@@ -280,10 +280,11 @@ class HGTConv(nn.Module):
     layout of PyG 2.3: kqv_lin.lins.<type>, out_lin.lins.<type>, k_rel/v_rel.weight [H*R,D,D] indexed
     h*R + r, skip.<type>, p_rel.<src>__<rel>__<dst>).  PARITY UNPINNED against the real wheel.
 
-    K|Q|V projections and the per-relation transforms run through mdg_linear (the per-head relation
-    matrices as one block-diagonal 128x128 weight, with p_rel/sqrt(D) folded into the key transform);
-    the edge softmax over ALL incoming edges of a node fused with the weighted value sum is
-    mdg_hgt_attention; output projection, GELU and the sigmoid(skip)-gated residual are fused epilogues."""
+    One mdg_linear per node type produces q and, for every edge type leaving that node type, the
+    relation-transformed key/value (the per-head relation matrices, as a block-diagonal 128x128 matrix with
+    p_rel/sqrt(D) folded in, are composed with the K / V projection weights); the edge softmax over ALL incoming
+    edges of a node fused with the weighted value sum is mdg_hgt_attention; output projection, GELU and the
+    sigmoid(skip)-gated residual are fused epilogues."""
 
     def __init__(self, in_channels, out_channels, metadata, heads=1, group="sum", **kwargs):
         super().__init__()
@@ -314,13 +315,16 @@ class HGTConv(nn.Module):
         self._plan_cache = {}
         self._host_cache = {}
 
-    def _plan(self, edge_index_dict, sizes, device):
-        key = (id(edge_index_dict), str(device), tuple(sorted(sizes.items())))
-        hit = self._plan_cache.get("p")
-        if hit is None or hit[0] != key:
-            hit = (key, hgt_plan(edge_index_dict, self.edge_types, sizes, device))
-            self._plan_cache["p"] = hit
-        return hit[1]
+    def _plan(self, edge_index_dict, sizes, device, want):
+        used = [et for et in self.edge_types if et in edge_index_dict and et[2] in want]
+        key = (id(edge_index_dict), str(device), tuple(sorted(sizes.items())), tuple(used))
+        hit = self._plan_cache.get(key)
+        if hit is None:
+            hit = hgt_plan(edge_index_dict, self.edge_types, sizes, device, used)
+            if len(self._plan_cache) > 8:
+                self._plan_cache.clear()
+            self._plan_cache[key] = hit
+        return hit
 
     def _skip_alpha(self, t: str) -> float:
         p = self.skip[t]
@@ -331,20 +335,37 @@ class HGTConv(nn.Module):
             self._host_cache[t] = hit
         return hit[1]
 
-    def _relation_weights(self, r: int, et) -> Tuple[torch.Tensor, torch.Tensor]:
-        """nn.Linear-layout [128,128] weights applying the per-head [D,D] relation matrices of edge type r
+    def _relation_matrices(self, r: int, et) -> Tuple[torch.Tensor, torch.Tensor]:
+        """[128,128] matrices (nn.Linear layout) applying the per-head [D,D] relation matrices of edge type r
         to K (scaled by p_rel[h]/sqrt(D)) and to V:  k' = k @ blockdiag(A_h)  ==  linear(k, blockdiag(A_h)^T)."""
         H, R = self.heads, len(self.edge_types)
         D = self.out_channels // H
-        prel = self.p_rel["__".join(et)]
+        idx = torch.arange(H, device=self.k_rel.weight.device) * R + r
+        pr = self.p_rel["__".join(et)].detach().view(H, 1, 1) / math.sqrt(D)
+        wk = torch.block_diag(*(self.k_rel.weight.detach()[idx] * pr).unbind(0)).t()
+        wv = torch.block_diag(*self.v_rel.weight.detach()[idx].unbind(0)).t()
+        return wk, wv
+
+    def _composite_projection(self, t: str, plan: dict):
+        """One weight per node type producing  q | k'_0 v'_0 | k'_1 v'_1 ...  in a single GEMM: the relation
+        transform of every used edge type leaving t is composed with the K / V projection
+        (k' = (x W_k^T + b_k) B_r  =  x (B_r^T W_k)^T + B_r^T b_k).  Rebuilt only when a parameter changes."""
+        F = self.out_channels
+        lin = self.kqv_lin.lins[t]
+        rels = [et for et in plan["used"] if et[0] == t]
+        srcs = [lin.weight, lin.bias, self.k_rel.weight, self.v_rel.weight] + [self.p_rel["__".join(et)] for et in rels]
 
         def build():
-            idx = torch.arange(H, device=self.k_rel.weight.device) * R + r
-            pr = prel.detach().view(H, 1, 1) / math.sqrt(D)
-            wk = torch.block_diag(*(self.k_rel.weight.detach()[idx] * pr).unbind(0)).t().contiguous()
-            wv = torch.block_diag(*self.v_rel.weight.detach()[idx].unbind(0)).t().contiguous()
-            return wk, wv
-        return _cached(self, ("rel", r), (self.k_rel.weight, self.v_rel.weight, prel), build)
+            W, b = lin.weight.detach(), lin.bias.detach()
+            Wk, Wq, Wv = W[0:F], W[F:2 * F], W[2 * F:3 * F]
+            bk, bq, bv = b[0:F], b[F:2 * F], b[2 * F:3 * F]
+            ws, bs = [Wq], [bq]
+            for et in rels:
+                mk, mv = self._relation_matrices(self.edge_types.index(et), et)
+                ws += [mk @ Wk, mv @ Wv]
+                bs += [mk @ bk, mv @ bv]
+            return torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous()
+        return _cached(self, ("proj", t, tuple(rels)), srcs, build)
 
     def forward(self, x_dict, edge_index_dict, needed_types=None):
         """``needed_types`` (extension): compute only these destination node types (the encoder reads
@@ -353,24 +374,24 @@ class HGTConv(nn.Module):
         F = self.out_channels
         dev = next(iter(x_dict.values())).device
         sizes = {t: int(x.shape[0]) for t, x in x_dict.items()}
-        plan = self._plan(edge_index_dict, sizes, dev)
         want = set(self.dst_node_types if needed_types is None else needed_types)
-        used = [et for et in plan["present"] if et[2] in want]
-        proj_types = want | {et[0] for et in used}
-        kqv = {t: _lin(x.float(), self.kqv_lin.lins[t].weight, self.kqv_lin.lins[t].bias) for t, x in x_dict.items() if t in proj_types}
-        kv = torch.empty((max(plan["total_rows"], 1), 2 * F), dtype=torch.float32, device=dev)
-        for et in used:
-            r = self.edge_types.index(et)
-            wk, wv = self._relation_weights(r, et)
-            o, n_s = plan["offset"][et], sizes[et[0]]
-            src = kqv[et[0]]
-            _lin(src[:, 0:F], wk, None, out=kv[o:o + n_s, 0:F])
-            _lin(src[:, 2 * F:3 * F], wv, None, out=kv[o:o + n_s, F:2 * F])
+        plan = self._plan(edge_index_dict, sizes, dev, want)
+        buf = torch.empty(max(plan["total_floats"], 128), dtype=torch.float32, device=dev)
+        proj = {}
+        for t, x in x_dict.items():
+            if plan["nrel"][t] == 0 and t not in want:
+                continue
+            w, b = self._composite_projection(t, plan)
+            n_t, wd = sizes[t], plan["width"][t]
+            proj[t] = buf[plan["base"][t]: plan["base"][t] + n_t * wd].view(n_t, wd)
+            if n_t:
+                _lin(x.float(), w, b, out=proj[t])
+        kv = buf.view(-1, 128)                             # key rows / value rows, addressed by the plan's col
         out = {}
         for t in self.node_types:
             if t not in self.dst_node_types or t not in x_dict or t not in want:
                 continue
-            agg = ops.hgt_attention(kqv[t][:, F:2 * F], kv, plan["per_dst"][t], self.heads, apply_gelu=True)
+            agg = ops.hgt_attention(proj[t][:, 0:F], kv, plan["per_dst"][t], self.heads, apply_gelu=True)
             lin = self.out_lin.lins[t]
             if x_dict[t].shape[-1] == F:
                 a = self._skip_alpha(t)

@@ -134,17 +134,42 @@ def _pad_last(t: torch.Tensor, mult: int = 4) -> torch.Tensor:
     return torch.nn.functional.pad(t, (0, mult - k % mult))
 
 
+def _wkey(w: torch.Tensor):
+    return (w.data_ptr(), tuple(w.shape), tuple(w.stride()), str(w.device))
+
+
 def padded_weight(w: torch.Tensor) -> torch.Tensor:
-    """nn.Linear weight [N,K] with K zero-padded to a multiple of 4; cached per (storage, version)."""
+    """nn.Linear weight [N,K] with K zero-padded to a multiple of 4.  Cached per storage address and in-place
+    version; the entry keeps the source tensor alive, so the address cannot be recycled under the cache."""
     if w.shape[-1] % 4 == 0 and w.is_contiguous():
         return w.detach()
-    key = (w.data_ptr(), w._version, tuple(w.shape))
-    hit = _pad_cache.get(id(w))
-    if hit is not None and hit[0] == key:
+    k = _wkey(w)
+    hit = _pad_cache.get(k)
+    if hit is not None and hit[0] == w._version:
         return hit[1]
     p = _pad_last(w.detach()).contiguous()
-    _pad_cache[id(w)] = (key, p)
+    _pad_cache[k] = (w._version, p, w)
     return p
+
+
+_pack_cache = {}
+
+
+def packed_weight_image(w: torch.Tensor, prec: int):
+    """Operand image of a (padded) nn.Linear weight for mdg_linear, built once per (storage, version, precision)."""
+    N, K = w.shape
+    nbytes = lib().mdg_pack_operand_bytes(_c64(N), _c64(K), _c(prec))
+    if nbytes == 0:
+        return None
+    k = _wkey(w) + (prec,)
+    hit = _pack_cache.get(k)
+    if hit is not None and hit[0] == w._version:
+        return hit[1]
+    img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    check(lib().mdg_pack_operand(_ptr(w), _c64(w.stride(0)), _c64(N), _c64(K), _c(prec), _ptr(img), ctypes.c_size_t(nbytes),
+                                 _stream(w)), "mdg_pack_operand")
+    _pack_cache[k] = (w._version, img, w)
+    return img
 
 
 def _rows2d(x: torch.Tensor, name: str):
@@ -156,11 +181,12 @@ def _rows2d(x: torch.Tensor, name: str):
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, scale=None, shift=None,
            act=None, residual: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 1.0,
-           precision="bf16x3", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           precision="bf16x3", out: Optional[torch.Tensor] = None, cache_weight: bool = True) -> torch.Tensor:
     """y = alpha * act((x W^T + b) * scale + shift) + beta * residual   (nn.Linear layout W [N,K]).
 
     ``x`` may be a strided 2-D view (row stride a multiple of 4); ``residual`` may be [N] / [1,N]
-    (broadcast over rows) or [M,N]."""
+    (broadcast over rows) or [M,N].  ``cache_weight``: keep the packed image of ``weight`` (hi/lo bf16 planes, K
+    padded) and reuse it while the tensor is unchanged; pass False for one-shot "weights" (e.g. InfoNCE's F F^T)."""
     forward_only(x, weight, bias, residual)
     if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.shape[1] % 4 == 0 and x.data_ptr() % 16 == 0 \
             and x.is_cuda and x.dtype == torch.float32:
@@ -194,9 +220,10 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         if t is not None and (t.numel() != N or not t.is_cuda or t.dtype != torch.float32):
             raise ValueError(f"{nm}: expected fp32 cuda [{N}]")
     prec = _prec(precision)
-    nbytes = lib().mdg_linear_workspace_bytes(_c64(M), _c64(N), _c64(K), _c(prec))
+    wimg = packed_weight_image(w, prec) if cache_weight else None
+    nbytes = lib().mdg_linear_workspace_bytes(_c64(M), _c64(N), _c64(K), _c(prec), _c(1 if wimg is not None else 0))
     ws = _workspace(nbytes, x2.device)
-    check(lib().mdg_linear(_ptr(x2), _c64(x2.stride(0)), _ptr(w), _c64(w.stride(0)), _ptr(out), _c64(out.stride(0)),
+    check(lib().mdg_linear(_ptr(x2), _c64(x2.stride(0)), _ptr(w), _c64(w.stride(0)), _ptr(wimg), _ptr(out), _c64(out.stride(0)),
                            _c64(M), _c64(N), _c64(K), _ptr(None if bias is None else bias.detach().contiguous()),
                            _ptr(None if scale is None else scale.contiguous()), _ptr(None if shift is None else shift.contiguous()),
                            _c(ACTS[act]), _ptr(residual), _c64(ldr), _f(alpha), _f(beta), _c(prec), _ptr(ws),
@@ -370,7 +397,7 @@ def info_nce(aug1: torch.Tensor, aug2: torch.Tensor, too_hard_neg: Optional[torc
         raise ValueError("aug1 / aug2 shapes differ")
     B = a1.shape[0]
     f = l2_normalize(torch.cat([a1, a2], dim=0))
-    sim = linear(f, f, None, precision=precision)
+    sim = linear(f, f, None, precision=precision, cache_weight=False)
     hard = None
     if too_hard_neg is not None:
         if too_hard_neg.shape != (B, B):

@@ -186,7 +186,13 @@ def test_hgt_attention_heavy_tail(ops, heads):
     dst[dst == 5] = 6                                    # destination 5 has no edges
     ei = {("a", "r", "b"): torch.stack([src, dst])}
     plan = hgt_plan({k: v.cuda() for k, v in ei.items()}, [("a", "r", "b")], {"a": n_src, "b": n_dst}, torch.device("cuda"))
-    q, kv = _rand((n_dst, 128), 71), _rand((n_src, 256), 72)
+    # projection layout of source type "a": rows of width 128 + 256 = [q | k' v']
+    assert plan["width"]["a"] == 384 and plan["base"]["a"] == 0
+    q = _rand((n_dst, 128), 71)
+    proj_a = _rand((n_src, 384), 72)
+    kv = proj_a[:, 128:]                                     # [n_src, 256] = k' | v' (reference view for the check below)
+    buf = torch.zeros(plan["total_floats"])
+    buf[: n_src * 384] = proj_a.flatten()
     D = 128 // heads
     a = (q[dst].view(-1, heads, D) * kv[src, :128].view(-1, heads, D)).sum(-1)
     amax = torch.full((n_dst, heads), float("-inf")).scatter_reduce(0, dst[:, None].expand(-1, heads), a, reduce="amax")
@@ -195,8 +201,9 @@ def test_hgt_attention_heavy_tail(ops, heads):
     alpha = e / (den[dst] + 1e-16)
     agg = torch.zeros(n_dst, heads, D).index_add_(0, dst, kv[src, 128:].view(-1, heads, D) * alpha[..., None]).reshape(n_dst, 128)
     from oracle import madrigal_oracle as O
-    got = ops.hgt_attention(q.cuda(), kv.cuda(), plan["per_dst"]["b"], heads, apply_gelu=False).cpu()
+    kvd = buf.cuda().view(-1, 128)
+    got = ops.hgt_attention(q.cuda(), kvd, plan["per_dst"]["b"], heads, apply_gelu=False).cpu()
     assert float((got - agg).abs().max()) < 2e-5
-    got_g = ops.hgt_attention(q.cuda(), kv.cuda(), plan["per_dst"]["b"], heads, apply_gelu=True).cpu()
+    got_g = ops.hgt_attention(q.cuda(), kvd, plan["per_dst"]["b"], heads, apply_gelu=True).cpu()
     assert float((got_g - O._act("gelu", agg)).abs().max()) < 2e-5
     assert float(got[5].abs().max()) == 0.0
