@@ -746,7 +746,12 @@ class TransformerFusion(nn.Module):
         return len(self.transformer_encoder.layers[-1].self_attn._forward_hooks) == 0
 
     def live_token_plan(self, fusion_mask: torch.Tensor, src_mask: Optional[torch.Tensor]) -> dict:
-        """Index plumbing for the compact path (torch ops on the device; one host sync for the row count)."""
+        """Index plumbing for the compact path (torch ops + one small host round trip per distinct mask).
+
+        Live tokens are stored drug after drug.  Attention tiles hold up to 32 consecutive live rows covering WHOLE
+        drugs (on average ~5 live tokens per drug, so several drugs share one 32x32 MFMA tile); ``row_bits[r]`` bit j
+        says that row r may not attend the j-th row of its tile: rows of other drugs, and the reference's [S,S]
+        source mask between rows of the same drug."""
         n, S = fusion_mask.shape
         live = ~fusion_mask
         dev = live.device
@@ -754,13 +759,36 @@ class TransformerFusion(nn.Module):
         row_start = torch.zeros(n + 1, dtype=torch.int64, device=dev)
         torch.cumsum(counts, 0, out=row_start[1:])
         token_index = live.flatten().nonzero().flatten()
+        R = int(token_index.numel())
         cidx = torch.cumsum(live.to(torch.int64), 1) - 1                                   # compact index inside the drug
-        row_bits = None
+        # greedy packing of consecutive drugs into tiles of <= 32 rows (host: n small integers)
+        cnt = counts.cpu().numpy()
+        tile_of_drug = np.empty(n, dtype=np.int64)
+        starts, fill, t = [0], 0, 0
+        for i in range(n):
+            c = int(cnt[i])
+            if fill + c > 32:
+                t += 1
+                starts.append(starts[-1] + fill)
+                fill = 0
+            tile_of_drug[i] = t
+            fill += c
+        starts.append(starts[-1] + fill)
+        tile_start = torch.tensor(starts, dtype=torch.int64, device=dev)                   # [n_tiles+1] row offsets
+        tile_of_drug = torch.from_numpy(tile_of_drug).to(dev)
+        row_drug = token_index // S
+        row_pos = token_index % S
+        off_in_tile = (row_start[:-1] - tile_start[tile_of_drug])                          # first row of the drug inside its tile
+        # bit j allowed <=> j in [off, off+count) of the same drug and not blocked by the source mask
+        allowed = torch.zeros(n, S, dtype=torch.int64, device=dev)
         if src_mask is not None:
-            blocked = live.unsqueeze(1) & src_mask.unsqueeze(0)                            # [n, query, key]
-            bits = (blocked.to(torch.int64) << cidx.clamp_min(0).unsqueeze(1)).sum(-1)     # [n, S]
-            row_bits = bits.flatten().index_select(0, token_index).to(torch.int32).contiguous()
-        plan = {"n": n, "S": S, "row_start": row_start, "token_index": token_index, "row_bits": row_bits}
+            ok = live.unsqueeze(1) & ~src_mask.unsqueeze(0)                                # [n, query pos, key pos]
+        else:
+            ok = live.unsqueeze(1).expand(n, S, S)
+        allowed = (ok.to(torch.int64) << (cidx.clamp_min(0) + off_in_tile.unsqueeze(1)).unsqueeze(1)).sum(-1)   # [n,S]
+        row_bits = (~allowed[row_drug, row_pos]).to(torch.int32).contiguous()              # set bit = NOT allowed
+        plan = {"n": n, "S": S, "R": R, "row_start": row_start, "token_index": token_index, "row_bits": row_bits,
+                "tile_start": tile_start, "n_tiles": int(tile_start.numel()) - 1}
         if self.transformer_agg == 'x-attn':
             off = S - (NUM_MODALITIES + self.num_tx_bottlenecks)                           # 1 if a cls token leads
             keys = torch.tensor([k + off for k in self._key_positions()], device=dev)
@@ -780,7 +808,7 @@ class TransformerFusion(nn.Module):
         agg = self.transformer_agg
 
         def attend(qkv, _x):
-            return ops.fusion_attention(qkv, n, S, H, dh, row_start=plan["row_start"], row_bits=plan["row_bits"])[0]
+            return ops.fusion_attention(qkv, plan["n_tiles"], S, H, dh, row_start=plan["tile_start"], row_bits=plan["row_bits"])[0]
         for li, L in enumerate(layers):
             last = li == len(layers) - 1
             keep = plan.get("key_rows") if (last and agg in ('x-attn', 'cls')) else None
@@ -934,6 +962,10 @@ class NovelDDIEncoder(nn.Module):
             self.uni_fuser = MLPAdaptor(feat_dim, ph['proj_hidden_dims'], feat_dim, ph['proj_dropout'], ph['proj_norm'], ph['proj_actn'], ph['proj_order'])
         # run the fusion transformer on live (unmasked) tokens only: identical z, a fraction of the rows
         self.live_tokens_only = True
+        # run the KG encoder on a second HIP stream beside the structure / cv / tx encoders
+        self.overlap_kg = True
+        self._plan_cache = None
+        self._kg_stream = None
 
     def set_cell_line_categories(self, cell_lines_lowercase) -> None:
         """Category order of the reference's sklearn OneHotEncoder (sorted unique names, models.py:648-649)."""
@@ -941,13 +973,12 @@ class NovelDDIEncoder(nn.Module):
         self._cell_line_index = {c: i for i, c in enumerate(cats)}
 
     # -- encoders ---------------------------------------------------------------------------
-    def _encode_tx(self, batch_tx_dict, n: int, device) -> torch.Tensor:
-        """[16*n, D] cell-line-major tx embeddings (models.py:753-769)."""
+    def _encode_tx(self, batch_tx_dict, n: int, device, present: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[16*n, D] cell-line-major tx embeddings (models.py:753-769).  ``present`` (bool [n,16]): encode only the
+        (drug, cell line) rows that exist; the others are left zero (callers that pass it never read them)."""
         if self.tx_encoder_dict is not None:
             return torch.cat([self.tx_encoder_dict[c](batch_tx_dict[c]['sigs']) for c in CELL_LINES], dim=0)
         sigs = torch.cat([batch_tx_dict[c]['sigs'] for c in CELL_LINES], dim=0)
-        drugs = torch.cat([batch_tx_dict[c]['drugs'] for c in CELL_LINES], dim=0)
-        dos = torch.cat([batch_tx_dict[c]['dosages'] for c in CELL_LINES], dim=0)
         idx = []
         for c in CELL_LINES:
             names = np.asarray(batch_tx_dict[c]['cell_lines'])
@@ -957,29 +988,58 @@ class NovelDDIEncoder(nn.Module):
             else:
                 idx.append(torch.full((names.size,), self._cell_line_index[first], dtype=torch.int64))
         cov = torch.cat(idx).to(device)
-        out = self.tx_encoder.predict(genes=sigs, drugs_idx=drugs, dosages=dos, covariates=None, covariate_indices=[cov],
-                                      return_latent_basal=self.use_tx_basal, return_latent_treated=(not self.use_tx_basal),
-                                      compute_reconstruction=False)
-        return out[2]
+        sel = None
+        if present is not None:
+            sel = present.t().reshape(-1).nonzero().flatten()          # rows of the cell-line-major stack that exist
+            sigs, cov = sigs.index_select(0, sel), cov.index_select(0, sel)
+        zeros = torch.zeros(sigs.shape[0], dtype=torch.int64, device=device)
+        if sigs.shape[0] == 0:
+            lat = torch.zeros(0, self.embed_dim, device=device)
+        else:
+            lat = self.tx_encoder.predict(genes=sigs, drugs_idx=zeros, dosages=zeros, covariates=None, covariate_indices=[cov],
+                                          return_latent_basal=self.use_tx_basal, return_latent_treated=(not self.use_tx_basal),
+                                          compute_reconstruction=False)[2]
+        if sel is None:
+            return lat
+        full = torch.zeros(16 * n, self.embed_dim, device=device)
+        full[sel] = lat
+        return full
 
     def encode(self, batch_drugs, batch_masks, batch_mols, batch_kg, batch_cv, batch_tx_dict, raw_encoder_output=False, **kwargs):
         _require_eval(self)
         dev = batch_cv.device
         n, Dm = batch_drugs.shape[0], self.embed_dim
-        str_out = self.str_encoder(batch_mols, batch_mols.node_feature.float())["graph_feature"]
+        compact = (not raw_encoder_output and self.live_tokens_only and self.fusion in ('transformer', 'transformer_uni_proj')
+                   and self.transformer.supports_live_tokens())
         kg_data, kg_map = batch_kg['data'], batch_kg['drug_index_map']
-        kg_valid = self.kg_encoder(kg_data.x_dict, kg_data.edge_index_dict, only_types=('drug',))['drug']
         # drugs absent from the KG get filler rows that are always masked (models.py:734-736); the size of the
         # table needs the largest drug id (the reference's .item() syncs here as well)
         filler = kwargs.get('kg_filler')
         if filler is None:
-            rows = max(int(batch_drugs.max().item()) + 1, int(kg_map.max().item()) + 1)
-            filler = torch.randn((rows, Dm), device=dev)
-        kg_table = filler.to(dev).clone()
-        kg_table[kg_map] = kg_valid
-        kg_out = kg_table[batch_drugs]
+            rows_f = max(int(batch_drugs.max().item()) + 1, int(kg_map.max().item()) + 1)
+            filler = torch.randn((rows_f, Dm), device=dev)
+
+        def run_kg():
+            kg_valid = self.kg_encoder(kg_data.x_dict, kg_data.edge_index_dict, only_types=('drug',))['drug']
+            table = filler.to(dev).clone()
+            table[kg_map] = kg_valid
+            return table[batch_drugs]
+        main = torch.cuda.current_stream(dev)
+        if self.overlap_kg:
+            if self._kg_stream is None or self._kg_stream.device != dev:
+                self._kg_stream = torch.cuda.Stream(device=dev)
+            self._kg_stream.wait_stream(main)
+            with torch.cuda.stream(self._kg_stream):
+                kg_out = run_kg()
+        str_out = self.str_encoder(batch_mols, batch_mols.node_feature.float())["graph_feature"]
         cv_out = self.cv_encoder(batch_cv)
-        tx_out = self._encode_tx(batch_tx_dict, n, dev)                                    # [16n, D]
+        # tx embeddings of absent cell lines are masked tokens: the live-token path never reads them
+        tx_out = self._encode_tx(batch_tx_dict, n, dev, present=(~batch_masks[:, NUM_NON_TX_MODALITIES:]) if compact else None)
+        if self.overlap_kg:
+            main.wait_stream(self._kg_stream)
+            kg_out.record_stream(main)
+        else:
+            kg_out = run_kg()
         if raw_encoder_output:
             all_embeds = torch.stack([str_out, kg_out, cv_out] + list(tx_out.split(n)), dim=1)
             uni = all_embeds[~batch_masks]
@@ -1029,8 +1089,11 @@ class NovelDDIEncoder(nn.Module):
                         pe=self.pos_encoder.table(), rows=rows, normalize=self.normalize)
         if nf == 0:
             z_f = torch.zeros(0, Dm, device=dev)
-        elif self.live_tokens_only and self.transformer.supports_live_tokens():
-            plan = self.transformer.live_token_plan(kpm, src)
+        elif compact:
+            pkey = (batch_masks.data_ptr(), batch_masks._version, tuple(batch_masks.shape), str(dev), nf)
+            if self._plan_cache is None or self._plan_cache[0] != pkey:
+                self._plan_cache = (pkey, self.transformer.live_token_plan(kpm, src), batch_masks)
+            plan = self._plan_cache[1]
             tokens = ops.assemble_tokens(str_out, kg_out, cv_out, tx_out, token_index=plan["token_index"], **tok_args)
             z_f = self.transformer.forward_tokens(tokens, plan)
         else:

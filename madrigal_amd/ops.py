@@ -56,7 +56,8 @@ def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
     """Per-device grow-only scratch buffer (the C ABI never allocates)."""
     if nbytes == 0:
         return None
-    key = (device.type, device.index)
+    # one scratch buffer per (device, stream): ops enqueued on different streams may run concurrently
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
