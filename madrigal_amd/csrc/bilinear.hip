@@ -5,12 +5,18 @@
 // One workgroup (8 waves) owns a slab of 256 head rows of ONE outcome l and sweeps every tail
 // drug.  Prologue: T = z_head[rows] . W_sym[l] (the reference's inner matmul, rounded to fp32) is
 // formed on the matrix cores, bounced once through LDS so that each wave holds its 32 rows of T as
-// the MFMA *A* operand in registers for the whole sweep.  Main loop: 64 tail rows at a time are
-// staged into LDS (z_tail is 2 MB at N=4096: it lives in every XCD's L2), each wave multiplies its
+// the MFMA *A* operand in registers for the whole sweep.  Main loop: 64 tail rows at a time arrive in
+// LDS by LDS-DMA (z_tail is 2 MB at N=4096: it lives in L2 / Infinity Cache), each wave multiplies its
 // resident T rows against the staged tile (2 accumulator tiles of 32x32) and the epilogue streams
 // the scores to HBM as full 128-byte lines (lane = column, so one store instruction writes two
-// complete rows segments).  Algorithmic traffic is 4 B written per score (STORE) and ~0 read, so the
+// complete row segments).  Algorithmic traffic is 4 B written per score (STORE) and ~0 read, so the
 // kernel is bound by HBM writes for the bf16 products and by the fp32 matrix pipe for MDG_PREC_F32.
+// Synchronisation: one raw s_barrier per stage; the 4 "loader" waves that issue the LDS-DMA drain
+// vmcnt(0) once per stage (after their MFMA phase, before their stores), the other 4 waves never wait
+// for their stores.  No counted vmcnt: an earlier version waited vmcnt(32) to leave the 32 stores of
+// the previous stage in flight, which is only sound if LDS-DMA loads and younger stores retire in
+// issue order -- out-of-range (dropped) stores retire at once, and the rare wrong tiles it produced
+// came and went with timing.
 //
 // LDS tile layout: [64 tail rows][D] with the 16-byte chunks of a row XOR-swizzled by (row & 15), so
 // the MFMA B-operand reads (lane = tail row, ds_read_b128) are bank-conflict free.
@@ -40,7 +46,9 @@ struct BilinearArgs {
   TileSrc w;          // W_sym (all labels); nrows = D
   float* out;
   int64_t n_head, n_tail, n_labels;
-  int stagger;
+  int stagger;          // per-workgroup sweep start (HBM channel spreading)
+  int stagger_waves;    // loader waves issue the previous tile's stores before their MFMAs
+  int loaders;          // waves that issue the LDS-DMA (1, 2, 4 or NW)
 };
 
 template <int MODE> struct AFrag;
@@ -119,25 +127,23 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_unifor
                : "memory");
 }
 
-template <int MODE, int NW>
-__device__ __forceinline__ void stage_dma(const TileSrc& s, int64_t row0, char* lds, int wave, int lane) {
+// `nload` waves (0..nload-1) share the pieces of a tile; the other waves issue nothing.
+template <int MODE>
+__device__ __forceinline__ void stage_dma(const TileSrc& s, int64_t row0, char* lds, int wave, int lane, int nload) {
   if constexpr (MODE == MDG_PREC_F32) {
-#pragma unroll
-    for (int i = 0; i < 32 / NW; ++i) {
-      const int p = wave + NW * i, row = 2 * p + (lane >> 5), c = (lane & 31) ^ (row & 15);
+    for (int p = wave; p < 32; p += nload) {
+      const int row = 2 * p + (lane >> 5), c = (lane & 31) ^ (row & 15);
       int64_t gr = row0 + row;
       gr = gr < s.nrows ? gr : s.nrows - 1;
       glds16(s.f32 + gr * D + c * 4, lds_addr(lds + p * 1024));
     }
   } else {
-#pragma unroll
-    for (int i = 0; i < 16 / NW; ++i) {
-      const int p = wave + NW * i, row = 4 * p + (lane >> 4), c = (lane & 15) ^ (row & 15);
+    for (int p = wave; p < 16; p += nload) {
+      const int row = 4 * p + (lane >> 4), c = (lane & 15) ^ (row & 15);
       int64_t gr = row0 + row;
       gr = gr < s.nrows ? gr : s.nrows - 1;
       glds16(s.hi + gr * D + c * 8, lds_addr(lds + p * 1024));
-      if constexpr (MODE == MDG_PREC_BF16X3)
-        glds16(s.lo + gr * D + c * 8, lds_addr(lds + LO_OFF + p * 1024));
+      if constexpr (MODE == MDG_PREC_BF16X3) glds16(s.lo + gr * D + c * 8, lds_addr(lds + LO_OFF + p * 1024));
     }
   }
 }
@@ -294,37 +300,23 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
     for (int v = 0; v < 16; ++v) { rsum[v] = 0.f; rmax[v] = -INFINITY; }
   }
 
-  // Pipeline (one raw barrier per stage, counted waits only):
-  //   top of stage s : wait until this wave's DMA pieces of tile s have landed (all but the NST
-  //                    youngest vector-memory ops -- the score stores of stage s-1 -- are done),
-  //                    barrier => every wave's pieces of tile s are in LDS AND every wave has
-  //                    finished reading tile s-1, whose buffer the next DMA overwrites;
-  //   then           : issue DMA(tile s+1), MFMA on tile s, issue the stores of tile s.
-  // The stores are never waited for inside the loop.
-  // Each workgroup starts its sweep at a different tail tile (and wraps): co-resident workgroups
-  // otherwise write addresses that differ only by multiples of the row / slab strides (16 KB, 4 MB
-  // at N=4096) at the same instant, which piles them onto a few HBM channels.
-  constexpr int NST = (EPI == MDG_EPI_ROWSTATS) ? 0 : 32;
+  // Pipeline: one raw barrier and ONE full vmcnt(0) wait per stage -- no counted waits: correctness never relies
+  // on the relative completion order of LDS-DMA loads and score stores (out-of-range stores retire at once, and
+  // loads / stores are only ordered among themselves).
+  //   barrier           every wave's DMA pieces of tile s have landed (each wave drained vmcnt before arriving)
+  //                     and every wave has finished reading tile s-1, whose buffer the next DMA overwrites
+  //   issue DMA(s+1)    asynchronous, lands under the MFMA phase
+  //   stores / MFMA     "late" waves: stores of tile s-1 (held in registers), then MFMA(s);
+  //                     "early" waves: MFMA(s), drain, then stores of tile s (they drain under the next stage)
+  //   s_waitcnt vmcnt(0)
+  // The two waves that share a SIMD (w and w + NW/2) would otherwise run MFMA together and store together; making
+  // the younger half "late" and the older half "early" keeps one of them storing while the other computes.
+  // Each workgroup starts its sweep at a different tail tile (and wraps): co-resident workgroups otherwise write
+  // addresses that differ only by multiples of the row / slab strides (16 KB, 4 MB at N=4096) at the same instant,
+  // which piles them onto a few HBM channels.
   const int start = p.stagger ? static_cast<int>((blockIdx.x * 5u + blockIdx.y * 3u) % static_cast<unsigned>(nst)) : 0;
   auto tile_of = [&](int s) { int t = s + start; return t >= nst ? t - nst : t; };
-  stage_dma<MODE, NW>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, buf0, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (int s = 0; s < nst; ++s) {
-    const int64_t tcol0 = static_cast<int64_t>(tile_of(s)) * BN;
-    char* const cur = (s & 1) ? buf1 : buf0;
-    char* const nxt = (s & 1) ? buf0 : buf1;
-    if constexpr (NST == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // past the end the row index clamps to the last tail row; that tile is never consumed
-    stage_dma<MODE, NW>(p.zt, static_cast<int64_t>(tile_of(s + 1 < nst ? s + 1 : s)) * BN, nxt, wave, lane);
-    f32x16 acc[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-    compute_tile<MODE>(At, cur, r, h, acc);
-
+  auto epilogue = [&](const f32x16 (&acc)[2], int64_t tcol0) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int64_t col = tcol0 + 32 * t + r;
@@ -346,8 +338,50 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
         }
       }
     }
+  };
+  // Only the first `nload` waves issue LDS-DMA; only they ever wait on vmcnt.  The other waves never wait for
+  // their stores inside the loop (the 6-bit vmcnt gives hardware back-pressure), so the store stream of the
+  // workgroup is continuous.  A loader that is "late" issues the stores of the previous tile before its MFMAs,
+  // so that its per-stage vmcnt(0) mostly finds them retired.
+  const int nload = p.loaders;
+  const bool loader = __builtin_amdgcn_readfirstlane(wave) < nload;
+  const bool late = (EPI != MDG_EPI_ROWSTATS) && loader && p.stagger_waves;
+  f32x16 held[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) held[t][v] = 0.f;
+  int64_t held_col0 = 0;
+  if (loader) {
+    stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, buf0, wave, lane, nload);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the trailing (unused) DMA before LDS is released
+  for (int s = 0; s < nst; ++s) {
+    const int64_t tcol0 = static_cast<int64_t>(tile_of(s)) * BN;
+    char* const cur = (s & 1) ? buf1 : buf0;
+    char* const nxt = (s & 1) ? buf0 : buf1;
+    __builtin_amdgcn_s_barrier();
+    if (loader && s + 1 < nst) stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(s + 1)) * BN, nxt, wave, lane, nload);
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+    if (late) {
+      if (s > 0) epilogue(held, held_col0);
+      compute_tile<MODE>(At, cur, r, h, acc);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) held[t] = acc[t];
+      held_col0 = tcol0;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      compute_tile<MODE>(At, cur, r, h, acc);
+      if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      epilogue(acc, tcol0);
+    }
+  }
+  if (late) epilogue(held, held_col0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   if constexpr (EPI == MDG_EPI_ROWSTATS) {
 #pragma unroll
@@ -474,6 +508,11 @@ extern "C" int mdg_bilinear_allpairs(const float* z_head, const float* z_tail, c
   a.n_head = n_head; a.n_tail = n_tail; a.n_labels = n_labels;
   a.zt.nrows = n_tail;
   a.stagger = 1;
+  a.stagger_waves = 0;
+  a.loaders = 4;
+  if (const char* e = getenv("MDG_BILINEAR_LOADERS")) a.loaders = atoi(e);
+  if (a.loaders != 1 && a.loaders != 2 && a.loaders != 4) a.loaders = 4;
+  if (const char* e = getenv("MDG_BILINEAR_STAGGER_WAVES")) a.stagger_waves = atoi(e);
   if (const char* e = getenv("MDG_BILINEAR_STAGGER")) a.stagger = atoi(e);
   a.w.nrows = D;
   if (precision == MDG_PREC_F32) {
