@@ -207,6 +207,11 @@ size_t mdg_rank_normalize_workspace_bytes(int64_t n_outcomes, int64_t N);
 int mdg_rank_normalize(const float* scores, float* out, int64_t n_outcomes, int64_t N, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* Elementwise geometric mean of K <= 8 equally shaped fp32 tensors (the 5-seed ensembling of normalised ranks,
+ * scipy.stats.mstats.gmean in notebooks/generate_embeddings.ipynb): out = exp(mean_k log x_k) in fp32; 0 where any
+ * x_k <= 0.  inputs_host is a HOST array of K device pointers; n (elements) must be a multiple of 4. */
+int mdg_gmean(const float* const* inputs_host, int K, float* out, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,12 +11,8 @@
 // the scores to HBM as full 128-byte lines (lane = column, so one store instruction writes two
 // complete row segments).  Algorithmic traffic is 4 B written per score (STORE) and ~0 read, so the
 // kernel is bound by HBM writes for the bf16 products and by the fp32 matrix pipe for MDG_PREC_F32.
-// Synchronisation: one raw s_barrier per stage; the 4 "loader" waves that issue the LDS-DMA drain
-// vmcnt(0) once per stage (after their MFMA phase, before their stores), the other 4 waves never wait
-// for their stores.  No counted vmcnt: an earlier version waited vmcnt(32) to leave the 32 stores of
-// the previous stage in flight, which is only sound if LDS-DMA loads and younger stores retire in
-// issue order -- out-of-range (dropped) stores retire at once, and the rare wrong tiles it produced
-// came and went with timing.
+// Synchronisation: one raw s_barrier per stage and a counted `s_waitcnt vmcnt(32)` that retires the LDS-DMA of
+// the next tile while the 32 score stores of the stage stay in flight (details at the main loop).
 //
 // LDS tile layout: [64 tail rows][D] with the 16-byte chunks of a row XOR-swizzled by (row & 15), so
 // the MFMA B-operand reads (lane = tail row, ds_read_b128) are bank-conflict free.
@@ -47,8 +43,9 @@ struct BilinearArgs {
   float* out;
   int64_t n_head, n_tail, n_labels;
   int stagger;          // per-workgroup sweep start (HBM channel spreading)
-  int stagger_waves;    // loader waves issue the previous tile's stores before their MFMAs
-  int loaders;          // waves that issue the LDS-DMA (1, 2, 4 or NW)
+  int stagger_waves;    // counted pipeline: younger half of the waves stores one stage late
+  int loaders;          // conservative pipeline: waves that issue the LDS-DMA (1, 2 or 4)
+  int pipeline;         // 0 = counted waits (default), 1 = conservative
 };
 
 template <int MODE> struct AFrag;
@@ -339,48 +336,79 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
       }
     }
   };
-  // Only the first `nload` waves issue LDS-DMA; only they ever wait on vmcnt.  The other waves never wait for
-  // their stores inside the loop (the 6-bit vmcnt gives hardware back-pressure), so the store stream of the
-  // workgroup is continuous.  A loader that is "late" issues the stores of the previous tile before its MFMAs,
-  // so that its per-stage vmcnt(0) mostly finds them retired.
-  const int nload = p.loaders;
-  const bool loader = __builtin_amdgcn_readfirstlane(wave) < nload;
-  const bool late = (EPI != MDG_EPI_ROWSTATS) && loader && p.stagger_waves;
   f32x16 held[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int v = 0; v < 16; ++v) held[t][v] = 0.f;
   int64_t held_col0 = 0;
-  if (loader) {
-    stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, buf0, wave, lane, nload);
+  if (p.pipeline == 0) {
+    // ---- counted pipeline (default).  Every wave issues its share of the LDS-DMA.  Per stage and wave the
+    // vector-memory stream is  [DMA(s+1) x NDMA] [32 score stores]  (in either order of stores / MFMAs, see
+    // below), so at the top of the next stage `s_waitcnt vmcnt(32)` retires the DMA while leaving the 32 stores
+    // in flight.  This is sound because loads, stores (also the out-of-range ones that are dropped) and LDS-DMA
+    // retire in issue order on gfx950 -- checked by scripts/micro/vmcnt_order.hip: 0 stale LDS reads in 131072
+    // trials behind 32 dropped or real stores, 131072 of 131072 without them.  The store count per stage must
+    // therefore be exactly 32 for every wave: ragged columns / rows are stored out of range, never skipped.
+    // Stagger: the two waves sharing a SIMD (w, w + NW/2) run the same code between the same barriers and would
+    // do their MFMAs together and their stores together; the younger half issues the stores of the PREVIOUS
+    // tile (held in registers) before its MFMAs, so one partner stores while the other computes.
+    const bool late = (EPI != MDG_EPI_ROWSTATS) && p.stagger_waves && (__builtin_amdgcn_readfirstlane(wave) >= NW / 2);
+    constexpr bool kStores = (EPI != MDG_EPI_ROWSTATS);
+    stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, buf0, wave, lane, NW);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  for (int s = 0; s < nst; ++s) {
-    const int64_t tcol0 = static_cast<int64_t>(tile_of(s)) * BN;
-    char* const cur = (s & 1) ? buf1 : buf0;
-    char* const nxt = (s & 1) ? buf0 : buf1;
-    __builtin_amdgcn_s_barrier();
-    if (loader && s + 1 < nst) stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(s + 1)) * BN, nxt, wave, lane, nload);
-    f32x16 acc[2];
+    for (int s = 0; s < nst; ++s) {
+      const int64_t tcol0 = static_cast<int64_t>(tile_of(s)) * BN;
+      char* const cur = (s & 1) ? buf1 : buf0;
+      char* const nxt = (s & 1) ? buf0 : buf1;
+      if constexpr (kStores) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // past the end the tile index repeats the last one; that copy is never consumed
+      stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(s + 1 < nst ? s + 1 : s)) * BN, nxt, wave, lane, NW);
+      f32x16 acc[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-    if (late) {
-      if (s > 0) epilogue(held, held_col0);
-      compute_tile<MODE>(At, cur, r, h, acc);
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+      if (late) {
+        epilogue(held, s > 0 ? held_col0 : p.n_tail);          // s == 0: all 32 stores out of range (dropped)
+        compute_tile<MODE>(At, cur, r, h, acc);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) held[t] = acc[t];
-      held_col0 = tcol0;
+        for (int t = 0; t < 2; ++t) held[t] = acc[t];
+        held_col0 = tcol0;
+      } else {
+        compute_tile<MODE>(At, cur, r, h, acc);
+        epilogue(acc, tcol0);
+      }
+    }
+    if (late) epilogue(held, held_col0);
+  } else {
+    // ---- conservative pipeline (MDG_BILINEAR_PIPELINE=1): no counted waits.  Only the first `nload` waves issue
+    // LDS-DMA and only they wait (a full vmcnt(0) once per stage, after their MFMAs and before their stores); the
+    // other waves never wait for their stores inside the loop.
+    const int nload = p.loaders;
+    const bool loader = __builtin_amdgcn_readfirstlane(wave) < nload;
+    if (loader) {
+      stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, buf0, wave, lane, nload);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
+    }
+    for (int s = 0; s < nst; ++s) {
+      const int64_t tcol0 = static_cast<int64_t>(tile_of(s)) * BN;
+      char* const cur = (s & 1) ? buf1 : buf0;
+      char* const nxt = (s & 1) ? buf0 : buf1;
+      __builtin_amdgcn_s_barrier();
+      if (loader && s + 1 < nst) stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(s + 1)) * BN, nxt, wave, lane, nload);
+      f32x16 acc[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
       compute_tile<MODE>(At, cur, r, h, acc);
       if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       epilogue(acc, tcol0);
     }
   }
-  if (late) epilogue(held, held_col0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   if constexpr (EPI == MDG_EPI_ROWSTATS) {
@@ -508,8 +536,10 @@ extern "C" int mdg_bilinear_allpairs(const float* z_head, const float* z_tail, c
   a.n_head = n_head; a.n_tail = n_tail; a.n_labels = n_labels;
   a.zt.nrows = n_tail;
   a.stagger = 1;
-  a.stagger_waves = 0;
+  a.stagger_waves = 1;
   a.loaders = 4;
+  a.pipeline = 0;
+  if (const char* e = getenv("MDG_BILINEAR_PIPELINE")) a.pipeline = atoi(e) ? 1 : 0;
   if (const char* e = getenv("MDG_BILINEAR_LOADERS")) a.loaders = atoi(e);
   if (a.loaders != 1 && a.loaders != 2 && a.loaders != 4) a.loaders = 4;
   if (const char* e = getenv("MDG_BILINEAR_STAGGER_WAVES")) a.stagger_waves = atoi(e);

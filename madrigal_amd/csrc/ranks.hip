@@ -157,6 +157,30 @@ __global__ __launch_bounds__(TPB) void zero_diag_kernel(float* __restrict__ out,
 
 inline size_t a256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
+// Geometric mean over K <= 8 tensors, elementwise, fp32 like scipy.stats.mstats.gmean on float32 input:
+// exp(mean_k(log x_k)).  Entries where any x_k <= 0 (the zero diagonal of normalised ranks; masked by scipy)
+// give 0.  (generate_embeddings.ipynb, the 5-seed ensembling cell.)
+struct GmeanArgs { const float* in[8]; int K; };
+
+__global__ __launch_bounds__(256) void gmean_kernel(const GmeanArgs a, float* __restrict__ out, int64_t n4) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  bool pos[4] = {true, true, true, true};
+  for (int k = 0; k < a.K; ++k) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(a.in[k])[i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      pos[c] = pos[c] && v[c] > 0.f;
+      acc[c] += logf(v[c] > 0.f ? v[c] : 1.f);
+    }
+  }
+  f32x4 o;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) o[c] = pos[c] ? expf(acc[c] / static_cast<float>(a.K)) : 0.f;
+  reinterpret_cast<f32x4*>(out)[i] = o;
+}
+
 }  // namespace
 
 extern "C" size_t mdg_rank_normalize_workspace_bytes(int64_t n_outcomes, int64_t N) {
@@ -208,5 +232,20 @@ extern "C" int mdg_rank_normalize(const float* scores, float* out, int64_t n_out
       hipLaunchKernelGGL((scatter_kernel<false, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, static_cast<int>(N), M, nblk, shift, denom);
   }
   MDG_CHECK_LAUNCH("mdg_rank_normalize");
+  return MDG_OK;
+}
+
+extern "C" int mdg_gmean(const float* const* inputs_host, int K, float* out, int64_t n, void* stream) {
+  MDG_CHECK_ARG(inputs_host && out && K >= 1 && K <= 8 && n >= 0 && n % 4 == 0, "mdg_gmean: 1 <= K <= 8 tensors of n (multiple of 4) floats");
+  if (n == 0) return MDG_OK;
+  GmeanArgs a{};
+  a.K = K;
+  for (int k = 0; k < K; ++k) {
+    MDG_CHECK_ARG(inputs_host[k] && mdg_aligned16(inputs_host[k]), "mdg_gmean: input %d null or not 16-byte aligned", k);
+    a.in[k] = inputs_host[k];
+  }
+  MDG_CHECK_ARG(mdg_aligned16(out), "mdg_gmean: out not 16-byte aligned");
+  hipLaunchKernelGGL(gmean_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n / 4, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), a, out, n / 4);
+  MDG_CHECK_LAUNCH("mdg_gmean");
   return MDG_OK;
 }

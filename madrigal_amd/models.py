@@ -79,17 +79,17 @@ _ACT_OF = {nn.ReLU: "relu", nn.LeakyReLU: "leakyrelu", nn.Tanh: "tanh", nn.Sigmo
            nn.Softplus: "softplus", nn.GELU: "gelu", nn.Identity: None}
 
 
-_derived = {}
-
-
 def _cached(owner, tag, tensors, build):
     """Weights derived from parameters (folded BatchNorm, block-diagonal relation matrices, padded / augmented
-    matrices) are rebuilt only when one of the source tensors changed (data pointer or in-place version)."""
-    key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors if t is not None)
-    slot = _derived.setdefault(id(owner), {})
+    matrices) are rebuilt only when one of the source tensors changed (storage address or in-place version).
+    The cache lives ON the owning module (it dies with it: Python recycles ids, the allocator recycles addresses)
+    and each entry pins its source tensors so that their addresses cannot be reused while the entry is alive."""
+    srcs = tuple(t for t in tensors if t is not None)
+    key = tuple((t.data_ptr(), t._version, str(t.device)) for t in srcs)
+    slot = owner.__dict__.setdefault("_mdg_derived", {})
     hit = slot.get(tag)
     if hit is None or hit[0] != key:
-        hit = (key, build())
+        hit = (key, build(), srcs)
         slot[tag] = hit
     return hit[1]
 

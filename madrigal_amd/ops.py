@@ -456,3 +456,23 @@ def rank_normalize(scores: torch.Tensor, out: Optional[torch.Tensor] = None, max
         check(lb.mdg_rank_normalize(_vp(s.data_ptr() + lo * N * N * 4), _vp(out.data_ptr() + lo * N * N * 4), _c64(hi - lo), _c64(N),
                                     _ptr(ws), ctypes.c_size_t(nbytes), _stream(s)), "mdg_rank_normalize")
     return out
+
+
+def gmean(tensors) -> torch.Tensor:
+    """Elementwise geometric mean of up to 8 equally shaped fp32 tensors (5-seed rank ensembling)."""
+    ts = [_f32_cuda(t, f"tensors[{i}]") for i, t in enumerate(tensors)]
+    if not 1 <= len(ts) <= 8 or any(t.shape != ts[0].shape for t in ts):
+        raise ValueError("gmean: 1..8 tensors of identical shape")
+    n = ts[0].numel()
+    if n % 4:
+        raise ValueError("gmean: element count must be a multiple of 4")
+    out = torch.empty_like(ts[0])
+    arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    check(lib().mdg_gmean(arr, _c(len(ts)), _ptr(out), _c64(n), _stream(out)), "mdg_gmean")
+    return out
+
+
+def ensemble_ranks(rank_tensors, max_workspace_bytes: int = 8 << 30) -> torch.Tensor:
+    """Seed ensembling of the reference (generate_embeddings.ipynb cells 18-20): geometric mean of the seeds'
+    normalised-rank tensors, then rank-normalised again per outcome."""
+    return rank_normalize(gmean(rank_tensors), max_workspace_bytes=max_workspace_bytes)

@@ -1,4 +1,5 @@
 // Does s_waitcnt vmcnt(K) after [LDS-DMA load][K younger stores] guarantee that the load has landed?
+// variant 3 (control): NO stores, so vmcnt(32) does not wait at all -> stale reads must show up.
 // variant 0: the K stores are out of range of their buffer descriptor (dropped); variant 1: real stores to
 // hot lines; variant 2: real stores, load from a hot (L2-resident) line.  Prints how many waves saw stale LDS.
 #include <hip/hip_runtime.h>
@@ -20,10 +21,12 @@ __global__ __launch_bounds__(64) void probe(const unsigned* src, size_t stride_w
     __syncthreads();
     const size_t line = (VARIANT == 2) ? 0 : ((size_t)blockIdx.x * rounds + it) * stride_words;
     glds16(src + line + lane * 4, (unsigned)(size_t)(lds_void*)buf);
+    if (VARIANT != 3) {
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      const unsigned off = (VARIANT == 0) ? 0xFFFFFFFFu : (unsigned)((k * 64 + lane) * 4);
-      __builtin_amdgcn_raw_buffer_store_b32(it * 1000u + k, rs, off, 0, 0);
+      for (int k = 0; k < 32; ++k) {
+        const unsigned off = (VARIANT == 0) ? 0xFFFFFFFFu : (unsigned)((k * 64 + lane) * 4);
+        __builtin_amdgcn_raw_buffer_store_b32(it * 1000u + k, rs, off, 0, 0);
+      }
     }
     asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     const unsigned v = buf[lane * 4];
@@ -42,12 +45,13 @@ int main() {
   hipMalloc(&src, words * 4); hipMemset(src, 0x11, words * 4);
   hipMalloc(&sink, (size_t)blocks * 4096 * 4); hipMalloc(&stale, blocks * 4);
   unsigned* h = (unsigned*)malloc(blocks * 4);
-  for (int variant = 0; variant < 3; ++variant) {
+  for (int variant = 0; variant < 4; ++variant) {
     hipMemset(stale, 0, blocks * 4);
     // evict: touch a big buffer so the source lines are cold again
     hipMemset(sink, variant, (size_t)blocks * 4096 * 4);
     if (variant == 0) hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(64), 0, 0, src, stride_words, sink, stale, rounds);
     if (variant == 1) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(64), 0, 0, src, stride_words, sink, stale, rounds);
+    if (variant == 3) hipLaunchKernelGGL(probe<3>, dim3(blocks), dim3(64), 0, 0, src, stride_words, sink, stale, rounds);
     if (variant == 2) hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(64), 0, 0, src, stride_words, sink, stale, rounds);
     hipDeviceSynchronize();
     hipMemcpy(h, stale, blocks * 4, hipMemcpyDeviceToHost);

@@ -115,3 +115,21 @@ def test_ranks_full_size_properties(ops):
         v = s[l][il[0], il[1]][order]
         assert bool(torch.all(v[1:] >= v[:-1]))                        # ascending scores <=> ascending ranks
         assert int(torch.unique(r).numel()) == M
+
+
+def test_gmean_and_seed_ensembling(ops):
+    """5-seed ensembling: gmean of normalised ranks (fp32, as scipy.stats.mstats.gmean on float32) then re-ranked."""
+    from oracle import madrigal_oracle as O
+    rng = np.random.default_rng(3)
+    N, L, K = 64, 3, 5
+    ranks = [O.rank_normalize(rng.standard_normal((L, N, N)).astype(np.float32)) for _ in range(K)]
+    with np.errstate(divide="ignore"):
+        ref = np.exp(np.mean(np.log(np.stack(ranks, -1)), axis=-1, dtype=np.float32)).astype(np.float32)
+    ref[:, np.arange(N), np.arange(N)] = 0.0
+    g = ops.gmean([torch.from_numpy(r).cuda() for r in ranks])
+    assert float(np.abs(g.cpu().numpy() - ref).max()) < 1e-6
+    ens = ops.ensemble_ranks([torch.from_numpy(r).cuda() for r in ranks]).cpu().numpy()
+    # re-ranking of the GPU gmean with the oracle: identical; vs the numpy gmean: same up to near-ties of fp32 log/exp
+    assert np.array_equal(ens, O.rank_normalize(g.cpu().numpy()))
+    assert float(np.abs(ens - O.rank_normalize(ref)).max()) < 5.0 / (N * (N - 1) / 2)
+    assert np.array_equal(ens, ens.transpose(0, 2, 1))
