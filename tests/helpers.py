@@ -155,3 +155,6 @@ def model_shapes_for_case(case, kg, L):
     else:
         s["encoder.pos_encoder.pe"] = (1, max_len, 128)
     return s
+
+
+from oracle.pipeline import oracle_pipeline  # noqa: E402,F401  (whole-path CPU oracle)

@@ -8,7 +8,7 @@ from oracle import madrigal_oracle as O
 from oracle.params import det_state_dict
 from madrigal_amd import data as D
 from helpers import (ENCODE_CASES, FUSION_CASES, chemcpa_shapes, fusion_params, mlp_shapes, model_shapes_for_case,
-                     rel_err, t)
+                     oracle_pipeline, rel_err, t)
 
 TOL = 2e-5
 
@@ -77,38 +77,14 @@ def test_chemcpa(golden):
 
 def encode_with_oracle(case, g):
     """Restated NovelDDIEncoder.encode + NovelDDIMultilabel.forward for one golden case."""
-    name, fusion, nb, pos, H, dh, ffn, nl, nf, agg, normalize, adapt = case
     n, L, seed = (int(v) for v in g["meta"])
     masks = t(g["masks"])
     batch, bkg = D.make_batch(n, seed, kg_nodes=300, kg_edges=2500, masks=masks)
-    keys = list(g["keys"])
     shapes = model_shapes_for_case(case, bkg["data"], L)
-    assert sorted(shapes) == keys
-    skip = [k for k in shapes if k.endswith("pos_encoder.pe") and pos == "sinusoidal"]
+    assert sorted(shapes) == list(g["keys"])
+    skip = [k for k in shapes if k.endswith("pos_encoder.pe") and case[3] == "sinusoidal"]
     p = det_state_dict(seed, shapes, skip)
-    enc = O._sub(p, "encoder.")
-    mols, kg = batch["strs"], bkg["data"]
-    str_out = O.gin_forward(O._sub(enc, "str_encoder."), mols.node_feature, mols.edge_list, mols.edge_feature,
-                            mols.node2graph, mols.batch_size, num_layers=4, num_mlp_layer=3)["graph_feature"]
-    kg_valid = O.hgt_forward(O._sub(enc, "kg_encoder."), kg.x_dict, kg.edge_index_dict, kg.node_types, kg.edge_types,
-                             num_layers=2, heads=4, hidden=128)["drug"]
-    kg_out = O.place_kg_rows(kg_valid, bkg["drug_index_map"], batch["drugs"], t(g["kg_filler"]))
-    cv_out = O.mlp_encoder_forward(O._sub(enc, "cv_encoder."), batch["cv"], 2, None, "relu", 0.2)
-    sigs = torch.cat([batch["tx"][c]["sigs"] for c in D.CELL_LINES])
-    cov = torch.arange(16).repeat_interleave(n)     # sklearn OneHotEncoder sorts categories; CELL_LINES is sorted
-    _, _, _, treated = O.chemcpa_predict(O._sub(enc, "tx_encoder."), sigs, cov, 3, 3, with_decoder=False)
-    all_embeds = torch.stack([str_out, kg_out, cv_out] + list(treated.split(n)), dim=1)
-    if pos == "sinusoidal":
-        max_len = (D.NUM_MODALITIES if nb == 0 else D.NUM_NON_TX_MODALITIES) + (1 if agg == "cls" else 0)
-        enc["pos_encoder.pe"] = O.sinusoidal_pe_table(128, max_len, nb, agg)
-    cfg = dict(fusion=fusion, normalize=normalize, adapt_before_fusion=adapt, pos_emb_type=pos, num_tx_bottlenecks=nb,
-               agg=agg, num_layers=nl, num_heads=H, norm_first=nf, actn="gelu",
-               proj=dict(n_hidden=2, norm="ln", actn="relu", dropout=0.2, order="nd"))
-    z = O.fuse_modalities(enc, all_embeds, masks, cfg)
-    z_raw = O.fuse_modalities(enc, all_embeds, masks, cfg, raw_encoder_output=True)
-    scores = O.bilinear_scores(z, z, p["decoder.parametrizations.weight.original"])
-    return dict(str_out=str_out, kg_out=kg_valid, cv_out=cv_out, z=z, z_raw=z_raw, scores=scores,
-                scores_2_5=O.bilinear_scores(z, z, p["decoder.parametrizations.weight.original"], (2, 5)))
+    return oracle_pipeline(case, p, batch, bkg, masks, t(g["kg_filler"]), label_slices=[(2, 5)])
 
 
 @pytest.mark.parametrize("case", ENCODE_CASES, ids=[c[0] for c in ENCODE_CASES])
