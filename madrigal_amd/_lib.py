@@ -36,6 +36,10 @@ def lib() -> ctypes.CDLL:
             raise MadrigalHipError(
                 f"{LIB_PATH} not found: build it with `python -m madrigal_amd.build` "
                 "(there is no CPU or PyTorch fallback for the HIP path)")
+        # torch first: its wheel bundles its own libamdhip64; loading ours afterwards makes the dynamic linker bind
+        # libmadrigal_hip.so to that same, already initialised HIP runtime (two runtimes in one process do not
+        # share devices, streams or allocations).
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.mdg_last_error.restype = ctypes.c_char_p
         _lib.mdg_build_arch.restype = ctypes.c_char_p
