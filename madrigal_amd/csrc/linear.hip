@@ -13,12 +13,25 @@
 // + MFMA: no conversion VALU, no ds_write, one raw barrier and one vmcnt wait per k-tile.
 // Arithmetic modes as in the head: exact fp32 MFMA, bf16x3 (fp32-grade), bf16.
 #include "mdg_common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
-constexpr int TILE_BYTES = BM * BK * 4;     // one operand, one stage: 16 KB (fp32) == hi 8 KB + lo 8 KB
-constexpr int LO_OFF = BM * BK * 2;
+constexpr int BK = 32;
+// Tile shapes: a wave owns MT x NT_ MFMA tiles of 32x32; WM x WN waves per workgroup.
+//   small: 2x2 tiles, 2x2 waves -> 128 x 128, 256 threads, 64 KB LDS, two workgroups per CU
+//   big  : 4x2 tiles, 2x4 waves -> 256 x 256, 512 threads, 128 KB LDS, one workgroup per CU: each staged operand
+//          byte feeds twice as many MFMAs, which is what the large fusion GEMMs (K = 2048) need.
+template <int MT_, int NT__, int WM_, int WN_>
+struct Shape {
+  static constexpr int MT = MT_, NT_ = NT__, WM = WM_, WN = WN_;
+  static constexpr int BM = 32 * MT_ * WM_, BN = 32 * NT__ * WN_, THREADS = 64 * WM_ * WN_, WAVES = WM_ * WN_;
+  static constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4;     // fp32 image == bf16 hi + lo images
+  static constexpr int A_LO = BM * BK * 2, B_LO = BN * BK * 2;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+};
+using Small = Shape<2, 2, 2, 2>;
+using Big = Shape<4, 2, 2, 4>;
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
@@ -51,15 +64,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_unifor
                : "memory");
 }
 
-// One operand tile (128 rows x 32 k) of stage k0 into LDS.  `base` is the operand image (fp32 [rows,ld] or one
+// One operand tile (ROWS rows x 32 k) of stage k0 into LDS.  `base` is the operand image (fp32 [rows,ld] or one
 // bf16 hi/lo image [rows,ld]); rows past the end clamp to the last row (their results are never stored).
-template <int ESIZE>   // 4 = fp32 tile (8 rows per 1-KiB piece), 2 = bf16 tile (16 rows per piece)
+template <int ESIZE, int ROWS, int WAVES>   // ESIZE 4 = fp32 tile (8 rows per 1-KiB piece), 2 = bf16 tile (16 rows per piece)
 __device__ __forceinline__ void dma_tile(const char* base, int64_t ld_bytes, int64_t row0, int64_t nrows, int64_t k0, char* lds,
                                          int wave, int lane) {
-  constexpr int PIECES = (ESIZE == 4) ? 16 : 8;
+  constexpr int PIECES = ROWS * BK * ESIZE / 1024;
+  static_assert(PIECES % WAVES == 0, "pieces must divide evenly over the waves");
 #pragma unroll
-  for (int i = 0; i < PIECES / 4; ++i) {
-    const int p = wave + 4 * i;
+  for (int i = 0; i < PIECES / WAVES; ++i) {
+    const int p = wave + WAVES * i;
     int row, c;
     if constexpr (ESIZE == 4) { row = 8 * p + (lane >> 3); c = (lane & 7) ^ ((row >> 1) & 7); }
     else { row = 16 * p + (lane >> 2); c = (lane & 3) ^ ((row >> 2) & 3); }
@@ -76,37 +90,38 @@ struct Operand {          // fp32: p0 = image; bf16 modes: p0 = hi image, p1 = l
   int64_t nrows;
 };
 
-template <int MODE>
+template <int MODE, class S>
 __device__ __forceinline__ void dma_stage(const Operand& A, const Operand& B, int64_t row0, int64_t col0, int64_t k0, char* lds,
                                           int wave, int lane) {
   if constexpr (MODE == MDG_PREC_F32) {
-    dma_tile<4>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane);
-    dma_tile<4>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + TILE_BYTES, wave, lane);
+    dma_tile<4, S::BM, S::WAVES>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane);
+    dma_tile<4, S::BN, S::WAVES>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES, wave, lane);
   } else {
-    dma_tile<2>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane);
-    dma_tile<2>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + TILE_BYTES, wave, lane);
+    dma_tile<2, S::BM, S::WAVES>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane);
+    dma_tile<2, S::BN, S::WAVES>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES, wave, lane);
     if constexpr (MODE == MDG_PREC_BF16X3) {
-      dma_tile<2>(A.p1, A.ld_bytes, row0, A.nrows, k0, lds + LO_OFF, wave, lane);
-      dma_tile<2>(B.p1, B.ld_bytes, col0, B.nrows, k0, lds + TILE_BYTES + LO_OFF, wave, lane);
+      dma_tile<2, S::BM, S::WAVES>(A.p1, A.ld_bytes, row0, A.nrows, k0, lds + S::A_LO, wave, lane);
+      dma_tile<2, S::BN, S::WAVES>(B.p1, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES + S::B_LO, wave, lane);
     }
   }
 }
 
-template <int MODE>
-__device__ __forceinline__ void mma_stage(const char* la, const char* lb, int wr, int wc, int r, int h, f32x16 (&acc)[2][2]) {
+template <int MODE, class S>
+__device__ __forceinline__ void mma_stage(const char* la, const char* lb, int wr, int wc, int r, int h,
+                                          f32x16 (&acc)[S::MT][S::NT_]) {
+  constexpr int MT = S::MT, NT_ = S::NT_;
   if constexpr (MODE == MDG_PREC_F32) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      f32x4 a[2], b[2];
+      f32x4 a[MT], b[NT_];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        a[t] = *reinterpret_cast<const f32x4*>(la + off_f32(wr * 64 + t * 32 + r, 2 * q + h));
-        b[t] = *reinterpret_cast<const f32x4*>(lb + off_f32(wc * 64 + t * 32 + r, 2 * q + h));
-      }
+      for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const f32x4*>(la + off_f32(wr * 32 * MT + t * 32 + r, 2 * q + h));
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int t = 0; t < NT_; ++t) b[t] = *reinterpret_cast<const f32x4*>(lb + off_f32(wc * 32 * NT_ + t * 32 + r, 2 * q + h));
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT_; ++nt)
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][e], b[nt][e], acc[mt][nt], 0, 0, 0);
@@ -114,21 +129,23 @@ __device__ __forceinline__ void mma_stage(const char* la, const char* lb, int wr
   } else {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 ah[2], al[2], bh[2], bl[2];
+      bf16x8 ah[MT], al[MT], bh[NT_], bl[NT_];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int oa = off_bf16(wr * 64 + t * 32 + r, 2 * s + h), ob = off_bf16(wc * 64 + t * 32 + r, 2 * s + h);
+      for (int t = 0; t < MT; ++t) {
+        const int oa = off_bf16(wr * 32 * MT + t * 32 + r, 2 * s + h);
         ah[t] = *reinterpret_cast<const bf16x8*>(la + oa);
-        bh[t] = *reinterpret_cast<const bf16x8*>(lb + ob);
-        if constexpr (MODE == MDG_PREC_BF16X3) {
-          al[t] = *reinterpret_cast<const bf16x8*>(la + LO_OFF + oa);
-          bl[t] = *reinterpret_cast<const bf16x8*>(lb + LO_OFF + ob);
-        }
+        if constexpr (MODE == MDG_PREC_BF16X3) al[t] = *reinterpret_cast<const bf16x8*>(la + S::A_LO + oa);
       }
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int t = 0; t < NT_; ++t) {
+        const int ob = off_bf16(wc * 32 * NT_ + t * 32 + r, 2 * s + h);
+        bh[t] = *reinterpret_cast<const bf16x8*>(lb + ob);
+        if constexpr (MODE == MDG_PREC_BF16X3) bl[t] = *reinterpret_cast<const bf16x8*>(lb + S::B_LO + ob);
+      }
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT_; ++nt) {
           if constexpr (MODE == MDG_PREC_BF16X3) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
@@ -152,45 +169,46 @@ struct LinearArgs {
 // Pipeline: one raw barrier per k-tile.  Top of tile kt: wait for this wave's DMA pieces of tile kt (the only
 // vector-memory ops in flight), barrier (=> every wave's pieces landed, every wave finished reading tile kt-1),
 // issue the DMA of tile kt+1 into the other buffer, then the MFMAs of tile kt run under that DMA.
-template <int MODE>
-__global__ __launch_bounds__(NT, 2) void linear_kernel(const LinearArgs p) {
+template <int MODE, class S>
+__global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A tile | B tile]
+  constexpr int MT = S::MT, NT_ = S::NT_;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int64_t col0 = static_cast<int64_t>(blockIdx.x) * BN, row0 = static_cast<int64_t>(blockIdx.y) * BM;
+  const int wr = wave / S::WN, wc = wave % S::WN;
+  const int64_t col0 = static_cast<int64_t>(blockIdx.x) * S::BN, row0 = static_cast<int64_t>(blockIdx.y) * S::BM;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][NT_];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NT_; ++b)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
 
   const int nk = static_cast<int>(p.K / BK);
-  dma_stage<MODE>(p.A, p.B, row0, col0, 0, smem, wave, lane);
+  dma_stage<MODE, S>(p.A, p.B, row0, col0, 0, smem, wave, lane);
   for (int kt = 0; kt < nk; ++kt) {
-    char* const cur = smem + (kt & 1) * 2 * TILE_BYTES;
-    char* const nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+    char* const cur = smem + (kt & 1) * S::STAGE;
+    char* const nxt = smem + ((kt + 1) & 1) * S::STAGE;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) dma_stage<MODE>(p.A, p.B, row0, col0, static_cast<int64_t>(kt + 1) * BK, nxt, wave, lane);
-    mma_stage<MODE>(cur, cur + TILE_BYTES, wr, wc, r, h, acc);
+    if (kt + 1 < nk) dma_stage<MODE, S>(p.A, p.B, row0, col0, static_cast<int64_t>(kt + 1) * BK, nxt, wave, lane);
+    mma_stage<MODE, S>(cur, cur + S::A_BYTES, wr, wc, r, h, acc);
   }
 
   // ---- epilogue: lane = output column, accumulator registers = rows ---------------------
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int64_t n = col0 + wc * 64 + nt * 32 + r;
+  for (int nt = 0; nt < NT_; ++nt) {
+    const int64_t n = col0 + wc * 32 * NT_ + nt * 32 + r;
     const bool n_ok = n < p.N;
     const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
     const float scale = (p.scale && n_ok) ? p.scale[n] : 1.f;
     const float shift = (p.shift && n_ok) ? p.shift[n] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll 4
       for (int v = 0; v < 16; ++v) {
-        const int64_t m = row0 + wr * 64 + mt * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+        const int64_t m = row0 + wr * 32 * MT + mt * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
         if (n_ok && m < p.M) {
           float val = acc[mt][nt][v] + bias;
           if (p.scale) val = val * scale + shift;
@@ -355,7 +373,7 @@ extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t l
   MDG_CHECK_ARG(ldy >= N && (!residual || ldr >= N || ldr == 0), "mdg_linear: ldy/ldr smaller than N (ldr == 0 broadcasts one row)");
   MDG_CHECK_ARG((scale == nullptr) == (shift == nullptr), "mdg_linear: scale and shift come together");
   MDG_CHECK_ARG(act >= MDG_ACT_NONE && act <= MDG_ACT_SELU, "mdg_linear: unknown activation %d", act);
-  MDG_CHECK_ARG(mdg_cdiv(M, BM) <= 65535, "mdg_linear: M too large for one launch");
+  MDG_CHECK_ARG(mdg_cdiv(M, Small::BM) <= 65535, "mdg_linear: M too large for one launch");
   MDG_CHECK_ARG(precision == MDG_PREC_F32 || precision == MDG_PREC_BF16X3 || precision == MDG_PREC_BF16, "mdg_linear: unknown precision %d", precision);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t xb = image_bytes(M, K, precision), wb = image_bytes(N, K, precision);
@@ -378,12 +396,26 @@ extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t l
   a.alpha = alpha; a.beta = beta; a.act = act; a.M = M; a.N = N; a.K = pad32(K);
   set_operand(a.A, x, ldx, ximg, M, K, precision);
   set_operand(a.B, w, ldw, wb == 0 ? nullptr : (w_packed ? static_cast<const char*>(w_packed) : wimg), N, K, precision);
-  const dim3 grid(static_cast<unsigned>(mdg_cdiv(N, BN)), static_cast<unsigned>(mdg_cdiv(M, BM)));
-  const size_t lds = 4 * TILE_BYTES;
-  switch (precision) {
-    case MDG_PREC_F32: hipLaunchKernelGGL(linear_kernel<MDG_PREC_F32>, grid, dim3(NT), lds, st, a); break;
-    case MDG_PREC_BF16X3: hipLaunchKernelGGL(linear_kernel<MDG_PREC_BF16X3>, grid, dim3(NT), lds, st, a); break;
-    default: hipLaunchKernelGGL(linear_kernel<MDG_PREC_BF16>, grid, dim3(NT), lds, st, a); break;
+  // tile shape: the 256x256 / 8-wave shape once the problem fills the chip with it, else 128x128 / 4 waves
+  // (measured on the fusion GEMMs: bf16x3 -9 % time with the big tile, fp32 +6 %: the fp32 MFMA wants two workgroups per CU)
+  bool big = (precision != MDG_PREC_F32 && N >= 256 && M >= 1024 && mdg_cdiv(M, Big::BM) * mdg_cdiv(N, Big::BN) >= 192);
+  if (const char* e = getenv("MDG_LINEAR_TILE")) big = atoi(e) == 256 ? true : (atoi(e) == 128 ? false : big);
+  if (big) {
+    const dim3 grid(static_cast<unsigned>(mdg_cdiv(N, Big::BN)), static_cast<unsigned>(mdg_cdiv(M, Big::BM)));
+    const size_t lds = 2 * Big::STAGE;
+    switch (precision) {
+      case MDG_PREC_F32: hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, Big>), grid, dim3(Big::THREADS), lds, st, a); break;
+      case MDG_PREC_BF16X3: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, Big>), grid, dim3(Big::THREADS), lds, st, a); break;
+      default: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, Big>), grid, dim3(Big::THREADS), lds, st, a); break;
+    }
+  } else {
+    const dim3 grid(static_cast<unsigned>(mdg_cdiv(N, Small::BN)), static_cast<unsigned>(mdg_cdiv(M, Small::BM)));
+    const size_t lds = 2 * Small::STAGE;
+    switch (precision) {
+      case MDG_PREC_F32: hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, Small>), grid, dim3(Small::THREADS), lds, st, a); break;
+      case MDG_PREC_BF16X3: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, Small>), grid, dim3(Small::THREADS), lds, st, a); break;
+      default: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, Small>), grid, dim3(Small::THREADS), lds, st, a); break;
+    }
   }
   MDG_CHECK_LAUNCH("mdg_linear");
   return MDG_OK;
