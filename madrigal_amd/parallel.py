@@ -34,6 +34,9 @@ def all_gather_rows(local: torch.Tensor, n_total: int, rank: int, world: int, gr
     Uneven blocks are padded to the largest block so that one ``all_gather_into_tensor`` suffices."""
     if world == 1:
         return local
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # functional rehearsal of the multi-rank path without RCCL (several ranks sharing one card): stage via the host
+        return all_gather_rows(local.cpu(), n_total, rank, world, group).to(local.device)
     sizes = shard_sizes(n_total, world)
     if local.shape[0] != sizes[rank]:
         raise ValueError(f"rank {rank}: expected {sizes[rank]} rows, got {local.shape[0]}")
