@@ -319,10 +319,18 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
       const int64_t col = tcol0 + 32 * t + r;
       const bool col_ok = col < p.n_tail;
       if constexpr (EPI == MDG_EPI_ROWSTATS) {
+        if (tcol0 + BN <= p.n_tail) {          // whole tile in range (wave-uniform): no per-element masking
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          rsum[v] += col_ok ? acc[t][v] : 0.f;
-          rmax[v] = fmaxf(rmax[v], col_ok ? acc[t][v] : -INFINITY);
+          for (int v = 0; v < 16; ++v) {
+            rsum[v] += acc[t][v];
+            rmax[v] = fmaxf(rmax[v], acc[t][v]);
+          }
+        } else {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            rsum[v] += col_ok ? acc[t][v] : 0.f;
+            rmax[v] = fmaxf(rmax[v], col_ok ? acc[t][v] : -INFINITY);
+          }
         }
       } else {
 #pragma unroll
@@ -354,15 +362,39 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
     // do their MFMAs together and their stores together; the younger half issues the stores of the PREVIOUS
     // tile (held in registers) before its MFMAs, so one partner stores while the other computes.
     const bool late = (EPI != MDG_EPI_ROWSTATS) && p.stagger_waves && (__builtin_amdgcn_readfirstlane(wave) >= NW / 2);
-    constexpr bool kStores = (EPI != MDG_EPI_ROWSTATS);
+    if constexpr (EPI == MDG_EPI_ROWSTATS) {
+      // Nothing is stored, so a stage is only the MFMAs of 64 tail rows (~1000 matrix-pipe cycles per SIMD): shorter
+      // than the LDS-DMA latency.  Three buffers, prefetch distance two; the vector-memory stream of a wave holds
+      // loads only (in order), so `vmcnt(NDMA)` retires tile s and leaves tile s+1 in flight.
+      constexpr int NDMA = (MODE == MDG_PREC_BF16 ? 16 : 32) / NW;       // LDS-DMA instructions per wave and tile
+      stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, smem, wave, lane, NW);
+      stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(1 < nst ? 1 : 0)) * BN, smem + STAGE_BYTES, wave, lane, NW);
+      int cur = 0;
+      for (int s = 0; s < nst; ++s) {
+        const int64_t tcol0 = static_cast<int64_t>(tile_of(s)) * BN;
+        if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // tile s landed for every wave; every wave finished reading tile s-1
+        const int nxt2 = cur == 0 ? 2 : cur - 1;                           // (cur + 2) % 3 = buffer of tile s-1
+        const int s2 = s + 2 < nst ? s + 2 : nst - 1;                      // past the end: a copy nobody consumes
+        stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(s2)) * BN, smem + nxt2 * STAGE_BYTES, wave, lane, NW);
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        compute_tile<MODE>(At, smem + cur * STAGE_BYTES, r, h, acc);
+        epilogue(acc, tcol0);
+        cur = cur == 2 ? 0 : cur + 1;
+      }
+    } else {
     stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, buf0, wave, lane, NW);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int s = 0; s < nst; ++s) {
       const int64_t tcol0 = static_cast<int64_t>(tile_of(s)) * BN;
       char* const cur = (s & 1) ? buf1 : buf0;
       char* const nxt = (s & 1) ? buf0 : buf1;
-      if constexpr (kStores) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       // past the end the tile index repeats the last one; that copy is never consumed
       stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(s + 1 < nst ? s + 1 : s)) * BN, nxt, wave, lane, NW);
@@ -381,6 +413,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
         compute_tile<MODE>(At, cur, r, h, acc);
         epilogue(acc, tcol0);
       }
+    }
     }
     if (late) epilogue(held, held_col0);
   } else {
@@ -473,8 +506,8 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
     case MDG_EPI_STORE_SIGMOID:
       hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE_SIGMOID, NW>), grid, block, lds, st, a);
       break;
-    case MDG_EPI_ROWSTATS:
-      hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_ROWSTATS, NW>), grid, block, lds, st, a);
+    case MDG_EPI_ROWSTATS:      // three-buffer ring (prefetch distance two)
+      hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_ROWSTATS, NW>), grid, block, 3 * STAGE_BYTES, st, a);
       break;
     default:
       mdg_set_error("mdg_bilinear_allpairs: unknown epilogue %d", epilogue);
