@@ -212,6 +212,49 @@ int mdg_rank_normalize(const float* scores, float* out, int64_t n_outcomes, int6
  * x_k <= 0.  inputs_host is a HOST array of K device pointers; n (elements) must be a multiple of 4. */
 int mdg_gmean(const float* const* inputs_host, int K, float* out, int64_t n, void* stream);
 
+/* ------------------------------------------------------- backward-pass building blocks ---- */
+/* (the finetune step of train_ddi_batch.py:285-354: loss.backward() through the modules above) */
+
+/* out[c, r] = in[r, c]   (dW = dY^T X and dX = dY W are mdg_linear calls on transposed operands) */
+int mdg_transpose(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t rows, int64_t cols, void* stream);
+
+/* out[c] = beta * out[c] + sum_r x[r, c], fixed summation order (bias / LayerNorm / learned-token gradients). */
+size_t mdg_colsum_workspace_bytes(int64_t rows, int64_t cols);
+int mdg_colsum(const float* x, int64_t ldx, float* out, int64_t rows, int64_t cols, float beta, void* workspace,
+               size_t workspace_bytes, void* stream);
+
+/* y = act(pre) and dx = dy * act'(pre), elementwise over n contiguous floats (training keeps the pre-activation). */
+int mdg_activation_fwd(const float* pre, float* y, int64_t n, int activation, void* stream);
+int mdg_activation_bwd(const float* dy, const float* pre, float* dx, int64_t n, int activation, void* stream);
+
+/* out[i] = alpha * a[i] + beta * b[i mod nb] (residual adds of the training path; nb < n broadcasts a row over rows). */
+int mdg_axpby(const float* a, const float* b, float* out, int64_t n, int64_t nb, float alpha, float beta, void* stream);
+
+/* Inverted dropout y = x * keep / (1-p); keep is a counter-based hash of (seed, element index), so calling it again
+ * with the same seed on dy is the backward pass (nn.Dropout of the transformer / MLPs / position encoder). */
+int mdg_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+
+/* nn.BatchNorm1d in training mode over the rows of x [rows, cols] (torchdrug MultiLayerPerceptron batch_norm,
+ * chemCPA MLP), fused with the following activation: y = act((x - mean) * rstd * gamma + beta); running statistics are
+ * updated in place (momentum, unbiased variance).  stats [4*cols] receives mean | rstd | scale | shift for the backward. */
+size_t mdg_batchnorm_workspace_bytes(int64_t rows, int64_t cols);
+int mdg_batchnorm_train_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, float* y, int64_t ldy, float* stats, int64_t rows, int64_t cols, float eps,
+                            float momentum, int activation, void* workspace, size_t workspace_bytes, void* stream);
+/* dy is the gradient at the BN output (before the activation); x, dy, dx contiguous [rows, cols]. */
+int mdg_batchnorm_train_bwd(const float* dy, const float* x, const float* stats, float* dx, float* dgamma, float* dbeta,
+                            int64_t rows, int64_t cols, void* workspace, size_t workspace_bytes, void* stream);
+
+/* y = act(x * scale[c] + shift[c]) per column (eval-mode BatchNorm inside a differentiated graph; shift may be NULL). */
+int mdg_affine_act(const float* x, int64_t ldx, const float* scale, const float* shift, float* y, int64_t ldy, int64_t rows,
+                   int64_t cols, int activation, void* stream);
+
+/* LayerNorm backward (statistics recomputed from x): dx, dgamma, dbeta.  d <= 1024. */
+size_t mdg_layernorm_bwd_workspace_bytes(int64_t rows, int64_t d);
+int mdg_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, float* dx, int64_t lddx,
+                      float* dgamma, float* dbeta, int64_t rows, int64_t d, float eps, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,205 @@
+"""Autograd nodes over the HIP kernels: the finetune step (train_ddi_batch.py:231-354) backpropagates through the
+same modules as inference, with every forward AND backward product computed by ``libmadrigal_hip.so``.
+
+``torch.autograd.Function`` is used for what it is — the tape; no torch arithmetic runs inside these nodes.  Each
+node's backward is checked in tests/test_train_gpu.py against torch's own autograd over the reference module
+structure on the CPU (the reference's backward *is* torch autograd).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import ops
+
+
+def needs_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
+def next_seed() -> int:
+    """A fresh dropout seed from torch's CPU generator (follows torch.manual_seed; no device sync)."""
+    return int(torch.randint(0, 2 ** 62, (1,), device="cpu").item())
+
+
+class _Linear(Function):
+    """y = act(x W^T + b);  dX = g W,  dW = g^T X,  db = colsum(g),  g = dy * act'(pre)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, precision):
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1])
+        if act in (None, "none", "relu"):
+            y = ops.linear(x2, w, b, act=act, precision=precision, cache_weight=False)
+            pre = y if act == "relu" else None
+        else:
+            pre = ops.linear(x2, w, b, precision=precision, cache_weight=False)
+            y = ops.activation_fwd(pre, act)
+        ctx.save_for_backward(x2, w, pre)
+        ctx.act, ctx.precision, ctx.has_bias, ctx.lead = act, precision, b is not None, lead
+        return y.view(*lead, w.shape[0])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, w, pre = ctx.saved_tensors
+        g = dy.reshape(-1, w.shape[0])
+        g = g if g.is_contiguous() else g.contiguous()
+        if pre is not None:
+            g = ops.activation_bwd(g, pre, ctx.act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear(g, ops.transpose(w), precision=ctx.precision, cache_weight=False)[:, :x2.shape[1]]
+            dx = dx.reshape(*ctx.lead, x2.shape[1])
+        if ctx.needs_input_grad[1]:
+            dw = ops.linear(ops.transpose(g), ops.transpose(x2), precision=ctx.precision, cache_weight=False)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(g)
+        return dx, dw, db, None, None
+
+
+def linear(x, w, b=None, act=None, precision="bf16x3"):
+    return _Linear.apply(x, w, b, act, precision)
+
+
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = x if x.is_contiguous() else x.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.eps = eps
+        return ops.layernorm(x, weight, bias, eps)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(dy if dy.is_contiguous() else dy.contiguous(), x, weight, ctx.eps)
+        return dx, dg, db, None
+
+
+def layernorm(x, weight, bias, eps=1e-5):
+    return _LayerNorm.apply(x, weight, bias, eps)
+
+
+class _BatchNormAct(Function):
+    """nn.BatchNorm1d with batch statistics, fused with the activation that follows it."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act):
+        x = x if x.is_contiguous() else x.contiguous()
+        fused = act if act in (None, "none", "relu") else None
+        y, stats = ops.batchnorm_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, act=fused)
+        pre = None
+        if act == "relu":
+            pre = y
+        elif fused is None and act not in (None, "none"):
+            pre, y = y, ops.activation_fwd(y, act)
+        ctx.save_for_backward(x, stats, pre)
+        ctx.act = act
+        ctx.affine = gamma is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, stats, pre = ctx.saved_tensors
+        g = dy if dy.is_contiguous() else dy.contiguous()
+        if pre is not None:
+            g = ops.activation_bwd(g, pre, ctx.act)
+        dx, dg, db = ops.batchnorm_train_bwd(g, x, stats)
+        return dx, (dg if ctx.affine else None), (db if ctx.affine else None), None, None, None, None, None
+
+
+def batchnorm_act(x, bn: torch.nn.BatchNorm1d, act=None):
+    """Training-mode BatchNorm1d (+ activation) of a [rows, C] tensor; updates bn.running_* and num_batches_tracked."""
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative average) is not used by the reference")
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return _BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, act)
+
+
+class _Dropout(Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return ops.dropout(x if x.is_contiguous() else x.contiguous(), p, seed)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return ops.dropout(dy if dy.is_contiguous() else dy.contiguous(), ctx.p, ctx.seed), None, None
+
+
+def dropout(x, p: float, training: bool = True, seed: Optional[int] = None):
+    if not training or p == 0.0:
+        return x
+    if p >= 1.0:
+        raise ValueError("dropout p must be < 1")
+    return _Dropout.apply(x, float(p), next_seed() if seed is None else seed)
+
+
+class _AffineAct(Function):
+    """Eval-mode BatchNorm (constant per-column scale / shift) + activation inside a differentiated graph."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, act):
+        x = x if x.is_contiguous() else x.contiguous()
+        if act in (None, "none", "relu"):
+            y = ops.affine_act(x, scale, shift, act)
+            pre = y if act == "relu" else None
+        else:
+            pre = ops.affine_act(x, scale, shift, None)
+            y = ops.activation_fwd(pre, act)
+        ctx.save_for_backward(scale, pre)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        scale, pre = ctx.saved_tensors
+        g = dy if dy.is_contiguous() else dy.contiguous()
+        if pre is not None:
+            g = ops.activation_bwd(g, pre, ctx.act)
+        return ops.affine_act(g, scale, None, None), None, None, None
+
+
+def affine_act(x, scale, shift, act=None):
+    return _AffineAct.apply(x, scale, shift, act)
+
+
+class _Axpby(Function):
+    """alpha * a + beta * b with b broadcast over the leading dims of a (residual adds)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha, beta):
+        ctx.alpha, ctx.beta, ctx.bshape, ctx.same = alpha, beta, b.shape, b.numel() == a.numel()
+        return ops.axpby(a, b, alpha, beta)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = dy if ctx.alpha == 1.0 else ops.axpby(dy, dy, ctx.alpha, 0.0)
+        if ctx.needs_input_grad[1]:
+            if ctx.same:
+                db = (dy if ctx.beta == 1.0 else ops.axpby(dy, dy, ctx.beta, 0.0)).view(ctx.bshape)
+            else:
+                nb = 1
+                for s in ctx.bshape:
+                    nb *= s
+                db = ops.colsum(dy.reshape(-1, nb))
+                db = (db if ctx.beta == 1.0 else ops.axpby(db, db, ctx.beta, 0.0)).view(ctx.bshape)
+        return da, db, None, None
+
+
+def add(a, b, alpha: float = 1.0, beta: float = 1.0):
+    return _Axpby.apply(a, b, alpha, beta)

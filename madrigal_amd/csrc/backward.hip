@@ -1,0 +1,441 @@
+// Backward-pass building blocks for gfx950 (finetune step of train_ddi_batch.py:231-354).
+// All streaming / HBM-bound except where noted; reductions are atomic-free with a fixed summation order.
+#include "mdg_common.h"
+
+namespace {
+
+// ---- out[c, r] = in[r, c]: 64x64 tiles through LDS (padded), coalesced on both sides ----------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int64_t ldi, float* __restrict__ out,
+                                                        int64_t ldo, int64_t rows, int64_t cols) {
+  __shared__ float tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * 64, c0 = static_cast<int64_t>(blockIdx.x) * 64;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t r = r0 + ty + 4 * i, c = c0 + tx;
+    tile[ty + 4 * i][tx] = (r < rows && c < cols) ? in[r * ldi + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t c = c0 + ty + 4 * i, r = r0 + tx;
+    if (c < cols && r < rows) out[c * ldo + r] = tile[tx][ty + 4 * i];
+  }
+}
+
+// ---- column sums: out[c] (+)= sum_r x[r, c].  Two passes: per-block partial sums over 256-row slabs, then a fixed
+// order reduction of the partials.  (bias gradients, LayerNorm gamma/beta gradients, learned-token gradients)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ part,
+                                                             int64_t rows, int64_t cols) {
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
+  const int ty = threadIdx.x >> 6;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * 256;
+  float s = 0.f;
+  if (c < cols)
+    for (int i = 0; i < 64; ++i) {
+      const int64_t r = r0 + ty + 4 * i;
+      if (r < rows) s += x[r * ldx + c];
+    }
+  __shared__ float sh[4][64];
+  sh[ty][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ty == 0 && c < cols) part[static_cast<int64_t>(blockIdx.y) * cols + c] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int64_t ldp, float* __restrict__ out,
+                                                           int64_t nparts, int64_t cols, float beta) {
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int64_t p = 0; p < nparts; ++p) s += part[p * ldp + c];
+  out[c] = (beta != 0.f ? beta * out[c] : 0.f) + s;
+}
+
+// ---- dx = dy * act'(pre) -------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_grad(float x, int act) {
+  switch (act) {
+    case MDG_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case MDG_ACT_GELU: {   // d/dx [x Phi(x)] = Phi(x) + x phi(x)
+      const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+      return cdf + x * 0.39894228040143268f * expf(-0.5f * x * x);
+    }
+    case MDG_ACT_SIGMOID: { const float s = 1.0f / (1.0f + expf(-x)); return s * (1.f - s); }
+    case MDG_ACT_TANH: { const float t = tanhf(x); return 1.f - t * t; }
+    case MDG_ACT_LEAKYRELU: return x >= 0.f ? 1.f : 0.01f;
+    case MDG_ACT_SOFTPLUS: return 1.0f / (1.0f + expf(-x));
+    case MDG_ACT_SELU: return 1.0507009873554804934193349852946f * (x > 0.f ? 1.f : 1.6732632423543772848170429916717f * expf(x));
+    default: return 1.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dx,
+                                                      int64_t n, int act) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) dx[i] = dy[i] * act_grad(pre[i], act);
+}
+
+// ---- y = act(pre) (training keeps the pre-activation for the backward pass) ------------------------------------
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  switch (act) {
+    case MDG_ACT_RELU: return fmaxf(v, 0.f);
+    case MDG_ACT_GELU: return mdg_gelu(v);
+    case MDG_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case MDG_ACT_TANH: return tanhf(v);
+    case MDG_ACT_LEAKYRELU: return v >= 0.f ? v : 0.01f * v;
+    case MDG_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
+    case MDG_ACT_SELU: return 1.0507009873554804934193349852946f * (v > 0.f ? v : 1.6732632423543772848170429916717f * (expf(v) - 1.f));
+    default: return v;
+  }
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ pre, float* __restrict__ y, int64_t n, int act) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) y[i] = act_fwd(pre[i], act);
+}
+
+// ---- out = alpha * a + beta * b[i mod nb]  (residual adds; nb < n broadcasts a row vector over rows) ------------------
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n,
+                                                    int64_t nb, float alpha, float beta) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) out[i] = alpha * a[i] + beta * b[nb == n ? i : i % nb];
+}
+
+// ---- dropout: y = x * keep / (1 - p), keep ~ Bernoulli(1-p) from a counter-based hash of (seed, element index);
+// the same (seed, index) reproduces the mask in the backward pass, so no mask tensor is stored. -------------------
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {      // splitmix64 finaliser, high word
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return static_cast<uint32_t>((z ^ (z >> 31)) >> 32);
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p,
+                                                      uint64_t seed) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t thr = static_cast<uint32_t>(static_cast<double>(p) * 4294967296.0);
+  const bool keep = mix32(seed * 0x100000001B3ull + static_cast<uint64_t>(i)) >= thr;
+  y[i] = keep ? x[i] * (1.0f / (1.0f - p)) : 0.f;
+}
+
+
+// ---- generalised column reductions for BatchNorm1d in training mode (torchdrug MLP / chemCPA MLP batch_norm) ------
+//   mode 0: sum_r x                      mode 1: sum_r (x - center[c])^2
+//   mode 2: sum_r x * (y - center[c]) * rstd[c]      (x = dy, y = BN input: the dgamma reduction)
+__global__ __launch_bounds__(256) void colreduce_partial_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ y,
+                                                                int64_t ldy, const float* __restrict__ center,
+                                                                const float* __restrict__ rstd, float* __restrict__ part,
+                                                                int64_t rows, int64_t cols, int mode) {
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
+  const int ty = threadIdx.x >> 6;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * 256;
+  float s = 0.f;
+  if (c < cols) {
+    const float mu = center ? center[c] : 0.f, rs = rstd ? rstd[c] : 1.f;
+    for (int i = 0; i < 64; ++i) {
+      const int64_t r = r0 + ty + 4 * i;
+      if (r >= rows) break;
+      const float v = x[r * ldx + c];
+      if (mode == 0) s += v;
+      else if (mode == 1) s += (v - mu) * (v - mu);
+      else s += v * ((y[r * ldy + c] - mu) * rs);
+    }
+  }
+  __shared__ float sh[4][64];
+  sh[ty][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ty == 0 && c < cols) part[static_cast<int64_t>(blockIdx.y) * cols + c] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+// stats[0:N]=mean, [N:2N]=rstd, [2N:3N]=scale=gamma*rstd, [3N:4N]=shift=beta-mean*scale; running stats updated like
+// nn.BatchNorm1d (momentum, unbiased variance).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sqsum, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ stats, int64_t rows,
+                                                          int64_t cols, float eps, float momentum, int phase) {
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (c >= cols) return;
+  if (phase == 0) { stats[c] = sum[c] / static_cast<float>(rows); return; }
+  const float mean = stats[c];
+  const float var = sqsum[c] / static_cast<float>(rows);
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  stats[cols + c] = rstd;
+  stats[2 * cols + c] = g * rstd;
+  stats[3 * cols + c] = b - mean * g * rstd;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (rows > 1 ? sqsum[c] / static_cast<float>(rows - 1) : var);
+}
+
+// y = act(x * scale[c] + shift[c])
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* __restrict__ y, int64_t ldy, int64_t rows,
+                                                         int64_t cols, int act) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int64_t r = i / cols, c = i - r * cols;
+  y[r * ldy + c] = act_fwd(x[r * ldx + c] * scale[c] + (shift ? shift[c] : 0.f), act);
+}
+
+// dx = scale[c] * (dy - sum_dy[c]/M - xhat * sum_dy_xhat[c]/M),  xhat = (x - mean[c]) * rstd[c]
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
+                                                           const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat,
+                                                           float* __restrict__ dx, int64_t rows, int64_t cols) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int64_t c = i % cols;
+  const float inv = 1.0f / static_cast<float>(rows);
+  const float xhat = (x[i] - stats[c]) * stats[cols + c];
+  dx[i] = stats[2 * cols + c] * (dy[i] - sum_dy[c] * inv - xhat * (sum_dy_xhat[c] * inv));
+}
+
+// ---- LayerNorm backward: one wave per row, 64 rows per block; per-block partial dgamma / dbeta -------------------
+constexpr int LN_MAXJ = 16;     // d <= 1024
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ gamma, float* __restrict__ dx, int64_t lddx,
+                                                            float* __restrict__ part, int64_t rows, int d, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nj = (d + 63) >> 6;
+  float dg[LN_MAXJ], db[LN_MAXJ];
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) dg[j] = db[j] = 0.f;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 64;
+  for (int i = wave; i < 64; i += 4) {
+    const int64_t r = r0 + i;
+    if (r >= rows) break;
+    float xv[LN_MAXJ], gv[LN_MAXJ];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      const int c = lane + 64 * j;
+      const bool ok = j < nj && c < d;
+      xv[j] = ok ? x[r * ldx + c] : 0.f;
+      gv[j] = ok ? dy[r * lddy + c] : 0.f;
+      s += xv[j];
+    }
+    const float mean = mdg_wave_sum(s) / static_cast<float>(d);
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      const int c = lane + 64 * j;
+      const float t = (j < nj && c < d) ? xv[j] - mean : 0.f;
+      v += t * t;
+    }
+    const float rstd = 1.0f / sqrtf(mdg_wave_sum(v) / static_cast<float>(d) + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      const int c = lane + 64 * j;
+      if (j < nj && c < d) {
+        const float xhat = (xv[j] - mean) * rstd;
+        const float dxh = gv[j] * gamma[c];
+        dg[j] += gv[j] * xhat;
+        db[j] += gv[j];
+        s1 += dxh;
+        s2 += dxh * xhat;
+        xv[j] = xhat;
+        gv[j] = dxh;
+      }
+    }
+    s1 = mdg_wave_sum(s1) / static_cast<float>(d);
+    s2 = mdg_wave_sum(s2) / static_cast<float>(d);
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      const int c = lane + 64 * j;
+      if (j < nj && c < d) dx[r * lddx + c] = rstd * (gv[j] - s1 - xv[j] * s2);
+    }
+  }
+  // block partials: part[block][0][c] = dgamma, part[block][1][c] = dbeta
+  extern __shared__ float sh[];       // [4][2][d]
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) {
+    const int c = lane + 64 * j;
+    if (j < nj && c < d) {
+      sh[(wave * 2 + 0) * d + c] = dg[j];
+      sh[(wave * 2 + 1) * d + c] = db[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * d; i += 256)
+    part[static_cast<int64_t>(blockIdx.x) * 2 * d + i] = (sh[i] + sh[2 * d + i]) + (sh[4 * d + i] + sh[6 * d + i]);
+}
+
+}  // namespace
+
+extern "C" int mdg_transpose(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t rows, int64_t cols, void* stream) {
+  MDG_CHECK_ARG(rows >= 0 && cols >= 0 && ldi >= cols && ldo >= rows, "mdg_transpose: bad shape");
+  if (rows == 0 || cols == 0) return MDG_OK;
+  MDG_CHECK_ARG(in && out && in != out, "mdg_transpose: null / aliased pointers");
+  hipLaunchKernelGGL(transpose_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64)), static_cast<unsigned>(mdg_cdiv(rows, 64))),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), in, ldi, out, ldo, rows, cols);
+  MDG_CHECK_LAUNCH("mdg_transpose");
+  return MDG_OK;
+}
+
+extern "C" size_t mdg_colsum_workspace_bytes(int64_t rows, int64_t cols) {
+  return rows <= 0 || cols <= 0 ? 0 : static_cast<size_t>(mdg_cdiv(rows, 256)) * cols * sizeof(float);
+}
+
+extern "C" int mdg_colsum(const float* x, int64_t ldx, float* out, int64_t rows, int64_t cols, float beta, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(rows >= 0 && cols > 0 && ldx >= cols, "mdg_colsum: bad shape");
+  MDG_CHECK_ARG(out, "mdg_colsum: null out");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t nparts = mdg_cdiv(rows, 256);
+  const size_t need = mdg_colsum_workspace_bytes(rows, cols);
+  if (need && (!workspace || workspace_bytes < need)) {
+    mdg_set_error("mdg_colsum: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return MDG_EWORKSPACE;
+  }
+  if (rows > 0) {
+    MDG_CHECK_ARG(x, "mdg_colsum: null x");
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64)), static_cast<unsigned>(nparts)), dim3(256), 0, st,
+                       x, ldx, static_cast<float*>(workspace), rows, cols);
+  }
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 256))), dim3(256), 0, st,
+                     static_cast<const float*>(workspace), cols, out, nparts, cols, beta);
+  MDG_CHECK_LAUNCH("mdg_colsum");
+  return MDG_OK;
+}
+
+extern "C" int mdg_activation_fwd(const float* pre, float* y, int64_t n, int activation, void* stream) {
+  MDG_CHECK_ARG(n >= 0 && activation >= MDG_ACT_NONE && activation <= MDG_ACT_SELU, "mdg_activation_fwd: bad arguments");
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(pre && y, "mdg_activation_fwd: null pointer");
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), pre, y, n, activation);
+  MDG_CHECK_LAUNCH("mdg_activation_fwd");
+  return MDG_OK;
+}
+
+extern "C" int mdg_activation_bwd(const float* dy, const float* pre, float* dx, int64_t n, int activation, void* stream) {
+  MDG_CHECK_ARG(n >= 0 && activation >= MDG_ACT_NONE && activation <= MDG_ACT_SELU, "mdg_activation_bwd: bad arguments");
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(dy && pre && dx, "mdg_activation_bwd: null pointer");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), dy, pre, dx, n, activation);
+  MDG_CHECK_LAUNCH("mdg_activation_bwd");
+  return MDG_OK;
+}
+
+extern "C" int mdg_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+  MDG_CHECK_ARG(n >= 0 && p >= 0.f && p < 1.f, "mdg_dropout: p must be in [0,1)");
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(x && y, "mdg_dropout: null pointer");
+  hipLaunchKernelGGL(dropout_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n, p, seed);
+  MDG_CHECK_LAUNCH("mdg_dropout");
+  return MDG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- BatchNorm1d (train)
+extern "C" size_t mdg_batchnorm_workspace_bytes(int64_t rows, int64_t cols) {
+  return rows <= 0 || cols <= 0 ? 0 : (static_cast<size_t>(mdg_cdiv(rows, 256)) + 2) * cols * sizeof(float);
+}
+
+static int colreduce(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* center, const float* rstd, float* out,
+                     int64_t rows, int64_t cols, int mode, float* ws, hipStream_t st) {
+  const int64_t nparts = mdg_cdiv(rows, 256);
+  hipLaunchKernelGGL(colreduce_partial_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64)), static_cast<unsigned>(nparts)), dim3(256), 0, st,
+                     x, ldx, y, ldy, center, rstd, ws, rows, cols, mode);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 256))), dim3(256), 0, st, static_cast<const float*>(ws), cols, out,
+                     nparts, cols, 0.f);
+  return MDG_OK;
+}
+
+extern "C" int mdg_batchnorm_train_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* running_mean,
+                                       float* running_var, float* y, int64_t ldy, float* stats, int64_t rows, int64_t cols, float eps,
+                                       float momentum, int activation, void* workspace, size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(rows > 1 && cols > 0 && ldx >= cols && ldy >= cols, "mdg_batchnorm_train_fwd: needs more than one row (nn.BatchNorm1d raises too)");
+  MDG_CHECK_ARG(x && y && stats, "mdg_batchnorm_train_fwd: null pointer");
+  MDG_CHECK_ARG(activation >= MDG_ACT_NONE && activation <= MDG_ACT_SELU, "mdg_batchnorm_train_fwd: unknown activation");
+  const size_t need = mdg_batchnorm_workspace_bytes(rows, cols);
+  if (!workspace || workspace_bytes < need) {
+    mdg_set_error("mdg_batchnorm_train_fwd: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return MDG_EWORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* sum = static_cast<float*>(workspace);
+  float* sq = sum + cols;
+  float* part = sq + cols;
+  const unsigned gb = static_cast<unsigned>(mdg_cdiv(cols, 256));
+  colreduce(x, ldx, nullptr, 0, nullptr, nullptr, sum, rows, cols, 0, part, st);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(gb), dim3(256), 0, st, sum, sq, gamma, beta, running_mean, running_var, stats, rows, cols, eps, momentum, 0);
+  colreduce(x, ldx, nullptr, 0, stats, nullptr, sq, rows, cols, 1, part, st);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(gb), dim3(256), 0, st, sum, sq, gamma, beta, running_mean, running_var, stats, rows, cols, eps, momentum, 1);
+  hipLaunchKernelGGL(affine_act_kernel, dim3(static_cast<unsigned>(mdg_cdiv(rows * cols, 256))), dim3(256), 0, st, x, ldx, stats + 2 * cols,
+                     stats + 3 * cols, y, ldy, rows, cols, activation);
+  MDG_CHECK_LAUNCH("mdg_batchnorm_train_fwd");
+  return MDG_OK;
+}
+
+extern "C" int mdg_batchnorm_train_bwd(const float* dy, const float* x, const float* stats, float* dx, float* dgamma, float* dbeta,
+                                       int64_t rows, int64_t cols, void* workspace, size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(rows > 1 && cols > 0, "mdg_batchnorm_train_bwd: bad shape");
+  MDG_CHECK_ARG(dy && x && stats && dx && dgamma && dbeta, "mdg_batchnorm_train_bwd: null pointer");
+  const size_t need = mdg_batchnorm_workspace_bytes(rows, cols);
+  if (!workspace || workspace_bytes < need) {
+    mdg_set_error("mdg_batchnorm_train_bwd: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return MDG_EWORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* part = static_cast<float*>(workspace) + 2 * cols;
+  colreduce(dy, cols, nullptr, 0, nullptr, nullptr, dbeta, rows, cols, 0, part, st);
+  colreduce(dy, cols, x, cols, stats, stats + cols, dgamma, rows, cols, 2, part, st);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(static_cast<unsigned>(mdg_cdiv(rows * cols, 256))), dim3(256), 0, st, dy, x, stats, dbeta, dgamma,
+                     dx, rows, cols);
+  MDG_CHECK_LAUNCH("mdg_batchnorm_train_bwd");
+  return MDG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- LayerNorm backward
+extern "C" size_t mdg_layernorm_bwd_workspace_bytes(int64_t rows, int64_t d) {
+  return rows <= 0 || d <= 0 ? 0 : static_cast<size_t>(mdg_cdiv(rows, 64)) * 2 * d * sizeof(float);
+}
+
+extern "C" int mdg_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, float* dx, int64_t lddx,
+                                 float* dgamma, float* dbeta, int64_t rows, int64_t d, float eps, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  MDG_CHECK_ARG(rows >= 0 && d > 0 && d <= 64 * LN_MAXJ, "mdg_layernorm_bwd: d must be in [1,1024]");
+  MDG_CHECK_ARG(lddy >= d && ldx >= d && lddx >= d, "mdg_layernorm_bwd: row strides shorter than d");
+  MDG_CHECK_ARG(gamma && dgamma && dbeta, "mdg_layernorm_bwd: null parameter pointers");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t nb = mdg_cdiv(rows, 64);
+  const size_t need = mdg_layernorm_bwd_workspace_bytes(rows, d);
+  if (need && (!workspace || workspace_bytes < need)) {
+    mdg_set_error("mdg_layernorm_bwd: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return MDG_EWORKSPACE;
+  }
+  if (rows > 0) {
+    MDG_CHECK_ARG(dy && x && dx, "mdg_layernorm_bwd: null pointer");
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), static_cast<size_t>(8 * d) * sizeof(float), st, dy, lddy, x,
+                       ldx, gamma, dx, lddx, static_cast<float*>(workspace), rows, static_cast<int>(d), eps);
+  }
+  // dgamma = sum of partial rows [nb, 2d] -> first d columns, dbeta the next d
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(d, 256))), dim3(256), 0, st, static_cast<const float*>(workspace),
+                     2 * d, dgamma, nb, d, 0.f);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(d, 256))), dim3(256), 0, st,
+                     static_cast<const float*>(workspace) + d, 2 * d, dbeta, nb, d, 0.f);
+  MDG_CHECK_LAUNCH("mdg_layernorm_bwd");
+  return MDG_OK;
+}
+
+// y = act(x * scale[c] + shift[c])   (eval-mode BatchNorm under autograd; shift may be null: the backward pass)
+extern "C" int mdg_affine_act(const float* x, int64_t ldx, const float* scale, const float* shift, float* y, int64_t ldy, int64_t rows,
+                              int64_t cols, int activation, void* stream) {
+  MDG_CHECK_ARG(rows >= 0 && cols > 0 && ldx >= cols && ldy >= cols, "mdg_affine_act: bad shape");
+  MDG_CHECK_ARG(activation >= MDG_ACT_NONE && activation <= MDG_ACT_SELU, "mdg_affine_act: unknown activation");
+  if (rows == 0) return MDG_OK;
+  MDG_CHECK_ARG(x && y && scale, "mdg_affine_act: null pointer");
+  hipLaunchKernelGGL(affine_act_kernel, dim3(static_cast<unsigned>(mdg_cdiv(rows * cols, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     ldx, scale, shift, y, ldy, rows, cols, activation);
+  MDG_CHECK_LAUNCH("mdg_affine_act");
+  return MDG_OK;
+}
+
+extern "C" int mdg_axpby(const float* a, const float* b, float* out, int64_t n, int64_t nb, float alpha, float beta, void* stream) {
+  MDG_CHECK_ARG(n >= 0 && nb > 0 && (n % nb) == 0, "mdg_axpby: numel(b) must divide numel(a)");
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(a && b && out, "mdg_axpby: null pointer");
+  hipLaunchKernelGGL(axpby_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, out, n, nb,
+                     alpha, beta);
+  MDG_CHECK_LAUNCH("mdg_axpby");
+  return MDG_OK;
+}

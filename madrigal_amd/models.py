@@ -21,6 +21,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import autograd as ag
 from . import ops
 from .data import CELL_LINES, MOL_DIM, NON_TX_MODALITIES, NUM_MODALITIES, NUM_NON_TX_MODALITIES
 from .graph_plans import hgt_plan, molecule_plan
@@ -55,6 +56,16 @@ def precision(p: str):
 
 def _lin(x, w, b=None, **kw):
     return ops.linear(x, w, b, precision=_state["precision"], **kw)
+
+
+def _train_path(m: nn.Module) -> bool:
+    """True when the call must go through the autograd nodes (madrigal_amd/autograd.py): the module is in
+    training mode (dropout / BatchNorm batch statistics) or a gradient is being recorded for its parameters."""
+    return m.training or (torch.is_grad_enabled() and any(p.requires_grad for p in m.parameters()))
+
+
+def _linT(x, w, b=None, act=None):
+    return ag.linear(x, w, b, act, _state["precision"])
 
 
 def _require_eval(m: nn.Module) -> None:
@@ -151,6 +162,55 @@ def _run_sequential(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def _bn_or_affine(x, bn: nn.BatchNorm1d, act):
+    """BatchNorm1d inside the differentiated graph: batch statistics when bn.training, else the folded running
+    statistics as a constant per-column affine map."""
+    if bn.training or not bn.track_running_stats:
+        return ag.batchnorm_act(x, bn, act)
+    if (bn.weight is not None and bn.weight.requires_grad) and torch.is_grad_enabled():
+        raise NotImplementedError("gradients of an eval-mode BatchNorm's affine parameters (freeze them or use train())")
+    scale, shift = _bn_scale_shift(bn)
+    return ag.affine_act(x, scale, shift, act)
+
+
+def _run_sequential_train(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """The same nn.Sequential walked through the autograd nodes: Linear absorbs the activation (and the
+    BatchNorm + activation) that follows it; Dropout / BatchNorm honour each sub-module's own ``training`` flag."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Identity):
+            i += 1
+        elif isinstance(m, nn.Dropout):
+            x = ag.dropout(x, m.p, m.training)
+            i += 1
+        elif isinstance(m, nn.LayerNorm):
+            x = ag.layernorm(x, m.weight, m.bias, m.eps)
+            i += 1
+        elif isinstance(m, nn.BatchNorm1d):
+            x = _bn_or_affine(x, m, None)
+            i += 1
+        elif isinstance(m, nn.Linear):
+            j, bn, act = i + 1, None, None
+            if j < len(mods) and isinstance(mods[j], nn.BatchNorm1d):
+                bn = mods[j]
+                j += 1
+            if j < len(mods) and type(mods[j]) in _ACT_OF and not isinstance(mods[j], nn.Identity):
+                act = _ACT_OF[type(mods[j])]
+                j += 1
+            if bn is None:
+                x = _linT(x, m.weight, m.bias, act)
+            else:
+                x = _bn_or_affine(_linT(x, m.weight, m.bias, None), bn, act)
+            i = j
+        elif type(m) in _ACT_OF:
+            raise NotImplementedError("activation without a preceding Linear")
+        else:
+            raise NotImplementedError(type(m).__name__)
+    return x
+
+
 # ------------------------------------------------------------------------------------- MLPs
 class MLPEncoder(nn.Module):
     """madrigal/models/models.py:121-180 (cv encoder; also tx_encoder='mlp')."""
@@ -187,9 +247,9 @@ class MLPEncoder(nn.Module):
         return layers
 
     def forward(self, x):
-        _require_eval(self)
         lead = x.shape[:-1]
-        return _run_sequential(self.fc, x.reshape(-1, x.shape[-1])).reshape(*lead, -1)
+        run = _run_sequential_train if _train_path(self) or ag.needs_grad(x) else _run_sequential
+        return run(self.fc, x.reshape(-1, x.shape[-1])).reshape(*lead, -1)
 
 
 class MLPAdaptor(MLPEncoder):
@@ -457,8 +517,10 @@ class ChemCPAMLP(nn.Module):
         self.activation = last_layer_act
 
     def forward(self, x, residual=None):
-        _require_eval(self)
         mods = list(self.network)
+        if _train_path(self) or ag.needs_grad(x, residual):
+            y = _run_sequential_train(self.network, x)
+            return y if residual is None else ag.add(y, residual)
         if residual is None:
             return _run_sequential(self.network, x)
         # fuse `+ residual` into the last Linear

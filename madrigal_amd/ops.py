@@ -476,3 +476,125 @@ def ensemble_ranks(rank_tensors, max_workspace_bytes: int = 8 << 30) -> torch.Te
     """Seed ensembling of the reference (generate_embeddings.ipynb cells 18-20): geometric mean of the seeds'
     normalised-rank tensors, then rank-normalised again per outcome."""
     return rank_normalize(gmean(rank_tensors), max_workspace_bytes=max_workspace_bytes)
+
+
+# ------------------------------------------------------------------------------- backward building blocks
+def _ceil4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+def transpose(x: torch.Tensor, pad_inner: bool = True) -> torch.Tensor:
+    """[R, C] (unit inner stride) -> [C, R']; R' = R rounded up to 4 with zero padding when ``pad_inner`` so that the
+    result can be an mdg_linear operand as is."""
+    if x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32 or x.stride(1) != 1:
+        x = _f32_cuda(x, "x", 2)
+    R, C = x.shape
+    Rp = _ceil4(R) if pad_inner else R
+    out = (torch.zeros if Rp != R else torch.empty)((C, Rp), dtype=torch.float32, device=x.device)
+    check(lib().mdg_transpose(_ptr(x), _c64(x.stride(0)), _ptr(out), _c64(Rp), _c64(R), _c64(C), _stream(x)), "mdg_transpose")
+    return out
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, beta: float = 0.0) -> torch.Tensor:
+    """Column sums of a 2-D tensor (fixed summation order): out = beta * out + x.sum(0)."""
+    if x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32 or x.stride(1) != 1:
+        x = _f32_cuda(x, "x", 2)
+    R, C = x.shape
+    if out is None:
+        out, beta = torch.empty(C, dtype=torch.float32, device=x.device), 0.0
+    nbytes = lib().mdg_colsum_workspace_bytes(_c64(R), _c64(C))
+    ws = _workspace(nbytes, x.device)
+    check(lib().mdg_colsum(_ptr(x), _c64(x.stride(0)), _ptr(out), _c64(R), _c64(C), _f(beta), _ptr(ws), ctypes.c_size_t(nbytes),
+                           _stream(x)), "mdg_colsum")
+    return out
+
+
+def activation_fwd(pre: torch.Tensor, act) -> torch.Tensor:
+    pre = _f32_cuda(pre, "pre")
+    y = torch.empty_like(pre)
+    check(lib().mdg_activation_fwd(_ptr(pre), _ptr(y), _c64(pre.numel()), _c(ACTS[act]), _stream(pre)), "mdg_activation_fwd")
+    return y
+
+
+def activation_bwd(dy: torch.Tensor, pre: torch.Tensor, act) -> torch.Tensor:
+    """dy * act'(pre); for relu ``pre`` may be the activation output itself."""
+    dy, pre = _f32_cuda(dy, "dy"), _f32_cuda(pre, "pre")
+    if dy.shape != pre.shape:
+        raise ValueError("activation_bwd: shape mismatch")
+    dx = torch.empty_like(dy)
+    check(lib().mdg_activation_bwd(_ptr(dy), _ptr(pre), _ptr(dx), _c64(dy.numel()), _c(ACTS[act]), _stream(dy)), "mdg_activation_bwd")
+    return dx
+
+
+def dropout(x: torch.Tensor, p: float, seed: int) -> torch.Tensor:
+    """Inverted dropout with a counter-based mask: the same (seed, p) applied to a gradient is the backward pass."""
+    x = _f32_cuda(x, "x")
+    y = torch.empty_like(x)
+    check(lib().mdg_dropout(_ptr(x), _ptr(y), _c64(x.numel()), _f(p), ctypes.c_uint64(seed & (2 ** 64 - 1)), _stream(x)), "mdg_dropout")
+    return y
+
+
+def batchnorm_train_fwd(x: torch.Tensor, gamma, beta, running_mean, running_var, eps: float, momentum: float, act=None):
+    """-> (y, stats[4N]); updates the running statistics in place (nn.BatchNorm1d training semantics)."""
+    x = _f32_cuda(x, "x", 2)
+    R, C = x.shape
+    if R < 2:
+        raise ValueError("Expected more than 1 value per channel when training")      # torch's message
+    y = torch.empty_like(x)
+    stats = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+    nbytes = lib().mdg_batchnorm_workspace_bytes(_c64(R), _c64(C))
+    ws = _workspace(nbytes, x.device)
+    check(lib().mdg_batchnorm_train_fwd(_ptr(x), _c64(C), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(y),
+                                        _c64(C), _ptr(stats), _c64(R), _c64(C), _f(eps), _f(momentum), _c(ACTS[act]), _ptr(ws),
+                                        ctypes.c_size_t(nbytes), _stream(x)), "mdg_batchnorm_train_fwd")
+    return y, stats
+
+
+def batchnorm_train_bwd(dy: torch.Tensor, x: torch.Tensor, stats: torch.Tensor):
+    """-> (dx, dgamma, dbeta) for the gradient ``dy`` at the BatchNorm output (before any activation)."""
+    dy, x = _f32_cuda(dy, "dy", 2), _f32_cuda(x, "x", 2)
+    R, C = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty_like(dg)
+    nbytes = lib().mdg_batchnorm_workspace_bytes(_c64(R), _c64(C))
+    ws = _workspace(nbytes, x.device)
+    check(lib().mdg_batchnorm_train_bwd(_ptr(dy), _ptr(x), _ptr(stats), _ptr(dx), _ptr(dg), _ptr(db), _c64(R), _c64(C), _ptr(ws),
+                                        ctypes.c_size_t(nbytes), _stream(x)), "mdg_batchnorm_train_bwd")
+    return dx, dg, db
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-5):
+    """-> (dx, dweight, dbias); ``x`` is the LayerNorm input (statistics are recomputed)."""
+    d = x.shape[-1]
+    x2 = x.reshape(-1, d) if x.stride(-1) == 1 and x.dim() == 2 else _f32_cuda(x, "x").reshape(-1, d)
+    dy2 = dy.reshape(-1, d) if dy.stride(-1) == 1 and dy.dim() == 2 else _f32_cuda(dy, "dy").reshape(-1, d)
+    R = x2.shape[0]
+    dx = torch.empty((R, d), dtype=torch.float32, device=x2.device)
+    dg = torch.empty(d, dtype=torch.float32, device=x2.device)
+    db = torch.empty_like(dg)
+    nbytes = lib().mdg_layernorm_bwd_workspace_bytes(_c64(R), _c64(d))
+    ws = _workspace(nbytes, x2.device)
+    check(lib().mdg_layernorm_bwd(_ptr(dy2), _c64(dy2.stride(0)), _ptr(x2), _c64(x2.stride(0)), _ptr(weight.detach().contiguous()), _ptr(dx),
+                                  _c64(d), _ptr(dg), _ptr(db), _c64(R), _c64(d), _f(eps), _ptr(ws), ctypes.c_size_t(nbytes), _stream(x2)),
+          "mdg_layernorm_bwd")
+    return dx.view(x.shape), dg, db
+
+
+def affine_act(x: torch.Tensor, scale: torch.Tensor, shift: Optional[torch.Tensor] = None, act=None) -> torch.Tensor:
+    """act(x * scale + shift) with per-column scale / shift."""
+    x = _f32_cuda(x, "x", 2)
+    y = torch.empty_like(x)
+    check(lib().mdg_affine_act(_ptr(x), _c64(x.stride(0)), _ptr(scale.contiguous()), _ptr(None if shift is None else shift.contiguous()),
+                               _ptr(y), _c64(y.stride(0)), _c64(x.shape[0]), _c64(x.shape[1]), _c(ACTS[act]), _stream(x)), "mdg_affine_act")
+    return y
+
+
+def axpby(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, beta: float = 1.0) -> torch.Tensor:
+    """alpha * a + beta * b; ``b`` may be a trailing-dims broadcast of ``a`` (numel(b) divides numel(a))."""
+    a, b = _f32_cuda(a, "a"), _f32_cuda(b, "b")
+    if a.numel() % max(b.numel(), 1) or (b.numel() != a.numel() and tuple(a.shape[a.dim() - b.dim():]) != tuple(b.shape)):
+        raise ValueError(f"axpby: cannot broadcast {tuple(b.shape)} over {tuple(a.shape)}")
+    out = torch.empty_like(a)
+    check(lib().mdg_axpby(_ptr(a), _ptr(b), _ptr(out), _c64(a.numel()), _c64(b.numel()), _f(alpha), _f(beta), _stream(a)), "mdg_axpby")
+    return out
