@@ -249,6 +249,36 @@ int mdg_batchnorm_train_bwd(const float* dy, const float* x, const float* stats,
 int mdg_affine_act(const float* x, int64_t ldx, const float* scale, const float* shift, float* y, int64_t ldy, int64_t rows,
                    int64_t cols, int activation, void* stream);
 
+/* Training-mode variants of the fusion kernels (nn.MultiheadAttention(dropout=p) drops attention WEIGHTS,
+ * models.py:363-379): same arguments as mdg_fusion_attention / mdg_xattn_pool plus the dropout probability and the
+ * seed of the counter-based mask; the backward entry points regenerate the mask from the same seed and recompute
+ * the attention weights from qkv (nothing else is kept from the forward pass).
+ * mdg_fusion_attention_bwd: dqkv [rows, 3d] receives dQ | dK | dV for every row of every tile.
+ * mdg_xattn_pool_bwd: dkv [n*Tk, 2d] receives dK | dV; dq_part [n, d] the per-drug gradient of the projected query
+ * (the caller sums it over drugs with mdg_colsum). */
+int mdg_fusion_attention_dropout(const float* qkv, int64_t ld, float* out, int64_t ldo, const uint32_t* kpm_bits,
+                                 const uint32_t* src_bits, float* probs, const int64_t* row_start, const uint32_t* row_bits,
+                                 int64_t n, int S, int H, int dh, float p_drop, uint64_t seed, void* stream);
+int mdg_fusion_attention_bwd(const float* qkv, int64_t ld, const float* dout, int64_t lddo, float* dqkv, int64_t lddq,
+                             const uint32_t* kpm_bits, const uint32_t* src_bits, const int64_t* row_start,
+                             const uint32_t* row_bits, int64_t n, int S, int H, int dh, float p_drop, uint64_t seed, void* stream);
+int mdg_xattn_pool_dropout(const float* q_proj, const float* kv_proj, int64_t ld, float* out, int64_t ldo, int64_t n, int Tk,
+                           int H, int dh, float p_drop, uint64_t seed, void* stream);
+int mdg_xattn_pool_bwd(const float* q_proj, const float* kv_proj, int64_t ld, const float* dout, int64_t lddo, float* dkv,
+                       int64_t lddkv, float* dq_part, int64_t n, int Tk, int H, int dh, float p_drop, uint64_t seed, void* stream);
+
+/* Backward of mdg_assemble_tokens (rows == NULL): dstr/dkg/dcv [n,128] and dtx [16*n,128] must be zero-filled (tokens
+ * that were not emitted leave no gradient); dlearned / dpe are zero-filled [n, S, 128] scratch receiving the per-drug
+ * gradients of the cls / bottleneck tokens and of the position table (sum over drugs with mdg_colsum). */
+int mdg_assemble_tokens_bwd(const float* dseq, const float* str_emb, const float* kg_emb, const float* cv_emb, const float* tx_emb,
+                            const float* bottleneck, const float* cls, const int64_t* token_index, int64_t n_tok, float* dstr,
+                            float* dkg, float* dcv, float* dtx, float* dlearned, float* dpe, int64_t n, int nb, int has_cls,
+                            int pe_len, int normalize, int64_t D, void* stream);
+
+/* dx of y = x / max(|x|_2, 1e-12) (F.normalize). */
+int mdg_l2_normalize_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dx, int64_t lddx, int64_t rows,
+                         int64_t d, void* stream);
+
 /* LayerNorm backward (statistics recomputed from x): dx, dgamma, dbeta.  d <= 1024. */
 size_t mdg_layernorm_bwd_workspace_bytes(int64_t rows, int64_t d);
 int mdg_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, float* dx, int64_t lddx,

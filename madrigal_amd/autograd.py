@@ -203,3 +203,98 @@ class _Axpby(Function):
 
 def add(a, b, alpha: float = 1.0, beta: float = 1.0):
     return _Axpby.apply(a, b, alpha, beta)
+
+
+# ------------------------------------------------------------------------------------------- fusion
+class _FusionAttention(Function):
+    """Self-attention over the tokens of each tile (dense drug or packed live-token tile), dropout on the weights."""
+
+    @staticmethod
+    def forward(ctx, qkv, n, S, H, dh, kpm_bits, src_bits, row_start, row_bits, p_drop, seed):
+        qkv = qkv if qkv.is_contiguous() else qkv.contiguous()
+        out, _ = ops.fusion_attention(qkv, n, S, H, dh, kpm_bits, src_bits, row_start=row_start, row_bits=row_bits, p_drop=p_drop,
+                                      seed=seed)
+        ctx.save_for_backward(qkv, kpm_bits, src_bits, row_start, row_bits)
+        ctx.meta = (n, S, H, dh, p_drop, seed)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        qkv, kpm_bits, src_bits, row_start, row_bits = ctx.saved_tensors
+        n, S, H, dh, p_drop, seed = ctx.meta
+        dqkv = ops.fusion_attention_bwd(qkv, dout if dout.is_contiguous() else dout.contiguous(), n, S, H, dh, kpm_bits, src_bits,
+                                        row_start, row_bits, p_drop, seed)
+        return (dqkv,) + (None,) * 10
+
+
+def fusion_attention(qkv, n, S, H, dh, kpm_bits=None, src_bits=None, row_start=None, row_bits=None, p_drop=0.0, seed=None):
+    p_drop = float(p_drop)
+    return _FusionAttention.apply(qkv, n, S, H, dh, kpm_bits, src_bits, row_start, row_bits, p_drop,
+                                  (next_seed() if p_drop > 0 else 0) if seed is None else seed)
+
+
+class _XAttnPool(Function):
+    @staticmethod
+    def forward(ctx, q_proj, kv_proj, n, Tk, H, dh, p_drop, seed):
+        kv_proj = kv_proj if kv_proj.is_contiguous() else kv_proj.contiguous()
+        ctx.save_for_backward(q_proj, kv_proj)
+        ctx.meta = (n, Tk, H, dh, p_drop, seed)
+        return ops.xattn_pool(q_proj, kv_proj, n, Tk, H, dh, p_drop, seed)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        q_proj, kv_proj = ctx.saved_tensors
+        n, Tk, H, dh, p_drop, seed = ctx.meta
+        dq, dkv = ops.xattn_pool_bwd(q_proj, kv_proj, dout if dout.is_contiguous() else dout.contiguous(), n, Tk, H, dh, p_drop, seed)
+        return dq.view(q_proj.shape), dkv, None, None, None, None, None, None
+
+
+def xattn_pool(q_proj, kv_proj, n, Tk, H, dh, p_drop=0.0, seed=None):
+    p_drop = float(p_drop)
+    return _XAttnPool.apply(q_proj, kv_proj, n, Tk, H, dh, p_drop, (next_seed() if p_drop > 0 else 0) if seed is None else seed)
+
+
+class _AssembleTokens(Function):
+    @staticmethod
+    def forward(ctx, str_emb, kg_emb, cv_emb, tx_emb, bottleneck, cls, pe, normalize, token_index):
+        ctx.save_for_backward(str_emb, kg_emb, cv_emb, tx_emb, bottleneck, cls, token_index)
+        ctx.pe_shape = None if pe is None else pe.shape
+        ctx.normalize = normalize
+        return ops.assemble_tokens(str_emb, kg_emb, cv_emb, tx_emb, bottleneck=bottleneck, cls=cls, pe=pe, normalize=normalize,
+                                   token_index=token_index)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dseq):
+        str_emb, kg_emb, cv_emb, tx_emb, bottleneck, cls, token_index = ctx.saved_tensors
+        pe_len = 0 if ctx.pe_shape is None else int(ctx.pe_shape[-2])
+        g = ops.assemble_tokens_bwd(dseq if dseq.is_contiguous() else dseq.contiguous(), str_emb, kg_emb, cv_emb, tx_emb,
+                                    bottleneck=bottleneck, cls=cls, pe_len=pe_len, normalize=ctx.normalize, token_index=token_index)
+        dpe = None if ctx.pe_shape is None else g["pe"].reshape(ctx.pe_shape)
+        dcls = None if cls is None else g["cls"].reshape(cls.shape)
+        dbn = None if bottleneck is None else g["bottleneck"].reshape(bottleneck.shape)
+        return g["str"], g["kg"], g["cv"], g["tx"], dbn, dcls, dpe, None, None
+
+
+def assemble_tokens(str_emb, kg_emb, cv_emb, tx_emb, bottleneck=None, cls=None, pe=None, normalize=False, token_index=None):
+    return _AssembleTokens.apply(str_emb, kg_emb, cv_emb, tx_emb, bottleneck, cls, pe, bool(normalize), token_index)
+
+
+class _L2Normalize(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x if x.is_contiguous() else x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.l2_normalize(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.l2_normalize_bwd(dy if dy.is_contiguous() else dy.contiguous(), x)
+
+
+def l2_normalize(x):
+    return _L2Normalize.apply(x)

@@ -102,19 +102,11 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a,
 
 // ---- dropout: y = x * keep / (1 - p), keep ~ Bernoulli(1-p) from a counter-based hash of (seed, element index);
 // the same (seed, index) reproduces the mask in the backward pass, so no mask tensor is stored. -------------------
-__device__ __forceinline__ uint32_t mix32(uint64_t z) {      // splitmix64 finaliser, high word
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return static_cast<uint32_t>((z ^ (z >> 31)) >> 32);
-}
-
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p,
                                                       uint64_t seed) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;
-  const uint32_t thr = static_cast<uint32_t>(static_cast<double>(p) * 4294967296.0);
-  const bool keep = mix32(seed * 0x100000001B3ull + static_cast<uint64_t>(i)) >= thr;
+  const bool keep = mdg_keep(seed, static_cast<uint64_t>(i), mdg_drop_threshold(p));
   y[i] = keep ? x[i] * (1.0f / (1.0f - p)) : 0.f;
 }
 

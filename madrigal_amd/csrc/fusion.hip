@@ -72,24 +72,15 @@ struct AttnArgs {
   int64_t n;
   int S, H, dh;
   float qscale;
+  float p_drop; uint64_t seed;       // training: dropout on the attention weights (nn.MultiheadAttention(dropout=p))
+  const float* dout; int64_t lddo;   // backward: gradient of `out`
+  float* dqkv; int64_t lddq;         // backward: gradient of qkv, same layout
 };
 
-__global__ __launch_bounds__(256) void fusion_attention_kernel(const AttnArgs p) {
-  const int lane = threadIdx.x & 63, x = lane & 31, half = lane >> 5;
-  const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  if (gw >= p.n * p.H) return;
-  const int64_t drug = gw / p.H;
-  const int head = static_cast<int>(gw % p.H);
-  const int d = p.H * p.dh;
-  // dense: the drug's S tokens are rows drug*S ..; compact: only its live tokens, rows row_start[drug] ..
-  const int64_t base = p.row_start ? p.row_start[drug] : drug * p.S;
-  const int T = p.row_start ? static_cast<int>(p.row_start[drug + 1] - base) : p.S;
-  if (T <= 0) return;
-  const int xr = x < T ? x : T - 1;
-  const float* qrow = p.qkv + (base + xr) * p.ld + head * p.dh;
-  const float* krow = qrow + d;
-
-  f32x16 acc;
+// Scores -> attention weights of one (tile, head) wave, in the swapped layout: lane (x = query, half) holds
+// acc[v] = P[x][j], j = (v&3) + 8(v>>2) + 4*half.  Shared by the forward and the backward kernel.
+__device__ __forceinline__ void attn_weights(const AttnArgs& p, const float* qrow, const float* krow, int64_t drug, int64_t base, int xr, int T,
+                                             int half, f32x16& acc) {
 #pragma unroll
   for (int v = 0; v < 16; ++v) acc[v] = 0.f;
   for (int k0 = 0; k0 < p.dh; k0 += 64) {
@@ -107,8 +98,6 @@ __global__ __launch_bounds__(256) void fusion_attention_kernel(const AttnArgs p)
       for (int e = 0; e < 4; ++e)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[q][e], qf[q][e] * p.qscale, acc, 0, 0, 0);
   }
-
-  // acc[v] = score(query x, key j), j = (v&3) + 8(v>>2) + 4*half
   const uint32_t blocked = p.row_start ? (p.row_bits ? p.row_bits[base + xr] : 0u)
                                        : ((p.kpm_bits ? p.kpm_bits[drug] : 0u) | (p.src_bits ? p.src_bits[xr] : 0u));
   float m = -INFINITY;
@@ -129,6 +118,30 @@ __global__ __launch_bounds__(256) void fusion_attention_kernel(const AttnArgs p)
   const float inv = 1.0f / sum;
 #pragma unroll
   for (int v = 0; v < 16; ++v) acc[v] *= inv;
+}
+
+// keep / (1-p) factor of attention weight (wave gw, query x, key j)
+__device__ __forceinline__ float attn_drop_scale(const AttnArgs& p, int64_t gw, int x, int j, uint32_t thr, float keep_scale) {
+  return mdg_keep(p.seed, (static_cast<uint64_t>(gw) * 32 + x) * 32 + j, thr) ? keep_scale : 0.f;
+}
+
+__global__ __launch_bounds__(256) void fusion_attention_kernel(const AttnArgs p) {
+  const int lane = threadIdx.x & 63, x = lane & 31, half = lane >> 5;
+  const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (gw >= p.n * p.H) return;
+  const int64_t drug = gw / p.H;
+  const int head = static_cast<int>(gw % p.H);
+  const int d = p.H * p.dh;
+  // dense: the drug's S tokens are rows drug*S ..; compact: only its live tokens, rows row_start[drug] ..
+  const int64_t base = p.row_start ? p.row_start[drug] : drug * p.S;
+  const int T = p.row_start ? static_cast<int>(p.row_start[drug + 1] - base) : p.S;
+  if (T <= 0) return;
+  const int xr = x < T ? x : T - 1;
+  const float* qrow = p.qkv + (base + xr) * p.ld + head * p.dh;
+  const float* krow = qrow + d;
+
+  f32x16 acc;
+  attn_weights(p, qrow, krow, drug, base, xr, T, half, acc);
 
   if (p.probs && x < T) {
     float* pr = p.probs + ((drug * p.H + head) * p.S + x) * p.S;
@@ -137,6 +150,13 @@ __global__ __launch_bounds__(256) void fusion_attention_kernel(const AttnArgs p)
       const int j = (v & 3) + 8 * (v >> 2) + 4 * half;
       if (j < T) pr[j] = acc[v];
     }
+  }
+
+  if (p.p_drop > 0.f) {
+    const uint32_t thr = mdg_drop_threshold(p.p_drop);
+    const float ks = 1.0f / (1.0f - p.p_drop);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] *= attn_drop_scale(p, gw, x, (v & 3) + 8 * (v >> 2) + 4 * half, thr, ks);
   }
 
   const float* vbase = p.qkv + base * p.ld + 2 * d + head * p.dh;
@@ -161,16 +181,157 @@ __global__ __launch_bounds__(256) void fusion_attention_kernel(const AttnArgs p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Backward of the self-attention above, same one-wave-per-(tile, head) decomposition.  The attention weights
+// are recomputed (nothing but qkv and the dropout seed is kept from the forward pass):
+//   dPd = dO V^T            (same swapped MFMA shape as the scores: lane = query, registers = keys)
+//   Pd  = P o D/(1-p),  dP = dPd o D/(1-p),  dS = P o (dP - rowsum(dP o P))
+//   dQ  = qscale dS K       (contraction over keys: the accumulator layout feeds the MFMA B operand directly)
+//   dK  = qscale dS^T Q,  dV = Pd^T dO   (contraction over queries: dS / Pd are transposed through a 32x33 LDS tile)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fusion_attention_bwd_kernel(const AttnArgs p) {
+  __shared__ float tile[4][2][32][33];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, x = lane & 31, half = lane >> 5;
+  const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+  if (gw >= p.n * p.H) return;
+  const int64_t drug = gw / p.H;
+  const int head = static_cast<int>(gw % p.H);
+  const int d = p.H * p.dh;
+  const int64_t base = p.row_start ? p.row_start[drug] : drug * p.S;
+  const int T = p.row_start ? static_cast<int>(p.row_start[drug + 1] - base) : p.S;
+  if (T <= 0) return;
+  const int xr = x < T ? x : T - 1;
+  const float* qrow = p.qkv + (base + xr) * p.ld + head * p.dh;
+  const float* krow = qrow + d;
+  const float* vrow = qrow + 2 * d;
+  const float* dorow = p.dout + (base + xr) * p.lddo + head * p.dh;
+
+  f32x16 P;
+  attn_weights(p, qrow, krow, drug, base, xr, T, half, P);
+
+  // dPd[x][j] = sum_c dO[x][c] V[j][c]
+  f32x16 dP;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) dP[v] = 0.f;
+  for (int k0 = 0; k0 < p.dh; k0 += 64) {
+    f32x4 gf[8], vf[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = k0 + 8 * q + 4 * half;
+      const bool ok = k < p.dh;
+      gf[q] = ok ? *reinterpret_cast<const f32x4*>(dorow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      vf[q] = ok ? *reinterpret_cast<const f32x4*>(vrow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dP = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[q][e], gf[q][e], dP, 0, 0, 0);
+  }
+
+  f32x16 Pd = P;
+  if (p.p_drop > 0.f) {
+    const uint32_t thr = mdg_drop_threshold(p.p_drop);
+    const float ks = 1.0f / (1.0f - p.p_drop);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const float f = attn_drop_scale(p, gw, x, (v & 3) + 8 * (v >> 2) + 4 * half, thr, ks);
+      Pd[v] *= f;
+      dP[v] *= f;
+    }
+  }
+  float delta = 0.f;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    const int j = (v & 3) + 8 * (v >> 2) + 4 * half;
+    if (j >= T) dP[v] = 0.f;                       // clamped key rows: P is exactly 0 there, keep 0 * garbage out
+    delta += dP[v] * P[v];
+  }
+  delta += __shfl_xor(delta, 32, 64);
+  f32x16 dS;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) dS[v] = (x < T) ? P[v] * (dP[v] - delta) * p.qscale : 0.f;
+  if (x >= T) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) Pd[v] = 0.f;      // duplicate query rows must not enter the sums over queries
+  }
+
+  // dQ[x][c] = sum_j dS[x][j] K[j][c]   (as the forward P V product, with K in place of V)
+  const float* kbase = p.qkv + base * p.ld + d + head * p.dh;
+  for (int c0 = 0; c0 < p.dh; c0 += 32) {
+    f32x16 o;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) o[v] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      int j = (s & 3) + 8 * (s >> 2) + 4 * half;
+      j = j < T ? j : T - 1;
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(kbase[static_cast<int64_t>(j) * p.ld + c0 + x], dS[s], o, 0, 0, 0);
+    }
+    if (x < T) {
+      float* r = p.dqkv + (base + x) * p.lddq + head * p.dh + c0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(r + 8 * g + 4 * half) = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+    }
+  }
+
+  // transpose dS and Pd through LDS: afterwards lane (j, half) holds X[x'][j] for x' = (s&3) + 8(s>>2) + 4*half
+  float (*tS)[33] = tile[wave][0];
+  float (*tP)[33] = tile[wave][1];
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    const int j = (v & 3) + 8 * (v >> 2) + 4 * half;
+    tS[x][j] = dS[v];
+    tP[x][j] = Pd[v];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the LDS writes of this wave have landed
+  f32x16 dSt, Pdt;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int xq = (s & 3) + 8 * (s >> 2) + 4 * half;
+    dSt[s] = tS[xq][x];
+    Pdt[s] = tP[xq][x];
+  }
+
+  // dK[j][c] = sum_x dS[x][j] Q[x][c],  dV[j][c] = sum_x Pd[x][j] dO[x][c]   (lane = key j after the transpose)
+  const float* qbase = p.qkv + base * p.ld + head * p.dh;
+  const float* gbase = p.dout + base * p.lddo + head * p.dh;
+  for (int c0 = 0; c0 < p.dh; c0 += 32) {
+    f32x16 ok, ov;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) ok[v] = ov[v] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      int xq = (s & 3) + 8 * (s >> 2) + 4 * half;
+      xq = xq < T ? xq : T - 1;                      // clamped query rows meet dS = Pd = 0
+      ok = __builtin_amdgcn_mfma_f32_32x32x2f32(qbase[static_cast<int64_t>(xq) * p.ld + c0 + x], dSt[s], ok, 0, 0, 0);
+      ov = __builtin_amdgcn_mfma_f32_32x32x2f32(gbase[static_cast<int64_t>(xq) * p.lddo + c0 + x], Pdt[s], ov, 0, 0, 0);
+    }
+    if (x < T) {
+      float* rk = p.dqkv + (base + x) * p.lddq + d + head * p.dh + c0;
+      float* rv = rk + d;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<f32x4*>(rk + 8 * g + 4 * half) = f32x4{ok[4 * g], ok[4 * g + 1], ok[4 * g + 2], ok[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(rv + 8 * g + 4 * half) = f32x4{ov[4 * g], ov[4 * g + 1], ov[4 * g + 2], ov[4 * g + 3]};
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Cross-attention pooling with ONE query shared by every drug: out[i, head] = softmax_j(q.K_ij) V_ij.
 // One wave per (drug, head); lanes span the head dimension.  (models.py:422-438; the fixed key mask
 // is applied by the caller by passing only the allowed key tokens.)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void xattn_pool_kernel(const float* __restrict__ q, const float* __restrict__ kv, int64_t ld,
                                                          float* __restrict__ out, int64_t ldo, int64_t n, int Tk, int H, int dh,
-                                                         float qscale) {
+                                                         float qscale, float p_drop, uint64_t seed) {
   const int lane = threadIdx.x & 63;
   const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (gw >= n * H) return;
+  const uint32_t thr = mdg_drop_threshold(p_drop);
+  const float ks = 1.0f / (1.0f - p_drop);
   const int64_t drug = gw / H;
   const int head = static_cast<int>(gw % H);
   const int d = H * dh;
@@ -198,10 +359,11 @@ __global__ __launch_bounds__(256) void xattn_pool_kernel(const float* __restrict
     const float mn = fmaxf(m, s);
     const float f = expf(m - mn), e = expf(s - mn);
     sum = sum * f + e;
+    const float ed = (p_drop > 0.f && !mdg_keep(seed, static_cast<uint64_t>(gw) * 32 + j, thr)) ? 0.f : (p_drop > 0.f ? e * ks : e);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int c = lane + 64 * u;
-      if (u < per && c < dh) o[u] = o[u] * f + e * vr[c];
+      if (u < per && c < dh) o[u] = o[u] * f + ed * vr[c];
     }
     m = mn;
   }
@@ -210,6 +372,149 @@ __global__ __launch_bounds__(256) void xattn_pool_kernel(const float* __restrict
   for (int u = 0; u < 4; ++u) {
     const int c = lane + 64 * u;
     if (u < per && c < dh) out[drug * ldo + head * dh + c] = o[u] * inv;
+  }
+}
+
+// Backward of the one-query cross-attention pooling: one wave per (drug, head); lane j keeps the score, weight and
+// weight gradient of key j (Tk <= 32).  dq is written per drug ([n, d]) and reduced over drugs by the caller
+// (the query is a shared parameter): fixed summation order, no atomics.
+__global__ __launch_bounds__(256) void xattn_pool_bwd_kernel(const float* __restrict__ q, const float* __restrict__ kv, int64_t ld,
+                                                             const float* __restrict__ dout, int64_t lddo, float* __restrict__ dkv,
+                                                             int64_t lddkv, float* __restrict__ dq_part, int64_t n, int Tk, int H, int dh,
+                                                             float qscale, float p_drop, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (gw >= n * H) return;
+  const int64_t drug = gw / H;
+  const int head = static_cast<int>(gw % H);
+  const int d = H * dh;
+  const int per = (dh + 63) / 64;
+  const uint32_t thr = mdg_drop_threshold(p_drop);
+  const float ks = 1.0f / (1.0f - p_drop);
+  float qv[4], gv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = lane + 64 * u;
+    const bool ok = u < per && c < dh;
+    qv[u] = ok ? q[head * dh + c] * qscale : 0.f;
+    gv[u] = ok ? dout[drug * lddo + head * dh + c] : 0.f;
+  }
+  float sv = -INFINITY, dpv = 0.f, fv = 1.f;
+#pragma unroll 1
+  for (int j = 0; j < Tk; ++j) {
+    const float* kr = kv + (drug * Tk + j) * ld + head * dh;
+    const float* vr = kr + d;
+    float s = 0.f, g = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = lane + 64 * u;
+      if (u < per && c < dh) { s += qv[u] * kr[c]; g += gv[u] * vr[c]; }
+    }
+    s = mdg_wave_sum(s);
+    g = mdg_wave_sum(g);
+    const float f = p_drop > 0.f ? (mdg_keep(seed, static_cast<uint64_t>(gw) * 32 + j, thr) ? ks : 0.f) : 1.f;
+    if (lane == j) { sv = s; dpv = g * f; fv = f; }
+  }
+  const float m = mdg_wave_max(sv);
+  const float e = lane < Tk ? expf(sv - m) : 0.f;
+  const float P = e / mdg_wave_sum(e);
+  const float delta = mdg_wave_sum(P * dpv);
+  const float ds = P * (dpv - delta);
+  const float pd = P * fv;
+  float dq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int j = 0; j < Tk; ++j) {
+    const float dsj = __shfl(ds, j, 64), pdj = __shfl(pd, j, 64);
+    const float* kr = kv + (drug * Tk + j) * ld + head * dh;
+    float* dkr = dkv + (drug * Tk + j) * lddkv + head * dh;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = lane + 64 * u;
+      if (u < per && c < dh) {
+        dkr[c] = dsj * qv[u];
+        dkr[d + c] = pdj * gv[u];
+        dq[u] += dsj * kr[c];
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = lane + 64 * u;
+    if (u < per && c < dh) dq_part[drug * d + head * dh + c] = dq[u] * qscale;
+  }
+}
+
+// Backward of assemble_tokens: each token's gradient goes back to its source row (through the L2 normalisation when
+// it was applied); the learned tokens (cls, bottleneck) and the position table are shared by all drugs: their
+// per-drug contributions are written to dense scratch ([n, S, 128], zero-filled by the caller) and summed over drugs
+// by mdg_colsum.  Requires rows == null (every modality row feeds exactly one token).
+struct AssembleBwdArgs {
+  const float* dseq;                                                    // [n_tok or n*S, 128]
+  const float* str; const float* kg; const float* cv; const float* tx;  // forward sources (for the normalisation)
+  const float* bottleneck; const float* cls;
+  const int64_t* token_index; int64_t n_tok;
+  float* dstr; float* dkg; float* dcv; float* dtx;                      // zero-filled by the caller (non-live tokens)
+  float* dlearned;                                                      // [n, S, 128] scratch or null
+  float* dpe;                                                           // [n, S, 128] scratch or null
+  int64_t n;
+  int nb, has_cls, pe_len, normalize;
+};
+
+__global__ __launch_bounds__(256) void assemble_tokens_bwd_kernel(const AssembleBwdArgs p) {
+  const int S = p.has_cls + 3 + p.nb + 16;
+  const int64_t slot = static_cast<int64_t>(blockIdx.x) * 8 + (threadIdx.x >> 5);
+  const int sub = threadIdx.x & 31;
+  if (slot >= (p.token_index ? p.n_tok : p.n * S)) return;
+  const int64_t tok = p.token_index ? p.token_index[slot] : slot;
+  const int64_t i = tok / S;
+  const int s = static_cast<int>(tok % S);
+  const int t = s - p.has_cls;
+  const float* row;
+  float* drow;
+  if (t < 0) { row = p.cls; drow = p.dlearned + tok * 128; }
+  else if (t == 0) { row = p.str + i * 128; drow = p.dstr + i * 128; }
+  else if (t == 1) { row = p.kg + i * 128; drow = p.dkg + i * 128; }
+  else if (t == 2) { row = p.cv + i * 128; drow = p.dcv + i * 128; }
+  else if (t < 3 + p.nb) { row = p.bottleneck + (t - 3) * 128; drow = p.dlearned + tok * 128; }
+  else { const int64_t r = static_cast<int64_t>(t - 3 - p.nb) * p.n + i; row = p.tx + r * 128; drow = p.dtx + r * 128; }
+  f32x4 g = *reinterpret_cast<const f32x4*>(p.dseq + slot * 128 + 4 * sub);
+  if (p.dpe && s < p.pe_len) *reinterpret_cast<f32x4*>(p.dpe + tok * 128 + 4 * sub) = g;
+  if (p.normalize) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * sub);
+    float q = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    float dot = v[0] * g[0] + v[1] * g[1] + v[2] * g[2] + v[3] * g[3];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { q += __shfl_xor(q, o, 64); dot += __shfl_xor(dot, o, 64); }
+    const float nrm = sqrtf(q);
+    if (nrm > 1e-12f) g = (g - v * (dot / q)) * (1.0f / nrm);       // d/dx [x/|x|] = (I - y y^T)/|x|
+    else g = g * 1e12f;                                              // clamped branch of F.normalize: y = x / eps
+  }
+  *reinterpret_cast<f32x4*>(drow + 4 * sub) = g;
+}
+
+// dx of y = x / max(|x|, 1e-12)
+__global__ __launch_bounds__(256) void l2_normalize_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
+                                                               float* __restrict__ dx, int64_t lddx, int64_t rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  const float* gr = dy + row * lddy;
+  float q = 0.f, dot = 0.f;
+  for (int c = 4 * lane; c < d; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gr + c);
+    q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    dot += (v[0] * g[0] + v[1] * g[1]) + (v[2] * g[2] + v[3] * g[3]);
+  }
+  q = mdg_wave_sum(q);
+  dot = mdg_wave_sum(dot);
+  const float nrm = sqrtf(q);
+  float* dr = dx + row * lddx;
+  for (int c = 4 * lane; c < d; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gr + c);
+    *reinterpret_cast<f32x4*>(dr + c) = nrm > 1e-12f ? (g - v * (dot / q)) * (1.0f / nrm) : g * 1e12f;
   }
 }
 
@@ -282,32 +587,116 @@ extern "C" int mdg_assemble_tokens(const float* str_emb, const float* kg_emb, co
   return MDG_OK;
 }
 
-extern "C" int mdg_fusion_attention(const float* qkv, int64_t ld, float* out, int64_t ldo, const uint32_t* kpm_bits,
-                                    const uint32_t* src_bits, float* probs, const int64_t* row_start, const uint32_t* row_bits,
-                                    int64_t n, int S, int H, int dh, void* stream) {
-  MDG_CHECK_ARG(n >= 0 && S >= 1 && S <= 32, "mdg_fusion_attention: S must be in [1,32] (got %d)", S);
-  MDG_CHECK_ARG(H >= 1 && dh >= 8 && dh % 32 == 0 && dh <= 1024, "mdg_fusion_attention: head_dim must be a multiple of 32 (got %d)", dh);
+static int attention_check(const char* who, const float* qkv, int64_t ld, const void* out, int64_t ldo, int64_t n, int S, int H, int dh,
+                           float p_drop) {
+  MDG_CHECK_ARG(n >= 0 && S >= 1 && S <= 32, "%s: S must be in [1,32] (got %d)", who, S);
+  MDG_CHECK_ARG(H >= 1 && dh >= 8 && dh % 32 == 0 && dh <= 1024, "%s: head_dim must be a multiple of 32 (got %d)", who, dh);
+  MDG_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "%s: dropout p must be in [0,1)", who);
   if (n == 0) return MDG_OK;
-  MDG_CHECK_ARG(qkv && out, "mdg_fusion_attention: null pointer");
+  MDG_CHECK_ARG(qkv && out, "%s: null pointer", who);
   MDG_CHECK_ARG(ld % 4 == 0 && ldo % 4 == 0 && ld >= 3 * H * dh && ldo >= H * dh && mdg_aligned16(qkv) && mdg_aligned16(out),
-                "mdg_fusion_attention: bad strides / alignment");
+                "%s: bad strides / alignment", who);
+  return MDG_OK;
+}
+
+extern "C" int mdg_fusion_attention_dropout(const float* qkv, int64_t ld, float* out, int64_t ldo, const uint32_t* kpm_bits,
+                                            const uint32_t* src_bits, float* probs, const int64_t* row_start, const uint32_t* row_bits,
+                                            int64_t n, int S, int H, int dh, float p_drop, uint64_t seed, void* stream) {
+  if (int rc = attention_check("mdg_fusion_attention", qkv, ld, out, ldo, n, S, H, dh, p_drop)) return rc;
+  if (n == 0) return MDG_OK;
   MDG_CHECK_ARG(!(row_start && probs), "mdg_fusion_attention: attention weights are only produced in dense mode");
-  AttnArgs a{qkv, ld, out, ldo, kpm_bits, src_bits, probs, row_start, row_bits, n, S, H, dh, 1.0f / sqrtf(static_cast<float>(dh))};
+  AttnArgs a{qkv, ld, out, ldo, kpm_bits, src_bits, probs, row_start, row_bits, n, S, H, dh, 1.0f / sqrtf(static_cast<float>(dh)),
+             p_drop, seed, nullptr, 0, nullptr, 0};
   hipLaunchKernelGGL(fusion_attention_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n * H, 4))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   MDG_CHECK_LAUNCH("mdg_fusion_attention");
   return MDG_OK;
 }
 
-extern "C" int mdg_xattn_pool(const float* q_proj, const float* kv_proj, int64_t ld, float* out, int64_t ldo, int64_t n, int Tk,
-                              int H, int dh, void* stream) {
+extern "C" int mdg_fusion_attention(const float* qkv, int64_t ld, float* out, int64_t ldo, const uint32_t* kpm_bits,
+                                    const uint32_t* src_bits, float* probs, const int64_t* row_start, const uint32_t* row_bits,
+                                    int64_t n, int S, int H, int dh, void* stream) {
+  return mdg_fusion_attention_dropout(qkv, ld, out, ldo, kpm_bits, src_bits, probs, row_start, row_bits, n, S, H, dh, 0.f, 0, stream);
+}
+
+extern "C" int mdg_fusion_attention_bwd(const float* qkv, int64_t ld, const float* dout, int64_t lddo, float* dqkv, int64_t lddq,
+                                        const uint32_t* kpm_bits, const uint32_t* src_bits, const int64_t* row_start,
+                                        const uint32_t* row_bits, int64_t n, int S, int H, int dh, float p_drop, uint64_t seed,
+                                        void* stream) {
+  if (int rc = attention_check("mdg_fusion_attention_bwd", qkv, ld, dout, lddo, n, S, H, dh, p_drop)) return rc;
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(dqkv && lddq % 4 == 0 && lddq >= 3 * H * dh && mdg_aligned16(dqkv) && dqkv != qkv, "mdg_fusion_attention_bwd: bad dqkv");
+  AttnArgs a{qkv, ld, nullptr, 0, kpm_bits, src_bits, nullptr, row_start, row_bits, n, S, H, dh, 1.0f / sqrtf(static_cast<float>(dh)),
+             p_drop, seed, dout, lddo, dqkv, lddq};
+  hipLaunchKernelGGL(fusion_attention_bwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n * H, 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  MDG_CHECK_LAUNCH("mdg_fusion_attention_bwd");
+  return MDG_OK;
+}
+
+extern "C" int mdg_xattn_pool_dropout(const float* q_proj, const float* kv_proj, int64_t ld, float* out, int64_t ldo, int64_t n, int Tk,
+                                      int H, int dh, float p_drop, uint64_t seed, void* stream) {
   MDG_CHECK_ARG(n >= 0 && Tk >= 1 && Tk <= 32 && H >= 1 && dh >= 1 && dh <= 256, "mdg_xattn_pool: bad shape (Tk=%d H=%d dh=%d)", Tk, H, dh);
+  MDG_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mdg_xattn_pool: dropout p must be in [0,1)");
   if (n == 0) return MDG_OK;
   MDG_CHECK_ARG(q_proj && kv_proj && out && ld >= 2 * H * dh && ldo >= H * dh, "mdg_xattn_pool: bad pointers / strides");
   hipLaunchKernelGGL(xattn_pool_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n * H, 4))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), q_proj, kv_proj, ld, out, ldo, n, Tk, H, dh,
-                     1.0f / sqrtf(static_cast<float>(dh)));
+                     1.0f / sqrtf(static_cast<float>(dh)), p_drop, seed);
   MDG_CHECK_LAUNCH("mdg_xattn_pool");
+  return MDG_OK;
+}
+
+extern "C" int mdg_xattn_pool(const float* q_proj, const float* kv_proj, int64_t ld, float* out, int64_t ldo, int64_t n, int Tk,
+                              int H, int dh, void* stream) {
+  return mdg_xattn_pool_dropout(q_proj, kv_proj, ld, out, ldo, n, Tk, H, dh, 0.f, 0, stream);
+}
+
+extern "C" int mdg_xattn_pool_bwd(const float* q_proj, const float* kv_proj, int64_t ld, const float* dout, int64_t lddo, float* dkv,
+                                  int64_t lddkv, float* dq_part, int64_t n, int Tk, int H, int dh, float p_drop, uint64_t seed,
+                                  void* stream) {
+  MDG_CHECK_ARG(n >= 0 && Tk >= 1 && Tk <= 32 && H >= 1 && dh >= 1 && dh <= 256, "mdg_xattn_pool_bwd: bad shape (Tk=%d H=%d dh=%d)", Tk, H, dh);
+  MDG_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mdg_xattn_pool_bwd: dropout p must be in [0,1)");
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(q_proj && kv_proj && dout && dkv && dq_part && ld >= 2 * H * dh && lddkv >= 2 * H * dh && lddo >= H * dh,
+                "mdg_xattn_pool_bwd: bad pointers / strides");
+  hipLaunchKernelGGL(xattn_pool_bwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n * H, 4))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     q_proj, kv_proj, ld, dout, lddo, dkv, lddkv, dq_part, n, Tk, H, dh, 1.0f / sqrtf(static_cast<float>(dh)), p_drop, seed);
+  MDG_CHECK_LAUNCH("mdg_xattn_pool_bwd");
+  return MDG_OK;
+}
+
+extern "C" int mdg_assemble_tokens_bwd(const float* dseq, const float* str_emb, const float* kg_emb, const float* cv_emb, const float* tx_emb,
+                                       const float* bottleneck, const float* cls, const int64_t* token_index, int64_t n_tok, float* dstr,
+                                       float* dkg, float* dcv, float* dtx, float* dlearned, float* dpe, int64_t n, int nb, int has_cls,
+                                       int pe_len, int normalize, int64_t D, void* stream) {
+  MDG_CHECK_ARG(D == 128, "mdg_assemble_tokens_bwd: D must be 128 (got %lld)", (long long)D);
+  MDG_CHECK_ARG(n >= 0 && nb >= 0 && nb <= 8, "mdg_assemble_tokens_bwd: bad sizes");
+  if (n == 0) return MDG_OK;
+  const int S = (has_cls ? 1 : 0) + 3 + nb + 16;
+  MDG_CHECK_ARG(S <= 32 && pe_len <= S, "mdg_assemble_tokens_bwd: sequence of %d tokens exceeds 32", S);
+  MDG_CHECK_ARG(dseq && dstr && dkg && dcv && dtx, "mdg_assemble_tokens_bwd: null pointer");
+  MDG_CHECK_ARG(!normalize || (str_emb && kg_emb && cv_emb && tx_emb && (nb == 0 || bottleneck) && (!has_cls || cls)),
+                "mdg_assemble_tokens_bwd: the forward sources are needed when tokens were normalised");
+  MDG_CHECK_ARG(((nb == 0 && !has_cls) || dlearned) && (pe_len == 0 || dpe), "mdg_assemble_tokens_bwd: missing scratch for shared tokens");
+  AssembleBwdArgs a{dseq, str_emb, kg_emb, cv_emb, tx_emb, bottleneck, cls, token_index, n_tok, dstr, dkg, dcv, dtx, dlearned, dpe, n, nb,
+                    has_cls ? 1 : 0, pe_len, normalize};
+  const int64_t slots = token_index ? n_tok : n * S;
+  if (slots == 0) return MDG_OK;
+  hipLaunchKernelGGL(assemble_tokens_bwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(slots, 8))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  MDG_CHECK_LAUNCH("mdg_assemble_tokens_bwd");
+  return MDG_OK;
+}
+
+extern "C" int mdg_l2_normalize_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dx, int64_t lddx, int64_t rows,
+                                    int64_t d, void* stream) {
+  MDG_CHECK_ARG(rows >= 0 && d > 0 && d % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ldx >= d && lddy >= d && lddx >= d,
+                "mdg_l2_normalize_bwd: bad shape");
+  if (rows == 0) return MDG_OK;
+  MDG_CHECK_ARG(dy && x && dx && mdg_aligned16(dy) && mdg_aligned16(x) && mdg_aligned16(dx), "mdg_l2_normalize_bwd: bad pointers");
+  hipLaunchKernelGGL(l2_normalize_bwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(rows, 4))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     dy, lddy, x, ldx, dx, lddx, rows, static_cast<int>(d));
+  MDG_CHECK_LAUNCH("mdg_l2_normalize_bwd");
   return MDG_OK;
 }
 

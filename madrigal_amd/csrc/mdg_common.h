@@ -52,6 +52,19 @@ __device__ __forceinline__ float mdg_sigmoid(float x) { return 1.0f / (1.0f + __
 
 __device__ __forceinline__ float mdg_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
+// counter-based random bits (splitmix64 finaliser, high word): dropout masks are a pure function of (seed, index),
+// so the backward pass regenerates them instead of storing them.
+__device__ __forceinline__ uint32_t mdg_mix32(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return static_cast<uint32_t>((z ^ (z >> 31)) >> 32);
+}
+__device__ __forceinline__ uint32_t mdg_drop_threshold(float p) { return static_cast<uint32_t>(static_cast<double>(p) * 4294967296.0); }
+__device__ __forceinline__ bool mdg_keep(uint64_t seed, uint64_t index, uint32_t thr) {
+  return mdg_mix32(seed * 0x100000001B3ull + index) >= thr;
+}
+
 // wave-wide reductions over all 64 lanes
 __device__ __forceinline__ float mdg_wave_sum(float v) {
 #pragma unroll

@@ -739,6 +739,67 @@ class TransformerFusion(nn.Module):
         t = _lin(u, L.linear2.weight, L.linear2.bias, residual=h)
         return ops.layernorm(t, L.norm2.weight, L.norm2.bias, L.norm2.eps)
 
+    def _layer_train(self, L, h, attend, keep_rows=None):
+        """The same layer through the autograd nodes, with the layer's three dropouts and the attention-weight
+        dropout active when the sub-modules are in training mode (nn.TransformerEncoderLayer._sa_block/_ff_block)."""
+        sa = L.self_attn
+        p_att = sa.dropout if sa.training else 0.0
+
+        def sa_block(x):
+            att = attend(_linT(x, sa.in_proj_weight, sa.in_proj_bias), p_att)
+            return att
+
+        def ff_block(x):
+            u = ag.dropout(_linT(x, L.linear1.weight, L.linear1.bias, self.actn), L.dropout.p, L.dropout.training)
+            return ag.dropout(_linT(u, L.linear2.weight, L.linear2.bias), L.dropout2.p, L.dropout2.training)
+        if self.norm_first:
+            att = sa_block(ag.layernorm(h, L.norm1.weight, L.norm1.bias, L.norm1.eps))
+            if keep_rows is not None:
+                att, h = att.index_select(0, keep_rows), h.index_select(0, keep_rows)
+            o = ag.dropout(_linT(att, sa.out_proj.weight, sa.out_proj.bias), L.dropout1.p, L.dropout1.training)
+            h = ag.add(h, o)
+            return ag.add(h, ff_block(ag.layernorm(h, L.norm2.weight, L.norm2.bias, L.norm2.eps)))
+        att = sa_block(h)
+        if keep_rows is not None:
+            att, h = att.index_select(0, keep_rows), h.index_select(0, keep_rows)
+        o = ag.dropout(_linT(att, sa.out_proj.weight, sa.out_proj.bias), L.dropout1.p, L.dropout1.training)
+        h = ag.layernorm(ag.add(h, o), L.norm1.weight, L.norm1.bias, L.norm1.eps)
+        return ag.layernorm(ag.add(h, ff_block(h)), L.norm2.weight, L.norm2.bias, L.norm2.eps)
+
+    def _x_attn_pool_train(self, h_keys, n, Tk):
+        d, H, dh = self.latent_dim, self.num_heads, self.head_dim
+        mha = self.x_attn_mha_layer
+        kvn = ag.layernorm(h_keys, self.x_attn_kv_norm.weight, self.x_attn_kv_norm.bias, self.x_attn_kv_norm.eps)
+        w, b = mha.in_proj_weight, mha.in_proj_bias             # row slices of a parameter: torch views carry the gradient
+        kvp = _linT(kvn, w[d:], b[d:])
+        q = self.x_attn_query
+        if self.norm_first:
+            q = ag.layernorm(q, self.x_attn_query_norm.weight, self.x_attn_query_norm.bias, self.x_attn_query_norm.eps)
+        qp = _linT(q, w[:d], b[:d])
+        pooled = ag.xattn_pool(qp, kvp, n, Tk, H, dh, mha.dropout if mha.training else 0.0)
+        o = _linT(pooled, mha.out_proj.weight, mha.out_proj.bias)
+        o = ag.dropout(o, self.x_attn_dropout.p, self.x_attn_dropout.training)
+        o = ag.add(o, q.reshape(-1))
+        if not self.norm_first:
+            o = ag.layernorm(o, self.x_attn_query_norm.weight, self.x_attn_query_norm.bias, self.x_attn_query_norm.eps)
+        return _linT(o, self.latent2embed.weight, self.latent2embed.bias)
+
+    def _forward_train(self, h_in, n, S, attend, keep_rows, dense: bool, Tk=None):
+        """Shared training-mode body of ``forward`` (dense) and ``forward_tokens`` (live tokens)."""
+        d = self.latent_dim
+        h = _linT(h_in, self.embed2latent.weight, self.embed2latent.bias)
+        layers = self.transformer_encoder.layers
+        agg = self.transformer_agg
+        for li, L in enumerate(layers):
+            last = li == len(layers) - 1
+            h = self._layer_train(L, h, attend, keep_rows if (last and agg in ('x-attn', 'cls')) else None)
+        self.last_attention_weights = None
+        if agg == 'x-attn':
+            return self._x_attn_pool_train(h, n, Tk)
+        if agg == 'cls':
+            return _linT(h, self.latent2embed.weight, self.latent2embed.bias)
+        raise NotImplementedError(f"transformer_agg={agg!r} in training mode (the shipped configs train with 'x-attn')")
+
     def _x_attn_pool(self, h_keys, n, Tk):
         """Cross-attention pooling over the (already selected) key tokens h_keys [n*Tk, d] (models.py:422-443)."""
         d, H, dh = self.latent_dim, self.num_heads, self.head_dim
@@ -763,11 +824,21 @@ class TransformerFusion(nn.Module):
         """Dense path, the reference's signature: fusion_sequence [n,S,D] (batch-major, as the encoder passes
         it), fusion_mask bool [n,S] (True = padding), src_mask bool [S,S] (True = not allowed) -> [n,D].
         Also produces the last layer's attention weights for forward hooks on ``layers[-1].self_attn``."""
-        _require_eval(self)
         n, S, D = fusion_sequence.shape
         d, H, dh = self.latent_dim, self.num_heads, self.head_dim
         kbits = None if fusion_mask is None else ops.mask_bits(fusion_mask)
         sbits = None if src_mask is None else ops.mask_bits(src_mask)
+        if _train_path(self) or ag.needs_grad(fusion_sequence):
+            def attend_t(qkv, p_att):
+                return ag.fusion_attention(qkv, n, S, H, dh, kbits, sbits, p_drop=p_att)
+            dev = fusion_sequence.device
+            if self.transformer_agg == 'x-attn':
+                keys = torch.tensor(self._key_positions(), device=dev)
+                keep = (torch.arange(n, device=dev).unsqueeze(1) * S + keys.unsqueeze(0)).flatten()
+                Tk = int(keys.numel())
+            else:
+                keep, Tk = torch.arange(n, device=dev) * S, None
+            return self._forward_train(fusion_sequence.reshape(n * S, D), n, S, attend_t, keep, True, Tk)
         h = _lin(fusion_sequence.reshape(n * S, D), self.embed2latent.weight, self.embed2latent.bias)
         layers = self.transformer_encoder.layers
         for li, L in enumerate(layers):
@@ -863,8 +934,12 @@ class TransformerFusion(nn.Module):
     def forward_tokens(self, tokens: torch.Tensor, plan: dict) -> torch.Tensor:
         """Same result as ``forward`` on the dense sequence, computed on the live token rows only
         (tokens [R,D] in plan['token_index'] order)."""
-        _require_eval(self)
         n, S, H, dh = plan["n"], plan["S"], self.num_heads, self.head_dim
+        if _train_path(self) or ag.needs_grad(tokens):
+            def attend_t(qkv, p_att):
+                return ag.fusion_attention(qkv, plan["n_tiles"], S, H, dh, row_start=plan["tile_start"], row_bits=plan["row_bits"],
+                                           p_drop=p_att)
+            return self._forward_train(tokens, n, S, attend_t, plan.get("key_rows"), False, plan.get("Tk"))
         h = _lin(tokens, self.embed2latent.weight, self.embed2latent.bias)
         layers = self.transformer_encoder.layers
         agg = self.transformer_agg

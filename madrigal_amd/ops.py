@@ -291,7 +291,7 @@ def assemble_tokens(str_emb, kg_emb, cv_emb, tx_emb, *, bottleneck=None, cls=Non
 
 def fusion_attention(qkv: torch.Tensor, n: int, S: int, H: int, dh: int, kpm_bits=None, src_bits=None,
                      want_probs: bool = False, row_start: Optional[torch.Tensor] = None,
-                     row_bits: Optional[torch.Tensor] = None):
+                     row_bits: Optional[torch.Tensor] = None, p_drop: float = 0.0, seed: int = 0):
     """Self-attention core over q|k|v rows -> (attention output rows, probs [n,H,S,S] | None).
     Dense: qkv [n*S, 3*H*dh].  Compact (``row_start`` [n+1] int64): qkv holds only live token rows."""
     qkv = _f32_cuda(qkv, "qkv", 2)
@@ -303,22 +303,54 @@ def fusion_attention(qkv: torch.Tensor, n: int, S: int, H: int, dh: int, kpm_bit
         raise ValueError("row_start: int64 [n+1]; attention weights need the dense layout")
     out = torch.empty((rows, d), dtype=torch.float32, device=qkv.device)
     probs = torch.empty((n, H, S, S), dtype=torch.float32, device=qkv.device) if want_probs else None
-    check(lib().mdg_fusion_attention(_ptr(qkv), _c64(qkv.stride(0)), _ptr(out), _c64(d), _ptr(kpm_bits), _ptr(src_bits), _ptr(probs),
-                                     _ptr(row_start), _ptr(row_bits), _c64(n), _c(S), _c(H), _c(dh), _stream(qkv)),
-          "mdg_fusion_attention")
+    check(lib().mdg_fusion_attention_dropout(_ptr(qkv), _c64(qkv.stride(0)), _ptr(out), _c64(d), _ptr(kpm_bits), _ptr(src_bits),
+                                             _ptr(probs), _ptr(row_start), _ptr(row_bits), _c64(n), _c(S), _c(H), _c(dh), _f(p_drop),
+                                             ctypes.c_uint64(seed & (2 ** 64 - 1)), _stream(qkv)), "mdg_fusion_attention")
     return out, probs
 
 
-def xattn_pool(q_proj: torch.Tensor, kv_proj: torch.Tensor, n: int, Tk: int, H: int, dh: int) -> torch.Tensor:
+def fusion_attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, n: int, S: int, H: int, dh: int, kpm_bits=None, src_bits=None,
+                         row_start=None, row_bits=None, p_drop: float = 0.0, seed: int = 0) -> torch.Tensor:
+    """Gradient of the q|k|v rows given the gradient of the attention output (weights recomputed, mask replayed)."""
+    qkv, dout = _f32_cuda(qkv, "qkv", 2), _f32_cuda(dout, "dout", 2)
+    d = H * dh
+    if qkv.shape[1] != 3 * d or dout.shape != (qkv.shape[0], d):
+        raise ValueError("fusion_attention_bwd: shape mismatch")
+    # rows outside every tile (none in practice) would stay unwritten: start from zeros only in that case
+    dqkv = torch.empty_like(qkv)
+    check(lib().mdg_fusion_attention_bwd(_ptr(qkv), _c64(qkv.stride(0)), _ptr(dout), _c64(d), _ptr(dqkv), _c64(3 * d), _ptr(kpm_bits),
+                                         _ptr(src_bits), _ptr(row_start), _ptr(row_bits), _c64(n), _c(S), _c(H), _c(dh), _f(p_drop),
+                                         ctypes.c_uint64(seed & (2 ** 64 - 1)), _stream(qkv)), "mdg_fusion_attention_bwd")
+    return dqkv
+
+
+def xattn_pool(q_proj: torch.Tensor, kv_proj: torch.Tensor, n: int, Tk: int, H: int, dh: int, p_drop: float = 0.0,
+               seed: int = 0) -> torch.Tensor:
     q = _f32_cuda(q_proj.reshape(-1), "q_proj", 1)
     kv = _f32_cuda(kv_proj, "kv_proj", 2)
     d = H * dh
     if q.numel() != d or kv.shape != (n * Tk, 2 * d):
         raise ValueError(f"xattn_pool: expected q [{d}] and kv [{n * Tk},{2 * d}]")
     out = torch.empty((n, d), dtype=torch.float32, device=kv.device)
-    check(lib().mdg_xattn_pool(_ptr(q), _ptr(kv), _c64(kv.stride(0)), _ptr(out), _c64(d), _c64(n), _c(Tk), _c(H), _c(dh), _stream(kv)),
-          "mdg_xattn_pool")
+    check(lib().mdg_xattn_pool_dropout(_ptr(q), _ptr(kv), _c64(kv.stride(0)), _ptr(out), _c64(d), _c64(n), _c(Tk), _c(H), _c(dh),
+                                       _f(p_drop), ctypes.c_uint64(seed & (2 ** 64 - 1)), _stream(kv)), "mdg_xattn_pool")
     return out
+
+
+def xattn_pool_bwd(q_proj: torch.Tensor, kv_proj: torch.Tensor, dout: torch.Tensor, n: int, Tk: int, H: int, dh: int,
+                   p_drop: float = 0.0, seed: int = 0):
+    """-> (dq_proj [d], dkv [n*Tk, 2d])."""
+    q = _f32_cuda(q_proj.reshape(-1), "q_proj", 1)
+    kv, dout = _f32_cuda(kv_proj, "kv_proj", 2), _f32_cuda(dout, "dout", 2)
+    d = H * dh
+    if q.numel() != d or kv.shape != (n * Tk, 2 * d) or dout.shape != (n, d):
+        raise ValueError("xattn_pool_bwd: shape mismatch")
+    dkv = torch.empty_like(kv)
+    dq_part = torch.empty((n, d), dtype=torch.float32, device=kv.device)
+    check(lib().mdg_xattn_pool_bwd(_ptr(q), _ptr(kv), _c64(kv.stride(0)), _ptr(dout), _c64(d), _ptr(dkv), _c64(2 * d), _ptr(dq_part),
+                                   _c64(n), _c(Tk), _c(H), _c(dh), _f(p_drop), ctypes.c_uint64(seed & (2 ** 64 - 1)), _stream(kv)),
+          "mdg_xattn_pool_bwd")
+    return colsum(dq_part), dkv
 
 
 # ------------------------------------------------------------------------------- graphs
@@ -598,3 +630,50 @@ def axpby(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, beta: float = 1.
     out = torch.empty_like(a)
     check(lib().mdg_axpby(_ptr(a), _ptr(b), _ptr(out), _c64(a.numel()), _c64(b.numel()), _f(alpha), _f(beta), _stream(a)), "mdg_axpby")
     return out
+
+
+def assemble_tokens_bwd(dseq: torch.Tensor, str_emb, kg_emb, cv_emb, tx_emb, *, bottleneck=None, cls=None, pe_len: int = 0,
+                        normalize: bool = False, token_index=None):
+    """Gradients of mdg_assemble_tokens (rows=None) -> dict(str, kg, cv, tx, bottleneck, cls, pe)."""
+    s, k, c, t = (_f32_cuda(a, nm, 2) for a, nm in ((str_emb, "str"), (kg_emb, "kg"), (cv_emb, "cv"), (tx_emb, "tx")))
+    n, D = s.shape
+    nb = 0 if bottleneck is None else int(bottleneck.shape[0])
+    has_cls = cls is not None
+    S = (1 if has_cls else 0) + 3 + nb + 16
+    dseq = _f32_cuda(dseq, "dseq").reshape(-1, D)
+    n_tok = 0 if token_index is None else int(token_index.numel())
+    if dseq.shape[0] != (n * S if token_index is None else n_tok):
+        raise ValueError("assemble_tokens_bwd: dseq rows disagree with the token list")
+    dev = s.device
+    # non-emitted tokens leave zero gradient; dense scratch for the shared tokens is summed over drugs below
+    dstr, dkg, dcv = (torch.zeros((n, D), dtype=torch.float32, device=dev) for _ in range(3))
+    dtx = torch.zeros((16 * n, D), dtype=torch.float32, device=dev)
+    dlearned = torch.zeros((n, S, D), dtype=torch.float32, device=dev) if (nb or has_cls) else None
+    dpe = torch.zeros((n, S, D), dtype=torch.float32, device=dev) if pe_len else None
+    check(lib().mdg_assemble_tokens_bwd(_ptr(dseq), _ptr(s), _ptr(k), _ptr(c), _ptr(t),
+                                        _ptr(None if bottleneck is None else bottleneck.detach().contiguous()),
+                                        _ptr(None if cls is None else cls.detach().contiguous()),
+                                        _ptr(None if token_index is None else token_index.contiguous()), _c64(n_tok), _ptr(dstr), _ptr(dkg),
+                                        _ptr(dcv), _ptr(dtx), _ptr(dlearned), _ptr(dpe), _c64(n), _c(nb), _c(1 if has_cls else 0),
+                                        _c(pe_len), _c(1 if normalize else 0), _c64(D), _stream(s)), "mdg_assemble_tokens_bwd")
+    out = {"str": dstr, "kg": dkg, "cv": dcv, "tx": dtx, "bottleneck": None, "cls": None, "pe": None}
+    if dlearned is not None:
+        tot = colsum(dlearned.view(n, S * D)).view(S, D)
+        off = 1 if has_cls else 0
+        if has_cls:
+            out["cls"] = tot[0]
+        if nb:
+            out["bottleneck"] = tot[off + 3: off + 3 + nb]
+    if dpe is not None:
+        out["pe"] = colsum(dpe.view(n, S * D)).view(S, D)[:pe_len]
+    return out
+
+
+def l2_normalize_bwd(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    dy, x = _f32_cuda(dy, "dy", 2), _f32_cuda(x, "x", 2)
+    if x.shape[1] % 4:
+        raise ValueError("l2_normalize_bwd: feature dim must be a multiple of 4")
+    dx = torch.empty_like(x)
+    check(lib().mdg_l2_normalize_bwd(_ptr(dy), _c64(dy.stride(0)), _ptr(x), _c64(x.stride(0)), _ptr(dx), _c64(dx.stride(0)),
+                                     _c64(x.shape[0]), _c64(x.shape[1]), _stream(x)), "mdg_l2_normalize_bwd")
+    return dx
