@@ -212,6 +212,30 @@ int mdg_rank_normalize(const float* scores, float* out, int64_t n_outcomes, int6
  * x_k <= 0.  inputs_host is a HOST array of K device pointers; n (elements) must be a multiple of 4. */
 int mdg_gmean(const float* const* inputs_host, int K, float* out, int64_t n, void* stream);
 
+/* ------------------------------------------------------- gathered head (finetune step) ---- */
+/* train_ddi_batch.py:285-288 computes sigmoid(model(...)) [L,N,N] and reads T (label, head, tail) entries of it.  These
+ * entry points compute only those entries: score[t] = z_head[head[t]]^T w[label] z_tail[tail[t]].
+ * The triples are sorted by label by the caller and cut into tiles of <= 32 triples of ONE label: tile_start [n_tiles+1]
+ * (triple offsets), tile_label [n_tiles]; head / tail / score / dscore are in that sorted order.  D must be 128. */
+int mdg_bilinear_gather(const float* z_head, const float* z_tail, const float* w, const int64_t* head, const int64_t* tail,
+                        const int64_t* tile_start, const int64_t* tile_label, int64_t n_tiles, float* score, int64_t D,
+                        void* stream);
+/* Backward: gz_head_rows / gz_tail_rows [T,128] receive one gradient row per triple (dscore[t] * w z_tail, dscore[t] *
+ * w^T z_head; the caller sums them per drug with mdg_csr_aggregate — no atomics); w_t is w transposed per label (pass
+ * w itself when it is symmetric).  dw [n_labels,128,128] (optional) is accumulated through dw_partial
+ * [n_chunks,128,128]: chunk_start [n_chunks+1] cuts the sorted triples into chunks of <= 256 triples of one label and
+ * label_chunk_ptr [n_labels+1] lists each label's chunks. */
+int mdg_bilinear_gather_bwd(const float* z_head, const float* z_tail, const float* w, const float* w_t, const int64_t* head,
+                            const int64_t* tail, const int64_t* tile_start, const int64_t* tile_label, int64_t n_tiles,
+                            const int64_t* chunk_start, int64_t n_chunks, const int64_t* label_chunk_ptr, int64_t n_labels,
+                            const float* dscore, float* gz_head_rows, float* gz_tail_rows, float* dw_partial, float* dw, int64_t D,
+                            void* stream);
+/* nn.BCELoss(sigmoid(score), target) per element (log clamp at -100) and/or its gradient w.r.t. the logit times
+ * grad_scale (1/T for reduction='mean').  madrigal/utils.py:616-619. */
+int mdg_bce_logits(const float* score, const float* target, float* term, float* dscore, int64_t n, float grad_scale, void* stream);
+/* Backward of mdg_symmetrize: dw_original = triu(dw_sym) + triu(dw_sym^T, 1). */
+int mdg_symmetrize_bwd(const float* dw_sym, float* dw_original, int64_t n_labels, int64_t D, void* stream);
+
 /* ------------------------------------------------------- backward-pass building blocks ---- */
 /* (the finetune step of train_ddi_batch.py:285-354: loss.backward() through the modules above) */
 
@@ -229,6 +253,9 @@ int mdg_activation_bwd(const float* dy, const float* pre, float* dx, int64_t n, 
 
 /* out[i] = alpha * a[i] + beta * b[i mod nb] (residual adds of the training path; nb < n broadcasts a row over rows). */
 int mdg_axpby(const float* a, const float* b, float* out, int64_t n, int64_t nb, float alpha, float beta, void* stream);
+
+/* out[i] = x[i] * scalar[0], scalar in device memory (scaling a stored gradient by the incoming scalar gradient). */
+int mdg_mul_device_scalar(const float* x, const float* scalar, float* out, int64_t n, void* stream);
 
 /* Inverted dropout y = x * keep / (1-p); keep is a counter-based hash of (seed, element index), so calling it again
  * with the same seed on dy is the backward pass (nn.Dropout of the transformer / MLPs / position encoder). */

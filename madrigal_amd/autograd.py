@@ -298,3 +298,66 @@ class _L2Normalize(Function):
 
 def l2_normalize(x):
     return _L2Normalize.apply(x)
+
+
+# ------------------------------------------------------------------------------------------- decoder
+class _Symmetrize(Function):
+    @staticmethod
+    def forward(ctx, w):
+        return ops.symmetrize(w if w.is_contiguous() else w.contiguous())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dws):
+        return ops.symmetrize_bwd(dws if dws.is_contiguous() else dws.contiguous())
+
+
+def symmetrize(w):
+    return _Symmetrize.apply(w)
+
+
+class _BilinearGather(Function):
+    """Scores of the plan's (label, head, tail) triples only (plan order = sorted by label)."""
+
+    @staticmethod
+    def forward(ctx, z_head, z_tail, w_sym, plan):
+        ctx.save_for_backward(z_head, z_tail, w_sym)
+        ctx.plan = plan
+        return ops.bilinear_gather(z_head, z_tail, w_sym, plan)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ds):
+        z_head, z_tail, w_sym = ctx.saved_tensors
+        dzh, dzt, dw = ops.bilinear_gather_bwd(z_head, z_tail, w_sym, ctx.plan, ds if ds.is_contiguous() else ds.contiguous(),
+                                               need_dw=ctx.needs_input_grad[2])
+        return (dzh if ctx.needs_input_grad[0] else None), (dzt if ctx.needs_input_grad[1] else None), dw, None
+
+
+def bilinear_gather(z_head, z_tail, w_sym, plan):
+    return _BilinearGather.apply(z_head, z_tail, w_sym, plan)
+
+
+class _BCEWithSigmoid(Function):
+    """nn.BCELoss(reduction)(sigmoid(score), target) -> scalar (madrigal/utils.py:616-619, train_ddi_batch.py:285-288)."""
+
+    @staticmethod
+    def forward(ctx, score, target, reduction):
+        n = score.numel()
+        gscale = 1.0 / max(n, 1) if reduction == "mean" else 1.0
+        term, ds = ops.bce_logits(score, target, want_term=True, grad_scale=gscale)
+        ctx.save_for_backward(ds)
+        tot = ops.colsum(term.view(-1, 1))                       # fixed-order sum
+        return (tot * gscale if reduction == "mean" else tot).reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dloss):
+        (ds,) = ctx.saved_tensors
+        return ops.mul_device_scalar(ds, dloss), None, None
+
+
+def bce_with_sigmoid(score, target, reduction="mean"):
+    if reduction not in ("mean", "sum"):
+        raise NotImplementedError(f"loss_readout={reduction!r}")
+    return _BCEWithSigmoid.apply(score, target, reduction)

@@ -100,6 +100,12 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a,
   if (i < n) out[i] = alpha * a[i] + beta * b[nb == n ? i : i % nb];
 }
 
+// ---- out = x * s[0], s on the device (chain-rule scaling by the incoming scalar gradient, no host sync) -------------
+__global__ __launch_bounds__(256) void mul_dev_scalar_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ out, int64_t n) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) out[i] = x[i] * s[0];
+}
+
 // ---- dropout: y = x * keep / (1 - p), keep ~ Bernoulli(1-p) from a counter-based hash of (seed, element index);
 // the same (seed, index) reproduces the mask in the backward pass, so no mask tensor is stored. -------------------
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p,
@@ -429,5 +435,14 @@ extern "C" int mdg_axpby(const float* a, const float* b, float* out, int64_t n, 
   hipLaunchKernelGGL(axpby_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, out, n, nb,
                      alpha, beta);
   MDG_CHECK_LAUNCH("mdg_axpby");
+  return MDG_OK;
+}
+
+extern "C" int mdg_mul_device_scalar(const float* x, const float* scalar, float* out, int64_t n, void* stream) {
+  MDG_CHECK_ARG(n >= 0, "mdg_mul_device_scalar: negative size");
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(x && scalar && out, "mdg_mul_device_scalar: null pointer");
+  hipLaunchKernelGGL(mul_dev_scalar_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), x, scalar, out, n);
+  MDG_CHECK_LAUNCH("mdg_mul_device_scalar");
   return MDG_OK;
 }

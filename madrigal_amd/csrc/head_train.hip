@@ -1,0 +1,241 @@
+// Gathered bilinear head for the finetune step (train_ddi_batch.py:285-288): the reference materialises
+// sigmoid(model(...)) [L, N, N] and then reads T (label, head, tail) entries of it; here only those T entries are
+// ever computed, forward and backward:
+//     s_t = z_head[h_t]^T W[l_t] z_tail[t_t]
+//     dz_head[h_t] += ds_t W[l_t] z_tail[t_t],  dz_tail[t_t] += ds_t W[l_t]^T z_head[h_t],  dW[l_t] += ds_t z_head[h_t] z_tail[t_t]^T
+// Triples are pre-sorted by label (host plan) and cut into tiles of <= 32 triples of one label; one wave per tile runs
+// U = Z_tail[tile] W_l^T on v_mfma_f32_32x32x2_f32 (exact fp32) with W_l streamed from L2 and the gathered embedding
+// rows held in registers.  No atomics anywhere: per-triple gradient rows are summed per drug by mdg_csr_aggregate and
+// per-chunk dW partials are summed per label in a fixed order.
+#include "mdg_common.h"
+
+namespace {
+
+constexpr int HD = 128;     // embedding width of every shipped config
+
+struct GatherArgs {
+  const float* zh; const float* zt;       // [Nh,128], [Nt,128]
+  const float* w; const float* wt;        // [L,128,128] and its per-label transpose (same pointer when symmetric)
+  const int64_t* head; const int64_t* tail;   // [T] sorted by label
+  const int64_t* tile_start;              // [n_tiles+1] first triple of each tile
+  const int64_t* tile_label;              // [n_tiles]
+  int64_t n_tiles;
+  float* score;                           // fwd: [T]
+  const float* ds;                        // bwd: [T]
+  float* gzh; float* gzt;                 // bwd: per-triple gradient rows [T,128]
+};
+
+// acc[v] (lane x = triple, half) <- sum_k W[c0 + i(v,half)][k] z[x][k], for the four 32-column tiles c0 = 0,32,64,96.
+// zf holds the lane's share of its z row in the permuted-k order (k = 8q + 4*half + e).
+__device__ __forceinline__ void wz_tile(const float* __restrict__ wl, int c0, int x, int half, const f32x4 (&zf)[16], f32x16& acc) {
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+  const float* wrow = wl + static_cast<int64_t>(c0 + x) * HD + 4 * half;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const f32x4 wf = *reinterpret_cast<const f32x4*>(wrow + 8 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[e], zf[q][e], acc, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void load_row_frag(const float* __restrict__ row, int half, f32x4 (&zf)[16]) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) zf[q] = *reinterpret_cast<const f32x4*>(row + 8 * q + 4 * half);
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bilinear_gather_kernel(const GatherArgs p) {
+  const int lane = threadIdx.x & 63, x = lane & 31, half = lane >> 5;
+  const int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (tile >= p.n_tiles) return;
+  const int64_t t0 = p.tile_start[tile];
+  const int cnt = static_cast<int>(p.tile_start[tile + 1] - t0);
+  if (cnt <= 0) return;
+  const int64_t t = t0 + (x < cnt ? x : cnt - 1);
+  const int64_t l = p.tile_label[tile];
+  const float* wl = p.w + l * HD * HD;
+  const float* zt_row = p.zt + p.tail[t] * HD;
+  const float* zh_row = p.zh + p.head[t] * HD;
+
+  f32x4 zf[16];
+  load_row_frag(zt_row, half, zf);
+  if (!BWD) {
+    float s = 0.f;
+    for (int c0 = 0; c0 < HD; c0 += 32) {
+      f32x16 acc;
+      wz_tile(wl, c0, x, half, zf, acc);                    // acc[v] = (W z_t)[c0 + (v&3) + 8(v>>2) + 4half]
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(zh_row + c0 + 8 * g + 4 * half);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += acc[4 * g + e] * hv[e];
+      }
+    }
+    s += __shfl_xor(s, 32, 64);
+    if (half == 0 && x < cnt) p.score[t] = s;
+  } else {
+    const float g_t = p.ds[t];
+    for (int c0 = 0; c0 < HD; c0 += 32) {                   // d z_head[h_t] row: ds * W z_t
+      f32x16 acc;
+      wz_tile(wl, c0, x, half, zf, acc);
+      if (x < cnt) {
+        float* r = p.gzh + t * HD + c0 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(r + 8 * g) = f32x4{acc[4 * g] * g_t, acc[4 * g + 1] * g_t, acc[4 * g + 2] * g_t, acc[4 * g + 3] * g_t};
+      }
+    }
+    load_row_frag(zh_row, half, zf);
+    const float* wtl = p.wt + l * HD * HD;
+    for (int c0 = 0; c0 < HD; c0 += 32) {                   // d z_tail[t_t] row: ds * W^T z_h
+      f32x16 acc;
+      wz_tile(wtl, c0, x, half, zf, acc);
+      if (x < cnt) {
+        float* r = p.gzt + t * HD + c0 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(r + 8 * g) = f32x4{acc[4 * g] * g_t, acc[4 * g + 1] * g_t, acc[4 * g + 2] * g_t, acc[4 * g + 3] * g_t};
+      }
+    }
+  }
+}
+
+// dW partial of one chunk (<= 256 triples of one label): P[a][b] = sum_t ds_t z_head[h_t][a] z_tail[t_t][b].
+// Wave w owns rows a in [32w, 32w+32) and all 128 columns (four accumulator tiles); the contraction runs over the
+// chunk's triples two at a time (MFMA k = lane half).
+__global__ __launch_bounds__(256) void bilinear_gather_dw_kernel(const float* __restrict__ zh, const float* __restrict__ zt,
+                                                                 const int64_t* __restrict__ head, const int64_t* __restrict__ tail,
+                                                                 const float* __restrict__ ds, const int64_t* __restrict__ chunk_start,
+                                                                 float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, x = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int64_t chunk = blockIdx.x;
+  const int64_t t0 = chunk_start[chunk], t1 = chunk_start[chunk + 1];
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+  for (int64_t t = t0 + half; t < t1 + half; t += 2) {       // both halves take the same number of steps
+    const bool ok = t < t1;
+    const int64_t tt = ok ? t : t1 - 1;
+    const float g = ok ? ds[tt] : 0.f;
+    const float a = zh[head[tt] * HD + 32 * wave + x] * g;
+    const float* zr = zt + tail[tt] * HD + x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, zr[32 * j], acc[j], 0, 0, 0);
+  }
+  // acc[j][v]: row a = 32*wave + (v&3) + 8(v>>2) + 4*half, column b = 32*j + x
+  float* out = partial + chunk * HD * HD;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) out[static_cast<int64_t>(32 * wave + (v & 3) + 8 * (v >> 2) + 4 * half) * HD + 32 * j + x] = acc[j][v];
+}
+
+// dW[l] = sum of the partials of label l's chunks, in chunk order; labels without triples get zeros.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, const int64_t* __restrict__ label_chunk_ptr,
+                                                              float* __restrict__ dw) {
+  const int64_t l = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float s = 0.f;
+  for (int64_t c = label_chunk_ptr[l]; c < label_chunk_ptr[l + 1]; ++c) s += partial[c * HD * HD + i];
+  dw[l * HD * HD + i] = s;
+}
+
+// BCE on probabilities p = sigmoid(s) with nn.BCELoss's log clamp at -100, and its gradient w.r.t. the logit
+// (through BCELoss.backward's 1e-12 clamp of p(1-p) and the sigmoid), scaled by `gscale` (1/T for 'mean').
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ s, const float* __restrict__ y, float* __restrict__ term,
+                                                         float* __restrict__ ds, int64_t n, float gscale) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float p = 1.0f / (1.0f + expf(-s[i]));
+  const float yy = y[i];
+  if (term) term[i] = -(yy * fmaxf(logf(p), -100.f) + (1.0f - yy) * fmaxf(logf(1.0f - p), -100.f));
+  if (ds) {
+    const float pq = p * (1.0f - p);
+    ds[i] = gscale * (p - yy) / fmaxf(pq, 1e-12f) * pq;
+  }
+}
+
+// dW_original = triu(dW_sym) + triu(dW_sym^T, 1): the upper triangle collects both mirrored entries.
+__global__ __launch_bounds__(256) void symmetrize_bwd_kernel(const float* __restrict__ dws, float* __restrict__ dwo, int64_t n_labels, int D) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n_labels * D * D) return;
+  const int64_t l = i / (static_cast<int64_t>(D) * D);
+  const int r = static_cast<int>((i / D) % D), c = static_cast<int>(i % D);
+  const float* m = dws + l * D * D;
+  dwo[i] = r == c ? m[r * D + c] : (r < c ? m[r * D + c] + m[c * D + r] : 0.f);
+}
+
+}  // namespace
+
+static int gather_check(const char* who, const void* zh, const void* zt, const void* w, const void* head, const void* tail,
+                        const void* tile_start, const void* tile_label, int64_t n_tiles, int64_t D) {
+  MDG_CHECK_ARG(D == HD, "%s: D must be 128 (got %lld)", who, (long long)D);
+  MDG_CHECK_ARG(n_tiles >= 0, "%s: negative tile count", who);
+  if (n_tiles == 0) return MDG_OK;
+  MDG_CHECK_ARG(zh && zt && w && head && tail && tile_start && tile_label, "%s: null pointer", who);
+  MDG_CHECK_ARG(mdg_aligned16(zh) && mdg_aligned16(zt) && mdg_aligned16(w), "%s: operands must be 16-byte aligned", who);
+  return MDG_OK;
+}
+
+extern "C" int mdg_bilinear_gather(const float* z_head, const float* z_tail, const float* w, const int64_t* head, const int64_t* tail,
+                                   const int64_t* tile_start, const int64_t* tile_label, int64_t n_tiles, float* score, int64_t D,
+                                   void* stream) {
+  if (int rc = gather_check("mdg_bilinear_gather", z_head, z_tail, w, head, tail, tile_start, tile_label, n_tiles, D)) return rc;
+  if (n_tiles == 0) return MDG_OK;
+  MDG_CHECK_ARG(score, "mdg_bilinear_gather: null score");
+  GatherArgs a{z_head, z_tail, w, w, head, tail, tile_start, tile_label, n_tiles, score, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(bilinear_gather_kernel<false>, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  MDG_CHECK_LAUNCH("mdg_bilinear_gather");
+  return MDG_OK;
+}
+
+extern "C" int mdg_bilinear_gather_bwd(const float* z_head, const float* z_tail, const float* w, const float* w_t, const int64_t* head,
+                                       const int64_t* tail, const int64_t* tile_start, const int64_t* tile_label, int64_t n_tiles,
+                                       const int64_t* chunk_start, int64_t n_chunks, const int64_t* label_chunk_ptr, int64_t n_labels,
+                                       const float* dscore, float* gz_head_rows, float* gz_tail_rows, float* dw_partial, float* dw,
+                                       int64_t D, void* stream) {
+  if (int rc = gather_check("mdg_bilinear_gather_bwd", z_head, z_tail, w, head, tail, tile_start, tile_label, n_tiles, D)) return rc;
+  MDG_CHECK_ARG(n_chunks >= 0 && n_labels >= 0, "mdg_bilinear_gather_bwd: negative size");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n_tiles > 0) {
+    MDG_CHECK_ARG(w_t && dscore && gz_head_rows && gz_tail_rows && mdg_aligned16(w_t) && mdg_aligned16(gz_head_rows) && mdg_aligned16(gz_tail_rows),
+                  "mdg_bilinear_gather_bwd: null / misaligned pointer");
+    GatherArgs a{z_head, z_tail, w, w_t, head, tail, tile_start, tile_label, n_tiles, nullptr, dscore, gz_head_rows, gz_tail_rows};
+    hipLaunchKernelGGL(bilinear_gather_kernel<true>, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0, st, a);
+  }
+  if (dw) {
+    MDG_CHECK_ARG(label_chunk_ptr && (n_chunks == 0 || (chunk_start && dw_partial && dscore)), "mdg_bilinear_gather_bwd: dW needs the chunk tables and scratch");
+    if (n_chunks > 0)
+      hipLaunchKernelGGL(bilinear_gather_dw_kernel, dim3(static_cast<unsigned>(n_chunks)), dim3(256), 0, st, z_head, z_tail, head, tail, dscore,
+                         chunk_start, dw_partial);
+    if (n_labels > 0)
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(HD * HD / 256, static_cast<unsigned>(n_labels)), dim3(256), 0, st, dw_partial,
+                         label_chunk_ptr, dw);
+  }
+  MDG_CHECK_LAUNCH("mdg_bilinear_gather_bwd");
+  return MDG_OK;
+}
+
+extern "C" int mdg_bce_logits(const float* score, const float* target, float* term, float* dscore, int64_t n, float grad_scale, void* stream) {
+  MDG_CHECK_ARG(n >= 0, "mdg_bce_logits: negative size");
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(score && target && (term || dscore), "mdg_bce_logits: null pointer");
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), score,
+                     target, term, dscore, n, grad_scale);
+  MDG_CHECK_LAUNCH("mdg_bce_logits");
+  return MDG_OK;
+}
+
+extern "C" int mdg_symmetrize_bwd(const float* dw_sym, float* dw_original, int64_t n_labels, int64_t D, void* stream) {
+  MDG_CHECK_ARG(n_labels >= 0 && D > 0 && D <= 4096, "mdg_symmetrize_bwd: bad shape");
+  if (n_labels == 0) return MDG_OK;
+  MDG_CHECK_ARG(dw_sym && dw_original && dw_sym != dw_original, "mdg_symmetrize_bwd: null / aliased pointers");
+  hipLaunchKernelGGL(symmetrize_bwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_labels * D * D, 256))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), dw_sym, dw_original, n_labels, static_cast<int>(D));
+  MDG_CHECK_LAUNCH("mdg_symmetrize_bwd");
+  return MDG_OK;
+}

@@ -966,8 +966,10 @@ class Symmetric(nn.Module):
     """madrigal/models/models.py:522-524 (parametrisation registered at :922)."""
 
     def forward(self, W):
-        if W.is_cuda and not (torch.is_grad_enabled() and W.requires_grad):
-            return ops.symmetrize(W if W.dim() == 3 else W.unsqueeze(0)).view_as(W)
+        if W.is_cuda and W.dim() == 3 and ag.needs_grad(W):
+            return ag.symmetrize(W)
+        if W.is_cuda:
+            return ops.symmetrize(W.detach() if W.dim() == 3 else W.detach().unsqueeze(0)).view_as(W)
         return W.triu() + W.triu(1).transpose(-1, -2)      # parameter materialisation off the GPU (state_dict tools)
 
 
@@ -995,7 +997,16 @@ class BilinearDDIScorer(nn.Bilinear):
         ops.forward_only(input1, input2)
         return ops.bilinear_allpairs(input1, input2, weight, precision=_state["precision"], epilogue=epilogue, out=out)
 
+    def score_triples(self, input1, input2, plan: dict) -> torch.Tensor:
+        """Extension (finetune step): scores of the plan's (label, head, tail) triples only, in the plan's
+        label-sorted order, differentiable w.r.t. both embeddings and the weight (train_ddi_batch.py:285-286
+        reads exactly these entries of the dense result)."""
+        return ag.bilinear_gather(input1, input2, self.weight, plan)
+
     def forward(self, input1, input2, label_range: tuple = None, epilogue=ops.EPI_STORE, out=None):
+        if ag.needs_grad(input1, input2) or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("the dense [L,N,N] result is not differentiable on the HIP path: use score_triples() "
+                                      "(NovelDDIMultilabel.score_triples) for the finetune step, or torch.no_grad() for inference")
         w = self.symmetric_weight()
         if label_range is not None:
             assert len(label_range) == 2

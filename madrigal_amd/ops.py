@@ -677,3 +677,108 @@ def l2_normalize_bwd(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     check(lib().mdg_l2_normalize_bwd(_ptr(dy), _c64(dy.stride(0)), _ptr(x), _c64(x.stride(0)), _ptr(dx), _c64(dx.stride(0)),
                                      _c64(x.shape[0]), _c64(x.shape[1]), _stream(x)), "mdg_l2_normalize_bwd")
     return dx
+
+
+# ------------------------------------------------------------------------------- gathered head (finetune step)
+def triple_plan(labels: torch.Tensor, heads: torch.Tensor, tails: torch.Tensor, n_labels: int, n_head: int, n_tail: int) -> dict:
+    """Index plumbing for the gathered head (torch sorts / prefix sums on the device, one host round trip for the tile
+    and chunk counts): triples sorted by label, cut into tiles of <= 32 and chunks of <= 256 triples of one label;
+    CSR lists of the sorted triples per head drug and per tail drug for the gradient row sums."""
+    T = int(labels.numel())
+    dev = labels.device
+    for nm, t in (("labels", labels), ("heads", heads), ("tails", tails)):
+        if t.dtype != torch.int64 or not t.is_cuda or t.numel() != T or t.dim() != 1:
+            raise ValueError(f"{nm}: expected int64 cuda [{T}]")
+    perm = torch.argsort(labels, stable=True)
+    ls, hs, ts = labels[perm], heads[perm].contiguous(), tails[perm].contiguous()
+    counts = torch.bincount(ls, minlength=n_labels)
+    if counts.numel() != n_labels:
+        raise ValueError("labels: value outside [0, n_labels)")
+    zero = torch.zeros(1, dtype=torch.int64, device=dev)
+    label_ptr = torch.cat([zero, torch.cumsum(counts, 0)])
+    lab = torch.arange(n_labels, device=dev)
+
+    def cut(size):
+        per = (counts + size - 1) // size
+        first = torch.cumsum(per, 0) - per
+        which = torch.repeat_interleave(lab, per)
+        start = label_ptr[which] + size * (torch.arange(which.numel(), device=dev) - first[which])
+        return per, which.contiguous(), torch.cat([start, torch.tensor([T], dtype=torch.int64, device=dev)]).contiguous()
+    _, tile_label, tile_start = cut(32)
+    chunks_per, _, chunk_start = cut(256)
+    label_chunk_ptr = torch.cat([zero, torch.cumsum(chunks_per, 0)]).contiguous()
+    bounds = torch.stack([hs.max() if T else zero[0], ts.max() if T else zero[0]]).tolist() if T else [-1, -1]
+    if bounds[0] >= n_head or bounds[1] >= n_tail or (T and (int(heads.min()) < 0 or int(tails.min()) < 0)):
+        raise ValueError("heads / tails: index outside the embedding tables")
+
+    def by_drug(idx, n):
+        order = torch.argsort(idx, stable=True)
+        return torch.cat([zero, torch.cumsum(torch.bincount(idx, minlength=n), 0)]).contiguous(), order.contiguous()
+    head_ptr, head_rows = by_drug(hs, n_head)
+    tail_ptr, tail_rows = by_drug(ts, n_tail)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(T, device=dev)
+    return {"T": T, "L": n_labels, "n_head": n_head, "n_tail": n_tail, "perm": perm, "inv_perm": inv, "heads": hs, "tails": ts,
+            "tile_start": tile_start, "tile_label": tile_label, "n_tiles": int(tile_label.numel()), "chunk_start": chunk_start,
+            "n_chunks": int(chunk_start.numel()) - 1, "label_chunk_ptr": label_chunk_ptr, "head_ptr": head_ptr,
+            "head_rows": head_rows, "tail_ptr": tail_ptr, "tail_rows": tail_rows}
+
+
+def bilinear_gather(z_head: torch.Tensor, z_tail: torch.Tensor, w: torch.Tensor, plan: dict) -> torch.Tensor:
+    """score[t] = z_head[h_t]^T w[l_t] z_tail[t_t] for the plan's triples, in the plan's (label-sorted) order."""
+    zh, zt, w = _f32_cuda(z_head, "z_head", 2), _f32_cuda(z_tail, "z_tail", 2), _f32_cuda(w, "w", 3)
+    if zh.shape != (plan["n_head"], 128) or zt.shape != (plan["n_tail"], 128) or w.shape != (plan["L"], 128, 128):
+        raise ValueError("bilinear_gather: operands disagree with the plan (D must be 128)")
+    score = torch.empty(plan["T"], dtype=torch.float32, device=zh.device)
+    check(lib().mdg_bilinear_gather(_ptr(zh), _ptr(zt), _ptr(w), _ptr(plan["heads"]), _ptr(plan["tails"]), _ptr(plan["tile_start"]),
+                                    _ptr(plan["tile_label"]), _c64(plan["n_tiles"]), _ptr(score), _c64(128), _stream(zh)),
+          "mdg_bilinear_gather")
+    return score
+
+
+def bilinear_gather_bwd(z_head, z_tail, w, plan: dict, dscore: torch.Tensor, w_t: Optional[torch.Tensor] = None, need_dw: bool = True):
+    """-> (dz_head [Nh,128], dz_tail [Nt,128], dw [L,128,128] | None).  ``w_t``: per-label transpose of ``w`` (omit when
+    ``w`` is symmetric)."""
+    zh, zt, w = _f32_cuda(z_head, "z_head", 2), _f32_cuda(z_tail, "z_tail", 2), _f32_cuda(w, "w", 3)
+    ds = _f32_cuda(dscore, "dscore", 1)
+    T, L, dev = plan["T"], plan["L"], zh.device
+    if ds.numel() != T:
+        raise ValueError("dscore: one entry per triple expected")
+    wt = w if w_t is None else _f32_cuda(w_t, "w_t", 3)
+    gh = torch.empty((T, 128), dtype=torch.float32, device=dev)
+    gt = torch.empty((T, 128), dtype=torch.float32, device=dev)
+    dw = torch.empty((L, 128, 128), dtype=torch.float32, device=dev) if need_dw else None
+    part = torch.empty((max(plan["n_chunks"], 1), 128, 128), dtype=torch.float32, device=dev) if need_dw else None
+    check(lib().mdg_bilinear_gather_bwd(_ptr(zh), _ptr(zt), _ptr(w), _ptr(wt), _ptr(plan["heads"]), _ptr(plan["tails"]),
+                                        _ptr(plan["tile_start"]), _ptr(plan["tile_label"]), _c64(plan["n_tiles"]), _ptr(plan["chunk_start"]),
+                                        _c64(plan["n_chunks"]), _ptr(plan["label_chunk_ptr"]), _c64(L), _ptr(ds), _ptr(gh), _ptr(gt),
+                                        _ptr(part), _ptr(dw), _c64(128), _stream(zh)), "mdg_bilinear_gather_bwd")
+    dzh = csr_aggregate(gh, plan["head_ptr"], plan["head_rows"])
+    dzt = csr_aggregate(gt, plan["tail_ptr"], plan["tail_rows"])
+    return dzh, dzt, dw
+
+
+def bce_logits(score: torch.Tensor, target: torch.Tensor, want_term: bool = True, grad_scale: Optional[float] = None):
+    """-> (term | None, dscore | None): nn.BCELoss(sigmoid(score), target) per element and its logit gradient * grad_scale."""
+    s, y = _f32_cuda(score, "score", 1), _f32_cuda(target, "target", 1)
+    if s.shape != y.shape:
+        raise ValueError("bce_logits: shape mismatch")
+    term = torch.empty_like(s) if want_term else None
+    ds = torch.empty_like(s) if grad_scale is not None else None
+    check(lib().mdg_bce_logits(_ptr(s), _ptr(y), _ptr(term), _ptr(ds), _c64(s.numel()), _f(grad_scale or 0.0), _stream(s)), "mdg_bce_logits")
+    return term, ds
+
+
+def symmetrize_bwd(dw_sym: torch.Tensor) -> torch.Tensor:
+    dws = _f32_cuda(dw_sym, "dw_sym", 3)
+    out = torch.empty_like(dws)
+    check(lib().mdg_symmetrize_bwd(_ptr(dws), _ptr(out), _c64(dws.shape[0]), _c64(dws.shape[1]), _stream(dws)), "mdg_symmetrize_bwd")
+    return out
+
+
+def mul_device_scalar(x: torch.Tensor, scalar: torch.Tensor) -> torch.Tensor:
+    x = _f32_cuda(x, "x")
+    s = _f32_cuda(scalar.reshape(1), "scalar", 1)
+    out = torch.empty_like(x)
+    check(lib().mdg_mul_device_scalar(_ptr(x), _ptr(s), _ptr(out), _c64(x.numel()), _stream(x)), "mdg_mul_device_scalar")
+    return out

@@ -422,3 +422,71 @@ def test_l2_normalize_backward():
     xg = x.to(DEV).requires_grad_(True)
     ag.l2_normalize(xg).backward(dy.to(DEV))
     _close(xg.grad, xr.grad, 1e-5, "l2 normalize dx")
+
+
+# ---------------------------------------------------------------------------------------------- gathered head
+def _triples(T, L, Nh, Nt, seed, skew=True):
+    g = torch.Generator().manual_seed(seed)
+    if skew:      # a few very frequent outcomes, many rare ones, some absent (as in DrugBank / TWOSIDES)
+        pr = torch.arange(1, L + 1, dtype=torch.float64) ** -1.3
+        pr[L // 2] = 0
+        labels = torch.multinomial(pr / pr.sum(), T, replacement=True, generator=g)
+    else:
+        labels = torch.randint(0, L, (T,), generator=g)
+    return labels, torch.randint(0, Nh, (T,), generator=g), torch.randint(0, Nt, (T,), generator=g)
+
+
+@pytest.mark.parametrize("T,L,Nh,Nt", [(1, 3, 2, 2), (33, 1, 5, 7), (5000, 40, 300, 200), (20000, 7, 64, 64)])
+def test_gathered_head_forward_backward_match_torch(T, L, Nh, Nt):
+    from madrigal_amd import autograd as ag, ops
+    labels, heads, tails = _triples(T, L, Nh, Nt, seed=T)
+    zh, zt = _rand(Nh, 128, seed=1), _rand(Nt, 128, seed=2)
+    w0 = _rand(L, 128, 128, seed=3, scale=128 ** -0.5)
+    ds = _rand(T, seed=4)
+    zr, tr, wr = (v.double().requires_grad_(True) for v in (zh, zt, w0))
+    ws = wr.triu() + wr.triu(1).transpose(-1, -2)
+    sr = torch.einsum("td,tde,te->t", zr[heads], ws[labels], tr[tails]) if T * 128 * 128 < 5e8 else None
+    sr.backward(ds.double())
+    plan = ops.triple_plan(labels.to(DEV), heads.to(DEV), tails.to(DEV), L, Nh, Nt)
+    assert torch.equal(labels[plan["perm"].cpu()], labels.sort(stable=True).values)
+    zg, tg, wg = (v.to(DEV).requires_grad_(True) for v in (zh, zt, w0))
+    s = ag.bilinear_gather(zg, tg, ag.symmetrize(wg), plan)
+    _close(s[plan["inv_perm"]], sr, 2e-5, "gathered scores")
+    s.backward(ds.to(DEV)[plan["perm"]])
+    _close(zg.grad, zr.grad, 2e-5, "dz_head")
+    _close(tg.grad, tr.grad, 2e-5, "dz_tail")
+    _close(wg.grad, wr.grad, 2e-5, "dW_original")
+    assert not wg.grad.tril(-1).any()                      # the parametrisation only ever reads the upper triangle
+    # the gathered scores are the entries of the dense all-pairs kernel (fp32 mode: same fp32 MFMA arithmetic class)
+    dense = ops.bilinear_allpairs(zg.detach(), tg.detach(), ops.symmetrize(wg.detach()), precision="f32")
+    _close(s.detach()[plan["inv_perm"]], dense[labels.to(DEV), heads.to(DEV), tails.to(DEV)], 2e-5, "vs dense head")
+    # bit-identical re-run (no atomics anywhere)
+    zg2, tg2, wg2 = (v.to(DEV).requires_grad_(True) for v in (zh, zt, w0))
+    ag.bilinear_gather(zg2, tg2, ag.symmetrize(wg2), plan).backward(ds.to(DEV)[plan["perm"]])
+    assert torch.equal(zg.grad, zg2.grad) and torch.equal(tg.grad, tg2.grad) and torch.equal(wg.grad, wg2.grad)
+
+
+def test_gathered_head_rejects_bad_triples():
+    from madrigal_amd import ops
+    l, h, t = (torch.tensor(v, device=DEV) for v in ([0, 1], [0, 5], [1, 1]))
+    with pytest.raises(ValueError):
+        ops.triple_plan(l, h, t, 2, 5, 2)                   # head index 5 outside a 5-row table
+    with pytest.raises(ValueError):
+        ops.triple_plan(l, h, t, 1, 6, 2)                   # label 1 outside [0,1)
+    with pytest.raises(ValueError):
+        ops.triple_plan(l.int(), h, t, 2, 6, 2)
+
+
+@pytest.mark.parametrize("reduction", ["mean", "sum"])
+def test_bce_with_sigmoid_matches_torch_including_saturation(reduction):
+    from madrigal_amd import autograd as ag
+    s = torch.cat([_rand(1000, seed=1, scale=4.0), torch.tensor([40.0, -40.0, 120.0, -120.0, 0.0, 17.5, -17.5])])
+    y = (torch.rand(s.numel(), generator=torch.Generator().manual_seed(2)) < 0.4).float()
+    sr = s.clone().requires_grad_(True)
+    lr = torch.nn.BCELoss(reduction=reduction)(torch.sigmoid(sr), y)      # the reference's loss, fp32 on the CPU
+    lr.backward()
+    sg = s.to(DEV).requires_grad_(True)
+    lg = ag.bce_with_sigmoid(sg, y.to(DEV), reduction)
+    (lg * 3.0).backward()
+    _close(lg, lr, 1e-5, "bce loss")
+    _close(sg.grad, 3.0 * sr.grad, 1e-5, "bce dlogit")
