@@ -361,3 +361,31 @@ def bce_with_sigmoid(score, target, reduction="mean"):
     if reduction not in ("mean", "sum"):
         raise NotImplementedError(f"loss_readout={reduction!r}")
     return _BCEWithSigmoid.apply(score, target, reduction)
+
+
+# ------------------------------------------------------------------------------------------- graphs
+class _CsrAggregate(Function):
+    """out[v] = (add + coef_dev) * x[v] (optional) + sum_{e in row v} w_e x[col_e]  (GIN neighbourhood sum, read-out).
+    The backward pass is the same kernel on the reversed edges (``tplan`` from graph_plans.transposed_csr)."""
+
+    @staticmethod
+    def forward(ctx, x, rowptr, col, w, tplan, with_self, coef_dev, coef_add, mean):
+        x = x if x.is_contiguous() else x.contiguous()
+        ctx.tplan, ctx.with_self, ctx.coef_add, ctx.cols = tplan, with_self, coef_add, x.shape[1]
+        ctx.save_for_backward(coef_dev)
+        return ops.csr_aggregate(x, rowptr, col, edge_weight=w, x_self=x if with_self else None, self_coef_dev=coef_dev,
+                                 self_coef_add=coef_add, mean=mean)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (coef_dev,) = ctx.saved_tensors
+        tp = ctx.tplan
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        dx = ops.csr_aggregate(dout, tp["rowptr"], tp["col"], edge_weight=tp["w"], x_self=dout if ctx.with_self else None,
+                               self_coef_dev=coef_dev, self_coef_add=ctx.coef_add)
+        return (dx[:, :ctx.cols],) + (None,) * 8
+
+
+def csr_aggregate(x, rowptr, col, w, tplan, with_self=False, coef_dev=None, coef_add=0.0, mean=False):
+    return _CsrAggregate.apply(x, rowptr, col, w, tplan, with_self, coef_dev, coef_add, mean)

@@ -59,6 +59,26 @@ def molecule_plan(graph) -> dict:
     return plan
 
 
+def transposed_csr(rowptr: torch.Tensor, col, w, n_src: int, mean: bool = False) -> dict:
+    """CSR of the reversed edges of (rowptr, col, w): the plan of the backward pass of mdg_csr_aggregate
+    (d x[u] = sum over edges u -> v of w_e * d out[v]).  ``col`` None = row v owns source rows rowptr[v]..rowptr[v+1];
+    ``mean`` folds the 1/len(row) factor of the forward mean into the reversed weights."""
+    dev = rowptr.device
+    n_dst = int(rowptr.numel()) - 1
+    counts = rowptr[1:] - rowptr[:-1]
+    E = int(rowptr[-1].item()) if n_dst > 0 else 0
+    row_of_edge = torch.repeat_interleave(torch.arange(n_dst, device=dev), counts)
+    src = torch.arange(E, device=dev) if col is None else col
+    order = torch.argsort(src, stable=True)
+    wt = None
+    if w is not None or mean:
+        wt = torch.ones(E, device=dev) if w is None else w.float()
+        if mean:
+            wt = wt / counts.clamp_min(1).to(torch.float32)[row_of_edge]
+        wt = wt[order].contiguous()
+    return {"rowptr": _rowptr(src[order], n_src), "col": row_of_edge[order].contiguous(), "w": wt}
+
+
 def hgt_plan(edge_index_dict, edge_types: Sequence[Tuple[str, str, str]], sizes: Dict[str, int], device, used=None) -> dict:
     """Layout + CSR plan of one HGTConv call.
 

@@ -24,7 +24,7 @@ import torch.nn as nn
 from . import autograd as ag
 from . import ops
 from .data import CELL_LINES, MOL_DIM, NON_TX_MODALITIES, NUM_MODALITIES, NUM_NON_TX_MODALITIES
-from .graph_plans import hgt_plan, molecule_plan
+from .graph_plans import hgt_plan, molecule_plan, transposed_csr
 
 TX_INPUT_DIM = 978
 CELL_LINES_CAPITALIZED = [c.upper() for c in CELL_LINES]
@@ -301,8 +301,45 @@ class GraphIsomorphismNetwork(nn.Module):
             layer.edge_linear = nn.Linear(edge_input_dim, self.dims[i]) if edge_input_dim else None
             self.layers.append(layer)
 
+    def _forward_train(self, graph, input):
+        """Training-mode / differentiated pass: the same kernels through the autograd nodes; BatchNorm uses batch
+        statistics over the atoms; the backward of every aggregation is mdg_csr_aggregate on the reversed edges."""
+        plan = molecule_plan(graph)
+        A = int(input.shape[0])
+        if "t_edges" not in plan:
+            plan["t_edges"] = transposed_csr(plan["rowptr"], plan["col"], plan["w"], A)
+            plan["t_readout"] = transposed_csr(plan["graph_rowptr"], None, None, A, mean=(self.readout_kind == "mean"))
+        h = ops._pad_last(input.float()).contiguous()
+        esum = None
+        for layer in self.layers:
+            if isinstance(layer.eps, nn.Parameter) and layer.eps.requires_grad and torch.is_grad_enabled():
+                raise NotImplementedError("learn_eps=True is not trained on the HIP path (Madrigal's GIN uses a fixed eps)")
+            k_in = layer.mlp.layers[0].weight.shape[1]
+            agg = ag.csr_aggregate(h, plan["rowptr"], plan["col"], plan["w"], plan["t_edges"], with_self=True,
+                                   coef_dev=layer.eps.detach(), coef_add=1.0)
+            if agg.shape[1] != k_in:
+                agg = agg[:, :k_in]
+            if layer.edge_linear is not None:
+                if esum is None:
+                    esum = ops.csr_aggregate(plan["edge_feat_aug"], plan["rowptr"], None, edge_weight=plan["w"])
+                fe = plan["edge_feat_dim"]
+                el = layer.edge_linear             # [W_e | b_e | 0] against [sum_e e_uv | weighted degree | 0]
+                we = torch.cat([el.weight, el.bias.unsqueeze(1), el.weight.new_zeros(k_in, esum.shape[1] - fe - 1)], dim=1)
+                agg = ag.add(agg, _linT(esum, we, None))
+            u = agg
+            n_mlp = len(layer.mlp.layers)
+            for j, lin in enumerate(layer.mlp.layers):
+                if j == n_mlp - 1 and hasattr(layer, "batch_norm"):
+                    u = _bn_or_affine(_linT(u, lin.weight, lin.bias, None), layer.batch_norm, self.activation)
+                else:
+                    u = _linT(u, lin.weight, lin.bias, self.activation)
+            h = u
+        g = ag.csr_aggregate(h, plan["graph_rowptr"], None, None, plan["t_readout"], mean=(self.readout_kind == "mean"))
+        return {"graph_feature": g[:, : self.output_dim], "node_feature": h}
+
     def forward(self, graph, input, all_loss=None, metric=None):
-        _require_eval(self)
+        if _train_path(self) or ag.needs_grad(input):
+            return self._forward_train(graph, input)
         plan = molecule_plan(graph)
         h = ops._pad_last(input.float()).contiguous()          # 67 atom features -> 68 (zero column)
         esum = None
@@ -557,19 +594,23 @@ class TxAdaptingComPert(nn.Module):
         """Same outputs as the reference.  ``compute_reconstruction=False`` skips the decoder (62 % of
         this block's flops) whose output Madrigal discards (models.py:761) and returns None in its slot;
         ``covariate_indices`` may replace the one-hot ``covariates`` (the reference only takes argmax)."""
-        _require_eval(self)
         assert (drugs is not None) or (drugs_idx is not None and dosages is not None)
         if covariate_indices is None:
             covariate_indices = [c.argmax(1) for c in covariates]
+        train = _train_path(self) or ag.needs_grad(genes)
+        if train and compute_reconstruction:
+            raise NotImplementedError("the reconstruction head is not differentiated on the HIP path (Madrigal discards it, "
+                                      "models.py:761): call predict(compute_reconstruction=False)")
         emb_sum = None
         for emb, idx in zip(self.covariates_embeddings, covariate_indices):
-            e = emb.weight.detach().index_select(0, idx.to(emb.weight.device))
-            emb_sum = e if emb_sum is None else emb_sum + e
+            wt = emb.weight if train else emb.weight.detach()            # row gather: torch indexing carries the gradient
+            e = wt.index_select(0, idx.to(emb.weight.device))
+            emb_sum = e if emb_sum is None else (ag.add(emb_sum, e) if train else emb_sum + e)
         last_emb = e
         need_basal = return_latent_basal or emb_sum is None
         if need_basal:
             latent_basal = self.encoder(genes)
-            latent_treated = latent_basal if emb_sum is None else self._add(latent_basal, emb_sum)
+            latent_treated = latent_basal if emb_sum is None else (ag.add(latent_basal, emb_sum) if train else latent_basal + emb_sum)
         else:
             latent_basal = None
             latent_treated = self.encoder(genes, residual=emb_sum)          # + cov embedding fused in the epilogue
@@ -584,10 +625,6 @@ class TxAdaptingComPert(nn.Module):
         if return_latent_treated:
             out += (latent_treated,)
         return out
-
-    @staticmethod
-    def _add(a, b):
-        return a + b
 
 
 # ------------------------------------------------------------------------------------- encoder factories

@@ -490,3 +490,93 @@ def test_bce_with_sigmoid_matches_torch_including_saturation(reduction):
     (lg * 3.0).backward()
     _close(lg, lr, 1e-5, "bce loss")
     _close(sg.grad, 3.0 * sr.grad, 1e-5, "bce dlogit")
+
+
+# ---------------------------------------------------------------------------------------------- structure / tx encoders
+def _torch_gin(ref, mols, x):
+    """GIN layer semantics restated on torch ops (same statement as oracle.gin_forward; torchdrug 0.2.1 is not in the
+    image): agg_v = (1+eps) h_v + sum_{u->v} w_uv (h_u + edge_linear(e_uv)); h' = act(BN(MLP(agg))); read-out."""
+    src, dst = mols.edge_list[:, 0], mols.edge_list[:, 1]
+    w = mols.edge_weight.double().unsqueeze(1)
+    h = x
+    act = {"relu": torch.relu, "gelu": torch.nn.functional.gelu}[ref.activation]
+    for layer in ref.layers:
+        msg = h[src]
+        if layer.edge_linear is not None:
+            msg = msg + layer.edge_linear(mols.edge_feature.double())
+        agg = torch.zeros_like(h).index_add(0, dst, msg * w) + (1.0 + layer.eps.double()) * h
+        u = agg
+        for j, lin in enumerate(layer.mlp.layers):
+            u = lin(u)
+            if j < len(layer.mlp.layers) - 1:
+                u = act(u)
+        if hasattr(layer, "batch_norm"):
+            u = layer.batch_norm(u)
+        h = act(u)
+    G = mols.batch_size
+    g = torch.zeros(G, h.shape[1], dtype=h.dtype).index_add(0, mols.node2graph, h)
+    if ref.readout_kind == "mean":
+        g = g / torch.bincount(mols.node2graph, minlength=G).clamp_min(1).unsqueeze(1)
+    return g
+
+
+@pytest.mark.parametrize("batch_norm,readout,weighted", [(True, "mean", False), (False, "sum", True)])
+def test_gin_training_gradients_match_torch(batch_norm, readout, weighted):
+    from madrigal_amd import data, models as M
+    torch.manual_seed(5)
+    mols = data.make_molecules(40, seed=3)
+    if weighted:
+        mols.edge_weight = torch.rand(mols.num_edge, generator=torch.Generator().manual_seed(1)) + 0.5
+    m = M.GraphIsomorphismNetwork(input_dim=67, hidden_dims=[128, 128], edge_input_dim=18, num_mlp_layer=3, eps=0.1,
+                                  batch_norm=batch_norm, activation="gelu", readout=readout)
+    ref = copy.deepcopy(m).double().train()
+    m = m.to(DEV).train()
+    xr = mols.node_feature.double()
+    out_r = _torch_gin(ref, mols, xr)
+    dy = _rand(*out_r.shape, seed=8)
+    out_r.backward(dy.double())
+    mg = mols.to(DEV)
+    out_g = m(mg, mg.node_feature.float())["graph_feature"]
+    out_g.backward(dy.to(DEV))
+    _close(out_g, out_r, 1e-4, "gin forward")
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+    n_checked = 0
+    for (name, pg), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
+        if pr.grad is None:
+            continue
+        assert pg.grad is not None, name
+        _close(pg.grad, pr.grad, 1e-4, name, floor=1e-2 * gmax)
+        n_checked += 1
+    assert n_checked >= 12
+    if batch_norm:
+        for (name, bg), (_, br) in zip(m.named_buffers(), ref.named_buffers()):
+            _close(bg.float(), br.float(), 1e-4, name)
+
+
+def test_chemcpa_predict_training_gradients_match_torch():
+    from madrigal_amd import models as M
+    torch.manual_seed(6)
+    cov = {"cell_type": [f"c{i}" for i in range(16)]}
+    m = M.TxAdaptingComPert(978, 10, cov, use_drugs=False, hparams={"autoencoder_width": 256, "autoencoder_depth": 2, "dim": 128})
+    ref = copy.deepcopy(m).double().train()
+    m = m.to(DEV).train()
+    genes = _rand(150, 978, seed=1)
+    idx = torch.randint(0, 16, (150,), generator=torch.Generator().manual_seed(2))
+    zeros = torch.zeros(150, dtype=torch.int64)
+    lat_r = ref.encoder.network(genes.double()) + ref.covariates_embeddings[0].weight[idx]
+    dy = _rand(150, 128, seed=3)
+    lat_r.backward(dy.double())
+    with M.precision("f32"):
+        out = m.predict(genes=genes.to(DEV), drugs_idx=zeros.to(DEV), dosages=zeros.to(DEV), covariate_indices=[idx.to(DEV)],
+                        return_latent_treated=True, compute_reconstruction=False)
+        lat_g = out[2]
+        lat_g.backward(dy.to(DEV))
+    _close(lat_g, lat_r, 2e-5, "latent_treated")
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+    for (name, pg), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
+        if pr.grad is None:
+            assert pg.grad is None, name                       # the decoder is never touched
+            continue
+        _close(pg.grad, pr.grad, 2e-5, name, floor=1e-2 * gmax)
+    with pytest.raises(NotImplementedError):
+        m.predict(genes=genes.to(DEV), drugs_idx=zeros.to(DEV), dosages=zeros.to(DEV), covariate_indices=[idx.to(DEV)])
