@@ -212,6 +212,26 @@ int mdg_rank_normalize(const float* scores, float* out, int64_t n_outcomes, int6
  * x_k <= 0.  inputs_host is a HOST array of K device pointers; n (elements) must be a multiple of 4. */
 int mdg_gmean(const float* const* inputs_host, int K, float* out, int64_t n, void* stream);
 
+/* mdg_hgt_attention that also returns the softmax statistics stats [n_dst, heads, 2] = (max logit, denominator) the
+ * backward pass needs; and that backward pass.  dout is the gradient at the attention output BEFORE the activation
+ * (call the forward with apply_gelu = 0 and differentiate the activation separately), out_pre that forward output.
+ * Reversed edge lists (built by the caller from col / the destination of each edge): the nnz edges stably sorted by
+ * key row; t_edge[e'] = forward edge id, t_dst[e'] = its destination; the n_src_rows distinct key rows t_row are cut
+ * into work items (t_item_begin/end, t_item_ptr [n_src_rows+1]).  dq [n_dst,128]; dkv has the layout of kv (lddkv =
+ * 128: value rows follow key rows) and only the rows of this call's key rows are written — zero-fill it first. */
+int mdg_hgt_attention_stats(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const int64_t* col,
+                            const int64_t* item_dst, const int64_t* item_begin, const int64_t* item_end, int64_t n_items,
+                            const int64_t* item_ptr, float* out, int64_t ldo, int64_t n_dst, int heads, int64_t F,
+                            int apply_gelu, float* stats, void* workspace, size_t workspace_bytes, void* stream);
+size_t mdg_hgt_attention_bwd_workspace_bytes(int64_t nnz, int64_t n_items, int64_t n_src_items, int heads);
+int mdg_hgt_attention_bwd(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const int64_t* col, int64_t nnz,
+                          const int64_t* item_dst, const int64_t* item_begin, const int64_t* item_end, int64_t n_items,
+                          const int64_t* item_ptr, int64_t n_dst, const float* dout, int64_t lddo, const float* out_pre,
+                          int64_t ldp, const float* stats, int heads, const int64_t* t_edge, const int64_t* t_dst,
+                          const int64_t* t_item_begin, const int64_t* t_item_end, int64_t n_src_items,
+                          const int64_t* t_item_ptr, const int64_t* t_row, int64_t n_src_rows, float* dq, int64_t lddq,
+                          float* dkv, int64_t lddkv, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------- gathered head (finetune step) ---- */
 /* train_ddi_batch.py:285-288 computes sigmoid(model(...)) [L,N,N] and reads T (label, head, tail) entries of it.  These
  * entry points compute only those entries: score[t] = z_head[head[t]]^T w[label] z_tail[tail[t]].
@@ -256,6 +276,12 @@ int mdg_axpby(const float* a, const float* b, float* out, int64_t n, int64_t nb,
 
 /* out[i] = x[i] * scalar[0], scalar in device memory (scaling a stored gradient by the incoming scalar gradient). */
 int mdg_mul_device_scalar(const float* x, const float* scalar, float* out, int64_t n, void* stream);
+
+/* HGTConv skip gate (PyG 2.3.1 HGTConv.forward): out = s * o + (1 - s) * x with s = sigmoid(skip[0]) read from device
+ * memory; backward: d_o, d_x and rowdot[v] = s (1-s) sum_c dout (o - x) whose sum over rows is d skip. */
+int mdg_gated_residual(const float* o, const float* x, const float* skip, float* out, int64_t n, void* stream);
+int mdg_gated_residual_bwd(const float* dout, const float* o, const float* x, const float* skip, float* d_o, float* d_x,
+                           float* rowdot, int64_t rows, int64_t cols, void* stream);
 
 /* Inverted dropout y = x * keep / (1-p); keep is a counter-based hash of (seed, element index), so calling it again
  * with the same seed on dy is the backward pass (nn.Dropout of the transformer / MLPs / position encoder). */

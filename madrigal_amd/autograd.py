@@ -389,3 +389,80 @@ class _CsrAggregate(Function):
 
 def csr_aggregate(x, rowptr, col, w, tplan, with_self=False, coef_dev=None, coef_add=0.0, mean=False):
     return _CsrAggregate.apply(x, rowptr, col, w, tplan, with_self, coef_dev, coef_add, mean)
+
+
+class _HgtAttention(Function):
+    """Edge softmax + aggregation of EVERY destination node type of one HGTConv in one node of the tape, so that the
+    key / value gradient buffer (layout of the flat projection buffer) is allocated and zero-filled once."""
+
+    @staticmethod
+    def forward(ctx, kv, heads, plans, *qs):
+        from .graph_plans import hgt_reverse_plan
+        outs, stats = [], []
+        for q, pd in zip(qs, plans):
+            o, s = ops.hgt_attention_stats(q, kv, pd, heads)
+            outs.append(o)
+            stats.append(s)
+        ctx.heads, ctx.plans = heads, plans
+        ctx.revs = [hgt_reverse_plan(pd) for pd in plans]
+        ctx.n = len(qs)
+        ctx.save_for_backward(kv, *qs, *outs, *stats)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *douts):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        kv, qs, outs, stats = saved[0], saved[1:1 + n], saved[1 + n:1 + 2 * n], saved[1 + 2 * n:1 + 3 * n]
+        dkv = torch.zeros_like(kv)
+        dqs = []
+        for q, pd, rev, o, s, g in zip(qs, ctx.plans, ctx.revs, outs, stats, douts):
+            g = g if g.is_contiguous() else g.contiguous()
+            dqs.append(ops.hgt_attention_bwd(q, kv, pd, rev, ctx.heads, g, o, s, dkv))
+        return (dkv, None, None) + tuple(dqs)
+
+
+def hgt_attention_all(kv, heads, plans, qs):
+    """-> tuple of pre-activation attention outputs, one per (q, plan) pair."""
+    return _HgtAttention.apply(kv, heads, plans, *qs)
+
+
+class _Activation(Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        x = x if x.is_contiguous() else x.contiguous()
+        ctx.act = act
+        y = ops.activation_fwd(x, act)
+        ctx.save_for_backward(y if act == "relu" else x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (pre,) = ctx.saved_tensors
+        return ops.activation_bwd(dy if dy.is_contiguous() else dy.contiguous(), pre, ctx.act), None
+
+
+def activation(x, act):
+    return x if act in (None, "none") else _Activation.apply(x, act)
+
+
+class _GatedResidual(Function):
+    @staticmethod
+    def forward(ctx, o, x, skip):
+        o = o if o.is_contiguous() else o.contiguous()
+        x = x if x.is_contiguous() else x.contiguous()
+        ctx.save_for_backward(o, x, skip)
+        return ops.gated_residual(o, x, skip.detach())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        o, x, skip = ctx.saved_tensors
+        d_o, d_x, d_skip = ops.gated_residual_bwd(dout if dout.is_contiguous() else dout.contiguous(), o, x, skip.detach())
+        return d_o, d_x, d_skip.view(skip.shape)
+
+
+def gated_residual(o, x, skip):
+    return _GatedResidual.apply(o, x, skip)

@@ -106,6 +106,35 @@ __global__ __launch_bounds__(256) void mul_dev_scalar_kernel(const float* __rest
   if (i < n) out[i] = x[i] * s[0];
 }
 
+// ---- HGT skip gate: out = s * o + (1 - s) * x,  s = sigmoid(skip[0]) read on the device (no host sync per step) -------
+__global__ __launch_bounds__(256) void gated_residual_kernel(const float* __restrict__ o, const float* __restrict__ x, const float* __restrict__ skip,
+                                                             float* __restrict__ out, int64_t n) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float s = 1.0f / (1.0f + expf(-skip[0]));
+  out[i] = s * o[i] + (1.0f - s) * x[i];
+}
+
+// do = s dout, dx = (1-s) dout, rowdot[v] = s (1-s) sum_c dout[v,c] (o[v,c] - x[v,c])   (d skip = sum_v rowdot[v])
+__global__ __launch_bounds__(256) void gated_residual_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ o, const float* __restrict__ x,
+                                                                 const float* __restrict__ skip, float* __restrict__ d_o, float* __restrict__ d_x,
+                                                                 float* __restrict__ rowdot, int64_t rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (v >= rows) return;
+  const float s = 1.0f / (1.0f + expf(-skip[0]));
+  float acc = 0.f;
+  for (int c = lane; c < cols; c += 64) {
+    const int64_t i = v * cols + c;
+    const float g = dout[i];
+    d_o[i] = s * g;
+    d_x[i] = (1.0f - s) * g;
+    acc += g * (o[i] - x[i]);
+  }
+  acc = mdg_wave_sum(acc);
+  if (lane == 0) rowdot[v] = s * (1.0f - s) * acc;
+}
+
 // ---- dropout: y = x * keep / (1 - p), keep ~ Bernoulli(1-p) from a counter-based hash of (seed, element index);
 // the same (seed, index) reproduces the mask in the backward pass, so no mask tensor is stored. -------------------
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p,
@@ -444,5 +473,25 @@ extern "C" int mdg_mul_device_scalar(const float* x, const float* scalar, float*
   MDG_CHECK_ARG(x && scalar && out, "mdg_mul_device_scalar: null pointer");
   hipLaunchKernelGGL(mul_dev_scalar_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), x, scalar, out, n);
   MDG_CHECK_LAUNCH("mdg_mul_device_scalar");
+  return MDG_OK;
+}
+
+extern "C" int mdg_gated_residual(const float* o, const float* x, const float* skip, float* out, int64_t n, void* stream) {
+  MDG_CHECK_ARG(n >= 0, "mdg_gated_residual: negative size");
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(o && x && skip && out, "mdg_gated_residual: null pointer");
+  hipLaunchKernelGGL(gated_residual_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), o, x, skip, out, n);
+  MDG_CHECK_LAUNCH("mdg_gated_residual");
+  return MDG_OK;
+}
+
+extern "C" int mdg_gated_residual_bwd(const float* dout, const float* o, const float* x, const float* skip, float* d_o, float* d_x,
+                                      float* rowdot, int64_t rows, int64_t cols, void* stream) {
+  MDG_CHECK_ARG(rows >= 0 && cols > 0 && cols <= (1 << 20), "mdg_gated_residual_bwd: bad shape");
+  if (rows == 0) return MDG_OK;
+  MDG_CHECK_ARG(dout && o && x && skip && d_o && d_x && rowdot, "mdg_gated_residual_bwd: null pointer");
+  hipLaunchKernelGGL(gated_residual_bwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(rows, 4))), dim3(256), 0, static_cast<hipStream_t>(stream), dout, o, x,
+                     skip, d_o, d_x, rowdot, rows, static_cast<int>(cols));
+  MDG_CHECK_LAUNCH("mdg_gated_residual_bwd");
   return MDG_OK;
 }

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void hgt_attention_kernel(const HgtArgs p) {
 
 __global__ __launch_bounds__(256) void hgt_combine_kernel(const float* __restrict__ part_acc, const float* __restrict__ part_ml,
                                                           const int64_t* __restrict__ item_ptr, float* __restrict__ out, int64_t ldo,
-                                                          int64_t n_dst, int H, int apply_gelu) {
+                                                          int64_t n_dst, int H, int apply_gelu, float* __restrict__ stats) {
   const int sub = threadIdx.x & 31;
   const int64_t v = static_cast<int64_t>(blockIdx.x) * 8 + (threadIdx.x >> 5);
   if (v >= n_dst) return;
@@ -165,11 +165,125 @@ __global__ __launch_bounds__(256) void hgt_combine_kernel(const float* __restric
   }
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
   if (l > 0.f) o = acc / (l + 1e-16f);          // torch_geometric.utils.softmax: exp / (sum + 1e-16)
+  if (stats && sub % (32 / H) == 0) {            // kept for the backward pass: alpha_e = exp(a_e - m) / denom
+    stats[(v * H + h) * 2 + 0] = m;
+    stats[(v * H + h) * 2 + 1] = l + 1e-16f;
+  }
   if (apply_gelu) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) o[c] = mdg_gelu(o[c]);
   }
   *reinterpret_cast<f32x4*>(out + v * ldo + 4 * sub) = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the HGT edge attention.  With g = d out_i (before the GELU), pre_i = sum_e alpha_e v'_e (kept from the
+// forward pass) and delta[h] = g[h] . pre_i[h]  (= sum_e alpha_e dalpha_e):
+//     dalpha_e[h] = g[h] . v'_e[h],   da_e[h] = alpha_e[h] (dalpha_e[h] - delta[h])
+//     dq_i[h] = sum_e da_e[h] k'_e[h]           (destination-centric: same work items as the forward pass)
+//     dk'_r[h] = sum_{e: c_e = r} da_e[h] q_{i(e)}[h],   dv'_r[h] = sum_{e: c_e = r} alpha_e[h] g_{i(e)}[h]
+// The second pair is a sum over the edges LEAVING a key row: the edge kernel stores (alpha_e, da_e) per edge and head
+// and a second, source-centric kernel walks the reversed edge lists (work items of <= CHUNK edges, partials merged in
+// item order).  No atomics: bit-reproducible gradients.
+// ---------------------------------------------------------------------------------------------
+struct HgtBwdArgs {
+  const float* q; int64_t ldq;
+  const float* kv; int64_t ldkv;
+  const int64_t* col;
+  const int64_t* item_dst; const int64_t* item_begin; const int64_t* item_end;
+  int64_t n_items;
+  const float* g; int64_t ldg;          // [n_dst,128] gradient at the attention output (pre-activation)
+  const float* pre; int64_t ldp;        // [n_dst,128] forward output before the activation
+  const float* stats;                   // [n_dst,H,2] (max, denominator)
+  float* edge_alpha; float* edge_da;    // [nnz,H]
+  float* part_dq;                       // [n_items,128]
+  int H;
+};
+
+__global__ __launch_bounds__(256) void hgt_attention_bwd_edge_kernel(const HgtBwdArgs p) {
+  const int lane = threadIdx.x & 63, sub = lane & 31, half = lane >> 5;
+  const int64_t item = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (item >= p.n_items) return;
+  const int lph = 32 / p.H;
+  const int h = sub / lph;
+  const int64_t dst = p.item_dst[item], e0 = p.item_begin[item], e1 = p.item_end[item];
+  const f32x4 q = *reinterpret_cast<const f32x4*>(p.q + dst * p.ldq + 4 * sub);
+  const f32x4 g = *reinterpret_cast<const f32x4*>(p.g + dst * p.ldg + 4 * sub);
+  const f32x4 pre = *reinterpret_cast<const f32x4*>(p.pre + dst * p.ldp + 4 * sub);
+  float delta = dot4(g, pre);
+  for (int o = lph >> 1; o > 0; o >>= 1) delta += __shfl_xor(delta, o, 64);
+  const float m = p.stats[(dst * p.H + h) * 2], inv = 1.0f / p.stats[(dst * p.H + h) * 2 + 1];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t e = e0 + half; e < e1; e += 2) {
+    const float* r = p.kv + p.col[e] * p.ldkv + 4 * sub;
+    const f32x4 k = *reinterpret_cast<const f32x4*>(r), v = *reinterpret_cast<const f32x4*>(r + 128);
+    float a = dot4(q, k), da = dot4(g, v);
+    for (int o = lph >> 1; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o, 64);
+      da += __shfl_xor(da, o, 64);
+    }
+    const float alpha = expf(a - m) * inv;
+    const float ds = alpha * (da - delta);
+    acc += ds * k;
+    if (sub % lph == 0) {
+      p.edge_alpha[e * p.H + h] = alpha;
+      p.edge_da[e * p.H + h] = ds;
+    }
+  }
+  f32x4 other;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) other[c] = __shfl_xor(acc[c], 32, 64);
+  if (half == 0) *reinterpret_cast<f32x4*>(p.part_dq + item * 128 + 4 * sub) = acc + other;
+}
+
+// out[v, 0:width] = sum of part[item, 0:width] over the items of row v, in item order; rows go to out + row_index[v]*ldo
+// (row_index null = v).  width = 128 (dq) or 256 (dk' | dv' = two consecutive kv rows).
+__global__ __launch_bounds__(256) void hgt_sum_items_kernel(const float* __restrict__ part, const int64_t* __restrict__ item_ptr,
+                                                            const int64_t* __restrict__ row_index, float* __restrict__ out, int64_t ldo,
+                                                            int64_t n_rows, int width) {
+  const int lpr = width / 4;                      // lanes per row: 32 or 64
+  const int sub = threadIdx.x % lpr;
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * (256 / lpr) + threadIdx.x / lpr;
+  if (v >= n_rows) return;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t it = item_ptr[v]; it < item_ptr[v + 1]; ++it) acc += *reinterpret_cast<const f32x4*>(part + it * width + 4 * sub);
+  const int64_t row = row_index ? row_index[v] : v;
+  *reinterpret_cast<f32x4*>(out + row * ldo + 4 * sub) = acc;
+}
+
+struct HgtSrcArgs {
+  const float* q; int64_t ldq;
+  const float* g; int64_t ldg;
+  const int64_t* t_edge; const int64_t* t_dst;     // reversed edge list (sorted by key row): forward edge id, destination
+  const int64_t* item_begin; const int64_t* item_end;
+  int64_t n_items;
+  const float* edge_alpha; const float* edge_da;
+  float* part;                                     // [n_items,256]: dk' | dv'
+  int H;
+};
+
+__global__ __launch_bounds__(256) void hgt_attention_bwd_src_kernel(const HgtSrcArgs p) {
+  const int lane = threadIdx.x & 63, sub = lane & 31, half = lane >> 5;
+  const int64_t item = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (item >= p.n_items) return;
+  const int h = sub / (32 / p.H);
+  f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t e = p.item_begin[item] + half; e < p.item_end[item]; e += 2) {
+    const int64_t eid = p.t_edge[e], d = p.t_dst[e];
+    const float da = p.edge_da[eid * p.H + h], al = p.edge_alpha[eid * p.H + h];
+    ak += da * *reinterpret_cast<const f32x4*>(p.q + d * p.ldq + 4 * sub);
+    av += al * *reinterpret_cast<const f32x4*>(p.g + d * p.ldg + 4 * sub);
+  }
+  f32x4 ok, ov;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    ok[c] = __shfl_xor(ak[c], 32, 64);
+    ov[c] = __shfl_xor(av[c], 32, 64);
+  }
+  if (half == 0) {
+    *reinterpret_cast<f32x4*>(p.part + item * 256 + 4 * sub) = ak + ok;
+    *reinterpret_cast<f32x4*>(p.part + item * 256 + 128 + 4 * sub) = av + ov;
+  }
 }
 
 template <int LPR>
@@ -207,10 +321,10 @@ extern "C" size_t mdg_hgt_attention_workspace_bytes(int64_t n_items, int heads) 
   return static_cast<size_t>(n_items) * (128 + 2 * static_cast<size_t>(heads)) * sizeof(float);
 }
 
-extern "C" int mdg_hgt_attention(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const int64_t* col,
-                                 const int64_t* item_dst, const int64_t* item_begin, const int64_t* item_end, int64_t n_items,
-                                 const int64_t* item_ptr, float* out, int64_t ldo, int64_t n_dst, int heads, int64_t F,
-                                 int apply_gelu, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int mdg_hgt_attention_stats(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const int64_t* col,
+                                       const int64_t* item_dst, const int64_t* item_begin, const int64_t* item_end, int64_t n_items,
+                                       const int64_t* item_ptr, float* out, int64_t ldo, int64_t n_dst, int heads, int64_t F,
+                                       int apply_gelu, float* stats, void* workspace, size_t workspace_bytes, void* stream) {
   MDG_CHECK_ARG(F == 128, "mdg_hgt_attention: hidden size must be 128 (got %lld)", (long long)F);
   MDG_CHECK_ARG(heads == 1 || heads == 2 || heads == 4 || heads == 8, "mdg_hgt_attention: heads must be 1, 2, 4 or 8 (got %d)", heads);
   MDG_CHECK_ARG(n_dst >= 0 && n_items >= 0, "mdg_hgt_attention: negative size");
@@ -231,7 +345,62 @@ extern "C" int mdg_hgt_attention(const float* q, int64_t ldq, const float* kv, i
     hipLaunchKernelGGL(hgt_attention_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_items, 4))), dim3(256), 0, st, a);
   }
   hipLaunchKernelGGL(hgt_combine_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_dst, 8))), dim3(256), 0, st, part_acc, part_ml, item_ptr,
-                     out, ldo, n_dst, heads, apply_gelu);
+                     out, ldo, n_dst, heads, apply_gelu, stats);
   MDG_CHECK_LAUNCH("mdg_hgt_attention");
+  return MDG_OK;
+}
+
+extern "C" int mdg_hgt_attention(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const int64_t* col,
+                                 const int64_t* item_dst, const int64_t* item_begin, const int64_t* item_end, int64_t n_items,
+                                 const int64_t* item_ptr, float* out, int64_t ldo, int64_t n_dst, int heads, int64_t F,
+                                 int apply_gelu, void* workspace, size_t workspace_bytes, void* stream) {
+  return mdg_hgt_attention_stats(q, ldq, kv, ldkv, col, item_dst, item_begin, item_end, n_items, item_ptr, out, ldo, n_dst, heads, F,
+                                 apply_gelu, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t mdg_hgt_attention_bwd_workspace_bytes(int64_t nnz, int64_t n_items, int64_t n_src_items, int heads) {
+  if (nnz <= 0) return 0;
+  return (static_cast<size_t>(nnz) * 2 * heads + static_cast<size_t>(n_items) * 128 + static_cast<size_t>(n_src_items) * 256) * sizeof(float);
+}
+
+extern "C" int mdg_hgt_attention_bwd(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const int64_t* col, int64_t nnz,
+                                     const int64_t* item_dst, const int64_t* item_begin, const int64_t* item_end, int64_t n_items,
+                                     const int64_t* item_ptr, int64_t n_dst, const float* dout, int64_t lddo, const float* out_pre,
+                                     int64_t ldp, const float* stats, int heads, const int64_t* t_edge, const int64_t* t_dst,
+                                     const int64_t* t_item_begin, const int64_t* t_item_end, int64_t n_src_items,
+                                     const int64_t* t_item_ptr, const int64_t* t_row, int64_t n_src_rows, float* dq, int64_t lddq,
+                                     float* dkv, int64_t lddkv, void* workspace, size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(heads == 1 || heads == 2 || heads == 4 || heads == 8, "mdg_hgt_attention_bwd: heads must be 1, 2, 4 or 8 (got %d)", heads);
+  MDG_CHECK_ARG(n_dst >= 0 && n_items >= 0 && nnz >= 0 && n_src_items >= 0 && n_src_rows >= 0, "mdg_hgt_attention_bwd: negative size");
+  if (n_dst == 0) return MDG_OK;
+  MDG_CHECK_ARG(q && dq && item_ptr && dout && out_pre && stats, "mdg_hgt_attention_bwd: null pointer");
+  MDG_CHECK_ARG(ldq % 4 == 0 && lddo % 4 == 0 && ldp % 4 == 0 && lddq % 4 == 0 && ldq >= 128 && lddo >= 128 && ldp >= 128 && lddq >= 128 &&
+                mdg_aligned16(q) && mdg_aligned16(dout) && mdg_aligned16(out_pre) && mdg_aligned16(dq), "mdg_hgt_attention_bwd: bad strides / alignment");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t need = mdg_hgt_attention_bwd_workspace_bytes(nnz, n_items, n_src_items, heads);
+  if (need && (!workspace || workspace_bytes < need || !mdg_aligned16(workspace))) {
+    mdg_set_error("mdg_hgt_attention_bwd: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return MDG_EWORKSPACE;
+  }
+  float* part_dq = static_cast<float*>(workspace);
+  float* part_src = part_dq ? part_dq + n_items * 128 : nullptr;
+  float* edge_alpha = part_src ? part_src + n_src_items * 256 : nullptr;
+  float* edge_da = edge_alpha ? edge_alpha + nnz * heads : nullptr;
+  if (n_items > 0) {
+    MDG_CHECK_ARG(kv && col && item_dst && item_begin && item_end && dkv && t_edge && t_dst && t_item_begin && t_item_end && t_item_ptr && t_row,
+                  "mdg_hgt_attention_bwd: null plan pointer");
+    MDG_CHECK_ARG(ldkv % 4 == 0 && lddkv % 4 == 0 && ldkv >= 128 && lddkv >= 128 && mdg_aligned16(kv) && mdg_aligned16(dkv), "mdg_hgt_attention_bwd: bad kv strides");
+    HgtBwdArgs a{q, ldq, kv, ldkv, col, item_dst, item_begin, item_end, n_items, dout, lddo, out_pre, ldp, stats, edge_alpha, edge_da, part_dq, heads};
+    hipLaunchKernelGGL(hgt_attention_bwd_edge_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_items, 4))), dim3(256), 0, st, a);
+  }
+  hipLaunchKernelGGL(hgt_sum_items_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_dst, 8))), dim3(256), 0, st, part_dq, item_ptr, nullptr, dq, lddq, n_dst, 128);
+  if (n_src_items > 0) {
+    HgtSrcArgs s{q, ldq, dout, lddo, t_edge, t_dst, t_item_begin, t_item_end, n_src_items, edge_alpha, edge_da, part_src, heads};
+    hipLaunchKernelGGL(hgt_attention_bwd_src_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_src_items, 4))), dim3(256), 0, st, s);
+    // dk' and dv' of key row r are rows r and r+1 of dkv (ldkv == 128 layout): written as one 256-float row
+    hipLaunchKernelGGL(hgt_sum_items_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_src_rows, 4))), dim3(256), 0, st, part_src, t_item_ptr, t_row, dkv,
+                       lddkv, n_src_rows, 256);
+  }
+  MDG_CHECK_LAUNCH("mdg_hgt_attention_bwd");
   return MDG_OK;
 }

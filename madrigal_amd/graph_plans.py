@@ -59,6 +59,35 @@ def molecule_plan(graph) -> dict:
     return plan
 
 
+def hgt_reverse_plan(pd: dict) -> dict:
+    """Reversed edge lists of one destination type's HGT plan (backward pass of mdg_hgt_attention): the edges stably
+    sorted by key row, cut into work items of <= HGT_CHUNK edges.  Cached inside the plan."""
+    if "rev" in pd:
+        return pd["rev"]
+    col, rowptr = pd["col"], pd["rowptr"]
+    dev = col.device
+    n_dst = int(rowptr.numel()) - 1
+    deg = rowptr[1:] - rowptr[:-1]
+    dst = torch.repeat_interleave(torch.arange(n_dst, device=dev), deg)
+    order = torch.argsort(col, stable=True)
+    cs = col[order]
+    rows, cnt = torch.unique_consecutive(cs, return_counts=True)
+    n_rows = int(rows.numel())
+    rptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(cnt, 0, out=rptr[1:])
+    chunks = (cnt + HGT_CHUNK - 1) // HGT_CHUNK
+    item_ptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(chunks, 0, out=item_ptr[1:])
+    item_row = torch.repeat_interleave(torch.arange(n_rows, device=dev), chunks)
+    k = torch.arange(item_row.numel(), device=dev) - item_ptr[item_row]
+    begin = rptr[item_row] + k * HGT_CHUNK
+    end = torch.minimum(begin + HGT_CHUNK, rptr[item_row + 1])
+    pd["rev"] = {"t_edge": order.contiguous(), "t_dst": dst[order].contiguous(), "item_begin": begin.contiguous(),
+                 "item_end": end.contiguous(), "item_ptr": item_ptr, "rows": rows.contiguous(), "n_rows": n_rows,
+                 "n_items": int(item_row.numel())}
+    return pd["rev"]
+
+
 def transposed_csr(rowptr: torch.Tensor, col, w, n_src: int, mean: bool = False) -> dict:
     """CSR of the reversed edges of (rowptr, col, w): the plan of the backward pass of mdg_csr_aggregate
     (d x[u] = sum over edges u -> v of w_e * d out[v]).  ``col`` None = row v owns source rows rowptr[v]..rowptr[v+1];

@@ -464,10 +464,50 @@ class HGTConv(nn.Module):
             return torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous()
         return _cached(self, ("proj", t, tuple(rels)), srcs, build)
 
+    def _forward_train(self, x_dict, edge_index_dict, needed_types=None):
+        """Differentiated pass.  Every product over node rows goes through the autograd nodes: the K|Q|V projection, then
+        one [n,128]x[128,128] product per outgoing relation for k' and v' (the block-diagonal relation matrices are
+        assembled from the parameters, p_rel/sqrt(D) folded into the key blocks), edge attention for all destination
+        types in one tape node, GELU, output projection and the sigmoid(skip) gate."""
+        F, H = self.out_channels, self.heads
+        R, D = len(self.edge_types), self.out_channels // self.heads
+        dev = next(iter(x_dict.values())).device
+        sizes = {t: int(x.shape[0]) for t, x in x_dict.items()}
+        want = set(self.dst_node_types if needed_types is None else needed_types)
+        plan = self._plan(edge_index_dict, sizes, dev, want)
+        proj, pieces = {}, []
+        for t, x in x_dict.items():
+            n_t, wd = sizes[t], plan["width"][t]
+            if (plan["nrel"][t] == 0 and t not in want) or n_t == 0:
+                pieces.append(torch.zeros(n_t * wd, device=dev))
+                continue
+            lin = self.kqv_lin.lins[t]
+            kqv = _linT(x.float(), lin.weight, lin.bias)
+            k, q, v = kqv[:, 0:F], kqv[:, F:2 * F], kqv[:, 2 * F:3 * F]
+            cols = [q]
+            for et in [e for e in plan["used"] if e[0] == t]:
+                idx = torch.arange(H, device=dev) * R + self.edge_types.index(et)
+                pr = self.p_rel["__".join(et)].view(H, 1, 1) / math.sqrt(D)
+                bk = torch.block_diag(*(self.k_rel.weight[idx] * pr).unbind(0)).t()       # parameter-space assembly
+                bv = torch.block_diag(*self.v_rel.weight[idx].unbind(0)).t()
+                cols += [_linT(k, bk), _linT(v, bv)]
+            proj[t] = torch.cat(cols, dim=1) if len(cols) > 1 else q.contiguous()
+            pieces.append(proj[t].reshape(-1))
+        kv = torch.cat(pieces).view(-1, 128)
+        dst_types = [t for t in self.node_types if t in self.dst_node_types and t in x_dict and t in want and sizes[t] > 0]
+        pres = ag.hgt_attention_all(kv, H, [plan["per_dst"][t] for t in dst_types], [proj[t][:, 0:F] for t in dst_types])
+        out = {}
+        for t, pre in zip(dst_types, pres):
+            lin = self.out_lin.lins[t]
+            o = _linT(ag.activation(pre, "gelu"), lin.weight, lin.bias)
+            out[t] = ag.gated_residual(o, x_dict[t].float(), self.skip[t]) if x_dict[t].shape[-1] == F else o
+        return out
+
     def forward(self, x_dict, edge_index_dict, needed_types=None):
         """``needed_types`` (extension): compute only these destination node types (the encoder reads
         ['drug'] of the LAST conv only, models.py:729); default = every destination type, as PyG does."""
-        _require_eval(self)
+        if _train_path(self) or ag.needs_grad(*x_dict.values()):
+            return self._forward_train(x_dict, edge_index_dict, needed_types)
         F = self.out_channels
         dev = next(iter(x_dict.values())).device
         sizes = {t: int(x.shape[0]) for t, x in x_dict.items()}
@@ -516,7 +556,9 @@ class HGT(nn.Module):
         for i in range(1, len(self.convs)):
             out = self.convs[i](out, edge_index_dict, needed_types=only_types if i == last else None)
             if i < last:
-                out = {t: torch.relu_(x) for t, x in out.items()}
+                out = {t: (ag.activation(x, "relu") if x.requires_grad else torch.relu_(x)) for t, x in out.items()}
+        if _train_path(self) or ag.needs_grad(*out.values()):
+            return {t: _linT(x, self.lin_dict[t].weight, self.lin_dict[t].bias) for t, x in out.items()}
         return {t: _lin(x, self.lin_dict[t].weight, self.lin_dict[t].bias) for t, x in out.items()}
 
 

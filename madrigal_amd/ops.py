@@ -782,3 +782,62 @@ def mul_device_scalar(x: torch.Tensor, scalar: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(x)
     check(lib().mdg_mul_device_scalar(_ptr(x), _ptr(s), _ptr(out), _c64(x.numel()), _stream(x)), "mdg_mul_device_scalar")
     return out
+
+
+# ------------------------------------------------------------------------------- HGT attention, training
+def hgt_attention_stats(q: torch.Tensor, kv: torch.Tensor, plan: dict, heads: int):
+    """mdg_hgt_attention without the activation -> (out_pre [n_dst,128], stats [n_dst,heads,2])."""
+    n_dst = q.shape[0]
+    if q.dim() != 2 or q.shape[1] != 128 or q.stride(1) != 1 or not q.is_cuda or q.dtype != torch.float32:
+        raise ValueError("q: expected fp32 cuda [n_dst,128] with unit inner stride")
+    out = torch.empty((n_dst, 128), dtype=torch.float32, device=q.device)
+    stats = torch.empty((n_dst, heads, 2), dtype=torch.float32, device=q.device)
+    n_items = int(plan["item_dst"].numel())
+    nbytes = lib().mdg_hgt_attention_workspace_bytes(_c64(n_items), _c(heads))
+    ws = _workspace(nbytes, q.device)
+    check(lib().mdg_hgt_attention_stats(_ptr(q), _c64(q.stride(0)), _ptr(kv), _c64(0 if kv is None else kv.stride(0)), _ptr(plan["col"]),
+                                        _ptr(plan["item_dst"]), _ptr(plan["item_begin"]), _ptr(plan["item_end"]), _c64(n_items),
+                                        _ptr(plan["item_ptr"]), _ptr(out), _c64(128), _c64(n_dst), _c(heads), _c64(128), _c(0),
+                                        _ptr(stats), _ptr(ws), ctypes.c_size_t(nbytes), _stream(q)), "mdg_hgt_attention_stats")
+    return out, stats
+
+
+def hgt_attention_bwd(q: torch.Tensor, kv: torch.Tensor, plan: dict, rev: dict, heads: int, dout: torch.Tensor, out_pre: torch.Tensor,
+                      stats: torch.Tensor, dkv: torch.Tensor) -> torch.Tensor:
+    """-> dq [n_dst,128]; writes this destination type's key / value gradient rows into ``dkv`` (layout of ``kv``)."""
+    n_dst = q.shape[0]
+    dout = _f32_cuda(dout, "dout", 2)
+    if kv.dim() != 2 or kv.shape[1] != 128 or not kv.is_contiguous() or dkv.shape != kv.shape or not dkv.is_contiguous():
+        raise ValueError("hgt_attention_bwd: kv / dkv must be contiguous [rows,128] (value rows follow key rows)")
+    dq = torch.empty((n_dst, 128), dtype=torch.float32, device=q.device)
+    nnz, n_items = int(plan["col"].numel()), int(plan["item_dst"].numel())
+    nbytes = lib().mdg_hgt_attention_bwd_workspace_bytes(_c64(nnz), _c64(n_items), _c64(rev["n_items"]), _c(heads))
+    ws = _workspace(nbytes, q.device)
+    check(lib().mdg_hgt_attention_bwd(_ptr(q), _c64(q.stride(0)), _ptr(kv), _c64(128), _ptr(plan["col"]), _c64(nnz), _ptr(plan["item_dst"]),
+                                      _ptr(plan["item_begin"]), _ptr(plan["item_end"]), _c64(n_items), _ptr(plan["item_ptr"]), _c64(n_dst),
+                                      _ptr(dout), _c64(dout.stride(0)), _ptr(out_pre), _c64(out_pre.stride(0)), _ptr(stats), _c(heads),
+                                      _ptr(rev["t_edge"]), _ptr(rev["t_dst"]), _ptr(rev["item_begin"]), _ptr(rev["item_end"]),
+                                      _c64(rev["n_items"]), _ptr(rev["item_ptr"]), _ptr(rev["rows"]), _c64(rev["n_rows"]), _ptr(dq), _c64(128),
+                                      _ptr(dkv), _c64(128), _ptr(ws), ctypes.c_size_t(nbytes), _stream(q)), "mdg_hgt_attention_bwd")
+    return dq
+
+
+def gated_residual(o: torch.Tensor, x: torch.Tensor, skip: torch.Tensor) -> torch.Tensor:
+    """sigmoid(skip) * o + (1 - sigmoid(skip)) * x, the gate read on the device."""
+    o, x = _f32_cuda(o, "o", 2), _f32_cuda(x, "x", 2)
+    if o.shape != x.shape:
+        raise ValueError("gated_residual: shape mismatch")
+    out = torch.empty_like(o)
+    check(lib().mdg_gated_residual(_ptr(o), _ptr(x), _ptr(_f32_cuda(skip.reshape(1), "skip", 1)), _ptr(out), _c64(o.numel()), _stream(o)),
+          "mdg_gated_residual")
+    return out
+
+
+def gated_residual_bwd(dout: torch.Tensor, o: torch.Tensor, x: torch.Tensor, skip: torch.Tensor):
+    """-> (d_o, d_x, d_skip [1])."""
+    dout, o, x = _f32_cuda(dout, "dout", 2), _f32_cuda(o, "o", 2), _f32_cuda(x, "x", 2)
+    d_o, d_x = torch.empty_like(o), torch.empty_like(o)
+    rowdot = torch.empty(o.shape[0], dtype=torch.float32, device=o.device)
+    check(lib().mdg_gated_residual_bwd(_ptr(dout), _ptr(o), _ptr(x), _ptr(_f32_cuda(skip.reshape(1), "skip", 1)), _ptr(d_o), _ptr(d_x),
+                                       _ptr(rowdot), _c64(o.shape[0]), _c64(o.shape[1]), _stream(o)), "mdg_gated_residual_bwd")
+    return d_o, d_x, colsum(rowdot.view(-1, 1))

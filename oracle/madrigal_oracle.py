@@ -399,15 +399,17 @@ def hgt_conv_forward(p: Params, x_dict: Dict[str, Tensor], edge_index_dict, node
             logit_parts.append(a)
             val_parts.append(vp[ei[0]])
             dst_parts.append(ei[1])
-        agg = torch.zeros(n_t, H, D)
+        agg = torch.zeros(n_t, H, D, dtype=x_dict[t].dtype)
         if logit_parts:
             a = torch.cat(logit_parts)
             v = torch.cat(val_parts)
             d = torch.cat(dst_parts)
-            amax = torch.full((n_t, H), float("-inf")).scatter_reduce(0, d.view(-1, 1).expand(-1, H), a,
-                                                                       reduce="amax", include_self=True)
+            # the shift by the row maximum is gradient-neutral: taken from detached logits (dtype follows the inputs so
+            # that the float64 autograd reference of the training tests runs through the same lines)
+            amax = torch.full((n_t, H), float("-inf"), dtype=a.dtype).scatter_reduce(0, d.view(-1, 1).expand(-1, H), a.detach(),
+                                                                                      reduce="amax", include_self=True)
             e = torch.exp(a - amax[d])
-            den = torch.zeros(n_t, H).index_add_(0, d, e)
+            den = torch.zeros(n_t, H, dtype=a.dtype).index_add_(0, d, e)
             alpha = e / (den[d] + 1e-16)      # torch_geometric.utils.softmax adds 1e-16
             agg = agg.index_add_(0, d, v * alpha.unsqueeze(-1))
         o = linear(_act("gelu", agg.reshape(n_t, F)), p[f"out_lin.lins.{t}.weight"], p[f"out_lin.lins.{t}.bias"])
