@@ -256,6 +256,15 @@ int mdg_bce_logits(const float* score, const float* target, float* term, float* 
 /* Backward of mdg_symmetrize: dw_original = triu(dw_sym) + triu(dw_sym^T, 1). */
 int mdg_symmetrize_bwd(const float* dw_sym, float* dw_original, int64_t n_labels, int64_t D, void* stream);
 
+/* ------------------------------------------------------- optimizer ---- */
+/* torch.optim.AdamW semantics (madrigal/utils.py:600-613) for every parameter tensor in one launch.  The tensors are cut
+ * into chunks of mdg_adamw_chunk_elems() elements: chunk_ptrs [n_chunks,4] = device addresses of the chunk inside
+ * (param, grad, exp_avg, exp_avg_sq), chunk_lens [n_chunks], chunk_tensor [n_chunks] = row of hyper [n_tensors,8] =
+ * {lr, beta1, beta2, eps, weight_decay, 1/(1-beta1^t), 1/sqrt(1-beta2^t), 0}.  All tables live in device memory. */
+int mdg_adamw_chunk_elems(void);
+int mdg_adamw_multi(const int64_t* chunk_ptrs, const int32_t* chunk_lens, const int32_t* chunk_tensor, const float* hyper,
+                    int64_t n_chunks, void* stream);
+
 /* ------------------------------------------------------- backward-pass building blocks ---- */
 /* (the finetune step of train_ddi_batch.py:285-354: loss.backward() through the modules above) */
 
@@ -332,7 +341,7 @@ int mdg_assemble_tokens_bwd(const float* dseq, const float* str_emb, const float
 int mdg_l2_normalize_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dx, int64_t lddx, int64_t rows,
                          int64_t d, void* stream);
 
-/* LayerNorm backward (statistics recomputed from x): dx, dgamma, dbeta.  d <= 1024. */
+/* LayerNorm backward (statistics recomputed from x): dx, dgamma, dbeta.  d <= 2048. */
 size_t mdg_layernorm_bwd_workspace_bytes(int64_t rows, int64_t d);
 int mdg_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, float* dx, int64_t lddx,
                       float* dgamma, float* dbeta, int64_t rows, int64_t d, float eps, void* workspace, size_t workspace_bytes,

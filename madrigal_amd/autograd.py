@@ -466,3 +466,28 @@ class _GatedResidual(Function):
 
 def gated_residual(o, x, skip):
     return _GatedResidual.apply(o, x, skip)
+
+
+class _GatherRows(Function):
+    """table[idx] with repeated indices (embedding lookup).  torch's own backward scatters with atomics (run-to-run
+    different low bits); here the gradient rows are summed per table row in index order by mdg_csr_aggregate."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        ctx.save_for_backward(idx)
+        ctx.n_rows = table.shape[0]
+        return table.index_select(0, idx)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        order = torch.argsort(idx, stable=True)
+        rowptr = torch.zeros(ctx.n_rows + 1, dtype=torch.int64, device=idx.device)
+        torch.cumsum(torch.bincount(idx, minlength=ctx.n_rows), 0, out=rowptr[1:])
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        return ops.csr_aggregate(dout, rowptr, order.contiguous())[:, :dout.shape[1]], None
+
+
+def gather_rows(table, idx):
+    return _GatherRows.apply(table, idx)

@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 // ---- LayerNorm backward: one wave per row, 64 rows per block; per-block partial dgamma / dbeta -------------------
-constexpr int LN_MAXJ = 16;     // d <= 1024
+constexpr int LN_DMAX = 2048;    // 64 lanes x LN_MAXJ columns; instantiated for d <= 128 / 512 / 2048
+template <int LN_MAXJ>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
                                                             const float* __restrict__ gamma, float* __restrict__ dx, int64_t lddx,
                                                             float* __restrict__ part, int64_t rows, int d, float eps) {
@@ -420,7 +421,7 @@ extern "C" size_t mdg_layernorm_bwd_workspace_bytes(int64_t rows, int64_t d) {
 extern "C" int mdg_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, float* dx, int64_t lddx,
                                  float* dgamma, float* dbeta, int64_t rows, int64_t d, float eps, void* workspace, size_t workspace_bytes,
                                  void* stream) {
-  MDG_CHECK_ARG(rows >= 0 && d > 0 && d <= 64 * LN_MAXJ, "mdg_layernorm_bwd: d must be in [1,1024]");
+  MDG_CHECK_ARG(rows >= 0 && d > 0 && d <= LN_DMAX, "mdg_layernorm_bwd: d must be in [1,%d]", LN_DMAX);
   MDG_CHECK_ARG(lddy >= d && ldx >= d && lddx >= d, "mdg_layernorm_bwd: row strides shorter than d");
   MDG_CHECK_ARG(gamma && dgamma && dbeta, "mdg_layernorm_bwd: null parameter pointers");
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -432,8 +433,14 @@ extern "C" int mdg_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
   }
   if (rows > 0) {
     MDG_CHECK_ARG(dy && x && dx, "mdg_layernorm_bwd: null pointer");
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), static_cast<size_t>(8 * d) * sizeof(float), st, dy, lddy, x,
-                       ldx, gamma, dx, lddx, static_cast<float*>(workspace), rows, static_cast<int>(d), eps);
+    const size_t lds = static_cast<size_t>(8 * d) * sizeof(float);
+    float* part = static_cast<float*>(workspace);
+    if (d <= 128)
+      hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(static_cast<unsigned>(nb)), dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, static_cast<int>(d), eps);
+    else if (d <= 512)
+      hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(static_cast<unsigned>(nb)), dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, static_cast<int>(d), eps);
+    else
+      hipLaunchKernelGGL(layernorm_bwd_kernel<32>, dim3(static_cast<unsigned>(nb)), dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, static_cast<int>(d), eps);
   }
   // dgamma = sum of partial rows [nb, 2d] -> first d columns, dbeta the next d
   hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(d, 256))), dim3(256), 0, st, static_cast<const float*>(workspace),

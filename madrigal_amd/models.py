@@ -645,8 +645,8 @@ class TxAdaptingComPert(nn.Module):
                                       "models.py:761): call predict(compute_reconstruction=False)")
         emb_sum = None
         for emb, idx in zip(self.covariates_embeddings, covariate_indices):
-            wt = emb.weight if train else emb.weight.detach()            # row gather: torch indexing carries the gradient
-            e = wt.index_select(0, idx.to(emb.weight.device))
+            idx = idx.to(emb.weight.device)
+            e = ag.gather_rows(emb.weight, idx) if train else emb.weight.detach().index_select(0, idx)
             emb_sum = e if emb_sum is None else (ag.add(emb_sum, e) if train else emb_sum + e)
         last_emb = e
         need_basal = return_latent_basal or emb_sum is None
@@ -1112,7 +1112,7 @@ class PositionEncodingSinusoidal(nn.Module):
             pe = full
         self.register_buffer('pe', pe)
 
-    def table(self):
+    def table(self, train: bool = False):
         return self.pe[0]
 
     def forward(self, x):
@@ -1129,8 +1129,8 @@ class PositionEncodingLearnable(nn.Module):
         self.max_len = max_len
         self.pe = nn.Parameter(torch.randn(1, max_len, d_model))
 
-    def table(self):
-        return self.pe.detach()[0]
+    def table(self, train: bool = False):
+        return self.pe[0] if train else self.pe.detach()[0]
 
     def forward(self, x):
         _require_eval(self)
@@ -1283,7 +1283,8 @@ class NovelDDIEncoder(nn.Module):
         return full
 
     def encode(self, batch_drugs, batch_masks, batch_mols, batch_kg, batch_cv, batch_tx_dict, raw_encoder_output=False, **kwargs):
-        _require_eval(self)
+        train = _train_path(self)
+        norm = ag.l2_normalize if train else ops.l2_normalize
         dev = batch_cv.device
         n, Dm = batch_drugs.shape[0], self.embed_dim
         compact = (not raw_encoder_output and self.live_tokens_only and self.fusion in ('transformer', 'transformer_uni_proj')
@@ -1302,7 +1303,8 @@ class NovelDDIEncoder(nn.Module):
             table[kg_map] = kg_valid
             return table[batch_drugs]
         main = torch.cuda.current_stream(dev)
-        if self.overlap_kg:
+        overlap = self.overlap_kg and not train              # one stream under autograd: the tape replays in launch order
+        if overlap:
             if self._kg_stream is None or self._kg_stream.device != dev:
                 self._kg_stream = torch.cuda.Stream(device=dev)
             self._kg_stream.wait_stream(main)
@@ -1310,9 +1312,11 @@ class NovelDDIEncoder(nn.Module):
                 kg_out = run_kg()
         str_out = self.str_encoder(batch_mols, batch_mols.node_feature.float())["graph_feature"]
         cv_out = self.cv_encoder(batch_cv)
-        # tx embeddings of absent cell lines are masked tokens: the live-token path never reads them
-        tx_out = self._encode_tx(batch_tx_dict, n, dev, present_rows=self._mask_plan(batch_masks, dev, compact)["tx_rows"] if compact else None)
-        if self.overlap_kg:
+        # tx embeddings of absent cell lines are masked tokens: the live-token path never reads them.  In training mode
+        # every row goes through the tx encoder, as in the reference: its BatchNorm batch statistics include them.
+        skip_absent = compact and not train
+        tx_out = self._encode_tx(batch_tx_dict, n, dev, present_rows=self._mask_plan(batch_masks, dev, compact)["tx_rows"] if skip_absent else None)
+        if overlap:
             main.wait_stream(self._kg_stream)
             kg_out.record_stream(main)
         else:
@@ -1321,11 +1325,13 @@ class NovelDDIEncoder(nn.Module):
             all_embeds = torch.stack([str_out, kg_out, cv_out] + list(tx_out.split(n)), dim=1)
             uni = all_embeds[~batch_masks]
             if self.normalize:
-                uni = ops.l2_normalize(uni)
+                uni = norm(uni)
             return self.uni_projector(uni)
         if self.adapt_before_fusion:
             str_out, kg_out, cv_out, tx_out = (self.uni_projector(t) for t in (str_out, kg_out, cv_out, tx_out))
         if self.fusion in ('mean', 'add'):
+            if train:
+                raise NotImplementedError(f"fusion={self.fusion!r} is not differentiated on the HIP path (shipped configs fuse with the transformer)")
             all_embeds = torch.stack([str_out, kg_out, cv_out] + list(tx_out.split(n)), dim=1)
             if self.normalize:
                 all_embeds = ops.l2_normalize(all_embeds)
@@ -1340,6 +1346,17 @@ class NovelDDIEncoder(nn.Module):
                         pe=self.pos_encoder.table(), rows=rows, normalize=self.normalize)
         if nf == 0:
             z_f = torch.zeros(0, Dm, device=dev)
+        elif train:
+            s_, k_, c_, t_ = str_out, kg_out, cv_out, tx_out
+            if rows is not None:                         # only multi-modal drugs enter the transformer (models.py:781-790)
+                s_, k_, c_ = (v.index_select(0, rows) for v in (s_, k_, c_))
+                t_ = t_.view(len(CELL_LINES), n, Dm).index_select(1, rows).reshape(-1, Dm)
+            plan = mp["live"] if compact else None
+            tokens = ag.assemble_tokens(s_, k_, c_, t_, bottleneck=self.tx_bottleneck_tokens if nb > 0 else None,
+                                        cls=self.cls if has_cls else None, pe=self.pos_encoder.table(train=True),
+                                        normalize=self.normalize, token_index=None if plan is None else plan["token_index"])
+            tokens = ag.dropout(tokens, self.pos_encoder.dropout.p, self.pos_encoder.dropout.training)
+            z_f = self.transformer.forward_tokens(tokens, plan) if compact else self.transformer(tokens, fusion_mask=mp["kpm"], src_mask=mp["src"])
         elif compact:
             plan = mp["live"]
             tokens = ops.assemble_tokens(str_out, kg_out, cv_out, tx_out, token_index=plan["token_index"], **tok_args)
@@ -1355,7 +1372,7 @@ class NovelDDIEncoder(nn.Module):
             all_embeds = torch.stack([str_out, kg_out, cv_out] + list(tx_out.split(n)), dim=1)
             uni = all_embeds[uni_rows, mp["uni_col"]]
             if self.normalize:
-                uni = ops.l2_normalize(uni)
+                uni = norm(uni)
             z[uni_rows] = self.uni_fuser(uni)
         return z
 
@@ -1380,13 +1397,28 @@ class NovelDDIMultilabel(nn.Module):
 
     def forward(self, batch_head, batch_tail, batch_head_mod_masks, batch_tail_mod_masks, batch_kg, label_range=None,
                 single_drug=False, **kwargs):
+        z_head, z_tail = self.embed(batch_head, batch_tail, batch_head_mod_masks, batch_tail_mod_masks, batch_kg, **kwargs)
+        return self.decoder(z_head, z_tail, label_range)
+
+    def embed(self, batch_head, batch_tail, batch_head_mod_masks, batch_tail_mod_masks, batch_kg, **kwargs):
+        """Head- and tail-side embeddings exactly as ``forward`` feeds them to the decoder (models.py:940-951).  In
+        training mode the two sides are encoded separately even when they are the same batch (independent dropout
+        masks / one BatchNorm update per side, as the reference does)."""
         def enc(b, m):
             return self.encoder(b['drugs'], m, b['strs'], batch_kg, b['cv'], b['tx'], **kwargs)
         z_head = enc(batch_head, batch_head_mod_masks)
-        same = self.reuse_identical_sides and batch_head is batch_tail and (
-            batch_head_mod_masks is batch_tail_mod_masks or torch.equal(batch_head_mod_masks, batch_tail_mod_masks))
+        same = (self.reuse_identical_sides and not self.training and batch_head is batch_tail and
+                (batch_head_mod_masks is batch_tail_mod_masks or torch.equal(batch_head_mod_masks, batch_tail_mod_masks)))
         z_tail = z_head if same else enc(batch_tail, batch_tail_mod_masks)
         if self.normalize:
-            z_head = ops.l2_normalize(z_head)
-            z_tail = z_head if same else ops.l2_normalize(z_tail)
-        return self.decoder(z_head, z_tail, label_range)
+            norm = ag.l2_normalize if ag.needs_grad(z_head, z_tail) else ops.l2_normalize
+            z_head = norm(z_head)
+            z_tail = z_head if same else norm(z_tail)
+        return z_head, z_tail
+
+    def score_triples(self, batch_head, batch_tail, batch_head_mod_masks, batch_tail_mod_masks, batch_kg, plan: dict, **kwargs):
+        """Extension for the finetune step: raw logits of the plan's (label, head, tail) triples only, in the ORIGINAL
+        order of the triples the plan was built from (``ops.triple_plan``) — the entries train_ddi_batch.py:285-286
+        gathers from the dense [L,N,N] result — differentiable end to end on the HIP path."""
+        z_head, z_tail = self.embed(batch_head, batch_tail, batch_head_mod_masks, batch_tail_mod_masks, batch_kg, **kwargs)
+        return self.decoder.score_triples(z_head, z_tail, plan).index_select(0, plan["inv_perm"])

@@ -1,0 +1,134 @@
+"""AdamW on the HIP path + the reference's parameter grouping (madrigal/utils.py:446-613).
+
+``AdamW`` is a ``torch.optim.Optimizer`` subclass (param_groups, ``state_dict`` layout of ``torch.optim.AdamW``:
+``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter, so LR schedulers and checkpoints interoperate); ``step()`` updates
+every parameter in ONE kernel launch (mdg_adamw_multi) instead of torch's per-tensor / foreach arithmetic.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, Iterable, List
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ._lib import check, lib
+
+
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False):
+        if amsgrad:
+            raise NotImplementedError("amsgrad is not used by the reference")
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
+        self._chunk = int(lib().mdg_adamw_chunk_elems())
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        by_dev: Dict[torch.device, list] = {}
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse or p.dtype != torch.float32 or not p.is_cuda:
+                    raise RuntimeError("madrigal_amd.optim.AdamW: dense fp32 parameters on the GPU only")
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                k = float(st["step"])
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if not p.is_contiguous():
+                    raise RuntimeError("madrigal_amd.optim.AdamW: parameters must be contiguous")
+                hyper = (group["lr"], b1, b2, group["eps"], group["weight_decay"], 1.0 / (1.0 - b1 ** k), 1.0 / math.sqrt(1.0 - b2 ** k), 0.0)
+                by_dev.setdefault(p.device, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], hyper))
+        for dev, items in by_dev.items():
+            ptrs, lens, owner, hyp = [], [], [], []
+            for ti, (p, g, m, v, h) in enumerate(items):
+                hyp.append(h)
+                n = p.numel()
+                for off in range(0, n, self._chunk):
+                    b = off * 4
+                    ptrs.append((p.data_ptr() + b, g.data_ptr() + b, m.data_ptr() + b, v.data_ptr() + b))
+                    lens.append(min(self._chunk, n - off))
+                    owner.append(ti)
+            if not ptrs:
+                continue
+            # one small pinned upload per table; the arrays stay referenced until the launch is enqueued
+            t_ptr = torch.from_numpy(np.asarray(ptrs, dtype=np.int64)).to(dev, non_blocking=False)
+            t_len = torch.from_numpy(np.asarray(lens, dtype=np.int32)).to(dev)
+            t_own = torch.from_numpy(np.asarray(owner, dtype=np.int32)).to(dev)
+            t_hyp = torch.from_numpy(np.asarray(hyp, dtype=np.float32)).to(dev)
+            with torch.cuda.device(dev):
+                check(lib().mdg_adamw_multi(ctypes.c_void_p(t_ptr.data_ptr()), ctypes.c_void_p(t_len.data_ptr()),
+                                            ctypes.c_void_p(t_own.data_ptr()), ctypes.c_void_p(t_hyp.data_ptr()),
+                                            ctypes.c_int64(len(lens)), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                      "mdg_adamw_multi")
+            for t in (t_ptr, t_len, t_own, t_hyp):
+                t.record_stream(torch.cuda.current_stream(dev))
+        return loss
+
+
+def parameter_names_outside(model: nn.Module, forbidden: tuple, prefix: str = "") -> List[str]:
+    """Names of the parameters that do not live inside a module of a ``forbidden`` type (the reference's
+    get_parameter_names, madrigal/utils.py:446-460, including its exclusion of the encoder's own cls / bottleneck
+    tokens from the module-level parameters)."""
+    out = []
+    for name, child in model.named_children():
+        if isinstance(child, forbidden):
+            continue
+        out += parameter_names_outside(child, forbidden, f"{prefix}{name}.")
+    out += [prefix + n for n in model._parameters.keys() if "cls" not in n and "bottleneck_tokens" not in n]
+    return out
+
+
+def create_optimizer(model: nn.Module, hparams: dict) -> AdamW:
+    """madrigal/utils.py:463-613: one (no-decay, decay) pair of parameter groups per model part with its own learning
+    rate — structure encoder, KG encoder, cv encoder(s), tx encoder(s), fusion (+ position encoding, projectors and the
+    learned tokens), decoder.  A parameter decays when it is outside every LayerNorm and is not a bias."""
+    from . import models as M
+    if hparams.get("optimizer", "adamw") != "adamw":
+        raise NotImplementedError("only AdamW runs on the HIP path (the reference's default, parse_args.py:135)")
+    decay = {n for n in parameter_names_outside(model, (nn.LayerNorm,)) if "bias" not in n}
+    named = dict(model.named_parameters())
+
+    def owner(name: str) -> str:
+        parts = name.split(".")
+        mod = model
+        kind = "fusion"                                   # module-level parameters ([CLS], bottleneck tokens) and glue
+        for part in parts[:-1]:
+            mod = getattr(mod, part) if not part.isdigit() else mod[int(part)]
+            if isinstance(mod, M.GraphIsomorphismNetwork):
+                return "str"
+            if isinstance(mod, (M.HGT, M.HAN, M.RGCN)):
+                return "kg"
+            if isinstance(mod, M.TxAdaptingComPert):
+                return "tx"
+            if isinstance(mod, M.MLPAdaptor):
+                return "fusion"
+            if isinstance(mod, M.MLPEncoder):
+                return "tx" if "tx_encoder" in name else "tab"
+            if isinstance(mod, (M.TransformerFusion, M.PositionEncodingSinusoidal, M.PositionEncodingLearnable)):
+                return "fusion"
+            if isinstance(mod, M.BilinearDDIScorer):
+                return "decoder"
+        return kind
+    lrs = {"str": hparams["structure_encoder_lr"], "kg": hparams["kg_encoder_lr"], "tab": hparams["perturb_encoders_lr"],
+           "tx": hparams["perturb_encoders_lr"], "fusion": hparams["fusion_lr"], "decoder": hparams["decoder_lr"]}
+    buckets: Dict[tuple, list] = {}
+    for name, p in named.items():
+        kind = owner(name)
+        wd = hparams["wd"] if (kind == "decoder" or name in decay) else 0.0
+        buckets.setdefault((kind, wd), []).append(p)
+    groups = [{"params": ps, "weight_decay": wd, "lr": lrs[kind]} for (kind, wd), ps in buckets.items() if ps]
+    return AdamW(groups, betas=(hparams["beta1"], hparams["beta2"]), eps=hparams["eps"])
