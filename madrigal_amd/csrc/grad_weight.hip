@@ -1,0 +1,142 @@
+// Weight gradient of a dense block:  dW[n,k] = sum_m g[m,n] x[m,k]   (g = dL/dy [M,N], x = layer input [M,K]).
+// A "TN" product: both operands are row-major with the REDUCTION index m as their row, the output is small
+// (N, K <= a few thousand) and M is the number of token / node / atom rows (10^4 .. 10^6).  The forward GEMM kernel
+// would give one workgroup per 128x128 output tile a serial loop over all of M; here the m range is split over
+// grid.z so that every launch has >= ~1000 workgroups, each accumulating a 128x128 partial tile on the exact-fp32
+// matrix cores (v_mfma_f32_32x32x2_f32: two rows of m per instruction, lane half = row), operands read straight from
+// global memory (lane = consecutive column: 128-byte coalesced pieces of the two current rows; neighbouring tiles
+// re-read them through L2).  Partials are summed in split order by a second kernel: deterministic, no atomics.
+#include "mdg_common.h"
+
+namespace {
+
+struct GwArgs {
+  const float* g; int64_t ldg;
+  const float* x; int64_t ldx;
+  float* out;                 // [S, N, K] partials (S > 1) or dW itself (S == 1)
+  int64_t M, rows_per_split;
+  int N, K;
+};
+
+__global__ __launch_bounds__(256) void grad_weight_kernel(const GwArgs p) {
+  const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.y * 128 + (wave >> 1) * 64, k0 = blockIdx.x * 128 + (wave & 1) * 64;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.z) * p.rows_per_split;
+  const int64_t m1 = m0 + p.rows_per_split < p.M ? m0 + p.rows_per_split : p.M;
+  // clamp out-of-range columns to column 0 and zero their contribution
+  const int na = n0 + i, nb = n0 + 32 + i, ka = k0 + i, kb = k0 + 32 + i;
+  const float fa = na < p.N ? 1.f : 0.f, fb = nb < p.N ? 1.f : 0.f;
+  const float* ga = p.g + (na < p.N ? na : 0);
+  const float* gb = p.g + (nb < p.N ? nb : 0);
+  const float* xa = p.x + (ka < p.K ? ka : 0);
+  const float* xb = p.x + (kb < p.K ? kb : 0);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[r][c][v] = 0.f;
+
+  constexpr int U = 8;                                   // row pairs in flight
+  int64_t m = m0;
+  for (; m + 2 * U <= m1; m += 2 * U) {
+    float a0[U], a1[U], b0[U], b1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = m + 2 * u + half;
+      a0[u] = ga[r * p.ldg];
+      a1[u] = gb[r * p.ldg];
+      b0[u] = xa[r * p.ldx];
+      b1[u] = xb[r * p.ldx];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float va = a0[u] * fa, vb = a1[u] * fb;
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, b0[u], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, b1[u], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, b0[u], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, b1[u], acc[1][1], 0, 0, 0);
+    }
+  }
+  for (; m < m1; m += 2) {                                // tail: the odd last row meets a zero partner
+    const int64_t r = m + half;
+    const bool ok = r < m1;
+    const int64_t rr = ok ? r : m1 - 1;
+    const float s = ok ? 1.f : 0.f;
+    const float va = ga[rr * p.ldg] * fa * s, vb = gb[rr * p.ldg] * fb * s;
+    const float b0 = xa[rr * p.ldx], b1 = xb[rr * p.ldx];
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, b1, acc[1][1], 0, 0, 0);
+  }
+  // acc[r][c][v]: row n = n0 + 32r + (v&3) + 8(v>>2) + 4*half, column k = k0 + 32c + i
+  float* out = p.out + static_cast<int64_t>(blockIdx.z) * p.N * p.K;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int k = k0 + 32 * c + i;
+      if (k >= p.K) continue;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int n = n0 + 32 * r + (v & 3) + 8 * (v >> 2) + 4 * half;
+        if (n < p.N) out[static_cast<int64_t>(n) * p.K + k] = acc[r][c][v];
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_splits_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int splits) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += part[static_cast<int64_t>(k) * n + i];
+  out[i] = s;
+}
+
+int pick_splits(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = mdg_cdiv(N, 128) * mdg_cdiv(K, 128);
+  int64_t s = mdg_cdiv(1024, tiles);
+  const int64_t max_s = mdg_cdiv(M, 64);                  // at least 64 rows per split
+  if (s > max_s) s = max_s;
+  if (s > 4096) s = 4096;
+  return static_cast<int>(s < 1 ? 1 : s);
+}
+
+}  // namespace
+
+extern "C" size_t mdg_grad_weight_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int s = pick_splits(M, N, K);
+  return s == 1 ? 0 : static_cast<size_t>(s) * N * K * sizeof(float);
+}
+
+extern "C" int mdg_grad_weight(const float* g, int64_t ldg, const float* x, int64_t ldx, float* dw, int64_t M, int64_t N, int64_t K,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(M >= 0 && N > 0 && K > 0 && N <= (1 << 20) && K <= (1 << 20), "mdg_grad_weight: bad shape");
+  MDG_CHECK_ARG(dw, "mdg_grad_weight: null dw");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (M == 0) {
+    (void)hipMemsetAsync(dw, 0, static_cast<size_t>(N) * K * sizeof(float), st);
+    return MDG_OK;
+  }
+  MDG_CHECK_ARG(g && x && ldg >= N && ldx >= K, "mdg_grad_weight: null operand / short row stride");
+  const int splits = pick_splits(M, N, K);
+  const size_t need = mdg_grad_weight_workspace_bytes(M, N, K);
+  if (need && (!workspace || workspace_bytes < need)) {
+    mdg_set_error("mdg_grad_weight: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return MDG_EWORKSPACE;
+  }
+  int64_t rps = mdg_cdiv(M, splits);
+  rps += rps & 1;                                           // whole row pairs per split
+  GwArgs a{g, ldg, x, ldx, splits == 1 ? dw : static_cast<float*>(workspace), M, rps, static_cast<int>(N), static_cast<int>(K)};
+  const int64_t used = mdg_cdiv(M, rps);
+  hipLaunchKernelGGL(grad_weight_kernel, dim3(static_cast<unsigned>(mdg_cdiv(K, 128)), static_cast<unsigned>(mdg_cdiv(N, 128)), static_cast<unsigned>(used)),
+                     dim3(256), 0, st, a);
+  if (splits > 1)
+    hipLaunchKernelGGL(sum_splits_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N * K, 256))), dim3(256), 0, st, static_cast<const float*>(workspace), dw,
+                       N * K, static_cast<int>(used));
+  MDG_CHECK_LAUNCH("mdg_grad_weight");
+  return MDG_OK;
+}

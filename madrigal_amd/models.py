@@ -69,12 +69,12 @@ def _linT(x, w, b=None, act=None):
 
 
 def _require_eval(m: nn.Module) -> None:
+    """Guard of the few modules that have no differentiated / training-mode path (stand-alone position encoders, the
+    SimCLR projection head): refuse rather than return tensors without a graph."""
     if m.training:
-        raise RuntimeError(f"{type(m).__name__}: the HIP path is forward-only; call .eval() first "
-                           "(dropout / BatchNorm batch statistics of training mode are not implemented)")
+        raise RuntimeError(f"{type(m).__name__}: this module has no training-mode path on the HIP side; call .eval() first")
     if torch.is_grad_enabled() and any(p.requires_grad for p in m.parameters()):
-        raise RuntimeError(f"{type(m).__name__}: the HIP path is forward-only: call it under torch.no_grad() "
-                           "(the kernels do not record an autograd graph; backward is not part of this release)")
+        raise RuntimeError(f"{type(m).__name__}: this module is forward-only on the HIP side: call it under torch.no_grad()")
 
 
 # madrigal/models/models.py:31.  Fresh instances per use; only the type matters for the fused epilogue.

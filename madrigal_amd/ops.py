@@ -121,11 +121,12 @@ _pad_cache = {}
 
 
 def forward_only(*tensors) -> None:
-    """The HIP ops are forward-only in this release: refuse to run under autograd rather than
-    silently return tensors that do not carry gradients."""
+    """The raw wrappers of this module are forward-only: refuse to run under autograd rather than silently return
+    tensors that do not carry gradients.  The differentiable entry points are in madrigal_amd.autograd (each node
+    calls these wrappers for its forward and its backward pass with autograd switched off)."""
     if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
-        raise RuntimeError("madrigal_amd HIP ops are forward-only: call the model under torch.no_grad() "
-                           "(backward kernels are not part of this release)")
+        raise RuntimeError("madrigal_amd.ops wrappers are forward-only: use madrigal_amd.autograd (or the model classes) "
+                           "to record a gradient, or call under torch.no_grad()")
 
 
 def _pad_last(t: torch.Tensor, mult: int = 4) -> torch.Tensor:
@@ -841,3 +842,19 @@ def gated_residual_bwd(dout: torch.Tensor, o: torch.Tensor, x: torch.Tensor, ski
     check(lib().mdg_gated_residual_bwd(_ptr(dout), _ptr(o), _ptr(x), _ptr(_f32_cuda(skip.reshape(1), "skip", 1)), _ptr(d_o), _ptr(d_x),
                                        _ptr(rowdot), _c64(o.shape[0]), _c64(o.shape[1]), _stream(o)), "mdg_gated_residual_bwd")
     return d_o, d_x, colsum(rowdot.view(-1, 1))
+
+
+def grad_weight(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW [N,K] = g^T x for g [M,N], x [M,K] (row-major, unit inner stride; rows may be strided)."""
+    for nm, v in (("g", g), ("x", x)):
+        if v.dim() != 2 or not v.is_cuda or v.dtype != torch.float32 or v.stride(1) != 1:
+            raise ValueError(f"grad_weight: {nm} must be a 2-D fp32 cuda tensor with unit inner stride")
+    if g.shape[0] != x.shape[0]:
+        raise ValueError("grad_weight: g and x disagree in the number of rows")
+    M, N, K = g.shape[0], g.shape[1], x.shape[1]
+    dw = torch.empty((N, K), dtype=torch.float32, device=g.device)
+    nbytes = lib().mdg_grad_weight_workspace_bytes(_c64(M), _c64(N), _c64(K))
+    ws = _workspace(nbytes, g.device)
+    check(lib().mdg_grad_weight(_ptr(g), _c64(g.stride(0)), _ptr(x), _c64(x.stride(0)), _ptr(dw), _c64(M), _c64(N), _c64(K), _ptr(ws),
+                                ctypes.c_size_t(nbytes), _stream(g)), "mdg_grad_weight")
+    return dw

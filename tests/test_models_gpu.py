@@ -38,15 +38,26 @@ def test_mlps_golden(M, golden, prec, name, cls, in_dim, hidden, out, p, norm, a
     assert rel_err(y, g[name + "_y"]) < TOL[prec]
 
 
-def test_training_mode_and_autograd_are_refused(M):
+def test_training_mode_records_a_tape_and_undifferentiable_paths_refuse(M):
+    """Training mode / autograd run through madrigal_amd.autograd (tests/test_train_gpu.py holds the parity checks); what
+    has no backward on the HIP path refuses loudly instead of returning tensors without a graph."""
     m = M.MLPEncoder(8, [8], 4, 0.0, None, "relu").cuda()
-    with pytest.raises(RuntimeError, match="eval"):
-        m(torch.zeros(2, 8, device="cuda"))
+    y = m(torch.zeros(2, 8, device="cuda"))
+    assert y.requires_grad and y.shape == (2, 4)
+    y.sum().backward()
+    assert all(p.grad is not None for p in m.parameters())
     m.eval()
-    with pytest.raises(RuntimeError, match="forward-only"):
-        m(torch.zeros(2, 8, device="cuda"))
     with torch.no_grad():
-        assert m(torch.zeros(2, 8, device="cuda")).shape == (2, 4)
+        assert not m(torch.zeros(2, 8, device="cuda")).requires_grad
+    dec = M.BilinearDDIScorer(128, 128, 3).cuda()
+    z = torch.zeros(4, 128, device="cuda")
+    with pytest.raises(NotImplementedError, match="score_triples"):
+        dec(z, z)                                              # dense [L,N,N] result under autograd
+    with torch.no_grad():
+        assert dec(z, z).shape == (3, 4, 4)
+    fus = M.TransformerFusion(128, 0, 1, 4, 32, 64, 0.0, "gelu", True, True, "mean").cuda().train()
+    with pytest.raises(NotImplementedError, match="x-attn"):
+        fus(torch.zeros(2, 19, 128, device="cuda"), torch.zeros(2, 19, dtype=torch.bool, device="cuda"))
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
