@@ -82,6 +82,34 @@ def cpu_baseline(n_drugs: int, n_outcomes: int, seconds: float = 12.0):
                       f"extrapolated linearly in rows"}
 
 
+def finetune_leg(model, batch, bkg, filler, N, L, args):
+    """DDI-finetune steps/s on the same model and batch (train_ddi_batch.py:275-350, 'full_full' mode): zero_grad ->
+    encode head and tail side (training mode: dropout, BatchNorm batch statistics) -> scores of T labelled triples
+    (gathered head) -> BCE -> backward through every encoder -> AdamW over the reference's parameter groups."""
+    import torch
+    from madrigal_amd import data as D
+    from madrigal_amd.optim import create_optimizer
+    from madrigal_amd.train import FinetuneStep
+    dev = batch["cv"].device
+    T = args.finetune_triples
+    lab, hd, tl, y = (t.to(dev) for t in D.make_labelled_triples(N, L, T, 0))
+    hp = dict(optimizer="adamw", structure_encoder_lr=1e-5, kg_encoder_lr=1e-5, perturb_encoders_lr=1e-5, fusion_lr=1e-6, decoder_lr=1e-4,
+              wd=1e-2, beta1=0.9, beta2=0.999, eps=1e-8)
+    fs = FinetuneStep(model, create_optimizer(model, hp))
+    losses = [float(fs.step(batch, batch, batch["masks"], batch["masks"], bkg, lab, hd, tl, y, kg_filler=filler))]     # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.finetune_steps):
+        losses.append(fs.step(batch, batch, batch["masks"], batch["masks"], bkg, lab, hd, tl, y, kg_filler=filler))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.finetune_steps
+    return {"metric": "DDI-finetune steps/sec", "value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "n_gpus": 1,
+            "steps": args.finetune_steps, "warmup": 1, "triples_per_step": T, "drugs": N, "outcomes": L,
+            "loss_first_last": [float(losses[0]), float(losses[-1])],
+            "work": "optimizer.zero_grad, encode+fuse head side and tail side (training mode), gathered bilinear head on the "
+                    "labelled triples, BCE, backward through all encoders, AdamW step"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +123,9 @@ def main():
     ap.add_argument("--kg-edges", type=int, default=8000000)
     ap.add_argument("--head-only", action="store_true", help="time the scoring stage alone (embeddings given)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--finetune-steps", type=int, default=3, help="second half of BASELINE's metric: DDI-finetune steps/s "
+                    "(encode both sides + gathered head + BCE + backward + AdamW), timed at N=1 after the headline; 0 = skip")
+    ap.add_argument("--finetune-triples", type=int, default=1_000_000)
     args = ap.parse_args()
 
     import torch
@@ -218,6 +249,10 @@ def main():
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, L)
+        if world == 1 and args.finetune_steps > 0 and not args.head_only:
+            del out
+            torch.cuda.empty_cache()
+            line["finetune"] = finetune_leg(model, batch, bkg, filler, N, L, args)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -55,7 +55,7 @@ class _Linear(Function):
             dx = ops.linear(g, ops.transpose(w), precision=ctx.precision, cache_weight=False)[:, :x2.shape[1]]
             dx = dx.reshape(*ctx.lead, x2.shape[1])
         if ctx.needs_input_grad[1]:
-            dw = ops.grad_weight(g, x2)
+            dw = ops.grad_weight(g, x2, ctx.precision)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(g)
         return dx, dw, db, None, None

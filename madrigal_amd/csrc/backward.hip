@@ -26,16 +26,14 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // ---- column sums: out[c] (+)= sum_r x[r, c].  Two passes: per-block partial sums over 256-row slabs, then a fixed
 // order reduction of the partials.  (bias gradients, LayerNorm gamma/beta gradients, learned-token gradients)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ part,
-                                                             int64_t rows, int64_t cols) {
+                                                             int64_t rows, int64_t cols, int64_t slab) {
   const int64_t c = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
   const int ty = threadIdx.x >> 6;
-  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * 256;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * slab;
+  const int64_t r1 = r0 + slab < rows ? r0 + slab : rows;
   float s = 0.f;
   if (c < cols)
-    for (int i = 0; i < 64; ++i) {
-      const int64_t r = r0 + ty + 4 * i;
-      if (r < rows) s += x[r * ldx + c];
-    }
+    for (int64_t r = r0 + ty; r < r1; r += 4) s += x[r * ldx + c];
   __shared__ float sh[4][64];
   sh[ty][threadIdx.x & 63] = s;
   __syncthreads();
@@ -300,8 +298,15 @@ extern "C" int mdg_transpose(const float* in, int64_t ldi, float* out, int64_t l
   return MDG_OK;
 }
 
+// rows per partial block: 256, grown so that no column needs more than 128 partials
+static int64_t colsum_slab(int64_t rows) {
+  int64_t slab = 256;
+  while (mdg_cdiv(rows, slab) > 128) slab *= 2;
+  return slab;
+}
+
 extern "C" size_t mdg_colsum_workspace_bytes(int64_t rows, int64_t cols) {
-  return rows <= 0 || cols <= 0 ? 0 : static_cast<size_t>(mdg_cdiv(rows, 256)) * cols * sizeof(float);
+  return rows <= 0 || cols <= 0 ? 0 : static_cast<size_t>(mdg_cdiv(rows, colsum_slab(rows))) * cols * sizeof(float);
 }
 
 extern "C" int mdg_colsum(const float* x, int64_t ldx, float* out, int64_t rows, int64_t cols, float beta, void* workspace,
@@ -309,7 +314,8 @@ extern "C" int mdg_colsum(const float* x, int64_t ldx, float* out, int64_t rows,
   MDG_CHECK_ARG(rows >= 0 && cols > 0 && ldx >= cols, "mdg_colsum: bad shape");
   MDG_CHECK_ARG(out, "mdg_colsum: null out");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int64_t nparts = mdg_cdiv(rows, 256);
+  const int64_t slab = colsum_slab(rows);
+  const int64_t nparts = mdg_cdiv(rows, slab);
   const size_t need = mdg_colsum_workspace_bytes(rows, cols);
   if (need && (!workspace || workspace_bytes < need)) {
     mdg_set_error("mdg_colsum: workspace of %zu bytes required, got %zu", need, workspace_bytes);
@@ -318,7 +324,7 @@ extern "C" int mdg_colsum(const float* x, int64_t ldx, float* out, int64_t rows,
   if (rows > 0) {
     MDG_CHECK_ARG(x, "mdg_colsum: null x");
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64)), static_cast<unsigned>(nparts)), dim3(256), 0, st,
-                       x, ldx, static_cast<float*>(workspace), rows, cols);
+                       x, ldx, static_cast<float*>(workspace), rows, cols, slab);
   }
   hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 256))), dim3(256), 0, st,
                      static_cast<const float*>(workspace), cols, out, nparts, cols, beta);

@@ -97,8 +97,8 @@ __global__ __launch_bounds__(256) void sum_splits_kernel(const float* __restrict
 
 int pick_splits(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = mdg_cdiv(N, 128) * mdg_cdiv(K, 128);
-  int64_t s = mdg_cdiv(1024, tiles);
-  const int64_t max_s = mdg_cdiv(M, 64);                  // at least 64 rows per split
+  int64_t s = mdg_cdiv(512, tiles);                       // ~2 workgroups per CU; every partial costs N*K*8 bytes of traffic
+  const int64_t max_s = mdg_cdiv(M, 256);                 // at least 256 rows per split
   if (s > max_s) s = max_s;
   if (s > 4096) s = 4096;
   return static_cast<int>(s < 1 ? 1 : s);

@@ -844,8 +844,14 @@ def gated_residual_bwd(dout: torch.Tensor, o: torch.Tensor, x: torch.Tensor, ski
     return d_o, d_x, colsum(rowdot.view(-1, 1))
 
 
-def grad_weight(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dW [N,K] = g^T x for g [M,N], x [M,K] (row-major, unit inner stride; rows may be strided)."""
+def grad_weight(g: torch.Tensor, x: torch.Tensor, precision="f32") -> torch.Tensor:
+    """dW [N,K] = g^T x for g [M,N], x [M,K] (row-major, unit inner stride; rows may be strided).
+
+    Small outputs (the usual case: 128..512-wide layers over 10^4..10^6 rows) run the split-reduction fp32 kernel.
+    Outputs with >= 96 tiles of 128x128 (the 2048-wide fusion transformer) already fill the chip tile-wise: in the
+    bf16 modes they go through the forward GEMM kernel on transposed operands, ~5x the fp32 matrix-core rate."""
+    if _prec(precision) != PREC_F32 and ((g.shape[1] + 127) // 128) * ((x.shape[1] + 127) // 128) >= 96:
+        return linear(transpose(g), transpose(x), precision=precision, cache_weight=False)
     for nm, v in (("g", g), ("x", x)):
         if v.dim() != 2 or not v.is_cuda or v.dtype != torch.float32 or v.stride(1) != 1:
             raise ValueError(f"grad_weight: {nm} must be a 2-D fp32 cuda tensor with unit inner stride")
