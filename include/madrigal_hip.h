@@ -268,12 +268,13 @@ int mdg_adamw_multi(const int64_t* chunk_ptrs, const int32_t* chunk_lens, const 
 /* ------------------------------------------------------- backward-pass building blocks ---- */
 /* (the finetune step of train_ddi_batch.py:285-354: loss.backward() through the modules above) */
 
-/* Weight gradient of y = x W^T:  dw[n,k] = sum_m g[m,n] x[m,k]  (g [M,N] = dL/dy, x [M,K] the layer input, both row-major
- * with unit inner stride).  The reduction over the M rows is split across the grid (exact fp32 MFMA, partials summed in
- * a fixed order); workspace from mdg_grad_weight_workspace_bytes. */
+/* Weight (and bias) gradient of y = x W^T + b:  dw[n,k] = sum_m g[m,n] x[m,k],  dbias[n] = sum_m g[m,n] (optional, NULL to
+ * skip)  (g [M,N] = dL/dy, x [M,K] the layer input, both row-major with unit inner stride).  The reduction over the M rows
+ * is split across the grid (exact fp32 MFMA, partials summed in a fixed order); workspace from
+ * mdg_grad_weight_workspace_bytes. */
 size_t mdg_grad_weight_workspace_bytes(int64_t M, int64_t N, int64_t K);
-int mdg_grad_weight(const float* g, int64_t ldg, const float* x, int64_t ldx, float* dw, int64_t M, int64_t N, int64_t K,
-                    void* workspace, size_t workspace_bytes, void* stream);
+int mdg_grad_weight(const float* g, int64_t ldg, const float* x, int64_t ldx, float* dw, float* dbias, int64_t M, int64_t N,
+                    int64_t K, void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[c, r] = in[r, c]   (dW = dY^T X and dX = dY W are mdg_linear calls on transposed operands) */
 int mdg_transpose(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t rows, int64_t cols, void* stream);

@@ -54,9 +54,12 @@ class _Linear(Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear(g, ops.transpose(w), precision=ctx.precision, cache_weight=False)[:, :x2.shape[1]]
             dx = dx.reshape(*ctx.lead, x2.shape[1])
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = ops.grad_weight(g, x2, ctx.precision)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dw = ops.grad_weight(g, x2, ctx.precision, want_bias=want_db)
+            if want_db:
+                dw, db = dw
+        elif want_db:
             db = ops.colsum(g)
         return dx, dw, db, None, None
 

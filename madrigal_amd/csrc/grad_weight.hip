@@ -14,9 +14,39 @@ struct GwArgs {
   const float* g; int64_t ldg;
   const float* x; int64_t ldx;
   float* out;                 // [S, N, K] partials (S > 1) or dW itself (S == 1)
+  float* db;                  // [S, N] partial column sums of g (bias gradient) or null
   int64_t M, rows_per_split;
   int N, K;
 };
+
+constexpr int GW_U = 8;       // row pairs per batch: 16 rows of both operands in flight per buffer
+
+struct GwBatch { float a0[GW_U], a1[GW_U], b0[GW_U], b1[GW_U]; };
+
+__device__ __forceinline__ void gw_load(GwBatch& t, const float* ga, const float* gb, const float* xa, const float* xb, int64_t ldg,
+                                        int64_t ldx, int64_t m, int half) {
+#pragma unroll
+  for (int u = 0; u < GW_U; ++u) {
+    const int64_t r = m + 2 * u + half;
+    t.a0[u] = ga[r * ldg];
+    t.a1[u] = gb[r * ldg];
+    t.b0[u] = xa[r * ldx];
+    t.b1[u] = xb[r * ldx];
+  }
+}
+
+__device__ __forceinline__ void gw_compute(const GwBatch& t, float fa, float fb, f32x16 (&acc)[2][2], float& sa, float& sb) {
+#pragma unroll
+  for (int u = 0; u < GW_U; ++u) {
+    const float va = t.a0[u] * fa, vb = t.a1[u] * fb;
+    sa += va;
+    sb += vb;
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, t.b0[u], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, t.b1[u], acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, t.b0[u], acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, t.b1[u], acc[1][1], 0, 0, 0);
+  }
+}
 
 __global__ __launch_bounds__(256) void grad_weight_kernel(const GwArgs p) {
   const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
@@ -37,35 +67,30 @@ __global__ __launch_bounds__(256) void grad_weight_kernel(const GwArgs p) {
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[r][c][v] = 0.f;
+  float sa = 0.f, sb = 0.f;                               // column sums of g over this lane's rows (bias gradient)
 
-  constexpr int U = 8;                                   // row pairs in flight
-  int64_t m = m0;
-  for (; m + 2 * U <= m1; m += 2 * U) {
-    float a0[U], a1[U], b0[U], b1[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t r = m + 2 * u + half;
-      a0[u] = ga[r * p.ldg];
-      a1[u] = gb[r * p.ldg];
-      b0[u] = xa[r * p.ldx];
-      b1[u] = xb[r * p.ldx];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float va = a0[u] * fa, vb = a1[u] * fb;
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, b0[u], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, b1[u], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, b0[u], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, b1[u], acc[1][1], 0, 0, 0);
-    }
+  // two register buffers: the loads of batch b+1 are in flight while the matrix cores work on batch b
+  const int64_t nbatch = (m1 - m0) / (2 * GW_U);
+  GwBatch A, B;
+  if (nbatch > 0) gw_load(A, ga, gb, xa, xb, p.ldg, p.ldx, m0, half);
+  int64_t b = 0;
+  while (b < nbatch) {
+    if (b + 1 < nbatch) gw_load(B, ga, gb, xa, xb, p.ldg, p.ldx, m0 + (b + 1) * 2 * GW_U, half);
+    gw_compute(A, fa, fb, acc, sa, sb);
+    if (++b >= nbatch) break;
+    if (b + 1 < nbatch) gw_load(A, ga, gb, xa, xb, p.ldg, p.ldx, m0 + (b + 1) * 2 * GW_U, half);
+    gw_compute(B, fa, fb, acc, sa, sb);
+    ++b;
   }
-  for (; m < m1; m += 2) {                                // tail: the odd last row meets a zero partner
+  for (int64_t m = m0 + nbatch * 2 * GW_U; m < m1; m += 2) {   // tail: the odd last row meets a zero partner
     const int64_t r = m + half;
     const bool ok = r < m1;
     const int64_t rr = ok ? r : m1 - 1;
     const float s = ok ? 1.f : 0.f;
     const float va = ga[rr * p.ldg] * fa * s, vb = gb[rr * p.ldg] * fb * s;
     const float b0 = xa[rr * p.ldx], b1 = xb[rr * p.ldx];
+    sa += va;
+    sb += vb;
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, b0, acc[0][0], 0, 0, 0);
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, b1, acc[0][1], 0, 0, 0);
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, b0, acc[1][0], 0, 0, 0);
@@ -85,6 +110,15 @@ __global__ __launch_bounds__(256) void grad_weight_kernel(const GwArgs p) {
         if (n < p.N) out[static_cast<int64_t>(n) * p.K + k] = acc[r][c][v];
       }
     }
+  if (p.db && blockIdx.x == 0 && (wave & 1) == 0) {         // one k-tile column of waves owns the bias partials
+    sa += __shfl_xor(sa, 32, 64);                           // even rows + odd rows
+    sb += __shfl_xor(sb, 32, 64);
+    if (half == 0) {
+      float* d = p.db + static_cast<int64_t>(blockIdx.z) * p.N;
+      if (na < p.N) d[na] = sa;
+      if (nb < p.N) d[nb] = sb;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void sum_splits_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int splits) {
@@ -97,8 +131,8 @@ __global__ __launch_bounds__(256) void sum_splits_kernel(const float* __restrict
 
 int pick_splits(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = mdg_cdiv(N, 128) * mdg_cdiv(K, 128);
-  int64_t s = mdg_cdiv(512, tiles);                       // ~2 workgroups per CU; every partial costs N*K*8 bytes of traffic
-  const int64_t max_s = mdg_cdiv(M, 256);                 // at least 256 rows per split
+  int64_t s = mdg_cdiv(1024, tiles);                      // ~4 workgroups per CU; every partial costs N*K*8 bytes of traffic
+  const int64_t max_s = mdg_cdiv(M, 128);                 // at least 128 rows (8 batches) per split
   if (s > max_s) s = max_s;
   if (s > 4096) s = 4096;
   return static_cast<int>(s < 1 ? 1 : s);
@@ -109,16 +143,17 @@ int pick_splits(int64_t M, int64_t N, int64_t K) {
 extern "C" size_t mdg_grad_weight_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int s = pick_splits(M, N, K);
-  return s == 1 ? 0 : static_cast<size_t>(s) * N * K * sizeof(float);
+  return s == 1 ? 0 : static_cast<size_t>(s) * N * (K + 1) * sizeof(float);
 }
 
-extern "C" int mdg_grad_weight(const float* g, int64_t ldg, const float* x, int64_t ldx, float* dw, int64_t M, int64_t N, int64_t K,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int mdg_grad_weight(const float* g, int64_t ldg, const float* x, int64_t ldx, float* dw, float* dbias, int64_t M, int64_t N,
+                               int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
   MDG_CHECK_ARG(M >= 0 && N > 0 && K > 0 && N <= (1 << 20) && K <= (1 << 20), "mdg_grad_weight: bad shape");
   MDG_CHECK_ARG(dw, "mdg_grad_weight: null dw");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (M == 0) {
     (void)hipMemsetAsync(dw, 0, static_cast<size_t>(N) * K * sizeof(float), st);
+    if (dbias) (void)hipMemsetAsync(dbias, 0, static_cast<size_t>(N) * sizeof(float), st);
     return MDG_OK;
   }
   MDG_CHECK_ARG(g && x && ldg >= N && ldx >= K, "mdg_grad_weight: null operand / short row stride");
@@ -130,13 +165,19 @@ extern "C" int mdg_grad_weight(const float* g, int64_t ldg, const float* x, int6
   }
   int64_t rps = mdg_cdiv(M, splits);
   rps += rps & 1;                                           // whole row pairs per split
-  GwArgs a{g, ldg, x, ldx, splits == 1 ? dw : static_cast<float*>(workspace), M, rps, static_cast<int>(N), static_cast<int>(K)};
   const int64_t used = mdg_cdiv(M, rps);
+  float* part = static_cast<float*>(workspace);
+  float* part_db = (splits == 1 || !dbias) ? dbias : part + static_cast<size_t>(splits) * N * K;
+  GwArgs a{g, ldg, x, ldx, splits == 1 ? dw : part, part_db, M, rps, static_cast<int>(N), static_cast<int>(K)};
   hipLaunchKernelGGL(grad_weight_kernel, dim3(static_cast<unsigned>(mdg_cdiv(K, 128)), static_cast<unsigned>(mdg_cdiv(N, 128)), static_cast<unsigned>(used)),
                      dim3(256), 0, st, a);
-  if (splits > 1)
+  if (splits > 1) {
     hipLaunchKernelGGL(sum_splits_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N * K, 256))), dim3(256), 0, st, static_cast<const float*>(workspace), dw,
                        N * K, static_cast<int>(used));
+    if (dbias)
+      hipLaunchKernelGGL(sum_splits_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N, 256))), dim3(256), 0, st, static_cast<const float*>(part_db), dbias,
+                         N, static_cast<int>(used));
+  }
   MDG_CHECK_LAUNCH("mdg_grad_weight");
   return MDG_OK;
 }

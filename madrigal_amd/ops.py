@@ -844,23 +844,27 @@ def gated_residual_bwd(dout: torch.Tensor, o: torch.Tensor, x: torch.Tensor, ski
     return d_o, d_x, colsum(rowdot.view(-1, 1))
 
 
-def grad_weight(g: torch.Tensor, x: torch.Tensor, precision="f32") -> torch.Tensor:
-    """dW [N,K] = g^T x for g [M,N], x [M,K] (row-major, unit inner stride; rows may be strided).
+def grad_weight(g: torch.Tensor, x: torch.Tensor, precision="f32", want_bias: bool = False):
+    """dW [N,K] = g^T x for g [M,N], x [M,K] (row-major, unit inner stride; rows may be strided); with ``want_bias`` also
+    db [N] = column sums of g -> (dW, db).
 
-    Small outputs (the usual case: 128..512-wide layers over 10^4..10^6 rows) run the split-reduction fp32 kernel.
-    Outputs with >= 96 tiles of 128x128 (the 2048-wide fusion transformer) already fill the chip tile-wise: in the
-    bf16 modes they go through the forward GEMM kernel on transposed operands, ~5x the fp32 matrix-core rate."""
-    if _prec(precision) != PREC_F32 and ((g.shape[1] + 127) // 128) * ((x.shape[1] + 127) // 128) >= 96:
-        return linear(transpose(g), transpose(x), precision=precision, cache_weight=False)
+    Small outputs (the usual case: 128..512-wide layers over 10^4..10^6 rows) run the split-reduction fp32 kernel, which
+    produces the bias gradient on the side.  Outputs with >= 96 tiles of 128x128 (the 2048-wide fusion transformer)
+    already fill the chip tile-wise: in the bf16 modes they go through the forward GEMM kernel on transposed operands,
+    ~5x the fp32 matrix-core rate."""
     for nm, v in (("g", g), ("x", x)):
         if v.dim() != 2 or not v.is_cuda or v.dtype != torch.float32 or v.stride(1) != 1:
             raise ValueError(f"grad_weight: {nm} must be a 2-D fp32 cuda tensor with unit inner stride")
     if g.shape[0] != x.shape[0]:
         raise ValueError("grad_weight: g and x disagree in the number of rows")
     M, N, K = g.shape[0], g.shape[1], x.shape[1]
+    if _prec(precision) != PREC_F32 and ((N + 127) // 128) * ((K + 127) // 128) >= 96:
+        dw = linear(transpose(g), transpose(x), precision=precision, cache_weight=False)
+        return (dw, colsum(g)) if want_bias else dw
     dw = torch.empty((N, K), dtype=torch.float32, device=g.device)
+    db = torch.empty(N, dtype=torch.float32, device=g.device) if want_bias else None
     nbytes = lib().mdg_grad_weight_workspace_bytes(_c64(M), _c64(N), _c64(K))
     ws = _workspace(nbytes, g.device)
-    check(lib().mdg_grad_weight(_ptr(g), _c64(g.stride(0)), _ptr(x), _c64(x.stride(0)), _ptr(dw), _c64(M), _c64(N), _c64(K), _ptr(ws),
-                                ctypes.c_size_t(nbytes), _stream(g)), "mdg_grad_weight")
-    return dw
+    check(lib().mdg_grad_weight(_ptr(g), _c64(g.stride(0)), _ptr(x), _c64(x.stride(0)), _ptr(dw), _ptr(db), _c64(M), _c64(N), _c64(K),
+                                _ptr(ws), ctypes.c_size_t(nbytes), _stream(g)), "mdg_grad_weight")
+    return (dw, db) if want_bias else dw
