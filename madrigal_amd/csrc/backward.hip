@@ -42,11 +42,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int64_t ldp, float* __restrict__ out,
                                                            int64_t nparts, int64_t cols, float beta) {
-  const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (c >= cols) return;
-  float s = 0.f;
-  for (int64_t p = 0; p < nparts; ++p) s += part[p * ldp + c];
-  out[c] = (beta != 0.f ? beta * out[c] : 0.f) + s;
+  // 64 columns per block, the partials interleaved over the four thread rows, combined through LDS in a fixed order
+  const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * 64 + e;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < cols) {
+    int64_t p = grp;
+    for (; p + 4 < nparts; p += 8) {
+      s0 += part[p * ldp + c];
+      s1 += part[(p + 4) * ldp + c];
+    }
+    for (; p < nparts; p += 4) s0 += part[p * ldp + c];
+  }
+  __shared__ float sh[4][64];
+  sh[grp][e] = s0 + s1;
+  __syncthreads();
+  if (grp == 0 && c < cols) out[c] = (beta != 0.f ? beta * out[c] : 0.f) + ((sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]));
 }
 
 // ---- dx = dy * act'(pre) -------------------------------------------------------------------------------------
@@ -326,7 +337,7 @@ extern "C" int mdg_colsum(const float* x, int64_t ldx, float* out, int64_t rows,
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64)), static_cast<unsigned>(nparts)), dim3(256), 0, st,
                        x, ldx, static_cast<float*>(workspace), rows, cols, slab);
   }
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 256))), dim3(256), 0, st,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64))), dim3(256), 0, st,
                      static_cast<const float*>(workspace), cols, out, nparts, cols, beta);
   MDG_CHECK_LAUNCH("mdg_colsum");
   return MDG_OK;
@@ -369,7 +380,7 @@ static int colreduce(const float* x, int64_t ldx, const float* y, int64_t ldy, c
   const int64_t nparts = mdg_cdiv(rows, 256);
   hipLaunchKernelGGL(colreduce_partial_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64)), static_cast<unsigned>(nparts)), dim3(256), 0, st,
                      x, ldx, y, ldy, center, rstd, ws, rows, cols, mode);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 256))), dim3(256), 0, st, static_cast<const float*>(ws), cols, out,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64))), dim3(256), 0, st, static_cast<const float*>(ws), cols, out,
                      nparts, cols, 0.f);
   return MDG_OK;
 }
@@ -449,9 +460,9 @@ extern "C" int mdg_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
       hipLaunchKernelGGL(layernorm_bwd_kernel<32>, dim3(static_cast<unsigned>(nb)), dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, static_cast<int>(d), eps);
   }
   // dgamma = sum of partial rows [nb, 2d] -> first d columns, dbeta the next d
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(d, 256))), dim3(256), 0, st, static_cast<const float*>(workspace),
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(d, 64))), dim3(256), 0, st, static_cast<const float*>(workspace),
                      2 * d, dgamma, nb, d, 0.f);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(d, 256))), dim3(256), 0, st,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(d, 64))), dim3(256), 0, st,
                      static_cast<const float*>(workspace) + d, 2 * d, dbeta, nb, d, 0.f);
   MDG_CHECK_LAUNCH("mdg_layernorm_bwd");
   return MDG_OK;

@@ -121,12 +121,26 @@ __global__ __launch_bounds__(256) void grad_weight_kernel(const GwArgs p) {
   }
 }
 
+// out[i] = sum_k part[k][i] in a fixed order: four interleaved groups of splits per element (thread rows of the block),
+// four independent accumulators per thread so that the loads overlap, groups combined through LDS.
 __global__ __launch_bounds__(256) void sum_splits_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int splits) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += part[static_cast<int64_t>(k) * n + i];
-  out[i] = s;
+  const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 64 + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int k = grp;
+    for (; k + 12 < splits; k += 16) {
+      s0 += part[static_cast<int64_t>(k) * n + i];
+      s1 += part[static_cast<int64_t>(k + 4) * n + i];
+      s2 += part[static_cast<int64_t>(k + 8) * n + i];
+      s3 += part[static_cast<int64_t>(k + 12) * n + i];
+    }
+    for (; k < splits; k += 4) s0 += part[static_cast<int64_t>(k) * n + i];
+  }
+  __shared__ float sh[4][64];
+  sh[grp][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && i < n) out[i] = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
 }
 
 int pick_splits(int64_t M, int64_t N, int64_t K) {
@@ -172,10 +186,10 @@ extern "C" int mdg_grad_weight(const float* g, int64_t ldg, const float* x, int6
   hipLaunchKernelGGL(grad_weight_kernel, dim3(static_cast<unsigned>(mdg_cdiv(K, 128)), static_cast<unsigned>(mdg_cdiv(N, 128)), static_cast<unsigned>(used)),
                      dim3(256), 0, st, a);
   if (splits > 1) {
-    hipLaunchKernelGGL(sum_splits_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N * K, 256))), dim3(256), 0, st, static_cast<const float*>(workspace), dw,
+    hipLaunchKernelGGL(sum_splits_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N * K, 64))), dim3(256), 0, st, static_cast<const float*>(workspace), dw,
                        N * K, static_cast<int>(used));
     if (dbias)
-      hipLaunchKernelGGL(sum_splits_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N, 256))), dim3(256), 0, st, static_cast<const float*>(part_db), dbias,
+      hipLaunchKernelGGL(sum_splits_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N, 64))), dim3(256), 0, st, static_cast<const float*>(part_db), dbias,
                          N, static_cast<int>(used));
   }
   MDG_CHECK_LAUNCH("mdg_grad_weight");

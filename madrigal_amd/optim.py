@@ -76,6 +76,10 @@ class AdamW(torch.optim.Optimizer):
                       "mdg_adamw_multi")
             for t in (t_ptr, t_len, t_own, t_hyp):
                 t.record_stream(torch.cuda.current_stream(dev))
+            # the kernel wrote the parameters and the moments behind torch's back: bump their in-place version counters so
+            # that everything keyed on them (packed / derived weight caches of the inference path, autograd's saved-tensor
+            # checks) sees the update
+            torch.autograd.graph.increment_version([t for p, _, m, v, _ in items for t in (p, m, v)])
         return loss
 
 

@@ -546,7 +546,8 @@ def test_gin_training_gradients_match_torch(batch_norm, readout, weighted):
         if pr.grad is None:
             continue
         assert pg.grad is not None, name
-        _close(pg.grad, pr.grad, 1e-4, name, floor=1e-2 * gmax)
+        # (the MLP bias in front of the BatchNorm has an analytically zero gradient: fp32 cancellation noise only)
+        _close(pg.grad, pr.grad, 1e-4, name, floor=(1e-1 if name.endswith("mlp.layers.2.bias") and batch_norm else 1e-2) * gmax)
         n_checked += 1
     assert n_checked >= 12
     if batch_norm:
@@ -759,3 +760,36 @@ def test_finetune_steps_reduce_loss_and_are_reproducible():
     for k in sd1:
         assert torch.equal(sd1[k], sd2[k]), k
     assert int(sd1["encoder.tx_encoder.encoder.network.1.num_batches_tracked"]) == 24    # head + tail pass per step
+
+
+def test_inference_after_training_sees_the_updated_weights():
+    """The optimizer writes parameters from a kernel; the inference path caches packed / folded / symmetrised weights keyed
+    on torch's version counters — a stale cache would silently score with the old weights."""
+    from madrigal_amd import data as D, models as M
+    from madrigal_amd.optim import create_optimizer
+    from madrigal_amd.train import FinetuneStep
+    case = ("drugbank163", "transformer", 4, "sinusoidal", 8, 64, 256, 2, True, "x-attn", False, False)
+    n, L, seed = 64, 8, 3
+    model, _, batch, bkg, masks = _small_model(M, case, n, L, seed, default_init=True)
+    model = model.cuda().eval()
+    b = D.batch_to(batch, "cuda")
+    kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
+    filler = torch.randn(n, 128, generator=torch.Generator().manual_seed(1)).cuda()
+    with torch.no_grad():
+        before = model(b, b, b["masks"], b["masks"], kgc, kg_filler=filler).clone()      # fills every weight cache
+    hp = dict(optimizer="adamw", structure_encoder_lr=1e-3, kg_encoder_lr=1e-3, perturb_encoders_lr=1e-3, fusion_lr=1e-3, decoder_lr=1e-2,
+              wd=0.0, beta1=0.9, beta2=0.999, eps=1e-8)
+    lab, hd, tl, y = (t.cuda() for t in D.make_labelled_triples(n, L, 500, seed))
+    fs = FinetuneStep(model, create_optimizer(model, hp))
+    for _ in range(2):
+        fs.step(b, b, b["masks"], b["masks"], kgc, lab, hd, tl, y, kg_filler=filler)
+    model.eval()
+    with torch.no_grad():
+        after = model(b, b, b["masks"], b["masks"], kgc, kg_filler=filler)
+    fresh, _, _, _, _ = _small_model(M, case, n, L, seed, default_init=True)
+    fresh.load_state_dict(model.state_dict())
+    fresh = fresh.cuda().eval()
+    with torch.no_grad():
+        want = fresh(b, b, b["masks"], b["masks"], kgc, kg_filler=filler)
+    assert float((after - before).abs().max()) > 1e-3 * float(before.abs().max())      # the steps moved the scores
+    assert torch.equal(after, want)                                                     # and no cache is stale
