@@ -186,6 +186,10 @@ int mdg_hgt_attention(const float* q, int64_t ldq, const float* kv, int64_t ldkv
  * row_loss [2B] and loss [1] = mean soft-label cross entropy. */
 int mdg_infonce_finish(const float* sim, const uint8_t* too_hard_neg, float* logits, float* labels, float* row_loss, float* loss,
                        int64_t B, float temperature, void* stream);
+/* Backward of mdg_infonce_finish: dsim [2B,2B] = d loss / d sim (zero diagonal, zero at too-hard negatives), scaled by
+ * dloss[0] (device scalar).  The caller chains it through sim = F F^T: dF = (dsim + dsim^T) F. */
+int mdg_infonce_bwd(const float* sim, const uint8_t* too_hard_neg, const float* dloss, float* dsim, int64_t B, float temperature,
+                    void* stream);
 
 /* pred[e] = f(scores[label[e], head[e], tail[e]]) with f = sigmoid (apply_sigmoid) or identity, and the
  * mean BCE of pred against target with nn.BCELoss's -100 clamp: term [n] and loss [1] (both nullable

@@ -494,3 +494,40 @@ class _GatherRows(Function):
 
 def gather_rows(table, idx):
     return _GatherRows.apply(table, idx)
+
+
+# ------------------------------------------------------------------------------------------- contrastive pretraining
+class _InfoNCE(Function):
+    """SimCLR_NovelDDI.contrastive_loss (madrigal/models/simclr.py:74-108) on the already L2-normalised features
+    F = normalize(cat(aug1, aug2)): returns (logits, labels, loss); only the loss carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, f, hard, temperature, precision):
+        f = f if f.is_contiguous() else f.contiguous()
+        B = f.shape[0] // 2
+        sim = ops.linear(f, f, None, precision=precision, cache_weight=False)
+        hard_u8 = None if hard is None else hard.to(device=f.device, dtype=torch.uint8).contiguous()
+        logits = torch.empty((2 * B, 2 * B - 1), dtype=torch.float32, device=f.device)
+        labels = torch.empty_like(logits)
+        row = torch.empty(2 * B, dtype=torch.float32, device=f.device)
+        loss = torch.empty(1, dtype=torch.float32, device=f.device)
+        ops.check(ops.lib().mdg_infonce_finish(ops._ptr(sim), ops._ptr(hard_u8), ops._ptr(logits), ops._ptr(labels), ops._ptr(row), ops._ptr(loss),
+                                               ops._c64(B), ops._f(temperature), ops._stream(f)), "mdg_infonce_finish")
+        ctx.save_for_backward(f, sim, hard_u8)
+        ctx.temperature, ctx.precision = temperature, precision
+        ctx.mark_non_differentiable(logits, labels)
+        return logits, labels, loss.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, _dlogits, _dlabels, dloss):
+        f, sim, hard = ctx.saved_tensors
+        dsim = ops.info_nce_bwd(sim, hard, dloss, ctx.temperature)
+        g = ops.axpby(dsim, ops.transpose(dsim, pad_inner=False))            # sim = F F^T: dF = (dsim + dsim^T) F
+        df = ops.linear(g, ops.transpose(f), precision=ctx.precision, cache_weight=False)
+        return df[:, :f.shape[1]], None, None, None
+
+
+def info_nce(aug1, aug2, too_hard_neg, temperature: float, precision="bf16x3"):
+    f = l2_normalize(torch.cat([aug1, aug2], dim=0))
+    return _InfoNCE.apply(f, too_hard_neg, float(temperature), precision)

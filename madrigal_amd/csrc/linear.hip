@@ -164,7 +164,27 @@ struct LinearArgs {
   float alpha, beta;
   int act;
   int64_t M, N, K;
+  int tiles_x, tiles_y, swizzle;   // swizzle: XCD-aware tile order (see tile_of)
 };
+
+// Workgroups are dealt to the 8 XCDs round-robin in dispatch order, and each XCD has its own L2.  With the plain
+// blockIdx -> tile map the ~32 workgroups resident on one XCD are spread over the whole tile grid and share few operand
+// bands.  Swizzled map: XCD x owns a contiguous run of the tile sequence, and that sequence walks the grid in groups of
+// 8 tile-rows, column by column, so that the resident set is an ~8 x 4 patch: 12 operand bands feed 32 tiles.
+__device__ __forceinline__ bool tile_of(const LinearArgs& p, int& tx, int& ty) {
+  const int id = blockIdx.x;
+  if (!p.swizzle) { tx = id % p.tiles_x; ty = id / p.tiles_x; return ty < p.tiles_y; }
+  const int total = p.tiles_x * p.tiles_y;
+  const int per_xcd = (total + 7) >> 3;
+  const int t = (id & 7) * per_xcd + (id >> 3);
+  if ((id >> 3) >= per_xcd || t >= total) return false;
+  constexpr int GM = 8;
+  const int group = t / (GM * p.tiles_x), in = t - group * GM * p.tiles_x;
+  const int rows = p.tiles_y - group * GM < GM ? p.tiles_y - group * GM : GM;
+  ty = group * GM + in % rows;
+  tx = in / rows;
+  return true;
+}
 
 // Pipeline: one raw barrier per k-tile.  Top of tile kt: wait for this wave's DMA pieces of tile kt (the only
 // vector-memory ops in flight), barrier (=> every wave's pieces landed, every wave finished reading tile kt-1),
@@ -175,7 +195,9 @@ __global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs 
   constexpr int MT = S::MT, NT_ = S::NT_;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wr = wave / S::WN, wc = wave % S::WN;
-  const int64_t col0 = static_cast<int64_t>(blockIdx.x) * S::BN, row0 = static_cast<int64_t>(blockIdx.y) * S::BM;
+  int tx, ty;
+  if (!tile_of(p, tx, ty)) return;                        // workgroup-uniform
+  const int64_t col0 = static_cast<int64_t>(tx) * S::BN, row0 = static_cast<int64_t>(ty) * S::BM;
 
   f32x16 acc[MT][NT_];
 #pragma unroll
@@ -373,7 +395,7 @@ extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t l
   MDG_CHECK_ARG(ldy >= N && (!residual || ldr >= N || ldr == 0), "mdg_linear: ldy/ldr smaller than N (ldr == 0 broadcasts one row)");
   MDG_CHECK_ARG((scale == nullptr) == (shift == nullptr), "mdg_linear: scale and shift come together");
   MDG_CHECK_ARG(act >= MDG_ACT_NONE && act <= MDG_ACT_SELU, "mdg_linear: unknown activation %d", act);
-  MDG_CHECK_ARG(mdg_cdiv(M, Small::BM) <= 65535, "mdg_linear: M too large for one launch");
+  MDG_CHECK_ARG(mdg_cdiv(M, Small::BM) * mdg_cdiv(N, Small::BN) < (1ll << 31) - 8, "mdg_linear: too many tiles for one launch");
   MDG_CHECK_ARG(precision == MDG_PREC_F32 || precision == MDG_PREC_BF16X3 || precision == MDG_PREC_BF16, "mdg_linear: unknown precision %d", precision);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t xb = image_bytes(M, K, precision), wb = image_bytes(N, K, precision);
@@ -400,8 +422,17 @@ extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t l
   // (measured on the fusion GEMMs: bf16x3 -9 % time with the big tile, fp32 +6 %: the fp32 MFMA wants two workgroups per CU)
   bool big = (precision != MDG_PREC_F32 && N >= 256 && M >= 1024 && mdg_cdiv(M, Big::BM) * mdg_cdiv(N, Big::BN) >= 192);
   if (const char* e = getenv("MDG_LINEAR_TILE")) big = atoi(e) == 256 ? true : (atoi(e) == 128 ? false : big);
+  // 1-D grid; the kernel maps the linear workgroup id to a tile (XCD-aware order once there are enough tiles to matter)
+  static const int swz_env = getenv("MDG_LINEAR_SWIZZLE") ? atoi(getenv("MDG_LINEAR_SWIZZLE")) : -1;
+  const auto grid_for = [&](int bm, int bn) {
+    a.tiles_x = static_cast<int>(mdg_cdiv(N, bn));
+    a.tiles_y = static_cast<int>(mdg_cdiv(M, bm));
+    const int total = a.tiles_x * a.tiles_y;
+    a.swizzle = swz_env >= 0 ? swz_env : (total >= 64 ? 1 : 0);
+    return dim3(static_cast<unsigned>(a.swizzle ? 8 * ((total + 7) / 8) : total));
+  };
   if (big) {
-    const dim3 grid(static_cast<unsigned>(mdg_cdiv(N, Big::BN)), static_cast<unsigned>(mdg_cdiv(M, Big::BM)));
+    const dim3 grid = grid_for(Big::BM, Big::BN);
     const size_t lds = 2 * Big::STAGE;
     switch (precision) {
       case MDG_PREC_F32: hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, Big>), grid, dim3(Big::THREADS), lds, st, a); break;
@@ -409,7 +440,7 @@ extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t l
       default: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, Big>), grid, dim3(Big::THREADS), lds, st, a); break;
     }
   } else {
-    const dim3 grid(static_cast<unsigned>(mdg_cdiv(N, Small::BN)), static_cast<unsigned>(mdg_cdiv(M, Small::BM)));
+    const dim3 grid = grid_for(Small::BM, Small::BN);
     const size_t lds = 2 * Small::STAGE;
     switch (precision) {
       case MDG_PREC_F32: hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, Small>), grid, dim3(Small::THREADS), lds, st, a); break;

@@ -47,6 +47,46 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(const float* __restri
   if (lane == 0) row_loss[i] = (logf(s) + m) - lp;
 }
 
+// Backward of the InfoNCE finish: d loss / d sim[i,j] = dloss / (2B T) * (softmax_j(logits[i,:]) - [j == positive(i)]) for
+// j != i, 0 on the diagonal; entries replaced by -1e9 (too-hard negatives) are constants of the graph (masked_fill).
+// One wave per row; the row's max / sum are recomputed from sim.  dloss is read from device memory.
+__global__ __launch_bounds__(256) void infonce_bwd_rows_kernel(const float* __restrict__ sim, const uint8_t* __restrict__ hard,
+                                                               const float* __restrict__ dloss, float* __restrict__ dsim, int B, float inv_T) {
+  const int lane = threadIdx.x & 63;
+  const int n2 = 2 * B;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n2) return;
+  const int ib = i % B;
+  const int pos = (i + B) % n2;
+  const float* srow = sim + static_cast<int64_t>(i) * n2;
+  float m = -INFINITY;
+  for (int j = lane; j < n2; j += 64) {
+    if (j == i) continue;
+    float v = srow[j];
+    if (hard && hard[static_cast<int64_t>(ib) * B + (j % B)]) v = -1e9f;
+    m = fmaxf(m, v * inv_T);
+  }
+  m = mdg_wave_max(m);
+  float s = 0.f;
+  for (int j = lane; j < n2; j += 64) {
+    if (j == i) continue;
+    float v = srow[j];
+    if (hard && hard[static_cast<int64_t>(ib) * B + (j % B)]) v = -1e9f;
+    s += expf(v * inv_T - m);
+  }
+  s = mdg_wave_sum(s);
+  const float scale = dloss[0] * inv_T / static_cast<float>(n2);
+  float* drow = dsim + static_cast<int64_t>(i) * n2;
+  for (int j = lane; j < n2; j += 64) {
+    float g = 0.f;
+    if (j != i) {
+      const bool masked = hard && hard[static_cast<int64_t>(ib) * B + (j % B)];
+      if (!masked) g = scale * (expf(srow[j] * inv_T - m) / s - (j == pos ? 1.f : 0.f));
+    }
+    drow[j] = g;
+  }
+}
+
 // mean of n floats -> out[0]; single workgroup, fixed summation order (reproducible)
 __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
   __shared__ float part[4];
@@ -90,6 +130,16 @@ extern "C" int mdg_infonce_finish(const float* sim, const uint8_t* too_hard_neg,
                      labels, row_loss, static_cast<int>(B), 1.0f / temperature);
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, row_loss, loss, 2 * B);
   MDG_CHECK_LAUNCH("mdg_infonce_finish");
+  return MDG_OK;
+}
+
+extern "C" int mdg_infonce_bwd(const float* sim, const uint8_t* too_hard_neg, const float* dloss, float* dsim, int64_t B, float temperature,
+                               void* stream) {
+  MDG_CHECK_ARG(B >= 1 && B <= (1 << 20) && temperature > 0.f, "mdg_infonce_bwd: bad B / temperature");
+  MDG_CHECK_ARG(sim && dloss && dsim && sim != dsim, "mdg_infonce_bwd: null / aliased pointer");
+  hipLaunchKernelGGL(infonce_bwd_rows_kernel, dim3(static_cast<unsigned>(mdg_cdiv(2 * B, 4))), dim3(256), 0, static_cast<hipStream_t>(stream), sim,
+                     too_hard_neg, dloss, dsim, static_cast<int>(B), 1.0f / temperature);
+  MDG_CHECK_LAUNCH("mdg_infonce_bwd");
   return MDG_OK;
 }
 

@@ -1297,8 +1297,19 @@ class NovelDDIEncoder(nn.Module):
             rows_f = max(int(batch_drugs.max().item()) + 1, int(kg_map.max().item()) + 1)
             filler = torch.randn((rows_f, Dm), device=dev)
 
+        # ``kg_share`` (extension, a dict owned by the caller): the KG encoder sees the same graph on the head and on the
+        # tail side of one step and has neither dropout nor batch statistics, so its two passes are identical; the
+        # second side reuses the first side's node embeddings (the tape then adds both sides' gradients into one
+        # backward pass — the same sum the reference forms from its two identical passes).
+        share = kwargs.get('kg_share')
+
         def run_kg():
-            kg_valid = self.kg_encoder(kg_data.x_dict, kg_data.edge_index_dict, only_types=('drug',))['drug']
+            key = (id(kg_data), "drug")
+            kg_valid = None if share is None else share.get(key)
+            if kg_valid is None:
+                kg_valid = self.kg_encoder(kg_data.x_dict, kg_data.edge_index_dict, only_types=('drug',))['drug']
+                if share is not None:
+                    share[key] = kg_valid
             table = filler.to(dev).clone()
             table[kg_map] = kg_valid
             return table[batch_drugs]
@@ -1394,6 +1405,8 @@ class NovelDDIMultilabel(nn.Module):
         # the reference encodes head and tail separately even when they are the same object (full-batch mode,
         # train_ddi_batch.py:285); in eval mode the two results are identical, so one pass is reused.
         self.reuse_identical_sides = True
+        # the KG encoder is deterministic and stateless (no dropout, no BatchNorm): head and tail side share one pass
+        self.share_kg_between_sides = True
 
     def forward(self, batch_head, batch_tail, batch_head_mod_masks, batch_tail_mod_masks, batch_kg, label_range=None,
                 single_drug=False, **kwargs):
@@ -1404,6 +1417,9 @@ class NovelDDIMultilabel(nn.Module):
         """Head- and tail-side embeddings exactly as ``forward`` feeds them to the decoder (models.py:940-951).  In
         training mode the two sides are encoded separately even when they are the same batch (independent dropout
         masks / one BatchNorm update per side, as the reference does)."""
+        if self.share_kg_between_sides and 'kg_share' not in kwargs:
+            kwargs = dict(kwargs, kg_share={})
+
         def enc(b, m):
             return self.encoder(b['drugs'], m, b['strs'], batch_kg, b['cv'], b['tx'], **kwargs)
         z_head = enc(batch_head, batch_head_mod_masks)

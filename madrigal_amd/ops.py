@@ -868,3 +868,14 @@ def grad_weight(g: torch.Tensor, x: torch.Tensor, precision="f32", want_bias: bo
     check(lib().mdg_grad_weight(_ptr(g), _c64(g.stride(0)), _ptr(x), _c64(x.stride(0)), _ptr(dw), _ptr(db), _c64(M), _c64(N), _c64(K),
                                 _ptr(ws), ctypes.c_size_t(nbytes), _stream(g)), "mdg_grad_weight")
     return (dw, db) if want_bias else dw
+
+
+def info_nce_bwd(sim: torch.Tensor, too_hard_neg: Optional[torch.Tensor], dloss: torch.Tensor, temperature: float) -> torch.Tensor:
+    """d loss / d sim for the InfoNCE finish (sim = F F^T [2B,2B]); ``dloss`` is a device scalar."""
+    sim = _f32_cuda(sim, "sim", 2)
+    B = sim.shape[0] // 2
+    hard = None if too_hard_neg is None else too_hard_neg.to(device=sim.device, dtype=torch.uint8).contiguous()
+    dsim = torch.empty_like(sim)
+    check(lib().mdg_infonce_bwd(_ptr(sim), _ptr(hard), _ptr(_f32_cuda(dloss.reshape(1), "dloss", 1)), _ptr(dsim), _c64(B), _f(temperature),
+                                _stream(sim)), "mdg_infonce_bwd")
+    return dsim

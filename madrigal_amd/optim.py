@@ -25,6 +25,7 @@ class AdamW(torch.optim.Optimizer):
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
         self._chunk = int(lib().mdg_adamw_chunk_elems())
+        self._layouts = {}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -53,29 +54,33 @@ class AdamW(torch.optim.Optimizer):
                 hyper = (group["lr"], b1, b2, group["eps"], group["weight_decay"], 1.0 / (1.0 - b1 ** k), 1.0 / math.sqrt(1.0 - b2 ** k), 0.0)
                 by_dev.setdefault(p.device, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], hyper))
         for dev, items in by_dev.items():
-            ptrs, lens, owner, hyp = [], [], [], []
-            for ti, (p, g, m, v, h) in enumerate(items):
-                hyp.append(h)
-                n = p.numel()
-                for off in range(0, n, self._chunk):
-                    b = off * 4
-                    ptrs.append((p.data_ptr() + b, g.data_ptr() + b, m.data_ptr() + b, v.data_ptr() + b))
-                    lens.append(min(self._chunk, n - off))
-                    owner.append(ti)
-            if not ptrs:
+            # chunk layout (offsets / lengths / owning tensor) depends only on the tensor sizes: built once, vectorised
+            sizes = tuple(p.numel() for p, *_ in items)
+            lay = self._layouts.get((dev, sizes))
+            if lay is None:
+                offs, lens, owner = [], [], []
+                for ti, n in enumerate(sizes):
+                    o = np.arange(0, n, self._chunk, dtype=np.int64)
+                    offs.append(o * 4)
+                    lens.append(np.minimum(self._chunk, n - o).astype(np.int32))
+                    owner.append(np.full(o.shape, ti, dtype=np.int32))
+                offs, lens, owner = (np.concatenate(a) if a else np.zeros(0, dtype=np.int64) for a in (offs, lens, owner))
+                lay = {"offs": offs, "owner": owner, "n": int(offs.shape[0]), "t_len": torch.from_numpy(lens).to(dev),
+                       "t_own": torch.from_numpy(owner).to(dev), "base": None, "t_ptr": None}
+                self._layouts[(dev, sizes)] = lay
+            if lay["n"] == 0:
                 continue
-            # one small pinned upload per table; the arrays stay referenced until the launch is enqueued
-            t_ptr = torch.from_numpy(np.asarray(ptrs, dtype=np.int64)).to(dev, non_blocking=False)
-            t_len = torch.from_numpy(np.asarray(lens, dtype=np.int32)).to(dev)
-            t_own = torch.from_numpy(np.asarray(owner, dtype=np.int32)).to(dev)
-            t_hyp = torch.from_numpy(np.asarray(hyp, dtype=np.float32)).to(dev)
+            base = np.asarray([(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()) for p, g, m, v, _ in items], dtype=np.int64)
+            if lay["base"] is None or not np.array_equal(base, lay["base"]):       # the allocator usually hands the same blocks back
+                lay["base"] = base
+                lay["t_ptr"] = torch.from_numpy(base[lay["owner"]] + lay["offs"][:, None]).to(dev)
+            t_hyp = torch.from_numpy(np.asarray([h for *_, h in items], dtype=np.float32)).to(dev)
             with torch.cuda.device(dev):
-                check(lib().mdg_adamw_multi(ctypes.c_void_p(t_ptr.data_ptr()), ctypes.c_void_p(t_len.data_ptr()),
-                                            ctypes.c_void_p(t_own.data_ptr()), ctypes.c_void_p(t_hyp.data_ptr()),
-                                            ctypes.c_int64(len(lens)), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                check(lib().mdg_adamw_multi(ctypes.c_void_p(lay["t_ptr"].data_ptr()), ctypes.c_void_p(lay["t_len"].data_ptr()),
+                                            ctypes.c_void_p(lay["t_own"].data_ptr()), ctypes.c_void_p(t_hyp.data_ptr()),
+                                            ctypes.c_int64(lay["n"]), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
                       "mdg_adamw_multi")
-            for t in (t_ptr, t_len, t_own, t_hyp):
-                t.record_stream(torch.cuda.current_stream(dev))
+            t_hyp.record_stream(torch.cuda.current_stream(dev))
             # the kernel wrote the parameters and the moments behind torch's back: bump their in-place version counters so
             # that everything keyed on them (packed / derived weight caches of the inference path, autograd's saved-tensor
             # checks) sees the update

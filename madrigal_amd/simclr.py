@@ -2,15 +2,17 @@
 
 ``SimCLR_NovelDDI`` keeps the reference's constructor, attribute names (``base_encoder``, ``predictor_1``,
 ``predictor_2`` / ``predictor``) and return value ``(aug_1, aug_2, (logits, labels, loss))``
-(madrigal/models/simclr.py:11-140).  Forward-only this release: eval-mode BatchNorm in the predictor MLPs.
+(madrigal/models/simclr.py:11-140).  In training mode (pretrain.py) the encoder, the predictor MLPs (BatchNorm batch
+statistics) and the InfoNCE loss record a tape through madrigal_amd.autograd; forward and backward run in HIP kernels.
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 
+from . import autograd as ag
 from . import ops
-from .models import _require_eval, _run_sequential, get_precision
+from .models import _run_sequential, _run_sequential_train, _train_path, get_precision
 
 
 class SimCLR_NovelDDI(nn.Module):
@@ -45,11 +47,12 @@ class SimCLR_NovelDDI(nn.Module):
 
     def contrastive_loss(self, aug1, aug2, batch_too_hard_neg_mask):
         """simclr.py:74-108 -> (logits [2B,2B-1], labels [2B,2B-1], loss)."""
+        if ag.needs_grad(aug1, aug2):
+            return ag.info_nce(aug1, aug2, batch_too_hard_neg_mask, float(self.T), precision=get_precision())
         return ops.info_nce(aug1, aug2, batch_too_hard_neg_mask, float(self.T), precision=get_precision())
 
     def forward(self, drug_indices, batch_mask_1, batch_mask_2, batch_too_hard_neg_mask, batch_data, batch_extra_mols=None,
                 batch_extra_masks=None):
-        _require_eval(self)
         batch_mols, batch_kg, batch_cv, batch_tx_dict = batch_data
         p1 = self.predictor if self.shared_predictor else self.predictor_1
         p2 = self.predictor if self.shared_predictor else self.predictor_2
@@ -57,5 +60,6 @@ class SimCLR_NovelDDI(nn.Module):
                                raw_encoder_output=self.raw_encoder_output)
         e2 = self.base_encoder(drug_indices, batch_mask_2, batch_mols, batch_kg, batch_cv, batch_tx_dict,
                                raw_encoder_output=self.raw_encoder_output)
-        aug_1, aug_2 = _run_sequential(p1, e1), _run_sequential(p2, e2)
+        run = _run_sequential_train if (_train_path(self) or ag.needs_grad(e1, e2)) else _run_sequential
+        aug_1, aug_2 = run(p1, e1), run(p2, e2)
         return aug_1, aug_2, self.contrastive_loss(aug_1, aug_2, batch_too_hard_neg_mask)

@@ -793,3 +793,96 @@ def test_inference_after_training_sees_the_updated_weights():
         want = fresh(b, b, b["masks"], b["masks"], kgc, kg_filler=filler)
     assert float((after - before).abs().max()) > 1e-3 * float(before.abs().max())      # the steps moved the scores
     assert torch.equal(after, want)                                                     # and no cache is stale
+
+
+# ---------------------------------------------------------------------------------------------- contrastive pretraining
+def _torch_contrastive_loss(aug1, aug2, hard, T):
+    """madrigal/models/simclr.py:74-108 (soft-label CrossEntropy over the off-diagonal similarities)."""
+    F = torch.nn.functional
+    features = F.normalize(torch.cat([aug1, aug2], dim=0), dim=1)
+    n2 = features.shape[0]
+    labels = torch.cat([torch.arange(aug1.shape[0])] * 2, dim=0)
+    labels = (labels.unsqueeze(0) == labels.unsqueeze(1)).to(features.dtype)
+    sim = features @ features.T
+    if hard is not None:
+        sim = sim.masked_fill(hard.repeat(2, 2), -1e9)
+    mask = torch.eye(n2, dtype=torch.bool)
+    labels = labels[~mask].view(n2, -1)
+    sim = sim[~mask].view(n2, -1)
+    logits = sim / T
+    return logits, labels, torch.nn.CrossEntropyLoss()(logits, labels)
+
+
+@pytest.mark.parametrize("B,with_hard,T", [(37, True, 0.5), (256, False, 1.0), (130, True, 0.1)])
+def test_infonce_and_predictors_gradients_match_torch(B, with_hard, T):
+    from madrigal_amd import models as M
+    from madrigal_amd.models import _run_sequential_train
+    from madrigal_amd.simclr import SimCLR_NovelDDI
+    torch.manual_seed(8)
+    p1 = SimCLR_NovelDDI._build_mlp(2, 128, 256, 128)
+    p2 = SimCLR_NovelDDI._build_mlp(2, 128, 256, 128)
+    r1, r2 = copy.deepcopy(p1).double().train(), copy.deepcopy(p2).double().train()
+    p1, p2 = p1.to(DEV).train(), p2.to(DEV).train()
+    e1, e2 = _rand(B, 128, seed=1), _rand(B, 128, seed=2)
+    hard = None
+    if with_hard:
+        hard = torch.rand(B, B, generator=torch.Generator().manual_seed(3)) < 0.05
+        hard = (hard | hard.T) & ~torch.eye(B, dtype=torch.bool)
+    x1, x2 = e1.double().requires_grad_(True), e2.double().requires_grad_(True)
+    lg_r, lb_r, loss_r = _torch_contrastive_loss(r1(x1), r2(x2), hard, T)
+    loss_r.backward()
+    g1, g2 = e1.to(DEV).requires_grad_(True), e2.to(DEV).requires_grad_(True)
+    holder = SimCLR_NovelDDI.__new__(SimCLR_NovelDDI)          # the loss method only reads self.T
+    torch.nn.Module.__init__(holder)
+    holder.T = T
+    with M.precision("f32"):                                     # ReLU in the predictors: exact-fp32 comparison
+        a1, a2 = _run_sequential_train(p1, g1), _run_sequential_train(p2, g2)
+        lg, lb, loss = holder.contrastive_loss(a1, a2, None if hard is None else hard.to(DEV))
+        (loss * 2.0).backward()
+    keep = lg_r.abs() < 1e8                                      # masked entries are -1e9 / T on both sides
+    _close(lg.cpu()[keep], lg_r[keep], 2e-5, "logits")
+    assert torch.equal(lb.cpu().double(), lb_r)
+    _close(loss, loss_r, 2e-5, "InfoNCE loss")
+    _close(g1.grad, 2.0 * x1.grad, 5e-5, "d e1")
+    _close(g2.grad, 2.0 * x2.grad, 5e-5, "d e2")
+    gmax = max(float(q.grad.abs().max()) for q in list(r1.parameters()) + list(r2.parameters()))
+    for mine, ref in ((p1, r1), (p2, r2)):
+        for (name, pg), (_, pr) in zip(mine.named_parameters(), ref.named_parameters()):
+            _close(pg.grad, 2.0 * pr.grad, 5e-5, name, floor=1e-2 * gmax)
+
+
+def test_simclr_pretraining_step_runs_end_to_end():
+    """SimCLR_NovelDDI.forward in training mode (pretrain.py:168): two masked views through the encoder's uni-modal
+    projector branch, predictors, InfoNCE; the loss decreases under AdamW and a run is reproducible."""
+    from madrigal_amd import data as D, models as M
+    from madrigal_amd.optim import AdamW
+    from madrigal_amd.simclr import SimCLR_NovelDDI
+    from test_models_gpu import build_model
+    case = ("twosides105", "transformer_uni_proj", 2, "learnable", 2, 64, 128, 1, True, "x-attn", True, False)
+    n, seed = 96, 12
+
+    def run(steps):
+        torch.manual_seed(seed)
+        masks = D.make_masks(n, seed)
+        batch, bkg = D.make_batch(n, seed, kg_nodes=600, kg_edges=6000, masks=masks)
+        enc = build_model(M, case, bkg["data"], 4).encoder
+        model = SimCLR_NovelDDI(enc, dim=128, mlp_dim=256, T=0.5, raw_encoder_output=False).cuda().train()
+        b = D.batch_to(batch, "cuda")
+        kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
+        m1 = b["masks"].clone()
+        m2 = b["masks"].clone()
+        m2[:, 1:] = True                                        # second view: structure only
+        opt = AdamW(model.parameters(), lr=1e-4, weight_decay=0.0)
+        losses = []
+        torch.manual_seed(99)
+        filler = torch.randn(n, 128, generator=torch.Generator().manual_seed(1)).cuda()
+        for _ in range(steps):
+            opt.zero_grad(set_to_none=True)
+            _, _, (_, _, loss) = model(b["drugs"], m1, m2, None, (b["strs"], kgc, b["cv"], b["tx"]))
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        return losses
+    l1, l2 = run(8), run(8)
+    assert all(np.isfinite(l1)) and l1[-1] < l1[0], l1
+    assert l1 == l2
