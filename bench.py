@@ -82,30 +82,49 @@ def cpu_baseline(n_drugs: int, n_outcomes: int, seconds: float = 12.0):
                       f"extrapolated linearly in rows"}
 
 
-def finetune_leg(model, batch, bkg, filler, N, L, args):
+def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend="nccl"):
     """DDI-finetune steps/s on the same model and batch (train_ddi_batch.py:275-350, 'full_full' mode): zero_grad ->
-    encode head and tail side (training mode: dropout, BatchNorm batch statistics) -> scores of T labelled triples
-    (gathered head) -> BCE -> backward through every encoder -> AdamW over the reference's parameter groups."""
+    encode head and tail side (training mode: dropout, BatchNorm batch statistics) -> scores of the labelled triples
+    (gathered head) -> BCE -> backward through every encoder -> AdamW over the reference's parameter groups.
+    world > 1: the SAME step data-parallel (strong scaling): drug-sharded encoders with SyncBatchNorm, all-gather of the
+    embeddings, triples dealt to the ranks, flat all-reduce of the gradients (madrigal_amd/train.py)."""
     import torch
+    import torch.distributed as dist
     from madrigal_amd import data as D
     from madrigal_amd.optim import create_optimizer
     from madrigal_amd.train import FinetuneStep
     dev = batch["cv"].device
-    T = args.finetune_triples
-    lab, hd, tl, y = (t.to(dev) for t in D.make_labelled_triples(N, L, T, 0))
+    if world > 1:                                      # the headline gave every rank its own outcomes: one model again
+        with torch.no_grad():
+            model.decoder.parametrizations.weight.original.copy_(
+                torch.randn(L, 128, 128, generator=torch.Generator().manual_seed(1000)) / 128 ** 0.5)
+    lab, hd, tl, y = (t.to(dev) for t in D.make_labelled_triples(N, L, args.finetune_triples, 0))
+    T = int(lab.numel())
     hp = dict(optimizer="adamw", structure_encoder_lr=1e-5, kg_encoder_lr=1e-5, perturb_encoders_lr=1e-5, fusion_lr=1e-6, decoder_lr=1e-4,
               wd=1e-2, beta1=0.9, beta2=0.999, eps=1e-8)
-    fs = FinetuneStep(model, create_optimizer(model, hp))
+    fs = FinetuneStep(model, create_optimizer(model, hp), rank=rank, world=world)
+    torch.manual_seed(4321 + rank)
     losses = [float(fs.step(batch, batch, batch["masks"], batch["masks"], bkg, lab, hd, tl, y, kg_filler=filler))]     # warm-up
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.finetune_steps):
         losses.append(fs.step(batch, batch, batch["masks"], batch["masks"], bkg, lab, hd, tl, y, kg_filler=filler))
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.finetune_steps
-    return {"metric": "DDI-finetune steps/sec", "value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "n_gpus": 1,
-            "steps": args.finetune_steps, "warmup": 1, "triples_per_step": T, "drugs": N, "outcomes": L,
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev if backend != "gloo" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    dt /= args.finetune_steps
+    return {"metric": "DDI-finetune steps/sec", "value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "n_gpus": world,
+            "scaling": "strong", "steps": args.finetune_steps, "warmup": 1, "triples_per_step": T, "drugs": N, "outcomes": L,
             "loss_first_last": [float(losses[0]), float(losses[-1])],
+            "parallelism": "single GPU" if world == 1 else
+            f"drug-sharded encoders (SyncBatchNorm), all-gather(z) / reduce-scatter(dz), triples dealt to {world} ranks, flat gradient all-reduce",
             "work": "optimizer.zero_grad, encode+fuse head side and tail side (training mode), gathered bilinear head on the "
                     "labelled triples, BCE, backward through all encoders, AdamW step"}
 
@@ -125,7 +144,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--finetune-steps", type=int, default=3, help="second half of BASELINE's metric: DDI-finetune steps/s "
                     "(encode both sides + gathered head + BCE + backward + AdamW), timed at N=1 after the headline; 0 = skip")
-    ap.add_argument("--finetune-triples", type=int, default=1_000_000)
+    ap.add_argument("--finetune-triples", type=int, default=1_000_000, help="positive triples; with 2 negatives each and both "
+                    "directions (the reference's collation) 6x as many labelled triples per step")
     args = ap.parse_args()
 
     import torch
@@ -214,6 +234,11 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    finetune = None
+    if args.finetune_steps > 0 and not args.head_only:
+        del out
+        torch.cuda.empty_cache()
+        finetune = finetune_leg(model, batch, bkg, filler, N, L, args, rank, world, backend)
     enc_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     head_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps     # head launch (+ its two operand-split pre-passes)
     value = float(L) * N * N * world * args.steps / dt
@@ -249,10 +274,8 @@ def main():
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, L)
-        if world == 1 and args.finetune_steps > 0 and not args.head_only:
-            del out
-            torch.cuda.empty_cache()
-            line["finetune"] = finetune_leg(model, batch, bkg, filler, N, L, args)
+        if finetune is not None:
+            line["finetune"] = finetune
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -319,6 +319,20 @@ int mdg_batchnorm_train_fwd(const float* x, int64_t ldx, const float* gamma, con
 int mdg_batchnorm_train_bwd(const float* dy, const float* x, const float* stats, float* dx, float* dgamma, float* dbeta,
                             int64_t rows, int64_t cols, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The phases of mdg_batchnorm_train_fwd / _bwd as separate calls, for SyncBatchNorm over drug-sharded ranks: the caller
+ * all-reduces the per-column sums between phases (count = rows over all ranks).
+ *   mdg_col_reduce mode 0: out[c] = sum_r x;  1: sum_r (x - center[c])^2;  2: sum_r x * (y - center[c]) * rstd[c]
+ *   mdg_batchnorm_finalize phase 0: stats[0:C] = sum / count;  phase 1: rstd | scale | shift from sqsum / count and the
+ *   running-statistics update;  then mdg_affine_act(x, stats + 2C, stats + 3C) applies the normalisation.
+ *   mdg_batchnorm_bwd_apply: dx from the (all-reduced) sum_dy and sum_dy_xhat. */
+int mdg_col_reduce(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* center, const float* rstd, float* out,
+                   int64_t rows, int64_t cols, int mode, void* workspace, size_t workspace_bytes, void* stream);
+int mdg_batchnorm_finalize(const float* sum, const float* sqsum, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float* stats, double count, int64_t cols, float eps, float momentum, int phase,
+                           void* stream);
+int mdg_batchnorm_bwd_apply(const float* dy, const float* x, const float* stats, const float* sum_dy, const float* sum_dy_xhat,
+                            float* dx, int64_t rows, int64_t cols, double count, void* stream);
+
 /* y = act(x * scale[c] + shift[c]) per column (eval-mode BatchNorm inside a differentiated graph; shift may be NULL). */
 int mdg_affine_act(const float* x, int64_t ldx, const float* scale, const float* shift, float* y, int64_t ldy, int64_t rows,
                    int64_t cols, int activation, void* stream);

@@ -88,6 +88,41 @@ def layernorm(x, weight, bias, eps=1e-5):
     return _LayerNorm.apply(x, weight, bias, eps)
 
 
+_bn_sync = {"reduce": None}
+
+
+def set_batchnorm_sync(reduce_fn) -> None:
+    """Data-parallel training: ``reduce_fn(t)`` sums a small device tensor over ranks in place; BatchNorm batch statistics
+    (and their backward sums) are then taken over every rank's rows (SyncBatchNorm).  None switches it off."""
+    _bn_sync["reduce"] = reduce_fn
+
+
+class _SyncBatchNormAct(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, reduce_):
+        x = x if x.is_contiguous() else x.contiguous()
+        fused = act if act in (None, "none", "relu") else None
+        y, stats, count = ops.sync_batchnorm_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, fused, reduce_)
+        pre = None
+        if act == "relu":
+            pre = y
+        elif fused is None and act not in (None, "none"):
+            pre, y = y, ops.activation_fwd(y, act)
+        ctx.save_for_backward(x, stats, pre)
+        ctx.act, ctx.affine, ctx.count, ctx.reduce_ = act, gamma is not None, count, reduce_
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, stats, pre = ctx.saved_tensors
+        g = dy if dy.is_contiguous() else dy.contiguous()
+        if pre is not None:
+            g = ops.activation_bwd(g, pre, ctx.act)
+        dx, dg, db = ops.sync_batchnorm_train_bwd(g, x, stats, ctx.count, ctx.reduce_)
+        return dx, (dg if ctx.affine else None), (db if ctx.affine else None), None, None, None, None, None, None
+
+
 class _BatchNormAct(Function):
     """nn.BatchNorm1d with batch statistics, fused with the activation that follows it."""
 
@@ -124,6 +159,8 @@ def batchnorm_act(x, bn: torch.nn.BatchNorm1d, act=None):
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    if _bn_sync["reduce"] is not None:
+        return _SyncBatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, act, _bn_sync["reduce"])
     return _BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, act)
 
 

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(const float* __r
 // nn.BatchNorm1d (momentum, unbiased variance).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sqsum, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var, float* __restrict__ stats, int64_t rows,
+                                                          float* __restrict__ running_var, float* __restrict__ stats, double rows,
                                                           int64_t cols, float eps, float momentum, int phase) {
   const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (c >= cols) return;
@@ -216,11 +216,11 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
 // dx = scale[c] * (dy - sum_dy[c]/M - xhat * sum_dy_xhat[c]/M),  xhat = (x - mean[c]) * rstd[c]
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
                                                            const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat,
-                                                           float* __restrict__ dx, int64_t rows, int64_t cols) {
+                                                           float* __restrict__ dx, int64_t rows, int64_t cols, float count) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= rows * cols) return;
   const int64_t c = i % cols;
-  const float inv = 1.0f / static_cast<float>(rows);
+  const float inv = 1.0f / count;
   const float xhat = (x[i] - stats[c]) * stats[cols + c];
   dx[i] = stats[2 * cols + c] * (dy[i] - sum_dy[c] * inv - xhat * (sum_dy_xhat[c] * inv));
 }
@@ -402,9 +402,9 @@ extern "C" int mdg_batchnorm_train_fwd(const float* x, int64_t ldx, const float*
   float* part = sq + cols;
   const unsigned gb = static_cast<unsigned>(mdg_cdiv(cols, 256));
   colreduce(x, ldx, nullptr, 0, nullptr, nullptr, sum, rows, cols, 0, part, st);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(gb), dim3(256), 0, st, sum, sq, gamma, beta, running_mean, running_var, stats, rows, cols, eps, momentum, 0);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(gb), dim3(256), 0, st, sum, sq, gamma, beta, running_mean, running_var, stats, static_cast<double>(rows), cols, eps, momentum, 0);
   colreduce(x, ldx, nullptr, 0, stats, nullptr, sq, rows, cols, 1, part, st);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(gb), dim3(256), 0, st, sum, sq, gamma, beta, running_mean, running_var, stats, rows, cols, eps, momentum, 1);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(gb), dim3(256), 0, st, sum, sq, gamma, beta, running_mean, running_var, stats, static_cast<double>(rows), cols, eps, momentum, 1);
   hipLaunchKernelGGL(affine_act_kernel, dim3(static_cast<unsigned>(mdg_cdiv(rows * cols, 256))), dim3(256), 0, st, x, ldx, stats + 2 * cols,
                      stats + 3 * cols, y, ldy, rows, cols, activation);
   MDG_CHECK_LAUNCH("mdg_batchnorm_train_fwd");
@@ -425,7 +425,7 @@ extern "C" int mdg_batchnorm_train_bwd(const float* dy, const float* x, const fl
   colreduce(dy, cols, nullptr, 0, nullptr, nullptr, dbeta, rows, cols, 0, part, st);
   colreduce(dy, cols, x, cols, stats, stats + cols, dgamma, rows, cols, 2, part, st);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(static_cast<unsigned>(mdg_cdiv(rows * cols, 256))), dim3(256), 0, st, dy, x, stats, dbeta, dgamma,
-                     dx, rows, cols);
+                     dx, rows, cols, static_cast<float>(rows));
   MDG_CHECK_LAUNCH("mdg_batchnorm_train_bwd");
   return MDG_OK;
 }
@@ -517,5 +517,50 @@ extern "C" int mdg_gated_residual_bwd(const float* dout, const float* o, const f
   hipLaunchKernelGGL(gated_residual_bwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(rows, 4))), dim3(256), 0, static_cast<hipStream_t>(stream), dout, o, x,
                      skip, d_o, d_x, rowdot, rows, static_cast<int>(cols));
   MDG_CHECK_LAUNCH("mdg_gated_residual_bwd");
+  return MDG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- BatchNorm1d in phases
+// The same kernels as mdg_batchnorm_train_fwd/bwd, one phase per call, so that a data-parallel caller can all-reduce the
+// per-column sums between phases (SyncBatchNorm over drug-sharded ranks): statistics over ALL ranks' rows.
+extern "C" int mdg_col_reduce(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* center, const float* rstd, float* out,
+                              int64_t rows, int64_t cols, int mode, void* workspace, size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(rows >= 0 && cols > 0 && ldx >= cols && mode >= 0 && mode <= 2, "mdg_col_reduce: bad arguments");
+  MDG_CHECK_ARG(out && (mode != 1 || center) && (mode != 2 || (y && center && rstd && ldy >= cols)), "mdg_col_reduce: missing operand for this mode");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (rows == 0) {
+    (void)hipMemsetAsync(out, 0, static_cast<size_t>(cols) * sizeof(float), st);
+    return MDG_OK;
+  }
+  MDG_CHECK_ARG(x, "mdg_col_reduce: null x");
+  const size_t need = mdg_batchnorm_workspace_bytes(rows, cols);
+  if (!workspace || workspace_bytes < need) {
+    mdg_set_error("mdg_col_reduce: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return MDG_EWORKSPACE;
+  }
+  colreduce(x, ldx, y, ldy, center, rstd, out, rows, cols, mode, static_cast<float*>(workspace), st);
+  MDG_CHECK_LAUNCH("mdg_col_reduce");
+  return MDG_OK;
+}
+
+extern "C" int mdg_batchnorm_finalize(const float* sum, const float* sqsum, const float* gamma, const float* beta, float* running_mean,
+                                      float* running_var, float* stats, double count, int64_t cols, float eps, float momentum, int phase,
+                                      void* stream) {
+  MDG_CHECK_ARG(cols > 0 && count > 1.0 && (phase == 0 || phase == 1), "mdg_batchnorm_finalize: bad arguments (needs more than one row in total)");
+  MDG_CHECK_ARG(stats && sum && (phase == 0 || sqsum), "mdg_batchnorm_finalize: null pointer");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), sum, sqsum,
+                     gamma, beta, running_mean, running_var, stats, count, cols, eps, momentum, phase);
+  MDG_CHECK_LAUNCH("mdg_batchnorm_finalize");
+  return MDG_OK;
+}
+
+extern "C" int mdg_batchnorm_bwd_apply(const float* dy, const float* x, const float* stats, const float* sum_dy, const float* sum_dy_xhat,
+                                       float* dx, int64_t rows, int64_t cols, double count, void* stream) {
+  MDG_CHECK_ARG(rows >= 0 && cols > 0 && count > 1.0, "mdg_batchnorm_bwd_apply: bad shape");
+  if (rows == 0) return MDG_OK;
+  MDG_CHECK_ARG(dy && x && stats && sum_dy && sum_dy_xhat && dx, "mdg_batchnorm_bwd_apply: null pointer");
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(static_cast<unsigned>(mdg_cdiv(rows * cols, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), dy, x,
+                     stats, sum_dy, sum_dy_xhat, dx, rows, cols, static_cast<float>(count));
+  MDG_CHECK_LAUNCH("mdg_batchnorm_bwd_apply");
   return MDG_OK;
 }

@@ -879,3 +879,53 @@ def info_nce_bwd(sim: torch.Tensor, too_hard_neg: Optional[torch.Tensor], dloss:
     check(lib().mdg_infonce_bwd(_ptr(sim), _ptr(hard), _ptr(_f32_cuda(dloss.reshape(1), "dloss", 1)), _ptr(dsim), _c64(B), _f(temperature),
                                 _stream(sim)), "mdg_infonce_bwd")
     return dsim
+
+
+# ------------------------------------------------------------------------------- SyncBatchNorm (phased BatchNorm)
+def _col_reduce(x, y, center, rstd, mode: int) -> torch.Tensor:
+    R, C = x.shape
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    nbytes = lib().mdg_batchnorm_workspace_bytes(_c64(max(R, 1)), _c64(C))
+    ws = _workspace(nbytes, x.device)
+    check(lib().mdg_col_reduce(_ptr(x), _c64(x.stride(0)), _ptr(y), _c64(0 if y is None else y.stride(0)), _ptr(center), _ptr(rstd), _ptr(out),
+                               _c64(R), _c64(C), _c(mode), _ptr(ws), ctypes.c_size_t(nbytes), _stream(x)), "mdg_col_reduce")
+    return out
+
+
+def sync_batchnorm_train_fwd(x: torch.Tensor, gamma, beta, running_mean, running_var, eps: float, momentum: float, act, reduce_):
+    """BatchNorm1d training forward with statistics over all ranks: ``reduce_(t)`` sums a small device tensor over ranks
+    in place; ``count`` rows in total.  -> (y, stats[4C], count)."""
+    x = _f32_cuda(x, "x", 2)
+    R, C = x.shape
+    cnt = torch.tensor([float(R)], dtype=torch.float64, device=x.device)
+    s = _col_reduce(x, None, None, None, 0)
+    reduce_(s)
+    reduce_(cnt)
+    count = float(cnt.item())                       # one host read per layer (the row count of the other shards)
+    if count < 2:
+        raise ValueError("Expected more than 1 value per channel when training")
+    stats = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+    fin = lib().mdg_batchnorm_finalize
+    check(fin(_ptr(s), _ptr(None), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(stats), ctypes.c_double(count), _c64(C),
+              _f(eps), _f(momentum), _c(0), _stream(x)), "mdg_batchnorm_finalize")
+    q = _col_reduce(x, None, stats, None, 1)
+    reduce_(q)
+    check(fin(_ptr(s), _ptr(q), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(stats), ctypes.c_double(count), _c64(C),
+              _f(eps), _f(momentum), _c(1), _stream(x)), "mdg_batchnorm_finalize")
+    y = affine_act(x, stats[2 * C:3 * C], stats[3 * C:4 * C], act)
+    return y, stats, count
+
+
+def sync_batchnorm_train_bwd(dy: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, count: float, reduce_):
+    """-> (dx, dgamma_local, dbeta_local): dx uses the sums over ALL ranks, the parameter gradients stay local partial sums
+    (they are summed over ranks with every other parameter gradient)."""
+    dy, x = _f32_cuda(dy, "dy", 2), _f32_cuda(x, "x", 2)
+    R, C = x.shape
+    db = _col_reduce(dy, None, None, None, 0)
+    dg = _col_reduce(dy, x, stats[0:C], stats[C:2 * C], 2)
+    both = torch.cat([db, dg])
+    reduce_(both)
+    dx = torch.empty_like(x)
+    check(lib().mdg_batchnorm_bwd_apply(_ptr(dy), _ptr(x), _ptr(stats), _ptr(both[:C].contiguous()), _ptr(both[C:].contiguous()), _ptr(dx),
+                                        _c64(R), _c64(C), ctypes.c_double(count), _stream(x)), "mdg_batchnorm_bwd_apply")
+    return dx, dg, db

@@ -9,10 +9,11 @@ parallel by outcome (or by head row), each rank writing only its own slab of the
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import Iterable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+from torch.autograd import Function
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -50,3 +51,75 @@ def all_gather_rows(local: torch.Tensor, n_total: int, rank: int, world: int, gr
     buf = torch.empty((world * m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(buf, pad, group=group)
     return torch.cat([buf[r * m: r * m + sizes[r]] for r in range(world)], dim=0)
+
+
+# ------------------------------------------------------------------------------------------- data-parallel finetuning
+# Drug-sharded encoders (SyncBatchNorm statistics over all ranks), all-gather of the embeddings with a reduce-scatter
+# gradient, the labelled triples sharded over ranks for the gathered head, one flat all-reduce of the parameter
+# gradients: every rank then applies the same AdamW update.  (madrigal_amd/train.py: FinetuneStep(world > 1))
+
+def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum over ranks.  gloo + GPU tensors (several ranks rehearsing on one card) are staged through the host."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.detach().cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+        return t
+    dist.all_reduce(t, group=group)
+    return t
+
+
+class _AllGatherRowsGrad(Function):
+    """Every rank's row block concatenated in rank order; the gradient of a rank's block is the sum over ranks of the
+    corresponding slice of their gradients (reduce-scatter; the [N,128] embedding matrix is a few MB, so it is done
+    as one all-reduce + slice)."""
+
+    @staticmethod
+    def forward(ctx, local, n_total, rank, world, group):
+        ctx.meta = (n_total, rank, world, group)
+        return all_gather_rows(local.contiguous(), n_total, rank, world, group)
+
+    @staticmethod
+    def backward(ctx, dfull):
+        n_total, rank, world, group = ctx.meta
+        lo, hi = shard_range(n_total, rank, world)
+        g = all_reduce_sum_(dfull.contiguous().clone(), group)
+        return g[lo:hi].contiguous(), None, None, None, None
+
+
+def all_gather_rows_grad(local: torch.Tensor, n_total: int, rank: int, world: int, group=None) -> torch.Tensor:
+    return local if world == 1 else _AllGatherRowsGrad.apply(local, n_total, rank, world, group)
+
+
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 256 << 20) -> None:
+    """Sum the gradients of ``params`` over ranks in place, in flat buckets (one collective per ~256 MB: xGMI rings are
+    per-link bound, a few large messages beat hundreds of small ones).  A parameter without a gradient on this rank
+    (e.g. outcomes absent from the rank's triple shard) contributes zeros."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    ps = [p for p in params if p.requires_grad]
+    for p in ps:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+        all_reduce_sum_(flat, group)
+        off = 0
+        for p in bucket:
+            n = p.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+        bucket, size = [], 0
+    for p in ps:
+        bucket.append(p)
+        size += p.numel() * p.element_size()
+        if size >= bucket_bytes:
+            flush()
+    flush()

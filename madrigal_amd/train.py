@@ -14,16 +14,25 @@ import torch
 
 from . import autograd as ag
 from . import ops
+from .parallel import all_gather_rows_grad, all_reduce_sum_, allreduce_gradients, shard_range
+from .pipeline import slice_batch
 
 
 class FinetuneStep:
     """``step(...)`` = one optimizer step of the reference's 'full_full' / 'double_random' modes;
     ``accumulate(...)`` = one ``loss.backward()`` of the multi-pass modes (call it per mask pair, then ``apply()``)."""
 
-    def __init__(self, model, optimizer, loss_readout: str = "mean", scheduler=None):
+    def __init__(self, model, optimizer, loss_readout: str = "mean", scheduler=None, rank: int = 0, world: int = 1, group=None):
+        """``world > 1``: data-parallel step over one process per GPU (the reference is single-GPU).  Every rank
+        holds the full model and the full batch description; rank r encodes a contiguous block of drugs on both sides
+        (SyncBatchNorm statistics over all ranks; the KG encoder is per-graph and runs replicated, once per step), the
+        embedding blocks are all-gathered (reduce-scatter gradient), the labelled triples are dealt round-robin to the ranks
+        for the gathered head, and the parameter gradients are summed in flat buckets before the identical AdamW update."""
         self.model, self.optimizer, self.loss_readout, self.scheduler = model, optimizer, loss_readout, scheduler
+        self.rank, self.world, self.group = rank, world, group
         self._plan_key = None
         self._plan = None
+        self._shards = {}
 
     def plan(self, labels: torch.Tensor, heads: torch.Tensor, tails: torch.Tensor, n_head: int, n_tail: int) -> dict:
         """Label-sorted tiling of the triples, rebuilt only when the index tensors change (they are fixed for a run)."""
@@ -35,7 +44,48 @@ class FinetuneStep:
             self._pinned = (labels, heads, tails)
         return self._plan
 
+    def _shard(self, batch, masks):
+        n = int(batch["drugs"].shape[0])
+        lo, hi = shard_range(n, self.rank, self.world)
+        key = (id(batch), lo, hi)
+        if key not in self._shards:
+            self._shards[key] = (slice_batch(batch, lo, hi), batch)          # keeps ``batch`` alive: ids are not recycled
+        return self._shards[key][0], masks[lo:hi], n
+
+    def _accumulate_sharded(self, batch_head, batch_tail, masks_head, masks_tail, batch_kg, labels, heads, tails, targets, **kwargs):
+        model, rank, world, group = self.model, self.rank, self.world, self.group
+        ag.set_batchnorm_sync(lambda t: all_reduce_sum_(t, group))
+        try:
+            kw = dict(kwargs, kg_share={}) if 'kg_share' not in kwargs else kwargs
+            sides = []
+            for batch, masks in ((batch_head, masks_head), (batch_tail, masks_tail)):
+                b, m, n = self._shard(batch, masks)
+                z = model.encoder(b["drugs"], m, b["strs"], batch_kg, b["cv"], b["tx"], **kw)
+                z = all_gather_rows_grad(z, n, rank, world, group)
+                sides.append(ag.l2_normalize(z) if model.normalize else z)
+            T = int(labels.numel())
+            key = tuple((t.data_ptr(), t._version, t.numel()) for t in (labels, heads, tails)) + (sides[0].shape[0], sides[1].shape[0], rank, world)
+            if self._plan_key != key:
+                mine = torch.arange(rank, T, world, device=labels.device)
+                self._plan = (ops.triple_plan(labels[mine].contiguous(), heads[mine].contiguous(), tails[mine].contiguous(),
+                                              int(model.decoder.out_features), sides[0].shape[0], sides[1].shape[0]), mine)
+                self._plan_key = key
+                self._pinned = (labels, heads, tails)
+            plan, mine = self._plan
+            scores = model.decoder.score_triples(sides[0], sides[1], plan)                    # label-sorted order of the local triples
+            y = targets[mine][plan["perm"]]
+            part = ag.bce_with_sigmoid(scores, y, "sum")
+            loss = part * (1.0 / T) if self.loss_readout == "mean" else part
+            loss.backward()
+            total = loss.detach().reshape(1).clone()
+            all_reduce_sum_(total, group)
+            return total.reshape(())
+        finally:
+            ag.set_batchnorm_sync(None)
+
     def accumulate(self, batch_head, batch_tail, masks_head, masks_tail, batch_kg, labels, heads, tails, targets, **kwargs) -> torch.Tensor:
+        if self.world > 1:
+            return self._accumulate_sharded(batch_head, batch_tail, masks_head, masks_tail, batch_kg, labels, heads, tails, targets, **kwargs)
         plan = self.plan(labels, heads, tails, int(batch_head["drugs"].shape[0]), int(batch_tail["drugs"].shape[0]))
         scores = self.model.score_triples(batch_head, batch_tail, masks_head, masks_tail, batch_kg, plan, **kwargs)
         loss = ag.bce_with_sigmoid(scores, targets, self.loss_readout)
@@ -43,6 +93,8 @@ class FinetuneStep:
         return loss.detach()
 
     def apply(self) -> None:
+        if self.world > 1:              # once per optimizer step, after every accumulate() of the step
+            allreduce_gradients(self.model.parameters(), self.group)
         self.optimizer.step()
         if self.scheduler is not None:
             self.scheduler.step()

@@ -110,3 +110,46 @@ def test_gloo_world2_sharded_encode_matches_full_batch(n):
         p.join(180)
         assert p.exitcode == 0
     assert ret[0] and ret[1]
+
+
+def _grad_worker(rank, world, port, ret):
+    """Collective autograd helpers of the data-parallel finetune step, on CPU tensors over gloo."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from madrigal_amd.parallel import all_gather_rows_grad, all_reduce_sum_, allreduce_gradients
+    n = 11
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(n, 8, generator=g)
+    wts = torch.randn(world, n, 8, generator=g)              # rank r's loss = sum(w_r * z_full)
+    lo, hi = shard_range(n, rank, world)
+    local = z[lo:hi].clone().requires_grad_(True)
+    full = all_gather_rows_grad(local, n, rank, world)
+    ok = torch.equal(full.detach(), z)
+    (full * wts[rank]).sum().backward()
+    ok = ok and torch.allclose(local.grad, wts.sum(0)[lo:hi])          # reduce-scatter: every rank's gradient of my rows
+    # flat-bucket all-reduce of parameter gradients, with a parameter that has no gradient on one rank
+    ps = [torch.nn.Parameter(torch.zeros(s)) for s in ((3, 5), (7,), (2, 2, 2))]
+    for i, p in enumerate(ps):
+        if not (i == 1 and rank == 1):
+            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    allreduce_gradients(ps, bucket_bytes=64)
+    for i, p in enumerate(ps):
+        want = sum(float(r + 1) * (i + 1) for r in range(world) if not (i == 1 and r == 1))
+        ok = ok and torch.allclose(p.grad, torch.full_like(p, want))
+    t = torch.tensor([float(rank + 1)])
+    ok = ok and float(all_reduce_sum_(t)) == sum(range(1, world + 1))
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_gradient_collectives():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(2)), dict(ret)
