@@ -15,7 +15,7 @@ from madrigal_amd.train import FinetuneStep  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--drugs", type=int, default=4096)
 ap.add_argument("--outcomes", type=int, default=896)
-ap.add_argument("--triples", type=int, default=1_000_000)
+ap.add_argument("--triples", type=int, default=1_000_000, help="positives; x6 labelled triples (2 negatives each, both directions)")
 ap.add_argument("--kg-nodes", type=int, default=130_000)
 ap.add_argument("--kg-edges", type=int, default=8_000_000)
 ap.add_argument("--steps", type=int, default=5)
@@ -45,7 +45,7 @@ for i in range(a.warmup + a.steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 out = {"ms_per_step": dt * 1e3, "steps_per_sec": 1 / dt, "loss": [float(x) for x in losses], "drugs": a.drugs, "outcomes": a.outcomes,
-       "triples": a.triples, "precision": a.precision, "max_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+       "triples": int(lab.numel()), "precision": a.precision, "max_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
 if a.phases:
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     model.train()
