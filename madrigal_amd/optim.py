@@ -88,6 +88,23 @@ class AdamW(torch.optim.Optimizer):
         return loss
 
 
+class LinearWarmupCosineDecaySchedule(torch.optim.lr_scheduler._LRScheduler):
+    """madrigal/utils.py:665-680 (train_ddi_batch.py:101-102): linear warm-up from 0 over ``warmup_epochs`` steps, then
+    ``num_cycles`` half-cosines down to 0 at ``total_epochs``; applied to every parameter group's own base rate."""
+
+    def __init__(self, optimizer, warmup_epochs, total_epochs, num_cycles=1.0, last_epoch=-1):
+        self.warmup_epochs, self.total_epochs, self.num_cycles = warmup_epochs, total_epochs, num_cycles
+        super().__init__(optimizer, last_epoch)
+
+    def get_lr(self):
+        e = self.last_epoch
+        if e < self.warmup_epochs:
+            f = e / self.warmup_epochs
+        else:
+            f = (1.0 + math.cos(math.pi * self.num_cycles * (e - self.warmup_epochs) / (self.total_epochs - self.warmup_epochs))) / 2.0
+        return [b * f for b in self.base_lrs]
+
+
 def parameter_names_outside(model: nn.Module, forbidden: tuple, prefix: str = "") -> List[str]:
     """Names of the parameters that do not live inside a module of a ``forbidden`` type (the reference's
     get_parameter_names, madrigal/utils.py:446-460, including its exclusion of the encoder's own cls / bottleneck

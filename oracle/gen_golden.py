@@ -384,6 +384,36 @@ def gen_bce():
     save("bce", scores=S_, labels=lab, heads=h, tails=t, y=y, pred=p, loss=loss)
 
 
+def gen_eval_masks_and_schedule():
+    """Harness-side host logic: the reference's own get_evaluate_masks (eval_utils.py:287-305) on a seeded
+    availability table for every evaluation type x finetune mode the training script uses, and the learning rates of its
+    LinearWarmupCosineDecaySchedule (utils.py:665-680)."""
+    sys.modules.setdefault("umap", types.ModuleType("umap")).UMAP = object
+    import madrigal.evaluate.eval_utils as EU
+    import madrigal.utils as U
+    base_h, base_t = D.make_masks(40, 5), D.make_masks(40, 6)
+    eval_types = ["full_full", "str_str", "str_full", "kg_kg", "cv_cv", "tx_tx", "str+tx_full", "str+kg_str+cv", "str+kg+cv_tx",
+                  "full_str+cv+tx", "kg+tx_cv"]
+    modes = ["full_full", "double_random", "str_full", "ablation_str_str", "ablation_kg_kg_subset", "ablation_cv_cv_padded",
+             "ablation_tx_tx_padded", "ablation_str_random_str+kg_full_sample", "ablation_str_random_str+tx_full_sample",
+             "ablation_str_random_str+kg+cv_full_sample", "ablation_str_random_str+cv+tx_full_sample"]
+    out = {"base_head": base_h, "base_tail": base_t, "eval_types": np.array(eval_types), "modes": np.array(modes)}
+    for i, et in enumerate(eval_types):
+        for j, fm in enumerate(modes):
+            h, t = EU.get_evaluate_masks(base_h, base_t, et, fm, "cpu")
+            out[f"h_{i}_{j}"], out[f"t_{i}_{j}"] = h, t
+    save("eval_masks", **out)
+    ps = [torch.nn.Parameter(torch.zeros(1)) for _ in range(2)]
+    opt = torch.optim.AdamW([{"params": [ps[0]], "lr": 1e-3}, {"params": [ps[1]], "lr": 5e-5}])
+    sch = U.LinearWarmupCosineDecaySchedule(opt, warmup_epochs=7, total_epochs=40, num_cycles=1.0)
+    lrs = []
+    for _ in range(40):
+        lrs.append([g["lr"] for g in opt.param_groups])
+        opt.step()
+        sch.step()
+    save("lr_schedule", lrs=np.asarray(lrs, dtype=np.float64), warmup=7, total=40)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -399,6 +429,7 @@ def main():
     gen_infonce(M, S)
     gen_ranks(args.ref)
     gen_bce()
+    gen_eval_masks_and_schedule()
 
 
 if __name__ == "__main__":

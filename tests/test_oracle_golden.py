@@ -120,3 +120,43 @@ def test_bce(golden):
     p, loss = O.gathered_bce_loss(t(g["scores"]), t(g["labels"]), t(g["heads"]), t(g["tails"]), t(g["y"]))
     assert rel_err(p, g["pred"]) < 1e-6
     assert abs(float(loss) - float(g["loss"])) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------- harness-side host logic
+def test_evaluate_masks_match_reference(golden):
+    """madrigal_amd.masks against the reference's own get_evaluate_masks (eval_utils.py:287-305), every evaluation type x
+    finetune mode of the fixture ({masks_base, eval_type} -> masks)."""
+    import torch
+    from madrigal_amd.masks import get_evaluate_masks
+    g = golden("eval_masks")
+    bh, bt = torch.from_numpy(g["base_head"]), torch.from_numpy(g["base_tail"])
+    n = 0
+    for i, et in enumerate(g["eval_types"]):
+        for j, fm in enumerate(g["modes"]):
+            h, t = get_evaluate_masks(bh, bt, str(et), str(fm), "cpu")
+            assert h.dtype == torch.bool and t.dtype == torch.bool
+            assert torch.equal(h, torch.from_numpy(g[f"h_{i}_{j}"])), (et, fm, "head")
+            assert torch.equal(t, torch.from_numpy(g[f"t_{i}_{j}"])), (et, fm, "tail")
+            n += 1
+    assert n == 121
+    import pytest
+    with pytest.raises(AssertionError):
+        get_evaluate_masks(bh, bt, "str", "full_full", "cpu")
+    with pytest.raises(KeyError):
+        get_evaluate_masks(bh, bt, "str_nosuch", "full_full", "cpu")
+
+
+def test_warmup_cosine_schedule_matches_reference(golden):
+    import numpy as np
+    import torch
+    from madrigal_amd.optim import LinearWarmupCosineDecaySchedule
+    g = golden("lr_schedule")
+    ps = [torch.nn.Parameter(torch.zeros(1)) for _ in range(2)]
+    opt = torch.optim.AdamW([{"params": [ps[0]], "lr": 1e-3}, {"params": [ps[1]], "lr": 5e-5}])
+    sch = LinearWarmupCosineDecaySchedule(opt, warmup_epochs=int(g["warmup"]), total_epochs=int(g["total"]))
+    lrs = []
+    for _ in range(int(g["total"])):
+        lrs.append([q["lr"] for q in opt.param_groups])
+        opt.step()
+        sch.step()
+    assert np.allclose(np.asarray(lrs), g["lrs"], rtol=1e-12, atol=0)

@@ -699,7 +699,10 @@ def test_whole_model_gradients_match_oracle_autograd(case):
     lab, hd, tl, y = D.make_labelled_triples(n, L, 700, seed)
     pr = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in p.items()}
     ref = oracle_pipeline(case, dict(pr), batch, bkg, masks, filler)
-    _, loss_r = O.gathered_bce_loss(ref["scores"], lab, hd, tl, y)
+    # the reference's own loss module (nn.BCELoss on sigmoid scores, utils.py:616-619): its backward is defined at saturated
+    # probabilities, where differentiating the oracle's explicit clamp(log(.)) formula gives 0 * inf
+    loss_r = torch.nn.BCELoss()(torch.sigmoid(ref["scores"])[lab, hd, tl], y)
+    assert abs(float(loss_r.detach()) - float(O.gathered_bce_loss(ref["scores"].detach(), lab, hd, tl, y)[1])) < 1e-6 * float(loss_r.detach())
     loss_r.backward()
     model = model.cuda().eval()
     for mod in model.modules():                                   # eval-mode BatchNorm: statistics and affine are constants here
@@ -723,6 +726,7 @@ def test_whole_model_gradients_match_oracle_autograd(case):
             continue
         assert named[k].grad is not None, f"{k}: no gradient on the HIP path"
         a, r = named[k].grad.cpu().double(), v.grad.double()
+        assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(r).all()), k
         err = float((a - r).abs().max()) / max(float(r.abs().max()), 1e-2 * gmax)
         worst = max(worst, (err, k))
         checked += 1
@@ -886,3 +890,81 @@ def test_simclr_pretraining_step_runs_end_to_end():
     l1, l2 = run(8), run(8)
     assert all(np.isfinite(l1)) and l1[-1] < l1[0], l1
     assert l1 == l2
+
+
+def test_one_adamw_step_matches_oracle_autograd_plus_torch_adamw():
+    """one optimizer step of the whole model.  Reference side: torch autograd over the CPU oracle
+    pipeline, then torch.optim.AdamW over the same parameter groups (madrigal/utils.py:463-613).  The first Adam step moves
+    an entry by -lr * g / (|g| + eps) - lr * wd * p: entries whose reference gradient is not at noise level must move
+    identically (1e-5 of the step), the rest (analytically zero gradients: biases in front of a BatchNorm, unused outcomes)
+    are compared on the weight-decay part only."""
+    from madrigal_amd import data as D, models as M
+    from madrigal_amd.optim import create_optimizer
+    from madrigal_amd.train import FinetuneStep
+    from helpers import oracle_pipeline
+    from oracle import madrigal_oracle as O
+    case = ("drugbank163", "transformer", 4, "learnable", 8, 64, 256, 2, True, "x-attn", True, False)
+    n, L, seed = 96, 24, 31
+    hp = dict(optimizer="adamw", structure_encoder_lr=3e-4, kg_encoder_lr=2e-4, perturb_encoders_lr=1e-4, fusion_lr=5e-5, decoder_lr=1e-3,
+              wd=1e-2, beta1=0.9, beta2=0.999, eps=1e-8)
+    model, _, batch, bkg, masks = _small_model(M, case, n, L, seed, default_init=True)       # torch initialisers: logits of order
+    p = {k: v.detach().clone() for k, v in model.state_dict().items()}                      # one, gradients far above Adam's eps
+    filler = torch.randn(n, 128, generator=torch.Generator().manual_seed(1))
+    lab, hd, tl, y = D.make_labelled_triples(n, L, 700, seed)
+    model = model.cuda().eval()
+    frozen = set()
+    for name, mod in model.named_modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            for pn, q in mod.named_parameters():
+                q.requires_grad_(False)
+                frozen.add(f"{name}.{pn}")
+    opt = create_optimizer(model, hp)
+    group_of = {}
+    for gi, g in enumerate(opt.param_groups):
+        for q in g["params"]:
+            group_of[id(q)] = gi
+    named = dict(model.named_parameters())
+    # reference: oracle forward + autograd + torch.optim.AdamW with the same groups
+    pr = {k: (v.clone().requires_grad_(k in named and k not in frozen) if v.dtype.is_floating_point else v) for k, v in p.items()}
+    ref = oracle_pipeline(case, dict(pr), batch, bkg, masks, filler)
+    loss_r = torch.nn.BCELoss()(torch.sigmoid(ref["scores"])[lab, hd, tl], y)           # the reference's loss module
+    loss_r.backward()
+    groups = [{"params": [], "lr": g["lr"], "weight_decay": g["weight_decay"]} for g in opt.param_groups]
+    for k, q in named.items():
+        if k in frozen:
+            continue
+        if pr[k].grad is None:
+            pr[k].grad = torch.zeros_like(pr[k])
+        groups[group_of[id(q)]]["params"].append(pr[k])
+    ropt = torch.optim.AdamW([g for g in groups if g["params"]], betas=(hp["beta1"], hp["beta2"]), eps=hp["eps"])
+    before = {k: v.detach().clone() for k, v in pr.items() if k in named}
+    gref = {k: pr[k].grad.detach().clone() for k in named if k not in frozen}
+    assert all(bool(torch.isfinite(g).all()) for g in gref.values())
+    ropt.step()
+    # HIP path
+    b = D.batch_to(batch, "cuda")
+    kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
+    fs = FinetuneStep(model, opt)
+    opt.zero_grad(set_to_none=True)
+    fs.accumulate(b, b, b["masks"], b["masks"], kgc, lab.cuda(), hd.cuda(), tl.cuda(), y.cuda(), kg_filler=filler.cuda())
+    fs.apply()
+    checked = moved = exact_n = 0
+    for k, q in named.items():
+        if k in frozen:
+            assert torch.equal(q.detach().cpu(), before[k]), k
+            continue
+        lr = opt.param_groups[group_of[id(q)]]["lr"]
+        d_gpu = q.detach().cpu().double() - before[k].double()
+        d_ref = pr[k].detach().double() - before[k].double()
+        g = gref[k].abs()
+        solid = (g > 1e-2 * max(float(g.max()), 1e-12)) & (g > 1e3 * hp["eps"])      # clear of gradient noise and of Adam's eps regime
+        if bool(solid.any()):
+            err = float((d_gpu - d_ref)[solid].abs().max()) / lr
+            # the step is lr * g / (|g| + eps): sign-identical for |g| >> eps, so nearly every entry moves identically
+            # (1e-5 of the step); entries with |g| within a few orders of eps = 1e-8 feel the gradient's own 1e-4 error
+            assert err < 2e-3, (k, err)
+            exact_n += int(((d_gpu - d_ref)[solid].abs() < 1e-5 * lr).sum())
+            moved += int(solid.sum())
+        checked += 1
+    assert checked > 150 and moved > 300_000
+    assert exact_n > 0.8 * moved, (exact_n, moved)       # the rest sits within 2e-3 of the step (asserted per tensor above)
