@@ -221,3 +221,41 @@ def test_baseline_configs_vs_oracle(M, prec, name, case, n, L, str_only):
     pr, lr = O.gathered_bce_loss(ref["scores"], lab, hd, tl, y)
     assert float((pred.cpu() - pr).abs().max()) < 2 * TOL[prec] * 10
     assert abs(float(loss) - float(lr)) < 1e-3 * abs(float(lr))
+
+
+def test_auprc_of_hip_predictions_within_1e3_of_oracle(M):
+    """north_star's acceptance check: AUPRC (macro over outcomes, sklearn as the judge) of the HIP path's predictions on a
+    labelled split within 1e-3 of the CPU reference path's.  Labels are planted from the oracle's own logits plus noise, so
+    the metric is far from both 0.5 and 1 and sensitive to score perturbations."""
+    import numpy as np
+    from sklearn.metrics import average_precision_score
+    from madrigal_amd import data as D, metrics
+    from helpers import oracle_pipeline
+    from oracle.params import det_state_dict
+    case = ("twosides105", "transformer", 2, "learnable", 2, 256, 512, 2, True, "x-attn", False, False)
+    n, L, seed = 160, 20, 17
+    masks = D.make_masks(n, seed)
+    batch, bkg = D.make_batch(n, seed, kg_nodes=1200, kg_edges=15000, masks=masks)
+    model = build_model(M, case, bkg["data"], L)
+    p = det_state_dict(seed, {k: tuple(v.shape) for k, v in model.state_dict().items()}, [])
+    model.load_state_dict({**model.state_dict(), **p})
+    model = model.cuda().eval()
+    filler = torch.randn(n, 128, generator=torch.Generator().manual_seed(1))
+    ref = oracle_pipeline(case, dict(p), batch, bkg, masks, filler)["scores"]
+    b = D.batch_to(batch, "cuda")
+    kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
+    with torch.no_grad(), M.precision("bf16x3"):
+        got = model(b, b, b["masks"], b["masks"], kgc, kg_filler=filler.cuda())
+    rng = np.random.default_rng(3)
+    T = 40000
+    lab, hd, tl = rng.integers(0, L, T), rng.integers(0, n, T), rng.integers(0, n, T)
+    logit_ref = ref[lab, hd, tl].numpy()
+    y = (logit_ref + rng.standard_normal(T) * logit_ref.std() > np.median(logit_ref)).astype(np.float32)     # noisy planted labels
+    p_ref = torch.sigmoid(ref)[lab, hd, tl].numpy()
+    p_got = torch.sigmoid(got)[torch.from_numpy(lab).cuda(), torch.from_numpy(hd).cuda(), torch.from_numpy(tl).cuda()]
+    ap_ref = np.mean([average_precision_score(y[lab == l], p_ref[lab == l]) for l in range(L)])
+    ap_got_sklearn = np.mean([average_precision_score(y[lab == l], p_got.cpu().numpy()[lab == l]) for l in range(L)])
+    ap_got_device, _ = metrics.macro_auprc(p_got, torch.from_numpy(y).cuda(), torch.from_numpy(lab).cuda(), L)
+    assert 0.55 < ap_ref < 0.98, ap_ref
+    assert abs(ap_got_sklearn - ap_ref) < 1e-3, (ap_got_sklearn, ap_ref)
+    assert abs(float(ap_got_device) - ap_got_sklearn) < 1e-9

@@ -160,3 +160,28 @@ def test_warmup_cosine_schedule_matches_reference(golden):
         opt.step()
         sch.step()
     assert np.allclose(np.asarray(lrs), g["lrs"], rtol=1e-12, atol=0)
+
+
+def test_average_precision_matches_sklearn():
+    import numpy as np
+    import torch
+    from sklearn.metrics import average_precision_score
+    from madrigal_amd.metrics import average_precision, macro_auprc
+    rng = np.random.default_rng(0)
+    for n, ties in ((1, False), (50, False), (5000, False), (5000, True)):
+        s = rng.standard_normal(n).astype(np.float32)
+        if ties:
+            s = np.round(s, 1)
+        y = (rng.random(n) < 0.3).astype(np.float32)
+        if y.sum() == 0:
+            y[0] = 1
+        got = float(average_precision(torch.from_numpy(s), torch.from_numpy(y)))
+        assert abs(got - average_precision_score(y, s)) < 1e-12, (n, ties)
+    T, L = 20000, 12
+    lab = rng.integers(0, L, T)
+    s = rng.standard_normal(T).astype(np.float32)
+    y = (rng.random(T) < 0.2).astype(np.float32)
+    y[lab == 3] = 1.0                                            # an outcome with one class only: skipped, as the reference does
+    macro, per = macro_auprc(torch.from_numpy(s), torch.from_numpy(y), torch.from_numpy(lab), L)
+    want = [average_precision_score(y[lab == l], s[lab == l]) for l in range(L) if l != 3]
+    assert abs(float(macro) - float(np.mean(want))) < 1e-12 and bool(torch.isnan(per[3]))
