@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from madrigal_amd import ops
-shapes = [(20480, 6144, 2048), (20480, 2048, 2048), (20480, 1024, 2048), (20480, 2048, 1024), (6144, 2048, 20480), (65536, 512, 978),
+shapes = [(130000, 128, 128), (106000, 128, 68), (20480, 2048, 128), (50000, 256, 256), (20480, 6144, 2048), (20480, 2048, 2048), (20480, 1024, 2048), (20480, 2048, 1024), (6144, 2048, 20480), (65536, 512, 978),
           (130000, 384, 128), (110000, 128, 128)]
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
 for M, N, K in shapes:
