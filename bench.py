@@ -238,7 +238,10 @@ def main():
     if args.finetune_steps > 0 and not args.head_only:
         del out
         torch.cuda.empty_cache()
-        finetune = finetune_leg(model, batch, bkg, filler, N, L, args, rank, world, backend)
+        try:
+            finetune = finetune_leg(model, batch, bkg, filler, N, L, args, rank, world, backend)
+        except Exception as e:          # the headline line must survive a failure of the secondary leg
+            finetune = {"metric": "DDI-finetune steps/sec", "value": None, "error": f"{type(e).__name__}: {e}"[:400]}
     enc_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     head_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps     # head launch (+ its two operand-split pre-passes)
     value = float(L) * N * N * world * args.steps / dt
