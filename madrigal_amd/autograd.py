@@ -568,3 +568,42 @@ class _InfoNCE(Function):
 def info_nce(aug1, aug2, too_hard_neg, temperature: float, precision="bf16x3"):
     f = l2_normalize(torch.cat([aug1, aug2], dim=0))
     return _InfoNCE.apply(f, too_hard_neg, float(temperature), precision)
+
+
+class _BilinearAllPairs(Function):
+    """The dense head S[l,i,j] = z_h[i]^T W[l] z_t[j] as a differentiable [L,Nh,Nt] tensor: what the reference's own loop
+    differentiates (train_ddi_batch.py:285-288: sigmoid(model(...))[labels, heads, tails] -> BCELoss -> backward), so that
+    the loop runs unchanged.  The incoming gradient is dense (torch builds it from the index / sigmoid backward); four
+    GEMMs through the HIP kernel turn it into dz_h, dz_t, dW.  Memory like the reference: a second [L,Nh,Nt] buffer for the
+    transposed gradient.  The gathered head (score_triples) is the fast path; this one is the drop-in path."""
+
+    @staticmethod
+    def forward(ctx, z_head, z_tail, w, precision):
+        ctx.save_for_backward(z_head, z_tail, w)
+        ctx.precision = precision
+        return ops.bilinear_allpairs(z_head, z_tail, w, precision=precision)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dS):
+        zh, zt, w = ctx.saved_tensors
+        L, Nh, Nt, D = w.shape[0], zh.shape[0], zt.shape[0], zh.shape[1]
+        prec = ctx.precision
+        lin = lambda x, wt: ops.linear(x, wt, precision=prec, cache_weight=False)       # noqa: E731
+        dS2 = (dS if dS.is_contiguous() else dS.contiguous()).view(L * Nh, Nt)
+        dzh = dzt = dw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            U = lin(dS2, ops.transpose(zt)).view(L, Nh, D)                               # U[l,i,:] = sum_j dS[l,i,j] z_t[j,:]
+            if ctx.needs_input_grad[0]:                                                  # dz_h[i,k] = sum_{l,m} U[l,i,m] W[l,k,m]
+                dzh = lin(U.permute(1, 0, 2).reshape(Nh, L * D), w.permute(1, 0, 2).reshape(D, L * D))
+            if ctx.needs_input_grad[2]:                                                  # dW[l,k,m] = sum_i z_h[i,k] U[l,i,m]
+                y = lin(U.transpose(1, 2).reshape(L * D, Nh), ops.transpose(zh))         # y[(l,m),k]
+                dw = y[:, :D].reshape(L, D, D).transpose(1, 2).contiguous()
+        if ctx.needs_input_grad[1]:                                                      # dz_t[j,m] = sum_{l,i} dS[l,i,j] (z_h W_l)[i,m]
+            V = lin(zh, w.transpose(1, 2).reshape(L * D, D)).view(Nh, L, D).permute(1, 0, 2).reshape(L * Nh, D)
+            dzt = lin(ops.transpose(dS2), ops.transpose(V))
+        return (None if dzh is None else dzh[:, :D].contiguous()), (None if dzt is None else dzt[:, :D].contiguous()), dw, None
+
+
+def bilinear_allpairs(z_head, z_tail, w, precision="bf16x3"):
+    return _BilinearAllPairs.apply(z_head, z_tail, w, precision)

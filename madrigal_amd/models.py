@@ -1084,8 +1084,15 @@ class BilinearDDIScorer(nn.Bilinear):
 
     def forward(self, input1, input2, label_range: tuple = None, epilogue=ops.EPI_STORE, out=None):
         if ag.needs_grad(input1, input2) or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("the dense [L,N,N] result is not differentiable on the HIP path: use score_triples() "
-                                      "(NovelDDIMultilabel.score_triples) for the finetune step, or torch.no_grad() for inference")
+            # drop-in path of the reference's own training loop: a differentiable dense [L,Nh,Nt] result (memory and
+            # backward cost proportional to L*Nh*Nt, as in the reference; score_triples() is the fast path)
+            if epilogue != ops.EPI_STORE or out is not None:
+                raise ValueError("epilogue / out are inference-only arguments")
+            w = self.weight
+            if label_range is not None:
+                assert len(label_range) == 2
+                w = w[label_range[0]:label_range[1]]
+            return ag.bilinear_allpairs(input1, input2, w.contiguous(), _state["precision"])
         w = self.symmetric_weight()
         if label_range is not None:
             assert len(label_range) == 2

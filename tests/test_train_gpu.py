@@ -968,3 +968,100 @@ def test_one_adamw_step_matches_oracle_autograd_plus_torch_adamw():
         checked += 1
     assert checked > 150 and moved > 300_000
     assert exact_n > 0.8 * moved, (exact_n, moved)       # the rest sits within 2e-3 of the step (asserted per tensor above)
+
+
+# ---------------------------------------------------------------------------------------------- dense head, drop-in loop
+@pytest.mark.parametrize("L,Nh,Nt,same", [(3, 5, 7, False), (6, 70, 70, True), (17, 130, 61, False)])
+def test_dense_head_is_differentiable_like_the_reference_loop(L, Nh, Nt, same):
+    """train_ddi_batch.py:285-288 verbatim on the HIP decoder: sigmoid(model_out)[labels, heads, tails] -> BCELoss -> backward."""
+    from madrigal_amd import models as M
+    torch.manual_seed(3)
+    dec = M.BilinearDDIScorer(128, 128, L)
+    torch.nn.utils.parametrize.register_parametrization(dec, "weight", M.Symmetric())
+    w0 = dec.parametrizations.weight.original.detach().clone()
+    dec = dec.to(DEV)
+    # moderate logits: at saturation fp32 BCELoss (clamped log) and a float64 reference differ by construction
+    zh, zt = _rand(Nh, 128, seed=1, scale=0.3), (_rand(Nh, 128, seed=1, scale=0.3) if same else _rand(Nt, 128, seed=2, scale=0.3))
+    Nt = Nh if same else Nt
+    T = 4 * L * Nh
+    g = torch.Generator().manual_seed(5)
+    lab, hd, tl = torch.randint(0, L, (T,), generator=g), torch.randint(0, Nh, (T,), generator=g), torch.randint(0, Nt, (T,), generator=g)
+    y = (torch.rand(T, generator=g) < 0.4).float()
+    # reference: torch on the CPU in float64
+    zr, tr, wr = zh.double().requires_grad_(True), zt.double().requires_grad_(True), w0.double().requires_grad_(True)
+    ws = wr.triu() + wr.triu(1).transpose(-1, -2)
+    tail_r = zr if same else tr
+    Sr = torch.matmul(torch.matmul(zr, ws), tail_r.t())
+    loss_r = torch.nn.BCELoss()(torch.sigmoid(Sr)[lab, hd, tl], y.double())
+    loss_r.backward()
+    zg = zh.to(DEV).requires_grad_(True)
+    tg = zg if same else zt.to(DEV).requires_grad_(True)
+    with M.precision("f32"):
+        pred = torch.sigmoid(dec(zg, tg))[lab.to(DEV), hd.to(DEV), tl.to(DEV)]          # the reference's lines, unchanged
+        loss = torch.nn.BCELoss()(pred, y.to(DEV))
+        loss.backward()
+    _close(loss, loss_r, 1e-5, "loss")
+    _close(zg.grad, zr.grad, 5e-5, "dz_head")
+    if not same:
+        _close(tg.grad, tr.grad, 5e-5, "dz_tail")
+    _close(dec.parametrizations.weight.original.grad, wr.grad, 5e-5, "dW_original")
+    # label_range slice (predict.py chunks the outcomes)
+    dec.zero_grad()
+    with M.precision("f32"):
+        part = dec(zg.detach().requires_grad_(True), tg.detach(), label_range=(1, L))
+        part.sum().backward()
+    assert part.shape == (L - 1, Nh, Nt)
+    assert not dec.parametrizations.weight.original.grad[0].any() and dec.parametrizations.weight.original.grad[1:].any()
+
+
+def test_reference_training_loop_lines_run_unchanged_and_agree_with_the_gathered_step():
+    """The body of train_ddi_batch.py:275-350 ('full_full'), verbatim, on the HIP model: optimizer.zero_grad();
+    pred = sigmoid(model(batch_head, batch_tail, masks, masks, batch_kg))[labels, heads, tails]; loss = BCELoss(pred, y);
+    loss.backward(); optimizer.step().  Same dropout seeds => same loss and gradients as FinetuneStep's gathered head."""
+    from madrigal_amd import data as D, models as M
+    from madrigal_amd.optim import create_optimizer
+    from madrigal_amd.train import FinetuneStep
+    case = ("twosides321", "transformer_uni_proj", 2, "sinusoidal", 4, 64, 256, 2, True, "x-attn", False, False)
+    n, L, seed = 80, 10, 13
+    hp = dict(optimizer="adamw", structure_encoder_lr=1e-4, kg_encoder_lr=1e-4, perturb_encoders_lr=1e-4, fusion_lr=1e-5, decoder_lr=1e-3,
+              wd=1e-2, beta1=0.9, beta2=0.999, eps=1e-8)
+    lab, hd, tl, y = (t.cuda() for t in D.make_labelled_triples(n, L, 300, seed))
+
+    def setup():
+        model, _, batch, bkg, _ = _small_model(M, case, n, L, seed, default_init=True)
+        model = model.cuda()
+        b = D.batch_to(batch, "cuda")
+        kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
+        return model, create_optimizer(model, hp), b, kgc
+    filler = torch.randn(n, 128, generator=torch.Generator().manual_seed(1)).cuda()
+    # --- the reference's lines
+    model, optimizer, batch_head, batch_kg = setup()
+    batch_tail, masks_X = batch_head, batch_head["masks"]
+    loss_fn = torch.nn.BCELoss(reduction="mean")
+    model.train()
+    torch.manual_seed(77)
+    optimizer.zero_grad()
+    pred_ddis = torch.sigmoid(model(batch_head, batch_tail, masks_X, masks_X, batch_kg, kg_filler=filler))
+    pred_ddis = pred_ddis[lab, hd, tl]
+    loss = loss_fn(pred_ddis, y)
+    loss.backward()
+    grads_ref = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    optimizer.step()
+    after_ref = {k: p.detach().clone() for k, p in model.named_parameters()}
+    # --- the gathered step
+    model2, optimizer2, b2, kgc2 = setup()
+    fs = FinetuneStep(model2, optimizer2)
+    model2.train()
+    torch.manual_seed(77)
+    optimizer2.zero_grad()
+    loss2 = fs.accumulate(b2, b2, b2["masks"], b2["masks"], kgc2, lab, hd, tl, y, kg_filler=filler)
+    gmax = max(float(g.abs().max()) for g in grads_ref.values())
+    for k, p in model2.named_parameters():
+        if p.grad is None:
+            assert k not in grads_ref or not grads_ref[k].any(), k
+            continue
+        _close(p.grad, grads_ref[k], 2e-4, k, floor=1e-2 * gmax)
+    fs.apply()
+    _close(loss2, loss, 1e-5, "loss")
+    moved = sum(float((after_ref[k] - p.detach()).abs().max()) for k, p in model2.named_parameters())
+    assert moved < 1e-2          # both optimizers took (numerically) the same step
