@@ -105,3 +105,60 @@ class FinetuneStep:
         loss = self.accumulate(batch_head, batch_tail, masks_head, masks_tail, batch_kg, labels, heads, tails, targets, **kwargs)
         self.apply()
         return loss
+
+
+class PretrainStep:
+    """One iteration of pretrain.py:59-93 (train_epoch): ``optimizer.zero_grad()``; ``SimCLR_NovelDDI(drug_indices, mask1, mask2,
+    too_hard_neg, batch_data)`` -> InfoNCE loss; ``backward()``; ``optimizer.step()``.
+
+    ``world > 1`` (BASELINE configs[2]: contrastive pretraining, batch 2048, data-parallel with an all-gather of the features):
+    rank r runs both views of a contiguous block of the batch through the encoder and the predictors (SyncBatchNorm), the
+    predictor outputs are all-gathered ([B,dim] per view, gradient = all-reduce + own slice), every rank evaluates the same
+    [2B,2B] loss scaled by 1/world (so that the summed gradients are exact), and the parameter gradients are summed in flat
+    buckets.  With dropout off it reproduces the single-process step."""
+
+    def __init__(self, model, optimizer, rank: int = 0, world: int = 1, group=None):
+        self.model, self.optimizer, self.rank, self.world, self.group = model, optimizer, rank, world, group
+        self._shards = {}
+
+    def _local(self, drug_indices, batch_data):
+        mols, kg, cv, tx = batch_data
+        B = int(drug_indices.shape[0])
+        lo, hi = shard_range(B, self.rank, self.world)
+        key = (id(mols), id(cv), lo, hi)
+        if key not in self._shards:
+            whole = {"drugs": drug_indices, "strs": mols, "cv": cv, "tx": tx, "masks": torch.zeros(B, 1, dtype=torch.bool, device=cv.device)}
+            self._shards[key] = (slice_batch(whole, lo, hi), batch_data)
+        return self._shards[key][0], lo, hi, B
+
+    def step(self, drug_indices, mask1, mask2, too_hard_neg, batch_data) -> torch.Tensor:
+        model = self.model
+        model.train()
+        self.optimizer.zero_grad(set_to_none=True)
+        if self.world == 1:
+            _, _, (_, _, loss) = model(drug_indices, mask1, mask2, too_hard_neg, batch_data)
+            loss.backward()
+            self.optimizer.step()
+            return loss.detach()
+        if model.raw_encoder_output:
+            raise NotImplementedError("data-parallel pretraining with raw_encoder_output=True (a variable number of rows per drug)")
+        from .models import _run_sequential_train
+        group = self.group
+        b, lo, hi, B = self._local(drug_indices, batch_data)
+        kg = batch_data[1]
+        ag.set_batchnorm_sync(lambda t: all_reduce_sum_(t, group))
+        try:
+            p1 = model.predictor if model.shared_predictor else model.predictor_1
+            p2 = model.predictor if model.shared_predictor else model.predictor_2
+            share = {}
+            views = []
+            for masks, pred in ((mask1, p1), (mask2, p2)):
+                e = model.base_encoder(b["drugs"], masks[lo:hi], b["strs"], kg, b["cv"], b["tx"], raw_encoder_output=False, kg_share=share)
+                views.append(all_gather_rows_grad(_run_sequential_train(pred, e), B, self.rank, self.world, group))
+            _, _, loss = model.contrastive_loss(views[0], views[1], too_hard_neg)
+            (loss * (1.0 / self.world)).backward()
+            allreduce_gradients(model.parameters(), group)
+        finally:
+            ag.set_batchnorm_sync(None)
+        self.optimizer.step()
+        return loss.detach()
