@@ -1065,3 +1065,47 @@ def test_reference_training_loop_lines_run_unchanged_and_agree_with_the_gathered
     _close(loss2, loss, 1e-5, "loss")
     moved = sum(float((after_ref[k] - p.detach()).abs().max()) for k, p in model2.named_parameters())
     assert moved < 1e-2          # both optimizers took (numerically) the same step
+
+
+def test_three_pass_finetune_mode_accumulates_like_the_reference():
+    """The 'str_*' finetune modes (train_ddi_batch.py:307-348): three backward passes with different modality-mask pairs
+    (str-str, X-X, str-X) into one optimizer step.  accumulate() x 3 + apply() must equal the sum of the three gradients."""
+    from madrigal_amd import data as D, models as M
+    from madrigal_amd.optim import create_optimizer
+    from madrigal_amd.train import FinetuneStep
+    case = ("drugbank163", "transformer", 4, "sinusoidal", 4, 32, 128, 1, True, "x-attn", False, False)
+    n, L, seed = 64, 6, 2
+    hp = dict(optimizer="adamw", structure_encoder_lr=1e-4, kg_encoder_lr=1e-4, perturb_encoders_lr=1e-4, fusion_lr=1e-4, decoder_lr=1e-3,
+              wd=0.0, beta1=0.9, beta2=0.999, eps=1e-8)
+    model, _, batch, bkg, _ = _small_model(M, case, n, L, seed, default_init=True)
+    model = model.cuda().eval()                       # eval: the three passes are then deterministic functions of the masks
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            for q in mod.parameters():
+                q.requires_grad_(False)
+    b = D.batch_to(batch, "cuda")
+    kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
+    filler = torch.randn(n, 128, generator=torch.Generator().manual_seed(1)).cuda()
+    lab, hd, tl, y = (t.cuda() for t in D.make_labelled_triples(n, L, 200, seed))
+    masks_x = b["masks"]
+    masks_str = torch.ones_like(masks_x)
+    masks_str[:, 0] = False
+    keep = hd < tl                                    # the directed subset of the str-str and X-X passes
+    fs = FinetuneStep(model, create_optimizer(model, hp))
+    passes = [(masks_str, masks_str, keep), (masks_x, masks_x, keep), (masks_str, masks_x, torch.ones_like(keep))]
+    singles = []
+    for mh, mt, sel in passes:
+        model.zero_grad(set_to_none=True)
+        fs.accumulate(b, b, mh, mt, kgc, lab[sel].contiguous(), hd[sel].contiguous(), tl[sel].contiguous(), y[sel].contiguous(), kg_filler=filler)
+        singles.append({k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    model.zero_grad(set_to_none=True)
+    for mh, mt, sel in passes:
+        fs.accumulate(b, b, mh, mt, kgc, lab[sel].contiguous(), hd[sel].contiguous(), tl[sel].contiguous(), y[sel].contiguous(), kg_filler=filler)
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        want = sum(s[k] for s in singles if k in s)
+        _close(p.grad, want, 1e-5, k, floor=1e-3 * float(want.abs().max()) + 1e-12)
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    fs.apply()
+    assert any(not torch.equal(before[k], p.detach()) for k, p in model.named_parameters())
