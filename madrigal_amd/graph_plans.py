@@ -9,7 +9,7 @@ KG is static across steps and the molecule batch is the single full batch of the
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, Sequence, Tuple
 
 import torch
 

@@ -15,7 +15,7 @@ from __future__ import annotations
 import math
 import os
 from contextlib import contextmanager
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from . import autograd as ag
 from . import ops
-from .data import CELL_LINES, MOL_DIM, NON_TX_MODALITIES, NUM_MODALITIES, NUM_NON_TX_MODALITIES
+from .data import CELL_LINES, MOL_DIM, NUM_MODALITIES, NUM_NON_TX_MODALITIES
 from .graph_plans import hgt_plan, molecule_plan, transposed_csr
 
 TX_INPUT_DIM = 978

@@ -7,7 +7,7 @@ assertion errors in the same situations) and ``MadrigalHipError`` if the library
 from __future__ import annotations
 
 import ctypes
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 

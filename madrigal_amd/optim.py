@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import math
-from typing import Dict, Iterable, List
+from typing import Dict, List
 
 import numpy as np
 import torch

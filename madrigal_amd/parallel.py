@@ -9,7 +9,7 @@ parallel by outcome (or by head row), each rank writing only its own slab of the
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Optional, Tuple
+from typing import Iterable, List, Tuple
 
 import torch
 import torch.distributed as dist

@@ -7,7 +7,6 @@ statistics) and the InfoNCE loss record a tape through madrigal_amd.autograd; fo
 """
 from __future__ import annotations
 
-import torch
 import torch.nn as nn
 
 from . import autograd as ag

@@ -8,8 +8,6 @@ entries (mdg_bilinear_gather), forward and backward.
 """
 from __future__ import annotations
 
-from typing import Optional
-
 import torch
 
 from . import autograd as ag
