@@ -363,6 +363,8 @@ def csr_aggregate(x: torch.Tensor, rowptr: torch.Tensor, col: Optional[torch.Ten
     x = _f32_cuda(x, "x", 2)
     if x.shape[1] % 4:
         x = _pad_last(x)
+    if x.shape[0] == 0:                       # no source rows (hence no edges): a valid pointer for the C side all the same
+        x = torch.zeros((1, x.shape[1]), dtype=torch.float32, device=x.device)
     F = x.shape[1]
     n_dst = int(rowptr.numel()) - 1
     if rowptr.dtype != torch.int64 or (col is not None and col.dtype != torch.int64):
@@ -852,6 +854,9 @@ def grad_weight(g: torch.Tensor, x: torch.Tensor, precision="f32", want_bias: bo
     produces the bias gradient on the side.  Outputs with >= 96 tiles of 128x128 (the 2048-wide fusion transformer)
     already fill the chip tile-wise: in the bf16 modes they go through the forward GEMM kernel on transposed operands,
     ~5x the fp32 matrix-core rate."""
+    if g.dim() == 2 and x.dim() == 2 and g.shape[0] == 0 and x.shape[0] == 0:          # no rows: exact zeros
+        dw = torch.zeros((g.shape[1], x.shape[1]), dtype=torch.float32, device=g.device)
+        return (dw, torch.zeros(g.shape[1], dtype=torch.float32, device=g.device)) if want_bias else dw
     for nm, v in (("g", g), ("x", x)):
         if v.dim() != 2 or not v.is_cuda or v.dtype != torch.float32 or v.stride(1) != 1:
             raise ValueError(f"grad_weight: {nm} must be a 2-D fp32 cuda tensor with unit inner stride")

@@ -1109,3 +1109,64 @@ def test_three_pass_finetune_mode_accumulates_like_the_reference():
     before = {k: p.detach().clone() for k, p in model.named_parameters()}
     fs.apply()
     assert any(not torch.equal(before[k], p.detach()) for k, p in model.named_parameters())
+
+
+def test_training_kernels_on_empty_and_ragged_inputs():
+    from madrigal_amd import autograd as ag, ops
+    # no triples at all: empty scores, zero gradients of the right shapes
+    e = torch.zeros(0, dtype=torch.int64, device=DEV)
+    plan = ops.triple_plan(e, e, e, 4, 5, 6)
+    zh, zt = _rand(5, 128, seed=1).to(DEV).requires_grad_(True), _rand(6, 128, seed=2).to(DEV).requires_grad_(True)
+    w = _rand(4, 128, 128, seed=3).to(DEV).requires_grad_(True)
+    s = ag.bilinear_gather(zh, zt, ag.symmetrize(w), plan)
+    assert s.shape == (0,)
+    loss = ag.bce_with_sigmoid(s, torch.zeros(0, device=DEV))
+    assert float(loss.detach()) == 0.0
+    (s.sum() + loss).backward()
+    assert zh.grad.shape == (5, 128) and not zh.grad.any() and not zt.grad.any() and not w.grad.any()
+    # one triple; a label with > 256 triples next to empty labels (chunk / tile boundaries)
+    for T, L in ((1, 3), (257, 3), (513, 2)):
+        lab = torch.full((T,), L - 1, dtype=torch.int64)
+        hd, tl = torch.arange(T) % 5, (torch.arange(T) * 7) % 6
+        plan = ops.triple_plan(lab.to(DEV), hd.to(DEV), tl.to(DEV), L, 5, 6)
+        assert plan["n_tiles"] == (T + 31) // 32 and plan["n_chunks"] == (T + 255) // 256
+        zr, tr = zh.detach().cpu().double().requires_grad_(True), zt.detach().cpu().double().requires_grad_(True)
+        wr = _rand(L, 128, 128, seed=3).double().requires_grad_(True)
+        ws = wr.triu() + wr.triu(1).transpose(-1, -2)
+        torch.einsum("td,tde,te->t", zr[hd], ws[lab], tr[tl]).sum().backward()
+        zg, tg = zh.detach().clone().requires_grad_(True), zt.detach().clone().requires_grad_(True)
+        wg = _rand(L, 128, 128, seed=3).to(DEV).requires_grad_(True)
+        ag.bilinear_gather(zg, tg, ag.symmetrize(wg), plan).sum().backward()
+        _close(zg.grad, zr.grad, 2e-5, f"T={T} dz_head")
+        _close(tg.grad, tr.grad, 2e-5, f"T={T} dz_tail")
+        _close(wg.grad, wr.grad, 2e-5, f"T={T} dW")
+        assert not wg.grad[:L - 1].any()                         # outcomes without triples: exact zeros
+    # dense blocks over zero rows / one row
+    x0 = torch.zeros(0, 64, device=DEV, requires_grad=True)
+    w1, b1 = _rand(32, 64, seed=4).to(DEV).requires_grad_(True), _rand(32, seed=5).to(DEV).requires_grad_(True)
+    y0 = ag.linear(x0, w1, b1, "gelu")
+    assert y0.shape == (0, 32)
+    y0.sum().backward()
+    assert not w1.grad.any() and not b1.grad.any()
+    x1 = _rand(1, 64, seed=6).to(DEV).requires_grad_(True)
+    ag.linear(x1, w1, b1, None).sum().backward()
+    _close(x1.grad, w1.detach().sum(0, keepdim=True), 1e-4, "single-row dx")
+    # BatchNorm over a single row refuses like torch
+    bn = torch.nn.BatchNorm1d(8).to(DEV).train()
+    with pytest.raises(ValueError, match="more than 1 value"):
+        ag.batchnorm_act(torch.zeros(1, 8, device=DEV), bn)
+    # attention tiles of ragged size, including a drug with a single live token
+    qkv = _rand(7, 3 * 64, seed=7).to(DEV).requires_grad_(True)
+    row_start = torch.tensor([0, 1, 4, 7], dtype=torch.int64, device=DEV)       # three tiles of 1, 3, 3 rows
+    out = ag.fusion_attention(qkv, 3, 19, 2, 32, row_start=row_start, row_bits=torch.zeros(7, dtype=torch.int32, device=DEV))
+    out.sum().backward()
+    qr = qkv.detach().cpu().double().requires_grad_(True)
+    outs = []
+    for lo, hi in ((0, 1), (1, 4), (4, 7)):
+        q, k, v = (qr[lo:hi, i * 64:(i + 1) * 64].reshape(hi - lo, 2, 32).transpose(0, 1) for i in range(3))
+        a = torch.softmax(q @ k.transpose(1, 2) / 32 ** 0.5, dim=-1) @ v
+        outs.append(a.transpose(0, 1).reshape(hi - lo, 64))
+    ref = torch.cat(outs)
+    ref.sum().backward()
+    _close(out, ref, 1e-5, "ragged attention fwd")
+    _close(qkv.grad, qr.grad, 2e-5, "ragged attention bwd")
