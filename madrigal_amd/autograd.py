@@ -607,3 +607,87 @@ class _BilinearAllPairs(Function):
 
 def bilinear_allpairs(z_head, z_tail, w, precision="bf16x3"):
     return _BilinearAllPairs.apply(z_head, z_tail, w, precision)
+
+
+# ------------------------------------------------------------------------------------------- HGT on the flat projection buffer
+class _HgtProject(Function):
+    """All node types' composite projections  x_t -> [ q | k'_0 v'_0 | k'_1 v'_1 ... ]  written straight into the flat
+    buffer the edge-attention kernels address (graph_plans.hgt_plan layout): one GEMM per node type, no concatenation.
+    args = x_0..x_{n-1}, W_0..W_{n-1}, b_0..b_{n-1} for the n projected node types (``layout`` = their (offset, rows, width))."""
+
+    @staticmethod
+    def forward(ctx, layout, total_floats, precision, *args):
+        n = len(layout)
+        xs, ws, bs = args[:n], args[n:2 * n], args[2 * n:]
+        dev = ws[0].device
+        flat = torch.zeros(max(total_floats, 128), dtype=torch.float32, device=dev)       # unprojected types stay zero
+        xs2 = []
+        for (off, rows, width), x, w, b in zip(layout, xs, ws, bs):
+            x2 = x if x.is_contiguous() else x.contiguous()
+            xs2.append(x2)
+            if rows:
+                ops.linear(x2, w, b, precision=precision, out=flat[off:off + rows * width].view(rows, width), cache_weight=False)
+        ctx.layout, ctx.precision, ctx.n = layout, precision, n
+        ctx.save_for_backward(*xs2, *ws)
+        return flat.view(-1, 128)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dflat):
+        n = ctx.n
+        xs, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        dflat = (dflat if dflat.is_contiguous() else dflat.contiguous()).view(-1)
+        dxs, dws, dbs = [], [], []
+        for i, ((off, rows, width), x, w) in enumerate(zip(ctx.layout, xs, ws)):
+            g = dflat[off:off + rows * width].view(rows, width)
+            dx = None
+            if ctx.needs_input_grad[3 + i] and rows:
+                dx = ops.linear(g, ops.transpose(w), precision=ctx.precision, cache_weight=False)[:, :x.shape[1]]
+            elif ctx.needs_input_grad[3 + i]:
+                dx = torch.zeros_like(x)
+            dw, db = ops.grad_weight(g, x, ctx.precision, want_bias=True)
+            dxs.append(dx)
+            dws.append(dw)
+            dbs.append(db)
+        return (None, None, None, *dxs, *dws, *dbs)
+
+
+def hgt_project(layout, total_floats, precision, xs, ws, bs):
+    return _HgtProject.apply(tuple(layout), total_floats, precision, *xs, *ws, *bs)
+
+
+class _HgtAttentionFlat(Function):
+    """Edge attention of every destination type, queries read from / query gradients written to the flat buffer itself:
+    one gradient tensor for the whole projection buffer, no per-type scatter of dq."""
+
+    @staticmethod
+    def forward(ctx, flat, heads, plans, qspec):
+        from .graph_plans import hgt_reverse_plan
+        outs, stats = [], []
+        f1 = flat.view(-1)
+        for pd, (off, rows, width) in zip(plans, qspec):
+            q = f1[off:off + rows * width].view(rows, width)[:, 0:128]
+            o, s = ops.hgt_attention_stats(q, flat, pd, heads)
+            outs.append(o)
+            stats.append(s)
+        ctx.heads, ctx.plans, ctx.qspec, ctx.n = heads, plans, qspec, len(plans)
+        ctx.revs = [hgt_reverse_plan(pd) for pd in plans]
+        ctx.save_for_backward(flat, *outs, *stats)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *douts):
+        n = ctx.n
+        flat, outs, stats = ctx.saved_tensors[0], ctx.saved_tensors[1:1 + n], ctx.saved_tensors[1 + n:1 + 2 * n]
+        dflat = torch.zeros_like(flat)
+        f1, d1 = flat.view(-1), dflat.view(-1)
+        for pd, rev, (off, rows, width), o, s, g in zip(ctx.plans, ctx.revs, ctx.qspec, outs, stats, douts):
+            q = f1[off:off + rows * width].view(rows, width)[:, 0:128]
+            dq = d1[off:off + rows * width].view(rows, width)[:, 0:128]
+            ops.hgt_attention_bwd(q, flat, pd, rev, ctx.heads, g if g.is_contiguous() else g.contiguous(), o, s, dflat, dq_out=dq)
+        return dflat, None, None, None
+
+
+def hgt_attention_flat(flat, heads, plans, qspec):
+    return _HgtAttentionFlat.apply(flat, heads, tuple(plans), tuple(qspec))

@@ -105,6 +105,14 @@ def _cached(owner, tag, tensors, build):
     return hit[1]
 
 
+def _put_diag(H: int, blocks: torch.Tensor) -> torch.Tensor:
+    """blocks [H,R,D,D] -> [R,H,D,H,D] with out[r, h, :, h, :] = blocks[h, r] and zeros elsewhere (block-diagonal placement
+    as one broadcast product with an identity mask: a single differentiable op in parameter space)."""
+    eye = torch.eye(H, dtype=blocks.dtype, device=blocks.device)
+    # [R,H,D,1,D] * [1,H,1,H,1]: the block of head h lands in column-block h only
+    return blocks.permute(1, 0, 2, 3).unsqueeze(3) * eye.view(1, H, 1, H, 1)
+
+
 def _bn_scale_shift(bn: nn.BatchNorm1d):
     """Eval-mode BatchNorm as y = x * scale + shift."""
     def build():
@@ -464,38 +472,67 @@ class HGTConv(nn.Module):
             return torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous()
         return _cached(self, ("proj", t, tuple(rels)), srcs, build)
 
+    def _relation_blocks_train(self):
+        """[R,128,128] block-diagonal relation matrices (nn.Linear layout, k' = linear(k, MK[r])) for the keys (p_rel/sqrt(D)
+        folded in) and the values, assembled from the live parameters in a handful of batched torch ops (parameter space)."""
+        H, R, D = self.heads, len(self.edge_types), self.out_channels // self.heads
+        dev = self.k_rel.weight.device
+        pr = torch.cat([self.p_rel["__".join(et)] for et in self.edge_types], dim=0) / math.sqrt(D)        # [R,H]
+        kr = self.k_rel.weight.view(H, R, D, D) * pr.t().reshape(H, R, 1, 1)
+        vr = self.v_rel.weight.view(H, R, D, D)
+        out = []
+        for blocks in (kr, vr):
+            # m[r, h, b, h, a] = blocks[h, r, a, b]  (transposed block on the diagonal: the nn.Linear layout of x @ blockdiag)
+            m = _put_diag(H, blocks.transpose(-1, -2))
+            out.append(m.reshape(R, H * D, H * D))
+        return out[0], out[1]
+
+    def _composite_projection_train(self, t: str, plan: dict, mk_all, mv_all):
+        """The composite projection of ``_composite_projection`` from the LIVE parameters: two batched [R_t,128,128] x
+        [128,in] products and one concatenation per node type (parameter space, O(parameters) — not O(nodes)); gradients
+        reach kqv_lin, k_rel, v_rel and p_rel through torch's autograd."""
+        F = self.out_channels
+        lin = self.kqv_lin.lins[t]
+        W, b = lin.weight, lin.bias
+        Wk, Wq, Wv = W[0:F], W[F:2 * F], W[2 * F:3 * F]
+        bk, bq, bv = b[0:F], b[F:2 * F], b[2 * F:3 * F]
+        rels = [self.edge_types.index(e) for e in plan["used"] if e[0] == t]
+        if not rels:
+            return Wq, bq
+        idx = self.__dict__.setdefault("_rel_idx", {}).get((t, tuple(rels)))
+        if idx is None or idx.device != W.device:
+            idx = torch.tensor(rels, dtype=torch.int64, device=W.device)
+            self.__dict__["_rel_idx"][(t, tuple(rels))] = idx
+        mk, mv = mk_all.index_select(0, idx), mv_all.index_select(0, idx)                       # [R_t,128,128]
+        wkv = torch.stack([torch.matmul(mk, Wk), torch.matmul(mv, Wv)], dim=1).reshape(-1, W.shape[1])      # rows: (r, k|v, 128)
+        bkv = torch.stack([torch.matmul(mk, bk), torch.matmul(mv, bv)], dim=1).reshape(-1)
+        return torch.cat([Wq, wkv], 0), torch.cat([bq, bkv], 0)
+
     def _forward_train(self, x_dict, edge_index_dict, needed_types=None):
-        """Differentiated pass.  Every product over node rows goes through the autograd nodes: the K|Q|V projection, then
-        one [n,128]x[128,128] product per outgoing relation for k' and v' (the block-diagonal relation matrices are
-        assembled from the parameters, p_rel/sqrt(D) folded into the key blocks), edge attention for all destination
-        types in one tape node, GELU, output projection and the sigmoid(skip) gate."""
+        """Differentiated pass on the same flat projection layout as inference: one composite GEMM per node type writes
+        q | k'_r v'_r ... into the flat buffer (ag.hgt_project), edge attention of all destination types reads queries, keys
+        and values from it and returns ONE gradient buffer (ag.hgt_attention_flat), then GELU, output projection and the
+        sigmoid(skip) gate.  The composite weights are rebuilt from the live parameters each call."""
         F, H = self.out_channels, self.heads
-        R, D = len(self.edge_types), self.out_channels // self.heads
         dev = next(iter(x_dict.values())).device
         sizes = {t: int(x.shape[0]) for t, x in x_dict.items()}
         want = set(self.dst_node_types if needed_types is None else needed_types)
         plan = self._plan(edge_index_dict, sizes, dev, want)
-        proj, pieces = {}, []
+        layout, xs, ws, bs, spec = [], [], [], [], {}
+        mk_all, mv_all = self._relation_blocks_train()
         for t, x in x_dict.items():
             n_t, wd = sizes[t], plan["width"][t]
             if (plan["nrel"][t] == 0 and t not in want) or n_t == 0:
-                pieces.append(torch.zeros(n_t * wd, device=dev))
                 continue
-            lin = self.kqv_lin.lins[t]
-            kqv = _linT(x.float(), lin.weight, lin.bias)
-            k, q, v = kqv[:, 0:F], kqv[:, F:2 * F], kqv[:, 2 * F:3 * F]
-            cols = [q]
-            for et in [e for e in plan["used"] if e[0] == t]:
-                idx = torch.arange(H, device=dev) * R + self.edge_types.index(et)
-                pr = self.p_rel["__".join(et)].view(H, 1, 1) / math.sqrt(D)
-                bk = torch.block_diag(*(self.k_rel.weight[idx] * pr).unbind(0)).t()       # parameter-space assembly
-                bv = torch.block_diag(*self.v_rel.weight[idx].unbind(0)).t()
-                cols += [_linT(k, bk), _linT(v, bv)]
-            proj[t] = torch.cat(cols, dim=1) if len(cols) > 1 else q.contiguous()
-            pieces.append(proj[t].reshape(-1))
-        kv = torch.cat(pieces).view(-1, 128)
+            w, b = self._composite_projection_train(t, plan, mk_all, mv_all)
+            layout.append((plan["base"][t], n_t, wd))
+            spec[t] = layout[-1]
+            xs.append(x.float())
+            ws.append(w)
+            bs.append(b)
+        flat = ag.hgt_project(layout, plan["total_floats"], _state["precision"], xs, ws, bs)
         dst_types = [t for t in self.node_types if t in self.dst_node_types and t in x_dict and t in want and sizes[t] > 0]
-        pres = ag.hgt_attention_all(kv, H, [plan["per_dst"][t] for t in dst_types], [proj[t][:, 0:F] for t in dst_types])
+        pres = ag.hgt_attention_flat(flat, H, [plan["per_dst"][t] for t in dst_types], [spec[t] for t in dst_types])
         out = {}
         for t, pre in zip(dst_types, pres):
             lin = self.out_lin.lins[t]

@@ -806,13 +806,19 @@ def hgt_attention_stats(q: torch.Tensor, kv: torch.Tensor, plan: dict, heads: in
 
 
 def hgt_attention_bwd(q: torch.Tensor, kv: torch.Tensor, plan: dict, rev: dict, heads: int, dout: torch.Tensor, out_pre: torch.Tensor,
-                      stats: torch.Tensor, dkv: torch.Tensor) -> torch.Tensor:
-    """-> dq [n_dst,128]; writes this destination type's key / value gradient rows into ``dkv`` (layout of ``kv``)."""
+                      stats: torch.Tensor, dkv: torch.Tensor, dq_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> dq [n_dst,128]; writes this destination type's key / value gradient rows into ``dkv`` (layout of ``kv``).
+    ``dq_out``: write dq there instead (a [n_dst,128] view with unit inner stride, e.g. the query slots of ``dkv`` itself)."""
     n_dst = q.shape[0]
     dout = _f32_cuda(dout, "dout", 2)
     if kv.dim() != 2 or kv.shape[1] != 128 or not kv.is_contiguous() or dkv.shape != kv.shape or not dkv.is_contiguous():
         raise ValueError("hgt_attention_bwd: kv / dkv must be contiguous [rows,128] (value rows follow key rows)")
-    dq = torch.empty((n_dst, 128), dtype=torch.float32, device=q.device)
+    if dq_out is None:
+        dq = torch.empty((n_dst, 128), dtype=torch.float32, device=q.device)
+    else:
+        dq = dq_out
+        if dq.shape != (n_dst, 128) or dq.stride(1) != 1 or dq.stride(0) % 4 or dq.dtype != torch.float32 or not dq.is_cuda:
+            raise ValueError("hgt_attention_bwd: dq_out must be an fp32 cuda [n_dst,128] view with unit inner stride")
     nnz, n_items = int(plan["col"].numel()), int(plan["item_dst"].numel())
     nbytes = lib().mdg_hgt_attention_bwd_workspace_bytes(_c64(nnz), _c64(n_items), _c64(rev["n_items"]), _c(heads))
     ws = _workspace(nbytes, q.device)
@@ -820,8 +826,9 @@ def hgt_attention_bwd(q: torch.Tensor, kv: torch.Tensor, plan: dict, rev: dict, 
                                       _ptr(plan["item_begin"]), _ptr(plan["item_end"]), _c64(n_items), _ptr(plan["item_ptr"]), _c64(n_dst),
                                       _ptr(dout), _c64(dout.stride(0)), _ptr(out_pre), _c64(out_pre.stride(0)), _ptr(stats), _c(heads),
                                       _ptr(rev["t_edge"]), _ptr(rev["t_dst"]), _ptr(rev["item_begin"]), _ptr(rev["item_end"]),
-                                      _c64(rev["n_items"]), _ptr(rev["item_ptr"]), _ptr(rev["rows"]), _c64(rev["n_rows"]), _ptr(dq), _c64(128),
-                                      _ptr(dkv), _c64(128), _ptr(ws), ctypes.c_size_t(nbytes), _stream(q)), "mdg_hgt_attention_bwd")
+                                      _c64(rev["n_items"]), _ptr(rev["item_ptr"]), _ptr(rev["rows"]), _c64(rev["n_rows"]), _ptr(dq),
+                                      _c64(dq.stride(0)), _ptr(dkv), _c64(128), _ptr(ws), ctypes.c_size_t(nbytes), _stream(q)),
+          "mdg_hgt_attention_bwd")
     return dq
 
 

@@ -1,0 +1,34 @@
+import cProfile, pstats, os, sys, io, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from madrigal_amd import configs, data as D, models as M
+from madrigal_amd.optim import create_optimizer
+from madrigal_amd.train import FinetuneStep
+batch, bkg = D.make_batch(4096, 0, kg_nodes=130000, kg_edges=8000000)
+torch.manual_seed(0)
+model = configs.build_model("twosides321", bkg["data"], 896).cuda()
+b = D.batch_to(batch, "cuda")
+kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
+lab, hd, tl, y = (t.cuda() for t in D.make_labelled_triples(4096, 896, 1000000, 0))
+filler = torch.randn(4096, 128, device="cuda")
+hp = dict(optimizer="adamw", structure_encoder_lr=1e-5, kg_encoder_lr=1e-5, perturb_encoders_lr=1e-5, fusion_lr=1e-6, decoder_lr=1e-4, wd=1e-2, beta1=0.9, beta2=0.999, eps=1e-8)
+fs = FinetuneStep(model, create_optimizer(model, hp))
+for _ in range(2):
+    fs.step(b, b, b["masks"], b["masks"], kgc, lab, hd, tl, y, kg_filler=filler)
+torch.cuda.synchronize()
+# host time of issuing one step (no sync inside) vs wall with sync
+t0 = time.perf_counter()
+fs.step(b, b, b["masks"], b["masks"], kgc, lab, hd, tl, y, kg_filler=filler)
+t_issue = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_total = time.perf_counter() - t0
+print(f"host issue time {t_issue * 1e3:.1f} ms, with sync {t_total * 1e3:.1f} ms")
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(3):
+    fs.step(b, b, b["masks"], b["masks"], kgc, lab, hd, tl, y, kg_filler=filler)
+torch.cuda.synchronize()
+pr.disable()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
+print(s.getvalue()[:6000])
