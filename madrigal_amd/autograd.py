@@ -523,8 +523,9 @@ class _GatherRows(Function):
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
         order = torch.argsort(idx, stable=True)
-        rowptr = torch.zeros(ctx.n_rows + 1, dtype=torch.int64, device=idx.device)
-        torch.cumsum(torch.bincount(idx, minlength=ctx.n_rows), 0, out=rowptr[1:])
+        # row pointers by binary search in the sorted indices: no host synchronisation (torch.bincount reads the maximum
+        # back to the host, which would stall the launch queue in the middle of the backward pass)
+        rowptr = torch.searchsorted(idx[order], torch.arange(ctx.n_rows + 1, device=idx.device))
         dout = dout if dout.is_contiguous() else dout.contiguous()
         return ops.csr_aggregate(dout, rowptr, order.contiguous())[:, :dout.shape[1]], None
 

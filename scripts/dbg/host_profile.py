@@ -23,6 +23,7 @@ t_issue = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_total = time.perf_counter() - t0
 print(f"host issue time {t_issue * 1e3:.1f} ms, with sync {t_total * 1e3:.1f} ms")
+torch.autograd.set_multithreading_enabled(False)
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(3):
@@ -30,5 +31,5 @@ for _ in range(3):
 torch.cuda.synchronize()
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
-print(s.getvalue()[:6000])
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(45)
+print(s.getvalue()[:9000])
