@@ -5,8 +5,9 @@ chemCPA ``TxAdaptingComPert.predict`` pieces it calls): same class names, constr
 runs in hand-written HIP kernels behind the C ABI of ``include/madrigal_hip.h`` (no PyTorch
 arithmetic on the hot path, no CPU fallback: the ops raise if the library is missing).
 
-Forward-only this release: modules must be in ``eval()`` mode and called under
-``torch.no_grad()``; training-mode statefulness (dropout, BatchNorm batch statistics) raises.
+Inference (``eval()`` under ``torch.no_grad()``) runs the fused forward kernels with cached derived weights.  Training
+mode / autograd (dropout, BatchNorm batch statistics, gradients) runs the same modules through the tape nodes of
+``madrigal_amd/autograd.py``: forward and backward arithmetic in HIP kernels, torch only as the tape.
 
 Reference lines cited per class (paths relative to the reference checkout).
 """
