@@ -14,4 +14,4 @@ void mdg_set_error(const char* fmt, ...) {
 
 extern "C" const char* mdg_last_error(void) { return g_err; }
 extern "C" const char* mdg_build_arch(void) { return "gfx950"; }
-extern "C" int mdg_abi_version(void) { return 2; }
+extern "C" int mdg_abi_version(void) { return 3; }
