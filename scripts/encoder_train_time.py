@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from madrigal_amd import configs, data as D, models as M
 batch, bkg = D.make_batch(4096, 0, kg_nodes=130000, kg_edges=8000000)

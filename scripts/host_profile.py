@@ -1,5 +1,5 @@
 import cProfile, pstats, os, sys, io, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from madrigal_amd import configs, data as D, models as M
 from madrigal_amd.optim import create_optimizer

@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from madrigal_amd import ops, autograd as ag
 x = torch.randn(64, 128, device="cuda"); w = torch.randn(128, 128, device="cuda"); b = torch.randn(128, device="cuda")
