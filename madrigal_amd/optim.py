@@ -118,13 +118,16 @@ def parameter_names_outside(model: nn.Module, forbidden: tuple, prefix: str = ""
     return out
 
 
-def create_optimizer(model: nn.Module, hparams: dict) -> AdamW:
+def parameter_groups(model: nn.Module, hparams: dict, include_learned_tokens: bool = False) -> List[dict]:
     """madrigal/utils.py:463-613: one (no-decay, decay) pair of parameter groups per model part with its own learning
-    rate — structure encoder, KG encoder, cv encoder(s), tx encoder(s), fusion (+ position encoding, projectors and the
-    learned tokens), decoder.  A parameter decays when it is outside every LayerNorm and is not a bias."""
+    rate — structure encoder, KG encoder, cv encoder(s), tx encoder(s), fusion (+ position encoding and projectors),
+    decoder.  A parameter decays when it is outside every LayerNorm and is not a bias; the decoder always decays.
+
+    The reference's grouping leaves the encoder's learned ``cls`` / ``tx_bottleneck_tokens`` out of every group (its
+    get_parameter_names drops them and the line meant to add them back reads the wrong module, utils.py:459,478), so they
+    are never updated; ``include_learned_tokens=False`` reproduces that (pinned by tests/golden/param_groups.npz),
+    ``True`` trains them with the fusion group."""
     from . import models as M
-    if hparams.get("optimizer", "adamw") != "adamw":
-        raise NotImplementedError("only AdamW runs on the HIP path (the reference's default, parse_args.py:135)")
     decay = {n for n in parameter_names_outside(model, (nn.LayerNorm,)) if "bias" not in n}
     named = dict(model.named_parameters())
 
@@ -153,8 +156,18 @@ def create_optimizer(model: nn.Module, hparams: dict) -> AdamW:
            "tx": hparams["perturb_encoders_lr"], "fusion": hparams["fusion_lr"], "decoder": hparams["decoder_lr"]}
     buckets: Dict[tuple, list] = {}
     for name, p in named.items():
+        leaf = name.split(".")[-1]
+        token = "cls" in leaf or "bottleneck_tokens" in leaf
+        if token and not include_learned_tokens:
+            continue
         kind = owner(name)
-        wd = hparams["wd"] if (kind == "decoder" or name in decay) else 0.0
+        wd = hparams["wd"] if (kind == "decoder" or name in decay or token) else 0.0
         buckets.setdefault((kind, wd), []).append(p)
-    groups = [{"params": ps, "weight_decay": wd, "lr": lrs[kind]} for (kind, wd), ps in buckets.items() if ps]
-    return AdamW(groups, betas=(hparams["beta1"], hparams["beta2"]), eps=hparams["eps"])
+    return [{"params": ps, "weight_decay": wd, "lr": lrs[kind]} for (kind, wd), ps in buckets.items() if ps]
+
+
+def create_optimizer(model: nn.Module, hparams: dict, include_learned_tokens: bool = False) -> AdamW:
+    """AdamW on the HIP path over ``parameter_groups`` (the reference's create_optimizer, madrigal/utils.py:463-613)."""
+    if hparams.get("optimizer", "adamw") != "adamw":
+        raise NotImplementedError("only AdamW runs on the HIP path (the reference's default, parse_args.py:135)")
+    return AdamW(parameter_groups(model, hparams, include_learned_tokens), betas=(hparams["beta1"], hparams["beta2"]), eps=hparams["eps"])

@@ -414,6 +414,30 @@ def gen_eval_masks_and_schedule():
     save("lr_schedule", lrs=np.asarray(lrs, dtype=np.float64), warmup=7, total=40)
 
 
+def gen_param_groups(M, C):
+    """The reference's create_optimizer (madrigal/utils.py:463-613) on its own model: per parameter name the learning rate
+    and weight decay of the group it lands in (NaN = the parameter is in no group, i.e. never updated)."""
+    import madrigal.utils as U
+    hp = dict(optimizer="adamw", structure_encoder_lr=1e-3, kg_encoder_lr=2e-3, perturb_encoders_lr=3e-3, fusion_lr=4e-3, decoder_lr=5e-3,
+              wd=0.25, beta1=0.9, beta2=0.999, eps=1e-8)
+    n, L, seed = 14, 6, 61
+    out = {}
+    for case in (ENCODE_CASES[1], ENCODE_CASES[2]):
+        batch, bkg = D.make_batch(n, seed, kg_nodes=300, kg_edges=2500, masks=D.make_masks(n, seed))
+        model = build_reference_model(M, C, bkg["data"], case, L, seed)
+        opt = U.create_optimizer(model, hp)
+        where = {}
+        for g in opt.param_groups:
+            for p in g["params"]:
+                assert id(p) not in where
+                where[id(p)] = (g["lr"], g["weight_decay"])
+        names = [k for k, _ in model.named_parameters()]
+        vals = np.array([where.get(id(p), (np.nan, np.nan)) for _, p in model.named_parameters()], dtype=np.float64)
+        out[f"{case[0]}_names"], out[f"{case[0]}_lr_wd"] = np.array(names), vals
+        out[f"{case[0]}_n_groups"] = len(opt.param_groups)
+    save("param_groups", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -430,6 +454,7 @@ def main():
     gen_ranks(args.ref)
     gen_bce()
     gen_eval_masks_and_schedule()
+    gen_param_groups(M, C)
 
 
 if __name__ == "__main__":

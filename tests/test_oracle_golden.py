@@ -185,3 +185,37 @@ def test_average_precision_matches_sklearn():
     macro, per = macro_auprc(torch.from_numpy(s), torch.from_numpy(y), torch.from_numpy(lab), L)
     want = [average_precision_score(y[lab == l], s[lab == l]) for l in range(L) if l != 3]
     assert abs(float(macro) - float(np.mean(want))) < 1e-12 and bool(torch.isnan(per[3]))
+
+
+def test_parameter_groups_match_reference_create_optimizer(golden):
+    """Learning rate and weight decay of every parameter as the reference's create_optimizer assigns them on its own model
+    (same state_dict names), including the parameters it leaves out of every group."""
+    import math
+    import numpy as np
+    import torch
+    from madrigal_amd import data as D, models as M
+    from madrigal_amd.optim import parameter_groups
+    from helpers import ENCODE_CASES
+    from test_models_gpu import build_model
+    g = golden("param_groups")
+    hp = dict(optimizer="adamw", structure_encoder_lr=1e-3, kg_encoder_lr=2e-3, perturb_encoders_lr=3e-3, fusion_lr=4e-3, decoder_lr=5e-3,
+              wd=0.25, beta1=0.9, beta2=0.999, eps=1e-8)
+    for case in (ENCODE_CASES[1], ENCODE_CASES[2]):
+        batch, bkg = D.make_batch(14, 61, kg_nodes=300, kg_edges=2500, masks=D.make_masks(14, 61))
+        model = build_model(M, case, bkg["data"], 6)
+        want = {str(n): tuple(v) for n, v in zip(g[case[0] + "_names"], g[case[0] + "_lr_wd"])}
+        groups = parameter_groups(model, hp)
+        got = {}
+        name_of = {id(p): k for k, p in model.named_parameters()}
+        for grp in groups:
+            for p in grp["params"]:
+                assert name_of[id(p)] not in got
+                got[name_of[id(p)]] = (grp["lr"], grp["weight_decay"])
+        assert set(want) == set(name_of.values()), set(want) ^ set(name_of.values())
+        for k, (lr, wd) in want.items():
+            if math.isnan(lr):
+                assert k not in got, k                       # the reference never updates these (cls / bottleneck tokens)
+            else:
+                assert got[k] == (lr, wd), (k, got.get(k), (lr, wd))
+        with_tokens = {name_of[id(p)] for grp in parameter_groups(model, hp, include_learned_tokens=True) for p in grp["params"]}
+        assert with_tokens == set(name_of.values())
