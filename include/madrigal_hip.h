@@ -324,14 +324,16 @@ int mdg_batchnorm_train_bwd(const float* dy, const float* x, const float* stats,
  *   mdg_col_reduce mode 0: out[c] = sum_r x;  1: sum_r (x - center[c])^2;  2: sum_r x * (y - center[c]) * rstd[c]
  *   mdg_batchnorm_finalize phase 0: stats[0:C] = sum / count;  phase 1: rstd | scale | shift from sqsum / count and the
  *   running-statistics update;  then mdg_affine_act(x, stats + 2C, stats + 3C) applies the normalisation.
- *   mdg_batchnorm_bwd_apply: dx from the (all-reduced) sum_dy and sum_dy_xhat. */
+ *   mdg_batchnorm_bwd_apply: dx from the (all-reduced) sum_dy and sum_dy_xhat.
+ * count_dev (optional): the total row count as a device double (itself all-reduced) read by the kernel instead of the
+ * host value — no host round trip inside the step. */
 int mdg_col_reduce(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* center, const float* rstd, float* out,
                    int64_t rows, int64_t cols, int mode, void* workspace, size_t workspace_bytes, void* stream);
 int mdg_batchnorm_finalize(const float* sum, const float* sqsum, const float* gamma, const float* beta, float* running_mean,
-                           float* running_var, float* stats, double count, int64_t cols, float eps, float momentum, int phase,
-                           void* stream);
+                           float* running_var, float* stats, double count, const double* count_dev, int64_t cols, float eps,
+                           float momentum, int phase, void* stream);
 int mdg_batchnorm_bwd_apply(const float* dy, const float* x, const float* stats, const float* sum_dy, const float* sum_dy_xhat,
-                            float* dx, int64_t rows, int64_t cols, double count, void* stream);
+                            float* dx, int64_t rows, int64_t cols, double count, const double* count_dev, void* stream);
 
 /* y = act(x * scale[c] + shift[c]) per column (eval-mode BatchNorm inside a differentiated graph; shift may be NULL). */
 int mdg_affine_act(const float* x, int64_t ldx, const float* scale, const float* shift, float* y, int64_t ldy, int64_t rows,

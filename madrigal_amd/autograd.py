@@ -108,18 +108,18 @@ class _SyncBatchNormAct(Function):
             pre = y
         elif fused is None and act not in (None, "none"):
             pre, y = y, ops.activation_fwd(y, act)
-        ctx.save_for_backward(x, stats, pre)
-        ctx.act, ctx.affine, ctx.count, ctx.reduce_ = act, gamma is not None, count, reduce_
+        ctx.save_for_backward(x, stats, pre, count)
+        ctx.act, ctx.affine, ctx.reduce_ = act, gamma is not None, reduce_
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, stats, pre = ctx.saved_tensors
+        x, stats, pre, count = ctx.saved_tensors
         g = dy if dy.is_contiguous() else dy.contiguous()
         if pre is not None:
             g = ops.activation_bwd(g, pre, ctx.act)
-        dx, dg, db = ops.sync_batchnorm_train_bwd(g, x, stats, ctx.count, ctx.reduce_)
+        dx, dg, db = ops.sync_batchnorm_train_bwd(g, x, stats, count, ctx.reduce_)
         return dx, (dg if ctx.affine else None), (db if ctx.affine else None), None, None, None, None, None, None
 
 

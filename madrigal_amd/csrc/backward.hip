@@ -188,9 +188,11 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(const float* __r
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sqsum, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var, float* __restrict__ stats, double rows,
-                                                          int64_t cols, float eps, float momentum, int phase) {
+                                                          int64_t cols, float eps, float momentum, int phase,
+                                                          const double* __restrict__ rows_dev = nullptr) {
   const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (c >= cols) return;
+  if (rows_dev) rows = rows_dev[0];
   if (phase == 0) { stats[c] = sum[c] / static_cast<float>(rows); return; }
   const float mean = stats[c];
   const float var = sqsum[c] / static_cast<float>(rows);
@@ -216,11 +218,12 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
 // dx = scale[c] * (dy - sum_dy[c]/M - xhat * sum_dy_xhat[c]/M),  xhat = (x - mean[c]) * rstd[c]
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
                                                            const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat,
-                                                           float* __restrict__ dx, int64_t rows, int64_t cols, float count) {
+                                                           float* __restrict__ dx, int64_t rows, int64_t cols, float count,
+                                                           const double* __restrict__ count_dev = nullptr) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= rows * cols) return;
   const int64_t c = i % cols;
-  const float inv = 1.0f / count;
+  const float inv = 1.0f / (count_dev ? static_cast<float>(count_dev[0]) : count);
   const float xhat = (x[i] - stats[c]) * stats[cols + c];
   dx[i] = stats[2 * cols + c] * (dy[i] - sum_dy[c] * inv - xhat * (sum_dy_xhat[c] * inv));
 }
@@ -544,23 +547,23 @@ extern "C" int mdg_col_reduce(const float* x, int64_t ldx, const float* y, int64
 }
 
 extern "C" int mdg_batchnorm_finalize(const float* sum, const float* sqsum, const float* gamma, const float* beta, float* running_mean,
-                                      float* running_var, float* stats, double count, int64_t cols, float eps, float momentum, int phase,
-                                      void* stream) {
-  MDG_CHECK_ARG(cols > 0 && count > 1.0 && (phase == 0 || phase == 1), "mdg_batchnorm_finalize: bad arguments (needs more than one row in total)");
+                                      float* running_var, float* stats, double count, const double* count_dev, int64_t cols, float eps,
+                                      float momentum, int phase, void* stream) {
+  MDG_CHECK_ARG(cols > 0 && (count_dev || count > 1.0) && (phase == 0 || phase == 1), "mdg_batchnorm_finalize: bad arguments (needs more than one row in total)");
   MDG_CHECK_ARG(stats && sum && (phase == 0 || sqsum), "mdg_batchnorm_finalize: null pointer");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), sum, sqsum,
-                     gamma, beta, running_mean, running_var, stats, count, cols, eps, momentum, phase);
+                     gamma, beta, running_mean, running_var, stats, count, cols, eps, momentum, phase, count_dev);
   MDG_CHECK_LAUNCH("mdg_batchnorm_finalize");
   return MDG_OK;
 }
 
 extern "C" int mdg_batchnorm_bwd_apply(const float* dy, const float* x, const float* stats, const float* sum_dy, const float* sum_dy_xhat,
-                                       float* dx, int64_t rows, int64_t cols, double count, void* stream) {
-  MDG_CHECK_ARG(rows >= 0 && cols > 0 && count > 1.0, "mdg_batchnorm_bwd_apply: bad shape");
+                                       float* dx, int64_t rows, int64_t cols, double count, const double* count_dev, void* stream) {
+  MDG_CHECK_ARG(rows >= 0 && cols > 0 && (count_dev || count > 1.0), "mdg_batchnorm_bwd_apply: bad shape");
   if (rows == 0) return MDG_OK;
   MDG_CHECK_ARG(dy && x && stats && sum_dy && sum_dy_xhat && dx, "mdg_batchnorm_bwd_apply: null pointer");
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(static_cast<unsigned>(mdg_cdiv(rows * cols, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), dy, x,
-                     stats, sum_dy, sum_dy_xhat, dx, rows, cols, static_cast<float>(count));
+                     stats, sum_dy, sum_dy_xhat, dx, rows, cols, static_cast<float>(count), count_dev);
   MDG_CHECK_LAUNCH("mdg_batchnorm_bwd_apply");
   return MDG_OK;
 }

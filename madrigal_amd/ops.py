@@ -906,29 +906,26 @@ def _col_reduce(x, y, center, rstd, mode: int) -> torch.Tensor:
 
 def sync_batchnorm_train_fwd(x: torch.Tensor, gamma, beta, running_mean, running_var, eps: float, momentum: float, act, reduce_):
     """BatchNorm1d training forward with statistics over all ranks: ``reduce_(t)`` sums a small device tensor over ranks
-    in place; ``count`` rows in total.  -> (y, stats[4C], count)."""
+    in place.  The total row count stays on the device (no host read inside the step).  -> (y, stats[4C], count_dev[1])."""
     x = _f32_cuda(x, "x", 2)
     R, C = x.shape
-    cnt = torch.tensor([float(R)], dtype=torch.float64, device=x.device)
+    cnt = torch.tensor([float(R)], dtype=torch.float64).to(x.device, non_blocking=True)
     s = _col_reduce(x, None, None, None, 0)
     reduce_(s)
     reduce_(cnt)
-    count = float(cnt.item())                       # one host read per layer (the row count of the other shards)
-    if count < 2:
-        raise ValueError("Expected more than 1 value per channel when training")
     stats = torch.empty(4 * C, dtype=torch.float32, device=x.device)
     fin = lib().mdg_batchnorm_finalize
-    check(fin(_ptr(s), _ptr(None), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(stats), ctypes.c_double(count), _c64(C),
-              _f(eps), _f(momentum), _c(0), _stream(x)), "mdg_batchnorm_finalize")
+    check(fin(_ptr(s), _ptr(None), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(stats), ctypes.c_double(0.0), _ptr(cnt),
+              _c64(C), _f(eps), _f(momentum), _c(0), _stream(x)), "mdg_batchnorm_finalize")
     q = _col_reduce(x, None, stats, None, 1)
     reduce_(q)
-    check(fin(_ptr(s), _ptr(q), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(stats), ctypes.c_double(count), _c64(C),
-              _f(eps), _f(momentum), _c(1), _stream(x)), "mdg_batchnorm_finalize")
+    check(fin(_ptr(s), _ptr(q), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(stats), ctypes.c_double(0.0), _ptr(cnt),
+              _c64(C), _f(eps), _f(momentum), _c(1), _stream(x)), "mdg_batchnorm_finalize")
     y = affine_act(x, stats[2 * C:3 * C], stats[3 * C:4 * C], act)
-    return y, stats, count
+    return y, stats, cnt
 
 
-def sync_batchnorm_train_bwd(dy: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, count: float, reduce_):
+def sync_batchnorm_train_bwd(dy: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, count: torch.Tensor, reduce_):
     """-> (dx, dgamma_local, dbeta_local): dx uses the sums over ALL ranks, the parameter gradients stay local partial sums
     (they are summed over ranks with every other parameter gradient)."""
     dy, x = _f32_cuda(dy, "dy", 2), _f32_cuda(x, "x", 2)
@@ -939,5 +936,5 @@ def sync_batchnorm_train_bwd(dy: torch.Tensor, x: torch.Tensor, stats: torch.Ten
     reduce_(both)
     dx = torch.empty_like(x)
     check(lib().mdg_batchnorm_bwd_apply(_ptr(dy), _ptr(x), _ptr(stats), _ptr(both[:C].contiguous()), _ptr(both[C:].contiguous()), _ptr(dx),
-                                        _c64(R), _c64(C), ctypes.c_double(count), _stream(x)), "mdg_batchnorm_bwd_apply")
+                                        _c64(R), _c64(C), ctypes.c_double(0.0), _ptr(count), _stream(x)), "mdg_batchnorm_bwd_apply")
     return dx, dg, db
