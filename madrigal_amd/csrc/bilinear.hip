@@ -235,9 +235,12 @@ __device__ __forceinline__ void compute_tile(const AFrag<MODE>& A, const char* l
 // accumulator register v of lane (r,h) is element [row (v&3)+8(v>>2)+4h][col r] of the 32x32 tile
 __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >> 2) + 4 * h; }
 
-template <int MODE, int EPI, int NW>
+// RB = 32-row blocks of z_head per wave.  RB = 2 (row statistics in bf16 only): every B fragment read from LDS feeds two
+// MFMAs instead of one — with a single bf16 product per k-step the sweep is otherwise bound by the LDS operand reads
+// (one ds_read_b128 per MFMA), not by the matrix cores.
+template <int MODE, int EPI, int NW, int RB = 1>
 __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const BilinearArgs p) {
-  constexpr int BM = 32 * NW;        // head rows per workgroup
+  constexpr int BM = 32 * NW * RB;   // head rows per workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const buf0 = smem;
   char* const buf1 = smem + STAGE_BYTES;
@@ -246,10 +249,12 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
   const int64_t row0 = static_cast<int64_t>(blockIdx.x) * BM;
 
   // ---------------- prologue: T = z_head[rows] . W_sym[l], kept as the A operand -------------
-  AFrag<MODE> At;
-  {
+  AFrag<MODE> Ats[RB];
+  AFrag<MODE>& At = Ats[0];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
     AFrag<MODE> Az;
-    int64_t zr = row0 + wave * 32 + r;
+    int64_t zr = row0 + (wave * RB + rb) * 32 + r;
     zr = zr < p.n_head ? zr : p.n_head - 1;
     afrag_from_global<MODE>(Az, p.z_head + zr * D, h);
     TileSrc ws = p.w;
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
         }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      afrag_from_slab<MODE>(At, slab, st, r, h);
+      afrag_from_slab<MODE>(Ats[rb], slab, st, r, h);
     }
     __syncthreads();
   }
@@ -291,10 +296,10 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
   __amdgpu_buffer_rsrc_t rsrc;
   if constexpr (EPI != MDG_EPI_ROWSTATS)
     rsrc = __builtin_amdgcn_make_buffer_rsrc(out_slab, 0, static_cast<int>(slab_rows * p.n_tail * 4), 0x00020000);
-  f32x16 rsum, rmax;
+  f32x16 rsum, rmax, rsum2, rmax2;       // (second pair: row block 1 when RB == 2)
   if constexpr (EPI == MDG_EPI_ROWSTATS) {
 #pragma unroll
-    for (int v = 0; v < 16; ++v) { rsum[v] = 0.f; rmax[v] = -INFINITY; }
+    for (int v = 0; v < 16; ++v) { rsum[v] = 0.f; rmax[v] = -INFINITY; rsum2[v] = 0.f; rmax2[v] = -INFINITY; }
   }
 
   // Pipeline: one raw barrier and ONE full vmcnt(0) wait per stage -- no counted waits: correctness never relies
@@ -383,8 +388,44 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-        compute_tile<MODE>(At, smem + cur * STAGE_BYTES, r, h, acc);
-        epilogue(acc, tcol0);
+        if constexpr (RB == 2) {
+          f32x16 acc1[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc1[t][v] = 0.f;
+          const char* lds = smem + cur * STAGE_BYTES;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+              const bf16x8 bh = *reinterpret_cast<const bf16x8*>(lds + tile_off<256>(32 * t + r, 2 * s + h));
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ats[0].hi[s], bh, acc[t], 0, 0, 0);
+              acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ats[RB - 1].hi[s], bh, acc1[t], 0, 0, 0);
+            }
+          epilogue(acc, tcol0);
+          // row block 1: same reduction into the second accumulator pair
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            if (tcol0 + BN <= p.n_tail) {                 // whole tile in range (wave-uniform): no per-element masking
+#pragma unroll
+              for (int v = 0; v < 16; ++v) {
+                rsum2[v] += acc1[t][v];
+                rmax2[v] = fmaxf(rmax2[v], acc1[t][v]);
+              }
+            } else {
+              const bool col_ok = tcol0 + 32 * t + r < p.n_tail;
+#pragma unroll
+              for (int v = 0; v < 16; ++v) {
+                rsum2[v] += col_ok ? acc1[t][v] : 0.f;
+                rmax2[v] = fmaxf(rmax2[v], col_ok ? acc1[t][v] : -INFINITY);
+              }
+            }
+          }
+        } else {
+          compute_tile<MODE>(At, smem + cur * STAGE_BYTES, r, h, acc);
+          epilogue(acc, tcol0);
+        }
         cur = cur == 2 ? 0 : cur + 1;
       }
     } else {
@@ -446,20 +487,22 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
 
   if constexpr (EPI == MDG_EPI_ROWSTATS) {
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      float sv = rsum[v], mv = rmax[v];
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {
-        sv += __shfl_xor(sv, o, 64);
-        mv = fmaxf(mv, __shfl_xor(mv, o, 64));
+      for (int v = 0; v < 16; ++v) {
+        float sv = rb == 0 ? rsum[v] : rsum2[v], mv = rb == 0 ? rmax[v] : rmax2[v];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          sv += __shfl_xor(sv, o, 64);
+          mv = fmaxf(mv, __shfl_xor(mv, o, 64));
+        }
+        const int64_t row = row0 + (wave * RB + rb) * 32 + acc_row(v, h);
+        if (r == 0 && row < p.n_head) {
+          float* o2 = p.out + (l * p.n_head + row) * 2;
+          o2[0] = sv;
+          o2[1] = mv;
+        }
       }
-      const int64_t row = row0 + wave * 32 + acc_row(v, h);
-      if (r == 0 && row < p.n_head) {
-        float* o2 = p.out + (l * p.n_head + row) * 2;
-        o2[0] = sv;
-        o2[1] = mv;
-      }
-    }
   }
 }
 
@@ -506,9 +549,16 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
     case MDG_EPI_STORE_SIGMOID:
       hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE_SIGMOID, NW>), grid, block, lds, st, a);
       break;
-    case MDG_EPI_ROWSTATS:      // three-buffer ring (prefetch distance two)
-      hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_ROWSTATS, NW>), grid, block, 3 * STAGE_BYTES, st, a);
+    case MDG_EPI_ROWSTATS: {    // three-buffer ring (prefetch distance two)
+      static const int rb2 = getenv("MDG_BILINEAR_RB") ? atoi(getenv("MDG_BILINEAR_RB")) : 2;
+      if (MODE == MDG_PREC_BF16 && rb2 == 2 && a.pipeline == 0) {     // 64 rows per wave: halves the LDS operand reads per MFMA
+        const dim3 grid2(static_cast<unsigned>(mdg_cdiv(a.n_head, 32 * NW * 2)), static_cast<unsigned>(a.n_labels));
+        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_ROWSTATS, NW, (MODE == MDG_PREC_BF16 ? 2 : 1)>), grid2, block, 3 * STAGE_BYTES, st, a);
+      } else {
+        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_ROWSTATS, NW>), grid, block, 3 * STAGE_BYTES, st, a);
+      }
       break;
+    }
     default:
       mdg_set_error("mdg_bilinear_allpairs: unknown epilogue %d", epilogue);
       return MDG_EINVAL;

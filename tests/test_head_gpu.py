@@ -84,16 +84,20 @@ def test_sigmoid_epilogue(ops):
     assert float((got - ref).abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
-def test_rowstats_epilogue(ops, prec):
-    zh, zt, w = _rand((300, 128), 10), _rand((333, 128), 11), _rand((4, 128, 128), 12, 0.1)
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("nh,nt", [(300, 333), (1, 1), (513, 64), (1100, 130)])
+def test_rowstats_epilogue(ops, prec, nh, nt):
+    """(bf16 runs the two-row-blocks-per-wave variant: 512 head rows per workgroup, ragged row and column tails.)"""
+    zh, zt, w = _rand((nh, 128), 10), _rand((nt, 128), 11), _rand((4, 128, 128), 12, 0.1)
     ref = _oracle(zh, zt, w)
     st = ops.bilinear_allpairs(zh.cuda(), zt.cuda(), ops.symmetrize(w.cuda()), precision=prec,
                                epilogue=ops.EPI_ROWSTATS).cpu()
-    assert st.shape == (4, 300, 2)
+    assert st.shape == (4, nh, 2)
     scale = float(ref.abs().max())
     assert float((st[..., 1] - ref.max(dim=2).values).abs().max()) < TOL[prec] * scale
-    assert float((st[..., 0] - ref.sum(dim=2)).abs().max()) < TOL[prec] * scale * 333 ** 0.5 * 4
+    assert float((st[..., 0] - ref.sum(dim=2)).abs().max()) < TOL[prec] * scale * max(nt, 2) ** 0.5 * 4
+    dense = ops.bilinear_allpairs(zh.cuda(), zt.cuda(), ops.symmetrize(w.cuda()), precision=prec).cpu()
+    assert torch.equal(st[..., 1], dense.max(dim=2).values)          # same products, same maxima, bit for bit
 
 
 def test_empty_and_errors(ops):
