@@ -76,3 +76,102 @@ def get_evaluate_masks(head_masks_base: torch.Tensor, tail_masks_base: torch.Ten
     for kind, base in zip(parts, (head_masks_base, tail_masks_base)):
         sides.append(full_mask_for_finetune_mode(finetune_mode, base) if kind == "full" else modality_mask(base, kind))
     return sides[0].to(device), sides[1].to(device)
+
+
+# ------------------------------------------------------------------------------------------- contrastive pretraining views
+# Host-side view sampling of pretrain.py:59-71 (train_epoch): a per-drug bank of candidate modality subsets built once
+# (madrigal/utils.py:51-145 get_pretrain_masks) and one draw per drug and iteration (utils.py:360-390
+# pretrain_modality_subset_sampler).  Every shipped contrastive config uses pretrain_mode 'str_center_uni': view 1 shows
+# the structure alone, view 2 shows exactly ONE of the drug's other modalities, so each view contributes one row per
+# drug to the raw-encoder-output path (models.py:890-894).
+
+import itertools
+
+import numpy as np
+
+PRETRAIN_MODES = ("double_random", "str_kg", "str_center", "str_center_uni", "str_center_comb")
+
+
+def _subset_row(present_cols, width: int) -> np.ndarray:
+    """float32[width], 0 at the shown columns and 1 (hidden) elsewhere — from_indices_to_tensor(cols, width) (utils.py:398)."""
+    row = np.ones(width, dtype=np.float32)
+    row[list(present_cols)] = 0
+    return row
+
+
+def _nonempty_subsets(cols):
+    """All non-empty subsets in the order of itertools' powerset recipe (utils.py:393-395), i.e. by size then lexicographic."""
+    cols = list(cols)
+    return [c for r in range(1, len(cols) + 1) for c in itertools.combinations(cols, r)]
+
+
+def modality_sampling_probs(masks: np.ndarray, tx_downsample_ratio: float) -> np.ndarray:
+    """utils.py:58-63: inverse availability counts, tx columns scaled down, normalised, clipped away from zero."""
+    assert tx_downsample_ratio <= 1
+    probs = 1.0 / (1 - masks).sum(axis=0)
+    probs[-len(CELL_LINES):] = tx_downsample_ratio * probs[-len(CELL_LINES):]
+    probs = np.array(probs / probs.sum())
+    return np.clip(probs, 1e-6, 1.0)
+
+
+def get_pretrain_masks(drugs, masks: np.ndarray, pretrain_mode: str, pretrain_unbalanced: bool,
+                       pretrain_tx_downsample_ratio: float) -> dict:
+    """utils.py:51-145 -> {drug: bank}.  ``masks`` is the int availability table [n,19] (1 = absent).  A bank is a
+    torch float32 tensor [k,19] of candidate views (unbalanced 'str_center_uni', 'double_random', 'str_kg') or a pair
+    (list of float32 numpy rows, probabilities) (balanced 'str_center_uni').
+
+    'str_center' and 'str_center_comb' are refused: the reference files those banks under the availability row with the
+    structure column overwritten (utils.py:75,83,121,129) and then looks them up under the unmodified row, so its own
+    call raises for any drug that has a structure (tests/golden/pretrain_views.npz records the four exceptions); no
+    shipped config uses them."""
+    if pretrain_mode not in PRETRAIN_MODES:
+        raise NotImplementedError(pretrain_mode)
+    if pretrain_mode in ("str_center", "str_center_comb"):
+        raise NotImplementedError(f"pretrain_mode={pretrain_mode!r}: the reference's own bank construction fails for this mode")
+    masks = np.asarray(masks)
+    width = masks.shape[1]
+    probs = None if pretrain_unbalanced else modality_sampling_probs(masks, pretrain_tx_downsample_ratio)
+    banks = {}
+    for pattern in np.unique(masks, axis=0):
+        shown = np.where(pattern == 0)[0].tolist()
+        if pretrain_mode in ("double_random", "str_kg"):
+            banks[tuple(pattern)] = torch.stack([torch.from_numpy(_subset_row(c, width)) for c in _nonempty_subsets(shown)])
+            continue
+        # 'str_center_uni' (utils.py:97-117): one candidate per available modality except the first available column,
+        # which is the structure (every drug has one)
+        rows = [_subset_row((c,), width) for c in shown[1:]]
+        if pretrain_unbalanced:
+            banks[tuple(pattern)] = torch.stack([torch.from_numpy(r) for r in rows])
+        else:
+            w = np.array([probs[c] for c in shown[1:]])
+            banks[tuple(pattern)] = (rows, w / sum(w))
+    return {d: banks[tuple(m)] for d, m in zip(drugs, masks)}
+
+
+def pretrain_modality_subset_sampler(all_subset_masks, pretrain_mode: str = "str_center_uni", unbalanced: bool = False):
+    """utils.py:360-390: one (view-1, view-2) pair of bool masks [B,19] (True = absent) for the drugs whose banks are
+    given.  Draws from numpy's global generator (balanced modes) or torch's (unbalanced / double_random), exactly where
+    the reference draws, so a seeded run picks the same views."""
+    n = len(all_subset_masks)
+    if pretrain_mode == "str_center_uni":
+        first = all_subset_masks[0][0][0] if not unbalanced else all_subset_masks[0][0]
+        width = int(np.asarray(first).shape[-1])
+        aug1 = torch.ones(n, width, dtype=torch.bool)
+        aug1[:, 0] = False
+        if not unbalanced:
+            picks = [rows[np.random.choice(np.arange(len(rows)), size=1, p=w)[0]] for rows, w in all_subset_masks]
+            aug2 = torch.from_numpy(np.stack(picks, axis=0)).bool()
+        else:
+            aug2 = torch.stack([bank[torch.randint(len(bank), (1,))[0].item()] for bank in all_subset_masks], dim=0).bool()
+        return aug1, aug2
+    if pretrain_mode == "double_random":
+        pairs = torch.stack([bank[torch.randperm(len(bank))[:2]] for bank in all_subset_masks], dim=0)     # two distinct views
+        return pairs[:, 0, :].bool(), pairs[:, 1, :].bool()
+    if pretrain_mode == "str_kg":
+        width = int(all_subset_masks[0].shape[-1])
+        aug1 = torch.ones(n, width, dtype=torch.bool)
+        aug2 = torch.ones(n, width, dtype=torch.bool)
+        aug1[:, 0] = False
+        aug2[:, 1] = False
+        return aug1, aug2
+    raise NotImplementedError(pretrain_mode)

@@ -9,7 +9,7 @@ parallel by outcome (or by head row), each rank writing only its own slab of the
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Tuple
+from typing import Iterable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -29,16 +29,19 @@ def shard_sizes(n: int, world: int) -> List[int]:
     return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
 
 
-def all_gather_rows(local: torch.Tensor, n_total: int, rank: int, world: int, group=None) -> torch.Tensor:
-    """Concatenate every rank's row block (sizes from ``shard_range``) in rank order -> [n_total, ...].
+def all_gather_rows(local: torch.Tensor, n_total: int, rank: int, world: int, group=None, sizes: Optional[List[int]] = None) -> torch.Tensor:
+    """Concatenate every rank's row block in rank order -> [n_total, ...].  Block sizes come from ``shard_range`` or, when
+    the blocks are not the even split (rows per drug vary), from ``sizes`` (known on every rank).
 
     Uneven blocks are padded to the largest block so that one ``all_gather_into_tensor`` suffices."""
     if world == 1:
         return local
     if local.is_cuda and dist.get_backend(group) == "gloo":
         # functional rehearsal of the multi-rank path without RCCL (several ranks sharing one card): stage via the host
-        return all_gather_rows(local.cpu(), n_total, rank, world, group).to(local.device)
-    sizes = shard_sizes(n_total, world)
+        return all_gather_rows(local.cpu(), n_total, rank, world, group, sizes).to(local.device)
+    sizes = shard_sizes(n_total, world) if sizes is None else [int(v) for v in sizes]
+    if len(sizes) != world or sum(sizes) != n_total:
+        raise ValueError(f"block sizes {sizes} do not add up to {n_total} rows over {world} ranks")
     if local.shape[0] != sizes[rank]:
         raise ValueError(f"rank {rank}: expected {sizes[rank]} rows, got {local.shape[0]}")
     m = max(sizes)
@@ -77,32 +80,50 @@ class _AllGatherRowsGrad(Function):
     as one all-reduce + slice)."""
 
     @staticmethod
-    def forward(ctx, local, n_total, rank, world, group):
-        ctx.meta = (n_total, rank, world, group)
-        return all_gather_rows(local.contiguous(), n_total, rank, world, group)
+    def forward(ctx, local, n_total, rank, world, group, sizes):
+        ctx.meta = (n_total, rank, world, group, sizes)
+        return all_gather_rows(local.contiguous(), n_total, rank, world, group, sizes)
 
     @staticmethod
     def backward(ctx, dfull):
-        n_total, rank, world, group = ctx.meta
-        lo, hi = shard_range(n_total, rank, world)
+        n_total, rank, world, group, sizes = ctx.meta
+        if sizes is None:
+            lo, hi = shard_range(n_total, rank, world)
+        else:
+            lo = sum(sizes[:rank])
+            hi = lo + sizes[rank]
         g = all_reduce_sum_(dfull.contiguous().clone(), group)
-        return g[lo:hi].contiguous(), None, None, None, None
+        return g[lo:hi].contiguous(), None, None, None, None, None
 
 
-def all_gather_rows_grad(local: torch.Tensor, n_total: int, rank: int, world: int, group=None) -> torch.Tensor:
-    return local if world == 1 else _AllGatherRowsGrad.apply(local, n_total, rank, world, group)
+def all_gather_rows_grad(local: torch.Tensor, n_total: int, rank: int, world: int, group=None, sizes: Optional[List[int]] = None) -> torch.Tensor:
+    return local if world == 1 else _AllGatherRowsGrad.apply(local, n_total, rank, world, group, None if sizes is None else tuple(int(v) for v in sizes))
 
 
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 256 << 20) -> None:
     """Sum the gradients of ``params`` over ranks in place, in flat buckets (one collective per ~256 MB: xGMI rings are
-    per-link bound, a few large messages beat hundreds of small ones).  A parameter without a gradient on this rank
-    (e.g. outcomes absent from the rank's triple shard) contributes zeros."""
+    per-link bound, a few large messages beat hundreds of small ones).
+
+    A parameter that has a gradient on SOME rank but not on this one (e.g. outcomes absent from the rank's triple shard)
+    contributes zeros.  A parameter without a gradient on ANY rank keeps ``grad=None`` -- the single-process step skips
+    such parameters (no weight decay, no step count), and so must every rank here: a has-gradient bitmap is summed over
+    ranks first (one small collective and one host read per step)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     ps = [p for p in params if p.requires_grad]
-    for p in ps:
+    if not ps:
+        return
+    dev = ps[0].device
+    have = torch.tensor([0 if p.grad is None else 1 for p in ps], dtype=torch.int32).to(dev)
+    all_reduce_sum_(have, group)
+    have = have.cpu().tolist()
+    live = []
+    for p, h in zip(ps, have):
+        if h == 0:
+            continue
         if p.grad is None:
             p.grad = torch.zeros_like(p)
+        live.append(p)
     bucket, size = [], 0
 
     def flush():
@@ -117,7 +138,7 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
             p.grad.copy_(flat[off:off + n].view_as(p.grad))
             off += n
         bucket, size = [], 0
-    for p in ps:
+    for p in live:
         bucket.append(p)
         size += p.numel() * p.element_size()
         if size >= bucket_bytes:

@@ -55,10 +55,13 @@ class SimCLR_NovelDDI(nn.Module):
         batch_mols, batch_kg, batch_cv, batch_tx_dict = batch_data
         p1 = self.predictor if self.shared_predictor else self.predictor_1
         p2 = self.predictor if self.shared_predictor else self.predictor_2
+        # both views see the same KG and the KG encoder has neither dropout nor batch statistics: one pass serves both
+        # (under autograd the two views' gradients meet in one backward pass, the sum the reference forms from two)
+        share = {}
         e1 = self.base_encoder(drug_indices, batch_mask_1, batch_mols, batch_kg, batch_cv, batch_tx_dict,
-                               raw_encoder_output=self.raw_encoder_output)
+                               raw_encoder_output=self.raw_encoder_output, kg_share=share)
         e2 = self.base_encoder(drug_indices, batch_mask_2, batch_mols, batch_kg, batch_cv, batch_tx_dict,
-                               raw_encoder_output=self.raw_encoder_output)
+                               raw_encoder_output=self.raw_encoder_output, kg_share=share)
         run = _run_sequential_train if (_train_path(self) or ag.needs_grad(e1, e2)) else _run_sequential
         aug_1, aug_2 = run(p1, e1), run(p2, e2)
         return aug_1, aug_2, self.contrastive_loss(aug_1, aug_2, batch_too_hard_neg_mask)

@@ -30,7 +30,7 @@ class FinetuneStep:
         self.rank, self.world, self.group = rank, world, group
         self._plan_key = None
         self._plan = None
-        self._shards = {}
+        self._shards = {}               # side ('head' | 'tail') -> (key, sliced batch, the batch itself): ONE entry per side
 
     def plan(self, labels: torch.Tensor, heads: torch.Tensor, tails: torch.Tensor, n_head: int, n_tail: int) -> dict:
         """Label-sorted tiling of the triples, rebuilt only when the index tensors change (they are fixed for a run)."""
@@ -42,13 +42,17 @@ class FinetuneStep:
             self._pinned = (labels, heads, tails)
         return self._plan
 
-    def _shard(self, batch, masks):
+    def _shard(self, batch, masks, side):
+        """This rank's block of drugs.  The slice of the last batch seen on each side is kept (full-batch finetuning
+        passes the same dict every step, train_ddi_batch.py:116); a different batch replaces it, nothing accumulates."""
         n = int(batch["drugs"].shape[0])
         lo, hi = shard_range(n, self.rank, self.world)
         key = (id(batch), lo, hi)
-        if key not in self._shards:
-            self._shards[key] = (slice_batch(batch, lo, hi), batch)          # keeps ``batch`` alive: ids are not recycled
-        return self._shards[key][0], masks[lo:hi], n
+        hit = self._shards.get(side)
+        if hit is None or hit[0] != key or hit[2] is not batch:
+            hit = (key, slice_batch(batch, lo, hi), batch)                   # holds ``batch``: its id cannot be recycled meanwhile
+            self._shards[side] = hit
+        return hit[1], masks[lo:hi], n
 
     def _accumulate_sharded(self, batch_head, batch_tail, masks_head, masks_tail, batch_kg, labels, heads, tails, targets, **kwargs):
         model, rank, world, group = self.model, self.rank, self.world, self.group
@@ -56,8 +60,8 @@ class FinetuneStep:
         try:
             kw = dict(kwargs, kg_share={}) if 'kg_share' not in kwargs else kwargs
             sides = []
-            for batch, masks in ((batch_head, masks_head), (batch_tail, masks_tail)):
-                b, m, n = self._shard(batch, masks)
+            for side, batch, masks in (("head", batch_head, masks_head), ("tail", batch_tail, masks_tail)):
+                b, m, n = self._shard(batch, masks, side)
                 z = model.encoder(b["drugs"], m, b["strs"], batch_kg, b["cv"], b["tx"], **kw)
                 z = all_gather_rows_grad(z, n, rank, world, group)
                 sides.append(ag.l2_normalize(z) if model.normalize else z)
@@ -111,23 +115,32 @@ class PretrainStep:
 
     ``world > 1`` (BASELINE configs[2]: contrastive pretraining, batch 2048, data-parallel with an all-gather of the features):
     rank r runs both views of a contiguous block of the batch through the encoder and the predictors (SyncBatchNorm), the
-    predictor outputs are all-gathered ([B,dim] per view, gradient = all-reduce + own slice), every rank evaluates the same
-    [2B,2B] loss scaled by 1/world (so that the summed gradients are exact), and the parameter gradients are summed in flat
-    buckets.  With dropout off it reproduces the single-process step."""
+    predictor outputs are all-gathered (gradient = all-reduce + own slice), every rank evaluates the same [2R,2R] loss scaled
+    by 1/world (so that the summed gradients are exact), and the parameter gradients are summed in flat buckets.  With
+    ``raw_encoder_output=True`` (every shipped config: encoders -> uni_projector only, models.py:890-894) a view holds one row
+    per AVAILABLE (drug, modality) pair in drug-major order, so the blocks of the ranks concatenate to the single-process row
+    order; their sizes follow from the full mask tensors every rank holds ('str_center_uni' views: exactly one row per drug).
+    With dropout off the sharded step reproduces the single-process step."""
 
     def __init__(self, model, optimizer, rank: int = 0, world: int = 1, group=None):
         self.model, self.optimizer, self.rank, self.world, self.group = model, optimizer, rank, world, group
-        self._shards = {}
+        self._last = None               # (key, sliced batch, batch_data): the slice of the LAST batch only (a DataLoader
+        #                                 hands over a fresh batch every iteration: nothing may accumulate here)
 
     def _local(self, drug_indices, batch_data):
         mols, kg, cv, tx = batch_data
         B = int(drug_indices.shape[0])
         lo, hi = shard_range(B, self.rank, self.world)
         key = (id(mols), id(cv), lo, hi)
-        if key not in self._shards:
+        if self._last is None or self._last[0] != key or self._last[2][0] is not mols:
             whole = {"drugs": drug_indices, "strs": mols, "cv": cv, "tx": tx, "masks": torch.zeros(B, 1, dtype=torch.bool, device=cv.device)}
-            self._shards[key] = (slice_batch(whole, lo, hi), batch_data)
-        return self._shards[key][0], lo, hi, B
+            self._last = (key, slice_batch(whole, lo, hi), batch_data)
+        return self._last[1], lo, hi, B
+
+    def _row_blocks(self, masks: torch.Tensor, B: int):
+        """Rows each rank contributes to a raw-encoder-output view: available (drug, modality) pairs of its drug block."""
+        per_drug = (~masks).sum(dim=1).cpu()
+        return [int(per_drug[slice(*shard_range(B, r, self.world))].sum()) for r in range(self.world)]
 
     def step(self, drug_indices, mask1, mask2, too_hard_neg, batch_data) -> torch.Tensor:
         model = self.model
@@ -138,12 +151,11 @@ class PretrainStep:
             loss.backward()
             self.optimizer.step()
             return loss.detach()
-        if model.raw_encoder_output:
-            raise NotImplementedError("data-parallel pretraining with raw_encoder_output=True (a variable number of rows per drug)")
         from .models import _run_sequential_train
         group = self.group
         b, lo, hi, B = self._local(drug_indices, batch_data)
         kg = batch_data[1]
+        raw = bool(model.raw_encoder_output)
         ag.set_batchnorm_sync(lambda t: all_reduce_sum_(t, group))
         try:
             p1 = model.predictor if model.shared_predictor else model.predictor_1
@@ -151,8 +163,9 @@ class PretrainStep:
             share = {}
             views = []
             for masks, pred in ((mask1, p1), (mask2, p2)):
-                e = model.base_encoder(b["drugs"], masks[lo:hi], b["strs"], kg, b["cv"], b["tx"], raw_encoder_output=False, kg_share=share)
-                views.append(all_gather_rows_grad(_run_sequential_train(pred, e), B, self.rank, self.world, group))
+                sizes = self._row_blocks(masks, B) if raw else None
+                e = model.base_encoder(b["drugs"], masks[lo:hi], b["strs"], kg, b["cv"], b["tx"], raw_encoder_output=raw, kg_share=share)
+                views.append(all_gather_rows_grad(_run_sequential_train(pred, e), sum(sizes) if raw else B, self.rank, self.world, group, sizes))
             _, _, loss = model.contrastive_loss(views[0], views[1], too_hard_neg)
             (loss * (1.0 / self.world)).backward()
             allreduce_gradients(model.parameters(), group)

@@ -268,7 +268,7 @@ ENCODE_CASES = [
 ]
 
 
-def build_reference_model(M, C, kg, case, L, seed):
+def build_reference_model(M, C, kg, case, L, seed, **enc_kwargs):
     name, fusion, nb, pos, H, dh, ffn, nl, nf, agg, normalize, adapt = case
     enc = M.NovelDDIEncoder(
         all_kg_data=kg, feat_dim=128, str_encoder_name="gin",
@@ -284,7 +284,8 @@ def build_reference_model(M, C, kg, case, L, seed):
                                         transformer_ffn_dim=ffn, transformer_dropout=0.3, transformer_actn="gelu",
                                         transformer_norm_first=nf, transformer_batch_first=False, transformer_agg=agg),
         proj_hparams=dict(proj_hidden_dims=[512, 512], proj_dropout=0.2, proj_norm="ln", proj_actn="relu", proj_order="nd"),
-        fusion=fusion, use_modality_pretrain=False, normalize=normalize, pos_emb_type=pos, adapt_before_fusion=adapt)
+        fusion=fusion, use_modality_pretrain=False, normalize=normalize, pos_emb_type=pos, adapt_before_fusion=adapt,
+        **enc_kwargs)
     # the shipped runs use the chemCPA tx encoder; its constructor path inside NovelDDIEncoder reads two
     # external data files (models.py:271-273), so attach the reference's own TxAdaptingComPert directly.
     from sklearn.preprocessing import OneHotEncoder
@@ -349,6 +350,74 @@ def gen_infonce(M, S):
         pred = model.predictor_1(x)
     save("infonce", aug1=a1, aug2=a2, hard=hard, logits=lg, labels=lb, loss=loss, logits_nomask=lg0, loss_nomask=loss0,
          T=np.array(0.1), pred_x=x, pred_y=pred, pred_keys=np.array(sorted(model.predictor_1.state_dict().keys())))
+
+
+from oracle.gen_cases import CL_CASE             # noqa: E402
+
+
+def gen_pretrain_views():
+    """Host logic of pretrain.py:59-71: the reference's own get_pretrain_masks / pretrain_modality_subset_sampler
+    (madrigal/utils.py:51-145, 360-390) on a seeded availability table, for every mode that constructs."""
+    import madrigal.utils as U
+    avail = D.make_masks(60, 7, p_kg=0.7, p_cv=0.5, p_tx=0.2).numpy().astype(np.int64)
+    avail[:, 1] = np.where(avail[:, 1:].all(axis=1), 0, avail[:, 1])          # every drug owns a second modality
+    drugs = list(range(100, 160))
+    out = {"avail": avail, "drugs": np.array(drugs)}
+    for mode in ("str_center_uni", "double_random", "str_kg", "str_center", "str_center_comb"):
+        for unb in (False, True):
+            tag = f"{mode}_{int(unb)}"
+            try:
+                bank = U.get_pretrain_masks(drugs, avail.copy(), mode, unb, 0.2)
+            except Exception as e:                                             # modes whose bank the reference cannot file
+                out[tag + "_error"] = np.array(type(e).__name__)
+                continue
+            np.random.seed(123)
+            torch.manual_seed(123)
+            order = [drugs[i] for i in np.random.default_rng(3).permutation(len(drugs))[:32]]
+            a1, a2 = U.pretrain_modality_subset_sampler([bank[d] for d in order], pretrain_mode=mode, unbalanced=unb)
+            b1, b2 = U.pretrain_modality_subset_sampler([bank[d] for d in order], pretrain_mode=mode, unbalanced=unb)
+            out[tag + "_order"] = np.array(order)
+            out[tag + "_aug1"], out[tag + "_aug2"], out[tag + "_aug1b"], out[tag + "_aug2b"] = a1, a2, b1, b2
+            if mode == "str_center_uni" and not unb:
+                out["uni_probs_d100"] = np.asarray(bank[100][1])
+    save("pretrain_views", **out)
+
+
+def gen_simclr_raw(M, S, C):
+    """BASELINE configs[2] as the reference ships it: SimCLR_NovelDDI.forward (simclr.py:110-140) with
+    raw_encoder_output=True (encoders -> uni_projector only, models.py:890-894) on views drawn by the reference's own
+    'str_center_uni' sampler; eval mode, both predictor layouts, both tx latents (use_tx_basal)."""
+    import madrigal.utils as U
+    n, seed = 40, 71
+    avail = D.make_masks(n, seed, p_kg=0.6, p_cv=0.5, p_tx=0.25)
+    avail[:, 1] = torch.where(avail[:, 1:].all(dim=1), torch.zeros(n, dtype=torch.bool), avail[:, 1])
+    batch, bkg = D.make_batch(n, seed, kg_nodes=300, kg_edges=2500, masks=avail)
+    drugs = batch["drugs"]
+    bank = U.get_pretrain_masks(drugs.tolist(), avail.numpy().astype(np.int64), "str_center_uni", False, 0.2)
+    np.random.seed(seed)
+    m1, m2 = U.pretrain_modality_subset_sampler([bank[d] for d in drugs.tolist()], pretrain_mode="str_center_uni", unbalanced=False)
+    hard = torch.from_numpy(np.random.default_rng(seed).random((n, n)) < 0.05)
+    hard = (hard | hard.T) & ~torch.eye(n, dtype=torch.bool)
+    filler_shape = (max(int(drugs.max()) + 1, int(bkg["drug_index_map"].max()) + 1), 128)
+    torch.manual_seed(seed)
+    filler = torch.randn(filler_shape)
+    out = dict(avail=avail, mask1=m1, mask2=m2, hard=hard, kg_filler=filler, meta=np.array([n, seed]), T=np.array(0.1))
+    for shared in (False, True):
+        for basal in (False, True):
+            enc = build_reference_model(M, C, bkg["data"], CL_CASE, 4, seed, use_tx_basal=basal).encoder
+            model = S.SimCLR_NovelDDI(enc, dim=128, mlp_dim=512, T=0.1, raw_encoder_output=True, shared_predictor=shared).eval()
+            fill_module(model, seed, skip=[])
+            tag = f"s{int(shared)}b{int(basal)}"
+            with torch.no_grad():
+                torch.manual_seed(seed)
+                a1, a2, (lg, lb, loss) = model(drugs, m1, m2, hard.clone(), (batch["strs"], bkg, batch["cv"], batch["tx"]), None, None)
+                torch.manual_seed(seed)
+                raw1 = model.base_encoder(drugs, m1, batch["strs"], bkg, batch["cv"], batch["tx"], raw_encoder_output=True)
+                torch.manual_seed(seed)
+                raw2 = model.base_encoder(drugs, m2, batch["strs"], bkg, batch["cv"], batch["tx"], raw_encoder_output=True)
+            out.update({f"{tag}_aug1": a1, f"{tag}_aug2": a2, f"{tag}_logits": lg, f"{tag}_loss": loss, f"{tag}_raw1": raw1, f"{tag}_raw2": raw2})
+            out[f"{tag}_keys"] = np.array(sorted(model.state_dict().keys()))
+    save("simclr_raw", **out)
 
 
 def gen_ranks(ref_root):
@@ -441,20 +510,20 @@ def gen_param_groups(M, C):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="", help="comma-separated fixture groups (default: all)")
     args = ap.parse_args()
     torch.set_num_threads(4)
     M, S, C = import_reference(args.ref)
-    gen_head(M)
-    gen_mlps(M)
-    gen_posenc(M)
-    gen_fusion(M)
-    gen_chemcpa(C)
-    gen_encode(M, C)
-    gen_infonce(M, S)
-    gen_ranks(args.ref)
-    gen_bce()
-    gen_eval_masks_and_schedule()
-    gen_param_groups(M, C)
+    groups = {
+        "head": lambda: gen_head(M), "mlps": lambda: gen_mlps(M), "posenc": lambda: gen_posenc(M), "fusion": lambda: gen_fusion(M),
+        "chemcpa": lambda: gen_chemcpa(C), "encode": lambda: gen_encode(M, C), "infonce": lambda: gen_infonce(M, S),
+        "pretrain_views": gen_pretrain_views, "simclr_raw": lambda: gen_simclr_raw(M, S, C), "ranks": lambda: gen_ranks(args.ref),
+        "bce": gen_bce, "eval_masks": gen_eval_masks_and_schedule, "param_groups": lambda: gen_param_groups(M, C),
+    }
+    only = [g for g in args.only.split(",") if g]
+    for name, fn in groups.items():
+        if not only or name in only:
+            fn()
 
 
 if __name__ == "__main__":

@@ -78,9 +78,39 @@ def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
     return (x - mu) / torch.sqrt(var + eps) * w + b
 
 
+_BN = {"batch": False, "record": None}
+
+
+class batch_statistics:
+    """``with batch_statistics(record):`` BatchNorm layers normalise with the statistics of the rows they are given
+    (nn.BatchNorm1d in training mode: biased variance) instead of the running ones -- the training-mode forward that
+    pretrain.py / train_ddi_batch.py differentiate.  ``record`` (optional dict) receives, per layer, the list of
+    (batch mean, UNBIASED batch variance) pairs in call order, keyed by id() of the layer's running_mean tensor, from
+    which a test derives the running statistics torch would hold after the step."""
+
+    def __init__(self, record: Optional[dict] = None):
+        self.record = record
+
+    def __enter__(self):
+        self.prev = dict(_BN)
+        _BN.update(batch=True, record=self.record)
+
+    def __exit__(self, *exc):
+        _BN.update(self.prev)
+
+
 def batch_norm_eval(x: Tensor, p: Params, prefix: str, eps: float = 1e-5) -> Tensor:
-    """BatchNorm1d in eval mode (running statistics); affine is optional."""
-    y = (x - p[prefix + "running_mean"]) / torch.sqrt(p[prefix + "running_var"] + eps)
+    """BatchNorm1d in eval mode (running statistics); affine is optional.  Inside ``batch_statistics()``: batch
+    statistics (torch/nn/modules/batchnorm.py semantics of the training forward)."""
+    if _BN["batch"]:
+        mean = x.mean(dim=0)
+        var = ((x - mean) ** 2).mean(dim=0)
+        if _BN["record"] is not None and prefix + "running_mean" in p:
+            n = x.shape[0]
+            _BN["record"].setdefault(id(p[prefix + "running_mean"]), []).append((mean.detach(), (var * (n / max(n - 1, 1))).detach()))
+        y = (x - mean) / torch.sqrt(var + eps)
+    else:
+        y = (x - p[prefix + "running_mean"]) / torch.sqrt(p[prefix + "running_var"] + eps)
     if prefix + "weight" in p:
         y = y * p[prefix + "weight"] + p[prefix + "bias"]
     return y
@@ -550,6 +580,13 @@ def info_nce(aug1: Tensor, aug2: Tensor, too_hard_neg_mask: Optional[Tensor], te
     lse = torch.logsumexp(logits, dim=1, keepdim=True)
     loss = -(lab * (logits - lse)).sum(1).mean()
     return logits, lab, loss
+
+
+def simclr_predictor(p: Params, x: Tensor) -> Tensor:
+    """SimCLR_NovelDDI._build_mlp(2, ...) (madrigal/models/simclr.py:46-62): Linear(no bias) -> BatchNorm -> ReLU ->
+    Linear(no bias) -> BatchNorm(affine=False).  Keys ``0.weight 1.* 3.weight 4.running_*``."""
+    h = torch.clamp_min(batch_norm_eval(linear(x, p["0.weight"]), p, "1."), 0.0)
+    return batch_norm_eval(linear(h, p["3.weight"]), p, "4.")
 
 
 # --------------------------------------------------------------------------- rank normalisation

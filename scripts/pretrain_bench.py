@@ -1,9 +1,15 @@
-"""Contrastive-pretraining step timing (BASELINE configs[2]: InfoNCE modality alignment, batch 2048): SimCLR_NovelDDI in
-training mode over the TWOSIDES encoder, two random modality-subset views per drug, AdamW."""
+"""Contrastive-pretraining step timing (BASELINE configs[2]: InfoNCE modality alignment, batch 2048).
+
+Default = the workload the reference ships (configs/cl_pretrain/*.yaml): SimCLR_NovelDDI with raw_encoder_output=True
+(encoders -> uni_projector -> predictors, madrigal/models/models.py:890-894), a fresh 'str_center_uni' view draw per iteration
+(madrigal/utils.py:97-117, 360-390: view 1 = structure alone, view 2 = one other modality of the drug), separate predictors,
+T = 0.1, mlp_dim 512, AdamW.  ``--fusion-views`` times the other path instead (raw_encoder_output=False: both views through
+the fusion transformer on multi-modal masks), which no shipped config uses."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
-from madrigal_amd import configs, data as D, models as M
+from madrigal_amd import configs, data as D, masks as MK, models as M
 from madrigal_amd.optim import AdamW
 from madrigal_amd.simclr import SimCLR_NovelDDI
 from madrigal_amd.train import PretrainStep
@@ -15,26 +21,41 @@ ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--kg-nodes", type=int, default=130_000)
 ap.add_argument("--kg-edges", type=int, default=8_000_000)
 ap.add_argument("--precision", default="bf16x3")
+ap.add_argument("--fusion-views", action="store_true")
 a = ap.parse_args()
 M.set_precision(a.precision)
-batch, bkg = D.make_batch(a.batch, 0, kg_nodes=a.kg_nodes, kg_edges=a.kg_edges)
+avail = D.make_masks(a.batch, 0)
+avail[:, 1] = torch.where(avail[:, 1:].all(dim=1), torch.zeros(a.batch, dtype=torch.bool), avail[:, 1])   # every drug owns a second modality
+batch, bkg = D.make_batch(a.batch, 0, kg_nodes=a.kg_nodes, kg_edges=a.kg_edges, masks=avail)
 torch.manual_seed(0)
+np.random.seed(0)
 enc = configs.build_model("twosides321", bkg["data"], 8).encoder
-model = SimCLR_NovelDDI(enc, dim=128, mlp_dim=1024, T=0.5, raw_encoder_output=False).cuda().train()
+raw = not a.fusion_views
+model = SimCLR_NovelDDI(enc, dim=128, mlp_dim=512 if raw else 1024, T=0.1 if raw else 0.5, raw_encoder_output=raw).cuda().train()
 b = D.batch_to(batch, "cuda")
 kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
-m1 = b["masks"].clone()
-m2 = b["masks"].clone()
-m2[:, 1:] = True                                      # second view: structure only ("str_*" pretrain modes)
+bank = MK.get_pretrain_masks(list(range(a.batch)), avail.numpy().astype(np.int64), "str_center_uni", False, 0.2) if raw else None
 step = PretrainStep(model, AdamW(model.parameters(), lr=1e-5, weight_decay=1e-2))
 data = (b["strs"], kgc, b["cv"], b["tx"])
-losses = []
+losses, t_views = [], 0.0
 for i in range(a.warmup + a.steps):
     if i == a.warmup:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        t_views = 0.0
+    tv = time.perf_counter()
+    if raw:                                               # host-side view draw of pretrain.py:71 (inside the timed step)
+        m1, m2 = MK.pretrain_modality_subset_sampler([bank[d] for d in range(a.batch)], "str_center_uni", False)
+        m1, m2 = m1.cuda(), m2.cuda()
+    else:
+        m1 = b["masks"].clone()
+        m2 = b["masks"].clone()
+        m2[:, 1:] = True
+    t_views += time.perf_counter() - tv
     losses.append(step.step(b["drugs"], m1, m2, None, data))
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
-print(json.dumps({"ms_per_step": dt * 1e3, "steps_per_sec": 1 / dt, "drugs_per_sec": a.batch / dt, "batch": a.batch, "precision": a.precision,
+print(json.dumps({"workload": "cl_pretrain as shipped (raw_encoder_output, str_center_uni)" if raw else "fusion-transformer views",
+                  "ms_per_step": dt * 1e3, "steps_per_sec": 1 / dt, "drugs_per_sec": a.batch / dt, "batch": a.batch, "precision": a.precision,
+                  "host_view_sampling_ms": t_views / a.steps * 1e3,
                   "loss": [float(x) for x in losses], "max_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}))

@@ -96,7 +96,7 @@ def test_chemcpa_golden(M, golden, prec):
     assert out2[0] is None
 
 
-def build_model(M, case, kg, L):
+def build_model(M, case, kg, L, **enc_kwargs):
     name, fusion, nb, pos, H, dh, ffn, nl, nf, agg, normalize, adapt = case
     enc = M.NovelDDIEncoder(
         all_kg_data=kg, feat_dim=128, str_encoder_name="gin",
@@ -114,7 +114,7 @@ def build_model(M, case, kg, L):
                                         transformer_ffn_dim=ffn, transformer_dropout=0.3, transformer_actn="gelu",
                                         transformer_norm_first=nf, transformer_batch_first=False, transformer_agg=agg),
         proj_hparams=dict(proj_hidden_dims=[512, 512], proj_dropout=0.2, proj_norm="ln", proj_actn="relu", proj_order="nd"),
-        fusion=fusion, use_modality_pretrain=False, normalize=normalize, pos_emb_type=pos, adapt_before_fusion=adapt)
+        fusion=fusion, use_modality_pretrain=False, normalize=normalize, pos_emb_type=pos, adapt_before_fusion=adapt, **enc_kwargs)
     return M.NovelDDIMultilabel(enc, 128, L, normalize=False)
 
 

@@ -219,3 +219,69 @@ def test_parameter_groups_match_reference_create_optimizer(golden):
                 assert got[k] == (lr, wd), (k, got.get(k), (lr, wd))
         with_tokens = {name_of[id(p)] for grp in parameter_groups(model, hp, include_learned_tokens=True) for p in grp["params"]}
         assert with_tokens == set(name_of.values())
+
+
+# ---------------------------------------------------------------------------------------------- contrastive pretraining as shipped
+def test_pretrain_view_sampler_matches_reference(golden):
+    """madrigal_amd.masks.get_pretrain_masks / pretrain_modality_subset_sampler against the reference's own functions
+    (madrigal/utils.py:51-145, 360-390) under the same numpy / torch seeds; the two modes whose bank the reference itself
+    cannot construct are refused."""
+    import torch
+    from madrigal_amd import masks as MK
+    g = golden("pretrain_views")
+    avail, drugs = g["avail"], g["drugs"].tolist()
+    for mode in ("str_center_uni", "double_random", "str_kg"):
+        for unb in (False, True):
+            tag = f"{mode}_{int(unb)}"
+            bank = MK.get_pretrain_masks(drugs, avail.copy(), mode, unb, 0.2)
+            np.random.seed(123)
+            torch.manual_seed(123)
+            order = g[tag + "_order"].tolist()
+            a1, a2 = MK.pretrain_modality_subset_sampler([bank[d] for d in order], mode, unb)
+            b1, b2 = MK.pretrain_modality_subset_sampler([bank[d] for d in order], mode, unb)
+            for got, key in ((a1, "_aug1"), (a2, "_aug2"), (b1, "_aug1b"), (b2, "_aug2b")):
+                assert got.dtype == torch.bool and np.array_equal(got.numpy(), g[tag + key]), (tag, key)
+    bank = MK.get_pretrain_masks(drugs, avail.copy(), "str_center_uni", False, 0.2)
+    assert np.allclose(bank[100][1], g["uni_probs_d100"], rtol=1e-12)
+    # 'str_center_uni': the structure alone / exactly one other modality the drug owns
+    a1, a2 = t(g["str_center_uni_0_aug1"]), t(g["str_center_uni_0_aug2"])
+    assert bool((~a1).sum(1).eq(1).all()) and bool((~a1[:, 0]).all()) and bool((~a2).sum(1).eq(1).all()) and bool(a2[:, 0].all())
+    for mode in ("str_center", "str_center_comb"):
+        for unb in (0, 1):
+            assert f"{mode}_{unb}_error" in g.files                      # the reference raises there
+            with pytest.raises(NotImplementedError):
+                MK.get_pretrain_masks(drugs, avail.copy(), mode, bool(unb), 0.2)
+
+
+def simclr_shapes(kg, shared, mlp_dim=512):
+    from helpers import model_shapes_for_case
+    from oracle.gen_cases import CL_CASE
+    s = {"base_encoder." + k[len("encoder."):]: v for k, v in model_shapes_for_case(CL_CASE, kg, 4).items() if k.startswith("encoder.")}
+    for pred in (("predictor",) if shared else ("predictor_1", "predictor_2")):
+        s.update({f"{pred}.0.weight": (mlp_dim, 128), f"{pred}.1.weight": (mlp_dim,), f"{pred}.1.bias": (mlp_dim,),
+                  f"{pred}.1.running_mean": (mlp_dim,), f"{pred}.1.running_var": (mlp_dim,), f"{pred}.1.num_batches_tracked": (),
+                  f"{pred}.3.weight": (128, mlp_dim), f"{pred}.4.running_mean": (128,), f"{pred}.4.running_var": (128,),
+                  f"{pred}.4.num_batches_tracked": ()})
+    return s
+
+
+@pytest.mark.parametrize("shared,basal", [(False, False), (False, True), (True, False), (True, True)])
+def test_simclr_raw_encoder_output_as_shipped(golden, shared, basal):
+    """BASELINE configs[2] as the reference ships it (configs/cl_pretrain/*.yaml: raw_encoder_output, str_center_uni):
+    the restated SimCLR forward against the reference's own SimCLR_NovelDDI.forward outputs."""
+    from oracle.pipeline import oracle_simclr
+    g = golden("simclr_raw")
+    n, seed = (int(v) for v in g["meta"])
+    batch, bkg = D.make_batch(n, seed, kg_nodes=300, kg_edges=2500, masks=t(g["avail"]))
+    tag = f"s{int(shared)}b{int(basal)}"
+    shapes = simclr_shapes(bkg["data"], shared)
+    assert sorted(shapes) == list(g[tag + "_keys"])
+    p = det_state_dict(seed, shapes)
+    got = oracle_simclr(p, batch, bkg, t(g["mask1"]), t(g["mask2"]), t(g["hard"]), float(g["T"]), t(g["kg_filler"]),
+                        shared_predictor=shared, use_tx_basal=basal)
+    assert got["raw1"].shape == (n, 128) and got["raw2"].shape == (n, 128)          # one row per drug and view
+    for k in ("raw1", "raw2", "aug1", "aug2"):
+        assert rel_err(got[k], g[f"{tag}_{k}"]) < 5e-5, k
+    keep = np.abs(g[tag + "_logits"]) < 1e8
+    assert rel_err(got["logits"].numpy()[keep], g[tag + "_logits"][keep]) < 5e-5
+    assert abs(float(got["loss"]) - float(g[tag + "_loss"])) < 2e-5 * abs(float(g[tag + "_loss"]))

@@ -166,3 +166,74 @@ def test_two_rank_pretraining_step_equals_single_process_step():
         assert lerr < 1e-5, (r, lerr)
         assert worst[0] < 2e-3, (r, worst)
         assert n_grads > 100
+
+
+def _pretrain_raw_worker(rank, world, port, ret):
+    """BASELINE configs[2] as shipped (raw_encoder_output=True, 'str_center_uni' views), data-parallel: four iterations with a
+    FRESH batch and a fresh view draw each (what pretrain.py's DataLoader hands over), against the single-process steps."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        import numpy as np
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from madrigal_amd import data as D, masks as MK, models as M
+        from madrigal_amd.optim import AdamW
+        from madrigal_amd.train import PretrainStep
+        from test_pretrain_gpu import _build, _no_dropout, _views
+        M.set_precision("f32")
+        n, seed = 67, 12                                  # odd batch: uneven drug blocks
+        avail, _, _ = _views(n, seed)
+        bank = MK.get_pretrain_masks(list(range(n)), avail.numpy().astype(np.int64), "str_center_uni", False, 0.2)
+        _, bkg0 = D.make_batch(n, seed, kg_nodes=600, kg_edges=6000, masks=avail)
+
+        def run(rank_, world_):
+            torch.manual_seed(seed)
+            np.random.seed(seed)
+            model = _no_dropout(_build(M, bkg0["data"], False, True, mlp_dim=256, T=0.5)).cuda().train()
+            step = PretrainStep(model, AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2), rank=rank_, world=world_)
+            kg_dev = bkg0["data"].to("cuda")
+            losses, mem = [], []
+            for it in range(4):
+                batch, bkg = D.make_batch(n, seed + it, kg=bkg0["data"], masks=avail)          # a different batch every iteration
+                b = D.batch_to(batch, "cuda")
+                kgc = {"data": kg_dev, "drug_index_map": bkg["drug_index_map"].cuda()}
+                m1, m2 = MK.pretrain_modality_subset_sampler([bank[d] for d in range(n)], "str_center_uni", False)
+                hard = torch.rand(n, n, generator=torch.Generator().manual_seed(it)) < 0.03
+                hard = ((hard | hard.T) & ~torch.eye(n, dtype=torch.bool)).cuda()
+                losses.append(float(step.step(b["drugs"], m1.cuda(), m2.cuda(), hard, (b["strs"], kgc, b["cv"], b["tx"]))))
+                del batch, b, kgc, m1, m2, hard
+                torch.cuda.synchronize()
+                mem.append(torch.cuda.memory_allocated())
+            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+            params = {k: p.detach().clone() for k, p in model.named_parameters()}
+            return losses, mem, grads, params
+        l2, mem2, g2, p2 = run(rank, world)
+        l1, _, g1, p1 = run(0, 1)
+        gmax = max(float(v.abs().max()) for v in g1.values())
+        worst = max((float((g2[k] - v).abs().max()) / max(float(v.abs().max()), 1e-2 * gmax), k) for k, v in g1.items())
+        # the same set of parameters received a gradient (the fusion transformer etc. stay grad=None on every rank, so
+        # weight decay leaves them untouched exactly as in the single-process step)
+        untouched = max(float((p2[k] - p1[k]).abs().max()) for k in p1 if k not in g1)
+        ret[rank] = (max(abs(a - b) / abs(b) for a, b in zip(l2, l1)), worst, set(g2) == set(g1), untouched, mem2)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_shipped_pretraining_steps_equal_single_process_and_hold_no_batches():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_pretrain_raw_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0
+    for r in range(2):
+        lerr, worst, same_set, untouched, mem = ret[r]
+        assert lerr < 2e-4, (r, lerr)                 # four optimizer steps deep
+        assert worst[0] < 5e-3, (r, worst)
+        assert same_set and untouched == 0.0, (r, same_set, untouched)
+        # nothing of an earlier iteration's batch stays allocated: memory after iteration 4 == after iteration 2
+        assert abs(mem[3] - mem[1]) < (1 << 20), (r, mem)
