@@ -38,7 +38,10 @@ enum mdg_precision {
   MDG_PREC_F32 = 0,    /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate        */
   MDG_PREC_BF16X3 = 1, /* each fp32 operand split hi+lo bf16; hi*hi + hi*lo + lo*hi on the
                           bf16 MFMA, fp32 accumulate: ~2^-17 relative per product             */
-  MDG_PREC_BF16 = 2    /* operands rounded to bf16 once, fp32 accumulate (cfg "bf16")          */
+  MDG_PREC_BF16 = 2,   /* operands rounded to bf16 once, fp32 accumulate (cfg "bf16")          */
+  MDG_PREC_F16 = 3     /* operands rounded to IEEE half once (v_mfma_f32_32x32x16_f16), fp32
+                          accumulate: BASELINE configs[4] "fp16 bilinear head".  Accepted by
+                          mdg_bilinear_allpairs only; inputs must stay inside the half range.   */
 };
 
 /* What the all-pairs head does with each score tile. */

@@ -48,10 +48,25 @@ struct BilinearArgs {
   int pipeline;         // 0 = counted waits (default), 1 = conservative
 };
 
+// 16-bit operand images travel as bf16x8 containers; MDG_PREC_F16 stores IEEE half bits in them and casts at the MFMA.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
 template <int MODE> struct AFrag;
 template <> struct AFrag<MDG_PREC_F32> { float a[64]; };
 template <> struct AFrag<MDG_PREC_BF16X3> { bf16x8 hi[8]; bf16x8 lo[8]; };
 template <> struct AFrag<MDG_PREC_BF16> { bf16x8 hi[8]; };
+template <> struct AFrag<MDG_PREC_F16> { bf16x8 hi[8]; };
+
+// one rounded product per k-step (operands rounded to bf16 / fp16 once)
+template <int MODE> constexpr bool kSingle16 = (MODE == MDG_PREC_BF16 || MODE == MDG_PREC_F16);
+
+template <int MODE>
+__device__ __forceinline__ f32x16 mma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (MODE == MDG_PREC_F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 template <int ROWB>
 __device__ __forceinline__ int tile_off(int row, int chunk) {
@@ -146,14 +161,23 @@ __device__ __forceinline__ void stage_dma(const TileSrc& s, int64_t row0, char* 
 }
 
 // ---- A fragment from 8 consecutive fp32 values --------------------------------------------
+template <int MODE>
 __device__ __forceinline__ void split8(const float4& x0, const float4& x1, bf16x8& hi, bf16x8& lo) {
   const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+  if constexpr (MODE == MDG_PREC_F16) {
+    f16x8 t;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    __bf16 a, b;
-    mdg_split_bf16(v[j], a, b);
-    hi[j] = a;
-    lo[j] = b;
+    for (int j = 0; j < 8; ++j) t[j] = static_cast<_Float16>(v[j]);       // round to nearest even
+    hi = __builtin_bit_cast(bf16x8, t);
+    lo = hi;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __bf16 a, b;
+      mdg_split_bf16(v[j], a, b);
+      hi[j] = a;
+      lo[j] = b;
+    }
   }
 }
 
@@ -172,7 +196,7 @@ __device__ __forceinline__ void afrag_from_global(AFrag<MODE>& A, const float* r
       const float4 v0 = *reinterpret_cast<const float4*>(row + 16 * s + 8 * h);
       const float4 v1 = *reinterpret_cast<const float4*>(row + 16 * s + 8 * h + 4);
       bf16x8 hi, lo;
-      split8(v0, v1, hi, lo);
+      split8<MODE>(v0, v1, hi, lo);
       A.hi[s] = hi;
       if constexpr (MODE == MDG_PREC_BF16X3) A.lo[s] = lo;
     }
@@ -195,7 +219,7 @@ __device__ __forceinline__ void afrag_from_slab(AFrag<MODE>& A, const char* slab
       const float4 v0 = *reinterpret_cast<const float4*>(slab + tile_off<256>(r, 4 * s + 2 * h));
       const float4 v1 = *reinterpret_cast<const float4*>(slab + tile_off<256>(r, 4 * s + 2 * h + 1));
       bf16x8 hi, lo;
-      split8(v0, v1, hi, lo);
+      split8<MODE>(v0, v1, hi, lo);
       A.hi[4 * st + s] = hi;
       if constexpr (MODE == MDG_PREC_BF16X3) A.lo[4 * st + s] = lo;
     }
@@ -223,11 +247,62 @@ __device__ __forceinline__ void compute_tile(const AFrag<MODE>& A, const char* l
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(lds + tile_off<256>(j, 2 * s + h));
         if constexpr (MODE == MDG_PREC_BF16X3) {
           const bf16x8 bl = *reinterpret_cast<const bf16x8*>(lds + LO_OFF + tile_off<256>(j, 2 * s + h));
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.lo[s], bh, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi[s], bl, acc[t], 0, 0, 0);
+          acc[t] = mma16<MODE>(A.lo[s], bh, acc[t]);
+          acc[t] = mma16<MODE>(A.hi[s], bl, acc[t]);
         }
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi[s], bh, acc[t], 0, 0, 0);
+        acc[t] = mma16<MODE>(A.hi[s], bh, acc[t]);
       }
+    }
+  }
+}
+
+// The same products with the 32 score stores of the PREVIOUS tile (held in registers by the caller) spread evenly between
+// the MFMAs instead of issued as one burst: `store_k(k)`, k = 0..31, issues store k.  B fragments are fetched one step
+// ahead by hand because the scheduling barriers that pin the store positions also stop the compiler from hoisting them.
+template <int MODE, typename StoreFn>
+__device__ __forceinline__ void compute_tile_spread(const AFrag<MODE>& A, const char* lds, int r, int h, f32x16 (&acc)[2],
+                                                    StoreFn&& store_k) {
+  if constexpr (MODE == MDG_PREC_F32) {
+    float4 b = *reinterpret_cast<const float4*>(lds + tile_off<512>(r, h));
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int t = i >> 4, q = i & 15;
+      float4 nb = b;
+      if (i + 1 < 32) nb = *reinterpret_cast<const float4*>(lds + tile_off<512>(32 * ((i + 1) >> 4) + r, 2 * ((i + 1) & 15) + h));
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.a[4 * q + 0], b.x, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.a[4 * q + 1], b.y, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.a[4 * q + 2], b.z, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.a[4 * q + 3], b.w, acc[t], 0, 0, 0);
+      store_k(i);
+      __builtin_amdgcn_sched_barrier(0);
+      b = nb;
+    }
+  } else {
+    bf16x8 bh = *reinterpret_cast<const bf16x8*>(lds + tile_off<256>(r, h)), bl = bh;
+    if constexpr (MODE == MDG_PREC_BF16X3) bl = *reinterpret_cast<const bf16x8*>(lds + LO_OFF + tile_off<256>(r, h));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = i >> 3, s = i & 7;
+      bf16x8 nbh = bh, nbl = bl;
+      if (i + 1 < 16) {
+        const int j = 32 * ((i + 1) >> 3) + r, c = 2 * ((i + 1) & 7) + h;
+        nbh = *reinterpret_cast<const bf16x8*>(lds + tile_off<256>(j, c));
+        if constexpr (MODE == MDG_PREC_BF16X3) nbl = *reinterpret_cast<const bf16x8*>(lds + LO_OFF + tile_off<256>(j, c));
+      }
+      if constexpr (MODE == MDG_PREC_BF16X3) {
+        acc[t] = mma16<MODE>(A.lo[s], bh, acc[t]);
+        store_k(2 * i);
+        acc[t] = mma16<MODE>(A.hi[s], bl, acc[t]);
+        store_k(2 * i + 1);
+        acc[t] = mma16<MODE>(A.hi[s], bh, acc[t]);
+      } else {
+        acc[t] = mma16<MODE>(A.hi[s], bh, acc[t]);
+        store_k(2 * i);
+        store_k(2 * i + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bh = nbh;
+      bl = nbl;
     }
   }
 }
@@ -238,8 +313,11 @@ __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >
 // RB = 32-row blocks of z_head per wave.  RB = 2 (row statistics in bf16 only): every B fragment read from LDS feeds two
 // MFMAs instead of one — with a single bf16 product per k-step the sweep is otherwise bound by the LDS operand reads
 // (one ds_read_b128 per MFMA), not by the matrix cores.
-template <int MODE, int EPI, int NW, int RB = 1>
+// VAR = 1: every wave keeps the finished tile in registers for one stage and issues its 32 stores one or two at a time
+// between the MFMAs of the next tile (compute_tile_spread), instead of the burst-per-stage of VAR = 0.
+template <int MODE, int EPI, int NW, int RB = 1, int VAR = 0>
 __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const BilinearArgs p) {
+  static_assert(NW == 4 || NW == 8, "the counted waits below are written for 4 or 8 waves per workgroup");
   constexpr int BM = 32 * NW * RB;   // head rows per workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const buf0 = smem;
@@ -302,17 +380,21 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
     for (int v = 0; v < 16; ++v) { rsum[v] = 0.f; rmax[v] = -INFINITY; rsum2[v] = 0.f; rmax2[v] = -INFINITY; }
   }
 
-  // Pipeline: one raw barrier and ONE full vmcnt(0) wait per stage -- no counted waits: correctness never relies
-  // on the relative completion order of LDS-DMA loads and score stores (out-of-range stores retire at once, and
-  // loads / stores are only ordered among themselves).
-  //   barrier           every wave's DMA pieces of tile s have landed (each wave drained vmcnt before arriving)
-  //                     and every wave has finished reading tile s-1, whose buffer the next DMA overwrites
-  //   issue DMA(s+1)    asynchronous, lands under the MFMA phase
-  //   stores / MFMA     "late" waves: stores of tile s-1 (held in registers), then MFMA(s);
-  //                     "early" waves: MFMA(s), drain, then stores of tile s (they drain under the next stage)
-  //   s_waitcnt vmcnt(0)
-  // The two waves that share a SIMD (w and w + NW/2) would otherwise run MFMA together and store together; making
-  // the younger half "late" and the older half "early" keeps one of them storing while the other computes.
+  // Pipeline (default, p.pipeline == 0): ONE raw s_barrier per stage and a COUNTED wait.  Per stage and wave the
+  // vector-memory stream is  [LDS-DMA pieces of tile s+1] [32 score stores]; `s_waitcnt vmcnt(32)` at the top of the next
+  // stage retires the DMA (older) and leaves the 32 stores (younger) in flight.  That relies on loads, stores -- also
+  // the out-of-range ones the buffer descriptor drops -- and LDS-DMA retiring in ISSUE ORDER (MI355X_MICROARCH.md:
+  // "`s_waitcnt vmcnt(N)` waits until all but the wave's N youngest vector-memory operations are done. Loads, stores,
+  // atomics and LDS-DMA count together, in issue order"; re-checked on the card by scripts/micro/vmcnt_order.hip) and
+  // on EXACTLY 32 stores per wave and stage: ragged rows / columns are stored out of range (epilogue()), never skipped.
+  //   s_waitcnt vmcnt(32)  this wave's DMA pieces of tile s have landed
+  //   s_barrier            ... and everybody else's; every wave has finished reading tile s-1 (its buffer is reused)
+  //   issue DMA(s+1)       asynchronous, lands under the MFMA phase
+  //   MFMA(s) / stores     VAR 0: "early" waves MFMA(s) then the 32 stores of tile s; "late" waves (the younger half, which
+  //                        shares each SIMD with an early wave) first the 32 stores of tile s-1, held in registers, then
+  //                        MFMA(s): one partner stores while the other computes.  VAR 1: every wave is late and its stores
+  //                        are spread between its MFMAs (compute_tile_spread).
+  // A conservative pipeline without counted waits (full vmcnt(0) per stage) is kept behind MDG_BILINEAR_PIPELINE=1.
   // Each workgroup starts its sweep at a different tail tile (and wraps): co-resident workgroups otherwise write
   // addresses that differ only by multiples of the row / slab strides (16 KB, 4 MB at N=4096) at the same instant,
   // which piles them onto a few HBM channels.
@@ -371,13 +453,15 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
       // Nothing is stored, so a stage is only the MFMAs of 64 tail rows (~1000 matrix-pipe cycles per SIMD): shorter
       // than the LDS-DMA latency.  Three buffers, prefetch distance two; the vector-memory stream of a wave holds
       // loads only (in order), so `vmcnt(NDMA)` retires tile s and leaves tile s+1 in flight.
-      constexpr int NDMA = (MODE == MDG_PREC_BF16 ? 16 : 32) / NW;       // LDS-DMA instructions per wave and tile
+      constexpr int NDMA = (kSingle16<MODE> ? 16 : 32) / NW;             // LDS-DMA instructions per wave and tile
+      static_assert(NDMA == 2 || NDMA == 4 || NDMA == 8, "s_waitcnt immediates below cover NDMA in {2,4,8}");
       stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, smem, wave, lane, NW);
       stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(1 < nst ? 1 : 0)) * BN, smem + STAGE_BYTES, wave, lane, NW);
       int cur = 0;
       for (int s = 0; s < nst; ++s) {
         const int64_t tcol0 = static_cast<int64_t>(tile_of(s)) * BN;
-        if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // = NDMA: tile s+1 stays in flight
+        else if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __builtin_amdgcn_s_barrier();      // tile s landed for every wave; every wave finished reading tile s-1
         const int nxt2 = cur == 0 ? 2 : cur - 1;                           // (cur + 2) % 3 = buffer of tile s-1
@@ -400,8 +484,8 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
               const bf16x8 bh = *reinterpret_cast<const bf16x8*>(lds + tile_off<256>(32 * t + r, 2 * s + h));
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ats[0].hi[s], bh, acc[t], 0, 0, 0);
-              acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ats[RB - 1].hi[s], bh, acc1[t], 0, 0, 0);
+              acc[t] = mma16<MODE>(Ats[0].hi[s], bh, acc[t]);
+              acc1[t] = mma16<MODE>(Ats[RB - 1].hi[s], bh, acc1[t]);
             }
           epilogue(acc, tcol0);
           // row block 1: same reduction into the second accumulator pair
@@ -428,6 +512,37 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
         }
         cur = cur == 2 ? 0 : cur + 1;
       }
+    } else if constexpr (VAR == 1) {
+      stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, buf0, wave, lane, NW);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      held_col0 = p.n_tail;                                       // first stage: 32 out-of-range (dropped) stores
+      for (int s = 0; s < nst; ++s) {
+        const int64_t tcol0 = static_cast<int64_t>(tile_of(s)) * BN;
+        char* const cur = (s & 1) ? buf1 : buf0;
+        char* const nxt = (s & 1) ? buf0 : buf1;
+        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(s + 1 < nst ? s + 1 : s)) * BN, nxt, wave, lane, NW);
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        const int64_t hc0 = held_col0;
+        compute_tile_spread<MODE>(At, cur, r, h, acc, [&](int k) {
+          const int t = k >> 4, v = k & 15;
+          const int64_t col = hc0 + 32 * t + r;
+          const int64_t e = static_cast<int64_t>(wave * 32 + acc_row(v, h)) * p.n_tail + col;
+          const unsigned off = col < p.n_tail ? static_cast<unsigned>(e * 4) : 0xFFFFFFFFu;    // out of range => dropped
+          float val = held[t][v];
+          if constexpr (EPI == MDG_EPI_STORE_SIGMOID) val = 1.0f / (1.0f + expf(-val));
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsrc, off, 0, 0);
+        });
+#pragma unroll
+        for (int t = 0; t < 2; ++t) held[t] = acc[t];
+        held_col0 = tcol0;
+      }
+      epilogue(held, held_col0);
     } else {
     stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, buf0, wave, lane, NW);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -455,8 +570,8 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
         epilogue(acc, tcol0);
       }
     }
-    }
     if (late) epilogue(held, held_col0);
+    }
   } else {
     // ---- conservative pipeline (MDG_BILINEAR_PIPELINE=1): no counted waits.  Only the first `nload` waves issue
     // LDS-DMA and only they wait (a full vmcnt(0) once per stage, after their MFMAs and before their stores); the
@@ -535,6 +650,16 @@ __global__ void split_bf16_kernel(const float* __restrict__ x, __bf16* __restric
   if (lo) reinterpret_cast<bf16x4*>(lo)[i] = l;
 }
 
+__global__ void round_f16_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int64_t n4) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = reinterpret_cast<const float4*>(x)[i];
+  typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+  f16x4 o;
+  o[0] = static_cast<_Float16>(v.x); o[1] = static_cast<_Float16>(v.y); o[2] = static_cast<_Float16>(v.z); o[3] = static_cast<_Float16>(v.w);
+  reinterpret_cast<f16x4*>(y)[i] = o;
+}
+
 inline size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
 template <int MODE, int NW>
@@ -542,18 +667,28 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
   const dim3 grid(static_cast<unsigned>(mdg_cdiv(a.n_head, 32 * NW)), static_cast<unsigned>(a.n_labels));
   const dim3 block(64 * NW);
   const size_t lds = 2 * STAGE_BYTES;
+  // MDG_BILINEAR_VARIANT: 0 = one burst of 32 stores per wave and stage (early / late halves), 1 = stores spread between the
+  // MFMAs of the next tile.  Read per call; changes speed only (same products, same accumulation order, same stores).
+  const char* ve = getenv("MDG_BILINEAR_VARIANT");
+  const int variant = (ve && atoi(ve) == 1) ? 1 : 0;
   switch (epilogue) {
     case MDG_EPI_STORE:
-      hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE, NW>), grid, block, lds, st, a);
+      if (variant == 1 && a.pipeline == 0)
+        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE, NW, 1, 1>), grid, block, lds, st, a);
+      else
+        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE, NW>), grid, block, lds, st, a);
       break;
     case MDG_EPI_STORE_SIGMOID:
-      hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE_SIGMOID, NW>), grid, block, lds, st, a);
+      if (variant == 1 && a.pipeline == 0)
+        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE_SIGMOID, NW, 1, 1>), grid, block, lds, st, a);
+      else
+        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE_SIGMOID, NW>), grid, block, lds, st, a);
       break;
     case MDG_EPI_ROWSTATS: {    // three-buffer ring (prefetch distance two)
       static const int rb2 = getenv("MDG_BILINEAR_RB") ? atoi(getenv("MDG_BILINEAR_RB")) : 2;
-      if (MODE == MDG_PREC_BF16 && rb2 == 2 && a.pipeline == 0) {     // 64 rows per wave: halves the LDS operand reads per MFMA
+      if (kSingle16<MODE> && rb2 == 2 && a.pipeline == 0) {     // 64 rows per wave: halves the LDS operand reads per MFMA
         const dim3 grid2(static_cast<unsigned>(mdg_cdiv(a.n_head, 32 * NW * 2)), static_cast<unsigned>(a.n_labels));
-        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_ROWSTATS, NW, (MODE == MDG_PREC_BF16 ? 2 : 1)>), grid2, block, 3 * STAGE_BYTES, st, a);
+        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_ROWSTATS, NW, (kSingle16<MODE> ? 2 : 1)>), grid2, block, 3 * STAGE_BYTES, st, a);
       } else {
         hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_ROWSTATS, NW>), grid, block, 3 * STAGE_BYTES, st, a);
       }
@@ -610,7 +745,7 @@ extern "C" int mdg_bilinear_allpairs(const float* z_head, const float* z_tail, c
   MDG_CHECK_ARG(z_head && z_tail && w_sym && out, "mdg_bilinear_allpairs: null pointer");
   MDG_CHECK_ARG(mdg_aligned16(z_head) && mdg_aligned16(z_tail) && mdg_aligned16(w_sym),
                 "mdg_bilinear_allpairs: z_head, z_tail and w_sym must be 16-byte aligned");
-  MDG_CHECK_ARG(precision == MDG_PREC_F32 || precision == MDG_PREC_BF16X3 || precision == MDG_PREC_BF16,
+  MDG_CHECK_ARG(precision == MDG_PREC_F32 || precision == MDG_PREC_BF16X3 || precision == MDG_PREC_BF16 || precision == MDG_PREC_F16,
                 "mdg_bilinear_allpairs: unknown precision %d", precision);
   hipStream_t st = static_cast<hipStream_t>(stream);
   BilinearArgs a{};
@@ -646,6 +781,14 @@ extern "C" int mdg_bilinear_allpairs(const float* z_head, const float* z_tail, c
   __bf16* zlo = x3 ? reinterpret_cast<__bf16*>(ws + zb + wb) : nullptr;
   __bf16* wlo = x3 ? reinterpret_cast<__bf16*>(ws + 2 * zb + wb) : nullptr;
   const int64_t z4 = n_tail * D / 4, w4 = n_labels * D * D / 4;
+  if (precision == MDG_PREC_F16) {           // operands rounded to IEEE half once (BASELINE configs[4]: "fp16 bilinear head")
+    hipLaunchKernelGGL(round_f16_kernel, dim3(static_cast<unsigned>(mdg_cdiv(z4, 256))), dim3(256), 0, st, z_tail, reinterpret_cast<_Float16*>(zhi), z4);
+    hipLaunchKernelGGL(round_f16_kernel, dim3(static_cast<unsigned>(mdg_cdiv(w4, 256))), dim3(256), 0, st, w_sym, reinterpret_cast<_Float16*>(whi), w4);
+    MDG_CHECK_LAUNCH("mdg_bilinear_allpairs(round)");
+    a.zt.hi = zhi; a.zt.lo = nullptr;
+    a.w.hi = whi; a.w.lo = nullptr;
+    return launch_allpairs<MDG_PREC_F16>(a, epilogue, st);
+  }
   hipLaunchKernelGGL(split_bf16_kernel, dim3(static_cast<unsigned>(mdg_cdiv(z4, 256))), dim3(256), 0, st, z_tail, zhi, zlo, z4);
   hipLaunchKernelGGL(split_bf16_kernel, dim3(static_cast<unsigned>(mdg_cdiv(w4, 256))), dim3(256), 0, st, w_sym, whi, wlo, w4);
   MDG_CHECK_LAUNCH("mdg_bilinear_allpairs(split)");

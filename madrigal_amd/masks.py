@@ -175,3 +175,36 @@ def pretrain_modality_subset_sampler(all_subset_masks, pretrain_mode: str = "str
         aug2[:, 1] = False
         return aug1, aug2
     raise NotImplementedError(pretrain_mode)
+
+
+class StrCenterUniSampler:
+    """The balanced 'str_center_uni' draw of pretrain_modality_subset_sampler for a whole batch at once.
+
+    The reference calls np.random.choice(arange(k), size=1, p=w) once per drug (utils.py:371): one uniform double per drug
+    from numpy's global generator, inverted through the cumulative weights (numpy's legacy choice: cdf = cumsum(p);
+    cdf /= cdf[-1]; searchsorted(cdf, u, side='right')).  Drawing the batch's doubles in one call consumes the same
+    stream and picks the same candidates (pinned against the reference in tests/test_oracle_golden.py), at 0.2 ms
+    instead of 24 ms per 2048-drug batch.  Built once from get_pretrain_masks(..., 'str_center_uni', False, ...)."""
+
+    def __init__(self, banks: dict, width: int = NUM_MODALITIES):
+        self.index = {d: i for i, d in enumerate(banks)}
+        kmax = max(len(rows) for rows, _ in banks.values())
+        self.cdf = np.full((len(banks), kmax), np.inf)
+        self.col = np.zeros((len(banks), kmax), dtype=np.int64)
+        for d, (rows, w) in banks.items():
+            c = np.cumsum(np.asarray(w, dtype=np.float64))
+            c /= c[-1]
+            i = self.index[d]
+            self.cdf[i, : len(rows)] = c
+            self.col[i, : len(rows)] = [int(np.where(r == 0)[0][0]) for r in rows]
+        self.width = width
+
+    def __call__(self, drugs):
+        ids = np.fromiter((self.index[int(d)] for d in drugs), dtype=np.int64)
+        u = np.random.random_sample(ids.size)
+        pick = (self.cdf[ids] <= u[:, None]).sum(axis=1)                   # == searchsorted(cdf, u, side='right')
+        aug1 = torch.ones(ids.size, self.width, dtype=torch.bool)
+        aug1[:, 0] = False
+        aug2 = torch.ones(ids.size, self.width, dtype=torch.bool)
+        aug2[torch.arange(ids.size), torch.from_numpy(self.col[ids, pick])] = False
+        return aug1, aug2

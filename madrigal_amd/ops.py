@@ -13,8 +13,9 @@ import torch
 
 from ._lib import check, lib
 
-PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
 PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
+HEAD_PRECISIONS = dict(PRECISIONS, f16=PREC_F16)          # the all-pairs head also runs on the fp16 matrix cores
 EPI_STORE, EPI_STORE_SIGMOID, EPI_ROWSTATS = 0, 1, 2
 
 _c64 = ctypes.c_int64
@@ -96,7 +97,9 @@ def bilinear_allpairs(z_head: torch.Tensor, z_tail: torch.Tensor, w_sym: torch.T
         out = _f32_cuda(out, "out")
         if tuple(out.shape) != shape or not out.is_contiguous():
             raise ValueError(f"out: expected contiguous {shape}, got {tuple(out.shape)}")
-    prec = _prec(precision)
+    if isinstance(precision, str) and precision not in HEAD_PRECISIONS:
+        raise ValueError(f"unknown precision {precision!r}; expected one of {sorted(HEAD_PRECISIONS)}")
+    prec = HEAD_PRECISIONS[precision] if isinstance(precision, str) else int(precision)
     L_ = lib()
     # the grid's y extent caps one call at 65535 outcomes; chunk above that
     for lo in range(0, max(L, 1), 65535):

@@ -138,6 +138,26 @@ def bilinear_scores(z_head: Tensor, z_tail: Tensor, w_original: Tensor,
     return torch.matmul(t, z_tail.t())        # [L', Nh, Nt]
 
 
+def round_operand(x: Tensor, mode: str) -> Tensor:
+    """fp32 -> the 16-bit operand type of a single-product head mode and back (round to nearest even): "f16" = IEEE half
+    (v_mfma_f32_32x32x16_f16 operands), "bf16" = bfloat16."""
+    if mode == "f16":
+        return x.to(torch.float16).to(torch.float32)
+    if mode == "bf16":
+        return x.to(torch.bfloat16).to(torch.float32)
+    raise ValueError(mode)
+
+
+def bilinear_scores_rounded(z_head: Tensor, z_tail: Tensor, w_original: Tensor, mode: str) -> Tensor:
+    """The head (models.py:537-547) as the reduced-precision modes of BASELINE configs[1]/[4] compute it: every matrix
+    operand rounded to the 16-bit type once -- z_head, W_sym, T = z_head W_sym (formed in fp32) and z_tail -- products
+    exact, sums in float64 here (fp32 on the device).  Returns float64 [L,Nh,Nt]."""
+    zh, zt = round_operand(z_head, mode).double(), round_operand(z_tail, mode).double()
+    ws = round_operand(symmetric(w_original), mode).double()
+    t_rounded = round_operand(torch.matmul(zh, ws).float(), mode).double()
+    return torch.matmul(t_rounded, zt.t())
+
+
 def gathered_bce_loss(scores: Tensor, labels: Tensor, heads: Tensor, tails: Tensor,
                       pos_neg: Tensor) -> Tuple[Tensor, Tensor]:
     """sigmoid -> gather labelled triples -> mean BCE on probabilities.

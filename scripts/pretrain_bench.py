@@ -35,6 +35,7 @@ model = SimCLR_NovelDDI(enc, dim=128, mlp_dim=512 if raw else 1024, T=0.1 if raw
 b = D.batch_to(batch, "cuda")
 kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
 bank = MK.get_pretrain_masks(list(range(a.batch)), avail.numpy().astype(np.int64), "str_center_uni", False, 0.2) if raw else None
+draw = MK.StrCenterUniSampler(bank) if raw else None
 step = PretrainStep(model, AdamW(model.parameters(), lr=1e-5, weight_decay=1e-2))
 data = (b["strs"], kgc, b["cv"], b["tx"])
 losses, t_views = [], 0.0
@@ -45,7 +46,7 @@ for i in range(a.warmup + a.steps):
         t_views = 0.0
     tv = time.perf_counter()
     if raw:                                               # host-side view draw of pretrain.py:71 (inside the timed step)
-        m1, m2 = MK.pretrain_modality_subset_sampler([bank[d] for d in range(a.batch)], "str_center_uni", False)
+        m1, m2 = draw(range(a.batch))
         m1, m2 = m1.cuda(), m2.cuda()
     else:
         m1 = b["masks"].clone()

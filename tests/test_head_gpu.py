@@ -9,7 +9,15 @@ pytestmark = pytest.mark.gpu
 
 # tolerance per arithmetic mode, norm-wise relative (max|d| / max|ref|).  BASELINE.json: fp32 scores
 # within 1e-4 relative of the reference CPU path; bf16 is the reduced-precision config ("bf16").
-TOL = {"f32": 2e-5, "bf16x3": 1e-4, "bf16": 3e-2}
+# "f16" = BASELINE configs[4] ("fp16 bilinear head"): operands rounded to IEEE half once, 8x finer than bf16.
+TOL = {"f32": 2e-5, "bf16x3": 1e-4, "bf16": 3e-2, "f16": 4e-3}
+
+
+@pytest.fixture(params=["0", "1"], ids=["burst_stores", "spread_stores"])
+def variant(request, monkeypatch):
+    """MDG_BILINEAR_VARIANT: the two store schedules of the kernel (same products, same accumulation order)."""
+    monkeypatch.setenv("MDG_BILINEAR_VARIANT", request.param)
+    return request.param
 
 
 @pytest.fixture(scope="module")
@@ -38,8 +46,8 @@ def test_symmetrize(ops):
     assert torch.equal(w2.cpu(), O.symmetric(w))
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
-def test_golden_head(ops, golden, prec):
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16", "f16"])
+def test_golden_head(ops, golden, prec, variant):
     g = golden("head")
     zh, zt, w = t(g["z_head"]).cuda(), t(g["z_tail"]).cuda(), t(g["w_original"]).cuda()
     ws = ops.symmetrize(w)
@@ -50,9 +58,9 @@ def test_golden_head(ops, golden, prec):
     assert rel_err(s14, g["scores_1_4"]) < TOL[prec]
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16", "f16"])
 @pytest.mark.parametrize("nh,nt,L", [(256, 256, 32), (301, 77, 3), (1, 1, 1), (31, 513, 2), (700, 64, 2), (257, 129, 5)])
-def test_vs_oracle(ops, prec, nh, nt, L):
+def test_vs_oracle(ops, prec, nh, nt, L, variant):
     zh, zt = _rand((nh, 128), 1), _rand((nt, 128), 2)
     w = _rand((L, 128, 128), 3, 1 / np.sqrt(128))
     ref = _oracle(zh, zt, w)
@@ -60,6 +68,40 @@ def test_vs_oracle(ops, prec, nh, nt, L):
     assert got.shape == ref.shape
     # scale floor sqrt(D): a lone score can sit near zero while its bf16 rounding error does not
     assert float((got - ref).abs().max()) < TOL[prec] * max(float(ref.abs().max()), 128 ** 0.5)
+
+
+@pytest.mark.parametrize("prec,np_dtype", [("f16", np.float16), ("bf16", None)])
+def test_rounded_operand_modes_against_the_rounded_oracle(ops, prec, np_dtype):
+    """The single-product modes round z_head, W, T = z_head W (fp32) and z_tail to the 16-bit type once and accumulate in
+    fp32: restating exactly those roundings in the oracle (float64 accumulation) pins the mode to fp32-accumulation noise,
+    far below the mode's own distance from the fp32 result."""
+    from oracle import madrigal_oracle as O
+    zh, zt = _rand((130, 128), 1), _rand((257, 128), 2)
+    w = _rand((3, 128, 128), 3, 1 / np.sqrt(128))
+    ref = O.bilinear_scores_rounded(zh, zt, w, prec)
+    got = ops.bilinear_allpairs(zh.cuda(), zt.cuda(), ops.symmetrize(w.cuda()), precision=prec).cpu()
+    # a T entry within fp32 rounding distance of a 16-bit tie may round the other way: allow a few such entries
+    err = (got.double() - ref).abs() / float(ref.abs().max())
+    assert float(err.median()) < 2e-7 and float(err.max()) < 2e-4, (float(err.median()), float(err.max()))
+    assert rel_err(got, _oracle(zh, zt, w)) < TOL[prec]
+
+
+def test_store_schedules_write_identical_bits(ops, monkeypatch):
+    zh, zt = _rand((1000, 128), 40).cuda(), _rand((3001, 128), 41).cuda()
+    w = ops.symmetrize(_rand((7, 128, 128), 42, 1 / np.sqrt(128)).cuda())
+    for prec in ("f32", "bf16x3", "bf16", "f16"):
+        outs = []
+        for var in ("0", "1"):
+            monkeypatch.setenv("MDG_BILINEAR_VARIANT", var)
+            out = torch.full((7, 1000, 3001), float("nan"), device="cuda")
+            ops.bilinear_allpairs(zh, zt, w, precision=prec, out=out)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]), prec
+    sg = []
+    for var in ("0", "1"):
+        monkeypatch.setenv("MDG_BILINEAR_VARIANT", var)
+        sg.append(ops.bilinear_allpairs(zh, zt, w, precision="bf16x3", epilogue=ops.EPI_STORE_SIGMOID))
+    assert torch.equal(sg[0], sg[1])
 
 
 def test_asymmetric_operands_catch_transposes(ops):
@@ -84,10 +126,10 @@ def test_sigmoid_epilogue(ops):
     assert float((got - ref).abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16", "f16"])
 @pytest.mark.parametrize("nh,nt", [(300, 333), (1, 1), (513, 64), (1100, 130)])
 def test_rowstats_epilogue(ops, prec, nh, nt):
-    """(bf16 runs the two-row-blocks-per-wave variant: 512 head rows per workgroup, ragged row and column tails.)"""
+    """(bf16 / f16 run the two-row-blocks-per-wave variant: 512 head rows per workgroup, ragged row and column tails.)"""
     zh, zt, w = _rand((nh, 128), 10), _rand((nt, 128), 11), _rand((4, 128, 128), 12, 0.1)
     ref = _oracle(zh, zt, w)
     st = ops.bilinear_allpairs(zh.cuda(), zt.cuda(), ops.symmetrize(w.cuda()), precision=prec,
@@ -141,9 +183,41 @@ def test_full_size_properties(ops, prec):
         assert rel_err(s[l:l + 1, i0:i0 + 200, j0:j0 + 300].cpu(), ref) < TOL[prec]
 
 
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_cfg5_scale_row_statistics(ops, prec):
+    """BASELINE configs[4] (100k drugs, 16-bit head; nothing can be materialised): N = 100 352 with a few outcomes through the
+    row-statistics epilogue.  (i) the row-sum identity  sum_j S[l,i,j] = T[l,i,:] . sum_j z_j  with the mode's roundings
+    restated (float64 sums); (ii) a block of head rows scored densely by the same kernel and by the CPU oracle: the
+    statistics of the full run equal the reductions of that dense block (maxima bit for bit)."""
+    from oracle import madrigal_oracle as O
+    N, L = 100_352, 3
+    z = _rand((N, 128), 50)
+    w = _rand((L, 128, 128), 51, 1 / np.sqrt(128))
+    zc, wc = z.cuda(), ops.symmetrize(w.cuda())
+    st = ops.bilinear_allpairs(zc, zc, wc, precision=prec, epilogue=ops.EPI_ROWSTATS).cpu()
+    assert st.shape == (L, N, 2) and bool(torch.isfinite(st).all())
+    # (i) every row of every outcome
+    zr = O.round_operand(z, prec).double()
+    T = O.round_operand((zr @ O.round_operand(O.symmetric(w), prec).double()).float(), prec).double()     # [L,N,128]
+    want = T @ zr.sum(dim=0)                                                                          # [L,N]
+    scale = float(st[..., 1].abs().max()) * N ** 0.5                                                  # size of a random-sign row sum
+    err = (st[..., 0].double() - want).abs() / scale
+    # an entry of T within fp32 rounding distance of a 16-bit tie may round the other way on the device: that moves a row
+    # sum by one 16-bit ulp of T times |sum_j z_j| -- rare, and bounded
+    assert float(err.median()) < 2e-6 and float((err > 2e-4).double().mean()) < 1e-3 and float(err.max()) < 4e-3, \
+        (float(err.median()), float((err > 2e-4).double().mean()), float(err.max()))
+    # (ii) 96 head rows (ragged against the 512-row workgroups) x all 100 352 tails, densely
+    rows = torch.arange(70_001, 70_097)
+    dense = ops.bilinear_allpairs(zc[rows.cuda()], zc, wc, precision=prec).cpu()
+    ref = O.bilinear_scores(z[rows], z, w)
+    assert rel_err(dense, ref) < TOL[prec]
+    assert torch.equal(st[:, rows, 1], dense.max(dim=2).values)
+    assert float((st[:, rows, 0] - dense.sum(dim=2)).abs().max()) < 1e-5 * scale
+
+
 @pytest.mark.parametrize("prec", ["bf16x3", "f32"])
 @pytest.mark.parametrize("nh,nt,L", [(4096, 4096, 24), (1000, 3001, 7)])
-def test_repeated_launches_are_bit_identical(ops, prec, nh, nt, L):
+def test_repeated_launches_are_bit_identical(ops, prec, nh, nt, L, variant):
     """Race detector: the kernel is deterministic (fixed summation order, no atomics), so every launch into a
     NaN-prefilled buffer must reproduce the first one bit for bit -- an LDS tile consumed before it landed or
     an unwritten element would show up here."""

@@ -243,6 +243,13 @@ def test_pretrain_view_sampler_matches_reference(golden):
                 assert got.dtype == torch.bool and np.array_equal(got.numpy(), g[tag + key]), (tag, key)
     bank = MK.get_pretrain_masks(drugs, avail.copy(), "str_center_uni", False, 0.2)
     assert np.allclose(bank[100][1], g["uni_probs_d100"], rtol=1e-12)
+    # the batched sampler consumes numpy's global stream exactly like the reference's per-drug loop
+    fast = MK.StrCenterUniSampler(bank)
+    np.random.seed(123)
+    order = g["str_center_uni_0_order"].tolist()
+    for tag in ("", "b"):
+        a1, a2 = fast(order)
+        assert np.array_equal(a1.numpy(), g["str_center_uni_0_aug1" + tag]) and np.array_equal(a2.numpy(), g["str_center_uni_0_aug2" + tag])
     # 'str_center_uni': the structure alone / exactly one other modality the drug owns
     a1, a2 = t(g["str_center_uni_0_aug1"]), t(g["str_center_uni_0_aug2"])
     assert bool((~a1).sum(1).eq(1).all()) and bool((~a1[:, 0]).all()) and bool((~a2).sum(1).eq(1).all()) and bool(a2[:, 0].all())

@@ -109,7 +109,7 @@ def test_simclr_raw_training_step_matches_oracle_autograd(shared, basal):
     gmax = max(float(v.grad.abs().max()) for v in pr.values() if torch.is_tensor(v) and v.grad is not None)
     checked, worst = 0, (0.0, "")
     for k, v in pr.items():
-        if not (torch.is_tensor(v) and v.requires_grad):
+        if k not in named or not (torch.is_tensor(v) and v.requires_grad):       # buffers (GIN eps, running statistics)
             continue
         if v.grad is None or not bool(v.grad.any()):
             # the fusion transformer, uni_fuser, learned tokens and (under str_center_uni) nothing else: unused by this path

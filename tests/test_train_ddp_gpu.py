@@ -191,7 +191,9 @@ def _pretrain_raw_worker(rank, world, port, ret):
             torch.manual_seed(seed)
             np.random.seed(seed)
             model = _no_dropout(_build(M, bkg0["data"], False, True, mlp_dim=256, T=0.5)).cuda().train()
-            step = PretrainStep(model, AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2), rank=rank_, world=world_)
+            # eps well above the gradients' rounding noise: Adam's first steps otherwise move every entry by +-lr whatever
+            # its size, so entries whose gradient is noise would take opposite steps in the two runs
+            step = PretrainStep(model, AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2, eps=1e-3), rank=rank_, world=world_)
             kg_dev = bkg0["data"].to("cuda")
             losses, mem = [], []
             for it in range(4):
