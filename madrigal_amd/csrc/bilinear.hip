@@ -46,6 +46,7 @@ struct BilinearArgs {
   int stagger_waves;    // counted pipeline: younger half of the waves stores one stage late
   int loaders;          // conservative pipeline: waves that issue the LDS-DMA (1, 2 or 4)
   int pipeline;         // 0 = counted waits (default), 1 = conservative
+  unsigned long long* stamps;   // diagnostics only (MDG_BILINEAR_STAMPS): per workgroup {shader cycles, 100 MHz ticks} of the sweep
 };
 
 // 16-bit operand images travel as bf16x8 containers; MDG_PREC_F16 stores IEEE half bits in them and casts at the MFMA.
@@ -315,6 +316,10 @@ __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >
 // (one ds_read_b128 per MFMA), not by the matrix cores.
 // VAR = 1: every wave keeps the finished tile in registers for one stage and issues its 32 stores one or two at a time
 // between the MFMAs of the next tile (compute_tile_spread), instead of the burst-per-stage of VAR = 0.
+// VAR = 2: the finished 32 x 64 tile of a wave is transposed through a wave-private 8 KB LDS slab (32 x ds_write_b32, lane =
+// column, then 8 x ds_read_b128, lane = 4 consecutive columns of one row) and leaves as 8 x buffer_store_dwordx4 -- 1 KB per
+// store instruction (4 whole 256-byte row segments) instead of 256 B -- issued between the MFMAs of the next tile.  Needs
+// n_tail % 4 == 0 and a 16-byte aligned output (the launcher falls back to VAR 0 otherwise).
 template <int MODE, int EPI, int NW, int RB = 1, int VAR = 0>
 __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const BilinearArgs p) {
   static_assert(NW == 4 || NW == 8, "the counted waits below are written for 4 or 8 waves per workgroup");
@@ -368,6 +373,8 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
   }
 
   // ---------------- main sweep over the tail drugs -----------------------------------------
+  unsigned long long stamp_c = 0, stamp_r = 0;          // diagnostic build path: clock held during the sweep (never in outputs)
+  if (p.stamps && tid == 0) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
   const int nst = static_cast<int>((p.n_tail + BN - 1) / BN);
   const int64_t slab_rows = (p.n_head - row0) < BM ? (p.n_head - row0) : BM;
   float* const out_slab = (EPI == MDG_EPI_ROWSTATS) ? nullptr : p.out + (l * p.n_head + row0) * p.n_tail;
@@ -512,6 +519,58 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
         }
         cur = cur == 2 ? 0 : cur + 1;
       }
+    } else if constexpr (VAR == 2) {
+      char* const stg = smem + 2 * STAGE_BYTES + wave * 8192;          // [32 rows][64 columns] fp32, this wave's tile
+      stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, buf0, wave, lane, NW);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int srow = lane >> 4, scol = 4 * (lane & 15);            // store role: row within a group of 4, first of 4 columns
+      u32x4 o[8];
+      auto out_store = [&](int q, int64_t col0) {                     // rows 4q .. 4q+3 of the wave's tile, 1 KB
+        const int64_t col = col0 + scol;
+        const int64_t e = static_cast<int64_t>(wave * 32 + 4 * q + srow) * p.n_tail + col;
+        const unsigned off = col < p.n_tail ? static_cast<unsigned>(e * 4) : 0xFFFFFFFFu;       // out of range => dropped
+        u32x4 v = o[q];
+        if constexpr (EPI == MDG_EPI_STORE_SIGMOID) {
+          const f32x4 x = __builtin_bit_cast(f32x4, v);
+          f32x4 y;
+          y[0] = 1.0f / (1.0f + expf(-x[0])); y[1] = 1.0f / (1.0f + expf(-x[1]));
+          y[2] = 1.0f / (1.0f + expf(-x[2])); y[3] = 1.0f / (1.0f + expf(-x[3]));
+          v = __builtin_bit_cast(u32x4, y);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 0);
+      };
+      held_col0 = p.n_tail;                                           // first stage: the slab is empty, 8 dropped stores
+      // Per stage and wave the vector-memory stream is [LDS-DMA of tile s+1][8 stores of tile s-1]: vmcnt(8) at the top of
+      // the next stage retires the DMA and leaves the stores in flight (same in-order argument as VAR 0, 8 instead of 32).
+      for (int s = 0; s < nst; ++s) {
+        const int64_t tcol0 = static_cast<int64_t>(tile_of(s)) * BN;
+        char* const cur = (s & 1) ? buf1 : buf0;
+        char* const nxt = (s & 1) ? buf0 : buf1;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(s + 1 < nst ? s + 1 : s)) * BN, nxt, wave, lane, NW);
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        const int64_t hc0 = held_col0;
+        compute_tile_spread<MODE>(At, cur, r, h, acc, [&](int k) {
+          if (k < 8) o[k] = *reinterpret_cast<const u32x4*>(stg + (4 * k + srow) * 256 + scol * 4);
+          else if (k >= 16 && (k & 1) == 0) out_store((k - 16) >> 1, hc0);
+        });
+        // tile s -> the slab (the 8 reads above are older LDS operations of this wave: the LDS executes them first)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int v = 0; v < 16; ++v)
+            *reinterpret_cast<float*>(stg + acc_row(v, h) * 256 + (32 * t + r) * 4) = acc[t][v];
+        held_col0 = tcol0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = *reinterpret_cast<const u32x4*>(stg + (4 * q + srow) * 256 + scol * 4);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) out_store(q, held_col0);
     } else if constexpr (VAR == 1) {
       stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, buf0, wave, lane, NW);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -599,6 +658,11 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (p.stamps && tid == 0) {
+    const size_t wg = static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x;
+    p.stamps[2 * wg] = __builtin_amdgcn_s_memtime() - stamp_c;
+    p.stamps[2 * wg + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r;
+  }
 
   if constexpr (EPI == MDG_EPI_ROWSTATS) {
 #pragma unroll
@@ -667,19 +731,27 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
   const dim3 grid(static_cast<unsigned>(mdg_cdiv(a.n_head, 32 * NW)), static_cast<unsigned>(a.n_labels));
   const dim3 block(64 * NW);
   const size_t lds = 2 * STAGE_BYTES;
-  // MDG_BILINEAR_VARIANT: 0 = one burst of 32 stores per wave and stage (early / late halves), 1 = stores spread between the
-  // MFMAs of the next tile.  Read per call; changes speed only (same products, same accumulation order, same stores).
+  // MDG_BILINEAR_VARIANT: 0 = one burst of 32 dword stores per wave and stage (early / late halves), 1 = those stores spread
+  // between the MFMAs of the next tile, 2 = tile transposed through LDS, 8 x 16-byte stores spread between the MFMAs.  Read per
+  // call; changes speed only (same products, same accumulation order, same bytes stored).
   const char* ve = getenv("MDG_BILINEAR_VARIANT");
-  const int variant = (ve && atoi(ve) == 1) ? 1 : 0;
+  int variant = ve ? atoi(ve) : 0;
+  if (variant < 0 || variant > 2 || a.pipeline != 0) variant = 0;
+  if (variant == 2 && ((a.n_tail & 3) != 0 || !mdg_aligned16(a.out))) variant = 0;     // 16-byte stores need aligned rows
+  const size_t lds2 = lds + static_cast<size_t>(NW) * 8192;
   switch (epilogue) {
     case MDG_EPI_STORE:
-      if (variant == 1 && a.pipeline == 0)
+      if (variant == 2)
+        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE, NW, 1, 2>), grid, block, lds2, st, a);
+      else if (variant == 1)
         hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE, NW, 1, 1>), grid, block, lds, st, a);
       else
         hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE, NW>), grid, block, lds, st, a);
       break;
     case MDG_EPI_STORE_SIGMOID:
-      if (variant == 1 && a.pipeline == 0)
+      if (variant == 2)
+        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE_SIGMOID, NW, 1, 2>), grid, block, lds2, st, a);
+      else if (variant == 1)
         hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE_SIGMOID, NW, 1, 1>), grid, block, lds, st, a);
       else
         hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE_SIGMOID, NW>), grid, block, lds, st, a);
@@ -762,6 +834,8 @@ extern "C" int mdg_bilinear_allpairs(const float* z_head, const float* z_tail, c
   if (a.loaders != 1 && a.loaders != 2 && a.loaders != 4) a.loaders = 4;
   if (const char* e = getenv("MDG_BILINEAR_STAGGER_WAVES")) a.stagger_waves = atoi(e);
   if (const char* e = getenv("MDG_BILINEAR_STAGGER")) a.stagger = atoi(e);
+  // diagnostics: device address (hex) of a buffer of 2 x (workgroups of the launch) uint64 that receives clock stamps
+  if (const char* e = getenv("MDG_BILINEAR_STAMPS")) a.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 16));
   a.w.nrows = D;
   if (precision == MDG_PREC_F32) {
     a.zt.f32 = z_tail;

@@ -9,12 +9,14 @@ ap.add_argument("--n", type=int, default=4096)
 ap.add_argument("--labels", type=int, default=896)
 ap.add_argument("--reps", type=int, default=6)
 ap.add_argument("--precisions", default="bf16x3,bf16,f16,f32")
-ap.add_argument("--variants", default="0,1")
+ap.add_argument("--variants", default="0,1,2")
 a = ap.parse_args()
 g = torch.Generator().manual_seed(0)
 z = torch.randn(a.n, 128, generator=g).cuda()
 w = ops.symmetrize((torch.randn(a.labels, 128, 128, generator=g) / 128 ** 0.5).cuda())
 out = torch.empty(a.labels, a.n, a.n, device="cuda")
+stamps = torch.zeros(2 * a.labels * ((a.n + 255) // 256), dtype=torch.int64, device="cuda")       # in-kernel clock stamps (diagnostics)
+os.environ["MDG_BILINEAR_STAMPS"] = hex(stamps.data_ptr())
 res = {}
 for prec in a.precisions.split(","):
     ref = None
@@ -33,7 +35,10 @@ for prec in a.precisions.split(","):
         chk = out[::37, ::5, ::3].clone()
         same = None if ref is None else bool(torch.equal(chk, ref))
         ref = chk if ref is None else ref
-        res[f"{prec}/v{var}"] = {"ms_median": ts[len(ts) // 2], "ms_min": ts[0], "tb_s": a.labels * a.n * a.n * 4 / ts[len(ts) // 2] / 1e9,
+        st = stamps.view(-1, 2).double()
+        st = st[st[:, 1] > 0]
+        clk = float((st[:, 0] / st[:, 1]).median()) * 100.0 if st.numel() else 0.0                 # MHz (s_memrealtime ticks at 100 MHz)
+        res[f"{prec}/v{var}"] = {"clock_mhz": round(clk), "sweep_cycles_median": float(st[:, 0].median()) if st.numel() else 0.0, "ms_median": ts[len(ts) // 2], "ms_min": ts[0], "tb_s": a.labels * a.n * a.n * 4 / ts[len(ts) // 2] / 1e9,
                                  "same_as_v0": same}
         print(prec, var, res[f"{prec}/v{var}"], flush=True)
 print(json.dumps(res))
