@@ -13,9 +13,16 @@ This is BASELINE configs[1]/[3]: 4-modality model (TWOSIDES hyper-parameters, ha
 
 N GPUs: one process per GPU (torch.distributed over RCCL).  Drugs are sharded by rank for encode+fuse (the KG
 encoder is per-graph and replicated), the [N/G,128] embedding blocks are all-gathered over xGMI (the path's one
-exchange step), then every rank scores ITS OWN `--outcomes` outcomes against all N x N pairs (outcome-sharded
-head).  Per-GPU work is fixed => "scaling": "weak"; global outcomes = outcomes x n_gpus.
-Rank 0 prints ONE JSON line.
+exchange step), then the head is sharded by outcome:
+  --scaling strong (default) = BASELINE configs[3] as named: the FIXED job `--drugs`^2 x `--outcomes` split over the
+      ranks (896 / 8 = 112 outcomes per GPU), every rank writing its own slab of the score tensor;
+  --scaling weak: every rank scores its own `--outcomes` outcomes (global outcomes = outcomes x n_gpus).
+At N > 1 the line of the default mode also carries the other mode's numbers under "weak_scaling".  Rank 0 prints ONE
+JSON line; it states the world size RCCL saw and a checksum of the all-gathered embeddings.
+
+Also in the line (N = 1 unless noted): "roofline_cfg5" -- BASELINE configs[4], 100 352 drugs x 1 024 outcomes = 1.03e13
+scores through the fp16 head with the row-statistics epilogue (nothing materialised), priced against the dense 16-bit
+MFMA peak (outcome-sharded over the ranks at N > 1); "finetune" -- DDI-finetune steps/s.
 """
 from __future__ import annotations
 
@@ -34,7 +41,53 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 FLOP_PER_SCORE = 256.0         # 2*D at D=128
 BYTES_PER_SCORE = 4.0          # fp32 score stored
 HEAD_KERNEL = {"f32": "bilinear_allpairs_kernel<0, 0, 8>", "bf16x3": "bilinear_allpairs_kernel<1, 0, 8>",
-               "bf16": "bilinear_allpairs_kernel<2, 0, 8>"}
+               "bf16": "bilinear_allpairs_kernel<2, 0, 8>", "f16": "bilinear_allpairs_kernel<3, 0, 8>"}
+
+
+def stress_leg(args, rank, world, dev, backend):
+    """BASELINE configs[4]: 100 352 drugs x 1 024 outcomes, 16-bit bilinear head, row-statistics epilogue (the 20 TB score
+    tensor cannot exist: per (outcome, head drug) the sum and the maximum over all tail drugs are kept).  Outcomes are
+    sharded over the ranks (no collective: z is generated from the same seed on every rank).  The kernel's launch is
+    bracketed by HIP events on its own stream; SURVEY 8(d): achieved = scores/s x 256 flop / 2.5e15."""
+    import torch
+    import torch.distributed as dist
+    from madrigal_amd import ops
+    N, L_all, prec = args.stress_drugs, args.stress_outcomes, args.stress_precision
+    lo, hi = (rank * L_all) // world, ((rank + 1) * L_all) // world
+    g = torch.Generator(device=dev).manual_seed(7)
+    z = torch.randn(N, 128, device=dev, generator=g)
+    w = ops.symmetrize((torch.randn(L_all, 128, 128, device=dev, generator=g) / 128 ** 0.5)[lo:hi].contiguous())
+    out = torch.empty(hi - lo, N, 2, device=dev)
+    ops.bilinear_allpairs(z[:8192], z[:8192], w[:4], precision=prec, epilogue=ops.EPI_ROWSTATS)          # warm-up (code load)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    ops.bilinear_allpairs(z, z, w, precision=prec, epilogue=ops.EPI_ROWSTATS, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev if backend != "gloo" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    kernel_ms = e0.elapsed_time(e1)
+    # size-independent check inside the run: sum_j S[l,i,j] = z_i^T W_l (sum_j z_j) on a block of rows (fp64 on the device)
+    ref = torch.einsum("id,lde,e->li", z[:256].double(), w[:2].double(), z.sum(0).double())
+    err = float((out[:2, :256, 0].double() - ref).abs().max() / ref.abs().max())
+    scores = float(L_all) * N * N
+    ach = scores / dt * FLOP_PER_SCORE / 1e12
+    return {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+            "traffic": None, "kernel": f"bilinear_allpairs_kernel<{ {'bf16': 2, 'f16': 3}[prec] }, 2, 8, 2> (row statistics, 64 head rows per wave)",
+            "kernel_ms_rank0": kernel_ms, "wall_ms_max_over_ranks": dt * 1e3, "scores": scores, "scores_per_s": scores / dt, "n_gpus": world,
+            "dtype": prec, "row_sum_identity_rel_err": err,
+            "workload": f"BASELINE configs[4]: {N} drugs x {L_all} outcomes = {scores:.3e} scores, {prec} operands / fp32 accumulate, "
+                        f"row statistics only (nothing materialised), outcomes {lo}..{hi} on rank 0" + ("" if world == 1 else f" of {world}"),
+            "formula": "achieved = scores/s x 256 flop per score (2 x D, SURVEY 8d) / 1e12; peak = dense 16-bit MFMA 2.5 PFLOP/s"}
 
 
 def pmc_traffic(n_drugs: int, n_outcomes: int, precision: str):
@@ -144,6 +197,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--finetune-steps", type=int, default=3, help="second half of BASELINE's metric: DDI-finetune steps/s "
                     "(encode both sides + gathered head + BCE + backward + AdamW), timed at N=1 after the headline; 0 = skip")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: strong = the fixed drugs^2 x outcomes job "
+                    "split by outcome over the ranks (BASELINE configs[3]); weak = --outcomes per rank")
+    ap.add_argument("--stress-drugs", type=int, default=100_352, help="BASELINE configs[4] row-statistics run; 0 = skip")
+    ap.add_argument("--stress-outcomes", type=int, default=1024)
+    ap.add_argument("--stress-precision", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--finetune-triples", type=int, default=1_000_000, help="positive triples; with 2 negatives each and both "
                     "directions (the reference's collation) 6x as many labelled triples per step")
     args = ap.parse_args()
@@ -174,107 +232,154 @@ def main():
 
     N, L = args.drugs, args.outcomes
     M.set_precision(args.precision)
-    out = torch.empty(L, N, N, dtype=torch.float32, device=dev)
-    if args.head_only:
-        g = torch.Generator().manual_seed(0)
-        z_all = torch.randn(N, 128, generator=g)
-        lo, hi = shard_range(N, rank, world)
-        z_shard = z_all[lo:hi].to(dev)
-        w_orig = (torch.randn(L, 128, 128, generator=torch.Generator().manual_seed(1000 + rank)) / 128 ** 0.5).to(dev)
-        w_sym = torch.empty_like(w_orig)
-        model = None
-    else:
+    model = batch = bkg = filler = None
+    if not args.head_only:
         # same synthetic batch on every rank (seeded); each rank encodes only its drug block
         batch, bkg = D.make_batch(N, 0, kg_nodes=args.kg_nodes, kg_edges=args.kg_edges)
         torch.manual_seed(1234)                       # identical encoder weights on every rank
-        model = configs.build_model(args.config, bkg["data"], L)
-        with torch.no_grad():                         # this rank's own outcomes
-            model.decoder.parametrizations.weight.original.copy_(
-                torch.randn(L, 128, 128, generator=torch.Generator().manual_seed(1000 + rank)) / 128 ** 0.5)
-        model = model.to(dev).eval()
+        model = configs.build_model(args.config, bkg["data"], L).to(dev).eval()
         batch = D.batch_to(batch, dev)
         bkg = {"data": bkg["data"].to(dev), "drug_index_map": bkg["drug_index_map"].to(dev)}
-        filler = torch.randn(N, 128, device=dev)       # rows of drugs absent from the KG (always masked)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        filler = torch.randn(N, 128, device=dev, generator=torch.Generator(device=dev).manual_seed(5))   # drugs absent from the KG (always masked)
 
-    @torch.no_grad()
-    def step(i=None):
-        if i is not None:
-            ev[i][0].record()
+    def headline(mode: str) -> dict:
+        """K timed steps of the whole job in one sharding mode -> timings of this rank (+ max over ranks)."""
+        if mode == "strong":                          # ONE model of L outcomes, rank r scores outcomes [lo_l, hi_l)
+            lo_l, hi_l = (rank * L) // world, ((rank + 1) * L) // world
+            w_seed = 1000
+        else:                                         # every rank its own L outcomes
+            lo_l, hi_l, w_seed = 0, L, 1000 + rank
+        w_orig = (torch.randn(L, 128, 128, generator=torch.Generator().manual_seed(w_seed)) / 128 ** 0.5).to(dev)
+        Lr = hi_l - lo_l
+        out = torch.empty(Lr, N, N, dtype=torch.float32, device=dev)
         if args.head_only:
-            z = all_gather_rows(z_shard, N, rank, world) if world > 1 else z_shard
-            ops.symmetrize(w_orig, out=w_sym)
-            if i is not None:
-                ev[i][1].record()
-            ops.bilinear_allpairs(z, z, w_sym, precision=args.precision, out=out)
+            lo, hi = shard_range(N, rank, world)
+            z_shard = torch.randn(N, 128, generator=torch.Generator().manual_seed(0))[lo:hi].to(dev)
+            w_sym = torch.empty_like(w_orig)
         else:
-            z = generate_embeddings(model, batch, bkg, rank=rank, world=world, kg_filler=filler)
-            model.decoder.symmetric_weight()          # W_sym (cached until the parameter changes)
-            if i is not None:
-                ev[i][1].record()
-            model.decoder(z, z, out=out)
-        if i is not None:
-            ev[i][2].record()
+            with torch.no_grad():
+                model.decoder.parametrizations.weight.original.copy_(w_orig)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        keep = {}
 
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev if backend != "gloo" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        @torch.no_grad()
+        def step(i=None):
+            if i is not None:
+                ev[i][0].record()
+            if args.head_only:
+                z = all_gather_rows(z_shard, N, rank, world) if world > 1 else z_shard
+                ops.symmetrize(w_orig, out=w_sym)
+                if i is not None:
+                    ev[i][1].record()
+                ops.bilinear_allpairs(z, z, w_sym[lo_l:hi_l], precision=args.precision, out=out)
+            else:
+                z = generate_embeddings(model, batch, bkg, rank=rank, world=world, kg_filler=filler)
+                model.decoder.symmetric_weight()          # W_sym (cached until the parameter changes)
+                if i is not None:
+                    ev[i][1].record()
+                model.decoder(z, z, (lo_l, hi_l), out=out)
+            if i is not None:
+                ev[i][2].record()
+            keep["z"] = z
+
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev if backend != "gloo" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        # what the exchange step delivered: every rank must hold the same z[N,128], made of every rank's block
+        z = keep["z"]
+        zsum = z.double().sum().reshape(1)
+        coll = {"world_size_seen": world, "backend": "none" if world == 1 else backend, "z_rows": int(z.shape[0]), "z_checksum": float(zsum)}
+        if world > 1:
+            both = torch.cat([zsum, -zsum]).to(dev if backend != "gloo" else "cpu")
+            dist.all_reduce(both, op=dist.ReduceOp.MAX)          # max(sum) and -min(sum) over ranks
+            coll.update(world_size_seen=dist.get_world_size(), z_checksum_spread_over_ranks=float(both[0] + both[1]),
+                        z_block_checksums=[float(z[slice(*shard_range(N, r, world))].double().sum()) for r in range(world)],
+                        op="all_gather_into_tensor of [N/G,128] fp32 blocks")
+        res = {"mode": mode, "dt": dt, "Lr": Lr, "L_total": L if mode == "strong" else L * world, "collective": coll,
+               "enc_ms": sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps,
+               "head_ms": sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps}     # head launch (+ its two operand-split pre-passes)
+        del out
+        torch.cuda.empty_cache()
+        return res
+
+    main_mode = args.scaling if world > 1 else "strong"
+    h = headline(main_mode)
+    other = headline("weak" if main_mode == "strong" else "strong") if world > 1 else None
 
     finetune = None
     if args.finetune_steps > 0 and not args.head_only:
-        del out
-        torch.cuda.empty_cache()
         try:
             finetune = finetune_leg(model, batch, bkg, filler, N, L, args, rank, world, backend)
         except Exception as e:          # the headline line must survive a failure of the secondary leg
             finetune = {"metric": "DDI-finetune steps/sec", "value": None, "error": f"{type(e).__name__}: {e}"[:400]}
-    enc_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
-    head_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps     # head launch (+ its two operand-split pre-passes)
-    value = float(L) * N * N * world * args.steps / dt
+    stress = None
+    if args.stress_drugs > 0:
+        model = batch = bkg = None
+        torch.cuda.empty_cache()
+        try:
+            stress = stress_leg(args, rank, world, dev, backend)
+        except Exception as e:
+            stress = {"bound": "mfma", "achieved": None, "error": f"{type(e).__name__}: {e}"[:400]}
+
+    def scores_per_s(r):
+        return float(r["L_total"]) * N * N * args.steps / r["dt"]
+
     if rank == 0:
-        per_launch = float(L) * N * N
-        traffic, traffic_src = pmc_traffic(N, L, args.precision)
+        per_launch = float(h["Lr"]) * N * N
+        head_ms, enc_ms = h["head_ms"], h["enc_ms"]
+        traffic, traffic_src = pmc_traffic(N, h["Lr"], args.precision)
         if args.precision == "f32":
             achieved = per_launch * FLOP_PER_SCORE / (head_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic}
         else:
             achieved = per_launch * BYTES_PER_SCORE / (head_ms * 1e-3) / 1e9
+            nprod = 3 if args.precision == "bf16x3" else 1
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "mfma_frac_bf16": per_launch * FLOP_PER_SCORE * (3 if args.precision == "bf16x3" else 1)
-                    / (head_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+                    # SURVEY 8(d): scores/s x 256 flop / dense 16-bit peak (what the materialising head reaches of the MFMA roof)
+                    "mfma_frac": per_launch * FLOP_PER_SCORE / (head_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                    # matrix-core ISSUE rate: the split-bf16 mode issues 3 products per score element
+                    "mfma_issue_frac_16bit": per_launch * FLOP_PER_SCORE * nprod / (head_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
         roof.update({"kernel": HEAD_KERNEL[args.precision], "kernel_ms": head_ms, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": per_launch * BYTES_PER_SCORE,
                      "head_only_scores_per_s": per_launch / (head_ms * 1e-3), "encode_fuse_ms": enc_ms})
-        wl = (f"all-pairs bilinear head only, {N} x {N} drugs x {L} outcomes per GPU" if args.head_only else
+        per_gpu = f"{h['Lr']} of {L} outcomes per GPU (fixed job)" if main_mode == "strong" else f"{L} outcomes per GPU"
+        wl = (f"all-pairs bilinear head only, {N} x {N} drugs x {per_gpu}" if args.head_only else
               f"all-pairs inference, whole job per step: encode+fuse {N} drugs (4 modalities, {args.config}: GIN + HGT over a "
               f"{args.kg_nodes}-node / {args.kg_edges}-edge KG + cv MLP + chemCPA tx, fusion transformer) then score {N} x {N} "
-              f"pairs x {L} outcomes per GPU, [L,N,N] fp32 logits materialised in HBM; BASELINE configs[1]/[3]")
-        line = {"metric": "drug-pair x outcome scores/sec (all-pairs)", "value": value, "unit": "scores/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None,
+              f"pairs x {per_gpu}, [L,N,N] fp32 logits materialised in HBM; BASELINE configs[1]/[3]")
+        line = {"metric": "drug-pair x outcome scores/sec (all-pairs)", "value": scores_per_s(h), "unit": "scores/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": h["dt"] / args.steps * 1e3, "higher_is_better": True,
+                "scaling": main_mode, "vs_baseline": None,
                 "dtype": {"f32": "f32", "bf16x3": "f32 via split-bf16 (bf16x3) MFMA", "bf16": "bf16"}[args.precision],
                 "data": "synthetic",
-                "config": {"workload": wl, "drugs": N, "outcomes_per_gpu": L, "outcomes_total": L * world, "feature_dim": 128,
+                "config": {"workload": wl, "drugs": N, "outcomes_per_gpu": h["Lr"], "outcomes_total": h["L_total"], "feature_dim": 128,
                            "model": None if args.head_only else args.config, "precision": args.precision,
                            "parallelism": "single GPU" if world == 1 else
-                           f"drug-sharded encode+fuse, all-gather(z) over RCCL, outcome-sharded head x{world}"},
+                           f"drug-sharded encode+fuse, all-gather(z) over RCCL, outcome-sharded head x{world} ({main_mode} scaling)"},
+                "collective": h["collective"],
                 "roofline": roof}
+        if other is not None:
+            line[f"{other['mode']}_scaling"] = {"value": scores_per_s(other), "unit": "scores/s", "ms_per_step": other["dt"] / args.steps * 1e3,
+                                                "outcomes_per_gpu": other["Lr"], "outcomes_total": other["L_total"], "scaling": other["mode"],
+                                                "head_ms": other["head_ms"], "encode_fuse_ms": other["enc_ms"]}
+        if stress is not None:
+            line["roofline_cfg5"] = stress
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, L)
         if finetune is not None:
