@@ -266,3 +266,102 @@ def batch_to(batch: dict, device) -> dict:
         else:
             out[k] = v
     return out
+
+
+# ------------------------------------------------------------------------------------------- on-device batch bundle
+# The reference rebuilds its one full batch from pandas / torchdrug / PyG on every run (madrigal/data/data.py:828-974) and
+# pickles the whole HeteroData KG into every checkpoint (madrigal/utils.py:222-224).  A *bundle* is that batch as plain
+# tensors: built once -- from this module's containers or from the collator's own objects (duck-typed: nothing of
+# torchdrug / PyG is imported) -- saved with torch.save, loaded without either package.
+
+def as_molecule_batch(mols) -> MoleculeBatch:
+    """A packed molecule batch from anything that carries the fields of torchdrug's ``PackedMolecule`` the structure encoder
+    reads (madrigal/models/models.py:720-721): ``node_feature edge_list edge_feature node2graph`` and ``batch_size``
+    (or ``num_nodes``-per-graph, from which it is counted); ``edge_weight`` optional."""
+    if isinstance(mols, MoleculeBatch):
+        return mols
+    node2graph = torch.as_tensor(mols.node2graph).long()
+    batch_size = getattr(mols, "batch_size", None)
+    if batch_size is None:
+        per_graph = getattr(mols, "num_nodes", None)
+        batch_size = int(len(per_graph)) if per_graph is not None and hasattr(per_graph, "__len__") else int(node2graph.max()) + 1
+    ew = getattr(mols, "edge_weight", None)
+    return MoleculeBatch(torch.as_tensor(mols.node_feature).float(), torch.as_tensor(mols.edge_list).long(),
+                         torch.as_tensor(mols.edge_feature).float(), node2graph, int(batch_size),
+                         None if ew is None else torch.as_tensor(ew).float())
+
+
+def as_kg_data(kg) -> KGData:
+    """A :class:`KGData` from a PyG ``HeteroData`` (``x_dict``, ``edge_index_dict``, ``metadata()``), from the plain dict
+    a bundle / checkpoint stores, or from a :class:`KGData`."""
+    if isinstance(kg, KGData):
+        return kg
+    if isinstance(kg, dict):
+        return KGData({k: torch.as_tensor(v) for k, v in kg["x_dict"].items()},
+                      {tuple(k): torch.as_tensor(v).long() for k, v in kg["edge_index_dict"].items()},
+                      list(kg.get("node_types", [])), [tuple(e) for e in kg.get("edge_types", [])])
+    node_types, edge_types = kg.metadata()
+    return KGData({t: torch.as_tensor(kg.x_dict[t]) for t in node_types if t in kg.x_dict},
+                  {tuple(e): torch.as_tensor(kg.edge_index_dict[tuple(e)]).long() for e in edge_types if tuple(e) in kg.edge_index_dict},
+                  list(node_types), [tuple(e) for e in edge_types])
+
+
+def kg_to_plain(kg) -> dict:
+    """The KG as a dict of plain tensors and names (no custom class inside: loads anywhere with torch.load)."""
+    kg = as_kg_data(kg)
+    return {"x_dict": {k: v.detach().cpu() for k, v in kg.x_dict.items()},
+            "edge_index_dict": {tuple(k): v.detach().cpu() for k, v in kg.edge_index_dict.items()},
+            "node_types": list(kg.node_types), "edge_types": [tuple(e) for e in kg.edge_types]}
+
+
+def bundle_from_batch(batch: dict, batch_kg: dict, labels=None) -> dict:
+    """One side of the collator's output dict (``'drugs' 'strs' 'cv' 'tx' 'masks'``, data.py:948-964) + ``batch_kg``
+    (``'data' 'drug_index_map'``) (+ optionally the labelled triples ``(label, head, tail, pos_neg)``) -> plain tensors."""
+    mols = as_molecule_batch(batch["strs"])
+    tx = {}
+    for c in CELL_LINES:
+        v = batch["tx"][c]
+        names = np.asarray(v["cell_lines"]).astype(str)
+        tx[c] = {"sigs": torch.as_tensor(v["sigs"]).float().cpu(), "drugs": torch.as_tensor(v["drugs"]).long().cpu(),
+                 "dosages": torch.as_tensor(v["dosages"]).float().cpu(), "cell_lines": [str(x) for x in names]}
+    out = {"format": "madrigal_amd.bundle/1",
+           "drugs": torch.as_tensor(batch["drugs"]).long().cpu(), "masks": torch.as_tensor(batch["masks"]).bool().cpu(),
+           "cv": torch.as_tensor(batch["cv"]).float().cpu(), "tx": tx,
+           "strs": {"node_feature": mols.node_feature.cpu(), "edge_list": mols.edge_list.cpu(), "edge_feature": mols.edge_feature.cpu(),
+                    "node2graph": mols.node2graph.cpu(), "batch_size": int(mols.batch_size), "edge_weight": mols.edge_weight.cpu()},
+           "kg": kg_to_plain(batch_kg["data"]), "drug_index_map": torch.as_tensor(batch_kg["drug_index_map"]).long().cpu()}
+    if labels is not None:
+        lab, head, tail, y = labels
+        out["triples"] = {"label": torch.as_tensor(lab).long().cpu(), "head": torch.as_tensor(head).long().cpu(),
+                          "tail": torch.as_tensor(tail).long().cpu(), "pos_neg": torch.as_tensor(y).float().cpu()}
+    return out
+
+
+def batch_from_bundle(bundle: dict, device=None):
+    """-> ``(batch, batch_kg, triples | None)`` in the boundary's format (the inverse of :func:`bundle_from_batch`)."""
+    if bundle.get("format") != "madrigal_amd.bundle/1":
+        raise ValueError(f"not a madrigal_amd bundle: format={bundle.get('format')!r}")
+    s = bundle["strs"]
+    mols = MoleculeBatch(s["node_feature"], s["edge_list"], s["edge_feature"], s["node2graph"], int(s["batch_size"]), s["edge_weight"])
+    tx = {c: {"sigs": v["sigs"], "drugs": v["drugs"], "dosages": v["dosages"], "cell_lines": np.array(v["cell_lines"], dtype=np.str_)}
+          for c, v in bundle["tx"].items()}
+    batch = {"drugs": bundle["drugs"], "strs": mols, "cv": bundle["cv"], "tx": tx, "masks": bundle["masks"]}
+    bkg = {"data": as_kg_data(bundle["kg"]), "drug_index_map": bundle["drug_index_map"]}
+    trip = None
+    if "triples" in bundle:
+        t = bundle["triples"]
+        trip = (t["label"], t["head"], t["tail"], t["pos_neg"])
+    if device is not None:
+        batch = batch_to(batch, device)
+        bkg = {"data": bkg["data"].to(device), "drug_index_map": bkg["drug_index_map"].to(device)}
+        trip = None if trip is None else tuple(x.to(device) for x in trip)
+    return batch, bkg, trip
+
+
+def save_bundle(path: str, batch: dict, batch_kg: dict, labels=None) -> None:
+    torch.save(bundle_from_batch(batch, batch_kg, labels), path)
+
+
+def load_bundle(path: str, device=None):
+    """Plain tensors, lists and strings only: loads with ``weights_only=True`` (no pickle code execution)."""
+    return batch_from_bundle(torch.load(path, map_location="cpu", weights_only=True), device)

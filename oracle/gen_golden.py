@@ -420,6 +420,38 @@ def gen_simclr_raw(M, S, C):
     save("simclr_raw", **out)
 
 
+def gen_checkpoint_fixtures(ref_root, M, S, C):
+    """(i) The CL -> finetune key filter: the reference's own loop (madrigal/utils.py:281-295 -- inline code of get_model, taken
+    from the file text at generation time like gen_ranks; nothing of it is stored) applied to the key list of its own
+    SimCLR_NovelDDI state_dict (+ the optional entries the loop names).  (ii) Parameter names and shapes -- no values -- of the
+    two weight files the reference ships (modality_pretraining/str/GIN_256x4_muv.pt, cv/cv_model_ae.pt)."""
+    import textwrap
+    src = open(os.path.join(ref_root, "madrigal", "utils.py")).read().splitlines()
+    start = next(i for i, l in enumerate(src) if l.strip() == "for k in list(state_dict.keys()):")
+    end = next(i for i in range(start, len(src)) if src[i].strip() == "del state_dict[k]")
+    loop = textwrap.dedent("\n".join(src[start:end + 1]))
+    batch, bkg = D.make_batch(12, 3, kg_nodes=200, kg_edges=900)
+    out = {}
+    for shared in (False, True):
+        enc = build_reference_model(M, C, bkg["data"], CL_CASE, 4, 3).encoder
+        model = S.SimCLR_NovelDDI(enc, dim=128, mlp_dim=512, T=0.1, raw_encoder_output=True, shared_predictor=shared)
+        keys = list(model.state_dict().keys()) + ["base_encoder.cls", "base_encoder.head.weight", "base_encoder.head.bias"]
+        for adaptor in (False, True):
+            ns = {"state_dict": {k: k for k in keys}, "use_pretrained_adaptor": adaptor}
+            exec(loop, ns)
+            out[f"s{int(shared)}a{int(adaptor)}_out"] = np.array(sorted(ns["state_dict"].keys()))
+            out[f"s{int(shared)}a{int(adaptor)}_src"] = np.array([ns["state_dict"][k] for k in sorted(ns["state_dict"].keys())])
+        out[f"s{int(shared)}_in"] = np.array(keys)
+    save("ckpt_filter", **out)
+    lay = {}
+    for name, rel in (("gin", "modality_pretraining/str/GIN_256x4_muv.pt"), ("cv", "modality_pretraining/cv/cv_model_ae.pt")):
+        sd = torch.load(os.path.join(ref_root, rel), map_location="cpu", weights_only=True)
+        lay[name + "_keys"] = np.array(list(sd.keys()))
+        lay[name + "_shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
+        lay[name + "_dtypes"] = np.array([str(v.dtype) for v in sd.values()])
+    save("pretrained_layouts", **lay)
+
+
 def gen_ranks(ref_root):
     # notebooks/normalize_scores.py runs file I/O at import (:26); take the pure-numpy function from the
     # file text at generation time (nothing of it is stored).
@@ -517,7 +549,8 @@ def main():
     groups = {
         "head": lambda: gen_head(M), "mlps": lambda: gen_mlps(M), "posenc": lambda: gen_posenc(M), "fusion": lambda: gen_fusion(M),
         "chemcpa": lambda: gen_chemcpa(C), "encode": lambda: gen_encode(M, C), "infonce": lambda: gen_infonce(M, S),
-        "pretrain_views": gen_pretrain_views, "simclr_raw": lambda: gen_simclr_raw(M, S, C), "ranks": lambda: gen_ranks(args.ref),
+        "pretrain_views": gen_pretrain_views, "simclr_raw": lambda: gen_simclr_raw(M, S, C),
+        "checkpoints": lambda: gen_checkpoint_fixtures(args.ref, M, S, C), "ranks": lambda: gen_ranks(args.ref),
         "bce": gen_bce, "eval_masks": gen_eval_masks_and_schedule, "param_groups": lambda: gen_param_groups(M, C),
     }
     only = [g for g in args.only.split(",") if g]
