@@ -107,9 +107,53 @@ def pmc_traffic(n_drugs: int, n_outcomes: int, precision: str):
     return None, None
 
 
-def cpu_baseline(n_drugs: int, n_outcomes: int, seconds: float = 12.0):
-    """The oracle's bilinear head (same torch ops as the reference's CPU path,
-    madrigal/models/models.py:539) on a bounded row sample of the same workload."""
+ORACLE_CASE = {   # name, fusion, nb, pos, heads, head_dim, ffn, layers, norm_first, agg, normalize, adapt  (configs.SHIPPED restated)
+    "twosides321": ("twosides321", "transformer_uni_proj", 2, "sinusoidal", 8, 256, 1024, 2, True, "x-attn", False, False),
+    "twosides105": ("twosides105", "transformer", 2, "learnable", 2, 256, 512, 2, True, "x-attn", False, False),
+    "drugbank163": ("drugbank163", "transformer", 4, "sinusoidal", 8, 64, 256, 2, True, "x-attn", False, False),
+}
+
+
+def cpu_encode_fuse(params, batch, bkg, config: str, sample: int = 256):
+    """The oracle's encode+fuse (eval mode; same stages as NovelDDIEncoder.encode, madrigal/models/models.py:717-896) timed on
+    the host: the KG encoder once on the WHOLE graph (it is per graph, not per drug), the per-drug stages (GIN, cv MLP,
+    chemCPA tx encoder, token assembly + fusion transformer) on the first ``sample`` drugs and scaled linearly to N."""
+    import torch
+    from madrigal_amd import data as D
+    from madrigal_amd.pipeline import slice_batch
+    from oracle import madrigal_oracle as O
+    case = ORACLE_CASE[config]
+    name, fusion, nb, pos, H, dh, ffn, nl, nf, agg, normalize, adapt = case
+    enc = O._sub(params, "encoder.")
+    kg = bkg["data"]
+    N = int(batch["drugs"].shape[0])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.hgt_forward(O._sub(enc, "kg_encoder."), kg.x_dict, kg.edge_index_dict, kg.node_types, kg.edge_types, num_layers=2, heads=4, hidden=128)
+        t_kg = time.perf_counter() - t0
+        n = min(sample, N)
+        b = slice_batch(batch, 0, n)
+        mols = b["strs"]
+        t0 = time.perf_counter()
+        str_out = O.gin_forward(O._sub(enc, "str_encoder."), mols.node_feature, mols.edge_list, mols.edge_feature, mols.node2graph,
+                                mols.batch_size, num_layers=4, num_mlp_layer=3)["graph_feature"]
+        cv_out = O.mlp_encoder_forward(O._sub(enc, "cv_encoder."), b["cv"], 2, None, "relu", 0.2)
+        sigs = torch.cat([b["tx"][c]["sigs"] for c in D.CELL_LINES])
+        _, _, _, treated = O.chemcpa_predict(O._sub(enc, "tx_encoder."), sigs, torch.arange(16).repeat_interleave(n), 3, 3, with_decoder=False)
+        all_embeds = torch.stack([str_out, torch.zeros_like(str_out), cv_out] + list(treated.split(n)), dim=1)
+        if pos == "sinusoidal":
+            enc["pos_encoder.pe"] = O.sinusoidal_pe_table(128, (D.NUM_MODALITIES if nb == 0 else D.NUM_NON_TX_MODALITIES), nb, agg)
+        cfg = dict(fusion=fusion, normalize=normalize, adapt_before_fusion=adapt, pos_emb_type=pos, num_tx_bottlenecks=nb, agg=agg,
+                   num_layers=nl, num_heads=H, norm_first=nf, actn="gelu", proj=dict(n_hidden=2, norm="ln", actn="relu", dropout=0.2, order="nd"))
+        O.fuse_modalities(enc, all_embeds, b["masks"], cfg)
+        t_drug = time.perf_counter() - t0
+    return {"kg_encoder_s": t_kg, "per_drug_stages_s_on_sample": t_drug, "sample_drugs": n, "encode_fuse_s_extrapolated": t_kg + t_drug * N / n}
+
+
+def cpu_baseline(n_drugs: int, n_outcomes: int, seconds: float = 12.0, encode=None):
+    """The oracle (CPU restatement of the reference path, pinned to the reference by tests/golden) timed on the host cores on a
+    bounded sample of the same workload: the bilinear head (same torch ops as madrigal/models/models.py:539) on a block of
+    head rows against all tail drugs and outcomes, and -- ``encode`` = (params, batch, bkg, config) -- encode+fuse."""
     import torch
     from oracle import madrigal_oracle as O
     cores = os.cpu_count() or 1
@@ -129,10 +173,20 @@ def cpu_baseline(n_drugs: int, n_outcomes: int, seconds: float = 12.0):
         O.bilinear_scores(z[:rows], z, w)
         times.append(time.perf_counter() - t0)
     med = sorted(times)[1]
-    return {"value": rows * n_drugs * n_outcomes / med, "unit": "scores/s", "cores": cores, "kind": "port",
-            "sample": f"oracle bilinear_scores (the scoring stage only: encode is amortised over N^2 L scores) on {rows} head "
-                      f"rows x {n_drugs} tail drugs x {n_outcomes} outcomes, fp32 torch CPU, {cores} threads, median of 3, "
-                      f"extrapolated linearly in rows"}
+    head_rate = rows * n_drugs * n_outcomes / med
+    out = {"value": head_rate, "unit": "scores/s", "cores": cores, "kind": "port", "head_only_scores_per_s": head_rate,
+           "sample": f"oracle bilinear_scores on {rows} head rows x {n_drugs} tail drugs x {n_outcomes} outcomes, fp32 torch CPU, "
+                     f"{cores} threads, median of 3, extrapolated linearly in rows"}
+    if encode is not None:
+        try:
+            e = cpu_encode_fuse(*encode)
+            total = float(n_drugs) * n_drugs * n_outcomes
+            out.update(encode_fuse=e, value=total / (total / head_rate + e["encode_fuse_s_extrapolated"]))
+            out["sample"] += (f"; + oracle encode+fuse: HGT over the whole KG once ({e['kg_encoder_s']:.2f} s), GIN / cv / chemCPA / fusion on "
+                              f"{e['sample_drugs']} drugs scaled to {n_drugs}; value = whole job (encode+fuse + all scores) per second")
+        except Exception as ex:
+            out["encode_fuse"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    return out
 
 
 def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend="nccl"):
@@ -232,12 +286,13 @@ def main():
 
     N, L = args.drugs, args.outcomes
     M.set_precision(args.precision)
-    model = batch = bkg = filler = None
+    model = batch = bkg = filler = cpu_inputs = None
     if not args.head_only:
         # same synthetic batch on every rank (seeded); each rank encodes only its drug block
         batch, bkg = D.make_batch(N, 0, kg_nodes=args.kg_nodes, kg_edges=args.kg_edges)
         torch.manual_seed(1234)                       # identical encoder weights on every rank
         model = configs.build_model(args.config, bkg["data"], L).to(dev).eval()
+        cpu_inputs = ({k: v.detach().cpu() for k, v in model.state_dict().items()}, batch, bkg, args.config) if (world == 1 and not args.no_cpu_baseline) else None
         batch = D.batch_to(batch, dev)
         bkg = {"data": bkg["data"].to(dev), "drug_index_map": bkg["drug_index_map"].to(dev)}
         filler = torch.randn(N, 128, device=dev, generator=torch.Generator(device=dev).manual_seed(5))   # drugs absent from the KG (always masked)
@@ -381,7 +436,7 @@ def main():
         if stress is not None:
             line["roofline_cfg5"] = stress
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(N, L)
+            line["cpu_baseline"] = cpu_baseline(N, L, encode=cpu_inputs)
         if finetune is not None:
             line["finetune"] = finetune
         print(json.dumps(line))

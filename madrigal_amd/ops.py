@@ -459,6 +459,14 @@ def gather_bce(scores: torch.Tensor, labels: torch.Tensor, heads: torch.Tensor, 
     for nm, t in (("labels", labels), ("heads", heads), ("tails", tails)):
         if t.dtype != torch.int64 or not t.is_cuda or t.numel() != n:
             raise ValueError(f"{nm}: expected int64 cuda [{n}]")
+    if n:
+        # torch's advanced indexing (train_ddi_batch.py:286) raises on an index outside the tensor; the kernel would read out of
+        # bounds instead, so the ranges are checked here (one small reduction + host read per call; negative indices, which
+        # torch would wrap around, never occur in the collator's triples and are refused as well)
+        lim = torch.stack([labels.min(), labels.max(), heads.min(), heads.max(), tails.min(), tails.max()]).tolist()
+        for (lo, hi), size, nm in zip(((lim[0], lim[1]), (lim[2], lim[3]), (lim[4], lim[5])), s.shape, ("labels", "heads", "tails")):
+            if lo < 0 or hi >= size:
+                raise IndexError(f"{nm}: index {lo if lo < 0 else hi} is out of bounds for dimension of size {size}")
     pred = torch.empty(n, dtype=torch.float32, device=s.device)
     term = loss = None
     if target is not None:

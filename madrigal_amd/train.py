@@ -16,6 +16,21 @@ from .parallel import all_gather_rows_grad, all_reduce_sum_, allreduce_gradients
 from .pipeline import slice_batch
 
 
+def _refuse_rank_local_batchnorm(encoder, world: int) -> None:
+    """Data-parallel steps synchronise BatchNorm statistics with collectives issued from inside the BatchNorm nodes, so every
+    rank must run every BatchNorm-bearing module the same number of times.  GIN and the chemCPA encoder always run (every
+    rank owns at least one drug, and training encodes every (drug, cell line) row); the uni-modal projector / fuser run only
+    on ranks whose drug block has uni-modal rows (models.py:855-865) -- with ``proj_norm='bn'`` a rank without such rows
+    would skip collectives the others issue (a hang under RCCL).  The shipped configs use LayerNorm there; 'bn' is refused."""
+    if world <= 1:
+        return
+    for name in ("uni_projector", "uni_fuser"):
+        mod = getattr(encoder, name, None)
+        if mod is not None and any(isinstance(m, torch.nn.BatchNorm1d) for m in mod.modules()):
+            raise NotImplementedError(f"data-parallel training with BatchNorm inside encoder.{name} (proj_norm='bn'): the module runs on a "
+                                      "data-dependent subset of the ranks, which would mismatch the SyncBatchNorm collectives")
+
+
 class FinetuneStep:
     """``step(...)`` = one optimizer step of the reference's 'full_full' / 'double_random' modes;
     ``accumulate(...)`` = one ``loss.backward()`` of the multi-pass modes (call it per mask pair, then ``apply()``)."""
@@ -28,6 +43,7 @@ class FinetuneStep:
         for the gathered head, and the parameter gradients are summed in flat buckets before the identical AdamW update."""
         self.model, self.optimizer, self.loss_readout, self.scheduler = model, optimizer, loss_readout, scheduler
         self.rank, self.world, self.group = rank, world, group
+        _refuse_rank_local_batchnorm(model.encoder, world)
         self._plan_key = None
         self._plan = None
         self._shards = {}               # side ('head' | 'tail') -> (key, sliced batch, the batch itself): ONE entry per side
@@ -124,6 +140,7 @@ class PretrainStep:
 
     def __init__(self, model, optimizer, rank: int = 0, world: int = 1, group=None):
         self.model, self.optimizer, self.rank, self.world, self.group = model, optimizer, rank, world, group
+        _refuse_rank_local_batchnorm(model.base_encoder, world)
         self._last = None               # (key, sliced batch, batch_data): the slice of the LAST batch only (a DataLoader
         #                                 hands over a fresh batch every iteration: nothing may accumulate here)
 

@@ -176,3 +176,19 @@ def test_bundle_round_trip_and_duck_typed_sources(small, tmp_path):
     assert ck.metadata() == kg.metadata() and all(torch.equal(ck.edge_index_dict[e], kg.edge_index_dict[e]) for e in kg.edge_types)
     with pytest.raises(ValueError):
         D.batch_from_bundle({"format": "something else"})
+
+
+def test_data_parallel_steps_refuse_rank_local_batchnorm(small):
+    """proj_norm='bn' puts a BatchNorm inside modules that only ranks WITH uni-modal drugs would run: under SyncBatchNorm that
+    is a collective mismatch, so the data-parallel steps refuse it up front (the single-process steps accept it)."""
+    from madrigal_amd.train import FinetuneStep, PretrainStep
+    batch, bkg = small
+    model, _ = _build(bkg["data"], proj_hparams=dict(configs.PROJ, proj_norm="bn"))
+    FinetuneStep(model, optimizer=None)
+    with pytest.raises(NotImplementedError, match="proj_norm"):
+        FinetuneStep(model, optimizer=None, rank=0, world=2)
+    sim = SimCLR_NovelDDI(model.encoder, dim=128, mlp_dim=64)
+    with pytest.raises(NotImplementedError, match="proj_norm"):
+        PretrainStep(sim, optimizer=None, rank=1, world=2)
+    ok, _ = _build(bkg["data"])
+    FinetuneStep(ok, optimizer=None, rank=0, world=2)

@@ -66,6 +66,11 @@ def test_gather_bce_golden(ops, golden):
     z = torch.zeros(1, dtype=torch.int64, device="cuda")
     _, l = ops.gather_bce(big, z, z, z, torch.zeros(1, device="cuda"))
     assert float(l) == 100.0
+    # an index outside the score tensor raises, as the reference's advanced indexing does (it is never read on the device)
+    for bad in ((1, 0, 0), (0, 2, 0), (0, 0, 2), (-1, 0, 0)):
+        idx = [torch.tensor([v], dtype=torch.int64, device="cuda") for v in bad]
+        with pytest.raises(IndexError):
+            ops.gather_bce(big, *idx, torch.zeros(1, device="cuda"))
 
 
 def test_ranks_golden_bit_exact(ops, golden):

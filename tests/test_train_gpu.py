@@ -973,6 +973,97 @@ def test_one_adamw_step_matches_oracle_autograd_plus_torch_adamw():
     assert exact_n > 0.8 * moved, (exact_n, moved)       # the rest sits within 2e-3 of the step (asserted per tensor above)
 
 
+def test_three_adamw_steps_match_oracle_autograd_plus_torch_adamw():
+    """SURVEY 8a H1 (iii) beyond the first step.  Adam's first step is -lr * g / (|g| + eps), blind to the gradient's size;
+    from the second step on the update is lr * m_hat / (sqrt(v_hat) + eps) with moments mixed over steps, so the parameter
+    deltas depend on the gradient MAGNITUDES of every step.  Three optimizer steps of the whole model (exact-fp32 products:
+    a ReLU derivative flips only where a pre-activation sits within fp32 rounding of zero) against three steps of torch
+    autograd over the CPU oracle + torch.optim.AdamW over the reference's parameter groups: per tensor, on the entries whose
+    reference gradient is clear of noise in all three steps, the total deltas agree to 1e-5 of the tensor's largest delta
+    (SURVEY: "parameter deltas within 1e-5 rel")."""
+    from madrigal_amd import data as D, models as M
+    from madrigal_amd.optim import create_optimizer
+    from madrigal_amd.train import FinetuneStep
+    from helpers import oracle_pipeline
+    case = ("drugbank163", "transformer", 4, "learnable", 8, 64, 256, 2, True, "x-attn", True, False)
+    n, L, seed, steps = 96, 24, 31, 3
+    hp = dict(optimizer="adamw", structure_encoder_lr=3e-4, kg_encoder_lr=2e-4, perturb_encoders_lr=1e-4, fusion_lr=5e-5, decoder_lr=1e-3,
+              wd=1e-2, beta1=0.9, beta2=0.999, eps=1e-8)
+    model, _, batch, bkg, masks = _small_model(M, case, n, L, seed, default_init=True)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    filler = torch.randn(n, 128, generator=torch.Generator().manual_seed(1))
+    lab, hd, tl, y = D.make_labelled_triples(n, L, 700, seed)
+    model = model.cuda().eval()
+    frozen = set()
+    for name, mod in model.named_modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            for pn, q in mod.named_parameters():
+                q.requires_grad_(False)
+                frozen.add(f"{name}.{pn}")
+    opt = create_optimizer(model, hp)
+    group_of = {id(q): gi for gi, g in enumerate(opt.param_groups) for q in g["params"]}
+    named = dict(model.named_parameters())
+    frozen |= {k for k, q in named.items() if id(q) not in group_of}
+    pr = {k: (v.clone().requires_grad_(k in named and k not in frozen) if v.dtype.is_floating_point else v) for k, v in p.items()}
+    groups = [{"params": [], "lr": g["lr"], "weight_decay": g["weight_decay"]} for g in opt.param_groups]
+    for k, q in named.items():
+        if k not in frozen:
+            groups[group_of[id(q)]]["params"].append(pr[k])
+    ropt = torch.optim.AdamW([g for g in groups if g["params"]], betas=(hp["beta1"], hp["beta2"]), eps=hp["eps"])
+    before = {k: v.detach().clone() for k, v in pr.items() if k in named}
+    solid = {}
+    ref_losses = []
+    for it in range(steps):
+        ropt.zero_grad(set_to_none=True)
+        ref = oracle_pipeline(case, dict(pr), batch, bkg, masks, filler)
+        loss_r = torch.nn.BCELoss()(torch.sigmoid(ref["scores"])[lab, hd, tl], y)
+        loss_r.backward()
+        ref_losses.append(float(loss_r.detach()))
+        for k in named:
+            if k in frozen:
+                continue
+            if pr[k].grad is None:                        # torch.optim skips grad=None: zero gradients keep the step counts aligned
+                pr[k].grad = torch.zeros_like(pr[k])
+            g = pr[k].grad.abs()
+            ok = (g > 1e-2 * max(float(g.max()), 1e-12)) & (g > 1e3 * hp["eps"])
+            solid[k] = ok if it == 0 else (solid[k] & ok)
+        ropt.step()
+    b = D.batch_to(batch, "cuda")
+    kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
+    fs = FinetuneStep(model, opt)
+    losses = []
+    with M.precision("f32"):
+        for it in range(steps):
+            opt.zero_grad(set_to_none=True)
+            losses.append(float(fs.accumulate(b, b, b["masks"], b["masks"], kgc, lab.cuda(), hd.cuda(), tl.cuda(), y.cuda(), kg_filler=filler.cuda())))
+            fs.apply()
+    for a, r in zip(losses, ref_losses):
+        assert abs(a - r) < 1e-5 * abs(r), (losses, ref_losses)          # BCE loss value: SURVEY H1 (ii), at every step
+    assert ref_losses[2] < ref_losses[0]
+    checked = n_solid = 0
+    worst, errs = (0.0, ""), []
+    for k, q in named.items():
+        if k in frozen:
+            assert torch.equal(q.detach().cpu(), before[k]), k
+            continue
+        d_gpu = q.detach().cpu().double() - before[k].double()
+        d_ref = pr[k].detach().double() - before[k].double()
+        m = solid[k]
+        if not bool(m.any()):
+            continue
+        scale = float(d_ref[m].abs().max())
+        e = (d_gpu - d_ref)[m].abs() / scale
+        errs.append(e)
+        worst = max(worst, (float(e.max()), k))
+        n_solid += int(m.sum())
+        checked += 1
+    errs = torch.cat(errs)
+    assert checked > 100 and n_solid > 200_000, (checked, n_solid)
+    q999 = float(torch.quantile(errs[torch.randperm(errs.numel())[:2_000_000]], 0.999))
+    assert q999 < 1e-5, (q999, worst)                    # 99.9 % of the well-conditioned entries: 1e-5 of the tensor's delta scale
+    assert worst[0] < 2e-3, worst                        # the rest: a ReLU flipped at rounding distance in GIN / cv MLP / chemCPA
+
+
 # ---------------------------------------------------------------------------------------------- dense head, drop-in loop
 @pytest.mark.parametrize("L,Nh,Nt,same", [(3, 5, 7, False), (6, 70, 70, True), (17, 130, 61, False)])
 def test_dense_head_is_differentiable_like_the_reference_loop(L, Nh, Nt, same):
