@@ -46,6 +46,7 @@ struct BilinearArgs {
   int stagger_waves;    // counted pipeline: younger half of the waves stores one stage late
   int loaders;          // conservative pipeline: waves that issue the LDS-DMA (1, 2 or 4)
   int pipeline;         // 0 = counted waits (default), 1 = conservative
+  int symmetric;        // z_head and z_tail are the same matrix (same pointer, same row count)
   unsigned long long* stamps;   // diagnostics only (MDG_BILINEAR_STAMPS): per workgroup {shader cycles, 100 MHz ticks} of the sweep
 };
 
@@ -685,6 +686,170 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
   }
 }
 
+// ---- symmetric sweep: z_head and z_tail are the SAME matrix ------------------------------------------------------
+// All-pairs scoring of one drug set (generate_embeddings.ipynb / predict.py:428 call decoder(z, z, ...)): W_sym is
+// symmetric, so S[l,i,j] = S[l,j,i] up to fp32 rounding of the two association orders (z_i W) z_j and (z_j W) z_i.
+// The kernel is bound by the card's power envelope, not by the store stream (MI355X holds 1.40 GHz under the full
+// bf16x3 sweep, 1.74 GHz with half the matrix work: DESIGN.md 4), so the matrix work is halved: only tiles on or right
+// of the block diagonal are computed; an off-diagonal tile is stored twice, as computed and transposed.  The 256 x 256
+// blocks ON the diagonal are computed in full (both triangles, as the general kernel does).
+// Work split: row block a does nb - a column blocks, so workgroup x handles the pair of row blocks (x, nb-1-x), one after
+// the other: every workgroup sweeps nb + 1 column blocks.  Stores: the wave's 32 x 64 tile goes through its 8 KB LDS slab
+// twice -- column-major (8 x ds_write_b128) to leave as 64 rows x 128 B of the mirrored block, then row-major
+// (32 x ds_write_b32) to leave as 32 rows x 256 B -- always as 16-byte-per-lane stores of whole 128-byte lines.
+template <int MODE, int EPI, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_sym_kernel(const BilinearArgs p) {
+  static_assert(NW == 8, "256-row blocks: 8 waves of 32 rows");
+  static_assert(EPI == MDG_EPI_STORE || EPI == MDG_EPI_STORE_SIGMOID, "materialising epilogues only");
+  constexpr int BM = 32 * NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const buf0 = smem;
+  char* const buf1 = smem + STAGE_BYTES;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  char* const stg = smem + 2 * STAGE_BYTES + wave * 8192;
+  const int64_t l = blockIdx.y, N = p.n_tail;
+  const int nst = static_cast<int>((N + BN - 1) / BN);
+  const int nb = static_cast<int>((N + BM - 1) / BM);
+  const int srow = lane >> 4, scol = 4 * (lane & 15);            // row-major store role: row in a group of 4, first of 4 columns
+  const int mrow = lane >> 3, mchunk = lane & 7;                 // mirrored store role: tile column in a group of 8, 16-B chunk of 32 rows
+  float* const out_l = p.out + l * N * N;
+  // whole [N,N] slab of this outcome (N * N * 4 < 2^32 is checked by the launcher): the mirrored stores land anywhere in it
+  const __amdgpu_buffer_rsrc_t rs_all = __builtin_amdgcn_make_buffer_rsrc(out_l, 0, static_cast<int>(static_cast<unsigned>(N * N * 4)), 0x00020000);
+  auto sig = [&](u32x4 v) {
+    if constexpr (EPI == MDG_EPI_STORE_SIGMOID) {
+      const f32x4 x = __builtin_bit_cast(f32x4, v);
+      f32x4 y;
+      y[0] = 1.0f / (1.0f + expf(-x[0])); y[1] = 1.0f / (1.0f + expf(-x[1]));
+      y[2] = 1.0f / (1.0f + expf(-x[2])); y[3] = 1.0f / (1.0f + expf(-x[3]));
+      return __builtin_bit_cast(u32x4, y);
+    } else {
+      return v;
+    }
+  };
+  unsigned long long stamp_c = 0, stamp_r = 0;
+  if (p.stamps && tid == 0) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
+
+  for (int half = 0; half < 2; ++half) {
+    const int rbk = half == 0 ? static_cast<int>(blockIdx.x) : nb - 1 - static_cast<int>(blockIdx.x);
+    if (half == 1 && rbk == static_cast<int>(blockIdx.x)) break;          // odd number of row blocks: the middle one once
+    const int64_t row0 = static_cast<int64_t>(rbk) * BM;
+    // ---- prologue: T = z[rows] . W_sym[l] as the A operand (same arithmetic as the general kernel) ----
+    AFrag<MODE> At;
+    {
+      AFrag<MODE> Az;
+      int64_t zr = row0 + wave * 32 + r;
+      zr = zr < N ? zr : N - 1;
+      afrag_from_global<MODE>(Az, p.z_head + zr * D, h);
+      TileSrc ws = p.w;
+      if constexpr (MODE == MDG_PREC_F32) ws.f32 += l * D * D;
+      else { ws.hi += l * D * D; if constexpr (MODE == MDG_PREC_BF16X3) ws.lo += l * D * D; }
+      char* const slab = smem + wave * 8192;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        u32x4 regs[32 / NW];
+        stage_load<MODE, NW>(ws, 64 * st, tid, regs);
+        __syncthreads();
+        stage_write<MODE, NW>(buf0, tid, regs);
+        __syncthreads();
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        compute_tile<MODE>(Az, buf0, r, h, acc);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int row = acc_row(v, h), n = 32 * t + r;
+            *reinterpret_cast<float*>(slab + tile_off<256>(row, n >> 2) + (n & 3) * 4) = acc[t][v];
+          }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        afrag_from_slab<MODE>(At, slab, st, r, h);
+      }
+      __syncthreads();
+    }
+    // ---- sweep: column tiles t0 .. nst-1 (the diagonal block first), rotated per workgroup (HBM channel spreading) ----
+    const int t0 = rbk * (BM / BN);
+    const int t_diag_end = t0 + BM / BN;                            // tiles below this index lie inside the diagonal block
+    const int nt = nst - t0;
+    const int start = p.stagger ? static_cast<int>((blockIdx.x * 5u + blockIdx.y * 3u) % static_cast<unsigned>(nt)) : 0;
+    auto tile_of = [&](int s) { int t = s + start; return t0 + (t >= nt ? t - nt : t); };
+    const int64_t slab_rows = (N - row0) < BM ? (N - row0) : BM;
+    const __amdgpu_buffer_rsrc_t rs_rows = __builtin_amdgcn_make_buffer_rsrc(out_l + row0 * N, 0, static_cast<int>(slab_rows * N * 4), 0x00020000);
+    u32x4 o[8];
+    auto store_rows = [&](int q, int64_t col0) {                      // rows 4q..4q+3 of the wave's tile: 4 x 256 B
+      const int64_t col = col0 + scol;
+      const int64_t e = static_cast<int64_t>(wave * 32 + 4 * q + srow) * N + col;
+      const unsigned off = col < N ? static_cast<unsigned>(e * 4) : 0xFFFFFFFFu;              // out of range => dropped
+      __builtin_amdgcn_raw_buffer_store_b128(sig(o[q]), rs_rows, off, 0, 0);
+    };
+    auto store_mirror = [&](int q, int64_t col0, bool on) {           // tile columns 8q..8q+7 as rows of the mirrored block: 8 x 128 B
+      const int64_t mr = col0 + 8 * q + mrow, mc = row0 + wave * 32 + 4 * mchunk;
+      const unsigned off = (on && mr < N && mc < N) ? static_cast<unsigned>((mr * N + mc) * 4) : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_buffer_store_b128(sig(o[q]), rs_all, off, 0, 0);
+    };
+    stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, buf0, wave, lane, NW);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int64_t prev_col0 = N;                                            // first stage: the slab is empty, 8 dropped stores
+    // Per stage and wave the vector-memory stream is [LDS-DMA of tile s+1][8 row stores of tile s-1][8 mirrored stores of
+    // tile s]: `s_waitcnt vmcnt(16)` at the top of the next stage retires the DMA and leaves 16 stores in flight (loads,
+    // stores -- dropped ones included -- and LDS-DMA retire in issue order; exactly 16 stores per wave and stage).
+    for (int s = 0; s < nt; ++s) {
+      const int tile = tile_of(s);
+      const int64_t tcol0 = static_cast<int64_t>(tile) * BN;
+      char* const cur = (s & 1) ? buf1 : buf0;
+      char* const nxt = (s & 1) ? buf0 : buf1;
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(s + 1 < nt ? s + 1 : s)) * BN, nxt, wave, lane, NW);
+      f32x16 acc[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+      const int64_t pc0 = prev_col0;
+      compute_tile_spread<MODE>(At, cur, r, h, acc, [&](int k) {
+        if (k < 8) o[k] = *reinterpret_cast<const u32x4*>(stg + (4 * k + srow) * 256 + scol * 4);
+        else if (k >= 16 && (k & 1) == 0) store_rows((k - 16) >> 1, pc0);
+      });
+      // tile s, column-major ([64 columns][32 rows]): a lane's 4 consecutive rows of one column are 16 contiguous bytes
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v4 = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(stg + (32 * t + r) * 128 + (8 * g + 4 * h) * 4) = v4;
+        }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = *reinterpret_cast<const u32x4*>(stg + (8 * q + mrow) * 128 + mchunk * 16);
+      const bool mirror = tile >= t_diag_end;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) store_mirror(q, tcol0, mirror);
+      // tile s, row-major, for the row stores of the next stage (the reads above are older LDS operations of this wave)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+          *reinterpret_cast<float*>(stg + acc_row(v, h) * 256 + (32 * t + r) * 4) = acc[t][v];
+      prev_col0 = tcol0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = *reinterpret_cast<const u32x4*>(stg + (4 * q + srow) * 256 + scol * 4);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) store_rows(q, prev_col0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                  // the next row block's prologue reuses the stage buffers
+  }
+  if (p.stamps && tid == 0) {
+    const size_t wg = static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x;
+    p.stamps[2 * wg] = __builtin_amdgcn_s_memtime() - stamp_c;
+    p.stamps[2 * wg + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r;
+  }
+}
+
 // ---- pre-passes ---------------------------------------------------------------------------
 __global__ void symmetrize_kernel(const float* __restrict__ w, float* __restrict__ ws, int64_t L, int D_) {
   const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -739,6 +904,23 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
   if (variant < 0 || variant > 2 || a.pipeline != 0) variant = 0;
   if (variant == 2 && ((a.n_tail & 3) != 0 || !mdg_aligned16(a.out))) variant = 0;     // 16-byte stores need aligned rows
   const size_t lds2 = lds + static_cast<size_t>(NW) * 8192;
+  // Symmetric sweep (z_head and z_tail are the same matrix): half the matrix work, every off-diagonal tile stored twice.
+  // Default for that case; MDG_BILINEAR_SYMMETRIC=0 switches it off.
+  if constexpr (NW == 8) {
+    const char* se = getenv("MDG_BILINEAR_SYMMETRIC");
+    const bool want = se ? atoi(se) != 0 : true;
+    if (want && a.symmetric && a.pipeline == 0 && (epilogue == MDG_EPI_STORE || epilogue == MDG_EPI_STORE_SIGMOID) && (a.n_tail & 3) == 0 &&
+        mdg_aligned16(a.out) && a.n_tail * a.n_tail * 4 < (int64_t(1) << 32) && a.n_tail > 256) {
+      const int nb = static_cast<int>(mdg_cdiv(a.n_tail, 256));
+      const dim3 gsym(static_cast<unsigned>((nb + 1) / 2), static_cast<unsigned>(a.n_labels));
+      if (epilogue == MDG_EPI_STORE)
+        hipLaunchKernelGGL((bilinear_allpairs_sym_kernel<MODE, MDG_EPI_STORE, 8>), gsym, block, lds2, st, a);
+      else
+        hipLaunchKernelGGL((bilinear_allpairs_sym_kernel<MODE, MDG_EPI_STORE_SIGMOID, 8>), gsym, block, lds2, st, a);
+      MDG_CHECK_LAUNCH("mdg_bilinear_allpairs(symmetric)");
+      return MDG_OK;
+    }
+  }
   switch (epilogue) {
     case MDG_EPI_STORE:
       if (variant == 2)
@@ -825,6 +1007,7 @@ extern "C" int mdg_bilinear_allpairs(const float* z_head, const float* z_tail, c
   a.out = out;
   a.n_head = n_head; a.n_tail = n_tail; a.n_labels = n_labels;
   a.zt.nrows = n_tail;
+  a.symmetric = (z_head == z_tail && n_head == n_tail) ? 1 : 0;
   a.stagger = 1;
   a.stagger_waves = 1;
   a.loaders = 4;

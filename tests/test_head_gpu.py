@@ -114,6 +114,38 @@ def test_store_schedules_write_identical_bits(ops, monkeypatch, nh, nt):
     assert torch.equal(view, ops.bilinear_allpairs(zh, zt, w, precision="bf16x3")) and bool(torch.isnan(buf[0]))
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16", "f16"])
+@pytest.mark.parametrize("N,L", [(1024, 3), (1000, 2), (516, 2), (2304, 1)])
+def test_symmetric_sweep_for_one_drug_set(ops, monkeypatch, prec, N, L):
+    """decoder(z, z, ...) (predict.py:428): the same matrix on both sides runs the symmetric sweep -- tiles on / right of the
+    block diagonal computed, every off-diagonal tile stored twice.  Against the general kernel (MDG_BILINEAR_SYMMETRIC=0):
+    the computed half is the same arithmetic in the same order => identical bits; the mirrored half is its exact transpose
+    and within the mode's tolerance of what the general kernel computes there (the other association order).  Ragged N
+    (not a multiple of 256 / 64), odd numbers of row blocks and the sigmoid epilogue included."""
+    z = _rand((N, 128), 60).cuda()
+    w = ops.symmetrize(_rand((L, 128, 128), 61, 1 / np.sqrt(128)).cuda())
+    monkeypatch.setenv("MDG_BILINEAR_SYMMETRIC", "0")
+    gen = ops.bilinear_allpairs(z, z, w, precision=prec)
+    gen_sig = ops.bilinear_allpairs(z, z, w, precision=prec, epilogue=ops.EPI_STORE_SIGMOID)
+    monkeypatch.setenv("MDG_BILINEAR_SYMMETRIC", "1")
+    out = torch.full((L, N, N), float("nan"), device="cuda")
+    ops.bilinear_allpairs(z, z, w, precision=prec, out=out)
+    assert not bool(torch.isnan(out).any())
+    blk = torch.arange(N, device="cuda") // 256
+    upper = (blk[None, :] >= blk[:, None])                                   # on / right of the block diagonal: computed
+    assert torch.equal(out[:, upper], gen[:, upper])
+    lower = ~upper
+    assert torch.equal(out[:, lower], out.transpose(1, 2)[:, lower])          # the mirrored half: exact transpose
+    scale = float(gen.abs().max())
+    assert float((out - gen).abs().max()) < max(TOL[prec], 1e-6) * scale
+    sg = ops.bilinear_allpairs(z, z, w, precision=prec, epilogue=ops.EPI_STORE_SIGMOID)
+    assert torch.equal(sg[:, upper], gen_sig[:, upper]) and torch.equal(sg[:, lower], sg.transpose(1, 2)[:, lower])
+    # a different tensor with the same values is not "the same matrix": the general kernel runs, bit for bit
+    assert torch.equal(ops.bilinear_allpairs(z, z.clone(), w, precision=prec), gen)
+    ref = _oracle(z.cpu(), z.cpu(), _rand((L, 128, 128), 61, 1 / np.sqrt(128)))
+    assert rel_err(out.cpu(), ref) < TOL[prec]
+
+
 def test_asymmetric_operands_catch_transposes(ops):
     """A = I style check with asymmetric operands: z_head one-hot rows pick out rows of W z_tail^T."""
     L, n = 2, 40

@@ -204,10 +204,11 @@ def _pretrain_raw_worker(rank, world, port, ret):
                 hard = torch.rand(n, n, generator=torch.Generator().manual_seed(it)) < 0.03
                 hard = ((hard | hard.T) & ~torch.eye(n, dtype=torch.bool)).cuda()
                 losses.append(float(step.step(b["drugs"], m1.cuda(), m2.cuda(), hard, (b["strs"], kgc, b["cv"], b["tx"]))))
+                if it == 0:                       # gradients of the FIRST step: same weights in both runs
+                    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
                 del batch, b, kgc, m1, m2, hard
                 torch.cuda.synchronize()
                 mem.append(torch.cuda.memory_allocated())
-            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
             params = {k: p.detach().clone() for k, p in model.named_parameters()}
             return losses, mem, grads, params
         l2, mem2, g2, p2 = run(rank, world)
@@ -217,7 +218,7 @@ def _pretrain_raw_worker(rank, world, port, ret):
         # the same set of parameters received a gradient (the fusion transformer etc. stay grad=None on every rank, so
         # weight decay leaves them untouched exactly as in the single-process step)
         untouched = max(float((p2[k] - p1[k]).abs().max()) for k in p1 if k not in g1)
-        ret[rank] = (max(abs(a - b) / abs(b) for a, b in zip(l2, l1)), worst, set(g2) == set(g1), untouched, mem2)
+        ret[rank] = ([abs(a - b) / abs(b) for a, b in zip(l2, l1)], worst, set(g2) == set(g1), untouched, mem2)
     finally:
         dist.destroy_process_group()
 
@@ -234,7 +235,9 @@ def test_two_rank_shipped_pretraining_steps_equal_single_process_and_hold_no_bat
         assert p.exitcode == 0
     for r in range(2):
         lerr, worst, same_set, untouched, mem = ret[r]
-        assert lerr < 2e-4, (r, lerr)                 # four optimizer steps deep
+        # the first step is the same function of the same weights (fp32 summation order only); later losses also carry the
+        # three AdamW updates in between, whose per-entry normalisation amplifies rounding-level gradient differences
+        assert lerr[0] < 1e-5 and max(lerr) < 2e-3, (r, lerr)
         assert worst[0] < 5e-3, (r, worst)
         assert same_set and untouched == 0.0, (r, same_set, untouched)
         # nothing of an earlier iteration's batch stays allocated: memory after iteration 4 == after iteration 2
