@@ -40,8 +40,9 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 FLOP_PER_SCORE = 256.0         # 2*D at D=128
 BYTES_PER_SCORE = 4.0          # fp32 score stored
-HEAD_KERNEL = {"f32": "bilinear_allpairs_kernel<0, 0, 8>", "bf16x3": "bilinear_allpairs_kernel<1, 0, 8>",
-               "bf16": "bilinear_allpairs_kernel<2, 0, 8>", "f16": "bilinear_allpairs_kernel<3, 0, 8>"}
+# one drug set on both sides (the all-pairs job): the symmetric sweep
+HEAD_KERNEL = {"f32": "bilinear_allpairs_sym_kernel<0, 0, 8, 0>", "bf16x3": "bilinear_allpairs_sym_kernel<1, 0, 8, 1>",
+               "bf16": "bilinear_allpairs_sym_kernel<2, 0, 8, 0>", "f16": "bilinear_allpairs_sym_kernel<3, 0, 8, 0>"}
 
 
 def stress_leg(args, rank, world, dev, backend):
@@ -102,7 +103,7 @@ def pmc_traffic(n_drugs: int, n_outcomes: int, precision: str):
         w = d.get("workload", {})
         if w.get("drugs") == n_drugs and w.get("outcomes") == n_outcomes and w.get("precision") == precision:
             for name, k in d.get("kernels", {}).items():
-                if "bilinear_allpairs_kernel" in name:
+                if "bilinear_allpairs" in name:
                     return k.get("hbm_bytes_per_launch_corrected"), os.path.basename(f)
     return None, None
 

@@ -686,6 +686,203 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
   }
 }
 
+// ---- row statistics on the 16x16x32 matrix instruction (single-product 16-bit modes) --------------------------------------
+// Same work as bilinear_allpairs_kernel<MODE, ROWSTATS, 8, 2> -- 64 head rows per wave, 64 tail rows per stage, three LDS
+// buffers with prefetch distance two -- issued as v_mfma_f32_16x16x32 instead of 32x32x16: this loop is bound by the power
+// envelope (MI355X_MICROARCH.md, DVFS give-back (7): the 16x16x32 form delivers ~1.15x the FLOP/s of 32x32x16 at equal
+// cycles per FLOP because the card holds a higher clock under it).  Per stage and wave: 16 ds_read_b128 (one per 16-column
+// tile and 32-deep k step), each feeding the 4 row tiles: 64 MFMAs.
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+
+template <int MODE>
+__device__ __forceinline__ f32x4v mma16x16(const bf16x8& a, const bf16x8& b, const f32x4v& c) {
+  if constexpr (MODE == MDG_PREC_F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// A operand of the 16x16x32 form for the 32 rows of a wave, from the wave's [32][64] fp32 slab of T (columns 64 st .. +63):
+// lane (c16, g4) holds row 16 rt + c16, k = 32 ks + 8 g4 .. +7.
+template <int MODE>
+__device__ __forceinline__ void afrag16_from_slab(bf16x8 (&Ahi)[2][4], bf16x8 (&Alo)[2][4], const char* slab, int st, int c16, int g4) {
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ksl = 0; ksl < 2; ++ksl) {
+      const int row = 16 * rt + c16, chunk = (32 * ksl + 8 * g4) >> 2;
+      const float4 v0 = *reinterpret_cast<const float4*>(slab + tile_off<256>(row, chunk));
+      const float4 v1 = *reinterpret_cast<const float4*>(slab + tile_off<256>(row, chunk + 1));
+      bf16x8 hi, lo;
+      split8<MODE>(v0, v1, hi, lo);
+      Ahi[rt][2 * st + ksl] = hi;
+      Alo[rt][2 * st + ksl] = lo;
+    }
+}
+
+// 32 rows (A, registers) x 64 staged tail rows (B, LDS) on v_mfma_f32_16x16x32: acc[rt][ct] is the 16 x 16 block of rows
+// 16 rt .., columns 16 ct ..; element i of lane (c16, g4) = row 16 rt + 4 g4 + i, column 16 ct + c16.  `hook(k)`, k = 0..31,
+// is called twice per (column tile, k step) between the MFMAs (store / LDS traffic of the previous tile); B fragments are
+// fetched one step ahead by hand (the scheduling barriers pin everything in place).
+template <int MODE, typename Hook>
+__device__ __forceinline__ void compute_tile_spread16(const bf16x8 (&Ahi)[2][4], const bf16x8 (&Alo)[2][4], const char* lds, int c16, int g4,
+                                                      f32x4v (&acc)[2][4], Hook&& hook) {
+  static_assert(MODE != MDG_PREC_F32, "16-bit operand modes");
+  bf16x8 bh = *reinterpret_cast<const bf16x8*>(lds + tile_off<256>(c16, g4)), bl = bh;
+  if constexpr (MODE == MDG_PREC_BF16X3) bl = *reinterpret_cast<const bf16x8*>(lds + LO_OFF + tile_off<256>(c16, g4));
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int ct = i >> 2, ks = i & 3;
+    bf16x8 nbh = bh, nbl = bl;
+    if (i + 1 < 16) {
+      const int j = 16 * ((i + 1) >> 2) + c16, c = 4 * ((i + 1) & 3) + g4;
+      nbh = *reinterpret_cast<const bf16x8*>(lds + tile_off<256>(j, c));
+      if constexpr (MODE == MDG_PREC_BF16X3) nbl = *reinterpret_cast<const bf16x8*>(lds + LO_OFF + tile_off<256>(j, c));
+    }
+    if constexpr (MODE == MDG_PREC_BF16X3) {
+      acc[0][ct] = mma16x16<MODE>(Alo[0][ks], bh, acc[0][ct]);
+      acc[1][ct] = mma16x16<MODE>(Alo[1][ks], bh, acc[1][ct]);
+      hook(2 * i);
+      acc[0][ct] = mma16x16<MODE>(Ahi[0][ks], bl, acc[0][ct]);
+      acc[1][ct] = mma16x16<MODE>(Ahi[1][ks], bl, acc[1][ct]);
+      hook(2 * i + 1);
+      acc[0][ct] = mma16x16<MODE>(Ahi[0][ks], bh, acc[0][ct]);
+      acc[1][ct] = mma16x16<MODE>(Ahi[1][ks], bh, acc[1][ct]);
+    } else {
+      acc[0][ct] = mma16x16<MODE>(Ahi[0][ks], bh, acc[0][ct]);
+      hook(2 * i);
+      acc[1][ct] = mma16x16<MODE>(Ahi[1][ks], bh, acc[1][ct]);
+      hook(2 * i + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bh = nbh;
+    bl = nbl;
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void bilinear_rowstats16_kernel(const BilinearArgs p) {
+  static_assert(kSingle16<MODE>, "one rounded 16-bit product per k step");
+  constexpr int NW = 8, BM = 512;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const buf0 = smem;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, c16 = lane & 15, g4 = lane >> 4;
+  const int64_t l = blockIdx.y;
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * BM;
+  // ---- prologue: T = z_head[rows] . W_sym[l] (32x32x16 products, as every other path), re-laid out for 16x16x32 ----
+  bf16x8 A16[4][4];                                  // [row tile of 16][k step of 32]: lane (c16, g4) holds row c16, k = 32 ks + 8 g4 ..+7
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    AFrag<MODE> Az;
+    int64_t zr = row0 + (wave * 2 + rb) * 32 + r;
+    zr = zr < p.n_head ? zr : p.n_head - 1;
+    afrag_from_global<MODE>(Az, p.z_head + zr * D, h);
+    TileSrc ws = p.w;
+    ws.hi += l * D * D;
+    char* const slab = smem + wave * 8192;             // [32 rows][64 cols] fp32, chunk-swizzled
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      u32x4 regs[32 / NW];
+      stage_load<MODE, NW>(ws, 64 * st, tid, regs);
+      __syncthreads();
+      stage_write<MODE, NW>(buf0, tid, regs);
+      __syncthreads();
+      f32x16 acc[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+      compute_tile<MODE>(Az, buf0, r, h, acc);
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int row = acc_row(v, h), n = 32 * t + r;
+          *reinterpret_cast<float*>(slab + tile_off<256>(row, n >> 2) + (n & 3) * 4) = acc[t][v];
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int rt2 = 0; rt2 < 2; ++rt2)
+#pragma unroll
+        for (int ksl = 0; ksl < 2; ++ksl) {
+          const int row = 16 * rt2 + c16, chunk = (32 * ksl + 8 * g4) >> 2;         // 4-float chunks of the 64-column half
+          const float4 v0 = *reinterpret_cast<const float4*>(slab + tile_off<256>(row, chunk));
+          const float4 v1 = *reinterpret_cast<const float4*>(slab + tile_off<256>(row, chunk + 1));
+          bf16x8 hi, lo;
+          split8<MODE>(v0, v1, hi, lo);
+          A16[2 * rb + rt2][2 * st + ksl] = hi;
+        }
+    }
+    __syncthreads();
+  }
+  // ---- sweep ----
+  const int nst = static_cast<int>((p.n_tail + BN - 1) / BN);
+  const int start = p.stagger ? static_cast<int>((blockIdx.x * 5u + blockIdx.y * 3u) % static_cast<unsigned>(nst)) : 0;
+  auto tile_of = [&](int s) { int t = s + start; return t >= nst ? t - nst : t; };
+  float rsum[4][4], rmax[4][4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { rsum[rt][i] = 0.f; rmax[rt][i] = -INFINITY; }
+  constexpr int NDMA = 16 / NW;                       // LDS-DMA instructions per wave and tile (2)
+  stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, smem, wave, lane, NW);
+  stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(1 < nst ? 1 : 0)) * BN, smem + STAGE_BYTES, wave, lane, NW);
+  int cur = 0;
+  for (int s = 0; s < nst; ++s) {
+    const int64_t tcol0 = static_cast<int64_t>(tile_of(s)) * BN;
+    static_assert(NDMA == 2, "vmcnt immediate below");
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");           // = NDMA: tile s landed, tile s+1 stays in flight
+    __builtin_amdgcn_s_barrier();
+    const int nxt2 = cur == 0 ? 2 : cur - 1;
+    const int s2 = s + 2 < nst ? s + 2 : nst - 1;
+    stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(s2)) * BN, smem + nxt2 * STAGE_BYTES, wave, lane, NW);
+    const char* lds = smem + cur * STAGE_BYTES;
+    const bool whole = tcol0 + BN <= p.n_tail;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      f32x4v acc[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(lds + tile_off<256>(16 * ct + c16, 4 * ks + g4));
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = mma16x16<MODE>(A16[rt][ks], b, acc[rt]);
+      }
+      const bool col_ok = whole || (tcol0 + 16 * ct + c16 < p.n_tail);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          rsum[rt][i] += col_ok ? acc[rt][i] : 0.f;
+          rmax[rt][i] = fmaxf(rmax[rt][i], col_ok ? acc[rt][i] : -INFINITY);
+        }
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // accumulator element i of lane (c16, g4) of row tile rt is row 16 rt + 4 g4 + i, column c16: reduce over the 16 columns
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float sv = rsum[rt][i], mv = rmax[rt][i];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        sv += __shfl_xor(sv, o, 64);
+        mv = fmaxf(mv, __shfl_xor(mv, o, 64));
+      }
+      const int64_t row = row0 + wave * 64 + 16 * rt + 4 * g4 + i;
+      if (c16 == 0 && row < p.n_head) {
+        float* o2 = p.out + (l * p.n_head + row) * 2;
+        o2[0] = sv;
+        o2[1] = mv;
+      }
+    }
+}
+
 // ---- symmetric sweep: z_head and z_tail are the SAME matrix ------------------------------------------------------
 // All-pairs scoring of one drug set (generate_embeddings.ipynb / predict.py:428 call decoder(z, z, ...)): W_sym is
 // symmetric, so S[l,i,j] = S[l,j,i] up to fp32 rounding of the two association orders (z_i W) z_j and (z_j W) z_i.
@@ -697,15 +894,21 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
 // the other: every workgroup sweeps nb + 1 column blocks.  Stores: the wave's 32 x 64 tile goes through its 8 KB LDS slab
 // twice -- column-major (8 x ds_write_b128) to leave as 64 rows x 128 B of the mirrored block, then row-major
 // (32 x ds_write_b32) to leave as 32 rows x 256 B -- always as 16-byte-per-lane stores of whole 128-byte lines.
-template <int MODE, int EPI, int NW>
+// SC1: the score stores carry the sc1 bit (write-through: the line is not kept in the XCD's L2, MI355X_MICROARCH.md "stores of
+// each flavour"), so the 60 GB store stream does not evict the 2 MB of z_tail images the LDS-DMA re-reads from L2.
+template <int MODE, int EPI, int NW, int SC1 = 0>
 __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_sym_kernel(const BilinearArgs p) {
   static_assert(NW == 8, "256-row blocks: 8 waves of 32 rows");
+  constexpr int AUX = SC1 ? 16 : 0;                     // gfx940+ cache-policy immediate: bit 4 = sc1
   static_assert(EPI == MDG_EPI_STORE || EPI == MDG_EPI_STORE_SIGMOID, "materialising epilogues only");
   constexpr int BM = 32 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const buf0 = smem;
   char* const buf1 = smem + STAGE_BYTES;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, c16 = lane & 15, g4 = lane >> 4;
+  // 16-bit operand modes run the sweep on v_mfma_f32_16x16x32 (the loop is bound by the power envelope: the card holds a higher
+  // clock under that form, MI355X_MICROARCH.md DVFS give-back (7)); exact fp32 stays on 32x32x2
+  constexpr bool M16 = (MODE != MDG_PREC_F32);
   char* const stg = smem + 2 * STAGE_BYTES + wave * 8192;
   const int64_t l = blockIdx.y, N = p.n_tail;
   const int nst = static_cast<int>((N + BN - 1) / BN);
@@ -735,6 +938,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_sym_kernel(const
     const int64_t row0 = static_cast<int64_t>(rbk) * BM;
     // ---- prologue: T = z[rows] . W_sym[l] as the A operand (same arithmetic as the general kernel) ----
     AFrag<MODE> At;
+    bf16x8 A16hi[2][4], A16lo[2][4];
     {
       AFrag<MODE> Az;
       int64_t zr = row0 + wave * 32 + r;
@@ -767,7 +971,8 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_sym_kernel(const
           }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        afrag_from_slab<MODE>(At, slab, st, r, h);
+        if constexpr (M16) afrag16_from_slab<MODE>(A16hi, A16lo, slab, st, c16, g4);
+        else afrag_from_slab<MODE>(At, slab, st, r, h);
       }
       __syncthreads();
     }
@@ -784,12 +989,12 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_sym_kernel(const
       const int64_t col = col0 + scol;
       const int64_t e = static_cast<int64_t>(wave * 32 + 4 * q + srow) * N + col;
       const unsigned off = col < N ? static_cast<unsigned>(e * 4) : 0xFFFFFFFFu;              // out of range => dropped
-      __builtin_amdgcn_raw_buffer_store_b128(sig(o[q]), rs_rows, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(sig(o[q]), rs_rows, off, 0, AUX);
     };
     auto store_mirror = [&](int q, int64_t col0, bool on) {           // tile columns 8q..8q+7 as rows of the mirrored block: 8 x 128 B
       const int64_t mr = col0 + 8 * q + mrow, mc = row0 + wave * 32 + 4 * mchunk;
       const unsigned off = (on && mr < N && mc < N) ? static_cast<unsigned>((mr * N + mc) * 4) : 0xFFFFFFFFu;
-      __builtin_amdgcn_raw_buffer_store_b128(sig(o[q]), rs_all, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(sig(o[q]), rs_all, off, 0, AUX);
     };
     stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, buf0, wave, lane, NW);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -805,35 +1010,61 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_sym_kernel(const
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(s + 1 < nt ? s + 1 : s)) * BN, nxt, wave, lane, NW);
-      f32x16 acc[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
       const int64_t pc0 = prev_col0;
-      compute_tile_spread<MODE>(At, cur, r, h, acc, [&](int k) {
+      const bool mirror = tile >= t_diag_end;
+      auto hook = [&](int k) {
         if (k < 8) o[k] = *reinterpret_cast<const u32x4*>(stg + (4 * k + srow) * 256 + scol * 4);
         else if (k >= 16 && (k & 1) == 0) store_rows((k - 16) >> 1, pc0);
-      });
-      // tile s, column-major ([64 columns][32 rows]): a lane's 4 consecutive rows of one column are 16 contiguous bytes
+      };
+      if constexpr (M16) {
+        f32x4v acc[2][4];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 v4 = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-          *reinterpret_cast<f32x4*>(stg + (32 * t + r) * 128 + (8 * g + 4 * h) * 4) = v4;
-        }
+          for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        compute_tile_spread16<MODE>(A16hi, A16lo, cur, c16, g4, acc, hook);
+        // tile s, column-major ([64 columns][32 rows]): a lane's 4 consecutive rows of one column are 16 contiguous bytes
 #pragma unroll
-      for (int q = 0; q < 8; ++q) o[q] = *reinterpret_cast<const u32x4*>(stg + (8 * q + mrow) * 128 + mchunk * 16);
-      const bool mirror = tile >= t_diag_end;
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) store_mirror(q, tcol0, mirror);
-      // tile s, row-major, for the row stores of the next stage (the reads above are older LDS operations of this wave)
+          for (int ct = 0; ct < 4; ++ct)
+            *reinterpret_cast<f32x4v*>(stg + (16 * ct + c16) * 128 + (16 * rt + 4 * g4) * 4) = acc[rt][ct];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int q = 0; q < 8; ++q) o[q] = *reinterpret_cast<const u32x4*>(stg + (8 * q + mrow) * 128 + mchunk * 16);
 #pragma unroll
-        for (int v = 0; v < 16; ++v)
-          *reinterpret_cast<float*>(stg + acc_row(v, h) * 256 + (32 * t + r) * 4) = acc[t][v];
+        for (int q = 0; q < 8; ++q) store_mirror(q, tcol0, mirror);
+        // tile s, row-major, for the row stores of the next stage (the reads above are older LDS operations of this wave)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              *reinterpret_cast<float*>(stg + (16 * rt + 4 * g4 + i) * 256 + (16 * ct + c16) * 4) = acc[rt][ct][i];
+      } else {
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        compute_tile_spread<MODE>(At, cur, r, h, acc, hook);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v4 = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(stg + (32 * t + r) * 128 + (8 * g + 4 * h) * 4) = v4;
+          }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = *reinterpret_cast<const u32x4*>(stg + (8 * q + mrow) * 128 + mchunk * 16);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) store_mirror(q, tcol0, mirror);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int v = 0; v < 16; ++v)
+            *reinterpret_cast<float*>(stg + acc_row(v, h) * 256 + (32 * t + r) * 4) = acc[t][v];
+      }
       prev_col0 = tcol0;
     }
 #pragma unroll
@@ -913,10 +1144,16 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
         mdg_aligned16(a.out) && a.n_tail * a.n_tail * 4 < (int64_t(1) << 32) && a.n_tail > 256) {
       const int nb = static_cast<int>(mdg_cdiv(a.n_tail, 256));
       const dim3 gsym(static_cast<unsigned>((nb + 1) / 2), static_cast<unsigned>(a.n_labels));
-      if (epilogue == MDG_EPI_STORE)
-        hipLaunchKernelGGL((bilinear_allpairs_sym_kernel<MODE, MDG_EPI_STORE, 8>), gsym, block, lds2, st, a);
-      else
+      // write-through score stores keep z_tail L2-resident (FETCH 11.3 -> 0.8 GB per launch at 4096^2 x 896); measured faster for
+      // the three-product mode (11.78 -> 11.53 ms), slower for the single-product 16-bit modes (10.70 -> 11.11 ms)
+      const char* ce = getenv("MDG_BILINEAR_SC1");
+      const bool sc1 = ce ? atoi(ce) != 0 : (MODE == MDG_PREC_BF16X3);
+      if (epilogue == MDG_EPI_STORE) {
+        if (sc1) hipLaunchKernelGGL((bilinear_allpairs_sym_kernel<MODE, MDG_EPI_STORE, 8, 1>), gsym, block, lds2, st, a);
+        else hipLaunchKernelGGL((bilinear_allpairs_sym_kernel<MODE, MDG_EPI_STORE, 8, 0>), gsym, block, lds2, st, a);
+      } else {
         hipLaunchKernelGGL((bilinear_allpairs_sym_kernel<MODE, MDG_EPI_STORE_SIGMOID, 8>), gsym, block, lds2, st, a);
+      }
       MDG_CHECK_LAUNCH("mdg_bilinear_allpairs(symmetric)");
       return MDG_OK;
     }
@@ -942,6 +1179,13 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
       static const int rb2 = getenv("MDG_BILINEAR_RB") ? atoi(getenv("MDG_BILINEAR_RB")) : 2;
       if (kSingle16<MODE> && rb2 == 2 && a.pipeline == 0) {     // 64 rows per wave: halves the LDS operand reads per MFMA
         const dim3 grid2(static_cast<unsigned>(mdg_cdiv(a.n_head, 32 * NW * 2)), static_cast<unsigned>(a.n_labels));
+        static const int shape16 = getenv("MDG_BILINEAR_MFMA16") ? atoi(getenv("MDG_BILINEAR_MFMA16")) : 1;
+        if constexpr (kSingle16<MODE> && NW == 8) {
+          if (shape16) {                                       // the same sweep on v_mfma_f32_16x16x32 (power-bound loop)
+            hipLaunchKernelGGL((bilinear_rowstats16_kernel<MODE>), grid2, block, 3 * STAGE_BYTES, st, a);
+            break;
+          }
+        }
         hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_ROWSTATS, NW, (kSingle16<MODE> ? 2 : 1)>), grid2, block, 3 * STAGE_BYTES, st, a);
       } else {
         hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_ROWSTATS, NW>), grid, block, 3 * STAGE_BYTES, st, a);

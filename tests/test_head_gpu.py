@@ -133,13 +133,17 @@ def test_symmetric_sweep_for_one_drug_set(ops, monkeypatch, prec, N, L):
     assert not bool(torch.isnan(out).any())
     blk = torch.arange(N, device="cuda") // 256
     upper = (blk[None, :] >= blk[:, None])                                   # on / right of the block diagonal: computed
-    assert torch.equal(out[:, upper], gen[:, upper])
+    scale = float(gen.abs().max())
+    if prec == "f32":                       # same instruction, same order: identical bits
+        assert torch.equal(out[:, upper], gen[:, upper])
+    else:                                   # 16-bit operand modes sweep on v_mfma 16x16x32 (general kernel: 32x32x16): same products,
+        assert float((out[:, upper] - gen[:, upper]).abs().max()) < 2e-6 * scale      # fp32 sums grouped 32 instead of 16 deep
     lower = ~upper
     assert torch.equal(out[:, lower], out.transpose(1, 2)[:, lower])          # the mirrored half: exact transpose
-    scale = float(gen.abs().max())
     assert float((out - gen).abs().max()) < max(TOL[prec], 1e-6) * scale
     sg = ops.bilinear_allpairs(z, z, w, precision=prec, epilogue=ops.EPI_STORE_SIGMOID)
-    assert torch.equal(sg[:, upper], gen_sig[:, upper]) and torch.equal(sg[:, lower], sg.transpose(1, 2)[:, lower])
+    assert float((sg[:, upper] - gen_sig[:, upper]).abs().max()) < 2e-6 and torch.equal(sg[:, lower], sg.transpose(1, 2)[:, lower])
+    assert torch.equal(sg, torch.sigmoid(out)) or float((sg - 1.0 / (1.0 + torch.exp(-out))).abs().max()) < 1e-6
     # a different tensor with the same values is not "the same matrix": the general kernel runs, bit for bit
     assert torch.equal(ops.bilinear_allpairs(z, z.clone(), w, precision=prec), gen)
     ref = _oracle(z.cpu(), z.cpu(), _rand((L, 128, 128), 61, 1 / np.sqrt(128)))
@@ -181,7 +185,10 @@ def test_rowstats_epilogue(ops, prec, nh, nt):
     assert float((st[..., 1] - ref.max(dim=2).values).abs().max()) < TOL[prec] * scale
     assert float((st[..., 0] - ref.sum(dim=2)).abs().max()) < TOL[prec] * scale * max(nt, 2) ** 0.5 * 4
     dense = ops.bilinear_allpairs(zh.cuda(), zt.cuda(), ops.symmetrize(w.cuda()), precision=prec).cpu()
-    assert torch.equal(st[..., 1], dense.max(dim=2).values)          # same products, same maxima, bit for bit
+    if prec in ("f32", "bf16x3"):
+        assert torch.equal(st[..., 1], dense.max(dim=2).values)      # same products, same order, same maxima, bit for bit
+    else:       # 16-bit modes: the statistics run on the 16x16x32 instruction (32 products per fp32 add chain step, not 16)
+        assert float((st[..., 1] - dense.max(dim=2).values).abs().max()) < 2e-6 * scale
 
 
 def test_empty_and_errors(ops):
@@ -253,7 +260,8 @@ def test_cfg5_scale_row_statistics(ops, prec):
     dense = ops.bilinear_allpairs(zc[rows.cuda()], zc, wc, precision=prec).cpu()
     ref = O.bilinear_scores(z[rows], z, w)
     assert rel_err(dense, ref) < TOL[prec]
-    assert torch.equal(st[:, rows, 1], dense.max(dim=2).values)
+    # (statistics: v_mfma 16x16x32, dense: 32x32x16 -- same products, fp32 sums grouped differently)
+    assert float((st[:, rows, 1] - dense.max(dim=2).values).abs().max()) < 2e-6 * float(dense.abs().max())
     assert float((st[:, rows, 0] - dense.sum(dim=2)).abs().max()) < 1e-5 * scale
 
 
