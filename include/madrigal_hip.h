@@ -322,6 +322,13 @@ int mdg_batchnorm_train_fwd(const float* x, int64_t ldx, const float* gamma, con
 int mdg_batchnorm_train_bwd(const float* dy, const float* x, const float* stats, float* dx, float* dgamma, float* dbeta,
                             int64_t rows, int64_t cols, void* workspace, size_t workspace_bytes, void* stream);
 
+/* One more momentum update of running_mean / running_var with the batch statistics of an earlier mdg_batchnorm_train_fwd
+ * (stats[0:C] mean, stats[C:2C] rstd): nn.BatchNorm1d seeing the same rows again.  The reference encodes head side and tail
+ * side of one step separately (madrigal/models/models.py:945-946); when both sides are the same batch, the encoders without
+ * dropout (GIN, chemCPA) produce the same output twice -- here they run once and their BatchNorm layers replay the update. */
+int mdg_batchnorm_replay_update(const float* stats, float* running_mean, float* running_var, int64_t rows, int64_t cols, float eps,
+                                float momentum, void* stream);
+
 /* The phases of mdg_batchnorm_train_fwd / _bwd as separate calls, for SyncBatchNorm over drug-sharded ranks: the caller
  * all-reduces the per-column sums between phases (count = rows over all ranks).
  *   mdg_col_reduce mode 0: out[c] = sum_r x;  1: sum_r (x - center[c])^2;  2: sum_r x * (y - center[c]) * rstd[c]

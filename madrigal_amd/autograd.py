@@ -131,6 +131,7 @@ class _BatchNormAct(Function):
         x = x if x.is_contiguous() else x.contiguous()
         fused = act if act in (None, "none", "relu") else None
         y, stats = ops.batchnorm_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, act=fused)
+        _BatchNormAct.last_stats = stats              # (read by record_batchnorm right after the call)
         pre = None
         if act == "relu":
             pre = y
@@ -152,6 +153,33 @@ class _BatchNormAct(Function):
         return dx, (dg if ctx.affine else None), (db if ctx.affine else None), None, None, None, None, None
 
 
+_bn_log = {"active": None}
+
+
+class record_batchnorm:
+    """``with record_batchnorm() as log:`` every training-mode BatchNorm forward inside appends (module, batch statistics,
+    rows) to ``log``, so that ``replay_batchnorm(log)`` can later apply the same running-statistics update again without
+    re-running the layers (a deterministic encoder that the reference runs twice on the same rows in one step)."""
+
+    def __enter__(self):
+        self.prev = _bn_log["active"]
+        self.log = []
+        _bn_log["active"] = self.log
+        return self.log
+
+    def __exit__(self, *exc):
+        _bn_log["active"] = self.prev
+
+
+def replay_batchnorm(log) -> None:
+    with torch.no_grad():
+        for bn, stats, rows in log:
+            if bn.track_running_stats and bn.running_mean is not None:
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked.add_(1)
+                ops.batchnorm_replay_update(stats, bn.running_mean, bn.running_var, rows, bn.eps, bn.momentum)
+
+
 def batchnorm_act(x, bn: torch.nn.BatchNorm1d, act=None):
     """Training-mode BatchNorm1d (+ activation) of a [rows, C] tensor; updates bn.running_* and num_batches_tracked."""
     if bn.momentum is None:
@@ -160,8 +188,12 @@ def batchnorm_act(x, bn: torch.nn.BatchNorm1d, act=None):
         bn.num_batches_tracked.add_(1)
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     if _bn_sync["reduce"] is not None:
+        # (synchronised statistics are not logged: encode() never shares passes under data parallelism)
         return _SyncBatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, act, _bn_sync["reduce"])
-    return _BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, act)
+    y = _BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, act)
+    if _bn_log["active"] is not None:
+        _bn_log["active"].append((bn, _BatchNormAct.last_stats, int(x.shape[0])))
+    return y
 
 
 class _Dropout(Function):

@@ -205,6 +205,19 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (rows > 1 ? sqsum[c] / static_cast<float>(rows - 1) : var);
 }
 
+// A second momentum update of the running statistics with batch statistics that a training-mode forward already produced
+// (stats[0:C] = mean, stats[C:2C] = rstd): what nn.BatchNorm1d does when the same module sees the same rows again.
+__global__ __launch_bounds__(256) void bn_replay_kernel(const float* __restrict__ stats, float* __restrict__ running_mean,
+                                                        float* __restrict__ running_var, double rows, int64_t cols, float eps, float momentum) {
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const float mean = stats[c], rstd = stats[cols + c];
+  const float var = 1.0f / (rstd * rstd) - eps;                                   // biased batch variance
+  const float unbiased = rows > 1 ? var * static_cast<float>(rows / (rows - 1.0)) : var;
+  running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+  running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+}
+
 // y = act(x * scale[c] + shift[c])
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, float* __restrict__ y, int64_t ldy, int64_t rows,
@@ -411,6 +424,15 @@ extern "C" int mdg_batchnorm_train_fwd(const float* x, int64_t ldx, const float*
   hipLaunchKernelGGL(affine_act_kernel, dim3(static_cast<unsigned>(mdg_cdiv(rows * cols, 256))), dim3(256), 0, st, x, ldx, stats + 2 * cols,
                      stats + 3 * cols, y, ldy, rows, cols, activation);
   MDG_CHECK_LAUNCH("mdg_batchnorm_train_fwd");
+  return MDG_OK;
+}
+
+extern "C" int mdg_batchnorm_replay_update(const float* stats, float* running_mean, float* running_var, int64_t rows, int64_t cols, float eps,
+                                           float momentum, void* stream) {
+  MDG_CHECK_ARG(stats && running_mean && running_var && rows > 0 && cols > 0, "mdg_batchnorm_replay_update: bad argument");
+  hipLaunchKernelGGL(bn_replay_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), stats,
+                     running_mean, running_var, static_cast<double>(rows), cols, eps, momentum);
+  MDG_CHECK_LAUNCH("mdg_batchnorm_replay_update");
   return MDG_OK;
 }
 

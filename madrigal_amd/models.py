@@ -1370,21 +1370,46 @@ class NovelDDIEncoder(nn.Module):
             self._kg_stream.wait_stream(main)
             with torch.cuda.stream(self._kg_stream):
                 kg_out = run_kg()
+        # Training: the reference encodes the head side and the tail side (or the two contrastive views) of one step separately
+        # (models.py:945-946, simclr.py:134-135).  When both passes are given the same molecule batch / tx dict, the encoders
+        # WITHOUT dropout -- GIN and the chemCPA encoder: Linear / BatchNorm(batch statistics) / ReLU only, all rows whatever the
+        # masks -- return the same tensor twice; the second pass reuses the first one's output (autograd adds both consumers'
+        # gradients into one backward pass, the sum the reference forms from two identical passes) and its BatchNorm layers
+        # replay their running-statistics update, so the module state after the step is what two passes leave behind.
+        share_enc = (train and share is not None and ag._bn_sync["reduce"] is None and os.environ.get("MDG_SHARE_SIDES", "1") != "0")
+        skey, tkey = ("str", id(batch_mols)), ("tx", id(batch_tx_dict))
+        s_hit = share.get(skey) if share_enc else None
         # training: the structure encoder (a chain of small launches over the atoms, forward and backward) on a third stream
-        str_side = overlap and train and os.environ.get("MDG_TRAIN_OVERLAP_STR", "1") != "0"
-        if str_side:
-            if self.__dict__.get("_str_stream") is None or self._str_stream.device != dev:
-                self.__dict__["_str_stream"] = torch.cuda.Stream(device=dev)
-            self._str_stream.wait_stream(main)
-            with torch.cuda.stream(self._str_stream):
-                str_out = self.str_encoder(batch_mols, batch_mols.node_feature.float())["graph_feature"]
+        str_side = overlap and train and s_hit is None and os.environ.get("MDG_TRAIN_OVERLAP_STR", "1") != "0"
+        if s_hit is not None:
+            str_out = s_hit[0]
+            ag.replay_batchnorm(s_hit[1])
         else:
-            str_out = self.str_encoder(batch_mols, batch_mols.node_feature.float())["graph_feature"]
+            with ag.record_batchnorm() as s_log:
+                if str_side:
+                    if self.__dict__.get("_str_stream") is None or self._str_stream.device != dev:
+                        self.__dict__["_str_stream"] = torch.cuda.Stream(device=dev)
+                    self._str_stream.wait_stream(main)
+                    with torch.cuda.stream(self._str_stream):
+                        str_out = self.str_encoder(batch_mols, batch_mols.node_feature.float())["graph_feature"]
+                else:
+                    str_out = self.str_encoder(batch_mols, batch_mols.node_feature.float())["graph_feature"]
+            if share_enc:
+                share[skey] = (str_out, s_log, batch_mols)
         cv_out = self.cv_encoder(batch_cv)
         # tx embeddings of absent cell lines are masked tokens: the live-token path never reads them.  In training mode
         # every row goes through the tx encoder, as in the reference: its BatchNorm batch statistics include them.
         skip_absent = compact and not train
-        tx_out = self._encode_tx(batch_tx_dict, n, dev, present_rows=self._mask_plan(batch_masks, dev, compact)["tx_rows"] if skip_absent else None)
+        tx_shareable = share_enc and self.tx_encoder_dict is None and not any(isinstance(m, nn.Dropout) and m.p > 0 for m in self.tx_encoder.modules())
+        t_hit = share.get(tkey) if tx_shareable else None
+        if t_hit is not None:
+            tx_out = t_hit[0]
+            ag.replay_batchnorm(t_hit[1])
+        else:
+            with ag.record_batchnorm() as t_log:
+                tx_out = self._encode_tx(batch_tx_dict, n, dev, present_rows=self._mask_plan(batch_masks, dev, compact)["tx_rows"] if skip_absent else None)
+            if tx_shareable:
+                share[tkey] = (tx_out, t_log, batch_tx_dict)
         if str_side:
             main.wait_stream(self._str_stream)
             str_out.record_stream(main)

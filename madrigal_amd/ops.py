@@ -596,6 +596,13 @@ def batchnorm_train_fwd(x: torch.Tensor, gamma, beta, running_mean, running_var,
     return y, stats
 
 
+def batchnorm_replay_update(stats: torch.Tensor, running_mean: torch.Tensor, running_var: torch.Tensor, rows: int, eps: float, momentum: float) -> None:
+    """A further momentum update of the running statistics from the batch statistics of an earlier training-mode forward."""
+    C = running_mean.numel()
+    check(lib().mdg_batchnorm_replay_update(_ptr(stats), _ptr(running_mean), _ptr(running_var), _c64(rows), _c64(C), _f(eps), _f(momentum),
+                                            _stream(stats)), "mdg_batchnorm_replay_update")
+
+
 def batchnorm_train_bwd(dy: torch.Tensor, x: torch.Tensor, stats: torch.Tensor):
     """-> (dx, dgamma, dbeta) for the gradient ``dy`` at the BatchNorm output (before any activation)."""
     dy, x = _f32_cuda(dy, "dy", 2), _f32_cuda(x, "x", 2)

@@ -74,7 +74,22 @@ class AdamW(torch.optim.Optimizer):
             if lay["base"] is None or not np.array_equal(base, lay["base"]):       # the allocator usually hands the same blocks back
                 lay["base"] = base
                 lay["t_ptr"] = torch.from_numpy(base[lay["owner"]] + lay["offs"][:, None]).to(dev)
-            t_hyp = torch.from_numpy(np.asarray([h for *_, h in items], dtype=np.float32)).to(dev)
+            # per-tensor hyper-parameters: through a rotating pair of PINNED host buffers and an asynchronous copy -- a pageable
+            # .to(device) waits for everything queued on the stream (the whole backward pass), which stops the host from
+            # issuing the next step while this one still runs
+            hyp = np.asarray([h for *_, h in items], dtype=np.float32)
+            slot = lay.setdefault("slot", 0)
+            pins = lay.setdefault("pins", [None, None])
+            if pins[slot] is None or pins[slot][0].shape != hyp.shape:
+                pins[slot] = [torch.empty(hyp.shape, dtype=torch.float32, pin_memory=True), None]
+            if pins[slot][1] is not None:
+                pins[slot][1].synchronize()            # the copy issued two steps ago has long landed
+            pins[slot][0].numpy()[...] = hyp
+            t_hyp = pins[slot][0].to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            pins[slot][1] = ev
+            lay["slot"] = 1 - slot
             with torch.cuda.device(dev):
                 check(lib().mdg_adamw_multi(ctypes.c_void_p(lay["t_ptr"].data_ptr()), ctypes.c_void_p(lay["t_len"].data_ptr()),
                                             ctypes.c_void_p(lay["t_own"].data_ptr()), ctypes.c_void_p(t_hyp.data_ptr()),

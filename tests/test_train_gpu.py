@@ -1269,3 +1269,49 @@ def test_training_kernels_on_empty_and_ragged_inputs():
     ref.sum().backward()
     _close(out, ref, 1e-5, "ragged attention fwd")
     _close(qkv.grad, qr.grad, 2e-5, "ragged attention bwd")
+
+
+def test_sharing_dropout_free_encoders_between_sides_equals_two_passes(monkeypatch):
+    """Head side and tail side of a full-batch step get the same molecules and tx signatures; GIN and the chemCPA encoder have no
+    dropout, so the reference's two passes (models.py:945-946) are one pass used twice.  With the sharing on, loss, every
+    gradient and every BatchNorm buffer (two momentum updates, num_batches_tracked + 2) equal the two-pass run."""
+    from madrigal_amd import data as D, models as M
+    from madrigal_amd.optim import AdamW
+    from madrigal_amd.train import FinetuneStep
+    case = ("twosides321", "transformer_uni_proj", 2, "sinusoidal", 4, 64, 256, 2, True, "x-attn", False, False)
+    n, L, seed = 80, 10, 19
+
+    def run(flag):
+        monkeypatch.setenv("MDG_SHARE_SIDES", flag)
+        model, _, batch, bkg, masks = _small_model(M, case, n, L, seed, default_init=True)
+        model = model.cuda().train()
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+        b = D.batch_to(batch, "cuda")
+        kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
+        lab, hd, tl, y = (t.cuda() for t in D.make_labelled_triples(n, L, 300, seed))
+        filler = torch.randn(n, 128, generator=torch.Generator().manual_seed(1)).cuda()
+        fs = FinetuneStep(model, AdamW(model.parameters(), lr=1e-4))
+        m_tail = b["masks"].clone()
+        m_tail[:, 3:] |= torch.rand(n, 16, generator=torch.Generator().manual_seed(2)).cuda() < 0.5      # the sides may differ in masks
+        with M.precision("f32"):
+            loss = fs.accumulate(b, b, b["masks"], m_tail, kgc, lab, hd, tl, y, kg_filler=filler)
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        bufs = {k: v.detach().clone() for k, v in model.named_buffers() if "running" in k or "num_batches" in k}
+        return float(loss), grads, bufs
+    l0, g0, b0 = run("0")
+    l1, g1, b1 = run("1")
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    assert set(g0) == set(g1)
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for k, v in g0.items():
+        assert float((g1[k] - v).abs().max()) <= 1e-5 * max(float(v.abs().max()), 1e-2 * gmax), k
+    for k, v in b0.items():
+        if "num_batches" in k:
+            assert int(b1[k]) == int(v), k
+        else:
+            assert float((b1[k] - v).abs().max()) <= 2e-6 * max(float(v.abs().max()), 1e-6), k
+    assert any(int(v) == 2 for k, v in b0.items() if "num_batches" in k)
