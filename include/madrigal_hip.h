@@ -257,6 +257,17 @@ int mdg_bilinear_gather_bwd(const float* z_head, const float* z_tail, const floa
                             const int64_t* chunk_start, int64_t n_chunks, const int64_t* label_chunk_ptr, int64_t n_labels,
                             const float* dscore, float* gz_head_rows, float* gz_tail_rows, float* dw_partial, float* dw, int64_t D,
                             void* stream);
+/* Pair-compressed gathered head (same sums as mdg_bilinear_gather / _bwd, grouped per (label, drug) PAIR before the 128 x 128
+ * products: the finetune batch holds more labelled triples than (outcome, drug) pairs, train_ddi_batch.py:285-288).
+ *   mdg_bilinear_matvec_rows: rows_out[p] = W[tile_label] z[row_index[p]] for pairs cut into tiles of <= 32 pairs of one label
+ *       (row_index NULL = identity); exact-fp32 matrix cores.
+ *   mdg_gather_rowdot: out[t] = a[ia[t]] . b[ib[t]] over rows of 128 floats (the per-triple score from the per-pair rows).
+ * mdg_bilinear_gather_bwd with n_tiles = 0 runs only its dW part; there `tail` NULL means row t of z_tail and `dscore` NULL
+ * means weight 1 (the dW sum over pairs). */
+int mdg_bilinear_matvec_rows(const float* z, const float* w, const int64_t* row_index, const int64_t* tile_start, const int64_t* tile_label,
+                             int64_t n_tiles, float* rows_out, int64_t D, void* stream);
+int mdg_gather_rowdot(const float* a, const int64_t* ia, const float* b, const int64_t* ib, float* out, int64_t n, int64_t D, void* stream);
+
 /* nn.BCELoss(sigmoid(score), target) per element (log clamp at -100) and/or its gradient w.r.t. the logit times
  * grad_scale (1/T for reduction='mean').  madrigal/utils.py:616-619. */
 int mdg_bce_logits(const float* score, const float* target, float* term, float* dscore, int64_t n, float grad_scale, void* stream);

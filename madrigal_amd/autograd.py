@@ -52,7 +52,8 @@ class _Linear(Function):
             g = ops.activation_bwd(g, pre, ctx.act)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear(g, ops.transpose(w), precision=ctx.precision, cache_weight=False)[:, :x2.shape[1]]
+            wt = ops.weight_transposed(w) if (w.is_leaf and w.requires_grad) else ops.transpose(w)
+            dx = ops.linear(g, wt, precision=ctx.precision, cache_weight=False)[:, :x2.shape[1]]
             dx = dx.reshape(*ctx.lead, x2.shape[1])
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
@@ -389,20 +390,22 @@ def symmetrize(w):
 
 
 class _BilinearGather(Function):
-    """Scores of the plan's (label, head, tail) triples only (plan order = sorted by label)."""
+    """Scores of the plan's (label, head, tail) triples only (plan order = sorted by label), through the (label, head drug)
+    pairs: one 128 x 128 product per pair forward, one backward (ops.bilinear_gather_pairs).  ``w_sym`` is symmetric."""
 
     @staticmethod
     def forward(ctx, z_head, z_tail, w_sym, plan):
-        ctx.save_for_backward(z_head, z_tail, w_sym)
+        score, V = ops.bilinear_gather_pairs(z_head, z_tail, w_sym, plan)
+        ctx.save_for_backward(z_head, z_tail, w_sym, V)
         ctx.plan = plan
-        return ops.bilinear_gather(z_head, z_tail, w_sym, plan)
+        return score
 
     @staticmethod
     @once_differentiable
     def backward(ctx, ds):
-        z_head, z_tail, w_sym = ctx.saved_tensors
-        dzh, dzt, dw = ops.bilinear_gather_bwd(z_head, z_tail, w_sym, ctx.plan, ds if ds.is_contiguous() else ds.contiguous(),
-                                               need_dw=ctx.needs_input_grad[2])
+        z_head, z_tail, w_sym, V = ctx.saved_tensors
+        dzh, dzt, dw = ops.bilinear_gather_pairs_bwd(z_head, z_tail, w_sym, ctx.plan, ds if ds.is_contiguous() else ds.contiguous(), V,
+                                                     need_dw=ctx.needs_input_grad[2])
         return (dzh if ctx.needs_input_grad[0] else None), (dzt if ctx.needs_input_grad[1] else None), dw, None
 
 

@@ -44,8 +44,11 @@ __device__ __forceinline__ void load_row_frag(const float* __restrict__ row, int
   for (int q = 0; q < 16; ++q) zf[q] = *reinterpret_cast<const f32x4*>(row + 8 * q + 4 * half);
 }
 
-template <bool BWD>
+// MODE 0: scores; MODE 1: both per-triple gradient rows; MODE 2: rows[t] = W[l] z_tail[tail[t]] only (one matrix-vector product
+// per "triple" -- the (label, drug) PAIRS of the pair-compressed path, whose inputs are rows of z or of a per-pair sum).
+template <int MODE>
 __global__ __launch_bounds__(256) void bilinear_gather_kernel(const GatherArgs p) {
+  constexpr bool BWD = MODE != 0;
   const int lane = threadIdx.x & 63, x = lane & 31, half = lane >> 5;
   const int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (tile >= p.n_tiles) return;
@@ -55,8 +58,8 @@ __global__ __launch_bounds__(256) void bilinear_gather_kernel(const GatherArgs p
   const int64_t t = t0 + (x < cnt ? x : cnt - 1);
   const int64_t l = p.tile_label[tile];
   const float* wl = p.w + l * HD * HD;
-  const float* zt_row = p.zt + p.tail[t] * HD;
-  const float* zh_row = p.zh + p.head[t] * HD;
+  const float* zt_row = p.zt + (p.tail ? p.tail[t] : t) * HD;           // null index = identity (row t)
+  const float* zh_row = MODE == 2 ? zt_row : p.zh + p.head[t] * HD;
 
   f32x4 zf[16];
   load_row_frag(zt_row, half, zf);
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void bilinear_gather_kernel(const GatherArgs p
     s += __shfl_xor(s, 32, 64);
     if (half == 0 && x < cnt) p.score[t] = s;
   } else {
-    const float g_t = p.ds[t];
+    const float g_t = MODE == 2 ? 1.0f : p.ds[t];
     for (int c0 = 0; c0 < HD; c0 += 32) {                   // d z_head[h_t] row: ds * W z_t
       f32x16 acc;
       wz_tile(wl, c0, x, half, zf, acc);
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(256) void bilinear_gather_kernel(const GatherArgs p
           *reinterpret_cast<f32x4*>(r + 8 * g) = f32x4{acc[4 * g] * g_t, acc[4 * g + 1] * g_t, acc[4 * g + 2] * g_t, acc[4 * g + 3] * g_t};
       }
     }
+    if constexpr (MODE == 2) return;
     load_row_frag(zh_row, half, zf);
     const float* wtl = p.wt + l * HD * HD;
     for (int c0 = 0; c0 < HD; c0 += 32) {                   // d z_tail[t_t] row: ds * W^T z_h
@@ -119,9 +123,9 @@ __global__ __launch_bounds__(256) void bilinear_gather_dw_kernel(const float* __
   for (int64_t t = t0 + half; t < t1 + half; t += 2) {       // both halves take the same number of steps
     const bool ok = t < t1;
     const int64_t tt = ok ? t : t1 - 1;
-    const float g = ok ? ds[tt] : 0.f;
+    const float g = ok ? (ds ? ds[tt] : 1.f) : 0.f;
     const float a = zh[head[tt] * HD + 32 * wave + x] * g;
-    const float* zr = zt + tail[tt] * HD + x;
+    const float* zr = zt + (tail ? tail[tt] : tt) * HD + x;              // null index = identity (row tt)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, zr[32 * j], acc[j], 0, 0, 0);
   }
@@ -168,6 +172,20 @@ __global__ __launch_bounds__(256) void symmetrize_bwd_kernel(const float* __rest
   dwo[i] = r == c ? m[r * D + c] : (r < c ? m[r * D + c] + m[c * D + r] : 0.f);
 }
 
+// out[t] = a[ia[t]] . b[ib[t]]  (rows of 128 floats): half a wave per entry, 16 bytes per lane, fixed summation order.
+__global__ __launch_bounds__(256) void gather_rowdot_kernel(const float* __restrict__ a, const int64_t* __restrict__ ia, const float* __restrict__ b,
+                                                            const int64_t* __restrict__ ib, float* __restrict__ out, int64_t n) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * 8 + (threadIdx.x >> 5);
+  const int x = threadIdx.x & 31;
+  if (t >= n) return;
+  const f32x4 u = *reinterpret_cast<const f32x4*>(a + ia[t] * HD + 4 * x);
+  const f32x4 v = *reinterpret_cast<const f32x4*>(b + ib[t] * HD + 4 * x);
+  float s = (u[0] * v[0] + u[1] * v[1]) + (u[2] * v[2] + u[3] * v[3]);
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (x == 0) out[t] = s;
+}
+
 }  // namespace
 
 static int gather_check(const char* who, const void* zh, const void* zt, const void* w, const void* head, const void* tail,
@@ -187,7 +205,7 @@ extern "C" int mdg_bilinear_gather(const float* z_head, const float* z_tail, con
   if (n_tiles == 0) return MDG_OK;
   MDG_CHECK_ARG(score, "mdg_bilinear_gather: null score");
   GatherArgs a{z_head, z_tail, w, w, head, tail, tile_start, tile_label, n_tiles, score, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(bilinear_gather_kernel<false>, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0,
+  hipLaunchKernelGGL(bilinear_gather_kernel<0>, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   MDG_CHECK_LAUNCH("mdg_bilinear_gather");
   return MDG_OK;
@@ -205,10 +223,10 @@ extern "C" int mdg_bilinear_gather_bwd(const float* z_head, const float* z_tail,
     MDG_CHECK_ARG(w_t && dscore && gz_head_rows && gz_tail_rows && mdg_aligned16(w_t) && mdg_aligned16(gz_head_rows) && mdg_aligned16(gz_tail_rows),
                   "mdg_bilinear_gather_bwd: null / misaligned pointer");
     GatherArgs a{z_head, z_tail, w, w_t, head, tail, tile_start, tile_label, n_tiles, nullptr, dscore, gz_head_rows, gz_tail_rows};
-    hipLaunchKernelGGL(bilinear_gather_kernel<true>, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bilinear_gather_kernel<1>, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0, st, a);
   }
   if (dw) {
-    MDG_CHECK_ARG(label_chunk_ptr && (n_chunks == 0 || (chunk_start && dw_partial && dscore)), "mdg_bilinear_gather_bwd: dW needs the chunk tables and scratch");
+    MDG_CHECK_ARG(label_chunk_ptr && (n_chunks == 0 || (chunk_start && dw_partial)), "mdg_bilinear_gather_bwd: dW needs the chunk tables and scratch");
     if (n_chunks > 0)
       hipLaunchKernelGGL(bilinear_gather_dw_kernel, dim3(static_cast<unsigned>(n_chunks)), dim3(256), 0, st, z_head, z_tail, head, tail, dscore,
                          chunk_start, dw_partial);
@@ -217,6 +235,30 @@ extern "C" int mdg_bilinear_gather_bwd(const float* z_head, const float* z_tail,
                          label_chunk_ptr, dw);
   }
   MDG_CHECK_LAUNCH("mdg_bilinear_gather_bwd");
+  return MDG_OK;
+}
+
+extern "C" int mdg_bilinear_matvec_rows(const float* z, const float* w, const int64_t* row_index, const int64_t* tile_start,
+                                        const int64_t* tile_label, int64_t n_tiles, float* rows_out, int64_t D, void* stream) {
+  MDG_CHECK_ARG(D == HD, "mdg_bilinear_matvec_rows: D must be 128 (got %lld)", (long long)D);
+  MDG_CHECK_ARG(n_tiles >= 0, "mdg_bilinear_matvec_rows: negative tile count");
+  if (n_tiles == 0) return MDG_OK;
+  MDG_CHECK_ARG(z && w && tile_start && tile_label && rows_out && mdg_aligned16(z) && mdg_aligned16(w) && mdg_aligned16(rows_out),
+                "mdg_bilinear_matvec_rows: null / misaligned pointer");
+  GatherArgs a{z, z, w, w, row_index, row_index, tile_start, tile_label, n_tiles, nullptr, nullptr, rows_out, nullptr};
+  hipLaunchKernelGGL(bilinear_gather_kernel<2>, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  MDG_CHECK_LAUNCH("mdg_bilinear_matvec_rows");
+  return MDG_OK;
+}
+
+extern "C" int mdg_gather_rowdot(const float* a, const int64_t* ia, const float* b, const int64_t* ib, float* out, int64_t n, int64_t D,
+                                 void* stream) {
+  MDG_CHECK_ARG(D == HD && n >= 0, "mdg_gather_rowdot: D must be 128, n >= 0");
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(a && ia && b && ib && out && mdg_aligned16(a) && mdg_aligned16(b), "mdg_gather_rowdot: null / misaligned pointer");
+  hipLaunchKernelGGL(gather_rowdot_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 8))), dim3(256), 0, static_cast<hipStream_t>(stream), a, ia, b, ib,
+                     out, n);
+  MDG_CHECK_LAUNCH("mdg_gather_rowdot");
   return MDG_OK;
 }
 

@@ -541,6 +541,23 @@ def transpose(x: torch.Tensor, pad_inner: bool = True) -> torch.Tensor:
     return out
 
 
+_wt_cache = {}
+
+
+def weight_transposed(w: torch.Tensor) -> torch.Tensor:
+    """``transpose(w)`` of a parameter, kept per (storage, in-place version): a step differentiates every layer once per
+    side / view, so each weight's transpose is needed two or three times between two optimizer updates (which bump the
+    version).  The entry keeps ``w`` alive, so its address cannot be recycled under the cache; a new version of the same
+    parameter replaces the old entry (memory: one transposed copy per Linear weight)."""
+    k = (w.data_ptr(), tuple(w.shape), str(w.device))
+    hit = _wt_cache.get(k)
+    if hit is not None and hit[0] == w._version:
+        return hit[1]
+    t = transpose(w.detach())
+    _wt_cache[k] = (w._version, t, w)
+    return t
+
+
 def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, beta: float = 0.0) -> torch.Tensor:
     """Column sums of a 2-D tensor (fixed summation order): out = beta * out + x.sum(0)."""
     if x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32 or x.stride(1) != 1:
@@ -739,7 +756,38 @@ def triple_plan(labels: torch.Tensor, heads: torch.Tensor, tails: torch.Tensor, 
     tail_ptr, tail_rows = by_drug(ts, n_tail)
     inv = torch.empty_like(perm)
     inv[perm] = torch.arange(T, device=dev)
-    return {"T": T, "L": n_labels, "n_head": n_head, "n_tail": n_tail, "perm": perm, "inv_perm": inv, "heads": hs, "tails": ts,
+    # ---- (label, head drug) PAIRS: the batch holds more labelled triples than pairs, and every 128 x 128 product of the head
+    # depends on the pair only (bilinear_gather_pairs / _bwd).  Triples re-sorted by (label, head): pair p owns the triples
+    # pair_ptr[p] .. pair_ptr[p+1] of that order.
+    pairs = None
+    if T:
+        key = ls * n_head + hs
+        order = torch.argsort(key, stable=True)                    # positions in the label-sorted triple order
+        pkey, pcnt = torch.unique_consecutive(key[order], return_counts=True)
+        P = int(pkey.numel())
+        pair_label, pair_drug = pkey // n_head, (pkey % n_head).contiguous()
+        pair_ptr = torch.cat([zero, torch.cumsum(pcnt, 0)]).contiguous()
+        pair_of_sorted = torch.repeat_interleave(torch.arange(P, device=dev), pcnt)
+        pair_of_triple = torch.empty(T, dtype=torch.int64, device=dev)
+        pair_of_triple[order] = pair_of_sorted                     # label-sorted triple -> its pair
+        pcounts = torch.bincount(pair_label, minlength=n_labels)
+        plabel_ptr = torch.cat([zero, torch.cumsum(pcounts, 0)])
+
+        def pcut(size):
+            per = (pcounts + size - 1) // size
+            first = torch.cumsum(per, 0) - per
+            which = torch.repeat_interleave(lab, per)
+            start = plabel_ptr[which] + size * (torch.arange(which.numel(), device=dev) - first[which])
+            return per, which.contiguous(), torch.cat([start, torch.tensor([P], dtype=torch.int64, device=dev)]).contiguous()
+        _, ptile_label, ptile_start = pcut(32)
+        pchunks_per, _, pchunk_start = pcut(256)
+        drug_ptr, drug_rows = by_drug(pair_drug, n_head)
+        pairs = {"P": P, "drug": pair_drug, "ptr": pair_ptr, "order": order.contiguous(), "tails_by_pair": ts[order].contiguous(),
+                 "of_triple": pair_of_triple, "tile_start": ptile_start, "tile_label": ptile_label, "n_tiles": int(ptile_label.numel()),
+                 "chunk_start": pchunk_start, "n_chunks": int(pchunk_start.numel()) - 1,
+                 "label_chunk_ptr": torch.cat([zero, torch.cumsum(pchunks_per, 0)]).contiguous(), "drug_ptr": drug_ptr, "drug_rows": drug_rows,
+                 "of_triple_by_tail": pair_of_triple[tail_rows].contiguous()}
+    return {"T": T, "L": n_labels, "n_head": n_head, "n_tail": n_tail, "perm": perm, "inv_perm": inv, "heads": hs, "tails": ts, "pairs": pairs,
             "tile_start": tile_start, "tile_label": tile_label, "n_tiles": int(tile_label.numel()), "chunk_start": chunk_start,
             "n_chunks": int(chunk_start.numel()) - 1, "label_chunk_ptr": label_chunk_ptr, "head_ptr": head_ptr,
             "head_rows": head_rows, "tail_ptr": tail_ptr, "tail_rows": tail_rows}
@@ -777,6 +825,59 @@ def bilinear_gather_bwd(z_head, z_tail, w, plan: dict, dscore: torch.Tensor, w_t
     dzh = csr_aggregate(gh, plan["head_ptr"], plan["head_rows"])
     dzt = csr_aggregate(gt, plan["tail_ptr"], plan["tail_rows"])
     return dzh, dzt, dw
+
+
+def bilinear_gather_pairs(z_head: torch.Tensor, z_tail: torch.Tensor, w: torch.Tensor, plan: dict, w_t: Optional[torch.Tensor] = None):
+    """The scores of bilinear_gather through the (label, head drug) pairs: V[p] = W[l_p]^T z_head[i_p] once per pair (the 128 x 128
+    product), then score[t] = V[pair(t)] . z_tail[t_t].  -> (score [T] in the plan's order, V [P,128] for the backward pass)."""
+    zh, zt, w = _f32_cuda(z_head, "z_head", 2), _f32_cuda(z_tail, "z_tail", 2), _f32_cuda(w, "w", 3)
+    if zh.shape != (plan["n_head"], 128) or zt.shape != (plan["n_tail"], 128) or w.shape != (plan["L"], 128, 128):
+        raise ValueError("bilinear_gather_pairs: operands disagree with the plan (D must be 128)")
+    pp = plan["pairs"]
+    score = torch.empty(plan["T"], dtype=torch.float32, device=zh.device)
+    if pp is None:
+        return score, torch.empty((0, 128), dtype=torch.float32, device=zh.device)
+    wt = w if w_t is None else _f32_cuda(w_t, "w_t", 3)
+    V = torch.empty((pp["P"], 128), dtype=torch.float32, device=zh.device)
+    L_ = lib()
+    check(L_.mdg_bilinear_matvec_rows(_ptr(zh), _ptr(wt), _ptr(pp["drug"]), _ptr(pp["tile_start"]), _ptr(pp["tile_label"]), _c64(pp["n_tiles"]),
+                                      _ptr(V), _c64(128), _stream(zh)), "mdg_bilinear_matvec_rows")
+    check(L_.mdg_gather_rowdot(_ptr(V), _ptr(pp["of_triple"]), _ptr(zt), _ptr(plan["tails"]), _ptr(score), _c64(plan["T"]), _c64(128),
+                               _stream(zh)), "mdg_gather_rowdot")
+    return score, V
+
+
+def bilinear_gather_pairs_bwd(z_head, z_tail, w, plan: dict, dscore: torch.Tensor, V: torch.Tensor, need_dw: bool = True):
+    """Backward of bilinear_gather_pairs -> (dz_head, dz_tail, dw | None), one 128 x 128 product per PAIR:
+        dz_tail[j]  = sum_{t: tail = j} ds_t V[pair(t)]                      (V = W^T z_head: saved by the forward pass)
+        u[p]        = sum_{t in pair p} ds_t z_tail[t_t]
+        dz_head[i]  = sum_{p: drug = i} W[l_p] u[p]
+        dW[l]       = sum_{p: label = l} z_head[i_p] u[p]^T
+    Sums run in fixed (sorted) order, no atomics."""
+    zh, zt, w = _f32_cuda(z_head, "z_head", 2), _f32_cuda(z_tail, "z_tail", 2), _f32_cuda(w, "w", 3)
+    ds = _f32_cuda(dscore, "dscore", 1)
+    T, L, dev = plan["T"], plan["L"], zh.device
+    if ds.numel() != T:
+        raise ValueError("dscore: one entry per triple expected")
+    pp = plan["pairs"]
+    if pp is None:
+        z = torch.zeros
+        return z((plan["n_head"], 128), device=dev), z((plan["n_tail"], 128), device=dev), (z((L, 128, 128), device=dev) if need_dw else None)
+    dzt = csr_aggregate(V, plan["tail_ptr"], pp["of_triple_by_tail"], edge_weight=ds.index_select(0, plan["tail_rows"]))
+    u = csr_aggregate(zt, pp["ptr"], pp["tails_by_pair"], edge_weight=ds.index_select(0, pp["order"]))
+    R = torch.empty((pp["P"], 128), dtype=torch.float32, device=dev)
+    L_ = lib()
+    check(L_.mdg_bilinear_matvec_rows(_ptr(u), _ptr(w), _ptr(None), _ptr(pp["tile_start"]), _ptr(pp["tile_label"]), _c64(pp["n_tiles"]), _ptr(R),
+                                      _c64(128), _stream(zh)), "mdg_bilinear_matvec_rows")
+    dzh = csr_aggregate(R, pp["drug_ptr"], pp["drug_rows"])
+    dw = None
+    if need_dw:
+        dw = torch.empty((L, 128, 128), dtype=torch.float32, device=dev)
+        part = torch.empty((max(pp["n_chunks"], 1), 128, 128), dtype=torch.float32, device=dev)
+        check(L_.mdg_bilinear_gather_bwd(_ptr(zh), _ptr(u), _ptr(w), _ptr(w), _ptr(pp["drug"]), _ptr(None), _ptr(None), _ptr(None), _c64(0),
+                                         _ptr(pp["chunk_start"]), _c64(pp["n_chunks"]), _ptr(pp["label_chunk_ptr"]), _c64(L), _ptr(None),
+                                         _ptr(None), _ptr(None), _ptr(part), _ptr(dw), _c64(128), _stream(zh)), "mdg_bilinear_gather_bwd")
+    return dzh[:, :128], dzt[:, :128], dw
 
 
 def bce_logits(score: torch.Tensor, target: torch.Tensor, want_term: bool = True, grad_scale: Optional[float] = None):
