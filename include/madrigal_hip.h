@@ -294,6 +294,13 @@ size_t mdg_grad_weight_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int mdg_grad_weight(const float* g, int64_t ldg, const float* x, int64_t ldx, float* dw, float* dbias, int64_t M, int64_t N,
                     int64_t K, void* workspace, size_t workspace_bytes, void* stream);
 
+/* y[N,K] = g^T x for row-major g [M,N] (row stride ldg) and x [M,K]: the weight gradient dW = dY^T X of a wide layer
+ * (autograd of nn.Linear).  Both operands are re-laid out (reduction index M innermost, padded to 64) by one transposing pack
+ * launch, then the mdg_linear tile kernel runs: no separate transposes of g and x. */
+size_t mdg_linear_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision);
+int mdg_linear_tn(const float* g, int64_t ldg, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                  int precision, void* workspace, size_t workspace_bytes, void* stream);
+
 /* out[c, r] = in[r, c]   (dW = dY^T X and dX = dY W are mdg_linear calls on transposed operands) */
 int mdg_transpose(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t rows, int64_t cols, void* stream);
 

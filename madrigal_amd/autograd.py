@@ -543,6 +543,9 @@ def gated_residual(o, x, skip):
     return _GatedResidual.apply(o, x, skip)
 
 
+_gather_plan = {}
+
+
 class _GatherRows(Function):
     """table[idx] with repeated indices (embedding lookup).  torch's own backward scatters with atomics (run-to-run
     different low bits); here the gradient rows are summed per table row in index order by mdg_csr_aggregate."""
@@ -557,12 +560,20 @@ class _GatherRows(Function):
     @once_differentiable
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
-        order = torch.argsort(idx, stable=True)
-        # row pointers by binary search in the sorted indices: no host synchronisation (torch.bincount reads the maximum
-        # back to the host, which would stall the launch queue in the middle of the backward pass)
-        rowptr = torch.searchsorted(idx[order], torch.arange(ctx.n_rows + 1, device=idx.device))
+        # the index tensor of an embedding lookup is fixed for a run (cell-line ids of the tx stack): its sort is kept per
+        # (storage, version, table size); the entry holds the tensor, so the address cannot be recycled under it
+        key = (idx.data_ptr(), idx._version, idx.numel(), ctx.n_rows)
+        hit = _gather_plan.get("last")
+        if hit is None or hit[0] != key:
+            order = torch.argsort(idx, stable=True)
+            # row pointers by binary search in the sorted indices: no host synchronisation (torch.bincount reads the maximum
+            # back to the host, which would stall the launch queue in the middle of the backward pass)
+            rowptr = torch.searchsorted(idx[order], torch.arange(ctx.n_rows + 1, device=idx.device))
+            hit = (key, order.contiguous(), rowptr, idx)
+            _gather_plan["last"] = hit
+        order, rowptr = hit[1], hit[2]
         dout = dout if dout.is_contiguous() else dout.contiguous()
-        return ops.csr_aggregate(dout, rowptr, order.contiguous())[:, :dout.shape[1]], None
+        return ops.csr_aggregate(dout, rowptr, order)[:, :dout.shape[1]], None
 
 
 def gather_rows(table, idx):

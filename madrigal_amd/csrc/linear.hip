@@ -277,7 +277,57 @@ __global__ __launch_bounds__(256) void prep_operands_kernel(const PrepArgs p) {
   }
 }
 
+// Transposing pack: source [M rows][C columns] row-major (row stride ld); image of the TRANSPOSED operand, rows c = 0..C-1 with
+// the inner index m padded to Mp (a multiple of 32), as fp32 or as bf16 hi (+ lo) planes.  64 x 64 tiles through LDS: global
+// reads run along the source rows, image writes along the image rows (8 bytes per lane, bf16).  grid = (Mp/64 tiles, C tiles, operands).
+struct PrepTArgs {
+  const float* src[2]; int64_t ld[2]; int64_t C[2];
+  char* dst0[2]; char* dst1[2];
+  int64_t M, Mp;
+  int bf16;
+};
+
+__global__ __launch_bounds__(256) void prep_transposed_kernel(const PrepTArgs p) {
+  __shared__ float tile[64][65];
+  const int which = blockIdx.z;
+  const int64_t c0 = static_cast<int64_t>(blockIdx.y) * 64, m0 = static_cast<int64_t>(blockIdx.x) * 64;
+  if (c0 >= p.C[which]) return;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;            // 64 x 4
+  const float* src = p.src[which];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t m = m0 + ty + 4 * i, c = c0 + tx;
+    tile[ty + 4 * i][tx] = (m < p.M && c < p.C[which]) ? src[m * p.ld[which] + c] : 0.f;
+  }
+  __syncthreads();
+  // image row c, inner index m: thread handles 4 consecutive m of one c
+  const int cm = threadIdx.x >> 4, mq = (threadIdx.x & 15) * 4;        // 16 rows x 16 quads per pass
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cl = cm + 16 * i;
+    const int64_t c = c0 + cl;
+    if (c >= p.C[which]) continue;
+    const f32x4 v = {tile[mq][cl], tile[mq + 1][cl], tile[mq + 2][cl], tile[mq + 3][cl]};
+    const int64_t off = c * p.Mp + m0 + mq;
+    if (p.bf16) {
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        __bf16 a, b;
+        mdg_split_bf16(v[e], a, b);
+        hi[e] = a;
+        lo[e] = b;
+      }
+      *reinterpret_cast<bf16x4*>(p.dst0[which] + off * 2) = hi;
+      if (p.dst1[which]) *reinterpret_cast<bf16x4*>(p.dst1[which] + off * 2) = lo;
+    } else {
+      *reinterpret_cast<f32x4*>(p.dst0[which] + off * 4) = v;
+    }
+  }
+}
+
 inline size_t al256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+inline int64_t pad64(int64_t k) { return (k + 63) / 64 * 64; }
 inline int64_t pad32(int64_t k) { return (k + 31) / 32 * 32; }
 
 // ---- LayerNorm: one wave per row -------------------------------------------------------------
@@ -359,6 +409,39 @@ static void set_operand(Operand& o, const float* raw, int64_t ld, const char* im
   o.ld_bytes = Kp * static_cast<int64_t>(es);
 }
 
+static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t N, hipStream_t st) {
+  // tile shape: the 256x256 / 8-wave shape once the problem fills the chip with it, else 128x128 / 4 waves
+  // (measured on the fusion GEMMs: bf16x3 -9 % time with the big tile, fp32 +6 %: the fp32 MFMA wants two workgroups per CU)
+  bool big = (precision != MDG_PREC_F32 && N >= 256 && M >= 1024 && mdg_cdiv(M, Big::BM) * mdg_cdiv(N, Big::BN) >= 192);
+  if (const char* e = getenv("MDG_LINEAR_TILE")) big = atoi(e) == 256 ? true : (atoi(e) == 128 ? false : big);
+  // 1-D grid; the kernel maps the linear workgroup id to a tile (XCD-aware order once there are enough tiles to matter)
+  static const int swz_env = getenv("MDG_LINEAR_SWIZZLE") ? atoi(getenv("MDG_LINEAR_SWIZZLE")) : -1;
+  const auto grid_for = [&](int bm, int bn) {
+    a.tiles_x = static_cast<int>(mdg_cdiv(N, bn));
+    a.tiles_y = static_cast<int>(mdg_cdiv(M, bm));
+    const int total = a.tiles_x * a.tiles_y;
+    a.swizzle = swz_env >= 0 ? swz_env : (total >= 64 ? 1 : 0);
+    return dim3(static_cast<unsigned>(a.swizzle ? 8 * ((total + 7) / 8) : total));
+  };
+  if (big) {
+    const dim3 grid = grid_for(Big::BM, Big::BN);
+    const size_t lds = 2 * Big::STAGE;
+    switch (precision) {
+      case MDG_PREC_F32: hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, Big>), grid, dim3(Big::THREADS), lds, st, a); break;
+      case MDG_PREC_BF16X3: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, Big>), grid, dim3(Big::THREADS), lds, st, a); break;
+      default: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, Big>), grid, dim3(Big::THREADS), lds, st, a); break;
+    }
+  } else {
+    const dim3 grid = grid_for(Small::BM, Small::BN);
+    const size_t lds = 2 * Small::STAGE;
+    switch (precision) {
+      case MDG_PREC_F32: hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, Small>), grid, dim3(Small::THREADS), lds, st, a); break;
+      case MDG_PREC_BF16X3: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, Small>), grid, dim3(Small::THREADS), lds, st, a); break;
+      default: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, Small>), grid, dim3(Small::THREADS), lds, st, a); break;
+    }
+  }
+}
+
 extern "C" size_t mdg_pack_operand_bytes(int64_t rows, int64_t K, int precision) { return image_bytes(rows, K, precision); }
 
 extern "C" int mdg_pack_operand(const float* src, int64_t ld, int64_t rows, int64_t K, int precision, void* dst, size_t dst_bytes,
@@ -418,37 +501,52 @@ extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t l
   a.alpha = alpha; a.beta = beta; a.act = act; a.M = M; a.N = N; a.K = pad32(K);
   set_operand(a.A, x, ldx, ximg, M, K, precision);
   set_operand(a.B, w, ldw, wb == 0 ? nullptr : (w_packed ? static_cast<const char*>(w_packed) : wimg), N, K, precision);
-  // tile shape: the 256x256 / 8-wave shape once the problem fills the chip with it, else 128x128 / 4 waves
-  // (measured on the fusion GEMMs: bf16x3 -9 % time with the big tile, fp32 +6 %: the fp32 MFMA wants two workgroups per CU)
-  bool big = (precision != MDG_PREC_F32 && N >= 256 && M >= 1024 && mdg_cdiv(M, Big::BM) * mdg_cdiv(N, Big::BN) >= 192);
-  if (const char* e = getenv("MDG_LINEAR_TILE")) big = atoi(e) == 256 ? true : (atoi(e) == 128 ? false : big);
-  // 1-D grid; the kernel maps the linear workgroup id to a tile (XCD-aware order once there are enough tiles to matter)
-  static const int swz_env = getenv("MDG_LINEAR_SWIZZLE") ? atoi(getenv("MDG_LINEAR_SWIZZLE")) : -1;
-  const auto grid_for = [&](int bm, int bn) {
-    a.tiles_x = static_cast<int>(mdg_cdiv(N, bn));
-    a.tiles_y = static_cast<int>(mdg_cdiv(M, bm));
-    const int total = a.tiles_x * a.tiles_y;
-    a.swizzle = swz_env >= 0 ? swz_env : (total >= 64 ? 1 : 0);
-    return dim3(static_cast<unsigned>(a.swizzle ? 8 * ((total + 7) / 8) : total));
-  };
-  if (big) {
-    const dim3 grid = grid_for(Big::BM, Big::BN);
-    const size_t lds = 2 * Big::STAGE;
-    switch (precision) {
-      case MDG_PREC_F32: hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, Big>), grid, dim3(Big::THREADS), lds, st, a); break;
-      case MDG_PREC_BF16X3: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, Big>), grid, dim3(Big::THREADS), lds, st, a); break;
-      default: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, Big>), grid, dim3(Big::THREADS), lds, st, a); break;
-    }
-  } else {
-    const dim3 grid = grid_for(Small::BM, Small::BN);
-    const size_t lds = 2 * Small::STAGE;
-    switch (precision) {
-      case MDG_PREC_F32: hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, Small>), grid, dim3(Small::THREADS), lds, st, a); break;
-      case MDG_PREC_BF16X3: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, Small>), grid, dim3(Small::THREADS), lds, st, a); break;
-      default: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, Small>), grid, dim3(Small::THREADS), lds, st, a); break;
-    }
-  }
+  launch_linear_core(a, precision, M, N, st);
   MDG_CHECK_LAUNCH("mdg_linear");
+  return MDG_OK;
+}
+
+// ---- TN product: y[N,K] = g^T x for row-major g [M,N], x [M,K] (weight gradients of the wide layers) -----------------------
+static size_t image_bytes_t(int64_t rows, int64_t inner, int precision) {      // always a full image (the inner index is re-laid out)
+  if (rows <= 0 || inner <= 0) return 0;
+  const size_t Mp = static_cast<size_t>(pad64(inner));
+  if (precision == MDG_PREC_F32) return al256(static_cast<size_t>(rows) * Mp * 4);
+  return (precision == MDG_PREC_BF16X3 ? 2 : 1) * al256(static_cast<size_t>(rows) * Mp * 2);
+}
+
+extern "C" size_t mdg_linear_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision) {
+  return image_bytes_t(N, M, precision) + image_bytes_t(K, M, precision);
+}
+
+extern "C" int mdg_linear_tn(const float* g, int64_t ldg, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                             int precision, void* workspace, size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(M > 0 && N > 0 && K > 0, "mdg_linear_tn: empty operand");
+  MDG_CHECK_ARG(g && x && y && ldg >= N && ldx >= K && ldy >= K, "mdg_linear_tn: null pointer / short row stride");
+  MDG_CHECK_ARG(precision == MDG_PREC_F32 || precision == MDG_PREC_BF16X3 || precision == MDG_PREC_BF16, "mdg_linear_tn: unknown precision %d", precision);
+  MDG_CHECK_ARG(mdg_cdiv(N, Small::BM) * mdg_cdiv(K, Small::BN) < (1ll << 31) - 8 && mdg_cdiv(N, 64) < 65536, "mdg_linear_tn: too many tiles");
+  const size_t ab = image_bytes_t(N, M, precision), bb = image_bytes_t(K, M, precision);
+  if (!workspace || workspace_bytes < ab + bb || !mdg_aligned16(workspace)) {
+    mdg_set_error("mdg_linear_tn: workspace of %zu bytes (16-byte aligned) required, got %zu", ab + bb, workspace_bytes);
+    return MDG_EWORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* aimg = static_cast<char*>(workspace);
+  char* bimg = aimg + ab;
+  const int64_t Mp = pad64(M);
+  const bool bf = precision != MDG_PREC_F32, x3 = precision == MDG_PREC_BF16X3;
+  const size_t es = bf ? 2 : 4;
+  PrepTArgs pa{};
+  pa.src[0] = g; pa.ld[0] = ldg; pa.C[0] = N; pa.dst0[0] = aimg; pa.dst1[0] = x3 ? aimg + al256(static_cast<size_t>(N) * Mp * es) : nullptr;
+  pa.src[1] = x; pa.ld[1] = ldx; pa.C[1] = K; pa.dst0[1] = bimg; pa.dst1[1] = x3 ? bimg + al256(static_cast<size_t>(K) * Mp * es) : nullptr;
+  pa.M = M; pa.Mp = Mp; pa.bf16 = bf ? 1 : 0;
+  const int64_t cmax = N > K ? N : K;
+  hipLaunchKernelGGL(prep_transposed_kernel, dim3(static_cast<unsigned>(Mp / 64), static_cast<unsigned>(mdg_cdiv(cmax, 64)), 2), dim3(256), 0, st, pa);
+  LinearArgs a{};
+  a.y = y; a.ldy = ldy; a.alpha = 1.f; a.beta = 0.f; a.act = MDG_ACT_NONE; a.M = N; a.N = K; a.K = Mp;
+  a.A.p0 = aimg; a.A.p1 = pa.dst1[0]; a.A.ld_bytes = Mp * static_cast<int64_t>(es); a.A.nrows = N;
+  a.B.p0 = bimg; a.B.p1 = pa.dst1[1]; a.B.ld_bytes = Mp * static_cast<int64_t>(es); a.B.nrows = K;
+  launch_linear_core(a, precision, N, K, st);
+  MDG_CHECK_LAUNCH("mdg_linear_tn");
   return MDG_OK;
 }
 

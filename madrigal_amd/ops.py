@@ -990,7 +990,12 @@ def grad_weight(g: torch.Tensor, x: torch.Tensor, precision="f32", want_bias: bo
         raise ValueError("grad_weight: g and x disagree in the number of rows")
     M, N, K = g.shape[0], g.shape[1], x.shape[1]
     if _prec(precision) != PREC_F32 and ((N + 127) // 128) * ((K + 127) // 128) >= 96:
-        dw = linear(transpose(g), transpose(x), precision=precision, cache_weight=False)
+        prec = _prec(precision)
+        dw = torch.empty((N, K), dtype=torch.float32, device=g.device)
+        nbytes = lib().mdg_linear_tn_workspace_bytes(_c64(M), _c64(N), _c64(K), _c(prec))
+        ws = _workspace(nbytes, g.device)
+        check(lib().mdg_linear_tn(_ptr(g), _c64(g.stride(0)), _ptr(x), _c64(x.stride(0)), _ptr(dw), _c64(K), _c64(M), _c64(N), _c64(K),
+                                  _c(prec), _ptr(ws), ctypes.c_size_t(nbytes), _stream(g)), "mdg_linear_tn")
         return (dw, colsum(g)) if want_bias else dw
     dw = torch.empty((N, K), dtype=torch.float32, device=g.device)
     db = torch.empty(N, dtype=torch.float32, device=g.device) if want_bias else None

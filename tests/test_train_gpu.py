@@ -1315,3 +1315,18 @@ def test_sharing_dropout_free_encoders_between_sides_equals_two_passes(monkeypat
         else:
             assert float((b1[k] - v).abs().max()) <= 2e-6 * max(float(v.abs().max()), 1e-6), k
     assert any(int(v) == 2 for k, v in b0.items() if "num_batches" in k)
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("M,N,K", [(1000, 1300, 1280), (4097, 2048, 1024), (63, 1536, 1100)])
+def test_wide_weight_gradient_tn_product(M, N, K, prec, tol):
+    """dW = g^T x of the wide layers (>= 96 output tiles) goes through mdg_linear_tn: both operands re-laid out by ONE transposing
+    pack launch (reduction index padded to 64), then the tile GEMM.  Ragged M / N / K and strided row views included."""
+    from madrigal_amd import ops
+    g = _rand(M, N + 4, seed=1)[:, :N]            # strided rows
+    x = _rand(M, K, seed=2)
+    ref = g.double().T @ x.double()
+    got, db = ops.grad_weight(g.to(DEV), x.to(DEV), prec, want_bias=True)
+    assert got.shape == (N, K)
+    _close(got, ref, tol, "dW")
+    _close(db, g.double().sum(0), 1e-5, "db")
