@@ -115,10 +115,12 @@ ORACLE_CASE = {   # name, fusion, nb, pos, heads, head_dim, ffn, layers, norm_fi
 }
 
 
-def cpu_encode_fuse(params, batch, bkg, config: str, sample: int = 256):
+def cpu_encode_fuse(params, batch, bkg, config: str, sample: int = 64, kg_edge_keep: int = 16):
     """The oracle's encode+fuse (eval mode; same stages as NovelDDIEncoder.encode, madrigal/models/models.py:717-896) timed on
-    the host: the KG encoder once on the WHOLE graph (it is per graph, not per drug), the per-drug stages (GIN, cv MLP,
-    chemCPA tx encoder, token assembly + fusion transformer) on the first ``sample`` drugs and scaled linearly to N."""
+    the host on a bounded sample: the KG encoder (per graph, not per drug) on the graph thinned to every ``kg_edge_keep``-th
+    edge and scaled by that factor (its cost is edge-proportional: 209 s for the whole 8M-edge graph on 256 threads), the
+    per-drug stages (GIN, cv MLP, chemCPA tx encoder, token assembly + fusion transformer) on the first ``sample`` drugs
+    and scaled linearly to N."""
     import torch
     from madrigal_amd import data as D
     from madrigal_amd.pipeline import slice_batch
@@ -128,10 +130,11 @@ def cpu_encode_fuse(params, batch, bkg, config: str, sample: int = 256):
     enc = O._sub(params, "encoder.")
     kg = bkg["data"]
     N = int(batch["drugs"].shape[0])
+    thin = {k: v[:, ::kg_edge_keep].contiguous() for k, v in kg.edge_index_dict.items()}
     with torch.no_grad():
         t0 = time.perf_counter()
-        O.hgt_forward(O._sub(enc, "kg_encoder."), kg.x_dict, kg.edge_index_dict, kg.node_types, kg.edge_types, num_layers=2, heads=4, hidden=128)
-        t_kg = time.perf_counter() - t0
+        O.hgt_forward(O._sub(enc, "kg_encoder."), kg.x_dict, thin, kg.node_types, kg.edge_types, num_layers=2, heads=4, hidden=128)
+        t_kg = (time.perf_counter() - t0) * kg_edge_keep
         n = min(sample, N)
         b = slice_batch(batch, 0, n)
         mols = b["strs"]
@@ -148,7 +151,8 @@ def cpu_encode_fuse(params, batch, bkg, config: str, sample: int = 256):
                    num_layers=nl, num_heads=H, norm_first=nf, actn="gelu", proj=dict(n_hidden=2, norm="ln", actn="relu", dropout=0.2, order="nd"))
         O.fuse_modalities(enc, all_embeds, b["masks"], cfg)
         t_drug = time.perf_counter() - t0
-    return {"kg_encoder_s": t_kg, "per_drug_stages_s_on_sample": t_drug, "sample_drugs": n, "encode_fuse_s_extrapolated": t_kg + t_drug * N / n}
+    return {"kg_encoder_s": t_kg, "kg_edges_kept": f"1/{kg_edge_keep}", "per_drug_stages_s_on_sample": t_drug, "sample_drugs": n,
+            "encode_fuse_s_extrapolated": t_kg + t_drug * N / n}
 
 
 def cpu_baseline(n_drugs: int, n_outcomes: int, seconds: float = 12.0, encode=None):
@@ -183,22 +187,87 @@ def cpu_baseline(n_drugs: int, n_outcomes: int, seconds: float = 12.0, encode=No
             e = cpu_encode_fuse(*encode)
             total = float(n_drugs) * n_drugs * n_outcomes
             out.update(encode_fuse=e, value=total / (total / head_rate + e["encode_fuse_s_extrapolated"]))
-            out["sample"] += (f"; + oracle encode+fuse: HGT over the whole KG once ({e['kg_encoder_s']:.2f} s), GIN / cv / chemCPA / fusion on "
-                              f"{e['sample_drugs']} drugs scaled to {n_drugs}; value = whole job (encode+fuse + all scores) per second")
+            out["sample"] += (f"; + oracle encode+fuse: HGT on the KG thinned to {e['kg_edges_kept']} of its edges, scaled back ({e['kg_encoder_s']:.1f} s), "
+                              f"GIN / cv / chemCPA / fusion on {e['sample_drugs']} drugs scaled to {n_drugs}; value = whole job (encode+fuse + all scores) per second")
         except Exception as ex:
             out["encode_fuse"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     return out
 
 
-def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend="nccl"):
+def cpu_finetune_step(params, batch, bkg, config: str, n_outcomes: int, triples, sample: int = 128, kg_edge_keep: int = 8):
+    """One finetune step of the oracle on the host (torch CPU autograd over the restated forward with training-mode BatchNorm
+    statistics, BCE on the gathered logits, backward; the reference's step is exactly torch autograd over these ops,
+    train_ddi_batch.py:275-350), on a bounded sample: the first ``sample`` drugs on both sides with their share of the labelled
+    triples, and a KG thinned to every ``kg_edge_keep``-th edge.  Scaled to the full step: per-drug stages x N / sample, KG
+    encoder x kg_edge_keep (edge-proportional), head x triples / sampled triples."""
+    import torch
+    from madrigal_amd import data as D
+    from madrigal_amd.pipeline import slice_batch
+    from oracle import madrigal_oracle as O
+    from oracle.pipeline import oracle_encoders
+    case = ORACLE_CASE[config]
+    name, fusion, nb, pos, H, dh, ffn, nl, nf, agg, normalize, adapt = case
+    N = int(batch["drugs"].shape[0])
+    n = min(sample, N)
+    b = slice_batch(batch, 0, n)
+    kg = bkg["data"]
+    thin = D.KGData(kg.x_dict, {k: v[:, ::kg_edge_keep].contiguous() for k, v in kg.edge_index_dict.items()}, list(kg.node_types), list(kg.edge_types))
+    lab, hd, tl, y = triples
+    keep = ((hd < n) & (tl < n)).nonzero().flatten()[: 20_000]          # (w[lab] materialises 64 KB per sampled triple on the host)
+    lab, hd, tl, y = lab[keep], hd[keep], tl[keep], y[keep]
+    pr = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in params.items()}
+    enc = O._sub(pr, "encoder.")
+    if pos == "sinusoidal":
+        enc["pos_encoder.pe"] = O.sinusoidal_pe_table(128, (D.NUM_MODALITIES if nb == 0 else D.NUM_NON_TX_MODALITIES), nb, agg)
+    cfg = dict(fusion=fusion, normalize=normalize, adapt_before_fusion=adapt, pos_emb_type=pos, num_tx_bottlenecks=nb, agg=agg,
+               num_layers=nl, num_heads=H, norm_first=nf, actn="gelu", proj=dict(n_hidden=2, norm="ln", actn="relu", dropout=0.2, order="nd"))
+    filler = torch.zeros(max(int(b["drugs"].max()) + 1, int(bkg["drug_index_map"].max()) + 1), 128)
+    t = {}
+    with O.batch_statistics():
+        t0 = time.perf_counter()
+        kg_valid = O.hgt_forward(O._sub(enc, "kg_encoder."), thin.x_dict, thin.edge_index_dict, thin.node_types, thin.edge_types,
+                                 num_layers=2, heads=4, hidden=128)["drug"]
+        t["kg_fwd"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        zs = []
+        for _side in range(2):                         # head side and tail side, as the reference encodes them
+            mols = b["strs"]
+            str_out = O.gin_forward(O._sub(enc, "str_encoder."), mols.node_feature, mols.edge_list, mols.edge_feature, mols.node2graph,
+                                    mols.batch_size, num_layers=4, num_mlp_layer=3)["graph_feature"]
+            kg_out = O.place_kg_rows(kg_valid, bkg["drug_index_map"], b["drugs"], filler)
+            cv_out = O.mlp_encoder_forward(O._sub(enc, "cv_encoder."), b["cv"], 2, None, "relu", 0.2)
+            sigs = torch.cat([b["tx"][c]["sigs"] for c in D.CELL_LINES])
+            _, _, _, treated = O.chemcpa_predict(O._sub(enc, "tx_encoder."), sigs, torch.arange(16).repeat_interleave(n), 3, 3, with_decoder=False)
+            all_embeds = torch.stack([str_out, kg_out, cv_out] + list(treated.split(n)), dim=1)
+            zs.append(O.fuse_modalities(enc, all_embeds, b["masks"], cfg))
+        t["encode_fwd"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        w = O.symmetric(pr["decoder.parametrizations.weight.original"])
+        s = torch.einsum("td,tde,te->t", zs[0][hd], w[lab], zs[1][tl])
+        loss = torch.nn.BCELoss()(torch.sigmoid(s), y)
+        t["head_fwd"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    loss.backward()
+    t["backward"] = time.perf_counter() - t0
+    fwd = t["kg_fwd"] + t["encode_fwd"] + t["head_fwd"]
+    bwd_over_fwd = t["backward"] / max(fwd, 1e-9)
+    T_full = int(triples[0].numel())
+    est = ((t["kg_fwd"] * kg_edge_keep + t["encode_fwd"] * N / n + t["head_fwd"] * T_full / max(int(keep.numel()), 1)) * (1.0 + bwd_over_fwd))
+    return {"step_s_extrapolated": est, "steps_per_s": 1.0 / est, "measured_s": t, "sample_drugs": n, "sample_triples": int(keep.numel()),
+            "kg_edges_kept": f"1/{kg_edge_keep}", "loss": float(loss.detach())}
+
+
+def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend="nccl", precision="bf16"):
     """DDI-finetune steps/s on the same model and batch (train_ddi_batch.py:275-350, 'full_full' mode): zero_grad ->
     encode head and tail side (training mode: dropout, BatchNorm batch statistics) -> scores of the labelled triples
     (gathered head) -> BCE -> backward through every encoder -> AdamW over the reference's parameter groups.
+    ``precision``: BASELINE configs[1] names bf16 for this step -- GEMM operands rounded to bf16, fp32 accumulation, fp32 master
+    weights, optimizer state and gathered head; "bf16x3" is the fp32-grade arithmetic of the inference headline.
     world > 1: the SAME step data-parallel (strong scaling): drug-sharded encoders with SyncBatchNorm, all-gather of the
     embeddings, triples dealt to the ranks, flat all-reduce of the gradients (madrigal_amd/train.py)."""
     import torch
     import torch.distributed as dist
-    from madrigal_amd import data as D
+    from madrigal_amd import data as D, models as M, ops
     from madrigal_amd.optim import create_optimizer
     from madrigal_amd.train import FinetuneStep
     dev = batch["cv"].device
@@ -212,14 +281,15 @@ def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend
               wd=1e-2, beta1=0.9, beta2=0.999, eps=1e-8)
     fs = FinetuneStep(model, create_optimizer(model, hp), rank=rank, world=world)
     torch.manual_seed(4321 + rank)
-    losses = [float(fs.step(batch, batch, batch["masks"], batch["masks"], bkg, lab, hd, tl, y, kg_filler=filler))]     # warm-up
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.finetune_steps):
-        losses.append(fs.step(batch, batch, batch["masks"], batch["masks"], bkg, lab, hd, tl, y, kg_filler=filler))
-    torch.cuda.synchronize()
+    with M.precision(precision):
+        losses = [float(fs.step(batch, batch, batch["masks"], batch["masks"], bkg, lab, hd, tl, y, kg_filler=filler))]     # warm-up
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.finetune_steps):
+            losses.append(fs.step(batch, batch, batch["masks"], batch["masks"], bkg, lab, hd, tl, y, kg_filler=filler))
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -228,13 +298,38 @@ def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     dt /= args.finetune_steps
-    return {"metric": "DDI-finetune steps/sec", "value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "n_gpus": world,
-            "scaling": "strong", "steps": args.finetune_steps, "warmup": 1, "triples_per_step": T, "drugs": N, "outcomes": L,
-            "loss_first_last": [float(losses[0]), float(losses[-1])],
-            "parallelism": "single GPU" if world == 1 else
-            f"drug-sharded encoders (SyncBatchNorm), all-gather(z) / reduce-scatter(dz), triples dealt to {world} ranks, flat gradient all-reduce",
-            "work": "optimizer.zero_grad, encode+fuse head side and tail side (training mode), gathered bilinear head on the "
-                    "labelled triples, BCE, backward through all encoders, AdamW step"}
+    out = {"metric": "DDI-finetune steps/sec", "value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "n_gpus": world,
+           "scaling": "strong", "steps": args.finetune_steps, "warmup": 1, "triples_per_step": T, "drugs": N, "outcomes": L,
+           "dtype": {"bf16": "bf16 GEMM operands, fp32 accumulate / master weights / optimizer / gathered head", "bf16x3": "f32 via split-bf16 (bf16x3) MFMA",
+                     "f32": "f32"}[precision],
+           "loss_first_last": [float(losses[0]), float(losses[-1])],
+           "parallelism": "single GPU" if world == 1 else
+           f"drug-sharded encoders (SyncBatchNorm), all-gather(z) / reduce-scatter(dz), triples dealt to {world} ranks, flat gradient all-reduce",
+           "work": "optimizer.zero_grad, encode+fuse head side and tail side (training mode), gathered bilinear head on the "
+                   "labelled triples, BCE, backward through all encoders, AdamW step"}
+    if rank == 0 and world == 1:
+        # roofline of the step's dominant kernel, the wide fusion-transformer GEMM (linear_kernel<bf16, 256x256 tile>; 14 of the
+        # 69 ms of kernel time, profiles/): one FFN-sized launch at the step's own row count, HIP events on its stream
+        live = int((~batch["masks"]).sum()) + int(model.encoder.num_tx_bottlenecks) * N            # live fusion tokens of one side
+        d = int(model.encoder.transformer.embed2latent.weight.shape[0])
+        x = torch.randn(live, d, device=dev)
+        w = torch.randn(d, d, device=dev) * d ** -0.5
+        with torch.no_grad():
+            for _ in range(2):
+                ops.linear(x, w, precision=precision, cache_weight=False)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                ops.linear(x, w, precision=precision, cache_weight=False)
+            e1.record()
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        ach = 2.0 * live * d * d / (ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                           "traffic": None, "kernel": "linear_kernel (wide fusion-transformer GEMM, operand pack included)", "kernel_ms": ms,
+                           "shape": [live, d, d], "formula": "2 M N K flop / launch time; peak = dense bf16 MFMA"
+                           + ("; the split-bf16 mode issues 3 products per element" if precision == "bf16x3" else "")}
+    return out
 
 
 def main():
@@ -257,6 +352,8 @@ def main():
     ap.add_argument("--stress-drugs", type=int, default=100_352, help="BASELINE configs[4] row-statistics run; 0 = skip")
     ap.add_argument("--stress-outcomes", type=int, default=1024)
     ap.add_argument("--stress-precision", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--finetune-precision", default="bf16", choices=["bf16", "bf16x3", "f32"], help="BASELINE configs[1] names bf16 for the "
+                    "finetune step; the line also carries the bf16x3 (fp32-grade) step under finetune.fp32_grade")
     ap.add_argument("--finetune-triples", type=int, default=1_000_000, help="positive triples; with 2 negatives each and both "
                     "directions (the reference's collation) 6x as many labelled triples per step")
     args = ap.parse_args()
@@ -379,7 +476,20 @@ def main():
     finetune = None
     if args.finetune_steps > 0 and not args.head_only:
         try:
-            finetune = finetune_leg(model, batch, bkg, filler, N, L, args, rank, world, backend)
+            finetune = finetune_leg(model, batch, bkg, filler, N, L, args, rank, world, backend, precision=args.finetune_precision)
+            if args.finetune_precision != "bf16x3":
+                second = finetune_leg(model, batch, bkg, filler, N, L, args, rank, world, backend, precision="bf16x3")
+                finetune["fp32_grade"] = {k: second[k] for k in ("value", "unit", "ms_per_step", "dtype", "loss_first_last")}
+            if world == 1 and not args.no_cpu_baseline and cpu_inputs is not None:
+                try:
+                    trip = tuple(t.cpu() for t in D.make_labelled_triples(N, L, args.finetune_triples, 0))
+                    c = cpu_finetune_step(cpu_inputs[0], cpu_inputs[1], cpu_inputs[2], args.config, L, trip)
+                    finetune["cpu_baseline"] = {"value": c["steps_per_s"], "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
+                                                "sample": f"oracle training step (torch CPU autograd, fp32) on {c['sample_drugs']} drugs per side, "
+                                                          f"{c['sample_triples']} labelled triples, KG thinned to {c['kg_edges_kept']} of its edges; scaled to "
+                                                          f"{N} drugs / {finetune['triples_per_step']} triples / the full KG", "detail": c}
+                except Exception as e:
+                    finetune["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
         except Exception as e:          # the headline line must survive a failure of the secondary leg
             finetune = {"metric": "DDI-finetune steps/sec", "value": None, "error": f"{type(e).__name__}: {e}"[:400]}
     stress = None
