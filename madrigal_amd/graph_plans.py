@@ -108,7 +108,7 @@ def transposed_csr(rowptr: torch.Tensor, col, w, n_src: int, mean: bool = False)
     return {"rowptr": _rowptr(src[order], n_src), "col": row_of_edge[order].contiguous(), "w": wt}
 
 
-def hgt_plan(edge_index_dict, edge_types: Sequence[Tuple[str, str, str]], sizes: Dict[str, int], device, used=None) -> dict:
+def hgt_plan(edge_index_dict, edge_types: Sequence[Tuple[str, str, str]], sizes: Dict[str, int], device, used=None, dst_range=None) -> dict:
     """Layout + CSR plan of one HGTConv call.
 
     Projection layout: node type t owns rows of ``width[t] = 128 + 256 * R_t`` floats in one flat buffer starting at
@@ -117,7 +117,12 @@ def hgt_plan(edge_index_dict, edge_types: Sequence[Tuple[str, str, str]], sizes:
     key of source node j under slot i is row (base[t] + j*width[t] + 128 + 256*i) / 128 and its value the next row.
 
     Per destination type: the incoming edges of every used edge type concatenated, stably sorted by destination,
-    ``col[e]`` = that key row; rows longer than HGT_CHUNK are split into work items."""
+    ``col[e]`` = that key row; rows longer than HGT_CHUNK are split into work items.
+
+    ``dst_range`` {type: (lo, hi)} (destination-partitioned conv, one rank of a multi-GPU encode): only the edges whose
+    destination lies in [lo, hi) are kept and destinations are renumbered from lo, so the per-destination lists describe
+    hi - lo rows; the projection layout (sources: every node) is unchanged.  A row's edge order is the unpartitioned one
+    (stable sorts), so its sums come out bit-identical."""
     present = [et for et in edge_types if et in edge_index_dict]
     used = present if used is None else [et for et in present if et in set(used)]
     slot, nrel = {}, {t: 0 for t in sizes}
@@ -136,6 +141,10 @@ def hgt_plan(edge_index_dict, edge_types: Sequence[Tuple[str, str, str]], sizes:
             if et[2] != t:
                 continue
             ei = edge_index_dict[et].to(device).long()
+            if dst_range is not None:
+                lo, hi = dst_range[t]
+                keep = (ei[1] >= lo) & (ei[1] < hi)
+                ei = torch.stack([ei[0][keep], ei[1][keep] - lo])
             if ei.shape[1] == 0:
                 continue
             s = et[0]
@@ -148,6 +157,8 @@ def hgt_plan(edge_index_dict, edge_types: Sequence[Tuple[str, str, str]], sizes:
         else:
             col = torch.zeros(0, dtype=torch.int64, device=device)
             dst = col
+        if dst_range is not None:
+            n_t = dst_range[t][1] - dst_range[t][0]
         rowptr = _rowptr(dst, n_t)
         deg = rowptr[1:] - rowptr[:-1]
         chunks = (deg + HGT_CHUNK - 1) // HGT_CHUNK

@@ -421,12 +421,13 @@ class HGTConv(nn.Module):
         self._plan_cache = {}
         self._host_cache = {}
 
-    def _plan(self, edge_index_dict, sizes, device, want):
+    def _plan(self, edge_index_dict, sizes, device, want, dst_range=None):
         used = [et for et in self.edge_types if et in edge_index_dict and et[2] in want]
-        key = (id(edge_index_dict), str(device), tuple(sorted(sizes.items())), tuple(used))
+        key = (id(edge_index_dict), str(device), tuple(sorted(sizes.items())), tuple(used),
+               None if dst_range is None else tuple(sorted(dst_range.items())))
         hit = self._plan_cache.get(key)
         if hit is None:
-            hit = hgt_plan(edge_index_dict, self.edge_types, sizes, device, used)
+            hit = hgt_plan(edge_index_dict, self.edge_types, sizes, device, used, dst_range)
             if len(self._plan_cache) > 8:
                 self._plan_cache.clear()
             self._plan_cache[key] = hit
@@ -541,16 +542,26 @@ class HGTConv(nn.Module):
             out[t] = ag.gated_residual(o, x_dict[t].float(), self.skip[t]) if x_dict[t].shape[-1] == F else o
         return out
 
-    def forward(self, x_dict, edge_index_dict, needed_types=None):
+    def forward(self, x_dict, edge_index_dict, needed_types=None, shard=None):
         """``needed_types`` (extension): compute only these destination node types (the encoder reads
-        ['drug'] of the LAST conv only, models.py:729); default = every destination type, as PyG does."""
+        ['drug'] of the LAST conv only, models.py:729); default = every destination type, as PyG does.
+        ``shard`` = (rank, world, group) (extension, inference): destination-partitioned conv for the multi-GPU encode -- the
+        K/Q/V projections (one GEMM per node type over all nodes) run on every rank, the edge attention (the bulk: every KG edge)
+        and the output projection only for this rank's block of each destination type, then the blocks of all ranks and types
+        travel in ONE all-gather.  Rows come out bit-identical to the unpartitioned conv."""
         if _train_path(self) or ag.needs_grad(*x_dict.values()):
+            if shard is not None and shard[1] > 1:
+                raise NotImplementedError("the destination-partitioned KG conv is an inference path (training keeps the KG encoder replicated)")
             return self._forward_train(x_dict, edge_index_dict, needed_types)
         F = self.out_channels
         dev = next(iter(x_dict.values())).device
         sizes = {t: int(x.shape[0]) for t, x in x_dict.items()}
         want = set(self.dst_node_types if needed_types is None else needed_types)
-        plan = self._plan(edge_index_dict, sizes, dev, want)
+        dst_range = None
+        if shard is not None and shard[1] > 1:
+            from .parallel import shard_range
+            dst_range = {t: shard_range(sizes[t], shard[0], shard[1]) for t in sizes}
+        plan = self._plan(edge_index_dict, sizes, dev, want, dst_range)
         buf = torch.empty(max(plan["total_floats"], 128), dtype=torch.float32, device=dev)
         proj = {}
         for t, x in x_dict.items():
@@ -566,14 +577,32 @@ class HGTConv(nn.Module):
         for t in self.node_types:
             if t not in self.dst_node_types or t not in x_dict or t not in want:
                 continue
-            agg = ops.hgt_attention(proj[t][:, 0:F], kv, plan["per_dst"][t], self.heads, apply_gelu=True)
+            lo, hi = (0, sizes[t]) if dst_range is None else dst_range[t]
+            agg = ops.hgt_attention(proj[t][lo:hi, 0:F], kv, plan["per_dst"][t], self.heads, apply_gelu=True)
             lin = self.out_lin.lins[t]
             if x_dict[t].shape[-1] == F:
                 a = self._skip_alpha(t)
-                out[t] = _lin(agg, lin.weight, lin.bias, alpha=a, residual=x_dict[t].float(), beta=1.0 - a)
+                out[t] = _lin(agg, lin.weight, lin.bias, alpha=a, residual=x_dict[t][lo:hi].float(), beta=1.0 - a)
             else:
                 out[t] = _lin(agg, lin.weight, lin.bias)
-        return out
+        if dst_range is None:
+            return out
+        # one exchange step for every destination type: each rank's blocks back to back, gathered, re-cut per type
+        from .parallel import all_gather_rows, shard_range
+        rank, world, group = shard
+        types = list(out.keys())
+        per_rank = [[shard_range(sizes[t], r, world)[1] - shard_range(sizes[t], r, world)[0] for t in types] for r in range(world)]
+        local = torch.cat([out[t] for t in types], dim=0) if types else torch.zeros(0, F, device=dev)
+        totals = [sum(v) for v in per_rank]
+        full = all_gather_rows(local.contiguous(), sum(totals), rank, world, group, sizes=totals)
+        res, start = {}, [sum(totals[:r]) for r in range(world)]
+        for ti, t in enumerate(types):
+            parts = []
+            for r in range(world):
+                off = start[r] + sum(per_rank[r][:ti])
+                parts.append(full[off: off + per_rank[r][ti]])
+            res[t] = torch.cat(parts, dim=0)
+        return res
 
 
 class HGT(nn.Module):
@@ -586,13 +615,15 @@ class HGT(nn.Module):
             self.convs.append(HGTConv(hidden_channels, hidden_channels, metadata, num_heads, group=group))
         self.lin_dict = nn.ModuleDict({t: nn.Linear(hidden_channels, out_channels) for t in metadata[0]})
 
-    def forward(self, x_dict, edge_index_dict, only_types=None):
+    def forward(self, x_dict, edge_index_dict, only_types=None, shard=None):
         """``only_types`` (extension): node types whose output the caller reads; the last conv and the final
-        Linear are then restricted to them (same values for those types)."""
+        Linear are then restricted to them (same values for those types).  ``shard`` = (rank, world, group) (extension,
+        inference): every conv runs destination-partitioned over the ranks (HGTConv.forward)."""
         last = len(self.convs) - 1
-        out = self.convs[0](x_dict, edge_index_dict, needed_types=only_types if last == 0 else None)
+        kw = {} if shard is None else {"shard": shard}
+        out = self.convs[0](x_dict, edge_index_dict, needed_types=only_types if last == 0 else None, **kw)
         for i in range(1, len(self.convs)):
-            out = self.convs[i](out, edge_index_dict, needed_types=only_types if i == last else None)
+            out = self.convs[i](out, edge_index_dict, needed_types=only_types if i == last else None, **kw)
             if i < last:
                 out = {t: (ag.activation(x, "relu") if x.requires_grad else torch.relu_(x)) for t, x in out.items()}
         if _train_path(self) or ag.needs_grad(*out.values()):
@@ -1352,7 +1383,8 @@ class NovelDDIEncoder(nn.Module):
             key = (id(kg_data), "drug")
             kg_valid = None if share is None else share.get(key)
             if kg_valid is None:
-                kg_valid = self.kg_encoder(kg_data.x_dict, kg_data.edge_index_dict, only_types=('drug',))['drug']
+                kg_kw = {} if kwargs.get('kg_shard') is None else {"shard": kwargs['kg_shard']}
+                kg_valid = self.kg_encoder(kg_data.x_dict, kg_data.edge_index_dict, only_types=('drug',), **kg_kw)['drug']
                 if share is not None:
                     share[key] = kg_valid
             table = filler.to(dev).clone()

@@ -9,7 +9,8 @@ wants it on the host / in a memmap, streams outcome chunks through two pinned bu
 so that the D2H copy of chunk k overlaps the kernel of chunk k+1.
 
 Multi-GPU (one process per GPU): encode+fuse is independent per drug, so rank r encodes a contiguous
-block of drugs (the KG encoder, which is per-graph rather than per-drug, is replicated); one
+block of drugs (the KG encoder, which is per-graph rather than per-drug, runs destination-partitioned:
+every rank computes its block of every node type and one all-gather per conv reassembles them); one
 all-gather of the [N/G,128] blocks over RCCL gives every rank z[N,128]; the head is sharded by
 outcome (rank-local rank normalisation afterwards) or by head row.
 """
@@ -59,7 +60,12 @@ def generate_embeddings(model, batch: dict, batch_kg: dict, masks: Optional[torc
     if local is None:
         local = slice_batch(batch, lo, hi)
         batch.setdefault("_shards", {})[(lo, hi)] = local
-    z_local = model.encoder(local["drugs"], masks[lo:hi], local["strs"], batch_kg, local["cv"], local["tx"], kg_filler=kg_filler)
+    # the KG encoder is per graph, not per drug: its convs run destination-partitioned over the ranks (HGTConv.forward) instead
+    # of replicated (MDG_SHARD_KG=0 keeps it replicated)
+    import os
+    kg_shard = (rank, world, None) if os.environ.get("MDG_SHARD_KG", "1") != "0" else None
+    z_local = model.encoder(local["drugs"], masks[lo:hi], local["strs"], batch_kg, local["cv"], local["tx"], kg_filler=kg_filler,
+                            kg_shard=kg_shard)
     return all_gather_rows(z_local.contiguous(), n, rank, world)
 
 

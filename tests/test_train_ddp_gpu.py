@@ -247,3 +247,56 @@ def test_two_rank_shipped_pretraining_steps_equal_single_process_and_hold_no_bat
         assert same_set and untouched == 0.0, (r, same_set, untouched)
         # nothing of an earlier iteration's batch stays allocated: memory after iteration 4 == after iteration 2
         assert abs(mem[3] - mem[1]) < (1 << 20), (r, mem)
+
+
+def _kg_shard_worker(rank, world, port, ret):
+    """Multi-GPU inference encode (pipeline.generate_embeddings): drugs sharded by rank, the KG encoder destination-partitioned
+    (every rank computes its block of every node type, one all-gather per conv) -- against the single-process encode."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from madrigal_amd import data as D, models as M
+        from madrigal_amd.pipeline import generate_embeddings
+        from test_models_gpu import build_model
+        n, seed = 83, 5                                              # uneven drug blocks; node-type sizes not divisible by 3
+        batch, bkg = D.make_batch(n, seed, kg_nodes=1501, kg_edges=30000)
+        torch.manual_seed(seed)
+        model = build_model(M, CASE, bkg["data"], 4).cuda().eval()
+        b = D.batch_to(batch, "cuda")
+        kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
+        filler = torch.randn(n, 128, generator=torch.Generator().manual_seed(1)).cuda()
+        with torch.no_grad(), M.precision("bf16x3"):
+            z_ref = generate_embeddings(model, b, kgc, kg_filler=filler)                       # one process, everything
+            z = generate_embeddings(model, b, kgc, rank=rank, world=world, kg_filler=filler)
+            os.environ["MDG_SHARD_KG"] = "0"
+            z_rep = generate_embeddings(model, b, kgc, rank=rank, world=world, kg_filler=filler)  # KG encoder replicated
+            # the conv on its own: partitioned rows == unpartitioned rows, every node type
+            conv = model.encoder.kg_encoder.convs[0]
+            full = conv(kgc["data"].x_dict, kgc["data"].edge_index_dict)
+            part = conv(kgc["data"].x_dict, kgc["data"].edge_index_dict, shard=(rank, world, None))
+        same_conv = all(torch.equal(full[t], part[t]) for t in full) and set(full) == set(part)
+        # sharded drugs change the row counts of the per-drug GEMMs (tile shapes, hence fp32 summation grouping): against the
+        # single-process encode the comparison is at rounding level; partitioned vs replicated KG encoder is bit for bit
+        err = float((z - z_ref).abs().max() / z_ref.abs().max())
+        ret[rank] = (bool(torch.equal(z, z_rep)), err, same_conv, tuple(z.shape))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_destination_partitioned_kg_encoder_equals_replicated(world):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_kg_shard_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    for r in range(world):
+        same_as_replicated, err, same_conv, shape = ret[r]
+        assert shape == (83, 128)
+        assert same_conv and same_as_replicated and err < 1e-5, (r, ret[r])
