@@ -12,7 +12,7 @@ import torch
 
 from . import autograd as ag
 from . import ops
-from .parallel import all_gather_rows_grad, all_reduce_sum_, allreduce_gradients, shard_range
+from .parallel import GradientBuckets, all_gather_rows_grad, all_reduce_sum_, allreduce_gradients, shard_range
 from .pipeline import slice_batch
 
 
@@ -44,6 +44,10 @@ class FinetuneStep:
         self.model, self.optimizer, self.loss_readout, self.scheduler = model, optimizer, loss_readout, scheduler
         self.rank, self.world, self.group = rank, world, group
         _refuse_rank_local_batchnorm(model.encoder, world)
+        # single-pass steps overlap the gradient all-reduce with the backward pass (buckets issued from gradient hooks);
+        # the multi-pass modes (accumulate() ... apply()) sum the finished gradients in flat buckets afterwards
+        self._buckets = GradientBuckets(model.parameters(), group) if world > 1 else None
+        self._overlapped = False
         self._plan_key = None
         self._plan = None
         self._shards = {}               # side ('head' | 'tail') -> (key, sliced batch, the batch itself): ONE entry per side
@@ -112,7 +116,11 @@ class FinetuneStep:
 
     def apply(self) -> None:
         if self.world > 1:              # once per optimizer step, after every accumulate() of the step
-            allreduce_gradients(self.model.parameters(), self.group)
+            if self._overlapped:
+                self._buckets.finish()
+                self._overlapped = False
+            else:
+                allreduce_gradients(self.model.parameters(), self.group)
         self.optimizer.step()
         if self.scheduler is not None:
             self.scheduler.step()
@@ -120,6 +128,9 @@ class FinetuneStep:
     def step(self, batch_head, batch_tail, masks_head, masks_tail, batch_kg, labels, heads, tails, targets, **kwargs) -> torch.Tensor:
         self.model.train()
         self.optimizer.zero_grad(set_to_none=True)
+        if self._buckets is not None:
+            self._buckets.arm()
+            self._overlapped = True
         loss = self.accumulate(batch_head, batch_tail, masks_head, masks_tail, batch_kg, labels, heads, tails, targets, **kwargs)
         self.apply()
         return loss
@@ -141,6 +152,7 @@ class PretrainStep:
     def __init__(self, model, optimizer, rank: int = 0, world: int = 1, group=None):
         self.model, self.optimizer, self.rank, self.world, self.group = model, optimizer, rank, world, group
         _refuse_rank_local_batchnorm(model.base_encoder, world)
+        self._buckets = GradientBuckets(model.parameters(), group) if world > 1 else None
         self._last = None               # (key, sliced batch, batch_data): the slice of the LAST batch only (a DataLoader
         #                                 hands over a fresh batch every iteration: nothing may accumulate here)
 
@@ -184,8 +196,9 @@ class PretrainStep:
                 e = model.base_encoder(b["drugs"], masks[lo:hi], b["strs"], kg, b["cv"], b["tx"], raw_encoder_output=raw, kg_share=share)
                 views.append(all_gather_rows_grad(_run_sequential_train(pred, e), sum(sizes) if raw else B, self.rank, self.world, group, sizes))
             _, _, loss = model.contrastive_loss(views[0], views[1], too_hard_neg)
+            self._buckets.arm()                     # gradient buckets are all-reduced from hooks while backward still runs
             (loss * (1.0 / self.world)).backward()
-            allreduce_gradients(model.parameters(), group)
+            self._buckets.finish()
         finally:
             ag.set_batchnorm_sync(None)
         self.optimizer.step()
