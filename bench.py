@@ -108,6 +108,23 @@ def pmc_traffic(n_drugs: int, n_outcomes: int, precision: str):
     return None, None
 
 
+def host_threads() -> int:
+    """Threads for the CPU baselines: the cores this process may actually use (cgroup CPU quota and affinity mask; os.cpu_count()
+    reports every core of the host, and torch's index / scatter ops collapse when oversubscribed 16x)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 ORACLE_CASE = {   # name, fusion, nb, pos, heads, head_dim, ffn, layers, norm_first, agg, normalize, adapt  (configs.SHIPPED restated)
     "twosides321": ("twosides321", "transformer_uni_proj", 2, "sinusoidal", 8, 256, 1024, 2, True, "x-attn", False, False),
     "twosides105": ("twosides105", "transformer", 2, "learnable", 2, 256, 512, 2, True, "x-attn", False, False),
@@ -126,6 +143,7 @@ def cpu_encode_fuse(params, batch, bkg, config: str, sample: int = 64, kg_edge_k
     from madrigal_amd.pipeline import slice_batch
     from oracle import madrigal_oracle as O
     case = ORACLE_CASE[config]
+    torch.set_num_threads(host_threads())
     name, fusion, nb, pos, H, dh, ffn, nl, nf, agg, normalize, adapt = case
     enc = O._sub(params, "encoder.")
     kg = bkg["data"]
@@ -161,7 +179,7 @@ def cpu_baseline(n_drugs: int, n_outcomes: int, seconds: float = 12.0, encode=No
     head rows against all tail drugs and outcomes, and -- ``encode`` = (params, batch, bkg, config) -- encode+fuse."""
     import torch
     from oracle import madrigal_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_threads()
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
     z = torch.randn(n_drugs, 128, generator=g)
@@ -206,6 +224,7 @@ def cpu_finetune_step(params, batch, bkg, config: str, n_outcomes: int, triples,
     from oracle import madrigal_oracle as O
     from oracle.pipeline import oracle_encoders
     case = ORACLE_CASE[config]
+    torch.set_num_threads(host_threads())
     name, fusion, nb, pos, H, dh, ffn, nl, nf, agg, normalize, adapt = case
     N = int(batch["drugs"].shape[0])
     n = min(sample, N)
@@ -484,7 +503,7 @@ def main():
                 try:
                     trip = tuple(t.cpu() for t in D.make_labelled_triples(N, L, args.finetune_triples, 0))
                     c = cpu_finetune_step(cpu_inputs[0], cpu_inputs[1], cpu_inputs[2], args.config, L, trip)
-                    finetune["cpu_baseline"] = {"value": c["steps_per_s"], "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
+                    finetune["cpu_baseline"] = {"value": c["steps_per_s"], "unit": "steps/s", "cores": host_threads(), "kind": "port",
                                                 "sample": f"oracle training step (torch CPU autograd, fp32) on {c['sample_drugs']} drugs per side, "
                                                           f"{c['sample_triples']} labelled triples, KG thinned to {c['kg_edges_kept']} of its edges; scaled to "
                                                           f"{N} drugs / {finetune['triples_per_step']} triples / the full KG", "detail": c}

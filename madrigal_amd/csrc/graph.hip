@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void csr_aggregate_kernel(const float* __restr
 // wave owns more than CHUNK edges; each item produces an online-softmax partial (m, l, acc) and a
 // second kernel merges the partials of a destination in item order (deterministic).
 // A half-wave (32 lanes x float4 = 128 floats) handles one edge; the two halves of a wave walk
-// alternate edges with 2 edges each in flight, and are merged at the end.
+// alternate edges with 4 edges each in flight, and are merged at the end.
 // ---------------------------------------------------------------------------------------------
 struct HgtArgs {
   const float* q; int64_t ldq;          // [n_dst, >=128]
@@ -97,24 +97,39 @@ __global__ __launch_bounds__(256) void hgt_attention_kernel(const HgtArgs p) {
   const f32x4 q = *reinterpret_cast<const f32x4*>(p.q + dst * p.ldq + 4 * sub);
   float m = -INFINITY, l = 0.f;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  // this half takes edges e0+half, e0+half+2, ...; two of them per iteration
-  for (int64_t e = e0 + half; e < e1; e += 4) {
-    const bool two = (e + 2) < e1;
-    const int64_t c0 = p.col[e], c1 = two ? p.col[e + 2] : c0;
-    const float* r0 = p.kv + c0 * p.ldkv + 4 * sub;
-    const float* r1 = p.kv + c1 * p.ldkv + 4 * sub;
-    const f32x4 k0 = *reinterpret_cast<const f32x4*>(r0), v0 = *reinterpret_cast<const f32x4*>(r0 + 128);
-    const f32x4 k1 = *reinterpret_cast<const f32x4*>(r1), v1 = *reinterpret_cast<const f32x4*>(r1 + 128);
-    float a0 = dot4(q, k0), a1 = dot4(q, k1);
-    for (int o = lph >> 1; o > 0; o >>= 1) {
-      a0 += __shfl_xor(a0, o, 64);
-      a1 += __shfl_xor(a1, o, 64);
+  // this half takes edges e0+half, e0+half+2, ...; FOUR of them per iteration (8 rows = 8 KB of k'|v' in flight per wave: every
+  // step is a dependent col -> row gather, so the rows in flight per wave are what hide its latency)
+  for (int64_t e = e0 + half; e < e1; e += 8) {
+    bool ok[4];
+    const float* r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ok[u] = (e + 2 * u) < e1;
+      r[u] = p.kv + p.col[ok[u] ? e + 2 * u : e] * p.ldkv + 4 * sub;
     }
-    if (!two) a1 = -INFINITY;
-    const float mn = fmaxf(m, fmaxf(a0, a1));
-    const float f = expf(m - mn), w0 = expf(a0 - mn), w1 = expf(a1 - mn);
-    l = l * f + w0 + w1;
-    acc = acc * f + w0 * v0 + w1 * v1;
+    f32x4 k[4], v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      k[u] = *reinterpret_cast<const f32x4*>(r[u]);
+      v[u] = *reinterpret_cast<const f32x4*>(r[u] + 128);
+    }
+    float a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = dot4(q, k[u]);
+    for (int o = lph >> 1; o > 0; o >>= 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] += __shfl_xor(a[u], o, 64);
+    }
+#pragma unroll
+    for (int u = 1; u < 4; ++u)
+      if (!ok[u]) a[u] = -INFINITY;
+    const float mn = fmaxf(fmaxf(m, a[0]), fmaxf(fmaxf(a[1], a[2]), a[3]));
+    const float f = expf(m - mn);
+    float w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w[u] = expf(a[u] - mn);
+    l = l * f + ((w[0] + w[1]) + (w[2] + w[3]));
+    acc = acc * f + ((w[0] * v[0] + w[1] * v[1]) + (w[2] * v[2] + w[3] * v[3]));
     m = mn;
   }
   // merge the two halves (each lane pairs with lane ^ 32, same feature columns)

@@ -160,6 +160,14 @@ class GradientBuckets:
     2 to 5 collectives per step, each long enough to run at link rate, the last ones hidden under the encoders' backward."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20):
+        # A communicator of its own: bucket collectives are issued from gradient hooks BETWEEN the collectives the backward
+        # pass itself issues (SyncBatchNorm sums, the embedding reduce-scatter); on a rank that lacks some gradient a bucket
+        # moves to finish(), i.e. to another position in that rank's stream of collectives.  Collectives of different
+        # communicators need no common order, so the buckets (fixed order among themselves) cannot pair up with the wrong
+        # partner.  (Constructed on every rank, like the step objects that own it.)
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            ranks = list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group)
+            group = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
         self.group = group
         self.bucket_bytes = bucket_bytes
         self.params = [p for p in params if p.requires_grad]
