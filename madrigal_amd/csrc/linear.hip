@@ -90,6 +90,14 @@ struct Operand {          // fp32: p0 = image; bf16 modes: p0 = hi image, p1 = l
   int64_t nrows;
 };
 
+// LDS layout of one stage.  fp32 / bf16x3: [A tile (fp32, or bf16 hi + lo) | B tile], S::STAGE bytes, two stages.  Single-product
+// bf16: only the hi images exist, [A hi | B hi] = half the bytes, so FOUR stages fit in the same LDS: with one bf16 product per
+// k step a 32-deep k tile is ~1000 matrix-pipe cycles per SIMD, shorter than the LDS-DMA round trip -- prefetch distance one
+// left the matrix cores waiting for operands (0.67 PFLOP/s); three tiles in flight cover it.
+template <int MODE, class S> constexpr int kStageBytes = (MODE == MDG_PREC_BF16) ? (S::A_LO + S::B_LO) : S::STAGE;
+template <int MODE, class S> constexpr int kBOffset = (MODE == MDG_PREC_BF16) ? S::A_LO : S::A_BYTES;
+template <int MODE> constexpr int kStages = (MODE == MDG_PREC_BF16) ? 4 : 2;
+
 template <int MODE, class S>
 __device__ __forceinline__ void dma_stage(const Operand& A, const Operand& B, int64_t row0, int64_t col0, int64_t k0, char* lds,
                                           int wave, int lane) {
@@ -98,7 +106,7 @@ __device__ __forceinline__ void dma_stage(const Operand& A, const Operand& B, in
     dma_tile<4, S::BN, S::WAVES>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES, wave, lane);
   } else {
     dma_tile<2, S::BM, S::WAVES>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane);
-    dma_tile<2, S::BN, S::WAVES>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES, wave, lane);
+    dma_tile<2, S::BN, S::WAVES>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + kBOffset<MODE, S>, wave, lane);
     if constexpr (MODE == MDG_PREC_BF16X3) {
       dma_tile<2, S::BM, S::WAVES>(A.p1, A.ld_bytes, row0, A.nrows, k0, lds + S::A_LO, wave, lane);
       dma_tile<2, S::BN, S::WAVES>(B.p1, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES + S::B_LO, wave, lane);
@@ -208,6 +216,24 @@ __global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs 
       for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
 
   const int nk = static_cast<int>(p.K / BK);
+  if constexpr (kStages<MODE> == 4) {
+    // four-stage ring, three k tiles in flight.  Every wave issues exactly 4 LDS-DMA pieces per tile (static_assert), its only
+    // vector-memory operations, and they retire in issue order: `vmcnt(8)` at the top of tile kt leaves the pieces of tiles
+    // kt+1 and kt+2 in flight.  The buffer refilled at the top of kt held tile kt-1, which every wave finished reading before
+    // it arrived at this barrier.
+    static_assert((S::BM + S::BN) * BK * 2 / 1024 / S::WAVES == 4, "counted waits below assume 4 pieces per wave and tile");
+    constexpr int SB = kStageBytes<MODE, S>;
+    for (int t = 0; t < 3 && t < nk; ++t) dma_stage<MODE, S>(p.A, p.B, row0, col0, static_cast<int64_t>(t) * BK, smem + t * SB, wave, lane);
+    for (int kt = 0; kt < nk; ++kt) {
+      char* const cur = smem + (kt & 3) * SB;
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 3 < nk) dma_stage<MODE, S>(p.A, p.B, row0, col0, static_cast<int64_t>(kt + 3) * BK, smem + ((kt + 3) & 3) * SB, wave, lane);
+      mma_stage<MODE, S>(cur, cur + kBOffset<MODE, S>, wr, wc, r, h, acc);
+    }
+  } else {
   dma_stage<MODE, S>(p.A, p.B, row0, col0, 0, smem, wave, lane);
   for (int kt = 0; kt < nk; ++kt) {
     char* const cur = smem + (kt & 1) * S::STAGE;
@@ -216,6 +242,7 @@ __global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs 
     __builtin_amdgcn_s_barrier();
     if (kt + 1 < nk) dma_stage<MODE, S>(p.A, p.B, row0, col0, static_cast<int64_t>(kt + 1) * BK, nxt, wave, lane);
     mma_stage<MODE, S>(cur, cur + S::A_BYTES, wr, wc, r, h, acc);
+  }
   }
 
   // ---- epilogue: lane = output column, accumulator registers = rows ---------------------
