@@ -1330,3 +1330,36 @@ def test_wide_weight_gradient_tn_product(M, N, K, prec, tol):
     assert got.shape == (N, K)
     _close(got, ref, tol, "dW")
     _close(db, g.double().sum(0), 1e-5, "db")
+
+
+def test_full_size_finetune_steps_bf16_track_the_fp32_grade_run():
+    """BASELINE configs[1] at full size (4096 drugs, 896 outcomes, 6e6 labelled triples, the TWOSIDES model over a 130k-node /
+    8M-edge KG): three finetune steps with bf16 GEMM operands (what bench.py times) against the same steps in the fp32-grade
+    split-bf16 arithmetic, same seeds: finite, decreasing, and the losses agree to 1e-3 -- the reduced-precision step trains
+    the same model."""
+    from madrigal_amd import configs, data as D, models as M
+    from madrigal_amd.optim import create_optimizer
+    from madrigal_amd.train import FinetuneStep
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs 40 GB of free HBM")
+    N, L = 4096, 896
+    batch, bkg = D.make_batch(N, 0, kg_nodes=130_000, kg_edges=8_000_000)
+    b = D.batch_to(batch, "cuda")
+    kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
+    lab, hd, tl, y = (t.cuda() for t in D.make_labelled_triples(N, L, 1_000_000, 0))
+    filler = torch.randn(N, 128, generator=torch.Generator().manual_seed(1)).cuda()
+    hp = dict(optimizer="adamw", structure_encoder_lr=1e-5, kg_encoder_lr=1e-5, perturb_encoders_lr=1e-5, fusion_lr=1e-6, decoder_lr=1e-4,
+              wd=1e-2, beta1=0.9, beta2=0.999, eps=1e-8)
+
+    def run(prec):
+        torch.manual_seed(0)
+        model = configs.build_model("twosides321", bkg["data"], L).cuda()
+        fs = FinetuneStep(model, create_optimizer(model, hp))
+        torch.manual_seed(4321)
+        with M.precision(prec):
+            return [float(fs.step(b, b, b["masks"], b["masks"], kgc, lab, hd, tl, y, kg_filler=filler)) for _ in range(3)]
+    lo, hi = run("bf16"), run("bf16x3")
+    assert all(np.isfinite(lo)) and lo[2] < lo[0] and hi[2] < hi[0], (lo, hi)
+    for a, r in zip(lo, hi):
+        assert abs(a - r) < 1e-3 * abs(r), (lo, hi)
