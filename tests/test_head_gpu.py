@@ -150,6 +150,33 @@ def test_symmetric_sweep_for_one_drug_set(ops, monkeypatch, prec, N, L):
     assert rel_err(out.cpu(), ref) < TOL[prec]
 
 
+def test_symmetric_sweep_beyond_2GiB_per_outcome(ops, monkeypatch):
+    """N = 23 552: one outcome's [N,N] slab is 2.2 GB, so the mirrored stores' byte offsets pass 2^31 (they are unsigned 32-bit
+    offsets into a buffer descriptor of N*N*4 bytes).  Mirrored half == exact transpose; sampled blocks == the general kernel."""
+    N = 23_552
+    free, _ = torch.cuda.mem_get_info()
+    if free < 6 * 2 ** 30:
+        pytest.skip("needs 6 GB of free HBM")
+    z = _rand((N, 128), 70).cuda()
+    w = ops.symmetrize(_rand((1, 128, 128), 71, 1 / np.sqrt(128)).cuda())
+    out = torch.full((1, N, N), float("nan"), device="cuda")
+    ops.bilinear_allpairs(z, z, w, precision="bf16", out=out)
+    s = out[0]
+    for i0, j0 in ((0, 0), (N - 512, N - 512), (256, N - 300), (N - 300, 256), (11_776, 12_032), (20_000, 777)):
+        blk = s[i0:i0 + 300, j0:j0 + 300]
+        assert not bool(torch.isnan(blk).any())
+        ref = ops.bilinear_allpairs(z[i0:i0 + 300].contiguous(), z[j0:j0 + 300].contiguous(), w, precision="bf16")[0]      # general kernel
+        # blocks right of the block diagonal are computed (same products as the general kernel: fp32 grouping only); blocks
+        # left of it are mirrored, i.e. the OTHER association order, which in a 16-bit mode differs at that mode's rounding of T
+        computed = (i0 + 299) // 256 <= j0 // 256
+        assert float((blk - ref).abs().max()) < (2e-6 if computed else TOL["bf16"]) * float(ref.abs().max()), (i0, j0)
+        ib = (torch.arange(i0, i0 + 300, device="cuda") // 256)[:, None]
+        jb = (torch.arange(j0, j0 + 300, device="cuda") // 256)[None, :]
+        off = ib != jb                                       # outside the diagonal blocks: S[i,j] and S[j,i] are one stored value
+        assert torch.equal(s[j0:j0 + 300, i0:i0 + 300].T[off], blk[off]), (i0, j0)
+    assert bool(torch.isfinite(s.sum(dim=1)).all())            # every row written
+
+
 def test_asymmetric_operands_catch_transposes(ops):
     """A = I style check with asymmetric operands: z_head one-hot rows pick out rows of W z_tail^T."""
     L, n = 2, 40
