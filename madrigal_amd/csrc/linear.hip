@@ -50,6 +50,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // that the 16 lanes of a ds_read_b128 group (16 consecutive rows, same chunk) hit 16 distinct 16-B slots.
 __device__ __forceinline__ int off_f32(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int off_bf16(int row, int cb) { return row * 64 + ((cb ^ ((row >> 2) & 3)) << 4); }
+// bf16 tile read by the 16x16x32 MFMA: the 4 lane groups of a fragment read the 4 chunks of the SAME 16 rows, so the
+// conflict-free rotation is by row pair (checked exhaustively against the ds_read_b128 lane grouping of the guide).
+__device__ __forceinline__ int off_bf16_m16(int row, int cb) { return row * 64 + ((cb ^ ((row >> 1) & 3)) << 4); }
 
 typedef __attribute__((address_space(3))) void lds_void;
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return static_cast<unsigned>(reinterpret_cast<size_t>((lds_void*)p)); }
@@ -66,7 +69,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_unifor
 
 // One operand tile (ROWS rows x 32 k) of stage k0 into LDS.  `base` is the operand image (fp32 [rows,ld] or one
 // bf16 hi/lo image [rows,ld]); rows past the end clamp to the last row (their results are never stored).
-template <int ESIZE, int ROWS, int WAVES>   // ESIZE 4 = fp32 tile (8 rows per 1-KiB piece), 2 = bf16 tile (16 rows per piece)
+template <int ESIZE, int ROWS, int WAVES, int MF = 32>   // ESIZE 4 = fp32 tile (8 rows per 1-KiB piece), 2 = bf16 tile (16 rows per piece)
 __device__ __forceinline__ void dma_tile(const char* base, int64_t ld_bytes, int64_t row0, int64_t nrows, int64_t k0, char* lds,
                                          int wave, int lane) {
   constexpr int PIECES = ROWS * BK * ESIZE / 1024;
@@ -76,7 +79,7 @@ __device__ __forceinline__ void dma_tile(const char* base, int64_t ld_bytes, int
     const int p = wave + WAVES * i;
     int row, c;
     if constexpr (ESIZE == 4) { row = 8 * p + (lane >> 3); c = (lane & 7) ^ ((row >> 1) & 7); }
-    else { row = 16 * p + (lane >> 2); c = (lane & 3) ^ ((row >> 2) & 3); }
+    else { row = 16 * p + (lane >> 2); c = (lane & 3) ^ (MF == 16 ? ((row >> 1) & 3) : ((row >> 2) & 3)); }
     int64_t gr = row0 + row;
     gr = gr < nrows ? gr : nrows - 1;
     glds16(base + gr * ld_bytes + k0 * ESIZE + c * 16, lds_addr(lds + p * 1024));
@@ -98,18 +101,18 @@ template <int MODE, class S> constexpr int kStageBytes = (MODE == MDG_PREC_BF16)
 template <int MODE, class S> constexpr int kBOffset = (MODE == MDG_PREC_BF16) ? S::A_LO : S::A_BYTES;
 template <int MODE> constexpr int kStages = (MODE == MDG_PREC_BF16) ? 4 : 2;
 
-template <int MODE, class S>
+template <int MODE, class S, int MF = 32>
 __device__ __forceinline__ void dma_stage(const Operand& A, const Operand& B, int64_t row0, int64_t col0, int64_t k0, char* lds,
                                           int wave, int lane) {
   if constexpr (MODE == MDG_PREC_F32) {
     dma_tile<4, S::BM, S::WAVES>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane);
     dma_tile<4, S::BN, S::WAVES>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES, wave, lane);
   } else {
-    dma_tile<2, S::BM, S::WAVES>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane);
-    dma_tile<2, S::BN, S::WAVES>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + kBOffset<MODE, S>, wave, lane);
+    dma_tile<2, S::BM, S::WAVES, MF>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane);
+    dma_tile<2, S::BN, S::WAVES, MF>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + kBOffset<MODE, S>, wave, lane);
     if constexpr (MODE == MDG_PREC_BF16X3) {
-      dma_tile<2, S::BM, S::WAVES>(A.p1, A.ld_bytes, row0, A.nrows, k0, lds + S::A_LO, wave, lane);
-      dma_tile<2, S::BN, S::WAVES>(B.p1, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES + S::B_LO, wave, lane);
+      dma_tile<2, S::BM, S::WAVES, MF>(A.p1, A.ld_bytes, row0, A.nrows, k0, lds + S::A_LO, wave, lane);
+      dma_tile<2, S::BN, S::WAVES, MF>(B.p1, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES + S::B_LO, wave, lane);
     }
   }
 }
@@ -164,6 +167,45 @@ __device__ __forceinline__ void mma_stage(const char* la, const char* lb, int wr
   }
 }
 
+// The same k tile on the 16x16x32 MFMA (16-bit modes): 8 passes for 16 Kflop against 16 passes for 32 Kflop on the 32x32x16 form,
+// i.e. the same matrix-pipe cycles, but each instruction switches a quarter of the accumulator registers; under the package
+// power limit that buys clock (measured on the row-statistics head, which has this loop shape: +13 %).  A wave's 32*MT x 32*NT
+// patch becomes 2MT x 2NT tiles of 16x16; lane (c = lane & 15, g = lane >> 4) holds row c / column c, k chunk g of a fragment
+// and rows 4g..4g+3 of column c of an accumulator tile.  B fragments stay in registers over the two halves of the A tiles.
+template <int MODE, class S>
+__device__ __forceinline__ void mma_stage16(const char* la, const char* lb, int wr, int wc, int c, int g,
+                                            f32x4 (&acc)[2 * S::MT][2 * S::NT_]) {
+  constexpr int MT2 = 2 * S::MT, NT2 = 2 * S::NT_;
+  bf16x8 bh[NT2], bl[NT2];
+#pragma unroll
+  for (int t = 0; t < NT2; ++t) {
+    const int ob = off_bf16_m16(wc * 16 * NT2 + t * 16 + c, g);
+    bh[t] = *reinterpret_cast<const bf16x8*>(lb + ob);
+    if constexpr (MODE == MDG_PREC_BF16X3) bl[t] = *reinterpret_cast<const bf16x8*>(lb + S::B_LO + ob);
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    bf16x8 ah[MT2 / 2], al[MT2 / 2];
+#pragma unroll
+    for (int t = 0; t < MT2 / 2; ++t) {
+      const int oa = off_bf16_m16(wr * 16 * MT2 + (half * (MT2 / 2) + t) * 16 + c, g);
+      ah[t] = *reinterpret_cast<const bf16x8*>(la + oa);
+      if constexpr (MODE == MDG_PREC_BF16X3) al[t] = *reinterpret_cast<const bf16x8*>(la + S::A_LO + oa);
+    }
+#pragma unroll
+    for (int t = 0; t < MT2 / 2; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT2; ++nt) {
+        f32x4& a = acc[half * (MT2 / 2) + t][nt];
+        if constexpr (MODE == MDG_PREC_BF16X3) {
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t], bh[nt], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bl[nt], a, 0, 0, 0);
+        }
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bh[nt], a, 0, 0, 0);
+      }
+  }
+}
+
 struct LinearArgs {
   Operand A, B;            // K is a multiple of 32 in both images (zero padded by the pre-pass when needed)
   float* y; int64_t ldy;
@@ -173,6 +215,7 @@ struct LinearArgs {
   int act;
   int64_t M, N, K;
   int tiles_x, tiles_y, swizzle;   // swizzle: XCD-aware tile order (see tile_of)
+  int vec_y, vec_r;                // y / residual rows may be accessed 16 B at a time (alignment and row stride)
 };
 
 // Workgroups are dealt to the 8 XCDs round-robin in dispatch order, and each XCD has its own L2.  With the plain
@@ -197,24 +240,8 @@ __device__ __forceinline__ bool tile_of(const LinearArgs& p, int& tx, int& ty) {
 // Pipeline: one raw barrier per k-tile.  Top of tile kt: wait for this wave's DMA pieces of tile kt (the only
 // vector-memory ops in flight), barrier (=> every wave's pieces landed, every wave finished reading tile kt-1),
 // issue the DMA of tile kt+1 into the other buffer, then the MFMAs of tile kt run under that DMA.
-template <int MODE, class S>
-__global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A tile | B tile]
-  constexpr int MT = S::MT, NT_ = S::NT_;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-  const int wr = wave / S::WN, wc = wave % S::WN;
-  int tx, ty;
-  if (!tile_of(p, tx, ty)) return;                        // workgroup-uniform
-  const int64_t col0 = static_cast<int64_t>(tx) * S::BN, row0 = static_cast<int64_t>(ty) * S::BM;
-
-  f32x16 acc[MT][NT_];
-#pragma unroll
-  for (int a = 0; a < MT; ++a)
-#pragma unroll
-    for (int b = 0; b < NT_; ++b)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
-
+template <int MODE, class S, int MF, class Mma>
+__device__ __forceinline__ void k_loop(const LinearArgs& p, int64_t row0, int64_t col0, char* smem, int wave, int lane, Mma&& mma) {
   const int nk = static_cast<int>(p.K / BK);
   if constexpr (kStages<MODE> == 4) {
     // four-stage ring, three k tiles in flight.  Every wave issues exactly 4 LDS-DMA pieces per tile (static_assert), its only
@@ -223,50 +250,148 @@ __global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs 
     // it arrived at this barrier.
     static_assert((S::BM + S::BN) * BK * 2 / 1024 / S::WAVES == 4, "counted waits below assume 4 pieces per wave and tile");
     constexpr int SB = kStageBytes<MODE, S>;
-    for (int t = 0; t < 3 && t < nk; ++t) dma_stage<MODE, S>(p.A, p.B, row0, col0, static_cast<int64_t>(t) * BK, smem + t * SB, wave, lane);
+    for (int t = 0; t < 3 && t < nk; ++t) dma_stage<MODE, S, MF>(p.A, p.B, row0, col0, static_cast<int64_t>(t) * BK, smem + t * SB, wave, lane);
     for (int kt = 0; kt < nk; ++kt) {
       char* const cur = smem + (kt & 3) * SB;
       if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (kt + 3 < nk) dma_stage<MODE, S>(p.A, p.B, row0, col0, static_cast<int64_t>(kt + 3) * BK, smem + ((kt + 3) & 3) * SB, wave, lane);
-      mma_stage<MODE, S>(cur, cur + kBOffset<MODE, S>, wr, wc, r, h, acc);
+      if (kt + 3 < nk) dma_stage<MODE, S, MF>(p.A, p.B, row0, col0, static_cast<int64_t>(kt + 3) * BK, smem + ((kt + 3) & 3) * SB, wave, lane);
+      mma(cur, cur + kBOffset<MODE, S>);
     }
   } else {
-  dma_stage<MODE, S>(p.A, p.B, row0, col0, 0, smem, wave, lane);
-  for (int kt = 0; kt < nk; ++kt) {
-    char* const cur = smem + (kt & 1) * S::STAGE;
-    char* const nxt = smem + ((kt + 1) & 1) * S::STAGE;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) dma_stage<MODE, S>(p.A, p.B, row0, col0, static_cast<int64_t>(kt + 1) * BK, nxt, wave, lane);
-    mma_stage<MODE, S>(cur, cur + S::A_BYTES, wr, wc, r, h, acc);
+    dma_stage<MODE, S, MF>(p.A, p.B, row0, col0, 0, smem, wave, lane);
+    for (int kt = 0; kt < nk; ++kt) {
+      char* const cur = smem + (kt & 1) * S::STAGE;
+      char* const nxt = smem + ((kt + 1) & 1) * S::STAGE;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) dma_stage<MODE, S, MF>(p.A, p.B, row0, col0, static_cast<int64_t>(kt + 1) * BK, nxt, wave, lane);
+      mma(cur, cur + S::A_BYTES);
+    }
   }
-  }
+}
 
-  // ---- epilogue: lane = output column, accumulator registers = rows ---------------------
+// ---- epilogue -----------------------------------------------------------------------------------------------------------------
+// The accumulators hold columns across lanes (a store straight from them writes 64- or 128-byte row pieces, and every workgroup
+// of a launch reaches its epilogue at about the same time, so the write burst is paid in full).  Instead each wave turns its
+// patch through LDS -- the staging buffers are free once the k loop is over: 16 KB per wave = 64 rows x 64 columns fp32 -- and
+// writes row-major, 16 B per lane, 256 contiguous bytes per row per instruction; bias / BN scale+shift / residual are read the
+// same way.  Slab layout: row-major with the 16-float column block XORed by (row >> 2) & 3, conflict-free for both accumulator
+// layouts on the way in (a 32x32 tile writes 32 columns of one row per half-wave, a 16x16 tile 16 columns of two rows four
+// apart) and for the float4 rows on the way out.
+__device__ __forceinline__ int slab_off(int row, int col) { return row * 64 + ((((col >> 4) ^ ((row >> 2) & 3)) << 4) | (col & 15)); }
+
+__device__ __forceinline__ float finish(const LinearArgs& p, float v, float bias, float scale, float shift) {
+  float val = v + bias;
+  if (p.scale) val = val * scale + shift;
+  val = apply_act(val, p.act);
+  if (p.alpha != 1.0f) val *= p.alpha;
+  return val;
+}
+
+// 64 x 64 slab -> y[m0.., n0..]
+__device__ __forceinline__ void slab_to_global(const LinearArgs& p, const float* slab, int64_t m0, int64_t n0, int lane) {
+  const int c4 = lane & 15;
+  const int64_t n = n0 + 4 * c4;
+  if (n >= p.N) return;
+  const bool full = n + 3 < p.N;
+  float bias[4] = {0.f, 0.f, 0.f, 0.f}, scale[4] = {1.f, 1.f, 1.f, 1.f}, shift[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int nt = 0; nt < NT_; ++nt) {
-    const int64_t n = col0 + wc * 32 * NT_ + nt * 32 + r;
-    const bool n_ok = n < p.N;
-    const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
-    const float scale = (p.scale && n_ok) ? p.scale[n] : 1.f;
-    const float shift = (p.shift && n_ok) ? p.shift[n] : 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+  for (int e = 0; e < 4; ++e)
+    if (n + e < p.N) {
+      if (p.bias) bias[e] = p.bias[n + e];
+      if (p.scale) { scale[e] = p.scale[n + e]; shift[e] = p.shift[n + e]; }
+    }
 #pragma unroll 4
-      for (int v = 0; v < 16; ++v) {
-        const int64_t m = row0 + wr * 32 * MT + mt * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-        if (n_ok && m < p.M) {
-          float val = acc[mt][nt][v] + bias;
-          if (p.scale) val = val * scale + shift;
-          val = apply_act(val, p.act);
-          if (p.alpha != 1.0f) val *= p.alpha;
-          if (p.res) val += p.beta * p.res[m * p.ldr + n];
-          p.y[m * p.ldy + n] = val;
-        }
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 4 + (lane >> 4);
+    const int64_t m = m0 + row;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(slab + slab_off(row, 4 * c4));
+    if (m >= p.M) continue;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = finish(p, a[e], bias[e], scale[e], shift[e]);
+    if (p.res) {
+      const float* rr = p.res + m * p.ldr + n;
+      if (full && p.vec_r) {
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(rr);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += p.beta * rv[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.N) o[e] += p.beta * rr[e];
       }
+    }
+    float* yr = p.y + m * p.ldy + n;
+    if (full && p.vec_y) *reinterpret_cast<f32x4*>(yr) = o;
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < p.N) yr[e] = o[e];
+    }
+  }
+}
+
+// MF = edge of the MFMA tile: 32 (fp32 always; 16-bit modes on request) or 16 (16-bit modes).
+template <int MODE, class S, int MF>
+__global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [stages][A tile | B tile]; reused as [wave][64][64] fp32 by the epilogue
+  constexpr int MT = S::MT, NT_ = S::NT_;
+  static_assert(MF == 32 || (MF == 16 && MODE != MDG_PREC_F32), "the 16x16x32 form exists for the 16-bit modes only");
+  static_assert(NT_ == 2 && MT % 2 == 0 && S::WAVES * 16384 <= 2 * S::STAGE, "the epilogue turns 64 x 64 patches through 16 KB of LDS per wave");
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wr = wave / S::WN, wc = wave % S::WN;
+  int tx, ty;
+  if (!tile_of(p, tx, ty)) return;                        // workgroup-uniform
+  const int64_t col0 = static_cast<int64_t>(tx) * S::BN, row0 = static_cast<int64_t>(ty) * S::BM;
+  float* const slab = reinterpret_cast<float*>(smem) + wave * 4096;
+  const int64_t pm0 = row0 + wr * 32 * MT, pn0 = col0 + wc * 64;
+
+  if constexpr (MF == 16) {
+    const int c = lane & 15, g = lane >> 4;
+    f32x4 acc[2 * MT][2 * NT_];
+#pragma unroll
+    for (int a = 0; a < 2 * MT; ++a)
+#pragma unroll
+      for (int b = 0; b < 2 * NT_; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    k_loop<MODE, S, MF>(p, row0, col0, smem, wave, lane,
+                        [&](const char* la, const char* lb) { mma_stage16<MODE, S>(la, lb, wr, wc, c, g, acc); });
+    __syncthreads();                                      // every wave is done with the staging buffers
+#pragma unroll
+    for (int pass = 0; pass < MT / 2; ++pass) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) slab[slab_off(mt * 16 + 4 * g + v, nt * 16 + c)] = acc[pass * 4 + mt][nt][v];
+      slab_to_global(p, slab, pm0 + pass * 64, pn0, lane);
+    }
+  } else {
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[MT][NT_];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT_; ++b)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+    k_loop<MODE, S, MF>(p, row0, col0, smem, wave, lane,
+                        [&](const char* la, const char* lb) { mma_stage<MODE, S>(la, lb, wr, wc, r, h, acc); });
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < MT / 2; ++pass) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int v = 0; v < 16; ++v)
+            slab[slab_off(mt * 32 + (v & 3) + 8 * (v >> 2) + 4 * h, nt * 32 + r)] = acc[pass * 2 + mt][nt][v];
+      slab_to_global(p, slab, pm0 + pass * 64, pn0, lane);
     }
   }
 }
@@ -437,6 +562,8 @@ static void set_operand(Operand& o, const float* raw, int64_t ld, const char* im
 }
 
 static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t N, hipStream_t st) {
+  a.vec_y = mdg_aligned16(a.y) && a.ldy % 4 == 0;
+  a.vec_r = a.res && mdg_aligned16(a.res) && a.ldr % 4 == 0;
   // tile shape: the 256x256 / 8-wave shape once the problem fills the chip with it, else 128x128 / 4 waves
   // (measured on the fusion GEMMs: bf16x3 -9 % time with the big tile, fp32 +6 %: the fp32 MFMA wants two workgroups per CU)
   bool big = (precision != MDG_PREC_F32 && N >= 256 && M >= 1024 && mdg_cdiv(M, Big::BM) * mdg_cdiv(N, Big::BN) >= 192);
@@ -450,23 +577,24 @@ static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t 
     a.swizzle = swz_env >= 0 ? swz_env : (total >= 64 ? 1 : 0);
     return dim3(static_cast<unsigned>(a.swizzle ? 8 * ((total + 7) / 8) : total));
   };
-  if (big) {
-    const dim3 grid = grid_for(Big::BM, Big::BN);
-    const size_t lds = 2 * Big::STAGE;
-    switch (precision) {
-      case MDG_PREC_F32: hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, Big>), grid, dim3(Big::THREADS), lds, st, a); break;
-      case MDG_PREC_BF16X3: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, Big>), grid, dim3(Big::THREADS), lds, st, a); break;
-      default: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, Big>), grid, dim3(Big::THREADS), lds, st, a); break;
-    }
-  } else {
-    const dim3 grid = grid_for(Small::BM, Small::BN);
-    const size_t lds = 2 * Small::STAGE;
-    switch (precision) {
-      case MDG_PREC_F32: hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, Small>), grid, dim3(Small::THREADS), lds, st, a); break;
-      case MDG_PREC_BF16X3: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, Small>), grid, dim3(Small::THREADS), lds, st, a); break;
-      default: hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, Small>), grid, dim3(Small::THREADS), lds, st, a); break;
-    }
-  }
+  // 16-bit modes run on the 16x16x32 MFMA unless MDG_LINEAR_MFMA=32 asks for the 32x32x16 form
+  static const bool m16 = !(getenv("MDG_LINEAR_MFMA") && atoi(getenv("MDG_LINEAR_MFMA")) == 32);
+#define MDG_LAUNCH_LINEAR(S)                                                                                                       \
+  do {                                                                                                                             \
+    const dim3 grid = grid_for(S::BM, S::BN);                                                                                      \
+    const size_t lds = 2 * S::STAGE;                                                                                               \
+    if (precision == MDG_PREC_F32) hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, S, 32>), grid, dim3(S::THREADS), lds, st, a);  \
+    else if (precision == MDG_PREC_BF16X3) {                                                                                       \
+      if (m16) hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, S, 16>), grid, dim3(S::THREADS), lds, st, a);                    \
+      else hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, S, 32>), grid, dim3(S::THREADS), lds, st, a);                        \
+    } else {                                                                                                                       \
+      if (m16) hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, S, 16>), grid, dim3(S::THREADS), lds, st, a);                      \
+      else hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, S, 32>), grid, dim3(S::THREADS), lds, st, a);                          \
+    }                                                                                                                              \
+  } while (0)
+  if (big) MDG_LAUNCH_LINEAR(Big);
+  else MDG_LAUNCH_LINEAR(Small);
+#undef MDG_LAUNCH_LINEAR
 }
 
 extern "C" size_t mdg_pack_operand_bytes(int64_t rows, int64_t K, int precision) { return image_bytes(rows, K, precision); }
