@@ -560,6 +560,14 @@ class _GatherRows(Function):
     @once_differentiable
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        if ctx.n_rows <= 128:
+            # a small table (the 16 cell lines) under 10^4..10^5 lookups: one workgroup per table row would add its rows one
+            # after the other; as onehot(idx)^T dout the sum is the split-reduction weight-gradient kernel (exact fp32
+            # matrix cores, the rows of a split in order, the splits in order: deterministic)
+            onehot = torch.zeros((idx.numel(), ctx.n_rows), dtype=torch.float32, device=dout.device)
+            onehot.scatter_(1, idx.unsqueeze(1), 1.0)
+            return ops.grad_weight(onehot, dout), None
         # the index tensor of an embedding lookup is fixed for a run (cell-line ids of the tx stack): its sort is kept per
         # (storage, version, table size); the entry holds the tensor, so the address cannot be recycled under it
         key = (idx.data_ptr(), idx._version, idx.numel(), ctx.n_rows)
@@ -572,7 +580,6 @@ class _GatherRows(Function):
             hit = (key, order.contiguous(), rowptr, idx)
             _gather_plan["last"] = hit
         order, rowptr = hit[1], hit[2]
-        dout = dout if dout.is_contiguous() else dout.contiguous()
         return ops.csr_aggregate(dout, rowptr, order)[:, :dout.shape[1]], None
 
 

@@ -313,6 +313,91 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     part[static_cast<int64_t>(blockIdx.x) * 2 * d + i] = (sh[i] + sh[2 * d + i]) + (sh[4 * d + i] + sh[6 * d + i]);
 }
 
+// The same with 16 bytes per lane (d, the row strides and the pointers multiples of 4 floats): lane owns columns
+// 4*(lane + 64 j) .. +3.  32 rows per block: 22k token rows give ~700 workgroups instead of ~340.
+constexpr int LN_VEC_ROWS = 32;
+template <int MAXJ>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
+                                                                const float* __restrict__ gamma, float* __restrict__ dx, int64_t lddx,
+                                                                float* __restrict__ part, int64_t rows, int d, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dg[MAXJ], db[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) dg[j] = db[j] = zero;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * LN_VEC_ROWS;
+  const float inv_d = 1.0f / static_cast<float>(d);
+  for (int i = wave; i < LN_VEC_ROWS; i += 4) {
+    const int64_t r = r0 + i;
+    if (r >= rows) break;
+    f32x4 xv[MAXJ], gv[MAXJ];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = 4 * (lane + 64 * j);
+      const bool ok = c < d;
+      xv[j] = ok ? *reinterpret_cast<const f32x4*>(x + r * ldx + c) : zero;
+      gv[j] = ok ? *reinterpret_cast<const f32x4*>(dy + r * lddy + c) : zero;
+      s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
+    }
+    const float mean = mdg_wave_sum(s) * inv_d;
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j)
+      if (4 * (lane + 64 * j) < d) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = xv[j][e] - mean;
+          v += t * t;
+        }
+      }
+    const float rstd = 1.0f / sqrtf(mdg_wave_sum(v) * inv_d + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = 4 * (lane + 64 * j);
+      if (c < d) {
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xhat = (xv[j][e] - mean) * rstd;
+          const float dxh = gv[j][e] * gm[e];
+          dg[j][e] += gv[j][e] * xhat;
+          db[j][e] += gv[j][e];
+          s1 += dxh;
+          s2 += dxh * xhat;
+          xv[j][e] = xhat;
+          gv[j][e] = dxh;
+        }
+      }
+    }
+    s1 = mdg_wave_sum(s1) * inv_d;
+    s2 = mdg_wave_sum(s2) * inv_d;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = 4 * (lane + 64 * j);
+      if (c < d) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd * (gv[j][e] - s1 - xv[j][e] * s2);
+        *reinterpret_cast<f32x4*>(dx + r * lddx + c) = o;
+      }
+    }
+  }
+  extern __shared__ float sh[];       // [4][2][d]
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int c = 4 * (lane + 64 * j);
+    if (c < d) {
+      *reinterpret_cast<f32x4*>(sh + (wave * 2 + 0) * d + c) = dg[j];
+      *reinterpret_cast<f32x4*>(sh + (wave * 2 + 1) * d + c) = db[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * d; i += 256)
+    part[static_cast<int64_t>(blockIdx.x) * 2 * d + i] = (sh[i] + sh[2 * d + i]) + (sh[4 * d + i] + sh[6 * d + i]);
+}
+
 }  // namespace
 
 extern "C" int mdg_transpose(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t rows, int64_t cols, void* stream) {
@@ -326,14 +411,19 @@ extern "C" int mdg_transpose(const float* in, int64_t ldi, float* out, int64_t l
 }
 
 // rows per partial block: 256, grown so that no column needs more than 128 partials
-static int64_t colsum_slab(int64_t rows) {
-  int64_t slab = 256;
-  while (mdg_cdiv(rows, slab) > 128) slab *= 2;
-  return slab;
+// rows per partial: enough slabs that (column blocks x slabs) is ~2048 workgroups (a narrow, tall matrix -- a bias gradient
+// over 10^5..10^6 rows -- used to get <= 128 workgroups), at least 64 rows each
+static int64_t colsum_slab(int64_t rows, int64_t cols) {
+  int64_t parts = mdg_cdiv(2048, mdg_cdiv(cols, 64));
+  const int64_t most = mdg_cdiv(rows, 64);
+  if (parts > most) parts = most;
+  if (parts < 1) parts = 1;
+  const int64_t slab = (mdg_cdiv(rows, parts) + 3) & ~static_cast<int64_t>(3);
+  return slab < 64 ? 64 : slab;      // (rows == 0 included)
 }
 
 extern "C" size_t mdg_colsum_workspace_bytes(int64_t rows, int64_t cols) {
-  return rows <= 0 || cols <= 0 ? 0 : static_cast<size_t>(mdg_cdiv(rows, colsum_slab(rows))) * cols * sizeof(float);
+  return rows <= 0 || cols <= 0 ? 0 : static_cast<size_t>(mdg_cdiv(rows, colsum_slab(rows, cols))) * cols * sizeof(float);
 }
 
 extern "C" int mdg_colsum(const float* x, int64_t ldx, float* out, int64_t rows, int64_t cols, float beta, void* workspace,
@@ -341,7 +431,7 @@ extern "C" int mdg_colsum(const float* x, int64_t ldx, float* out, int64_t rows,
   MDG_CHECK_ARG(rows >= 0 && cols > 0 && ldx >= cols, "mdg_colsum: bad shape");
   MDG_CHECK_ARG(out, "mdg_colsum: null out");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int64_t slab = colsum_slab(rows);
+  const int64_t slab = colsum_slab(rows, cols);
   const int64_t nparts = mdg_cdiv(rows, slab);
   const size_t need = mdg_colsum_workspace_bytes(rows, cols);
   if (need && (!workspace || workspace_bytes < need)) {
@@ -457,7 +547,7 @@ extern "C" int mdg_batchnorm_train_bwd(const float* dy, const float* x, const fl
 
 // ------------------------------------------------------------------------------------------------- LayerNorm backward
 extern "C" size_t mdg_layernorm_bwd_workspace_bytes(int64_t rows, int64_t d) {
-  return rows <= 0 || d <= 0 ? 0 : static_cast<size_t>(mdg_cdiv(rows, 64)) * 2 * d * sizeof(float);
+  return rows <= 0 || d <= 0 ? 0 : static_cast<size_t>(mdg_cdiv(rows, LN_VEC_ROWS)) * 2 * d * sizeof(float);
 }
 
 extern "C" int mdg_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, float* dx, int64_t lddx,
@@ -467,7 +557,9 @@ extern "C" int mdg_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
   MDG_CHECK_ARG(lddy >= d && ldx >= d && lddx >= d, "mdg_layernorm_bwd: row strides shorter than d");
   MDG_CHECK_ARG(gamma && dgamma && dbeta, "mdg_layernorm_bwd: null parameter pointers");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int64_t nb = mdg_cdiv(rows, 64);
+  const bool vec = d % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && mdg_aligned16(dy) && mdg_aligned16(x) && mdg_aligned16(dx) &&
+                   mdg_aligned16(gamma);
+  const int64_t nb = mdg_cdiv(rows, vec ? LN_VEC_ROWS : 64);
   const size_t need = mdg_layernorm_bwd_workspace_bytes(rows, d);
   if (need && (!workspace || workspace_bytes < need)) {
     mdg_set_error("mdg_layernorm_bwd: workspace of %zu bytes required, got %zu", need, workspace_bytes);
@@ -477,12 +569,19 @@ extern "C" int mdg_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
     MDG_CHECK_ARG(dy && x && dx, "mdg_layernorm_bwd: null pointer");
     const size_t lds = static_cast<size_t>(8 * d) * sizeof(float);
     float* part = static_cast<float*>(workspace);
-    if (d <= 128)
-      hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(static_cast<unsigned>(nb)), dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, static_cast<int>(d), eps);
+    const dim3 grid(static_cast<unsigned>(nb));
+    const int di = static_cast<int>(d);
+    if (vec) {
+      if (d <= 256) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<1>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps);
+      else if (d <= 512) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<2>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps);
+      else if (d <= 1024) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<4>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps);
+      else hipLaunchKernelGGL(layernorm_bwd_vec_kernel<8>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps);
+    } else if (d <= 128)
+      hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps);
     else if (d <= 512)
-      hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(static_cast<unsigned>(nb)), dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, static_cast<int>(d), eps);
+      hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps);
     else
-      hipLaunchKernelGGL(layernorm_bwd_kernel<32>, dim3(static_cast<unsigned>(nb)), dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, static_cast<int>(d), eps);
+      hipLaunchKernelGGL(layernorm_bwd_kernel<32>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps);
   }
   // dgamma = sum of partial rows [nb, 2d] -> first d columns, dbeta the next d
   hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(d, 64))), dim3(256), 0, st, static_cast<const float*>(workspace),

@@ -752,6 +752,19 @@ def triple_plan(labels: torch.Tensor, heads: torch.Tensor, tails: torch.Tensor, 
     def by_drug(idx, n):
         order = torch.argsort(idx, stable=True)
         return torch.cat([zero, torch.cumsum(torch.bincount(idx, minlength=n), 0)]).contiguous(), order.contiguous()
+
+    def pieces(ptr):
+        """A drug's list can hold thousands of entries while mdg_csr_aggregate gives a row to one group of lanes: cut every
+        list into pieces of <= 64 entries -> (piece_ptr over the entries, row_ptr over the pieces) for a two-level sum
+        (_sum_rows); None when no list is long enough to matter."""
+        counts_ = ptr[1:] - ptr[:-1]
+        if counts_.numel() == 0 or int(counts_.max()) <= 256:
+            return None
+        per = (counts_ + 63) // 64
+        first = torch.cumsum(per, 0) - per
+        which = torch.repeat_interleave(torch.arange(counts_.numel(), device=dev), per)
+        start = ptr[which] + 64 * (torch.arange(which.numel(), device=dev) - first[which])
+        return (torch.cat([start, ptr[-1:]]).contiguous(), torch.cat([zero, torch.cumsum(per, 0)]).contiguous())
     head_ptr, head_rows = by_drug(hs, n_head)
     tail_ptr, tail_rows = by_drug(ts, n_tail)
     inv = torch.empty_like(perm)
@@ -786,11 +799,21 @@ def triple_plan(labels: torch.Tensor, heads: torch.Tensor, tails: torch.Tensor, 
                  "of_triple": pair_of_triple, "tile_start": ptile_start, "tile_label": ptile_label, "n_tiles": int(ptile_label.numel()),
                  "chunk_start": pchunk_start, "n_chunks": int(pchunk_start.numel()) - 1,
                  "label_chunk_ptr": torch.cat([zero, torch.cumsum(pchunks_per, 0)]).contiguous(), "drug_ptr": drug_ptr, "drug_rows": drug_rows,
-                 "of_triple_by_tail": pair_of_triple[tail_rows].contiguous()}
+                 "of_triple_by_tail": pair_of_triple[tail_rows].contiguous(), "drug_pieces": pieces(drug_ptr)}
     return {"T": T, "L": n_labels, "n_head": n_head, "n_tail": n_tail, "perm": perm, "inv_perm": inv, "heads": hs, "tails": ts, "pairs": pairs,
             "tile_start": tile_start, "tile_label": tile_label, "n_tiles": int(tile_label.numel()), "chunk_start": chunk_start,
             "n_chunks": int(chunk_start.numel()) - 1, "label_chunk_ptr": label_chunk_ptr, "head_ptr": head_ptr,
-            "head_rows": head_rows, "tail_ptr": tail_ptr, "tail_rows": tail_rows}
+            "head_rows": head_rows, "tail_ptr": tail_ptr, "tail_rows": tail_rows, "head_pieces": pieces(head_ptr),
+            "tail_pieces": pieces(tail_ptr)}
+
+
+def _sum_rows(x, ptr, rows, pieces, edge_weight=None):
+    """csr_aggregate(x, ptr, rows) with the long lists cut into the plan's pieces: piece sums first (many short rows), then
+    the pieces of a drug in order.  Same fixed order of additions from run to run."""
+    if pieces is None:
+        return csr_aggregate(x, ptr, rows, edge_weight=edge_weight)
+    part = csr_aggregate(x, pieces[0], rows, edge_weight=edge_weight)
+    return csr_aggregate(part, pieces[1], None)
 
 
 def bilinear_gather(z_head: torch.Tensor, z_tail: torch.Tensor, w: torch.Tensor, plan: dict) -> torch.Tensor:
@@ -822,8 +845,8 @@ def bilinear_gather_bwd(z_head, z_tail, w, plan: dict, dscore: torch.Tensor, w_t
                                         _ptr(plan["tile_start"]), _ptr(plan["tile_label"]), _c64(plan["n_tiles"]), _ptr(plan["chunk_start"]),
                                         _c64(plan["n_chunks"]), _ptr(plan["label_chunk_ptr"]), _c64(L), _ptr(ds), _ptr(gh), _ptr(gt),
                                         _ptr(part), _ptr(dw), _c64(128), _stream(zh)), "mdg_bilinear_gather_bwd")
-    dzh = csr_aggregate(gh, plan["head_ptr"], plan["head_rows"])
-    dzt = csr_aggregate(gt, plan["tail_ptr"], plan["tail_rows"])
+    dzh = _sum_rows(gh, plan["head_ptr"], plan["head_rows"], plan.get("head_pieces"))
+    dzt = _sum_rows(gt, plan["tail_ptr"], plan["tail_rows"], plan.get("tail_pieces"))
     return dzh, dzt, dw
 
 
@@ -863,13 +886,13 @@ def bilinear_gather_pairs_bwd(z_head, z_tail, w, plan: dict, dscore: torch.Tenso
     if pp is None:
         z = torch.zeros
         return z((plan["n_head"], 128), device=dev), z((plan["n_tail"], 128), device=dev), (z((L, 128, 128), device=dev) if need_dw else None)
-    dzt = csr_aggregate(V, plan["tail_ptr"], pp["of_triple_by_tail"], edge_weight=ds.index_select(0, plan["tail_rows"]))
+    dzt = _sum_rows(V, plan["tail_ptr"], pp["of_triple_by_tail"], plan.get("tail_pieces"), edge_weight=ds.index_select(0, plan["tail_rows"]))
     u = csr_aggregate(zt, pp["ptr"], pp["tails_by_pair"], edge_weight=ds.index_select(0, pp["order"]))
     R = torch.empty((pp["P"], 128), dtype=torch.float32, device=dev)
     L_ = lib()
     check(L_.mdg_bilinear_matvec_rows(_ptr(u), _ptr(w), _ptr(None), _ptr(pp["tile_start"]), _ptr(pp["tile_label"]), _c64(pp["n_tiles"]), _ptr(R),
                                       _c64(128), _stream(zh)), "mdg_bilinear_matvec_rows")
-    dzh = csr_aggregate(R, pp["drug_ptr"], pp["drug_rows"])
+    dzh = _sum_rows(R, pp["drug_ptr"], pp["drug_rows"], pp.get("drug_pieces"))
     dw = None
     if need_dw:
         dw = torch.empty((L, 128, 128), dtype=torch.float32, device=dev)
