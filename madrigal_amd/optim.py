@@ -27,6 +27,24 @@ class AdamW(torch.optim.Optimizer):
         self._chunk = int(lib().mdg_adamw_chunk_elems())
         self._layouts = {}
 
+    @staticmethod
+    def _upload(lay: dict, name: str, host: np.ndarray, dev) -> torch.Tensor:
+        """host array -> device tensor without waiting for the stream: a ring of pinned staging buffers per table (a buffer is
+        reused only after the copy issued from it has completed, which its event says)."""
+        ring = lay.setdefault("ring_" + name, {"slot": 0, "bufs": [None] * 3})
+        i = ring["slot"]
+        ring["slot"] = (i + 1) % len(ring["bufs"])
+        ent = ring["bufs"][i]
+        if ent is None or ent[0].shape != host.shape or ent[0].numpy().dtype != host.dtype:
+            ent = ring["bufs"][i] = [torch.from_numpy(np.empty_like(host)).pin_memory(), None]
+        if ent[1] is not None:
+            ent[1].synchronize()                        # issued three steps ago: long complete
+        ent[0].numpy()[...] = host
+        out = ent[0].to(dev, non_blocking=True)
+        ent[1] = torch.cuda.Event()
+        ent[1].record(torch.cuda.current_stream(dev))
+        return out
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -70,32 +88,22 @@ class AdamW(torch.optim.Optimizer):
                 self._layouts[(dev, sizes)] = lay
             if lay["n"] == 0:
                 continue
+            # per-step tables: the chunk pointers (gradients are re-allocated by every backward pass, so their addresses move)
+            # and the per-tensor hyper-parameters.  Both go through rotating PINNED host buffers and asynchronous copies: a
+            # pageable .to(device) waits for everything queued on the stream (the whole backward pass), which would stop the
+            # host from queueing the next step while this one still runs.
             base = np.asarray([(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()) for p, g, m, v, _ in items], dtype=np.int64)
-            if lay["base"] is None or not np.array_equal(base, lay["base"]):       # the allocator usually hands the same blocks back
+            if lay["base"] is None or not np.array_equal(base, lay["base"]):
                 lay["base"] = base
-                lay["t_ptr"] = torch.from_numpy(base[lay["owner"]] + lay["offs"][:, None]).to(dev)
-            # per-tensor hyper-parameters: through a rotating pair of PINNED host buffers and an asynchronous copy -- a pageable
-            # .to(device) waits for everything queued on the stream (the whole backward pass), which stops the host from
-            # issuing the next step while this one still runs
-            hyp = np.asarray([h for *_, h in items], dtype=np.float32)
-            slot = lay.setdefault("slot", 0)
-            pins = lay.setdefault("pins", [None, None])
-            if pins[slot] is None or pins[slot][0].shape != hyp.shape:
-                pins[slot] = [torch.empty(hyp.shape, dtype=torch.float32, pin_memory=True), None]
-            if pins[slot][1] is not None:
-                pins[slot][1].synchronize()            # the copy issued two steps ago has long landed
-            pins[slot][0].numpy()[...] = hyp
-            t_hyp = pins[slot][0].to(dev, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-            pins[slot][1] = ev
-            lay["slot"] = 1 - slot
+                lay["t_ptr"] = self._upload(lay, "ptr", base[lay["owner"]] + lay["offs"][:, None], dev)
+            t_hyp = self._upload(lay, "hyp", np.asarray([h for *_, h in items], dtype=np.float32), dev)
             with torch.cuda.device(dev):
                 check(lib().mdg_adamw_multi(ctypes.c_void_p(lay["t_ptr"].data_ptr()), ctypes.c_void_p(lay["t_len"].data_ptr()),
                                             ctypes.c_void_p(lay["t_own"].data_ptr()), ctypes.c_void_p(t_hyp.data_ptr()),
                                             ctypes.c_int64(lay["n"]), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
                       "mdg_adamw_multi")
             t_hyp.record_stream(torch.cuda.current_stream(dev))
+            lay["t_ptr"].record_stream(torch.cuda.current_stream(dev))
             # the kernel wrote the parameters and the moments behind torch's back: bump their in-place version counters so
             # that everything keyed on them (packed / derived weight caches of the inference path, autograd's saved-tensor
             # checks) sees the update

@@ -42,9 +42,10 @@ for i in range(a.warmup + a.steps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
     losses.append(fs.step(b, b, b["masks"], b["masks"], kgc, lab, hd, tl, y, kg_filler=filler))
+host_issue = (time.perf_counter() - t0) / a.steps          # the host is done queueing here; the GPU may still be working
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
-out = {"ms_per_step": dt * 1e3, "steps_per_sec": 1 / dt, "loss": [float(x) for x in losses], "drugs": a.drugs, "outcomes": a.outcomes,
+out = {"ms_per_step": dt * 1e3, "host_issue_ms_per_step": host_issue * 1e3, "steps_per_sec": 1 / dt, "loss": [float(x) for x in losses], "drugs": a.drugs, "outcomes": a.outcomes,
        "triples": int(lab.numel()), "precision": a.precision, "max_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
 if a.phases:
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
