@@ -101,26 +101,64 @@ template <int MODE, class S> constexpr int kStageBytes = (MODE == MDG_PREC_BF16)
 template <int MODE, class S> constexpr int kBOffset = (MODE == MDG_PREC_BF16) ? S::A_LO : S::A_BYTES;
 template <int MODE> constexpr int kStages = (MODE == MDG_PREC_BF16) ? 4 : 2;
 
-template <int MODE, class S, int MF = 32>
+// PART 0: the A tiles, 1: the B tiles, -1: both
+template <int MODE, class S, int MF = 32, int PART = -1>
 __device__ __forceinline__ void dma_stage(const Operand& A, const Operand& B, int64_t row0, int64_t col0, int64_t k0, char* lds,
                                           int wave, int lane) {
   if constexpr (MODE == MDG_PREC_F32) {
-    dma_tile<4, S::BM, S::WAVES>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane);
-    dma_tile<4, S::BN, S::WAVES>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES, wave, lane);
+    if constexpr (PART != 1) dma_tile<4, S::BM, S::WAVES>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane);
+    if constexpr (PART != 0) dma_tile<4, S::BN, S::WAVES>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES, wave, lane);
   } else {
-    dma_tile<2, S::BM, S::WAVES, MF>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane);
-    dma_tile<2, S::BN, S::WAVES, MF>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + kBOffset<MODE, S>, wave, lane);
-    if constexpr (MODE == MDG_PREC_BF16X3) {
-      dma_tile<2, S::BM, S::WAVES, MF>(A.p1, A.ld_bytes, row0, A.nrows, k0, lds + S::A_LO, wave, lane);
-      dma_tile<2, S::BN, S::WAVES, MF>(B.p1, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES + S::B_LO, wave, lane);
+    if constexpr (PART != 1) {
+      dma_tile<2, S::BM, S::WAVES, MF>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane);
+      if constexpr (MODE == MDG_PREC_BF16X3) dma_tile<2, S::BM, S::WAVES, MF>(A.p1, A.ld_bytes, row0, A.nrows, k0, lds + S::A_LO, wave, lane);
+    }
+    if constexpr (PART != 0) {
+      dma_tile<2, S::BN, S::WAVES, MF>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + kBOffset<MODE, S>, wave, lane);
+      if constexpr (MODE == MDG_PREC_BF16X3) dma_tile<2, S::BN, S::WAVES, MF>(B.p1, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES + S::B_LO, wave, lane);
     }
   }
 }
 
-template <int MODE, class S>
+// One of the wave's pieces of a bf16 tile, and the 8 issue slots of a k tile on the 16x16x32 path: the LDS-DMA of the next tile
+// is spread over the MFMA groups of the current one (slot = A-fragment group), one piece per slot, instead of arriving at the
+// memory system as one burst from every CU at the same moment (measured on the 2048-deep blocks: -4..-7 % time).
+template <int ROWS, int WAVES, int MF>
+__device__ __forceinline__ void dma_piece(const char* base, int64_t ld_bytes, int64_t row0, int64_t nrows, int64_t k0, char* lds,
+                                          int wave, int lane, int i) {
+  static_assert(ROWS * BK * 2 / 1024 / WAVES == 2, "two pieces per wave and tile plane");
+  const int p = wave + WAVES * i;
+  const int row = 16 * p + (lane >> 2);
+  const int c = (lane & 3) ^ (MF == 16 ? ((row >> 1) & 3) : ((row >> 2) & 3));
+  int64_t gr = row0 + row;
+  gr = gr < nrows ? gr : nrows - 1;
+  glds16(base + gr * ld_bytes + k0 * 2 + c * 16, lds_addr(lds + p * 1024));
+}
+
+template <int MODE, class S, int MF>
+__device__ __forceinline__ void dma_slot(const Operand& A, const Operand& B, int64_t row0, int64_t col0, int64_t k0, char* lds,
+                                         int wave, int lane, int slot) {
+  static_assert(MODE != MDG_PREC_F32, "16-bit modes");
+  int plane, i;                        // plane 0: A hi, 1: A lo, 2: B hi, 3: B lo
+  if constexpr (MODE == MDG_PREC_BF16X3) { plane = slot >> 1; i = slot & 1; }
+  else {
+    if (slot & 1) return;
+    plane = (slot >> 2) * 2;
+    i = (slot >> 1) & 1;
+  }
+  switch (plane) {
+    case 0: dma_piece<S::BM, S::WAVES, MF>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane, i); break;
+    case 1: dma_piece<S::BM, S::WAVES, MF>(A.p1, A.ld_bytes, row0, A.nrows, k0, lds + S::A_LO, wave, lane, i); break;
+    case 2: dma_piece<S::BN, S::WAVES, MF>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + kBOffset<MODE, S>, wave, lane, i); break;
+    default: dma_piece<S::BN, S::WAVES, MF>(B.p1, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES + S::B_LO, wave, lane, i); break;
+  }
+}
+
+template <int MODE, class S, class Mid>
 __device__ __forceinline__ void mma_stage(const char* la, const char* lb, int wr, int wc, int r, int h,
-                                          f32x16 (&acc)[S::MT][S::NT_]) {
+                                          f32x16 (&acc)[S::MT][S::NT_], Mid&& mid) {
   constexpr int MT = S::MT, NT_ = S::NT_;
+  mid(0);
   if constexpr (MODE == MDG_PREC_F32) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -136,6 +174,7 @@ __device__ __forceinline__ void mma_stage(const char* la, const char* lb, int wr
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][e], b[nt][e], acc[mt][nt], 0, 0, 0);
+      if (q == 1) mid(1);
     }
   } else {
 #pragma unroll
@@ -163,6 +202,7 @@ __device__ __forceinline__ void mma_stage(const char* la, const char* lb, int wr
           }
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
         }
+      if (s == 0) mid(1);
     }
   }
 }
@@ -172,9 +212,9 @@ __device__ __forceinline__ void mma_stage(const char* la, const char* lb, int wr
 // power limit that buys clock (measured on the row-statistics head, which has this loop shape: +13 %).  A wave's 32*MT x 32*NT
 // patch becomes 2MT x 2NT tiles of 16x16; lane (c = lane & 15, g = lane >> 4) holds row c / column c, k chunk g of a fragment
 // and rows 4g..4g+3 of column c of an accumulator tile.  B fragments stay in registers over the two halves of the A tiles.
-template <int MODE, class S>
+template <int MODE, class S, class Mid>
 __device__ __forceinline__ void mma_stage16(const char* la, const char* lb, int wr, int wc, int c, int g,
-                                            f32x4 (&acc)[2 * S::MT][2 * S::NT_]) {
+                                            f32x4 (&acc)[2 * S::MT][2 * S::NT_], Mid&& mid) {
   constexpr int MT2 = 2 * S::MT, NT2 = 2 * S::NT_;
   bf16x8 bh[NT2], bl[NT2];
 #pragma unroll
@@ -193,7 +233,9 @@ __device__ __forceinline__ void mma_stage16(const char* la, const char* lb, int 
       if constexpr (MODE == MDG_PREC_BF16X3) al[t] = *reinterpret_cast<const bf16x8*>(la + S::A_LO + oa);
     }
 #pragma unroll
-    for (int t = 0; t < MT2 / 2; ++t)
+    for (int t = 0; t < MT2 / 2; ++t) {
+#pragma unroll
+      for (int u = 0; u < 8 / MT2; ++u) mid((half * (MT2 / 2) + t) * (8 / MT2) + u);      // 8 issue slots per k tile
 #pragma unroll
       for (int nt = 0; nt < NT2; ++nt) {
         f32x4& a = acc[half * (MT2 / 2) + t][nt];
@@ -203,6 +245,7 @@ __device__ __forceinline__ void mma_stage16(const char* la, const char* lb, int 
         }
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bh[nt], a, 0, 0, 0);
       }
+    }
   }
 }
 
@@ -237,6 +280,22 @@ __device__ __forceinline__ bool tile_of(const LinearArgs& p, int& tx, int& ty) {
   return true;
 }
 
+// the part of the next tile's LDS-DMA that goes out at issue slot `slot` of the current tile's MFMA sequence
+template <int MODE, class S, int MF>
+__device__ __forceinline__ void issue(const Operand& A, const Operand& B, int64_t row0, int64_t col0, int64_t k0, char* lds, int wave,
+                                      int lane, int slot) {
+  if constexpr (MF == 16 && MODE == MDG_PREC_BF16X3) {
+    // two stages only: the pieces must be out early enough to land before the next tile starts -- two per slot over the
+    // first half of the MFMA sequence (all eight over the whole sequence was slower again)
+    if (slot < 4) {
+      dma_slot<MODE, S, MF>(A, B, row0, col0, k0, lds, wave, lane, 2 * slot);
+      dma_slot<MODE, S, MF>(A, B, row0, col0, k0, lds, wave, lane, 2 * slot + 1);
+    }
+  } else if constexpr (MF == 16) dma_slot<MODE, S, MF>(A, B, row0, col0, k0, lds, wave, lane, slot);
+  else if (slot == 0) dma_stage<MODE, S, MF, 0>(A, B, row0, col0, k0, lds, wave, lane);
+  else dma_stage<MODE, S, MF, 1>(A, B, row0, col0, k0, lds, wave, lane);
+}
+
 // Pipeline: one raw barrier per k-tile.  Top of tile kt: wait for this wave's DMA pieces of tile kt (the only
 // vector-memory ops in flight), barrier (=> every wave's pieces landed, every wave finished reading tile kt-1),
 // issue the DMA of tile kt+1 into the other buffer, then the MFMAs of tile kt run under that DMA.
@@ -257,8 +316,10 @@ __device__ __forceinline__ void k_loop(const LinearArgs& p, int64_t row0, int64_
       else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (kt + 3 < nk) dma_stage<MODE, S, MF>(p.A, p.B, row0, col0, static_cast<int64_t>(kt + 3) * BK, smem + ((kt + 3) & 3) * SB, wave, lane);
-      mma(cur, cur + kBOffset<MODE, S>);
+      const bool more = kt + 3 < nk;
+      char* const dst = smem + ((kt + 3) & 3) * SB;
+      const int64_t kn = static_cast<int64_t>(kt + 3) * BK;
+      mma(cur, cur + kBOffset<MODE, S>, [&](int slot) { if (more) issue<MODE, S, MF>(p.A, p.B, row0, col0, kn, dst, wave, lane, slot); });
     }
   } else {
     dma_stage<MODE, S, MF>(p.A, p.B, row0, col0, 0, smem, wave, lane);
@@ -267,8 +328,9 @@ __device__ __forceinline__ void k_loop(const LinearArgs& p, int64_t row0, int64_
       char* const nxt = smem + ((kt + 1) & 1) * S::STAGE;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (kt + 1 < nk) dma_stage<MODE, S, MF>(p.A, p.B, row0, col0, static_cast<int64_t>(kt + 1) * BK, nxt, wave, lane);
-      mma(cur, cur + S::A_BYTES);
+      const bool more = kt + 1 < nk;
+      const int64_t kn = static_cast<int64_t>(kt + 1) * BK;
+      mma(cur, cur + S::A_BYTES, [&](int slot) { if (more) issue<MODE, S, MF>(p.A, p.B, row0, col0, kn, nxt, wave, lane, slot); });
     }
   }
 }
@@ -358,7 +420,7 @@ __global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs 
 #pragma unroll
       for (int b = 0; b < 2 * NT_; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     k_loop<MODE, S, MF>(p, row0, col0, smem, wave, lane,
-                        [&](const char* la, const char* lb) { mma_stage16<MODE, S>(la, lb, wr, wc, c, g, acc); });
+                        [&](const char* la, const char* lb, auto&& mid) { mma_stage16<MODE, S>(la, lb, wr, wc, c, g, acc, mid); });
     __syncthreads();                                      // every wave is done with the staging buffers
 #pragma unroll
     for (int pass = 0; pass < MT / 2; ++pass) {
@@ -380,7 +442,7 @@ __global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs 
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
     k_loop<MODE, S, MF>(p, row0, col0, smem, wave, lane,
-                        [&](const char* la, const char* lb) { mma_stage<MODE, S>(la, lb, wr, wc, r, h, acc); });
+                        [&](const char* la, const char* lb, auto&& mid) { mma_stage<MODE, S>(la, lb, wr, wc, r, h, acc, mid); });
     __syncthreads();
 #pragma unroll
     for (int pass = 0; pass < MT / 2; ++pass) {

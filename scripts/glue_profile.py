@@ -20,6 +20,45 @@ fs = FinetuneStep(model, create_optimizer(model, hp))
 for _ in range(2):
     fs.step(b, b, b["masks"], b["masks"], kgc, lab, hd, tl, y, kg_filler=filler)
 torch.cuda.synchronize()
+import sys as _sys
+from torch.overrides import TorchFunctionMode, resolve_name
+
+
+class Sites(TorchFunctionMode):
+    """Counts torch.* calls made from the package's Python (not the ones the autograd engine makes itself) by call site."""
+
+    def __init__(self):
+        super().__init__()
+        self.count = collections.Counter()
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        f = _sys._getframe(1)
+        site = None
+        while f is not None:
+            fn = f.f_code.co_filename
+            if "madrigal_amd" in fn:
+                site = f"{os.path.basename(fn)}:{f.f_lineno}"
+                break
+            f = f.f_back
+        name = resolve_name(func) or getattr(func, "__name__", str(func))
+        self.count[(name, site)] += 1
+        return func(*args, **(kwargs or {}))
+
+
+LAUNCHING = ("zeros", "zero_", "fill_", "ones", "full", "add", "sub", "mul", "div", "cat", "stack", "index_select", "clone", "copy_", "contiguous",
+             "index_add", "sum", "cumsum", "arange", "where", "to", "reshape", "__getitem__", "__setitem__", "repeat_interleave", "gather",
+             "scatter", "empty", "neg", "exp", "sigmoid", "mean", "masked_fill", "expand", "float", "long", "bool", "any", "all", "sort", "argsort")
+with Sites() as sites:
+    fs.step(b, b, b["masks"], b["masks"], kgc, lab, hd, tl, y, kg_filler=filler)
+    torch.cuda.synchronize()
+by_op = collections.Counter()
+for (name, site), c in sites.count.items():
+    by_op[name] += c
+print("torch calls from package Python in one step:", sum(by_op.values()))
+for name, c in by_op.most_common(40):
+    top = sorted(((cc, st) for (n, st), cc in sites.count.items() if n == name), reverse=True)[:6]
+    print(f"== {name}: {c}   " + "  ".join(f"{st}x{cc}" for cc, st in top))
+_sys.exit(0)
 with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=False) as prof:
     fs.step(b, b, b["masks"], b["masks"], kgc, lab, hd, tl, y, kg_filler=filler)
     torch.cuda.synchronize()
