@@ -77,27 +77,99 @@ struct AttnArgs {
   float* dqkv; int64_t lddq;         // backward: gradient of qkv, same layout
 };
 
-// Scores -> attention weights of one (tile, head) wave, in the swapped layout: lane (x = query, half) holds
-// acc[v] = P[x][j], j = (v&3) + 8(v>>2) + 4*half.  Shared by the forward and the backward kernel.
-__device__ __forceinline__ void attn_weights(const AttnArgs& p, const float* qrow, const float* krow, int64_t drug, int64_t base, int xr, int T,
-                                             int half, f32x16& acc) {
+// Operand staging.  The 32x32x2 MFMA wants lane x to hold ROW x of its operand, but a row-per-lane global load touches 32
+// rows 24 KB apart for 32 bytes each.  So a wave first copies the 32 rows x 64 floats it is about to consume into its own
+// LDS tile with row-major loads (16 lanes x 16 B = one 256-byte row piece, 4 rows per instruction) and reads its row back from
+// there.  64 floats per row with the 16-byte piece index XORed by the row: the row reads of 16 consecutive lanes fall on 16
+// distinct pieces.  No barrier: a wave's LDS operations execute in order and the tile is private to the wave.
+constexpr int kTileFloats = 32 * 64;
+__device__ __forceinline__ int tile_off(int row, int piece) { return row * 64 + ((piece ^ (row & 15)) << 2); }
+
+__device__ __forceinline__ void load_rows(const float* mat, int64_t ld, int T, int k0, int dh, int lane, f32x4 (&r)[8]) {
+  const int k = k0 + 4 * (lane & 15);
 #pragma unroll
-  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-  for (int k0 = 0; k0 < p.dh; k0 += 64) {
-    f32x4 qf[8], kf[8];
+  for (int i = 0; i < 8; ++i) {
+    const int row = (lane >> 4) + 4 * i;
+    const int rr = row < T ? row : T - 1;                      // rows past the tile repeat its last row (they meet zero weights)
+    r[i] = k < dh ? *reinterpret_cast<const f32x4*>(mat + static_cast<int64_t>(rr) * ld + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+__device__ __forceinline__ void write_rows(const f32x4 (&r)[8], float* tile, int lane) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int k = k0 + 8 * q + 4 * half;
-      const bool ok = k < p.dh;
-      qf[q] = ok ? *reinterpret_cast<const f32x4*>(qrow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-      kf[q] = ok ? *reinterpret_cast<const f32x4*>(krow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(tile + tile_off((lane >> 4) + 4 * i, lane & 15)) = r[i];
+}
+
+// out[i][c] = sum_j w[i][j] m[j][c] for the 32 x 32 weights a wave holds in the swapped layout (lane x = row i, registers =
+// j) and a row-major operand m (32 rows x dh): the P V product of the forward pass, and dS K, dS^T Q, Pd^T dO of the backward
+// pass.  m is staged 64 columns at a time, the next piece in flight (in registers) while the current one feeds the MFMAs from
+// LDS; with the weights as the A operand the result comes out with the lane on the column, so every store is a 128-byte
+// row piece.
+__device__ __forceinline__ void weights_rows_product(const f32x16& w, const float* m, int64_t ldm, float* out, int64_t ldo, int T, int dh,
+                                                     float* ta, float* tb, int x, int half, int lane) {
+  f32x4 pre[8];
+  load_rows(m, ldm, T, 0, dh, lane, pre);
+  write_rows(pre, ta, lane);
+  for (int c0 = 0, it = 0; c0 < dh; c0 += 64, ++it) {
+    const float* cur = (it & 1) ? tb : ta;
+    float* nxt = (it & 1) ? ta : tb;
+    const bool more = c0 + 64 < dh;
+    if (more) load_rows(m, ldm, T, c0 + 64, dh, lane, pre);
+#pragma unroll
+    for (int hc = 0; hc < 2; ++hc) {
+      const int col = hc * 32 + x;
+      f32x16 o;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) o[v] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int j = (s & 3) + 8 * (s >> 2) + 4 * half;
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s], cur[tile_off(j, col >> 2) + (col & 3)], o, 0, 0, 0);
+      }
+      if (c0 + col < dh) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int i = (v & 3) + 8 * (v >> 2) + 4 * half;
+          if (i < T) out[static_cast<int64_t>(i) * ldo + c0 + col] = o[v];
+        }
+      }
+    }
+    if (more) write_rows(pre, nxt, lane);
+  }
+}
+
+// acc += B^T-style product of the swapped layout: acc[v] (lane x) += sum_k a[j_v][k] * b[x][k] over the dh columns of two
+// row-major operands a (rows -> accumulator registers) and b (rows -> lanes), b scaled by `bscale`.
+__device__ __forceinline__ void rows_product(const float* a, int64_t lda, const float* b, int64_t ldb, int T, int dh, float bscale, float* ta,
+                                             float* tb, int x, int half, int lane, f32x16& acc) {
+  f32x4 ra[8], rb[8];
+  load_rows(a, lda, T, 0, dh, lane, ra);
+  load_rows(b, ldb, T, 0, dh, lane, rb);
+  for (int k0 = 0; k0 < dh; k0 += 64) {
+    write_rows(ra, ta, lane);
+    write_rows(rb, tb, lane);
+    if (k0 + 64 < dh) {                                        // the next 64 columns travel while these feed the MFMAs
+      load_rows(a, lda, T, k0 + 64, dh, lane, ra);
+      load_rows(b, ldb, T, k0 + 64, dh, lane, rb);
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 af = *reinterpret_cast<const f32x4*>(ta + tile_off(x, 2 * q + half));
+      const f32x4 bf = *reinterpret_cast<const f32x4*>(tb + tile_off(x, 2 * q + half));
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[q][e], qf[q][e] * p.qscale, acc, 0, 0, 0);
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e] * bscale, acc, 0, 0, 0);
+    }
   }
+}
+
+// Scores -> attention weights of one (tile, head) wave, in the swapped layout: lane (x = query, half) holds
+// acc[v] = P[x][j], j = (v&3) + 8(v>>2) + 4*half.  Shared by the forward and the backward kernel.  qmat / kmat: the tile's
+// first row of q / k at this head's columns; ta / tb: the wave's two staging tiles.
+__device__ __forceinline__ void attn_weights(const AttnArgs& p, const float* qmat, const float* kmat, int64_t drug, int64_t base, int x, int xr, int T,
+                                             int half, int lane, float* ta, float* tb, f32x16& acc) {
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+  rows_product(kmat, p.ld, qmat, p.ld, T, p.dh, p.qscale, ta, tb, x, half, lane, acc);
   const uint32_t blocked = p.row_start ? (p.row_bits ? p.row_bits[base + xr] : 0u)
                                        : ((p.kpm_bits ? p.kpm_bits[drug] : 0u) | (p.src_bits ? p.src_bits[xr] : 0u));
   float m = -INFINITY;
@@ -126,8 +198,9 @@ __device__ __forceinline__ float attn_drop_scale(const AttnArgs& p, int64_t gw, 
 }
 
 __global__ __launch_bounds__(256) void fusion_attention_kernel(const AttnArgs p) {
-  const int lane = threadIdx.x & 63, x = lane & 31, half = lane >> 5;
-  const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  __shared__ __attribute__((aligned(16))) float stage[4][2][kTileFloats];
+  const int lane = threadIdx.x & 63, x = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + wave;
   if (gw >= p.n * p.H) return;
   const int64_t drug = gw / p.H;
   const int head = static_cast<int>(gw % p.H);
@@ -137,11 +210,10 @@ __global__ __launch_bounds__(256) void fusion_attention_kernel(const AttnArgs p)
   const int T = p.row_start ? static_cast<int>(p.row_start[drug + 1] - base) : p.S;
   if (T <= 0) return;
   const int xr = x < T ? x : T - 1;
-  const float* qrow = p.qkv + (base + xr) * p.ld + head * p.dh;
-  const float* krow = qrow + d;
+  const float* qmat = p.qkv + base * p.ld + head * p.dh;
 
   f32x16 acc;
-  attn_weights(p, qrow, krow, drug, base, xr, T, half, acc);
+  attn_weights(p, qmat, qmat + d, drug, base, x, xr, T, half, lane, stage[wave][0], stage[wave][1], acc);
 
   if (p.probs && x < T) {
     float* pr = p.probs + ((drug * p.H + head) * p.S + x) * p.S;
@@ -159,25 +231,7 @@ __global__ __launch_bounds__(256) void fusion_attention_kernel(const AttnArgs p)
     for (int v = 0; v < 16; ++v) acc[v] *= attn_drop_scale(p, gw, x, (v & 3) + 8 * (v >> 2) + 4 * half, thr, ks);
   }
 
-  const float* vbase = p.qkv + base * p.ld + 2 * d + head * p.dh;
-  for (int c0 = 0; c0 < p.dh; c0 += 32) {
-    f32x16 o;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) o[v] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      int j = (s & 3) + 8 * (s >> 2) + 4 * half;
-      j = j < T ? j : T - 1;                        // clamped rows meet p == 0
-      const float vv = vbase[static_cast<int64_t>(j) * p.ld + c0 + x];
-      o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, acc[s], o, 0, 0, 0);
-    }
-    if (x < T) {
-      float* orow = p.out + (base + x) * p.ldo + head * p.dh + c0;
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4*>(orow + 8 * g + 4 * half) = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
-    }
-  }
+  weights_rows_product(acc, qmat + 2 * d, p.ld, p.out + base * p.ldo + head * p.dh, p.ldo, T, p.dh, stage[wave][0], stage[wave][1], x, half, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -189,7 +243,8 @@ __global__ __launch_bounds__(256) void fusion_attention_kernel(const AttnArgs p)
 //   dK  = qscale dS^T Q,  dV = Pd^T dO   (contraction over queries: dS / Pd are transposed through a 32x33 LDS tile)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void fusion_attention_bwd_kernel(const AttnArgs p) {
-  __shared__ float tile[4][2][32][33];
+  __shared__ __attribute__((aligned(16))) float stage[4][2][kTileFloats];       // staging tiles, later the two 32x33 transpose tiles
+  static_assert(kTileFloats >= 32 * 33, "the transpose tiles reuse the staging tiles");
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63, x = lane & 31, half = lane >> 5;
   const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + wave;
@@ -201,32 +256,18 @@ __global__ __launch_bounds__(256) void fusion_attention_bwd_kernel(const AttnArg
   const int T = p.row_start ? static_cast<int>(p.row_start[drug + 1] - base) : p.S;
   if (T <= 0) return;
   const int xr = x < T ? x : T - 1;
-  const float* qrow = p.qkv + (base + xr) * p.ld + head * p.dh;
-  const float* krow = qrow + d;
-  const float* vrow = qrow + 2 * d;
-  const float* dorow = p.dout + (base + xr) * p.lddo + head * p.dh;
+  const float* qmat = p.qkv + base * p.ld + head * p.dh;
+  float* const ta = stage[wave][0];
+  float* const tb = stage[wave][1];
 
   f32x16 P;
-  attn_weights(p, qrow, krow, drug, base, xr, T, half, P);
+  attn_weights(p, qmat, qmat + d, drug, base, x, xr, T, half, lane, ta, tb, P);
 
   // dPd[x][j] = sum_c dO[x][c] V[j][c]
   f32x16 dP;
 #pragma unroll
   for (int v = 0; v < 16; ++v) dP[v] = 0.f;
-  for (int k0 = 0; k0 < p.dh; k0 += 64) {
-    f32x4 gf[8], vf[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int k = k0 + 8 * q + 4 * half;
-      const bool ok = k < p.dh;
-      gf[q] = ok ? *reinterpret_cast<const f32x4*>(dorow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-      vf[q] = ok ? *reinterpret_cast<const f32x4*>(vrow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dP = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[q][e], gf[q][e], dP, 0, 0, 0);
-  }
+  rows_product(qmat + 2 * d, p.ld, p.dout + base * p.lddo + head * p.dh, p.lddo, T, p.dh, 1.0f, ta, tb, x, half, lane, dP);
 
   f32x16 Pd = P;
   if (p.p_drop > 0.f) {
@@ -256,27 +297,12 @@ __global__ __launch_bounds__(256) void fusion_attention_bwd_kernel(const AttnArg
   }
 
   // dQ[x][c] = sum_j dS[x][j] K[j][c]   (as the forward P V product, with K in place of V)
-  const float* kbase = p.qkv + base * p.ld + d + head * p.dh;
-  for (int c0 = 0; c0 < p.dh; c0 += 32) {
-    f32x16 o;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) o[v] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      int j = (s & 3) + 8 * (s >> 2) + 4 * half;
-      j = j < T ? j : T - 1;
-      o = __builtin_amdgcn_mfma_f32_32x32x2f32(kbase[static_cast<int64_t>(j) * p.ld + c0 + x], dS[s], o, 0, 0, 0);
-    }
-    if (x < T) {
-      float* r = p.dqkv + (base + x) * p.lddq + head * p.dh + c0;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(r + 8 * g + 4 * half) = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
-    }
-  }
+  float* const dq = p.dqkv + base * p.lddq + head * p.dh;
+  weights_rows_product(dS, qmat + d, p.ld, dq, p.lddq, T, p.dh, ta, tb, x, half, lane);
 
   // transpose dS and Pd through LDS: afterwards lane (j, half) holds X[x'][j] for x' = (s&3) + 8(s>>2) + 4*half
-  float (*tS)[33] = tile[wave][0];
-  float (*tP)[33] = tile[wave][1];
+  float (*tS)[33] = reinterpret_cast<float (*)[33]>(ta);
+  float (*tP)[33] = reinterpret_cast<float (*)[33]>(tb);
 #pragma unroll
   for (int v = 0; v < 16; ++v) {
     const int j = (v & 3) + 8 * (v >> 2) + 4 * half;
@@ -294,29 +320,8 @@ __global__ __launch_bounds__(256) void fusion_attention_bwd_kernel(const AttnArg
   }
 
   // dK[j][c] = sum_x dS[x][j] Q[x][c],  dV[j][c] = sum_x Pd[x][j] dO[x][c]   (lane = key j after the transpose)
-  const float* qbase = p.qkv + base * p.ld + head * p.dh;
-  const float* gbase = p.dout + base * p.lddo + head * p.dh;
-  for (int c0 = 0; c0 < p.dh; c0 += 32) {
-    f32x16 ok, ov;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) ok[v] = ov[v] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      int xq = (s & 3) + 8 * (s >> 2) + 4 * half;
-      xq = xq < T ? xq : T - 1;                      // clamped query rows meet dS = Pd = 0
-      ok = __builtin_amdgcn_mfma_f32_32x32x2f32(qbase[static_cast<int64_t>(xq) * p.ld + c0 + x], dSt[s], ok, 0, 0, 0);
-      ov = __builtin_amdgcn_mfma_f32_32x32x2f32(gbase[static_cast<int64_t>(xq) * p.lddo + c0 + x], Pdt[s], ov, 0, 0, 0);
-    }
-    if (x < T) {
-      float* rk = p.dqkv + (base + x) * p.lddq + d + head * p.dh + c0;
-      float* rv = rk + d;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        *reinterpret_cast<f32x4*>(rk + 8 * g + 4 * half) = f32x4{ok[4 * g], ok[4 * g + 1], ok[4 * g + 2], ok[4 * g + 3]};
-        *reinterpret_cast<f32x4*>(rv + 8 * g + 4 * half) = f32x4{ov[4 * g], ov[4 * g + 1], ov[4 * g + 2], ov[4 * g + 3]};
-      }
-    }
-  }
+  weights_rows_product(dSt, qmat, p.ld, dq + d, p.lddq, T, p.dh, ta, tb, x, half, lane);
+  weights_rows_product(Pdt, p.dout + base * p.lddo + head * p.dh, p.lddo, dq + 2 * d, p.lddq, T, p.dh, ta, tb, x, half, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
