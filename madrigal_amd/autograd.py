@@ -710,6 +710,53 @@ def hgt_project(layout, total_floats, precision, xs, ws, bs):
     return _HgtProject.apply(tuple(layout), total_floats, precision, *xs, *ws, *bs)
 
 
+class _HgtProjectRows(Function):
+    """_HgtProject with the composite weights of all node types stacked in ONE matrix (rows offs[i]..offs[i+1] belong to type
+    i; all types share the input width): one weight / bias gradient tensor comes back instead of one pair per type, so the
+    parameter-space graph above it stays small.  args = big_w [rows,in], big_b [rows], x_0..x_{n-1}."""
+
+    @staticmethod
+    def forward(ctx, layout, total_floats, precision, offs, big_w, big_b, *xs):
+        flat = torch.zeros(max(total_floats, 128), dtype=torch.float32, device=big_w.device)      # unprojected types stay zero
+        big_w = big_w if big_w.is_contiguous() else big_w.contiguous()
+        big_b = big_b if big_b.is_contiguous() else big_b.contiguous()
+        xs2 = []
+        for i, ((off, rows, width), x) in enumerate(zip(layout, xs)):
+            x2 = x if x.is_contiguous() else x.contiguous()
+            xs2.append(x2)
+            if offs[i + 1] - offs[i] != width:
+                raise ValueError("hgt_project_rows: weight rows disagree with the projection width")
+            if rows:
+                ops.linear(x2, big_w[offs[i]:offs[i + 1]], big_b[offs[i]:offs[i + 1]], precision=precision,
+                           out=flat[off:off + rows * width].view(rows, width), cache_weight=False)
+        ctx.layout, ctx.precision, ctx.offs = layout, precision, offs
+        ctx.save_for_backward(big_w, *xs2)
+        return flat.view(-1, 128)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dflat):
+        big_w, xs = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        offs = ctx.offs
+        dflat = (dflat if dflat.is_contiguous() else dflat.contiguous()).view(-1)
+        dw = torch.empty_like(big_w)
+        db = torch.empty(big_w.shape[0], dtype=torch.float32, device=big_w.device)
+        dxs = []
+        for i, ((off, rows, width), x) in enumerate(zip(ctx.layout, xs)):
+            g = dflat[off:off + rows * width].view(rows, width)
+            w = big_w[offs[i]:offs[i + 1]]
+            dx = None
+            if ctx.needs_input_grad[6 + i]:
+                dx = ops.linear(g, ops.transpose(w), precision=ctx.precision, cache_weight=False)[:, :x.shape[1]] if rows else torch.zeros_like(x)
+            ops.grad_weight(g, x, ctx.precision, want_bias=True, out=(dw[offs[i]:offs[i + 1]], db[offs[i]:offs[i + 1]]))
+            dxs.append(dx)
+        return (None, None, None, None, dw, db, *dxs)
+
+
+def hgt_project_rows(layout, total_floats, precision, xs, big_w, big_b, offs):
+    return _HgtProjectRows.apply(tuple(layout), total_floats, precision, tuple(offs), big_w, big_b, *xs)
+
+
 class _HgtAttentionFlat(Function):
     """Edge attention of every destination type, queries read from / query gradients written to the flat buffer itself:
     one gradient tensor for the whole projection buffer, no per-type scatter of dq."""

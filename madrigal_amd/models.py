@@ -510,6 +510,59 @@ class HGTConv(nn.Module):
         bkv = torch.stack([torch.matmul(mk, bk), torch.matmul(mv, bv)], dim=1).reshape(-1)
         return torch.cat([Wq, wkv], 0), torch.cat([bq, bkv], 0)
 
+    def _composite_all_train(self, types, plan: dict):
+        """Every projected node type's composite weight at once (all types share the input width): the rows
+        q | k'_r v'_r ... of all types as ONE matrix [rows, in] in the order of the flat projection buffer, built from the live
+        parameters with two batched products over the used relations (bmm of the [Ru,128,128] relation blocks with the
+        source types' K / V weights) instead of four products, six slices and two concatenations per node type -- and,
+        above all, with a backward graph of ~25 nodes instead of ~25 per type.  -> (W [rows,in], b [rows], first row per type)."""
+        F = self.out_channels
+        mk_all, mv_all = self._relation_blocks_train()
+        key = ("all", tuple(types), tuple(plan["used"]))
+        meta = self.__dict__.setdefault("_rel_idx", {}).get(key)
+        dev = mk_all.device
+        if meta is None or meta[0].device != dev:
+            rel_idx, src_slot, perm, offs, row = [], [], [], [], 0
+            for i, t in enumerate(types):
+                offs.append(row)
+                perm.extend(range(i * F, (i + 1) * F))
+                row += F
+                for e in plan["used"]:
+                    if e[0] == t:
+                        g = len(rel_idx)
+                        rel_idx.append(self.edge_types.index(e))
+                        src_slot.append(i)
+                        perm.extend(range(len(types) * F + g * 2 * F, len(types) * F + (g + 1) * 2 * F))
+                        row += 2 * F
+            offs.append(row)
+            # source type of each used relation as a 0/1 selection matrix: several relations leave the same type, and the
+            # backward of an index_select with repeated indices adds with atomics (run-to-run different low bits); as a
+            # product with a constant matrix the gradient is a plain GEMM
+            sel = torch.zeros(len(rel_idx), len(types), device=dev)
+            if rel_idx:
+                sel[torch.arange(len(rel_idx)), torch.tensor(src_slot)] = 1.0
+            meta = (torch.tensor(rel_idx, dtype=torch.int64, device=dev), sel, torch.tensor(perm, dtype=torch.int64, device=dev), offs)
+            self.__dict__["_rel_idx"][key] = meta
+        rel_idx, sel, perm, offs = meta
+        lins = [self.kqv_lin.lins[t] for t in types]
+        NT, cin = len(types), lins[0].weight.shape[1]
+        Wk, Wq, Wv = torch.stack([l.weight for l in lins]).view(NT, 3, F, cin).unbind(1)              # [NT,F,in] each
+        bk, bq, bv = torch.stack([l.bias for l in lins]).view(NT, 3, F).unbind(1)
+        if rel_idx.numel() == 0:
+            return Wq.reshape(NT * F, cin).index_select(0, perm), bq.reshape(-1).index_select(0, perm), offs
+        mk, mv = mk_all.index_select(0, rel_idx), mv_all.index_select(0, rel_idx)                       # [Ru,128,128]
+        Ru = int(rel_idx.numel())
+
+        def of_source(v):                                              # [NT, ...] -> [Ru, ...]: row of each relation's source type
+            return torch.matmul(sel, v.reshape(NT, -1)).view(Ru, *v.shape[1:])
+        K = torch.bmm(mk, of_source(Wk))
+        V = torch.bmm(mv, of_source(Wv))
+        bK = torch.bmm(mk, of_source(bk).unsqueeze(-1)).squeeze(-1)
+        bV = torch.bmm(mv, of_source(bv).unsqueeze(-1)).squeeze(-1)
+        big_w = torch.cat([Wq.reshape(NT * F, cin), torch.stack([K, V], dim=1).reshape(-1, cin)], 0).index_select(0, perm)
+        big_b = torch.cat([bq.reshape(-1), torch.stack([bK, bV], dim=1).reshape(-1)], 0).index_select(0, perm)
+        return big_w, big_b, offs
+
     def _forward_train(self, x_dict, edge_index_dict, needed_types=None):
         """Differentiated pass on the same flat projection layout as inference: one composite GEMM per node type writes
         q | k'_r v'_r ... into the flat buffer (ag.hgt_project), edge attention of all destination types reads queries, keys
@@ -520,19 +573,17 @@ class HGTConv(nn.Module):
         sizes = {t: int(x.shape[0]) for t, x in x_dict.items()}
         want = set(self.dst_node_types if needed_types is None else needed_types)
         plan = self._plan(edge_index_dict, sizes, dev, want)
-        layout, xs, ws, bs, spec = [], [], [], [], {}
-        mk_all, mv_all = self._relation_blocks_train()
-        for t, x in x_dict.items():
-            n_t, wd = sizes[t], plan["width"][t]
-            if (plan["nrel"][t] == 0 and t not in want) or n_t == 0:
-                continue
-            w, b = self._composite_projection_train(t, plan, mk_all, mv_all)
-            layout.append((plan["base"][t], n_t, wd))
-            spec[t] = layout[-1]
-            xs.append(x.float())
-            ws.append(w)
-            bs.append(b)
-        flat = ag.hgt_project(layout, plan["total_floats"], _state["precision"], xs, ws, bs)
+        types = [t for t in x_dict if not ((plan["nrel"][t] == 0 and t not in want) or sizes[t] == 0)]
+        layout = [(plan["base"][t], sizes[t], plan["width"][t]) for t in types]
+        spec = dict(zip(types, layout))
+        xs = [x_dict[t].float() for t in types]
+        if types and len({x.shape[1] for x in xs}) == 1 and os.environ.get("MDG_HGT_BATCHED_WEIGHTS", "1") != "0":
+            big_w, big_b, offs = self._composite_all_train(types, plan)
+            flat = ag.hgt_project_rows(layout, plan["total_floats"], _state["precision"], xs, big_w, big_b, offs)
+        else:                                                         # node types of different input width: one weight each
+            mk_all, mv_all = self._relation_blocks_train()
+            ws, bs = zip(*(self._composite_projection_train(t, plan, mk_all, mv_all) for t in types)) if types else ((), ())
+            flat = ag.hgt_project(layout, plan["total_floats"], _state["precision"], xs, list(ws), list(bs))
         dst_types = [t for t in self.node_types if t in self.dst_node_types and t in x_dict and t in want and sizes[t] > 0]
         pres = ag.hgt_attention_flat(flat, H, [plan["per_dst"][t] for t in dst_types], [spec[t] for t in dst_types])
         out = {}

@@ -995,7 +995,7 @@ def gated_residual_bwd(dout: torch.Tensor, o: torch.Tensor, x: torch.Tensor, ski
     return d_o, d_x, colsum(rowdot.view(-1, 1))
 
 
-def grad_weight(g: torch.Tensor, x: torch.Tensor, precision="f32", want_bias: bool = False):
+def grad_weight(g: torch.Tensor, x: torch.Tensor, precision="f32", want_bias: bool = False, out=None):
     """dW [N,K] = g^T x for g [M,N], x [M,K] (row-major, unit inner stride; rows may be strided); with ``want_bias`` also
     db [N] = column sums of g -> (dW, db).
 
@@ -1003,7 +1003,17 @@ def grad_weight(g: torch.Tensor, x: torch.Tensor, precision="f32", want_bias: bo
     produces the bias gradient on the side.  Outputs with >= 96 tiles of 128x128 (the 2048-wide fusion transformer)
     already fill the chip tile-wise: in the bf16 modes they go through the forward GEMM kernel on transposed operands,
     ~5x the fp32 matrix-core rate."""
+    if out is not None:                         # (dW, db | None): contiguous fp32 tensors to write into (row blocks of a stacked gradient)
+        ow, ob = out
+        if tuple(ow.shape) != (g.shape[1], x.shape[1]) or not ow.is_contiguous() or ow.dtype != torch.float32 or \
+                (want_bias and (ob is None or ob.numel() != g.shape[1] or not ob.is_contiguous())):
+            raise ValueError("grad_weight: out must be contiguous fp32 (dW [N,K], db [N])")
     if g.dim() == 2 and x.dim() == 2 and g.shape[0] == 0 and x.shape[0] == 0:          # no rows: exact zeros
+        if out is not None:
+            out[0].zero_()
+            if want_bias:
+                out[1].zero_()
+            return out if want_bias else out[0]
         dw = torch.zeros((g.shape[1], x.shape[1]), dtype=torch.float32, device=g.device)
         return (dw, torch.zeros(g.shape[1], dtype=torch.float32, device=g.device)) if want_bias else dw
     for nm, v in (("g", g), ("x", x)):
@@ -1014,14 +1024,19 @@ def grad_weight(g: torch.Tensor, x: torch.Tensor, precision="f32", want_bias: bo
     M, N, K = g.shape[0], g.shape[1], x.shape[1]
     if _prec(precision) != PREC_F32 and ((N + 127) // 128) * ((K + 127) // 128) >= 96:
         prec = _prec(precision)
-        dw = torch.empty((N, K), dtype=torch.float32, device=g.device)
+        dw = torch.empty((N, K), dtype=torch.float32, device=g.device) if out is None else out[0]
         nbytes = lib().mdg_linear_tn_workspace_bytes(_c64(M), _c64(N), _c64(K), _c(prec))
         ws = _workspace(nbytes, g.device)
         check(lib().mdg_linear_tn(_ptr(g), _c64(g.stride(0)), _ptr(x), _c64(x.stride(0)), _ptr(dw), _c64(K), _c64(M), _c64(N), _c64(K),
                                   _c(prec), _ptr(ws), ctypes.c_size_t(nbytes), _stream(g)), "mdg_linear_tn")
-        return (dw, colsum(g)) if want_bias else dw
-    dw = torch.empty((N, K), dtype=torch.float32, device=g.device)
-    db = torch.empty(N, dtype=torch.float32, device=g.device) if want_bias else None
+        if not want_bias:
+            return dw
+        if out is None:
+            return dw, colsum(g)
+        out[1].copy_(colsum(g))
+        return dw, out[1]
+    dw = torch.empty((N, K), dtype=torch.float32, device=g.device) if out is None else out[0]
+    db = (torch.empty(N, dtype=torch.float32, device=g.device) if out is None else out[1]) if want_bias else None
     nbytes = lib().mdg_grad_weight_workspace_bytes(_c64(M), _c64(N), _c64(K))
     ws = _workspace(nbytes, g.device)
     check(lib().mdg_grad_weight(_ptr(g), _c64(g.stride(0)), _ptr(x), _c64(x.stride(0)), _ptr(dw), _ptr(db), _c64(M), _c64(N), _c64(K),

@@ -608,11 +608,13 @@ def test_chemcpa_predict_training_gradients_match_torch():
 
 
 # ---------------------------------------------------------------------------------------------- KG encoder
-@pytest.mark.parametrize("only_drug", [False, True])
-def test_hgt_training_gradients_match_oracle_autograd(only_drug):
+@pytest.mark.parametrize("only_drug,batched", [(False, "1"), (True, "1"), (False, "0")])
+def test_hgt_training_gradients_match_oracle_autograd(only_drug, batched, monkeypatch):
     """The oracle's HGT restatement is written on torch ops: in float64 with parameters that require grad it is its own
-    autograd reference (PyG 2.3.1 is not in the image: the formula, not the wheel, is what is pinned here)."""
+    autograd reference (PyG 2.3.1 is not in the image: the formula, not the wheel, is what is pinned here).  ``batched``:
+    composite projection weights of all node types built at once (default) or one node type at a time."""
     from madrigal_amd import data, models as M
+    monkeypatch.setenv("MDG_HGT_BATCHED_WEIGHTS", batched)
     from oracle import madrigal_oracle as O
     torch.manual_seed(7)
     kg = data.make_kg(60, seed=4, n_nodes=700, n_edges=9000, n_node_types=5, n_rel_pairs=6)
