@@ -203,8 +203,10 @@ class StrCenterUniSampler:
         ids = np.fromiter((self.index[int(d)] for d in drugs), dtype=np.int64)
         u = np.random.random_sample(ids.size)
         pick = (self.cdf[ids] <= u[:, None]).sum(axis=1)                   # == searchsorted(cdf, u, side='right')
-        aug1 = torch.ones(ids.size, self.width, dtype=torch.bool)
+        # numpy throughout: torch's CPU kernels fan out over the intra-op thread pool, whose idle workers spin -- inside a
+        # training loop that keeps the host busy queueing launches this costs more than the draw itself
+        aug1 = np.ones((ids.size, self.width), dtype=np.bool_)
         aug1[:, 0] = False
-        aug2 = torch.ones(ids.size, self.width, dtype=torch.bool)
-        aug2[torch.arange(ids.size), torch.from_numpy(self.col[ids, pick])] = False
-        return aug1, aug2
+        aug2 = np.ones((ids.size, self.width), dtype=np.bool_)
+        aug2[np.arange(ids.size), self.col[ids, pick]] = False
+        return torch.from_numpy(aug1), torch.from_numpy(aug2)

@@ -1419,10 +1419,24 @@ class NovelDDIEncoder(nn.Module):
         kg_data, kg_map = batch_kg['data'], batch_kg['drug_index_map']
         # drugs absent from the KG get filler rows that are always masked (models.py:734-736); the size of the
         # table needs the largest drug id (the reference's .item() syncs here as well)
+        # Per-iteration inputs may arrive on the CPU (what a loader yields; the contrastive loop draws fresh masks every
+        # iteration): the index work that needs their VALUES is then done on the host and the tensors travel through pinned
+        # buffers, so nothing here waits for the device (hostio.py).  Device inputs behave as in the reference (.item() syncs).
+        host_masks = host_drugs = None
+        if dev.type == 'cuda':
+            from . import hostio
+            if batch_masks.device.type == 'cpu':
+                host_masks, batch_masks = batch_masks, hostio.upload(batch_masks, dev, "masks")
+            if batch_drugs.device.type == 'cpu':
+                host_drugs, batch_drugs = batch_drugs, hostio.upload(batch_drugs, dev, "drugs")
         filler = kwargs.get('kg_filler')
         if filler is None:
-            rows_f = max(int(batch_drugs.max().item()) + 1, int(kg_map.max().item()) + 1)
-            filler = torch.randn((rows_f, Dm), device=dev)
+            mkey = (kg_map.data_ptr(), kg_map._version, kg_map.numel())
+            hit = self.__dict__.get("_kg_map_max")
+            if hit is None or hit[0] != mkey:
+                hit = self.__dict__["_kg_map_max"] = (mkey, int(kg_map.max().item()) if kg_map.numel() else -1, kg_map)
+            dmax = int(host_drugs.numpy().max()) if host_drugs is not None and n else (int(batch_drugs.max().item()) if n else -1)
+            filler = torch.randn((max(dmax, hit[1]) + 1, Dm), device=dev)
 
         # ``kg_share`` (extension, a dict owned by the caller): the KG encoder sees the same graph on the head and on the
         # tail side of one step and has neither dropout nor batch statistics, so its two passes are identical; the
@@ -1503,7 +1517,12 @@ class NovelDDIEncoder(nn.Module):
             kg_out = run_kg()
         if raw_encoder_output:
             all_embeds = torch.stack([str_out, kg_out, cv_out] + list(tx_out.split(n)), dim=1)
-            uni = all_embeds[~batch_masks]
+            if host_masks is not None:               # the available (drug, modality) pairs, row-major as boolean indexing lists them
+                from . import hostio
+                pairs = hostio.upload(torch.from_numpy(np.flatnonzero(~host_masks.numpy().reshape(-1))), dev, "pairs")
+                uni = all_embeds.reshape(n * all_embeds.shape[1], Dm).index_select(0, pairs)
+            else:
+                uni = all_embeds[~batch_masks]
             if self.normalize:
                 uni = norm(uni)
             return self.uni_projector(uni)

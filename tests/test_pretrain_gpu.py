@@ -154,7 +154,7 @@ def test_simclr_raw_pretraining_steps_reduce_loss_and_are_reproducible():
     from madrigal_amd.train import PretrainStep
     n, seed = 96, 12
 
-    def run(steps):
+    def run(steps, host_inputs=False):
         torch.manual_seed(seed)
         np.random.seed(seed)
         avail, _, _ = _views(n, seed)
@@ -167,8 +167,13 @@ def test_simclr_raw_pretraining_steps_reduce_loss_and_are_reproducible():
         losses = []
         for _ in range(steps):
             m1, m2 = MK.pretrain_modality_subset_sampler([bank[d] for d in range(n)], "str_center_uni", False)
-            losses.append(float(step.step(b["drugs"], m1.cuda(), m2.cuda(), None, (b["strs"], kgc, b["cv"], b["tx"]))))
+            if host_inputs:             # the loader's CPU tensors as they are: index work on the host, pinned asynchronous uploads
+                loss = step.step(batch["drugs"], m1, m2, None, (b["strs"], kgc, b["cv"], b["tx"]))
+            else:
+                loss = step.step(b["drugs"], m1.cuda(), m2.cuda(), None, (b["strs"], kgc, b["cv"], b["tx"]))
+            losses.append(float(loss))
         return losses
     l1, l2 = run(10), run(10)
     assert all(np.isfinite(l1)) and min(l1[-3:]) < l1[0], l1
     assert l1 == l2
+    assert run(10, host_inputs=True) == l1          # same rows in the same order, same kernels: bit-identical

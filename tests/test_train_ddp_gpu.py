@@ -196,7 +196,7 @@ def _pretrain_raw_worker(rank, world, port, ret):
             step = PretrainStep(model, AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2, eps=1e-3), rank=rank_, world=world_)
             kg_dev = bkg0["data"].to("cuda")
             losses, mem = [], []
-            for it in range(4):
+            for it in range(6):
                 batch, bkg = D.make_batch(n, seed + it, kg=bkg0["data"], masks=avail)          # a different batch every iteration
                 b = D.batch_to(batch, "cuda")
                 kgc = {"data": kg_dev, "drug_index_map": bkg["drug_index_map"].cuda()}
@@ -242,11 +242,13 @@ def test_two_rank_shipped_pretraining_steps_equal_single_process_and_hold_no_bat
         lerr, worst, same_set, untouched, mem = ret[r]
         # the first step is the same function of the same weights (fp32 summation order only); later losses also carry the
         # three AdamW updates in between, whose per-entry normalisation amplifies rounding-level gradient differences
-        assert lerr[0] < 1e-5 and max(lerr) < 2e-3, (r, lerr)
+        assert lerr[0] < 1e-5 and max(lerr[:4]) < 2e-3, (r, lerr)     # (iterations 5 and 6 only feed the memory check below)
         assert worst[0] < 5e-3 and worst[2] < 5e-2, (r, worst)
         assert same_set and untouched == 0.0, (r, same_set, untouched)
-        # nothing of an earlier iteration's batch stays allocated: memory after iteration 4 == after iteration 2
-        assert abs(mem[3] - mem[1]) < (1 << 20), (r, mem)
+        # nothing of an earlier iteration's batch stays allocated.  A rank's share of one batch is > 2 MB (tx signatures alone:
+        # 34 drugs x 16 x 978 floats), so holding batches would add > 8 MB between iterations 2 and 6; what is allowed to move
+        # is the one-entry plan caches (sized by the LAST batch's atom count) and the allocator's block rounding (~1 MB)
+        assert abs(mem[5] - mem[1]) < (3 << 20) and max(mem[1:]) - min(mem[1:]) < (4 << 20), (r, mem)
 
 
 def _kg_shard_worker(rank, world, port, ret):
