@@ -351,6 +351,46 @@ def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend
     return out
 
 
+def pretrain_leg(model, bkg, masks_all, args, precision="bf16x3"):
+    """BASELINE configs[2] as the reference ships it (configs/cl_pretrain/*.yaml: raw_encoder_output, 'str_center_uni' views,
+    separate predictors, T = 0.1, mlp_dim 512): one iteration of pretrain.py:59-93 = fresh view draw on the host, both views
+    through the encoders -> uni_projector -> predictors, InfoNCE, backward, AdamW, on a 2048-drug batch over the bench's KG."""
+    import numpy as np
+    import torch
+    from madrigal_amd import data as D, masks as MK, models as M
+    from madrigal_amd.optim import AdamW
+    from madrigal_amd.simclr import SimCLR_NovelDDI
+    from madrigal_amd.train import PretrainStep
+    B = args.pretrain_batch
+    dev = bkg["drug_index_map"].device
+    # the first B drugs of the bench's drug table: their KG membership is a property of the bench's KG (drug_index_map)
+    avail = masks_all[:B].clone().cpu()
+    avail[:, 2] = torch.where(avail[:, 1:].all(dim=1), torch.zeros(B, dtype=torch.bool), avail[:, 2])       # every drug owns a second modality
+    batch, _ = D.make_batch(B, 0, kg=bkg["data"].to("cpu"), masks=avail)
+    np.random.seed(0)
+    sim = SimCLR_NovelDDI(model.encoder, dim=128, mlp_dim=512, T=0.1, raw_encoder_output=True).to(dev).train()
+    b = D.batch_to(batch, dev)
+    kgc = bkg
+    draw = MK.StrCenterUniSampler(MK.get_pretrain_masks(list(range(B)), avail.numpy().astype(np.int64), "str_center_uni", False, 0.2))
+    step = PretrainStep(sim, AdamW(sim.parameters(), lr=1e-5, weight_decay=1e-2))
+    data = (b["strs"], kgc, b["cv"], b["tx"])
+    losses = []
+    with M.precision(precision):
+        for i in range(2 + args.pretrain_steps):
+            if i == 2:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            m1, m2 = draw(range(B))                          # host tensors: the step uploads them (madrigal_amd/hostio.py)
+            losses.append(step.step(batch["drugs"], m1, m2, None, data))
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.pretrain_steps
+    return {"metric": "contrastive-pretraining steps/sec", "value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "drugs_per_s": B / dt,
+            "n_gpus": 1, "steps": args.pretrain_steps, "warmup": 2, "batch": B, "dtype": "f32 via split-bf16 (bf16x3) MFMA",
+            "loss_first_last": [float(losses[0]), float(losses[-1])],
+            "config": {"workload": "BASELINE configs[2] as shipped: SimCLR_NovelDDI(raw_encoder_output=True), 'str_center_uni' views drawn per "
+                                   "iteration on the host, separate predictors, T=0.1, mlp_dim=512, AdamW; the bench's KG"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -364,6 +404,8 @@ def main():
     ap.add_argument("--kg-edges", type=int, default=8000000)
     ap.add_argument("--head-only", action="store_true", help="time the scoring stage alone (embeddings given)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pretrain-steps", type=int, default=5, help="contrastive-pretraining leg (BASELINE configs[2]); 0 disables; single GPU only")
+    ap.add_argument("--pretrain-batch", type=int, default=2048)
     ap.add_argument("--finetune-steps", type=int, default=3, help="second half of BASELINE's metric: DDI-finetune steps/s "
                     "(encode both sides + gathered head + BCE + backward + AdamW), timed at N=1 after the headline; 0 = skip")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: strong = the fixed drugs^2 x outcomes job "
@@ -511,6 +553,12 @@ def main():
                     finetune["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
         except Exception as e:          # the headline line must survive a failure of the secondary leg
             finetune = {"metric": "DDI-finetune steps/sec", "value": None, "error": f"{type(e).__name__}: {e}"[:400]}
+    pretrain = None
+    if args.pretrain_steps > 0 and world == 1 and not args.head_only:
+        try:
+            pretrain = pretrain_leg(model, bkg, batch["masks"], args)
+        except Exception as e:
+            pretrain = {"metric": "contrastive-pretraining steps/sec", "value": None, "error": f"{type(e).__name__}: {e}"[:400]}
     stress = None
     if args.stress_drugs > 0:
         model = batch = bkg = None
@@ -569,6 +617,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(N, L, encode=cpu_inputs)
         if finetune is not None:
             line["finetune"] = finetune
+        if pretrain is not None:
+            line["pretrain"] = pretrain
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
