@@ -294,7 +294,10 @@ def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend
         with torch.no_grad():
             model.decoder.parametrizations.weight.original.copy_(
                 torch.randn(L, 128, 128, generator=torch.Generator().manual_seed(1000)) / 128 ** 0.5)
-    lab, hd, tl, y = (t.to(dev) for t in D.make_labelled_triples(N, L, args.finetune_triples, 0))
+    # a DIFFERENT set of labelled triples every step, as in an epoch: the triple plan (sorts by label / pair / drug) is rebuilt
+    # inside every timed step; the drug batch itself is the fixed synthetic one (its molecule / mask plans are cached)
+    sets = [tuple(t.to(dev) for t in D.make_labelled_triples(N, L, args.finetune_triples, s_)) for s_ in range(3)]
+    lab, hd, tl, y = sets[0]
     T = int(lab.numel())
     hp = dict(optimizer="adamw", structure_encoder_lr=1e-5, kg_encoder_lr=1e-5, perturb_encoders_lr=1e-5, fusion_lr=1e-6, decoder_lr=1e-4,
               wd=1e-2, beta1=0.9, beta2=0.999, eps=1e-8)
@@ -306,8 +309,8 @@ def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.finetune_steps):
-            losses.append(fs.step(batch, batch, batch["masks"], batch["masks"], bkg, lab, hd, tl, y, kg_filler=filler))
+        for i_ in range(args.finetune_steps):
+            losses.append(fs.step(batch, batch, batch["masks"], batch["masks"], bkg, *sets[(i_ + 1) % 3], kg_filler=filler))
         torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -324,8 +327,8 @@ def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend
            "loss_first_last": [float(losses[0]), float(losses[-1])],
            "parallelism": "single GPU" if world == 1 else
            f"drug-sharded encoders (SyncBatchNorm), all-gather(z) / reduce-scatter(dz), triples dealt to {world} ranks, flat gradient all-reduce",
-           "work": "optimizer.zero_grad, encode+fuse head side and tail side (training mode), gathered bilinear head on the "
-                   "labelled triples, BCE, backward through all encoders, AdamW step"}
+           "work": "optimizer.zero_grad, triple plan of a fresh set of labelled triples, encode+fuse head side and tail side (training "
+                   "mode), gathered bilinear head on the labelled triples, BCE, backward through all encoders, AdamW step"}
     if rank == 0 and world == 1:
         # roofline of the step's dominant kernel, the wide fusion-transformer GEMM (linear_kernel<bf16, 256x256 tile>; 14 of the
         # 69 ms of kernel time, profiles/): one FFN-sized launch at the step's own row count, HIP events on its stream

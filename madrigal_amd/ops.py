@@ -727,7 +727,12 @@ def triple_plan(labels: torch.Tensor, heads: torch.Tensor, tails: torch.Tensor, 
     for nm, t in (("labels", labels), ("heads", heads), ("tails", tails)):
         if t.dtype != torch.int64 or not t.is_cuda or t.numel() != T or t.dim() != 1:
             raise ValueError(f"{nm}: expected int64 cuda [{T}]")
-    perm = torch.argsort(labels, stable=True)
+    # ONE sort serves the label order and the (label, head drug) pair order: by label, then by head inside a label (any
+    # label-sorted order will do for the tiles; a pair's triples must be consecutive for the pair-compressed head).
+    # int32 keys when they fit (twice the radix-sort rate).
+    big = n_labels * max(n_head, 1) >= 2 ** 31
+    key = labels * n_head + heads if big else (labels * n_head + heads).to(torch.int32)
+    perm = torch.argsort(key, stable=True)
     ls, hs, ts = labels[perm], heads[perm].contiguous(), tails[perm].contiguous()
     counts = torch.bincount(ls, minlength=n_labels)
     if counts.numel() != n_labels:
@@ -745,12 +750,12 @@ def triple_plan(labels: torch.Tensor, heads: torch.Tensor, tails: torch.Tensor, 
     _, tile_label, tile_start = cut(32)
     chunks_per, _, chunk_start = cut(256)
     label_chunk_ptr = torch.cat([zero, torch.cumsum(chunks_per, 0)]).contiguous()
-    bounds = torch.stack([hs.max() if T else zero[0], ts.max() if T else zero[0]]).tolist() if T else [-1, -1]
-    if bounds[0] >= n_head or bounds[1] >= n_tail or (T and (int(heads.min()) < 0 or int(tails.min()) < 0)):
+    bounds = torch.stack([hs.max(), ts.max(), hs.min(), ts.min()]).tolist() if T else [-1, -1, 0, 0]      # one round trip
+    if bounds[0] >= n_head or bounds[1] >= n_tail or bounds[2] < 0 or bounds[3] < 0:
         raise ValueError("heads / tails: index outside the embedding tables")
 
     def by_drug(idx, n):
-        order = torch.argsort(idx, stable=True)
+        order = torch.argsort(idx if n >= 2 ** 31 else idx.to(torch.int32), stable=True)
         return torch.cat([zero, torch.cumsum(torch.bincount(idx, minlength=n), 0)]).contiguous(), order.contiguous()
 
     def pieces(ptr):
@@ -774,15 +779,12 @@ def triple_plan(labels: torch.Tensor, heads: torch.Tensor, tails: torch.Tensor, 
     # pair_ptr[p] .. pair_ptr[p+1] of that order.
     pairs = None
     if T:
-        key = ls * n_head + hs
-        order = torch.argsort(key, stable=True)                    # positions in the label-sorted triple order
-        pkey, pcnt = torch.unique_consecutive(key[order], return_counts=True)
+        pkey, pcnt = torch.unique_consecutive(key[perm], return_counts=True)     # the plan's triple order IS the pair order
         P = int(pkey.numel())
+        pkey = pkey.to(torch.int64)
         pair_label, pair_drug = pkey // n_head, (pkey % n_head).contiguous()
         pair_ptr = torch.cat([zero, torch.cumsum(pcnt, 0)]).contiguous()
-        pair_of_sorted = torch.repeat_interleave(torch.arange(P, device=dev), pcnt)
-        pair_of_triple = torch.empty(T, dtype=torch.int64, device=dev)
-        pair_of_triple[order] = pair_of_sorted                     # label-sorted triple -> its pair
+        pair_of_triple = torch.repeat_interleave(torch.arange(P, device=dev), pcnt)  # sorted triple -> its pair
         pcounts = torch.bincount(pair_label, minlength=n_labels)
         plabel_ptr = torch.cat([zero, torch.cumsum(pcounts, 0)])
 
@@ -795,7 +797,7 @@ def triple_plan(labels: torch.Tensor, heads: torch.Tensor, tails: torch.Tensor, 
         _, ptile_label, ptile_start = pcut(32)
         pchunks_per, _, pchunk_start = pcut(256)
         drug_ptr, drug_rows = by_drug(pair_drug, n_head)
-        pairs = {"P": P, "drug": pair_drug, "ptr": pair_ptr, "order": order.contiguous(), "tails_by_pair": ts[order].contiguous(),
+        pairs = {"P": P, "drug": pair_drug, "ptr": pair_ptr, "tails_by_pair": ts,
                  "of_triple": pair_of_triple, "tile_start": ptile_start, "tile_label": ptile_label, "n_tiles": int(ptile_label.numel()),
                  "chunk_start": pchunk_start, "n_chunks": int(pchunk_start.numel()) - 1,
                  "label_chunk_ptr": torch.cat([zero, torch.cumsum(pchunks_per, 0)]).contiguous(), "drug_ptr": drug_ptr, "drug_rows": drug_rows,
@@ -887,7 +889,7 @@ def bilinear_gather_pairs_bwd(z_head, z_tail, w, plan: dict, dscore: torch.Tenso
         z = torch.zeros
         return z((plan["n_head"], 128), device=dev), z((plan["n_tail"], 128), device=dev), (z((L, 128, 128), device=dev) if need_dw else None)
     dzt = _sum_rows(V, plan["tail_ptr"], pp["of_triple_by_tail"], plan.get("tail_pieces"), edge_weight=ds.index_select(0, plan["tail_rows"]))
-    u = csr_aggregate(zt, pp["ptr"], pp["tails_by_pair"], edge_weight=ds.index_select(0, pp["order"]))
+    u = csr_aggregate(zt, pp["ptr"], pp["tails_by_pair"], edge_weight=ds)
     R = torch.empty((pp["P"], 128), dtype=torch.float32, device=dev)
     L_ = lib()
     check(L_.mdg_bilinear_matvec_rows(_ptr(u), _ptr(w), _ptr(None), _ptr(pp["tile_start"]), _ptr(pp["tile_label"]), _c64(pp["n_tiles"]), _ptr(R),

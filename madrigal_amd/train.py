@@ -50,11 +50,16 @@ class FinetuneStep:
         self._overlapped = False
         self._plan_key = None
         self._plan = None
+        self._plan_stream = None
         self._shards = {}               # side ('head' | 'tail') -> (key, sliced batch, the batch itself): ONE entry per side
+
+    @staticmethod
+    def _key_of(labels, heads, tails, n_head, n_tail):
+        return tuple((t.data_ptr(), t._version, t.numel()) for t in (labels, heads, tails)) + (n_head, n_tail)
 
     def plan(self, labels: torch.Tensor, heads: torch.Tensor, tails: torch.Tensor, n_head: int, n_tail: int) -> dict:
         """Label-sorted tiling of the triples, rebuilt only when the index tensors change (they are fixed for a run)."""
-        key = tuple((t.data_ptr(), t._version, t.numel()) for t in (labels, heads, tails)) + (n_head, n_tail)
+        key = self._key_of(labels, heads, tails, n_head, n_tail)
         if self._plan_key != key:
             n_labels = int(self.model.decoder.out_features)
             self._plan = ops.triple_plan(labels, heads, tails, n_labels, n_head, n_tail)
@@ -108,8 +113,27 @@ class FinetuneStep:
     def accumulate(self, batch_head, batch_tail, masks_head, masks_tail, batch_kg, labels, heads, tails, targets, **kwargs) -> torch.Tensor:
         if self.world > 1:
             return self._accumulate_sharded(batch_head, batch_tail, masks_head, masks_tail, batch_kg, labels, heads, tails, targets, **kwargs)
-        plan = self.plan(labels, heads, tails, int(batch_head["drugs"].shape[0]), int(batch_tail["drugs"].shape[0]))
-        scores = self.model.score_triples(batch_head, batch_tail, masks_head, masks_tail, batch_kg, plan, **kwargs)
+        n_head, n_tail = int(batch_head["drugs"].shape[0]), int(batch_tail["drugs"].shape[0])
+        dev = labels.device
+        if dev.type == "cuda" and self._plan_key != self._key_of(labels, heads, tails, n_head, n_tail):
+            # A new set of triples (every batch of an epoch): its plan is a handful of sorts with host round trips for the
+            # tile / pair counts.  Queue the encoders first, then build the plan on a side stream that waits only for what
+            # was queued BEFORE this step (where the index tensors come from): the sorts run beside the encoders and the host
+            # round trips wait for the sorts alone, not for the encoders.
+            main = torch.cuda.current_stream(dev)
+            start = torch.cuda.Event()
+            start.record(main)
+            z_head, z_tail = self.model.embed(batch_head, batch_tail, masks_head, masks_tail, batch_kg, **kwargs)
+            if self._plan_stream is None:
+                self._plan_stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(self._plan_stream):
+                self._plan_stream.wait_event(start)
+                plan = self.plan(labels, heads, tails, n_head, n_tail)
+            main.wait_stream(self._plan_stream)
+            scores = self.model.decoder.score_triples(z_head, z_tail, plan).index_select(0, plan["inv_perm"])
+        else:
+            plan = self.plan(labels, heads, tails, n_head, n_tail)
+            scores = self.model.score_triples(batch_head, batch_tail, masks_head, masks_tail, batch_kg, plan, **kwargs)
         loss = ag.bce_with_sigmoid(scores, targets, self.loss_readout)
         loss.backward()
         return loss.detach()
