@@ -26,6 +26,21 @@ class AdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
         self._chunk = int(lib().mdg_adamw_chunk_elems())
         self._layouts = {}
+        self._count = {}                # parameter -> number of updates so far (mirrored into state[p]["step"] on demand)
+
+    def _sync_steps(self) -> None:
+        for p, k in self._count.items():
+            st = self.state.get(p)
+            if st:
+                st["step"].fill_(float(k))
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._count = {}                # re-read from the loaded ``step`` tensors at the next update
 
     @staticmethod
     def _upload(lay: dict, name: str, host: np.ndarray, dev) -> torch.Tensor:
@@ -52,24 +67,35 @@ class AdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         by_dev: Dict[torch.device, list] = {}
-        for group in self.param_groups:
+        count, hyper_of = self._count, {}
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
             for p in group["params"]:
-                if p.grad is None:
+                g = p.grad
+                if g is None:
                     continue
-                if p.grad.is_sparse or p.dtype != torch.float32 or not p.is_cuda:
-                    raise RuntimeError("madrigal_amd.optim.AdamW: dense fp32 parameters on the GPU only")
                 st = self.state[p]
-                if not st:
-                    st["step"] = torch.tensor(0.0)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                k = float(st["step"])
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                if not p.is_contiguous():
-                    raise RuntimeError("madrigal_amd.optim.AdamW: parameters must be contiguous")
-                hyper = (group["lr"], b1, b2, group["eps"], group["weight_decay"], 1.0 / (1.0 - b1 ** k), 1.0 / math.sqrt(1.0 - b2 ** k), 0.0)
+                k = count.get(p)
+                if k is None:                                   # first update of this parameter (or the first after a load)
+                    if g.is_sparse or p.dtype != torch.float32 or not p.is_cuda:
+                        raise RuntimeError("madrigal_amd.optim.AdamW: dense fp32 parameters on the GPU only")
+                    if not p.is_contiguous():
+                        raise RuntimeError("madrigal_amd.optim.AdamW: parameters must be contiguous")
+                    if not st:
+                        st["step"] = torch.tensor(0.0)
+                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    k = int(float(st["step"]))
+                # the step counters live in a host-side table and reach the state's ``step`` tensors when the state is read
+                # (state_dict): a tensor increment + read-back per parameter and step was a third of this loop
+                k += 1
+                count[p] = k
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                hyper = hyper_of.get((gi, k))
+                if hyper is None:
+                    hyper = hyper_of[(gi, k)] = (group["lr"], b1, b2, group["eps"], group["weight_decay"], 1.0 / (1.0 - b1 ** k),
+                                                 1.0 / math.sqrt(1.0 - b2 ** k), 0.0)
                 by_dev.setdefault(p.device, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], hyper))
         for dev, items in by_dev.items():
             # chunk layout (offsets / lengths / owning tensor) depends only on the tensor sizes: built once, vectorised

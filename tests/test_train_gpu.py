@@ -688,8 +688,24 @@ def test_adamw_matches_torch_optim_over_param_groups():
         _close(b, a, 2e-6, "adamw parameter")
     sd = mine.state_dict()
     assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}       # torch.optim.AdamW's layout
-    fresh = AdamW(groups([torch.nn.Parameter(p.detach().clone()) for p in my_p]), betas=(0.9, 0.98), eps=1e-6)
-    fresh.load_state_dict(sd)
+    ref_sd = ref.state_dict()
+    assert [float(sd["state"][i]["step"]) for i in range(5)] == [float(ref_sd["state"][i]["step"]) for i in range(5)] == [5, 5, 5, 5, 4]
+    # resume: a fresh optimizer loaded from the state continues exactly like the original (step counts included)
+    fresh_p = [torch.nn.Parameter(p.detach().clone()) for p in my_p]
+    fresh = AdamW(groups(fresh_p), betas=(0.9, 0.98), eps=1e-6)
+    fresh.load_state_dict(copy.deepcopy(sd))                 # (torch shares the state tensors with the dict it loads from)
+    for grp, src in zip(fresh.param_groups, mine.param_groups):
+        grp["lr"] = src["lr"]
+    for i, (a, b, c) in enumerate(zip(ref_p, my_p, fresh_p)):
+        g = torch.randn(a.shape, generator=torch.Generator().manual_seed(900 + i))
+        a.grad, b.grad, c.grad = g.clone(), g.clone().to(DEV), g.clone().to(DEV)
+    ref.step()
+    mine.step()
+    fresh.step()
+    for a, b, c in zip(ref_p, my_p, fresh_p):
+        _close(b, a, 2e-6, "adamw parameter after 6 steps")
+        assert torch.equal(b, c)
+    assert float(fresh.state_dict()["state"][4]["step"]) == 5.0
 
 
 def _small_model(M, case, n, L, seed, default_init=False):
