@@ -123,9 +123,19 @@ __global__ __launch_bounds__(256) void grad_weight_kernel(const GwArgs p) {
 
 // out[i] = sum_k part[k][i] in a fixed order: four interleaved groups of splits per element (thread rows of the block),
 // four independent accumulators per thread so that the loads overlap, groups combined through LDS.
-__global__ __launch_bounds__(256) void sum_splits_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int splits) {
+// Two arrays in one launch (the weight partials [splits][n] and, behind them, the bias partials [splits][n2]): blocks past
+// ceil(n / 64) serve the second one.
+__global__ __launch_bounds__(256) void sum_splits_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int splits,
+                                                         const float* __restrict__ part2, float* __restrict__ out2, int64_t n2) {
   const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * 64 + e;
+  const int64_t first = (n + 63) / 64;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * 64 + e;
+  if (static_cast<int64_t>(blockIdx.x) >= first) {       // block-uniform
+    i -= first * 64;
+    part = part2;
+    out = out2;
+    n = n2;
+  }
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < n) {
     int k = grp;
@@ -186,11 +196,9 @@ extern "C" int mdg_grad_weight(const float* g, int64_t ldg, const float* x, int6
   hipLaunchKernelGGL(grad_weight_kernel, dim3(static_cast<unsigned>(mdg_cdiv(K, 128)), static_cast<unsigned>(mdg_cdiv(N, 128)), static_cast<unsigned>(used)),
                      dim3(256), 0, st, a);
   if (splits > 1) {
-    hipLaunchKernelGGL(sum_splits_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N * K, 64))), dim3(256), 0, st, static_cast<const float*>(workspace), dw,
-                       N * K, static_cast<int>(used));
-    if (dbias)
-      hipLaunchKernelGGL(sum_splits_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N, 64))), dim3(256), 0, st, static_cast<const float*>(part_db), dbias,
-                         N, static_cast<int>(used));
+    const int64_t blocks = mdg_cdiv(N * K, 64) + (dbias ? mdg_cdiv(N, 64) : 0);
+    hipLaunchKernelGGL(sum_splits_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, static_cast<const float*>(workspace), dw, N * K,
+                       static_cast<int>(used), static_cast<const float*>(part_db), dbias, dbias ? N : 0);
   }
   MDG_CHECK_LAUNCH("mdg_grad_weight");
   return MDG_OK;

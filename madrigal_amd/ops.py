@@ -57,6 +57,10 @@ def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
     """Per-device grow-only scratch buffer (the C ABI never allocates)."""
     if nbytes == 0:
         return None
+    if torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture: scratch from the graph's own pool (a cached buffer would be shared between the replays and
+        # whatever eager op later lands on a stream with the same handle)
+        return torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
     # one scratch buffer per (device, stream): ops enqueued on different streams may run concurrently
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
@@ -549,6 +553,8 @@ def weight_transposed(w: torch.Tensor) -> torch.Tensor:
     side / view, so each weight's transpose is needed two or three times between two optimizer updates (which bump the
     version).  The entry keeps ``w`` alive, so its address cannot be recycled under the cache; a new version of the same
     parameter replaces the old entry (memory: one transposed copy per Linear weight)."""
+    if w.is_cuda and torch.cuda.is_current_stream_capturing():
+        return transpose(w.detach())            # a captured pass must contain the transpose itself: replays see newer weights
     k = (w.data_ptr(), tuple(w.shape), str(w.device))
     hit = _wt_cache.get(k)
     if hit is not None and hit[0] == w._version:

@@ -659,6 +659,41 @@ def test_hgt_training_gradients_match_oracle_autograd(only_drug, batched, monkey
             assert torch.equal(p_.grad, g1[k]), k
 
 
+def test_kg_encoder_training_pass_as_captured_graphs_equals_eager(monkeypatch):
+    """Opt-in MDG_KG_GRAPH=1: the KG encoder's forward / backward replayed as hipGraphs give the eager pass's drug rows and
+    parameter gradients bit for bit, and follow in-place parameter updates (the optimizer's) from one replay to the next."""
+    from madrigal_amd import data, models as M
+    torch.manual_seed(3)
+    batch, bkg = data.make_batch(64, seed=5, kg_nodes=800, kg_edges=9000)
+    from test_models_gpu import build_model
+    model = build_model(M, ("twosides105", "transformer", 2, "learnable", 2, 64, 128, 1, True, "x-attn", False, False), bkg["data"], 4).to(DEV).train()
+    enc = model.encoder
+    kg = bkg["data"].to(DEV)
+    dy = None
+
+    def once(runner):
+        nonlocal dy
+        enc.kg_encoder.zero_grad()
+        out = runner(kg.x_dict["drug"]) if runner is not None else enc.kg_encoder(kg.x_dict, kg.edge_index_dict, only_types=("drug",))["drug"]
+        dy = torch.randn_like(out) if dy is None else dy
+        out.backward(dy)
+        return out.detach().clone(), {k: p.grad.clone() for k, p in enc.kg_encoder.named_parameters() if p.grad is not None}
+    with M.precision("bf16x3"):
+        assert enc._kg_graphed(kg, torch.device(DEV)) is None                   # off unless asked for
+        monkeypatch.setenv("MDG_KG_GRAPH", "1")
+        runner = enc._kg_graphed(kg, torch.device(DEV))
+        assert runner is not None
+        for step in range(2):
+            o_e, g_e = once(None)
+            o_g, g_g = once(runner)
+            assert torch.equal(o_e, o_g) and set(g_e) == set(g_g)
+            for k in g_e:
+                assert torch.equal(g_e[k], g_g[k]), k
+            with torch.no_grad():                                              # an in-place update, as the optimizer makes it
+                for p in enc.kg_encoder.parameters():
+                    p.add_(0.01 * torch.randn_like(p))
+
+
 # ---------------------------------------------------------------------------------------------- optimizer + whole step
 def test_adamw_matches_torch_optim_over_param_groups():
     from madrigal_amd.optim import AdamW
