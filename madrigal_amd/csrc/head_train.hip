@@ -8,6 +8,7 @@
 // rows held in registers.  No atomics anywhere: per-triple gradient rows are summed per drug by mdg_csr_aggregate and
 // per-chunk dW partials are summed per label in a fixed order.
 #include "mdg_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -42,6 +43,86 @@ __device__ __forceinline__ void wz_tile(const float* __restrict__ wl, int c0, in
 __device__ __forceinline__ void load_row_frag(const float* __restrict__ row, int half, f32x4 (&zf)[16]) {
 #pragma unroll
   for (int q = 0; q < 16; ++q) zf[q] = *reinterpret_cast<const f32x4*>(row + 8 * q + 4 * half);
+}
+
+// ---- rows[t] = W[l] z[index[t]] for tiles of <= 32 rows of one label: the (label, drug) PAIR products of the pair-compressed
+// head (V = W^T z_head forward, R = W u backward), 2.4 million rows per call.  The matrix work is the same as in
+// bilinear_gather_kernel<2>; what differs is how the operands and the result move.  There a lane loaded ITS z row and ITS W row
+// straight from global memory (32 rows x 32 bytes per instruction) and stored ITS result row in 16-byte pieces.  Here the
+// wave copies the gathered z rows (64 columns at a time) and the 32 x 64 pieces of W_l into its own LDS tiles with row-major
+// loads (one 256-byte row piece per 16 lanes), keeps its z fragments in registers over the four 32-row chunks of W_l, prefetches
+// the next W piece while the current one feeds the MFMAs, and takes z as the A operand so that the result has the lane on the
+// output feature: every store is a 128-byte row piece.  (Same scheme as the fusion self-attention, fusion.hip.)
+__device__ __forceinline__ int mv_tile_off(int row, int piece) { return row * 64 + ((piece ^ (row & 15)) << 2); }
+
+__device__ __forceinline__ void mv_load_w(const float* __restrict__ w, int r0, int k0, int lane, f32x4 (&r)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = *reinterpret_cast<const f32x4*>(w + static_cast<int64_t>(r0 + (lane >> 4) + 4 * i) * HD + k0 + 4 * (lane & 15));
+}
+
+__device__ __forceinline__ void mv_write(const f32x4 (&r)[8], float* tile, int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(tile + mv_tile_off((lane >> 4) + 4 * i, lane & 15)) = r[i];
+}
+
+__global__ __launch_bounds__(256) void bilinear_matvec_rows_kernel(const GatherArgs p) {
+  __shared__ __attribute__((aligned(16))) float stage[4][2][32 * 64];
+  const int lane = threadIdx.x & 63, x = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+  if (tile >= p.n_tiles) return;
+  const int64_t t0 = p.tile_start[tile];
+  const int cnt = static_cast<int>(p.tile_start[tile + 1] - t0);
+  if (cnt <= 0) return;
+  const float* wl = p.w + p.tile_label[tile] * HD * HD;
+  float* const tz = stage[wave][0];
+  float* const tw = stage[wave][1];
+  // source row of tile row r (rows past the tile repeat its last row; their results are never stored)
+  int64_t src[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = (lane >> 4) + 4 * i;
+    const int64_t t = t0 + (r < cnt ? r : cnt - 1);
+    src[i] = p.tail ? p.tail[t] : t;
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[c][v] = 0.f;
+  f32x4 pre[8];
+  mv_load_w(wl, 0, 0, lane, pre);
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    {                                                     // the tile's z rows, columns 64 kh .. 64 kh + 63
+      f32x4 zr[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) zr[i] = *reinterpret_cast<const f32x4*>(p.zt + src[i] * HD + 64 * kh + 4 * (lane & 15));
+      mv_write(zr, tz, lane);
+    }
+    f32x4 zf[8];                                          // lane x: row x of the z tile, pieces 2q + half
+#pragma unroll
+    for (int q = 0; q < 8; ++q) zf[q] = *reinterpret_cast<const f32x4*>(tz + mv_tile_off(x, 2 * q + half));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      mv_write(pre, tw, lane);
+      const int nc = c + 1, nk = nc == 4 ? kh + 1 : kh;   // next piece of W_l travels while this one is used
+      if (nk < 2) mv_load_w(wl, 32 * (nc & 3), 64 * nk, lane, pre);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 wf = *reinterpret_cast<const f32x4*>(tw + mv_tile_off(x, 2 * q + half));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(zf[q][e], wf[e], acc[c], 0, 0, 0);
+      }
+    }
+  }
+  // acc[c][v] on lane x = rows[t0 + i_v][32 c + x]
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int i = (v & 3) + 8 * (v >> 2) + 4 * half;
+      if (i < cnt) p.gzh[(t0 + i) * HD + 32 * c + x] = acc[c][v];
+    }
 }
 
 // MODE 0: scores; MODE 1: both per-triple gradient rows; MODE 2: rows[t] = W[l] z_tail[tail[t]] only (one matrix-vector product
@@ -246,7 +327,9 @@ extern "C" int mdg_bilinear_matvec_rows(const float* z, const float* w, const in
   MDG_CHECK_ARG(z && w && tile_start && tile_label && rows_out && mdg_aligned16(z) && mdg_aligned16(w) && mdg_aligned16(rows_out),
                 "mdg_bilinear_matvec_rows: null / misaligned pointer");
   GatherArgs a{z, z, w, w, row_index, row_index, tile_start, tile_label, n_tiles, nullptr, nullptr, rows_out, nullptr};
-  hipLaunchKernelGGL(bilinear_gather_kernel<2>, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  static const bool old_path = getenv("MDG_MATVEC_ROWS_OLD") != nullptr;
+  if (old_path) hipLaunchKernelGGL(bilinear_gather_kernel<2>, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL(bilinear_matvec_rows_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   MDG_CHECK_LAUNCH("mdg_bilinear_matvec_rows");
   return MDG_OK;
 }
