@@ -201,14 +201,45 @@ __global__ __launch_bounds__(256) void bilinear_gather_dw_kernel(const float* __
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
-  for (int64_t t = t0 + half; t < t1 + half; t += 2) {       // both halves take the same number of steps
-    const bool ok = t < t1;
-    const int64_t tt = ok ? t : t1 - 1;
-    const float g = ok ? (ds ? ds[tt] : 1.f) : 0.f;
-    const float a = zh[head[tt] * HD + 32 * wave + x] * g;
-    const float* zr = zt + (tail ? tail[tt] : tt) * HD + x;              // null index = identity (row tt)
+  // Batches of DW_U row pairs: the index loads of a batch, then its operand loads (each depends on an index), then its MFMAs,
+  // with the NEXT batch's indices and operands already in flight (the plain loop paid two dependent memory latencies per step).
+  constexpr int DW_U = 8;
+  struct Batch { float a[DW_U], b[DW_U][4]; };
+  const auto load = [&](int64_t tb, Batch& o) {
+    int64_t hi[DW_U], ti[DW_U];
+    float g[DW_U];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, zr[32 * j], acc[j], 0, 0, 0);
+    for (int u = 0; u < DW_U; ++u) {
+      const int64_t t = tb + 2 * u + half;
+      const bool ok = t < t1;
+      const int64_t tt = ok ? t : t1 - 1;
+      hi[u] = head[tt];
+      ti[u] = tail ? tail[tt] : tt;                      // null index = identity (row tt)
+      g[u] = ok ? (ds ? ds[tt] : 1.f) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < DW_U; ++u) {
+      o.a[u] = zh[hi[u] * HD + 32 * wave + x] * g[u];
+      const float* zr = zt + ti[u] * HD + x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.b[u][j] = zr[32 * j];
+    }
+  };
+  const auto compute = [&](const Batch& o) {
+#pragma unroll
+    for (int u = 0; u < DW_U; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[u], o.b[u][j], acc[j], 0, 0, 0);
+  };
+  if (t1 > t0) {                                          // (rows past t1 enter with weight 0: both halves take the same steps)
+    Batch cur, nxt;
+    load(t0, cur);
+    for (int64_t tb = t0; tb < t1; tb += 2 * DW_U) {
+      const bool more = tb + 2 * DW_U < t1;
+      if (more) load(tb + 2 * DW_U, nxt);
+      compute(cur);
+      if (more) cur = nxt;
+    }
   }
   // acc[j][v]: row a = 32*wave + (v&3) + 8(v>>2) + 4*half, column b = 32*j + x
   float* out = partial + chunk * HD * HD;
