@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void bilinear_gather_dw_kernel(const float* __
     for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
   // Batches of DW_U row pairs: the index loads of a batch, then its operand loads (each depends on an index), then its MFMAs,
   // with the NEXT batch's indices and operands already in flight (the plain loop paid two dependent memory latencies per step).
-  constexpr int DW_U = 8;
+  constexpr int DW_U = 16;
   struct Batch { float a[DW_U], b[DW_U][4]; };
   const auto load = [&](int64_t tb, Batch& o) {
     int64_t hi[DW_U], ti[DW_U];
