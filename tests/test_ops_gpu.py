@@ -58,6 +58,37 @@ def test_linear_unpadded_k_strided_views_and_broadcast_residual(ops):
     assert rel_err(got, big[:, :128].cpu() @ w2.t() + r) < 2e-5
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16x3", 1e-4)])
+def test_linear_epilogue_on_misaligned_destinations_and_in_place_residual(ops, prec, tol):
+    """The row-major epilogue writes 16 bytes per lane when the destination allows it and falls back to single floats when
+    it does not: a destination view starting at an odd column, a residual with an odd row stride, 300 x 130 outputs (a ragged
+    last column group), and y aliasing the residual (each lane reads its own four residual values before it stores)."""
+    x, w, b = _rand((300, 128), 31), _rand((130, 128), 32, 0.1), _rand((130,), 33)
+    want = x @ w.t() + b
+    wide = torch.zeros(300, 133, device="cuda")
+    ops.linear(x.cuda(), w.cuda(), b.cuda(), precision=prec, out=wide[:, 3:])
+    assert rel_err(wide[:, 3:].cpu(), want) < tol and float(wide[:, :3].abs().max()) == 0.0
+    res_wide = _rand((300, 131), 34).cuda()
+    got = ops.linear(x.cuda(), w.cuda(), b.cuda(), residual=res_wide[:, 1:], precision=prec).cpu()
+    assert rel_err(got, want + res_wide[:, 1:].cpu()) < tol
+    y = _rand((300, 130), 35).cuda()
+    y0 = y.cpu().clone()
+    ops.linear(x.cuda(), w.cuda(), b.cuda(), residual=y, precision=prec, out=y)
+    assert rel_err(y.cpu(), want + y0) < tol
+
+
+def test_pinned_ring_uploads_keep_their_contents():
+    """hostio.upload: more uploads under one tag than the ring has buffers, queued without any synchronisation in between."""
+    from madrigal_amd import hostio
+    src = [torch.arange(1000, dtype=torch.int64) * (i + 1) for i in range(11)]
+    dev = [hostio.upload(t, "cuda", "test-ring", depth=3) for t in src]
+    torch.cuda.synchronize()
+    for a, b in zip(src, dev):
+        assert torch.equal(a, b.cpu())
+    m = torch.rand(64, 19) < 0.5
+    assert torch.equal(hostio.upload(m, "cuda", "test-ring-mask").cpu(), m)
+
+
 def test_linear_errors(ops):
     x, w = torch.zeros(4, 8, device="cuda"), torch.zeros(3, 12, device="cuda")
     with pytest.raises(ValueError):
