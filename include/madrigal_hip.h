@@ -294,6 +294,24 @@ size_t mdg_grad_weight_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int mdg_grad_weight(const float* g, int64_t ldg, const float* x, int64_t ldx, float* dw, float* dbias, int64_t M, int64_t N,
                     int64_t K, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Grouped dense block: G independent products y_g = alpha_g * act(x_g W_g^T + b_g) + beta_g * r_g sharing K, in ONE launch.
+ * Replaces the per-node-type linear layers of PyG HGTConv (kqv_lin / out_lin, a HeteroDictLinear each: one GEMM per node
+ * type; call site madrigal/models/models.py:76-79,90-94).  The x rows of all groups are stacked in one [rows_total, K] matrix,
+ * the W rows (and biases) of all groups in one [w_rows_total, K] matrix (packed with mdg_pack_operand, or raw fp32 where the
+ * mode needs no image); `tiles` is a DEVICE table of n_tiles descriptors of mdg_linear_group_tile_words() int64 words, one per
+ * 128 x 128 output tile:
+ *   0 a_row0  1 a_row_end  2 b_row0  3 b_row_end   tile origin / end of the group's rows in the stacked x and W
+ *   4 m_base  5 n_base                             the group's first x row / first W row
+ *   6 y_off   7 ldy                                output element (m, n) -> y[y_off + (m - m_base) * ldy + (n - n_base)]
+ *   8 res_off (-1: none)  9 ldr                    residual element, same addressing relative to `residual`
+ *   10 alpha (float bits) | beta (float bits) << 32          11 unused
+ * Offsets and row strides must be multiples of 4 floats.  Workspace (the packed x): mdg_linear_grouped_workspace_bytes. */
+int mdg_linear_group_tile_words(void);
+size_t mdg_linear_grouped_workspace_bytes(int64_t rows_total, int64_t K, int precision);
+int mdg_linear_grouped(const float* x, int64_t ldx, int64_t rows_total, int64_t K, const float* w, int64_t ldw, const void* w_packed,
+                       int64_t w_rows_total, const float* bias, const int64_t* tiles, int64_t n_tiles, float* y,
+                       const float* residual, int act, int precision, void* workspace, size_t workspace_bytes, void* stream);
+
 /* y[N,K] = g^T x for row-major g [M,N] (row stride ldg) and x [M,K]: the weight gradient dW = dY^T X of a wide layer
  * (autograd of nn.Linear).  Both operands are re-laid out (reduction index M innermost, padded to 64) by one transposing pack
  * launch, then the mdg_linear tile kernel runs: no separate transposes of g and x. */

@@ -259,6 +259,7 @@ struct LinearArgs {
   int64_t M, N, K;
   int tiles_x, tiles_y, swizzle;   // swizzle: XCD-aware tile order (see tile_of)
   int vec_y, vec_r;                // y / residual rows may be accessed 16 B at a time (alignment and row stride)
+  const int64_t* tiles;            // grouped launch: [n_tiles][kGroupTileWords] tile descriptors (device), else null
 };
 
 // Workgroups are dealt to the 8 XCDs round-robin in dispatch order, and each XCD has its own L2.  With the plain
@@ -398,17 +399,45 @@ __device__ __forceinline__ void slab_to_global(const LinearArgs& p, const float*
 }
 
 // MF = edge of the MFMA tile: 32 (fp32 always; 16-bit modes on request) or 16 (16-bit modes).
-template <int MODE, class S, int MF>
-__global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs p) {
+// Grouped launch (GROUPED): G independent products y_g = x_g W_g^T that share K and one launch.  The x rows of all groups are
+// stacked in one operand image and so are the W rows (and the biases); a device table lists the output tiles, one descriptor
+// each.  Used where a layer exists once per node type of the knowledge graph (ten small GEMMs per HGT conv otherwise).
+//   words: 0 a_row0  1 a_row_end  2 b_row0  3 b_row_end   first row / end of the group's rows in the stacked images (tile origin in 0, 2)
+//          4 m_base  5 n_base     the group's first x row / first W row: output element (m, n) is y[y_off + (m - m_base) * ldy + (n - n_base)]
+//          6 y_off   7 ldy   8 res_off (-1: none)  9 ldr   10 alpha (float bits) | beta (float bits) << 32
+constexpr int kGroupTileWords = 12;
+
+template <int MODE, class S, int MF, bool GROUPED = false>
+__global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs pk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [stages][A tile | B tile]; reused as [wave][64][64] fp32 by the epilogue
   constexpr int MT = S::MT, NT_ = S::NT_;
   static_assert(MF == 32 || (MF == 16 && MODE != MDG_PREC_F32), "the 16x16x32 form exists for the 16-bit modes only");
   static_assert(NT_ == 2 && MT % 2 == 0 && S::WAVES * 16384 <= 2 * S::STAGE, "the epilogue turns 64 x 64 patches through 16 KB of LDS per wave");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wr = wave / S::WN, wc = wave % S::WN;
-  int tx, ty;
-  if (!tile_of(p, tx, ty)) return;                        // workgroup-uniform
-  const int64_t col0 = static_cast<int64_t>(tx) * S::BN, row0 = static_cast<int64_t>(ty) * S::BM;
+  LinearArgs p = pk;
+  int64_t col0, row0;
+  if constexpr (GROUPED) {
+    const int64_t* e = pk.tiles + static_cast<int64_t>(blockIdx.x) * kGroupTileWords;      // workgroup-uniform (scalar loads)
+    row0 = e[0];
+    col0 = e[2];
+    p.A.nrows = e[1];
+    p.B.nrows = e[3];
+    p.M = e[1];
+    p.N = e[3];
+    p.ldy = e[7];
+    p.y = pk.y + e[6] - e[4] * e[7] - e[5];              // so that y[m * ldy + n] with the stacked (m, n) lands in the group's block
+    p.ldr = e[9];
+    p.res = (pk.res && e[8] >= 0) ? pk.res + e[8] - e[4] * e[9] - e[5] : nullptr;
+    const unsigned long long ab = static_cast<unsigned long long>(e[10]);
+    p.alpha = __builtin_bit_cast(float, static_cast<unsigned>(ab & 0xffffffffull));
+    p.beta = __builtin_bit_cast(float, static_cast<unsigned>(ab >> 32));
+  } else {
+    int tx, ty;
+    if (!tile_of(p, tx, ty)) return;                        // workgroup-uniform
+    col0 = static_cast<int64_t>(tx) * S::BN;
+    row0 = static_cast<int64_t>(ty) * S::BM;
+  }
   float* const slab = reinterpret_cast<float*>(smem) + wave * 4096;
   const int64_t pm0 = row0 + wr * 32 * MT, pn0 = col0 + wc * 64;
 
@@ -720,6 +749,49 @@ extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t l
   set_operand(a.B, w, ldw, wb == 0 ? nullptr : (w_packed ? static_cast<const char*>(w_packed) : wimg), N, K, precision);
   launch_linear_core(a, precision, M, N, st);
   MDG_CHECK_LAUNCH("mdg_linear");
+  return MDG_OK;
+}
+
+// ---- grouped launch: see the GROUPED kernel variant -------------------------------------------------------------------------
+extern "C" int mdg_linear_group_tile_words(void) { return kGroupTileWords; }
+
+extern "C" size_t mdg_linear_grouped_workspace_bytes(int64_t rows_total, int64_t K, int precision) { return image_bytes(rows_total, K, precision); }
+
+extern "C" int mdg_linear_grouped(const float* x, int64_t ldx, int64_t rows_total, int64_t K, const float* w, int64_t ldw, const void* w_packed,
+                                  int64_t w_rows_total, const float* bias, const int64_t* tiles, int64_t n_tiles, float* y,
+                                  const float* residual, int act, int precision, void* workspace, size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(rows_total >= 0 && w_rows_total >= 0 && n_tiles >= 0, "mdg_linear_grouped: negative size");
+  if (n_tiles == 0 || rows_total == 0 || w_rows_total == 0) return MDG_OK;
+  MDG_CHECK_ARG(x && y && tiles && (w || w_packed), "mdg_linear_grouped: null pointer");
+  MDG_CHECK_ARG(K > 0 && K % 4 == 0 && ldx % 4 == 0 && ldx >= K, "mdg_linear_grouped: K and ldx must be multiples of 4, ldx >= K");
+  MDG_CHECK_ARG(mdg_aligned16(x) && mdg_aligned16(y) && (!residual || mdg_aligned16(residual)) && (!w_packed || mdg_aligned16(w_packed)),
+                "mdg_linear_grouped: x, y, residual, w_packed must be 16-byte aligned (offsets and row strides in the table: multiples of 4)");
+  MDG_CHECK_ARG(act >= MDG_ACT_NONE && act <= MDG_ACT_SELU, "mdg_linear_grouped: unknown activation %d", act);
+  MDG_CHECK_ARG(precision == MDG_PREC_F32 || precision == MDG_PREC_BF16X3 || precision == MDG_PREC_BF16, "mdg_linear_grouped: unknown precision %d", precision);
+  MDG_CHECK_ARG(n_tiles < (1ll << 31), "mdg_linear_grouped: too many tiles");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t xb = image_bytes(rows_total, K, precision), wb = image_bytes(w_rows_total, K, precision);
+  MDG_CHECK_ARG(wb == 0 ? (w != nullptr && ldw >= K && ldw % 4 == 0 && mdg_aligned16(w)) : w_packed != nullptr,
+                "mdg_linear_grouped: the stacked weights must come packed (mdg_pack_operand), or raw where the mode needs no image");
+  if (xb && (!workspace || workspace_bytes < xb || !mdg_aligned16(workspace))) {
+    mdg_set_error("mdg_linear_grouped: workspace of %zu bytes (16-byte aligned) required, got %zu", xb, workspace_bytes);
+    return MDG_EWORKSPACE;
+  }
+  char* ximg = xb ? static_cast<char*>(workspace) : nullptr;
+  if (ximg) launch_prep(x, ldx, rows_total, ximg, nullptr, 0, 0, nullptr, K, precision, st);
+  LinearArgs a{};
+  a.y = y; a.ldy = 0; a.bias = bias; a.res = residual; a.ldr = 0; a.alpha = 1.f; a.beta = 1.f; a.act = act;
+  a.M = rows_total; a.N = w_rows_total; a.K = pad32(K);
+  a.vec_y = 1; a.vec_r = residual ? 1 : 0;               // the table's offsets and strides are multiples of 4 floats (checked by the caller's builder)
+  a.tiles = tiles;
+  set_operand(a.A, x, ldx, ximg, rows_total, K, precision);
+  set_operand(a.B, w, ldw, wb == 0 ? nullptr : static_cast<const char*>(w_packed), w_rows_total, K, precision);
+  const dim3 grid(static_cast<unsigned>(n_tiles));
+  const size_t lds = 2 * Small::STAGE;
+  if (precision == MDG_PREC_F32) hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, Small, 32, true>), grid, dim3(Small::THREADS), lds, st, a);
+  else if (precision == MDG_PREC_BF16X3) hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, Small, 16, true>), grid, dim3(Small::THREADS), lds, st, a);
+  else hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, Small, 16, true>), grid, dim3(Small::THREADS), lds, st, a);
+  MDG_CHECK_LAUNCH("mdg_linear_grouped");
   return MDG_OK;
 }
 

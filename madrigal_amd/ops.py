@@ -362,6 +362,57 @@ def xattn_pool_bwd(q_proj: torch.Tensor, kv_proj: torch.Tensor, dout: torch.Tens
 
 
 # ------------------------------------------------------------------------------- graphs
+# ------------------------------------------------------------------------------- grouped dense block
+GROUP_TILE = 128          # output tile edge of mdg_linear_grouped
+
+
+def group_tile_table(groups, device) -> torch.Tensor:
+    """Tile descriptors of a grouped launch (include/madrigal_hip.h: mdg_linear_grouped) -> int64 [n_tiles, words] on
+    ``device``.  ``groups``: dicts with m_base, rows (the group's rows in the stacked x), n_base, n (its rows in the stacked W),
+    y_off, ldy (float offset of its output block in y and that block's row stride) and optionally res_off, ldr, alpha, beta."""
+    import struct
+    words = int(lib().mdg_linear_group_tile_words())
+    rows = []
+    for g in groups:
+        for v in (g["n_base"], g["y_off"], g["ldy"], g.get("res_off", 0) or 0, g.get("ldr", 0)):
+            if v % 4:
+                raise ValueError("group_tile_table: offsets and row strides must be multiples of 4 floats")
+        ab = struct.unpack("<q", struct.pack("<ff", float(g.get("alpha", 1.0)), float(g.get("beta", 1.0))))[0]
+        has_res = "res_off" in g and g["res_off"] is not None
+        for ty in range((g["rows"] + GROUP_TILE - 1) // GROUP_TILE):
+            for tx in range((g["n"] + GROUP_TILE - 1) // GROUP_TILE):
+                e = [g["m_base"] + ty * GROUP_TILE, g["m_base"] + g["rows"], g["n_base"] + tx * GROUP_TILE, g["n_base"] + g["n"],
+                     g["m_base"], g["n_base"], g["y_off"], g["ldy"], g["res_off"] if has_res else -1, g.get("ldr", 0) if has_res else 0, ab, 0]
+                rows.append(e + [0] * (words - len(e)))
+    t = torch.tensor(rows, dtype=torch.int64).reshape(-1, words) if rows else torch.zeros((0, words), dtype=torch.int64)
+    return t.to(device)
+
+
+def linear_grouped(x: torch.Tensor, w_all: torch.Tensor, bias_all: Optional[torch.Tensor], tiles: torch.Tensor, y: torch.Tensor,
+                   residual: Optional[torch.Tensor] = None, act=None, precision="bf16x3") -> torch.Tensor:
+    """G products y_g = alpha_g act(x_g W_g^T + b_g) + beta_g r_g in one launch: ``x`` [rows_total, K] and ``w_all``
+    [w_rows_total, K] hold the groups' rows stacked, ``tiles`` = group_tile_table(...), ``y`` / ``residual`` the buffers its
+    offsets address.  The packed image of ``w_all`` is kept while the tensor is unchanged (as for linear)."""
+    forward_only(x, w_all, bias_all, residual)
+    x, w_all = _f32_cuda(x, "x", 2), _f32_cuda(w_all, "w_all", 2)
+    if x.stride(1) != 1 or w_all.shape[1] != x.shape[1] or not w_all.is_contiguous() or x.shape[1] % 4 or x.stride(0) % 4:
+        raise ValueError("linear_grouped: x [rows,K] (unit inner stride, K and row stride multiples of 4), w_all [w_rows,K] contiguous")
+    if not y.is_cuda or y.dtype != torch.float32 or not y.is_contiguous() or (residual is not None and not residual.is_contiguous()):
+        raise ValueError("linear_grouped: y / residual must be contiguous fp32 cuda buffers")
+    if act not in ACTS:
+        raise ValueError(f"unknown activation {act!r}")
+    prec = _prec(precision)
+    K = x.shape[1]
+    wimg = packed_weight_image(w_all, prec)
+    nbytes = lib().mdg_linear_grouped_workspace_bytes(_c64(x.shape[0]), _c64(K), _c(prec))
+    ws = _workspace(nbytes, x.device)
+    check(lib().mdg_linear_grouped(_ptr(x), _c64(x.stride(0)), _c64(x.shape[0]), _c64(K), _ptr(w_all), _c64(w_all.stride(0)), _ptr(wimg),
+                                   _c64(w_all.shape[0]), _ptr(None if bias_all is None else bias_all.detach().contiguous()), _ptr(tiles),
+                                   _c64(tiles.shape[0]), _ptr(y), _ptr(residual), _c(ACTS[act]), _c(prec), _ptr(ws), ctypes.c_size_t(nbytes),
+                                   _stream(x)), "mdg_linear_grouped")
+    return y
+
+
 def csr_aggregate(x: torch.Tensor, rowptr: torch.Tensor, col: Optional[torch.Tensor] = None, *, edge_weight=None,
                   x_self: Optional[torch.Tensor] = None, self_coef_dev: Optional[torch.Tensor] = None,
                   self_coef_add: float = 0.0, mean: bool = False) -> torch.Tensor:
@@ -390,13 +441,18 @@ def csr_aggregate(x: torch.Tensor, rowptr: torch.Tensor, col: Optional[torch.Ten
     return out
 
 
-def hgt_attention(q: torch.Tensor, kv: torch.Tensor, plan: dict, heads: int, apply_gelu: bool = True) -> torch.Tensor:
+def hgt_attention(q: torch.Tensor, kv: torch.Tensor, plan: dict, heads: int, apply_gelu: bool = True,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Edge softmax + aggregation for one destination node type.  ``q`` may be a column-slice view
-    [n_dst,128] of the k|q|v projection; ``plan`` holds col / item_* / item_ptr (see graph_plans)."""
+    [n_dst,128] of the k|q|v projection; ``plan`` holds col / item_* / item_ptr (see graph_plans).  ``out``: contiguous
+    [n_dst,128] rows to write (a row block of a buffer shared by all destination types)."""
     n_dst = q.shape[0]
     if q.dim() != 2 or q.shape[1] != 128 or q.stride(1) != 1 or not q.is_cuda or q.dtype != torch.float32:
         raise ValueError("q: expected fp32 cuda [n_dst,128] with unit inner stride")
-    out = torch.empty((n_dst, 128), dtype=torch.float32, device=q.device)
+    if out is None:
+        out = torch.empty((n_dst, 128), dtype=torch.float32, device=q.device)
+    elif tuple(out.shape) != (n_dst, 128) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != q.device:
+        raise ValueError("out: expected contiguous fp32 [n_dst,128] on q's device")
     n_items = int(plan["item_dst"].numel())
     nbytes = lib().mdg_hgt_attention_workspace_bytes(_c64(n_items), _c(heads))
     ws = _workspace(nbytes, q.device)

@@ -89,6 +89,42 @@ def test_pinned_ring_uploads_keep_their_contents():
     assert torch.equal(hostio.upload(m, "cuda", "test-ring-mask").cpu(), m)
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+def test_grouped_linear_equals_one_launch_per_group(ops, prec):
+    """mdg_linear_grouped: groups of different row counts and widths (a group smaller than a tile, one with a ragged last tile,
+    an empty one), outputs into blocks of different row strides, per-group gated residual -- bit-identical to one mdg_linear per
+    group (same tiles, same k order)."""
+    K = 128
+    rows = [300, 17, 0, 1000]
+    widths = [384, 128, 256, 640]
+    xs = [_rand((r, K), 40 + i).cuda() for i, r in enumerate(rows)]
+    ws = [_rand((n, K), 50 + i, 0.1).cuda() for i, n in enumerate(widths)]
+    bs = [_rand((n,), 60 + i).cuda() for i, n in enumerate(widths)]
+    x_all, w_all, b_all = torch.cat(xs), torch.cat(ws), torch.cat(bs)
+    groups, m, n, off = [], 0, 0, 0
+    for r, wd in zip(rows, widths):
+        groups.append(dict(m_base=m, rows=r, n_base=n, n=wd, y_off=off, ldy=wd))
+        m, n, off = m + r, n + wd, off + r * wd
+    y = torch.full((off,), float("nan"), device="cuda")
+    ops.linear_grouped(x_all, w_all, b_all, ops.group_tile_table(groups, "cuda"), y, act="gelu", precision=prec)
+    for g, x, w, b in zip(groups, xs, ws, bs):
+        want = ops.linear(x, w, b, act="gelu", precision=prec, cache_weight=False)
+        got = y[g["y_off"]: g["y_off"] + g["rows"] * g["ldy"]].view(g["rows"], g["ldy"])
+        assert torch.equal(got, want)
+    # 128 -> 128 layers with x itself as the gated residual (the output projection of the KG conv)
+    ws2 = [_rand((128, K), 70 + i, 0.1).cuda() for i in range(4)]
+    gates = [0.3, 0.9, 0.5, 0.1]
+    groups2, m = [], 0
+    for i, r in enumerate(rows):
+        groups2.append(dict(m_base=m, rows=r, n_base=128 * i, n=128, y_off=m * 128, ldy=128, res_off=m * 128, ldr=128, alpha=gates[i], beta=1 - gates[i]))
+        m += r
+    y2 = torch.empty(m, 128, device="cuda")
+    ops.linear_grouped(x_all, torch.cat(ws2), None, ops.group_tile_table(groups2, "cuda"), y2, residual=x_all, precision=prec)
+    for g, x, w, a in zip(groups2, xs, ws2, gates):
+        want = ops.linear(x, w, None, residual=x, alpha=a, beta=1 - a, precision=prec, cache_weight=False)
+        assert torch.equal(y2[g["m_base"]: g["m_base"] + g["rows"]], want)
+
+
 def test_linear_errors(ops):
     x, w = torch.zeros(4, 8, device="cuda"), torch.zeros(3, 12, device="cuda")
     with pytest.raises(ValueError):
