@@ -179,6 +179,13 @@ int mdg_hgt_attention(const float* q, int64_t ldq, const float* kv, int64_t ldkv
                       const int64_t* item_begin, const int64_t* item_end, int64_t n_items, const int64_t* item_ptr, float* out,
                       int64_t ldo, int64_t n_dst, int heads, int64_t F, int apply_gelu, void* workspace, size_t workspace_bytes,
                       void* stream);
+/* The same for ALL destination node types of a conv in one launch: destinations numbered across the types, query row of
+ * destination d at q_base + q_off[d] floats (the types' projection rows differ in width), items / edges / item_ptr of the types
+ * concatenated, out [n_dst,128].  (PyG HGTConv runs its message passing per edge type: models.py:76-79.) */
+int mdg_hgt_attention_rows(const float* q_base, const int64_t* q_off, const float* kv, int64_t ldkv, const int64_t* col,
+                           const int64_t* item_dst, const int64_t* item_begin, const int64_t* item_end, int64_t n_items,
+                           const int64_t* item_ptr, float* out, int64_t ldo, int64_t n_dst, int heads, int apply_gelu,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------ losses ---- */
 

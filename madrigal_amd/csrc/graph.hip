@@ -84,6 +84,8 @@ struct HgtArgs {
   float* part_ml;                       // [n_items,H,2]
   int64_t n_items;
   int H;
+  const int64_t* q_off;                 // optional: float offset of each destination's query row from q (destinations of several
+                                        // node types, whose rows differ in width, in ONE launch); null: row dst at q + dst * ldq
 };
 
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]); }
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void hgt_attention_kernel(const HgtArgs p) {
   if (item >= p.n_items) return;
   const int lph = 32 / p.H;                       // lanes per head
   const int64_t dst = p.item_dst[item], e0 = p.item_begin[item], e1 = p.item_end[item];
-  const f32x4 q = *reinterpret_cast<const f32x4*>(p.q + dst * p.ldq + 4 * sub);
+  const f32x4 q = *reinterpret_cast<const f32x4*>(p.q + (p.q_off ? p.q_off[dst] : dst * p.ldq) + 4 * sub);
   float m = -INFINITY, l = 0.f;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   // this half takes edges e0+half, e0+half+2, ...; FOUR of them per iteration (8 rows = 8 KB of k'|v' in flight per wave: every
@@ -356,7 +358,7 @@ extern "C" int mdg_hgt_attention_stats(const float* q, int64_t ldq, const float*
   float* part_acc = static_cast<float*>(workspace);
   float* part_ml = part_acc ? part_acc + n_items * 128 : nullptr;
   if (n_items > 0) {
-    HgtArgs a{q, ldq, kv, ldkv, col, item_dst, item_begin, item_end, part_acc, part_ml, n_items, heads};
+    HgtArgs a{q, ldq, kv, ldkv, col, item_dst, item_begin, item_end, part_acc, part_ml, n_items, heads, nullptr};
     hipLaunchKernelGGL(hgt_attention_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_items, 4))), dim3(256), 0, st, a);
   }
   hipLaunchKernelGGL(hgt_combine_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_dst, 8))), dim3(256), 0, st, part_acc, part_ml, item_ptr,
@@ -371,6 +373,36 @@ extern "C" int mdg_hgt_attention(const float* q, int64_t ldq, const float* kv, i
                                  int apply_gelu, void* workspace, size_t workspace_bytes, void* stream) {
   return mdg_hgt_attention_stats(q, ldq, kv, ldkv, col, item_dst, item_begin, item_end, n_items, item_ptr, out, ldo, n_dst, heads, F,
                                  apply_gelu, nullptr, workspace, workspace_bytes, stream);
+}
+
+// All destination types of a conv in one launch: destinations numbered across the types, query row of destination d at
+// q_base + q_off[d] (the types' projection rows differ in width), outputs in one [n_dst,128] buffer.  Inference (no stats).
+extern "C" int mdg_hgt_attention_rows(const float* q_base, const int64_t* q_off, const float* kv, int64_t ldkv, const int64_t* col,
+                                      const int64_t* item_dst, const int64_t* item_begin, const int64_t* item_end, int64_t n_items,
+                                      const int64_t* item_ptr, float* out, int64_t ldo, int64_t n_dst, int heads, int apply_gelu,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(heads == 1 || heads == 2 || heads == 4 || heads == 8, "mdg_hgt_attention_rows: heads must be 1, 2, 4 or 8 (got %d)", heads);
+  MDG_CHECK_ARG(n_dst >= 0 && n_items >= 0, "mdg_hgt_attention_rows: negative size");
+  if (n_dst == 0) return MDG_OK;
+  MDG_CHECK_ARG(q_base && q_off && out && item_ptr && (n_items == 0 || (kv && col && item_dst && item_begin && item_end)), "mdg_hgt_attention_rows: null pointer");
+  MDG_CHECK_ARG(ldkv % 4 == 0 && ldo % 4 == 0 && ldkv >= 128 && ldo >= 128 && mdg_aligned16(q_base) && mdg_aligned16(out) && (!kv || mdg_aligned16(kv)),
+                "mdg_hgt_attention_rows: bad strides / alignment (query offsets must be multiples of 4 floats)");
+  const size_t need = mdg_hgt_attention_workspace_bytes(n_items, heads);
+  if (need && (!workspace || workspace_bytes < need || !mdg_aligned16(workspace))) {
+    mdg_set_error("mdg_hgt_attention_rows: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return MDG_EWORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* part_acc = static_cast<float*>(workspace);
+  float* part_ml = part_acc ? part_acc + n_items * 128 : nullptr;
+  if (n_items > 0) {
+    HgtArgs a{q_base, 0, kv, ldkv, col, item_dst, item_begin, item_end, part_acc, part_ml, n_items, heads, q_off};
+    hipLaunchKernelGGL(hgt_attention_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_items, 4))), dim3(256), 0, st, a);
+  }
+  hipLaunchKernelGGL(hgt_combine_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_dst, 8))), dim3(256), 0, st, part_acc, part_ml, item_ptr,
+                     out, ldo, n_dst, heads, apply_gelu, static_cast<float*>(nullptr));
+  MDG_CHECK_LAUNCH("mdg_hgt_attention_rows");
+  return MDG_OK;
 }
 
 extern "C" size_t mdg_hgt_attention_bwd_workspace_bytes(int64_t nnz, int64_t n_items, int64_t n_src_items, int heads) {

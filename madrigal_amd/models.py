@@ -649,15 +649,28 @@ class HGTConv(nn.Module):
             for t in dst_types:
                 drow[t] = d0
                 d0 += sizes[t]
-            tabs = plan[tkey] = {"proj": ops.group_tile_table(groups, dev), "drow": drow, "rows_dst": d0, "out": None, "alphas": None}
+            # the destination types' attention plans concatenated: destinations, items and edges numbered across the types
+            pieces = {k: [] for k in ("q_off", "col", "item_dst", "item_begin", "item_end", "item_ptr")}
+            n_it = n_e = 0
+            for t in dst_types:
+                pd = plan["per_dst"][t]
+                pieces["q_off"].append(plan["base"][t] + torch.arange(sizes[t], device=dev, dtype=torch.int64) * plan["width"][t])
+                pieces["col"].append(pd["col"])
+                pieces["item_dst"].append(pd["item_dst"] + drow[t])
+                pieces["item_begin"].append(pd["item_begin"] + n_e)
+                pieces["item_end"].append(pd["item_end"] + n_e)
+                pieces["item_ptr"].append(pd["item_ptr"][:-1] + n_it)
+                n_it += int(pd["item_dst"].numel())
+                n_e += int(pd["col"].numel())
+            pieces["item_ptr"].append(torch.tensor([n_it], dtype=torch.int64, device=dev))
+            att = {k: torch.cat(v).contiguous() for k, v in pieces.items()} if dst_types else None
+            tabs = plan[tkey] = {"proj": ops.group_tile_table(groups, dev), "drow": drow, "rows_dst": d0, "out": None, "alphas": None, "att": att}
         buf = torch.empty(max(plan["total_floats"], 128), dtype=torch.float32, device=dev)
         ops.linear_grouped(X_all, W_all, b_all, tabs["proj"], buf, precision=_state["precision"])
-        kv = buf.view(-1, 128)
         drow, rows_dst = tabs["drow"], tabs["rows_dst"]
         agg_all = torch.empty((rows_dst, F), dtype=torch.float32, device=dev)
-        for t in dst_types:
-            q = buf[plan["base"][t]: plan["base"][t] + sizes[t] * plan["width"][t]].view(sizes[t], plan["width"][t])[:, 0:F]
-            ops.hgt_attention(q, kv, plan["per_dst"][t], self.heads, apply_gelu=True, out=agg_all[drow[t]: drow[t] + sizes[t]])
+        if tabs["att"] is not None:
+            ops.hgt_attention_rows(buf, tabs["att"], self.heads, agg_all, apply_gelu=True)
         alphas = tuple(self._skip_alpha(t) if gated else 1.0 for t in dst_types)
         if tabs["out"] is None or tabs["alphas"] != alphas:             # the gates sit in the table: rebuilt when a skip parameter changes
             groups = [dict(m_base=drow[t], rows=sizes[t], n_base=F * i, n=F, y_off=drow[t] * F, ldy=F, alpha=a, beta=1.0 - a,

@@ -463,6 +463,24 @@ def hgt_attention(q: torch.Tensor, kv: torch.Tensor, plan: dict, heads: int, app
     return out
 
 
+def hgt_attention_rows(buf: torch.Tensor, plan_all: dict, heads: int, out: torch.Tensor, apply_gelu: bool = True) -> torch.Tensor:
+    """Edge attention of ALL destination types of a conv in one launch (inference).  ``buf``: the flat projection buffer (queries,
+    keys and values); ``plan_all``: the destination types' plans concatenated (models.HGTConv._forward_grouped): q_off [n_dst] float
+    offsets of the query rows in ``buf``, col / item_* / item_ptr with destinations numbered across the types; ``out`` [n_dst,128]."""
+    n_dst = int(plan_all["q_off"].numel())
+    if tuple(out.shape) != (n_dst, 128) or not out.is_contiguous() or out.dtype != torch.float32 or not buf.is_contiguous():
+        raise ValueError("hgt_attention_rows: out must be contiguous fp32 [n_dst,128], buf contiguous")
+    n_items = int(plan_all["item_dst"].numel())
+    nbytes = lib().mdg_hgt_attention_workspace_bytes(_c64(n_items), _c(heads))
+    ws = _workspace(nbytes, buf.device)
+    kv = buf.view(-1, 128)
+    check(lib().mdg_hgt_attention_rows(_ptr(buf), _ptr(plan_all["q_off"]), _ptr(kv), _c64(128), _ptr(plan_all["col"]), _ptr(plan_all["item_dst"]),
+                                       _ptr(plan_all["item_begin"]), _ptr(plan_all["item_end"]), _c64(n_items), _ptr(plan_all["item_ptr"]),
+                                       _ptr(out), _c64(128), _c64(n_dst), _c(heads), _c(1 if apply_gelu else 0), _ptr(ws),
+                                       ctypes.c_size_t(nbytes), _stream(buf)), "mdg_hgt_attention_rows")
+    return out
+
+
 def l2_normalize(x: torch.Tensor) -> torch.Tensor:
     """F.normalize(x, p=2, dim=-1)."""
     forward_only(x)
