@@ -1021,16 +1021,29 @@ class TransformerFusion(nn.Module):
         """``attend(qkv) -> attention output rows``; ``keep_rows`` (int64 index) prunes the rows that
         continue after the attention (last layer: only the pooled key tokens are ever read again)."""
         sa = L.self_attn
+
+        def in_proj(a):
+            """q | k | v rows.  When only ``keep_rows`` continue past the attention, only THEIR queries are ever used (a query
+            row decides its own output row and nothing else): keys and values for all rows, queries for the kept rows only --
+            the other rows' query slots stay unwritten and so do the outputs computed from them, which are dropped."""
+            w, b = sa.in_proj_weight.detach(), sa.in_proj_bias.detach()
+            if keep_rows is None or os.environ.get("MDG_FUSION_Q_KEPT_ONLY", "1") == "0" or a.shape[0] < 4 * keep_rows.numel() // 3:
+                return _lin(a, w, b)
+            d = w.shape[1]
+            qkv = torch.empty((a.shape[0], 3 * d), dtype=torch.float32, device=a.device)
+            _lin(a, w[d:], b[d:], out=qkv[:, d:])
+            qkv[:, :d].index_copy_(0, keep_rows, _lin(a.index_select(0, keep_rows), w[:d], b[:d]))
+            return qkv
         if self.norm_first:
             a = ops.layernorm(h, L.norm1.weight, L.norm1.bias, L.norm1.eps)
-            att = attend(_lin(a, sa.in_proj_weight, sa.in_proj_bias), a)
+            att = attend(in_proj(a), a)
             if keep_rows is not None:
                 att, h = att.index_select(0, keep_rows), h.index_select(0, keep_rows)
             h = _lin(att, sa.out_proj.weight, sa.out_proj.bias, residual=h)
             f = ops.layernorm(h, L.norm2.weight, L.norm2.bias, L.norm2.eps)
             u = _lin(f, L.linear1.weight, L.linear1.bias, act=self.actn)
             return _lin(u, L.linear2.weight, L.linear2.bias, residual=h)
-        att = attend(_lin(h, sa.in_proj_weight, sa.in_proj_bias), h)
+        att = attend(in_proj(h), h)
         if keep_rows is not None:
             att, h = att.index_select(0, keep_rows), h.index_select(0, keep_rows)
         t = _lin(att, sa.out_proj.weight, sa.out_proj.bias, residual=h)
