@@ -114,6 +114,15 @@ int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const v
  * MLPAdaptor, models.py:492.  d multiple of 4, <= 2048. */
 int mdg_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy, int64_t rows,
                   int64_t d, float eps, void* stream);
+/* LayerNorm that also writes y as the packed operand image of the dense block consuming it (mdg_pack_operand_bytes(rows, d,
+ * precision) bytes, bit-identical to mdg_linear's own pre-pass; 16-bit modes, d a multiple of 32; y may be NULL when only
+ * the image is wanted), and mdg_linear on such an
+ * image: the norm -> projection pairs of nn.TransformerEncoderLayer (models.py:366) without the pre-pass in between. */
+int mdg_layernorm_packed(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy, int64_t rows,
+                         int64_t d, float eps, int precision, void* y_packed, size_t y_packed_bytes, void* stream);
+int mdg_linear_packed_x(const void* x_packed, int64_t M, int64_t K, const float* w, int64_t ldw, const void* w_packed, float* y,
+                        int64_t ldy, int64_t N, const float* bias, int act, const float* residual, int64_t ldr, float alpha,
+                        float beta, int precision, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------- cross-modal fusion ---- */
 

@@ -577,7 +577,7 @@ inline int64_t pad32(int64_t k) { return (k + 31) / 32 * 32; }
 template <int VEC>   // floats per lane = 4*VEC, d <= 256*VEC
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ g,
                                                         const float* __restrict__ b, float* __restrict__ y, int64_t ldy,
-                                                        int64_t rows, int d, float eps) {
+                                                        int64_t rows, int d, float eps, char* __restrict__ img_hi, char* __restrict__ img_lo) {
   const int lane = threadIdx.x & 63;
   const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -613,7 +613,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
-      *reinterpret_cast<f32x4*>(yr + c) = o;
+      if (y) *reinterpret_cast<f32x4*>(yr + c) = o;
+      if (img_hi) {                                      // the next dense block's operand image (what its pre-pass would write)
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          __bf16 a_, b_;
+          mdg_split_bf16(o[e], a_, b_);
+          hi[e] = a_;
+          lo[e] = b_;
+        }
+        *reinterpret_cast<bf16x4*>(img_hi + (row * d + c) * 2) = hi;
+        if (img_lo) *reinterpret_cast<bf16x4*>(img_lo + (row * d + c) * 2) = lo;
+      }
     }
   }
 }
@@ -839,21 +851,79 @@ extern "C" int mdg_linear_tn(const float* g, int64_t ldg, const float* x, int64_
   return MDG_OK;
 }
 
-extern "C" int mdg_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
-                             int64_t rows, int64_t d, float eps, void* stream) {
+static int layernorm_impl(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy, int64_t rows, int64_t d,
+                          float eps, int precision, void* y_packed, size_t y_packed_bytes, void* stream) {
   MDG_CHECK_ARG(rows >= 0 && d > 0, "mdg_layernorm: bad shape");
   if (rows == 0) return MDG_OK;
-  MDG_CHECK_ARG(x && gamma && beta && y, "mdg_layernorm: null pointer");
-  MDG_CHECK_ARG(d % 4 == 0 && d <= 2048 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= d && ldy >= d,
+  MDG_CHECK_ARG(x && gamma && beta && (y || y_packed), "mdg_layernorm: null pointer");
+  MDG_CHECK_ARG(d % 4 == 0 && d <= 2048 && ldx % 4 == 0 && ldx >= d && (!y || (ldy % 4 == 0 && ldy >= d)),
                 "mdg_layernorm: d must be a multiple of 4 and <= 2048 (got %lld)", (long long)d);
-  MDG_CHECK_ARG(mdg_aligned16(x) && mdg_aligned16(y) && mdg_aligned16(gamma) && mdg_aligned16(beta), "mdg_layernorm: 16-byte alignment");
+  MDG_CHECK_ARG(mdg_aligned16(x) && (!y || mdg_aligned16(y)) && mdg_aligned16(gamma) && mdg_aligned16(beta), "mdg_layernorm: 16-byte alignment");
+  char* hi = nullptr;
+  char* lo = nullptr;
+  if (y_packed) {
+    MDG_CHECK_ARG(precision == MDG_PREC_BF16X3 || precision == MDG_PREC_BF16, "mdg_layernorm_packed: a 16-bit operand mode (the fp32 mode reads y itself)");
+    MDG_CHECK_ARG(d % 32 == 0 && mdg_aligned16(y_packed), "mdg_layernorm_packed: d must be a multiple of 32 (the image has no padding to fill)");
+    const size_t need = image_bytes(rows, d, precision);
+    if (y_packed_bytes < need) {
+      mdg_set_error("mdg_layernorm_packed: image of %zu bytes required, got %zu", need, y_packed_bytes);
+      return MDG_EWORKSPACE;
+    }
+    hi = static_cast<char*>(y_packed);
+    lo = precision == MDG_PREC_BF16X3 ? hi + al256(static_cast<size_t>(rows) * d * 2) : nullptr;
+  }
   const dim3 grid(static_cast<unsigned>(mdg_cdiv(rows, 4)));
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int di = static_cast<int>(d);
-  if (d <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, rows, di, eps);
-  else if (d <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, rows, di, eps);
-  else if (d <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, rows, di, eps);
-  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, rows, di, eps);
+  if (d <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, rows, di, eps, hi, lo);
+  else if (d <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, rows, di, eps, hi, lo);
+  else if (d <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, rows, di, eps, hi, lo);
+  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, rows, di, eps, hi, lo);
   MDG_CHECK_LAUNCH("mdg_layernorm");
+  return MDG_OK;
+}
+
+extern "C" int mdg_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
+                             int64_t rows, int64_t d, float eps, void* stream) {
+  return layernorm_impl(x, ldx, gamma, beta, y, ldy, rows, d, eps, MDG_PREC_F32, nullptr, 0, stream);
+}
+
+// LayerNorm that also writes y as the operand image of the dense block that consumes it (mdg_pack_operand_bytes(rows, d, precision)
+// bytes; identical to what mdg_linear's own pre-pass would write): that block then starts from mdg_linear_packed_x.
+extern "C" int mdg_layernorm_packed(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy, int64_t rows,
+                                    int64_t d, float eps, int precision, void* y_packed, size_t y_packed_bytes, void* stream) {
+  MDG_CHECK_ARG(y_packed, "mdg_layernorm_packed: null image");
+  return layernorm_impl(x, ldx, gamma, beta, y, ldy, rows, d, eps, precision, y_packed, y_packed_bytes, stream);
+}
+
+// mdg_linear on an x that already exists as an operand image (written by mdg_layernorm_packed / mdg_pack_operand): no pre-pass.
+extern "C" int mdg_linear_packed_x(const void* x_packed, int64_t M, int64_t K, const float* w, int64_t ldw, const void* w_packed, float* y,
+                                   int64_t ldy, int64_t N, const float* bias, int act, const float* residual, int64_t ldr, float alpha,
+                                   float beta, int precision, void* workspace, size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(M >= 0 && N >= 0 && K > 0, "mdg_linear_packed_x: bad size");
+  if (M == 0 || N == 0) return MDG_OK;
+  MDG_CHECK_ARG(precision == MDG_PREC_BF16X3 || precision == MDG_PREC_BF16, "mdg_linear_packed_x: a 16-bit operand mode");
+  MDG_CHECK_ARG(x_packed && y && (w || w_packed) && mdg_aligned16(x_packed), "mdg_linear_packed_x: null / misaligned pointer");
+  MDG_CHECK_ARG(K % 32 == 0, "mdg_linear_packed_x: K must be a multiple of 32");
+  MDG_CHECK_ARG(ldy >= N && (!residual || ldr >= N || ldr == 0), "mdg_linear_packed_x: ldy/ldr smaller than N");
+  MDG_CHECK_ARG(act >= MDG_ACT_NONE && act <= MDG_ACT_SELU, "mdg_linear_packed_x: unknown activation %d", act);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t wb = image_bytes(N, K, precision);
+  char* wimg = nullptr;
+  if (!w_packed) {
+    MDG_CHECK_ARG(w && ldw % 4 == 0 && ldw >= K && mdg_aligned16(w), "mdg_linear_packed_x: raw w must be 16-byte aligned with ldw >= K");
+    if (!workspace || workspace_bytes < wb || !mdg_aligned16(workspace)) {
+      mdg_set_error("mdg_linear_packed_x: workspace of %zu bytes required for the weight image, got %zu", wb, workspace_bytes);
+      return MDG_EWORKSPACE;
+    }
+    wimg = static_cast<char*>(workspace);
+    launch_prep(w, ldw, N, wimg, nullptr, 0, 0, nullptr, K, precision, st);
+  }
+  LinearArgs a{};
+  a.y = y; a.ldy = ldy; a.bias = bias; a.res = residual; a.ldr = ldr; a.alpha = alpha; a.beta = beta; a.act = act; a.M = M; a.N = N; a.K = K;
+  set_operand(a.A, nullptr, 0, static_cast<const char*>(x_packed), M, K, precision);
+  set_operand(a.B, w, ldw, w_packed ? static_cast<const char*>(w_packed) : wimg, N, K, precision);
+  launch_linear_core(a, precision, M, N, st);
+  MDG_CHECK_LAUNCH("mdg_linear_packed_x");
   return MDG_OK;
 }

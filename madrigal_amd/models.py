@@ -1022,33 +1022,47 @@ class TransformerFusion(nn.Module):
         continue after the attention (last layer: only the pooled key tokens are ever read again)."""
         sa = L.self_attn
 
-        def in_proj(a):
+        fused = os.environ.get("MDG_FUSED_PACK", "1") != "0"
+
+        def norm(x, ln, want_fp32=True):
+            """LayerNorm whose kernel also writes the output as the packed operand of the dense block that consumes it
+            (image None: fp32 mode / odd width / switched off -> the block packs its input itself).  ``want_fp32=False``:
+            the fp32 rows are skipped when the image exists (pre-norm: only linear1 reads norm2's output)."""
+            if not fused:
+                return ops.layernorm(x, ln.weight, ln.bias, ln.eps), None
+            return ops.layernorm_packed(x, ln.weight, ln.bias, ln.eps, _state["precision"], want_fp32)
+
+        def lin_of(x, img, w, b, rows=None, **kw):
+            return _lin(x, w, b, **kw) if img is None else ops.linear_packed(img, x.shape[0] if rows is None else rows, w, b,
+                                                                             precision=_state["precision"], **kw)
+
+        def in_proj(a, img=None):
             """q | k | v rows.  When only ``keep_rows`` continue past the attention, only THEIR queries are ever used (a query
             row decides its own output row and nothing else): keys and values for all rows, queries for the kept rows only --
             the other rows' query slots stay unwritten and so do the outputs computed from them, which are dropped."""
             w, b = sa.in_proj_weight.detach(), sa.in_proj_bias.detach()
             if keep_rows is None or os.environ.get("MDG_FUSION_Q_KEPT_ONLY", "1") == "0" or a.shape[0] < 4 * keep_rows.numel() // 3:
-                return _lin(a, w, b)
+                return lin_of(a, img, w, b)
             d = w.shape[1]
             qkv = torch.empty((a.shape[0], 3 * d), dtype=torch.float32, device=a.device)
-            _lin(a, w[d:], b[d:], out=qkv[:, d:])
+            lin_of(a, img, w[d:], b[d:], out=qkv[:, d:])
             qkv[:, :d].index_copy_(0, keep_rows, _lin(a.index_select(0, keep_rows), w[:d], b[:d]))
             return qkv
         if self.norm_first:
-            a = ops.layernorm(h, L.norm1.weight, L.norm1.bias, L.norm1.eps)
-            att = attend(in_proj(a), a)
+            a, a_img = norm(h, L.norm1)
+            att = attend(in_proj(a, a_img), a)
             if keep_rows is not None:
                 att, h = att.index_select(0, keep_rows), h.index_select(0, keep_rows)
             h = _lin(att, sa.out_proj.weight, sa.out_proj.bias, residual=h)
-            f = ops.layernorm(h, L.norm2.weight, L.norm2.bias, L.norm2.eps)
-            u = _lin(f, L.linear1.weight, L.linear1.bias, act=self.actn)
+            f, f_img = norm(h, L.norm2, want_fp32=False)
+            u = lin_of(f, f_img, L.linear1.weight, L.linear1.bias, rows=h.shape[0], act=self.actn)
             return _lin(u, L.linear2.weight, L.linear2.bias, residual=h)
         att = attend(in_proj(h), h)
         if keep_rows is not None:
             att, h = att.index_select(0, keep_rows), h.index_select(0, keep_rows)
         t = _lin(att, sa.out_proj.weight, sa.out_proj.bias, residual=h)
-        h = ops.layernorm(t, L.norm1.weight, L.norm1.bias, L.norm1.eps)
-        u = _lin(h, L.linear1.weight, L.linear1.bias, act=self.actn)
+        h, h_img = norm(t, L.norm1)
+        u = lin_of(h, h_img, L.linear1.weight, L.linear1.bias, act=self.actn)
         t = _lin(u, L.linear2.weight, L.linear2.bias, residual=h)
         return ops.layernorm(t, L.norm2.weight, L.norm2.bias, L.norm2.eps)
 

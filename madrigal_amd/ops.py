@@ -240,6 +240,51 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return out.view(*lead, N) if len(lead) != 1 or lead[0] != M else out
 
 
+def layernorm_packed(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float, precision, want_fp32: bool = True):
+    """LayerNorm of a 2-D ``x`` -> (y, image): ``image`` is y as the packed operand of the dense block that consumes it
+    (linear_packed), written by the same kernel; None where the arithmetic mode or the width takes no image (then the
+    consumer is the ordinary linear).  ``want_fp32=False``: y is None when the image exists (nothing else reads y)."""
+    forward_only(x, weight, bias)
+    x2 = x if (x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.is_cuda and x.dtype == torch.float32) else _rows2d(x, "x")[0]
+    R, d = x2.shape
+    prec = _prec(precision)
+    if prec == PREC_F32 or d % 32 or R == 0:
+        return layernorm(x2, weight, bias, eps), None
+    y = torch.empty((R, d), dtype=torch.float32, device=x2.device) if want_fp32 else None      # image only: y itself is never written
+    nbytes = int(lib().mdg_pack_operand_bytes(_c64(R), _c64(d), _c(prec)))
+    img = torch.empty(nbytes, dtype=torch.uint8, device=x2.device)
+    check(lib().mdg_layernorm_packed(_ptr(x2), _c64(x2.stride(0)), _ptr(weight.detach().contiguous()), _ptr(bias.detach().contiguous()), _ptr(y),
+                                     _c64(d), _c64(R), _c64(d), _f(eps), _c(prec), _ptr(img), ctypes.c_size_t(nbytes), _stream(x2)),
+          "mdg_layernorm_packed")
+    return y, img
+
+
+def linear_packed(x_img: torch.Tensor, M: int, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act=None,
+                  residual: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 1.0, precision="bf16x3",
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """linear() on an input that already exists as an operand image (layernorm_packed): no pre-pass over x."""
+    w = padded_weight(_f32_cuda(weight, "weight", 2))
+    N, K = w.shape
+    if act not in ACTS:
+        raise ValueError(f"unknown activation {act!r}")
+    prec = _prec(precision)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x_img.device)
+    elif out.dim() != 2 or out.shape != (M, N) or out.stride(1) != 1 or out.dtype != torch.float32 or not out.is_cuda:
+        raise ValueError(f"out: expected fp32 cuda [{M},{N}] with unit inner stride")
+    ldr = 0
+    if residual is not None:
+        if residual.numel() != N:
+            if residual.dim() != 2 or residual.shape != (M, N) or residual.stride(1) != 1:
+                raise ValueError(f"residual: expected [{M},{N}] or [{N}]")
+            ldr = residual.stride(0)
+    wimg = packed_weight_image(w, prec)
+    check(lib().mdg_linear_packed_x(_ptr(x_img), _c64(M), _c64(K), _ptr(w), _c64(w.stride(0)), _ptr(wimg), _ptr(out), _c64(out.stride(0)), _c64(N),
+                                    _ptr(None if bias is None else bias.detach().contiguous()), _c(ACTS[act]), _ptr(residual), _c64(ldr),
+                                    _f(alpha), _f(beta), _c(prec), _ptr(None), ctypes.c_size_t(0), _stream(x_img)), "mdg_linear_packed_x")
+    return out
+
+
 def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Row-wise LayerNorm over the last dim; ``x`` / ``out`` may be strided 2-D views (row stride % 4 == 0)."""

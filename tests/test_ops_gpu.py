@@ -125,6 +125,29 @@ def test_grouped_linear_equals_one_launch_per_group(ops, prec):
         assert torch.equal(y2[g["m_base"]: g["m_base"] + g["rows"]], want)
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16", "f32"])
+def test_layernorm_emits_the_operand_image_of_the_next_dense_block(ops, prec):
+    """layernorm_packed + linear_packed == layernorm + linear bit for bit (the image is what linear's own pre-pass writes);
+    the fp32 rows can be skipped; fp32 mode / widths that are no multiple of 32 fall back to no image."""
+    x = _rand((333, 256), 80).cuda()
+    g, b = _rand((256,), 81).cuda(), _rand((256,), 82).cuda()
+    w, bias = _rand((192, 256), 83, 0.1).cuda(), _rand((192,), 84).cuda()
+    y_ref = ops.layernorm(x, g, b, 1e-5)
+    want = ops.linear(y_ref, w, bias, act="gelu", precision=prec)
+    y, img = ops.layernorm_packed(x, g, b, 1e-5, prec)
+    assert torch.equal(y, y_ref)
+    if prec == "f32":
+        assert img is None
+        return
+    assert torch.equal(ops.linear_packed(img, 333, w, bias, act="gelu", precision=prec), want)
+    y2, img2 = ops.layernorm_packed(x, g, b, 1e-5, prec, want_fp32=False)
+    assert y2 is None and torch.equal(img2, img)
+    wide = torch.zeros(333, 400, device="cuda")
+    ops.linear_packed(img, 333, w, bias, act="gelu", precision=prec, out=wide[:, 8:200])
+    assert torch.equal(wide[:, 8:200], want) and float(wide[:, 200:].abs().max()) == 0.0
+    assert ops.layernorm_packed(x[:, :100].contiguous(), g[:100].contiguous(), b[:100].contiguous(), 1e-5, prec)[1] is None
+
+
 def test_linear_errors(ops):
     x, w = torch.zeros(4, 8, device="cuda"), torch.zeros(3, 12, device="cuda")
     with pytest.raises(ValueError):
