@@ -1131,13 +1131,24 @@ class TransformerFusion(nn.Module):
         """Cross-attention pooling over the (already selected) key tokens h_keys [n*Tk, d] (models.py:422-443)."""
         d, H, dh = self.latent_dim, self.num_heads, self.head_dim
         mha = self.x_attn_mha_layer
-        kvn = ops.layernorm(h_keys, self.x_attn_kv_norm.weight, self.x_attn_kv_norm.bias, self.x_attn_kv_norm.eps)
         w, b = mha.in_proj_weight.detach(), mha.in_proj_bias.detach()
-        kvp = _lin(kvn, w[d:], b[d:])                              # [n*Tk, 2d] = K|V
-        q = self.x_attn_query.detach()
-        if self.norm_first:
-            q = ops.layernorm(q, self.x_attn_query_norm.weight, self.x_attn_query_norm.bias, self.x_attn_query_norm.eps)
-        qp = _lin(q, w[:d], b[:d])
+        ln = self.x_attn_kv_norm
+        img = None
+        if os.environ.get("MDG_FUSED_PACK", "1") != "0":           # the norm writes the K|V projection's packed operand itself
+            _, img = ops.layernorm_packed(h_keys, ln.weight, ln.bias, ln.eps, _state["precision"], want_fp32=False)
+        if img is not None:
+            kvp = ops.linear_packed(img, h_keys.shape[0], w[d:], b[d:], precision=_state["precision"])
+        else:
+            kvp = _lin(ops.layernorm(h_keys, ln.weight, ln.bias, ln.eps), w[d:], b[d:])                 # [n*Tk, 2d] = K|V
+        # the projected query depends on parameters only: computed once per parameter version (a 1-row product through the
+        # tile kernel costs ~70 us of launch + operand packing per step otherwise)
+        def build_q():
+            q_ = self.x_attn_query.detach()
+            if self.norm_first:
+                q_ = ops.layernorm(q_, self.x_attn_query_norm.weight, self.x_attn_query_norm.bias, self.x_attn_query_norm.eps)
+            return q_, _lin(q_, w[:d], b[:d])
+        q, qp = _cached(self, ("x_attn_q", _state["precision"]),
+                        [self.x_attn_query, self.x_attn_query_norm.weight, self.x_attn_query_norm.bias, mha.in_proj_weight, mha.in_proj_bias], build_q)
         pooled = ops.xattn_pool(qp, kvp, n, Tk, H, dh)
         o = _lin(pooled, mha.out_proj.weight, mha.out_proj.bias, residual=q.reshape(-1))        # + query (broadcast)
         if not self.norm_first:
