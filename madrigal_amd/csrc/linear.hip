@@ -14,6 +14,7 @@
 // Arithmetic modes as in the head: exact fp32 MFMA, bf16x3 (fp32-grade), bf16.
 #include "mdg_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -70,7 +71,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_unifor
 // One operand tile (ROWS rows x 32 k) of stage k0 into LDS.  `base` is the operand image (fp32 [rows,ld] or one
 // bf16 hi/lo image [rows,ld]); rows past the end clamp to the last row (their results are never stored).
 template <int ESIZE, int ROWS, int WAVES, int MF = 32>   // ESIZE 4 = fp32 tile (8 rows per 1-KiB piece), 2 = bf16 tile (16 rows per piece)
-__device__ __forceinline__ void dma_tile(const char* base, int64_t ld_bytes, int64_t row0, int64_t nrows, int64_t k0, char* lds,
+__device__ __forceinline__ void dma_tile(const char* base, int64_t ld_bytes, int kb, int64_t row0, int64_t nrows, int64_t k0, char* lds,
                                          int wave, int lane) {
   constexpr int PIECES = ROWS * BK * ESIZE / 1024;
   static_assert(PIECES % WAVES == 0, "pieces must divide evenly over the waves");
@@ -86,11 +87,16 @@ __device__ __forceinline__ void dma_tile(const char* base, int64_t ld_bytes, int
   }
 }
 
-struct Operand {          // fp32: p0 = image; bf16 modes: p0 = hi image, p1 = lo image
+// Operand images.  fp32: the tensor itself (or a zero-padded copy), row = Kp * 4 bytes.  bf16: [rows][Kp] bf16, Kp a multiple of 64.
+// bf16x3: ONE image, per row and per block of 32 k: 64 B of hi values then 64 B of lo values (row = Kp * 4 bytes), so that a
+// k tile of a row is one 128-byte line in both 16-bit modes; p1 = p0 + 64 addresses the lo halves.  kb = bytes a row advances
+// per k (2 / 4 / 4).
+struct Operand {
   const char* p0;
   const char* p1;
   int64_t ld_bytes;
   int64_t nrows;
+  int kb;
 };
 
 // LDS layout of one stage.  fp32 / bf16x3: [A tile (fp32, or bf16 hi + lo) | B tile], S::STAGE bytes, two stages.  Single-product
@@ -106,16 +112,16 @@ template <int MODE, class S, int MF = 32, int PART = -1>
 __device__ __forceinline__ void dma_stage(const Operand& A, const Operand& B, int64_t row0, int64_t col0, int64_t k0, char* lds,
                                           int wave, int lane) {
   if constexpr (MODE == MDG_PREC_F32) {
-    if constexpr (PART != 1) dma_tile<4, S::BM, S::WAVES>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane);
-    if constexpr (PART != 0) dma_tile<4, S::BN, S::WAVES>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES, wave, lane);
+    if constexpr (PART != 1) dma_tile<4, S::BM, S::WAVES>(A.p0, A.ld_bytes, 4, row0, A.nrows, k0, lds, wave, lane);
+    if constexpr (PART != 0) dma_tile<4, S::BN, S::WAVES>(B.p0, B.ld_bytes, 4, col0, B.nrows, k0, lds + S::A_BYTES, wave, lane);
   } else {
     if constexpr (PART != 1) {
-      dma_tile<2, S::BM, S::WAVES, MF>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane);
-      if constexpr (MODE == MDG_PREC_BF16X3) dma_tile<2, S::BM, S::WAVES, MF>(A.p1, A.ld_bytes, row0, A.nrows, k0, lds + S::A_LO, wave, lane);
+      dma_tile<2, S::BM, S::WAVES, MF>(A.p0, A.ld_bytes, A.kb, row0, A.nrows, k0, lds, wave, lane);
+      if constexpr (MODE == MDG_PREC_BF16X3) dma_tile<2, S::BM, S::WAVES, MF>(A.p1, A.ld_bytes, A.kb, row0, A.nrows, k0, lds + S::A_LO, wave, lane);
     }
     if constexpr (PART != 0) {
-      dma_tile<2, S::BN, S::WAVES, MF>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + kBOffset<MODE, S>, wave, lane);
-      if constexpr (MODE == MDG_PREC_BF16X3) dma_tile<2, S::BN, S::WAVES, MF>(B.p1, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES + S::B_LO, wave, lane);
+      dma_tile<2, S::BN, S::WAVES, MF>(B.p0, B.ld_bytes, B.kb, col0, B.nrows, k0, lds + kBOffset<MODE, S>, wave, lane);
+      if constexpr (MODE == MDG_PREC_BF16X3) dma_tile<2, S::BN, S::WAVES, MF>(B.p1, B.ld_bytes, B.kb, col0, B.nrows, k0, lds + S::A_BYTES + S::B_LO, wave, lane);
     }
   }
 }
@@ -124,7 +130,7 @@ __device__ __forceinline__ void dma_stage(const Operand& A, const Operand& B, in
 // is spread over the MFMA groups of the current one (slot = A-fragment group), one piece per slot, instead of arriving at the
 // memory system as one burst from every CU at the same moment (measured on the 2048-deep blocks: -4..-7 % time).
 template <int ROWS, int WAVES, int MF>
-__device__ __forceinline__ void dma_piece(const char* base, int64_t ld_bytes, int64_t row0, int64_t nrows, int64_t k0, char* lds,
+__device__ __forceinline__ void dma_piece(const char* base, int64_t ld_bytes, int kb, int64_t row0, int64_t nrows, int64_t k0, char* lds,
                                           int wave, int lane, int i) {
   static_assert(ROWS * BK * 2 / 1024 / WAVES == 2, "two pieces per wave and tile plane");
   const int p = wave + WAVES * i;
@@ -132,7 +138,7 @@ __device__ __forceinline__ void dma_piece(const char* base, int64_t ld_bytes, in
   const int c = (lane & 3) ^ (MF == 16 ? ((row >> 1) & 3) : ((row >> 2) & 3));
   int64_t gr = row0 + row;
   gr = gr < nrows ? gr : nrows - 1;
-  glds16(base + gr * ld_bytes + k0 * 2 + c * 16, lds_addr(lds + p * 1024));
+  glds16(base + gr * ld_bytes + k0 * kb + c * 16, lds_addr(lds + p * 1024));
 }
 
 template <int MODE, class S, int MF>
@@ -147,10 +153,10 @@ __device__ __forceinline__ void dma_slot(const Operand& A, const Operand& B, int
     i = (slot >> 1) & 1;
   }
   switch (plane) {
-    case 0: dma_piece<S::BM, S::WAVES, MF>(A.p0, A.ld_bytes, row0, A.nrows, k0, lds, wave, lane, i); break;
-    case 1: dma_piece<S::BM, S::WAVES, MF>(A.p1, A.ld_bytes, row0, A.nrows, k0, lds + S::A_LO, wave, lane, i); break;
-    case 2: dma_piece<S::BN, S::WAVES, MF>(B.p0, B.ld_bytes, col0, B.nrows, k0, lds + kBOffset<MODE, S>, wave, lane, i); break;
-    default: dma_piece<S::BN, S::WAVES, MF>(B.p1, B.ld_bytes, col0, B.nrows, k0, lds + S::A_BYTES + S::B_LO, wave, lane, i); break;
+    case 0: dma_piece<S::BM, S::WAVES, MF>(A.p0, A.ld_bytes, A.kb, row0, A.nrows, k0, lds, wave, lane, i); break;
+    case 1: dma_piece<S::BM, S::WAVES, MF>(A.p1, A.ld_bytes, A.kb, row0, A.nrows, k0, lds + S::A_LO, wave, lane, i); break;
+    case 2: dma_piece<S::BN, S::WAVES, MF>(B.p0, B.ld_bytes, B.kb, col0, B.nrows, k0, lds + kBOffset<MODE, S>, wave, lane, i); break;
+    default: dma_piece<S::BN, S::WAVES, MF>(B.p1, B.ld_bytes, B.kb, col0, B.nrows, k0, lds + S::A_BYTES + S::B_LO, wave, lane, i); break;
   }
 }
 
@@ -487,13 +493,213 @@ __global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs 
   }
 }
 
+// ---- 256 x 256 "ping-pong" dense block (16-bit modes) -----------------------------------------------------------------------
+// The large blocks of the path (fusion transformer at d = 2048, chemCPA / cv first layers over 65k rows).  One 8-wave workgroup
+// per CU, waves as 2 (M) x 4 (N), each wave a 128 x 64 patch = 8 x 4 accumulator tiles of the 16x16x32 MFMA (128 VGPRs).
+//
+// LDS: two stages of four 16-KB HALF-TILES, each 128 rows x 128 B: A0 | B0 | B1 | A1.  A row holds one k tile of an image row:
+// bf16: 64 k; bf16x3: 32 k as 64 B hi | 64 B lo (the image interleaves them, so both modes stage identical bytes and differ
+// only in the MFMA sequence: 2 products over k 0..31, 32..63 against lo.hi + hi.lo + hi.hi).  Half mh of A holds rows
+// 128 wr + 64 mh + (0..63) of the tile for wr = 0, 1 (so every wave reads every half: rows 64 wr .. of it), half nh of B the
+// columns 64 wc + 32 nh + (0..31): a wave's patch is contiguous, and quadrant (mh, nh) of it needs exactly A[mh] and B[nh].
+// 16-byte chunk j of LDS row r sits at chunk j ^ ((r >> 1) & 7): the 16 lanes of every ds_read_b128 lane group then cover all
+// 64 banks (checked exhaustively against the guide's lane grouping, scripts/lds_swizzle_check.py); the LDS-DMA writes rows
+// linearly, so the XOR is applied to each lane's SOURCE chunk.
+//
+// Schedule per k tile t (stage t & 1), four phases, one quadrant of MFMAs each (16 / 24 instructions):
+//   P1  read B0, A0 -> (0,0)     issues B1[t+1]          P3  read A1 -> (1,1)     issues A0[t+2]
+//   P2  read B1     -> (0,1)     issues A1[t+1]          P4  (b0 kept) -> (1,0)   issues B0[t+2], waits vmcnt(4)
+// Each phase is  { fragment reads, LDS-DMA issue } s_barrier { MFMAs } s_barrier.  Waves 4-7 run ONE barrier behind waves 0-3
+// (an extra barrier in front, one fewer behind): a SIMD hosts one wave of each half, so while one feeds the matrix pipe the
+// other issues its LDS reads and DMA, and the pipe sees back-to-back MFMA clusters.
+// Hazards.  A half-tile is refilled two phases (four barriers) after the phase that read it, so every wave's reads have been
+// waited for (the MFMAs of the reading phase consumed them) two barriers before the first refill is issued.  Every wave issues
+// exactly two LDS-DMA pieces per half-tile, in order H(g + 6) at phase g; P4's counted wait (after its own issue) leaves the
+// youngest two half-tiles (A0, B0 of tile t+2) in flight and retires all of tile t+1; both wave halves have passed that wait
+// before the barrier that opens tile t+1's first read (the late half waits one barrier later and reads one barrier later).
+namespace pp {
+constexpr int HT = 16384, STAGE = 4 * HT, LDS_BYTES = 2 * STAGE;
+constexpr int OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT;
+constexpr int BM = 256, BN = 256, THREADS = 512;
+
+// LDS-DMA with the global address as SGPR base + 32-bit lane offset: one VGPR per piece instead of two
+__device__ __forceinline__ void glds16_so(const char* sbase, unsigned voff, unsigned lds_dst_uniform) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst_uniform);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(dst)
+               : "memory");
+}
+}  // namespace pp
+
+template <int MODE, bool GROUPED = false>
+__global__ __launch_bounds__(pp::THREADS, 2) void linear_pp_kernel(const LinearArgs pk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A0 | B0 | B1 | A1]; reused as [wave][64][64] fp32 by the epilogue
+  static_assert(MODE == MDG_PREC_BF16 || MODE == MDG_PREC_BF16X3, "16-bit operand modes");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  LinearArgs p = pk;
+  int tx, ty;
+  if (!tile_of(p, tx, ty)) return;                            // workgroup-uniform
+  const int64_t col0 = static_cast<int64_t>(tx) * pp::BN, row0 = static_cast<int64_t>(ty) * pp::BM;
+  const int nk = static_cast<int>(MODE == MDG_PREC_BF16 ? p.K / 64 : p.K / 32);
+
+  // ---- LDS-DMA sources: piece i of this wave covers LDS rows 8 (2 wave + i) .. + 7 of a half-tile; lane -> (row, chunk) ----
+  // offsets are relative to the tile's first image row (32 bits: 256 rows x a row of at most a few hundred KB)
+  unsigned off_a[2][2], off_b[2][2];                          // [half][piece]
+  const int64_t a_rows = p.A.nrows - row0, b_rows = p.B.nrows - col0;   // rows of the image at / below the tile origin (>= 1)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = 8 * (2 * wave + i) + (lane >> 3);
+    const unsigned chunk = static_cast<unsigned>((lane & 7) ^ ((r >> 1) & 7)) << 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int64_t ta = 128 * (r >> 6) + 64 * h + (r & 63), tb = 64 * (r >> 5) + 32 * h + (r & 31);
+      ta = ta < a_rows ? ta : a_rows - 1;                     // rows past the end re-read the last row (never stored)
+      tb = tb < b_rows ? tb : b_rows - 1;
+      off_a[h][i] = static_cast<unsigned>(ta * p.A.ld_bytes) + chunk;
+      off_b[h][i] = static_cast<unsigned>(tb * p.B.ld_bytes) + chunk;
+    }
+  }
+  const char* const a_base = p.A.p0 + row0 * p.A.ld_bytes;
+  const char* const b_base = p.B.p0 + col0 * p.B.ld_bytes;
+  const unsigned lds0 = lds_addr(smem) + static_cast<unsigned>(wave) * 2048u;
+  // half-tile q (0 A0, 1 B0, 2 B1, 3 A1) of k tile kt
+  auto dma = [&](auto qc, int kt) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int off = q == 0 ? pp::OFF_A0 : q == 1 ? pp::OFF_B0 : q == 2 ? pp::OFF_B1 : pp::OFF_A1;
+    const char* sb = ((q == 0 || q == 3) ? a_base : b_base) + static_cast<int64_t>(kt) * 128;
+    const unsigned dst = lds0 + static_cast<unsigned>((kt & 1) * pp::STAGE + off);
+    const unsigned o0 = q == 0 ? off_a[0][0] : q == 3 ? off_a[1][0] : q == 1 ? off_b[0][0] : off_b[1][0];
+    const unsigned o1 = q == 0 ? off_a[0][1] : q == 3 ? off_a[1][1] : q == 1 ? off_b[0][1] : off_b[1][1];
+    pp::glds16_so(sb, o0, dst);
+    pp::glds16_so(sb, o1, dst + 1024u);
+  };
+  using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
+  using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
+
+  // ---- fragment addresses: lane (c = row / column in a 16-wide tile, g = 16-byte k chunk) ----
+  const int c = lane & 15, g = lane >> 4, x = (c >> 1) & 7;
+  const int fo0 = c * 128 + ((g ^ x) << 4), fo1 = c * 128 + (((4 + g) ^ x) << 4);       // chunk g / 4 + g of row c, swizzled
+  const char* const fa = smem + (64 * wr) * 128;              // + OFF_A{mh} + mt * 2048
+  const char* const fb = smem + (32 * wc) * 128;              // + OFF_B{nh} + nt * 2048
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2], b0f[2][2], b1f[2][2];                      // [tile][k chunk group: bf16 k 0..31 / 32..63, bf16x3 hi / lo]
+
+  auto read_a = [&](const char* st, int off) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      af[mt][0] = *reinterpret_cast<const bf16x8*>(st + off + (fa - smem) + mt * 2048 + fo0);
+      af[mt][1] = *reinterpret_cast<const bf16x8*>(st + off + (fa - smem) + mt * 2048 + fo1);
+    }
+  };
+  auto read_b = [&](const char* st, int off, bf16x8 (&bf)[2][2]) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      bf[nt][0] = *reinterpret_cast<const bf16x8*>(st + off + (fb - smem) + nt * 2048 + fo0);
+      bf[nt][1] = *reinterpret_cast<const bf16x8*>(st + off + (fb - smem) + nt * 2048 + fo1);
+    }
+  };
+  auto quadrant = [&](auto mhc, auto nhc, const bf16x8 (&bf)[2][2]) {
+    constexpr int mh = decltype(mhc)::value, nh = decltype(nhc)::value;
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (MODE == MDG_PREC_BF16) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[4 * mh + mt][2 * nh + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][ks], bf[nt][ks], acc[4 * mh + mt][2 * nh + nt], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int pr = 0; pr < 3; ++pr)                          // lo.hi, hi.lo, hi.hi: per element the order of the 128-tile kernel
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[4 * mh + mt][2 * nh + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][pr == 0 ? 1 : 0], bf[nt][pr == 1 ? 1 : 0],
+                                                                                    acc[4 * mh + mt][2 * nh + nt], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+
+  // ---- prologue: all of tile 0, A0 / B0 of tile 1 ----
+  dma(Q0{}, 0); dma(Q1{}, 0); dma(Q2{}, 0); dma(Q3{}, 0);
+  if (nk > 1) { dma(Q0{}, 1); dma(Q1{}, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();                  // the late half runs one barrier behind
+
+  for (int t = 0; t < nk; ++t) {
+    const char* const st = smem + (t & 1) * pp::STAGE;
+    // P1
+    read_b(st, pp::OFF_B0, b0f);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(st, pp::OFF_A0);
+    if (t + 1 < nk) dma(Q2{}, t + 1);
+    __builtin_amdgcn_s_barrier();
+    quadrant(I0{}, I0{}, b0f);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // P2
+    read_b(st, pp::OFF_B1, b1f);
+    if (t + 1 < nk) dma(Q3{}, t + 1);
+    __builtin_amdgcn_s_barrier();
+    quadrant(I0{}, I1{}, b1f);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // P3
+    read_a(st, pp::OFF_A1);
+    if (t + 2 < nk) dma(Q0{}, t + 2);
+    __builtin_amdgcn_s_barrier();
+    quadrant(I1{}, I1{}, b1f);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // P4
+    if (t + 2 < nk) { dma(Q1{}, t + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    quadrant(I1{}, I0{}, b0f);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: as the 128-tile kernel (64 x 64 patches through 16 KB of LDS per wave, row-major 16-byte stores) ----
+  __syncthreads();
+  float* const slab = reinterpret_cast<float*>(smem) + wave * 4096;
+  const int64_t pm0 = row0 + wr * 128, pn0 = col0 + wc * 64;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) slab[slab_off(mt * 16 + 4 * g + v, nt * 16 + c)] = acc[pass * 4 + mt][nt][v];
+    slab_to_global(p, slab, pm0 + pass * 64, pn0, lane);
+  }
+}
+
 // ---- pre-pass: both operands -> K padded to a multiple of 32 (zeros), split hi/lo bf16 or copied as fp32 ------
-// grid.y = 0: x rows, 1: w rows.  One thread per 4 consecutive k.
+// grid.y = 0: x rows, 1: w rows.  One thread per 4 consecutive k.  (16-bit images pad K to a multiple of 64.)
+// byte offset of the hi value of (row, k) in a bf16x3 image: per row and block of 32 k, 64 B of hi values then 64 B of lo values
+__host__ __device__ __forceinline__ int64_t img_off_x3(int64_t row, int64_t k, int64_t Kp) { return row * Kp * 4 + (k >> 5) * 128 + (k & 31) * 2; }
+
 struct PrepArgs {
   const float* src[2]; int64_t ld[2]; int64_t rows[2];
-  char* dst0[2]; char* dst1[2];       // fp32 copy / bf16 hi ; bf16 lo (or null)
+  char* dst0[2];                      // fp32 copy / bf16 image / bf16x3 image (hi | lo interleaved per 32 k)
   int64_t K, Kp;
-  int bf16;
+  int bf16, x3;
 };
 
 __global__ __launch_bounds__(256) void prep_operands_kernel(const PrepArgs p) {
@@ -513,8 +719,13 @@ __global__ __launch_bounds__(256) void prep_operands_kernel(const PrepArgs p) {
       hi[e] = a;
       lo[e] = b;
     }
-    *reinterpret_cast<bf16x4*>(p.dst0[which] + (row * p.Kp + k) * 2) = hi;
-    if (p.dst1[which]) *reinterpret_cast<bf16x4*>(p.dst1[which] + (row * p.Kp + k) * 2) = lo;
+    if (p.x3) {
+      char* d = p.dst0[which] + img_off_x3(row, k, p.Kp);
+      *reinterpret_cast<bf16x4*>(d) = hi;
+      *reinterpret_cast<bf16x4*>(d + 64) = lo;
+    } else {
+      *reinterpret_cast<bf16x4*>(p.dst0[which] + (row * p.Kp + k) * 2) = hi;
+    }
   } else {
     *reinterpret_cast<f32x4*>(p.dst0[which] + (row * p.Kp + k) * 4) = v;
   }
@@ -525,9 +736,9 @@ __global__ __launch_bounds__(256) void prep_operands_kernel(const PrepArgs p) {
 // reads run along the source rows, image writes along the image rows (8 bytes per lane, bf16).  grid = (Mp/64 tiles, C tiles, operands).
 struct PrepTArgs {
   const float* src[2]; int64_t ld[2]; int64_t C[2];
-  char* dst0[2]; char* dst1[2];
+  char* dst0[2];
   int64_t M, Mp;
-  int bf16;
+  int bf16, x3;
 };
 
 __global__ __launch_bounds__(256) void prep_transposed_kernel(const PrepTArgs p) {
@@ -561,8 +772,13 @@ __global__ __launch_bounds__(256) void prep_transposed_kernel(const PrepTArgs p)
         hi[e] = a;
         lo[e] = b;
       }
-      *reinterpret_cast<bf16x4*>(p.dst0[which] + off * 2) = hi;
-      if (p.dst1[which]) *reinterpret_cast<bf16x4*>(p.dst1[which] + off * 2) = lo;
+      if (p.x3) {
+        char* d = p.dst0[which] + img_off_x3(c, m0 + mq, p.Mp);
+        *reinterpret_cast<bf16x4*>(d) = hi;
+        *reinterpret_cast<bf16x4*>(d + 64) = lo;
+      } else {
+        *reinterpret_cast<bf16x4*>(p.dst0[which] + off * 2) = hi;
+      }
     } else {
       *reinterpret_cast<f32x4*>(p.dst0[which] + off * 4) = v;
     }
@@ -577,7 +793,7 @@ inline int64_t pad32(int64_t k) { return (k + 31) / 32 * 32; }
 template <int VEC>   // floats per lane = 4*VEC, d <= 256*VEC
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ g,
                                                         const float* __restrict__ b, float* __restrict__ y, int64_t ldy,
-                                                        int64_t rows, int d, float eps, char* __restrict__ img_hi, char* __restrict__ img_lo) {
+                                                        int64_t rows, int d, float eps, char* __restrict__ img_hi, int img_x3) {
   const int lane = threadIdx.x & 63;
   const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -623,8 +839,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
           hi[e] = a_;
           lo[e] = b_;
         }
-        *reinterpret_cast<bf16x4*>(img_hi + (row * d + c) * 2) = hi;
-        if (img_lo) *reinterpret_cast<bf16x4*>(img_lo + (row * d + c) * 2) = lo;
+        if (img_x3) {
+          char* o_ = img_hi + img_off_x3(row, c, d);
+          *reinterpret_cast<bf16x4*>(o_) = hi;
+          *reinterpret_cast<bf16x4*>(o_ + 64) = lo;
+        } else {
+          *reinterpret_cast<bf16x4*>(img_hi + (row * d + c) * 2) = hi;
+        }
       }
     }
   }
@@ -632,36 +853,38 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 }  // namespace
 
+// inner length of an operand image: fp32 pads K to 32, the 16-bit images to 64 (the 256-tile kernel's bf16 k tile)
+static int64_t pad_k(int64_t K, int precision) { return precision == MDG_PREC_F32 ? pad32(K) : pad64(K); }
+
 static size_t image_bytes(int64_t rows, int64_t K, int precision) {
   if (rows <= 0 || K <= 0) return 0;
-  const size_t Kp = static_cast<size_t>(pad32(K));
+  const size_t Kp = static_cast<size_t>(pad_k(K, precision));
   if (precision == MDG_PREC_F32) return (K % 32 == 0) ? 0 : al256(static_cast<size_t>(rows) * Kp * 4);
-  return (precision == MDG_PREC_BF16X3 ? 2 : 1) * al256(static_cast<size_t>(rows) * Kp * 2);
+  return al256(static_cast<size_t>(rows) * Kp * (precision == MDG_PREC_BF16X3 ? 4 : 2));
 }
 
 static void launch_prep(const float* s0, int64_t ld0, int64_t rows0, char* dst0, const float* s1, int64_t ld1, int64_t rows1,
                         char* dst1, int64_t K, int precision, hipStream_t st) {
-  const int64_t Kp = pad32(K);
-  const bool bf = precision != MDG_PREC_F32, x3 = precision == MDG_PREC_BF16X3;
-  const size_t es = bf ? 2 : 4;
+  const int64_t Kp = pad_k(K, precision);
   PrepArgs pa{};
   pa.src[0] = s0; pa.ld[0] = ld0; pa.rows[0] = rows0; pa.dst0[0] = dst0;
-  pa.dst1[0] = (x3 && dst0) ? dst0 + al256(static_cast<size_t>(rows0) * Kp * es) : nullptr;
   pa.src[1] = s1; pa.ld[1] = ld1; pa.rows[1] = s1 ? rows1 : 0; pa.dst0[1] = dst1;
-  pa.dst1[1] = (x3 && dst1) ? dst1 + al256(static_cast<size_t>(rows1) * Kp * es) : nullptr;
-  pa.K = K; pa.Kp = Kp; pa.bf16 = bf ? 1 : 0;
+  pa.K = K; pa.Kp = Kp; pa.bf16 = precision != MDG_PREC_F32 ? 1 : 0; pa.x3 = precision == MDG_PREC_BF16X3 ? 1 : 0;
   const int64_t groups = (rows0 > pa.rows[1] ? rows0 : pa.rows[1]) * (Kp / 4);
   hipLaunchKernelGGL(prep_operands_kernel, dim3(static_cast<unsigned>(mdg_cdiv(groups, 256)), s1 ? 2 : 1), dim3(256), 0, st, pa);
 }
 
-static void set_operand(Operand& o, const float* raw, int64_t ld, const char* image, int64_t rows, int64_t K, int precision) {
-  const int64_t Kp = pad32(K);
+static void set_image(Operand& o, const char* image, int64_t rows, int64_t Kp, int precision) {
   o.nrows = rows;
-  if (!image) { o.p0 = reinterpret_cast<const char*>(raw); o.p1 = nullptr; o.ld_bytes = ld * 4; return; }
-  const size_t es = precision == MDG_PREC_F32 ? 4 : 2;
   o.p0 = image;
-  o.p1 = precision == MDG_PREC_BF16X3 ? image + al256(static_cast<size_t>(rows) * Kp * es) : nullptr;
-  o.ld_bytes = Kp * static_cast<int64_t>(es);
+  o.kb = precision == MDG_PREC_BF16 ? 2 : 4;
+  o.p1 = precision == MDG_PREC_BF16X3 ? image + 64 : nullptr;
+  o.ld_bytes = Kp * static_cast<int64_t>(o.kb);
+}
+
+static void set_operand(Operand& o, const float* raw, int64_t ld, const char* image, int64_t rows, int64_t K, int precision) {
+  if (!image) { o.nrows = rows; o.p0 = reinterpret_cast<const char*>(raw); o.p1 = nullptr; o.ld_bytes = ld * 4; o.kb = 4; return; }
+  set_image(o, image, rows, pad_k(K, precision), precision);
 }
 
 static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t N, hipStream_t st) {
@@ -669,7 +892,7 @@ static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t 
   a.vec_r = a.res && mdg_aligned16(a.res) && a.ldr % 4 == 0;
   // tile shape: the 256x256 / 8-wave shape once the problem fills the chip with it, else 128x128 / 4 waves
   // (measured on the fusion GEMMs: bf16x3 -9 % time with the big tile, fp32 +6 %: the fp32 MFMA wants two workgroups per CU)
-  bool big = (precision != MDG_PREC_F32 && N >= 256 && M >= 1024 && mdg_cdiv(M, Big::BM) * mdg_cdiv(N, Big::BN) >= 192);
+  bool big = (precision != MDG_PREC_F32 && N >= 256 && M >= 1024 && mdg_cdiv(M, pp::BM) * mdg_cdiv(N, pp::BN) >= 192);
   if (const char* e = getenv("MDG_LINEAR_TILE")) big = atoi(e) == 256 ? true : (atoi(e) == 128 ? false : big);
   // 1-D grid; the kernel maps the linear workgroup id to a tile (XCD-aware order once there are enough tiles to matter)
   static const int swz_env = getenv("MDG_LINEAR_SWIZZLE") ? atoi(getenv("MDG_LINEAR_SWIZZLE")) : -1;
@@ -680,24 +903,25 @@ static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t 
     a.swizzle = swz_env >= 0 ? swz_env : (total >= 64 ? 1 : 0);
     return dim3(static_cast<unsigned>(a.swizzle ? 8 * ((total + 7) / 8) : total));
   };
-  // 16-bit modes run on the 16x16x32 MFMA unless MDG_LINEAR_MFMA=32 asks for the 32x32x16 form
+  // 16-bit modes run on the 16x16x32 MFMA unless MDG_LINEAR_MFMA=32 asks for the 32x32x16 form (128-tile kernel only)
   static const bool m16 = !(getenv("MDG_LINEAR_MFMA") && atoi(getenv("MDG_LINEAR_MFMA")) == 32);
-#define MDG_LAUNCH_LINEAR(S)                                                                                                       \
-  do {                                                                                                                             \
-    const dim3 grid = grid_for(S::BM, S::BN);                                                                                      \
-    const size_t lds = 2 * S::STAGE;                                                                                               \
-    if (precision == MDG_PREC_F32) hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, S, 32>), grid, dim3(S::THREADS), lds, st, a);  \
-    else if (precision == MDG_PREC_BF16X3) {                                                                                       \
-      if (m16) hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, S, 16>), grid, dim3(S::THREADS), lds, st, a);                    \
-      else hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, S, 32>), grid, dim3(S::THREADS), lds, st, a);                        \
-    } else {                                                                                                                       \
-      if (m16) hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, S, 16>), grid, dim3(S::THREADS), lds, st, a);                      \
-      else hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, S, 32>), grid, dim3(S::THREADS), lds, st, a);                          \
-    }                                                                                                                              \
-  } while (0)
-  if (big) MDG_LAUNCH_LINEAR(Big);
-  else MDG_LAUNCH_LINEAR(Small);
-#undef MDG_LAUNCH_LINEAR
+  if (big) {
+    const dim3 grid = grid_for(pp::BM, pp::BN);
+    if (precision == MDG_PREC_BF16X3) hipLaunchKernelGGL((linear_pp_kernel<MDG_PREC_BF16X3>), grid, dim3(pp::THREADS), pp::LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((linear_pp_kernel<MDG_PREC_BF16>), grid, dim3(pp::THREADS), pp::LDS_BYTES, st, a);
+    return;
+  }
+  using S = Small;
+  const dim3 grid = grid_for(S::BM, S::BN);
+  const size_t lds = 2 * S::STAGE;
+  if (precision == MDG_PREC_F32) hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, S, 32>), grid, dim3(S::THREADS), lds, st, a);
+  else if (precision == MDG_PREC_BF16X3) {
+    if (m16) hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, S, 16>), grid, dim3(S::THREADS), lds, st, a);
+    else hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, S, 32>), grid, dim3(S::THREADS), lds, st, a);
+  } else {
+    if (m16) hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, S, 16>), grid, dim3(S::THREADS), lds, st, a);
+    else hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, S, 32>), grid, dim3(S::THREADS), lds, st, a);
+  }
 }
 
 extern "C" size_t mdg_pack_operand_bytes(int64_t rows, int64_t K, int precision) { return image_bytes(rows, K, precision); }
@@ -756,7 +980,7 @@ extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t l
   }
   LinearArgs a{};
   a.y = y; a.ldy = ldy; a.bias = bias; a.scale = scale; a.shift = shift; a.res = residual; a.ldr = ldr;
-  a.alpha = alpha; a.beta = beta; a.act = act; a.M = M; a.N = N; a.K = pad32(K);
+  a.alpha = alpha; a.beta = beta; a.act = act; a.M = M; a.N = N; a.K = pad_k(K, precision);
   set_operand(a.A, x, ldx, ximg, M, K, precision);
   set_operand(a.B, w, ldw, wb == 0 ? nullptr : (w_packed ? static_cast<const char*>(w_packed) : wimg), N, K, precision);
   launch_linear_core(a, precision, M, N, st);
@@ -793,7 +1017,7 @@ extern "C" int mdg_linear_grouped(const float* x, int64_t ldx, int64_t rows_tota
   if (ximg) launch_prep(x, ldx, rows_total, ximg, nullptr, 0, 0, nullptr, K, precision, st);
   LinearArgs a{};
   a.y = y; a.ldy = 0; a.bias = bias; a.res = residual; a.ldr = 0; a.alpha = 1.f; a.beta = 1.f; a.act = act;
-  a.M = rows_total; a.N = w_rows_total; a.K = pad32(K);
+  a.M = rows_total; a.N = w_rows_total; a.K = pad_k(K, precision);
   a.vec_y = 1; a.vec_r = residual ? 1 : 0;               // the table's offsets and strides are multiples of 4 floats (checked by the caller's builder)
   a.tiles = tiles;
   set_operand(a.A, x, ldx, ximg, rows_total, K, precision);
@@ -811,8 +1035,7 @@ extern "C" int mdg_linear_grouped(const float* x, int64_t ldx, int64_t rows_tota
 static size_t image_bytes_t(int64_t rows, int64_t inner, int precision) {      // always a full image (the inner index is re-laid out)
   if (rows <= 0 || inner <= 0) return 0;
   const size_t Mp = static_cast<size_t>(pad64(inner));
-  if (precision == MDG_PREC_F32) return al256(static_cast<size_t>(rows) * Mp * 4);
-  return (precision == MDG_PREC_BF16X3 ? 2 : 1) * al256(static_cast<size_t>(rows) * Mp * 2);
+  return al256(static_cast<size_t>(rows) * Mp * (precision == MDG_PREC_BF16 ? 2 : 4));
 }
 
 extern "C" size_t mdg_linear_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision) {
@@ -834,18 +1057,16 @@ extern "C" int mdg_linear_tn(const float* g, int64_t ldg, const float* x, int64_
   char* aimg = static_cast<char*>(workspace);
   char* bimg = aimg + ab;
   const int64_t Mp = pad64(M);
-  const bool bf = precision != MDG_PREC_F32, x3 = precision == MDG_PREC_BF16X3;
-  const size_t es = bf ? 2 : 4;
   PrepTArgs pa{};
-  pa.src[0] = g; pa.ld[0] = ldg; pa.C[0] = N; pa.dst0[0] = aimg; pa.dst1[0] = x3 ? aimg + al256(static_cast<size_t>(N) * Mp * es) : nullptr;
-  pa.src[1] = x; pa.ld[1] = ldx; pa.C[1] = K; pa.dst0[1] = bimg; pa.dst1[1] = x3 ? bimg + al256(static_cast<size_t>(K) * Mp * es) : nullptr;
-  pa.M = M; pa.Mp = Mp; pa.bf16 = bf ? 1 : 0;
+  pa.src[0] = g; pa.ld[0] = ldg; pa.C[0] = N; pa.dst0[0] = aimg;
+  pa.src[1] = x; pa.ld[1] = ldx; pa.C[1] = K; pa.dst0[1] = bimg;
+  pa.M = M; pa.Mp = Mp; pa.bf16 = precision != MDG_PREC_F32 ? 1 : 0; pa.x3 = precision == MDG_PREC_BF16X3 ? 1 : 0;
   const int64_t cmax = N > K ? N : K;
   hipLaunchKernelGGL(prep_transposed_kernel, dim3(static_cast<unsigned>(Mp / 64), static_cast<unsigned>(mdg_cdiv(cmax, 64)), 2), dim3(256), 0, st, pa);
   LinearArgs a{};
   a.y = y; a.ldy = ldy; a.alpha = 1.f; a.beta = 0.f; a.act = MDG_ACT_NONE; a.M = N; a.N = K; a.K = Mp;
-  a.A.p0 = aimg; a.A.p1 = pa.dst1[0]; a.A.ld_bytes = Mp * static_cast<int64_t>(es); a.A.nrows = N;
-  a.B.p0 = bimg; a.B.p1 = pa.dst1[1]; a.B.ld_bytes = Mp * static_cast<int64_t>(es); a.B.nrows = K;
+  set_image(a.A, aimg, N, Mp, precision);
+  set_image(a.B, bimg, K, Mp, precision);
   launch_linear_core(a, precision, N, K, st);
   MDG_CHECK_LAUNCH("mdg_linear_tn");
   return MDG_OK;
@@ -860,25 +1081,25 @@ static int layernorm_impl(const float* x, int64_t ldx, const float* gamma, const
                 "mdg_layernorm: d must be a multiple of 4 and <= 2048 (got %lld)", (long long)d);
   MDG_CHECK_ARG(mdg_aligned16(x) && (!y || mdg_aligned16(y)) && mdg_aligned16(gamma) && mdg_aligned16(beta), "mdg_layernorm: 16-byte alignment");
   char* hi = nullptr;
-  char* lo = nullptr;
+  int x3 = 0;
   if (y_packed) {
     MDG_CHECK_ARG(precision == MDG_PREC_BF16X3 || precision == MDG_PREC_BF16, "mdg_layernorm_packed: a 16-bit operand mode (the fp32 mode reads y itself)");
-    MDG_CHECK_ARG(d % 32 == 0 && mdg_aligned16(y_packed), "mdg_layernorm_packed: d must be a multiple of 32 (the image has no padding to fill)");
+    MDG_CHECK_ARG(d % 64 == 0 && mdg_aligned16(y_packed), "mdg_layernorm_packed: d must be a multiple of 64 (the image has no padding to fill)");
     const size_t need = image_bytes(rows, d, precision);
     if (y_packed_bytes < need) {
       mdg_set_error("mdg_layernorm_packed: image of %zu bytes required, got %zu", need, y_packed_bytes);
       return MDG_EWORKSPACE;
     }
     hi = static_cast<char*>(y_packed);
-    lo = precision == MDG_PREC_BF16X3 ? hi + al256(static_cast<size_t>(rows) * d * 2) : nullptr;
+    x3 = precision == MDG_PREC_BF16X3 ? 1 : 0;
   }
   const dim3 grid(static_cast<unsigned>(mdg_cdiv(rows, 4)));
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int di = static_cast<int>(d);
-  if (d <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, rows, di, eps, hi, lo);
-  else if (d <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, rows, di, eps, hi, lo);
-  else if (d <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, rows, di, eps, hi, lo);
-  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, rows, di, eps, hi, lo);
+  if (d <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, rows, di, eps, hi, x3);
+  else if (d <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, rows, di, eps, hi, x3);
+  else if (d <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, rows, di, eps, hi, x3);
+  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, rows, di, eps, hi, x3);
   MDG_CHECK_LAUNCH("mdg_layernorm");
   return MDG_OK;
 }
@@ -904,7 +1125,7 @@ extern "C" int mdg_linear_packed_x(const void* x_packed, int64_t M, int64_t K, c
   if (M == 0 || N == 0) return MDG_OK;
   MDG_CHECK_ARG(precision == MDG_PREC_BF16X3 || precision == MDG_PREC_BF16, "mdg_linear_packed_x: a 16-bit operand mode");
   MDG_CHECK_ARG(x_packed && y && (w || w_packed) && mdg_aligned16(x_packed), "mdg_linear_packed_x: null / misaligned pointer");
-  MDG_CHECK_ARG(K % 32 == 0, "mdg_linear_packed_x: K must be a multiple of 32");
+  MDG_CHECK_ARG(K % 64 == 0, "mdg_linear_packed_x: K must be a multiple of 64");
   MDG_CHECK_ARG(ldy >= N && (!residual || ldr >= N || ldr == 0), "mdg_linear_packed_x: ldy/ldr smaller than N");
   MDG_CHECK_ARG(act >= MDG_ACT_NONE && act <= MDG_ACT_SELU, "mdg_linear_packed_x: unknown activation %d", act);
   hipStream_t st = static_cast<hipStream_t>(stream);

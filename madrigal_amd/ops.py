@@ -248,7 +248,7 @@ def layernorm_packed(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, 
     x2 = x if (x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.is_cuda and x.dtype == torch.float32) else _rows2d(x, "x")[0]
     R, d = x2.shape
     prec = _prec(precision)
-    if prec == PREC_F32 or d % 32 or R == 0:
+    if prec == PREC_F32 or d % 64 or R == 0:
         return layernorm(x2, weight, bias, eps), None
     y = torch.empty((R, d), dtype=torch.float32, device=x2.device) if want_fp32 else None      # image only: y itself is never written
     nbytes = int(lib().mdg_pack_operand_bytes(_c64(R), _c64(d), _c(prec)))
