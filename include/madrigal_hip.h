@@ -15,7 +15,8 @@
  *   - never allocates or frees device memory: scratch is passed in as `workspace`, sized by the
  *     matching *_workspace_bytes() query; never synchronises: work is enqueued on `stream`
  *     (a hipStream_t passed as void*; NULL = the default stream) and the call returns;
- *   - re-entrant, no global mutable state, no internal threads; safe under hipGraph capture.
+ *   - re-entrant, no internal threads, safe under hipGraph capture; no global mutable state apart
+ *     from the two diagnostics hooks at the end of this header (tuning switches, clock stamps).
  */
 #ifndef MADRIGAL_HIP_H
 #define MADRIGAL_HIP_H
@@ -62,6 +63,15 @@ const char* mdg_last_error(void);
 /* "gfx950" build tag, and the ABI version (bumped on any signature change). */
 const char* mdg_build_arch(void);
 int mdg_abi_version(void);
+
+/* Diagnostics.  The MDG_* environment variables are experiment switches that select between kernel schedules
+ * with identical results; each is read once per process, at its first use.  mdg_tuning_reload() makes every
+ * switch re-read the environment at its next use (tests and timing scripts flip one between two launches).
+ * mdg_debug_bilinear_stamps hands mdg_bilinear_allpairs a device buffer of `entries` uint64 that receives
+ * {shader cycles, 100 MHz ticks} per workgroup of each following launch whose grid fits; NULL switches it off.
+ * Neither is meant to be called concurrently with launches from other threads. */
+void mdg_tuning_reload(void);
+void mdg_debug_bilinear_stamps(void* buffer, int64_t entries);
 
 /* ------------------------------------------------------------------ bilinear DDI head ---- */
 
@@ -365,7 +375,7 @@ int mdg_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, voi
 
 /* nn.BatchNorm1d in training mode over the rows of x [rows, cols] (torchdrug MultiLayerPerceptron batch_norm,
  * chemCPA MLP), fused with the following activation: y = act((x - mean) * rstd * gamma + beta); running statistics are
- * updated in place (momentum, unbiased variance).  stats [4*cols] receives mean | rstd | scale | shift for the backward. */
+ * updated in place (momentum, unbiased variance).  stats [5*cols] receives mean | rstd | scale | shift for the backward, and the biased batch variance. */
 size_t mdg_batchnorm_workspace_bytes(int64_t rows, int64_t cols);
 int mdg_batchnorm_train_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* running_mean,
                             float* running_var, float* y, int64_t ldy, float* stats, int64_t rows, int64_t cols, float eps,
@@ -375,7 +385,7 @@ int mdg_batchnorm_train_bwd(const float* dy, const float* x, const float* stats,
                             int64_t rows, int64_t cols, void* workspace, size_t workspace_bytes, void* stream);
 
 /* One more momentum update of running_mean / running_var with the batch statistics of an earlier mdg_batchnorm_train_fwd
- * (stats[0:C] mean, stats[C:2C] rstd): nn.BatchNorm1d seeing the same rows again.  The reference encodes head side and tail
+ * (stats[0:C] mean, stats[4C:5C] biased variance): nn.BatchNorm1d seeing the same rows again.  The reference encodes head side and tail
  * side of one step separately (madrigal/models/models.py:945-946); when both sides are the same batch, the encoders without
  * dropout (GIN, chemCPA) produce the same output twice -- here they run once and their BatchNorm layers replay the update. */
 int mdg_batchnorm_replay_update(const float* stats, float* running_mean, float* running_var, int64_t rows, int64_t cols, float eps,
@@ -384,7 +394,7 @@ int mdg_batchnorm_replay_update(const float* stats, float* running_mean, float* 
 /* The phases of mdg_batchnorm_train_fwd / _bwd as separate calls, for SyncBatchNorm over drug-sharded ranks: the caller
  * all-reduces the per-column sums between phases (count = rows over all ranks).
  *   mdg_col_reduce mode 0: out[c] = sum_r x;  1: sum_r (x - center[c])^2;  2: sum_r x * (y - center[c]) * rstd[c]
- *   mdg_batchnorm_finalize phase 0: stats[0:C] = sum / count;  phase 1: rstd | scale | shift from sqsum / count and the
+ *   mdg_batchnorm_finalize phase 0: stats[0:C] = sum / count;  phase 1: rstd | scale | shift | variance (stats has 5C entries) from sqsum / count and the
  *   running-statistics update;  then mdg_affine_act(x, stats + 2C, stats + 3C) applies the normalisation.
  *   mdg_batchnorm_bwd_apply: dx from the (all-reduced) sum_dy and sum_dy_xhat.
  * count_dev (optional): the total row count as a device double (itself all-reduced) read by the kernel instead of the

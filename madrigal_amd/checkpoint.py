@@ -101,7 +101,7 @@ def _encoder_from_configs(encoder_configs: dict):
 
 
 def load_finetune_checkpoint(path_or_dict, device=None, strict: bool = True):
-    """madrigal/evaluate/predict.py:178-205 -> ``(model, checkpoint)``: rebuild encoder and model from the stored configs and
+    """madrigal/evaluate/predict.py:178-205 -> ``(model, checkpoint, incompatible_keys)``: rebuild encoder and model from the stored configs and
     load the weights.  ``use_modality_pretrain`` is switched off for the rebuild (the stored weights replace the
     unimodal ones the constructor would fetch from ENCODER_CKPT_DIR)."""
     from .models import NovelDDIMultilabel
@@ -145,11 +145,19 @@ def load_pretrained_encoder(path_or_dict, overrides: Optional[dict] = None, use_
             raise KeyError(f"{k!r} cannot be overridden on a pretrained encoder (allowed: {TRANSFER_OVERRIDES})")
         if v is not None:
             cfg[k] = v
-    cfg['use_modality_pretrain'] = False             # the checkpoint's weights replace the unimodal ones
-    encoder, cfg = _encoder_from_configs(cfg)
-    state = ckpt['state_dict']
-    if 'epoch' in ckpt:                              # a SimCLR checkpoint: keys live under base_encoder. (utils.py:272-296)
-        state = filter_pretrained_state_dict(state, use_pretrained_adaptor)
+    # utils.py:281-295 filters and renames UNCONDITIONALLY (whatever other entries the checkpoint holds)
+    state = filter_pretrained_state_dict(ckpt['state_dict'], use_pretrained_adaptor)
+    if not state:
+        raise ValueError("load_pretrained_encoder: no 'base_encoder.*' modality-encoder weights in this checkpoint -- not a contrastive-"
+                         "pretraining checkpoint (the reference would silently return a randomly initialised encoder here)")
+    # The reference builds the encoder with the checkpoint's own `use_modality_pretrain` (its constructor then fetches the unimodal
+    # files from ENCODER_CKPT_DIR) and overwrites those weights with the state dict.  When the state dict covers all four
+    # modality encoders the fetch changes nothing, so it is skipped; the returned configs keep the checkpoint's value either way.
+    wanted = bool(cfg.get('use_modality_pretrain', True))
+    covered = all(any(k.startswith(m + '.') for k in state) for m in ('str_encoder', 'kg_encoder', 'cv_encoder', 'tx_encoder'))
+    build_cfg = dict(cfg)
+    build_cfg['use_modality_pretrain'] = wanted and not covered
+    encoder, _ = _encoder_from_configs(build_cfg)
     msg = encoder.load_state_dict(state, strict=False)
     if device is not None:
         encoder = encoder.to(device)

@@ -183,8 +183,9 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(const float* __r
   if (ty == 0 && c < cols) part[static_cast<int64_t>(blockIdx.y) * cols + c] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
-// stats[0:N]=mean, [N:2N]=rstd, [2N:3N]=scale=gamma*rstd, [3N:4N]=shift=beta-mean*scale; running stats updated like
-// nn.BatchNorm1d (momentum, unbiased variance).
+// stats[0:N]=mean, [N:2N]=rstd, [2N:3N]=scale=gamma*rstd, [3N:4N]=shift=beta-mean*scale, [4N:5N]=biased batch variance (kept
+// for the replayed running-statistics update: 1/rstd^2 - eps cancels catastrophically where var << eps); running stats updated
+// like nn.BatchNorm1d (momentum, unbiased variance).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sqsum, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var, float* __restrict__ stats, double rows,
@@ -201,18 +202,19 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   stats[cols + c] = rstd;
   stats[2 * cols + c] = g * rstd;
   stats[3 * cols + c] = b - mean * g * rstd;
+  stats[4 * cols + c] = var;
   if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
   if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (rows > 1 ? sqsum[c] / static_cast<float>(rows - 1) : var);
 }
 
 // A second momentum update of the running statistics with batch statistics that a training-mode forward already produced
-// (stats[0:C] = mean, stats[C:2C] = rstd): what nn.BatchNorm1d does when the same module sees the same rows again.
+// (stats[0:C] = mean, stats[4C:5C] = biased variance): what nn.BatchNorm1d does when the same module sees the same rows again.
 __global__ __launch_bounds__(256) void bn_replay_kernel(const float* __restrict__ stats, float* __restrict__ running_mean,
                                                         float* __restrict__ running_var, double rows, int64_t cols, float eps, float momentum) {
   const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (c >= cols) return;
-  const float mean = stats[c], rstd = stats[cols + c];
-  const float var = 1.0f / (rstd * rstd) - eps;                                   // biased batch variance
+  const float mean = stats[c];
+  const float var = fmaxf(stats[4 * cols + c], 0.f);                              // biased batch variance, as the forward pass formed it
   const float unbiased = rows > 1 ? var * static_cast<float>(rows / (rows - 1.0)) : var;
   running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
   running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;

@@ -47,7 +47,7 @@ struct BilinearArgs {
   int loaders;          // conservative pipeline: waves that issue the LDS-DMA (1, 2 or 4)
   int pipeline;         // 0 = counted waits (default), 1 = conservative
   int symmetric;        // z_head and z_tail are the same matrix (same pointer, same row count)
-  unsigned long long* stamps;   // diagnostics only (MDG_BILINEAR_STAMPS): per workgroup {shader cycles, 100 MHz ticks} of the sweep
+  unsigned long long* stamps;   // diagnostics only (mdg_debug_bilinear_stamps): per workgroup {shader cycles, 100 MHz ticks} of the sweep
 };
 
 // 16-bit operand images travel as bf16x8 containers; MDG_PREC_F16 stores IEEE half bits in them and casts at the MFMA.
@@ -1130,24 +1130,24 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
   // MDG_BILINEAR_VARIANT: 0 = one burst of 32 dword stores per wave and stage (early / late halves), 1 = those stores spread
   // between the MFMAs of the next tile, 2 = tile transposed through LDS, 8 x 16-byte stores spread between the MFMAs.  Read per
   // call; changes speed only (same products, same accumulation order, same bytes stored).
-  const char* ve = getenv("MDG_BILINEAR_VARIANT");
-  int variant = ve ? atoi(ve) : 0;
+  static MdgEnvInt variant_sw{"MDG_BILINEAR_VARIANT", 0};
+  int variant = variant_sw.get();
   if (variant < 0 || variant > 2 || a.pipeline != 0) variant = 0;
   if (variant == 2 && ((a.n_tail & 3) != 0 || !mdg_aligned16(a.out))) variant = 0;     // 16-byte stores need aligned rows
   const size_t lds2 = lds + static_cast<size_t>(NW) * 8192;
   // Symmetric sweep (z_head and z_tail are the same matrix): half the matrix work, every off-diagonal tile stored twice.
   // Default for that case; MDG_BILINEAR_SYMMETRIC=0 switches it off.
   if constexpr (NW == 8) {
-    const char* se = getenv("MDG_BILINEAR_SYMMETRIC");
-    const bool want = se ? atoi(se) != 0 : true;
+    static MdgEnvInt sym_sw{"MDG_BILINEAR_SYMMETRIC", 1};
+    const bool want = sym_sw.get() != 0;
     if (want && a.symmetric && a.pipeline == 0 && (epilogue == MDG_EPI_STORE || epilogue == MDG_EPI_STORE_SIGMOID) && (a.n_tail & 3) == 0 &&
         mdg_aligned16(a.out) && a.n_tail * a.n_tail * 4 < (int64_t(1) << 32) && a.n_tail > 256) {
       const int nb = static_cast<int>(mdg_cdiv(a.n_tail, 256));
       const dim3 gsym(static_cast<unsigned>((nb + 1) / 2), static_cast<unsigned>(a.n_labels));
       // write-through score stores keep z_tail L2-resident (FETCH 11.3 -> 0.8 GB per launch at 4096^2 x 896); measured faster for
       // the three-product mode (11.78 -> 11.53 ms), slower for the single-product 16-bit modes (10.70 -> 11.11 ms)
-      const char* ce = getenv("MDG_BILINEAR_SC1");
-      const bool sc1 = ce ? atoi(ce) != 0 : (MODE == MDG_PREC_BF16X3);
+      static MdgEnvInt sc1_sw{"MDG_BILINEAR_SC1", -1};
+      const bool sc1 = sc1_sw.get() >= 0 ? sc1_sw.get() != 0 : (MODE == MDG_PREC_BF16X3);
       if (epilogue == MDG_EPI_STORE) {
         if (sc1) hipLaunchKernelGGL((bilinear_allpairs_sym_kernel<MODE, MDG_EPI_STORE, 8, 1>), gsym, block, lds2, st, a);
         else hipLaunchKernelGGL((bilinear_allpairs_sym_kernel<MODE, MDG_EPI_STORE, 8, 0>), gsym, block, lds2, st, a);
@@ -1176,10 +1176,12 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
         hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE_SIGMOID, NW>), grid, block, lds, st, a);
       break;
     case MDG_EPI_ROWSTATS: {    // three-buffer ring (prefetch distance two)
-      static const int rb2 = getenv("MDG_BILINEAR_RB") ? atoi(getenv("MDG_BILINEAR_RB")) : 2;
+      static MdgEnvInt rb_sw{"MDG_BILINEAR_RB", 2};
+      const int rb2 = rb_sw.get();
       if (kSingle16<MODE> && rb2 == 2 && a.pipeline == 0) {     // 64 rows per wave: halves the LDS operand reads per MFMA
         const dim3 grid2(static_cast<unsigned>(mdg_cdiv(a.n_head, 32 * NW * 2)), static_cast<unsigned>(a.n_labels));
-        static const int shape16 = getenv("MDG_BILINEAR_MFMA16") ? atoi(getenv("MDG_BILINEAR_MFMA16")) : 1;
+        static MdgEnvInt m16_sw{"MDG_BILINEAR_MFMA16", 1};
+        const int shape16 = m16_sw.get();
         if constexpr (kSingle16<MODE> && NW == 8) {
           if (shape16) {                                       // the same sweep on v_mfma_f32_16x16x32 (power-bound loop)
             hipLaunchKernelGGL((bilinear_rowstats16_kernel<MODE>), grid2, block, 3 * STAGE_BYTES, st, a);
@@ -1205,13 +1207,22 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
 // (4 or 8) overrides the choice for experiments; it is read per call and changes speed only.
 template <int MODE>
 int launch_allpairs(const BilinearArgs& a, int epilogue, hipStream_t st) {
-  int nw = 8;
-  if (const char* e = getenv("MDG_BILINEAR_WAVES")) nw = atoi(e);
+  static MdgEnvInt nw_sw{"MDG_BILINEAR_WAVES", 8};
+  const int nw = nw_sw.get();
   if (nw == 8) return launch_allpairs_nw<MODE, 8>(a, epilogue, st);
   return launch_allpairs_nw<MODE, 4>(a, epilogue, st);
 }
 
 }  // namespace
+
+// Diagnostics (scripts/head_variants.py): a device buffer of `entries` uint64 that receives {shader cycles, 100 MHz ticks} per
+// workgroup of every following mdg_bilinear_allpairs launch with at most entries / 2 workgroups; NULL / 0 switches it off.
+static unsigned long long* g_stamps = nullptr;
+static int64_t g_stamp_entries = 0;
+extern "C" void mdg_debug_bilinear_stamps(void* buffer, int64_t entries) {
+  g_stamps = static_cast<unsigned long long*>(buffer);
+  g_stamp_entries = buffer ? entries : 0;
+}
 
 extern "C" int mdg_symmetrize(const float* w_original, float* w_sym, int64_t L, int64_t D_, void* stream) {
   MDG_CHECK_ARG(w_original && w_sym, "mdg_symmetrize: null pointer");
@@ -1255,14 +1266,18 @@ extern "C" int mdg_bilinear_allpairs(const float* z_head, const float* z_tail, c
   a.stagger = 1;
   a.stagger_waves = 1;
   a.loaders = 4;
-  a.pipeline = 0;
-  if (const char* e = getenv("MDG_BILINEAR_PIPELINE")) a.pipeline = atoi(e) ? 1 : 0;
-  if (const char* e = getenv("MDG_BILINEAR_LOADERS")) a.loaders = atoi(e);
+  static MdgEnvInt pipe_sw{"MDG_BILINEAR_PIPELINE", 0}, load_sw{"MDG_BILINEAR_LOADERS", 4}, stw_sw{"MDG_BILINEAR_STAGGER_WAVES", 1},
+      stg_sw{"MDG_BILINEAR_STAGGER", 1};
+  a.pipeline = pipe_sw.get() ? 1 : 0;
+  a.loaders = load_sw.get();
   if (a.loaders != 1 && a.loaders != 2 && a.loaders != 4) a.loaders = 4;
-  if (const char* e = getenv("MDG_BILINEAR_STAGGER_WAVES")) a.stagger_waves = atoi(e);
-  if (const char* e = getenv("MDG_BILINEAR_STAGGER")) a.stagger = atoi(e);
-  // diagnostics: device address (hex) of a buffer of 2 x (workgroups of the launch) uint64 that receives clock stamps
-  if (const char* e = getenv("MDG_BILINEAR_STAMPS")) a.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 16));
+  a.stagger_waves = stw_sw.get();
+  a.stagger = stg_sw.get();
+  // diagnostics: clock stamps per workgroup, only into a buffer handed over through mdg_debug_bilinear_stamps and only when it is large enough
+  {
+    const int64_t wgs = mdg_cdiv(n_head, 128) * n_labels;          // the largest grid any variant launches
+    a.stamps = (g_stamps && g_stamp_entries >= 2 * wgs) ? g_stamps : nullptr;
+  }
   a.w.nrows = D;
   if (precision == MDG_PREC_F32) {
     a.zt.f32 = z_tail;

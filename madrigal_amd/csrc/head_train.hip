@@ -358,7 +358,8 @@ extern "C" int mdg_bilinear_matvec_rows(const float* z, const float* w, const in
   MDG_CHECK_ARG(z && w && tile_start && tile_label && rows_out && mdg_aligned16(z) && mdg_aligned16(w) && mdg_aligned16(rows_out),
                 "mdg_bilinear_matvec_rows: null / misaligned pointer");
   GatherArgs a{z, z, w, w, row_index, row_index, tile_start, tile_label, n_tiles, nullptr, nullptr, rows_out, nullptr};
-  static const bool old_path = getenv("MDG_MATVEC_ROWS_OLD") != nullptr;
+  static MdgEnvInt old_sw{"MDG_MATVEC_ROWS_OLD", 0};
+  const bool old_path = old_sw.get() != 0;
   if (old_path) hipLaunchKernelGGL(bilinear_gather_kernel<2>, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   else hipLaunchKernelGGL(bilinear_matvec_rows_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   MDG_CHECK_LAUNCH("mdg_bilinear_matvec_rows");

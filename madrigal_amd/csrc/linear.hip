@@ -893,9 +893,12 @@ static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t 
   // tile shape: the 256x256 / 8-wave shape once the problem fills the chip with it, else 128x128 / 4 waves
   // (measured on the fusion GEMMs: bf16x3 -9 % time with the big tile, fp32 +6 %: the fp32 MFMA wants two workgroups per CU)
   bool big = (precision != MDG_PREC_F32 && N >= 256 && M >= 1024 && mdg_cdiv(M, pp::BM) * mdg_cdiv(N, pp::BN) >= 192);
-  if (const char* e = getenv("MDG_LINEAR_TILE")) big = atoi(e) == 256 ? true : (atoi(e) == 128 ? false : big);
+  static MdgEnvInt tile_sw{"MDG_LINEAR_TILE", 0};
+  if (tile_sw.get() == 256) big = true;
+  else if (tile_sw.get() == 128) big = false;
   // 1-D grid; the kernel maps the linear workgroup id to a tile (XCD-aware order once there are enough tiles to matter)
-  static const int swz_env = getenv("MDG_LINEAR_SWIZZLE") ? atoi(getenv("MDG_LINEAR_SWIZZLE")) : -1;
+  static MdgEnvInt swz_sw{"MDG_LINEAR_SWIZZLE", -1};
+  const int swz_env = swz_sw.get();
   const auto grid_for = [&](int bm, int bn) {
     a.tiles_x = static_cast<int>(mdg_cdiv(N, bn));
     a.tiles_y = static_cast<int>(mdg_cdiv(M, bm));
@@ -904,7 +907,8 @@ static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t 
     return dim3(static_cast<unsigned>(a.swizzle ? 8 * ((total + 7) / 8) : total));
   };
   // 16-bit modes run on the 16x16x32 MFMA unless MDG_LINEAR_MFMA=32 asks for the 32x32x16 form (128-tile kernel only)
-  static const bool m16 = !(getenv("MDG_LINEAR_MFMA") && atoi(getenv("MDG_LINEAR_MFMA")) == 32);
+  static MdgEnvInt mfma_sw{"MDG_LINEAR_MFMA", 16};
+  const bool m16 = mfma_sw.get() != 32;
   if (big) {
     const dim3 grid = grid_for(pp::BM, pp::BN);
     if (precision == MDG_PREC_BF16X3) hipLaunchKernelGGL((linear_pp_kernel<MDG_PREC_BF16X3>), grid, dim3(pp::THREADS), pp::LDS_BYTES, st, a);

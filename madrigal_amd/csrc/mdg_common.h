@@ -41,6 +41,17 @@ void mdg_set_error(const char* fmt, ...);
 static inline bool mdg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int64_t mdg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- tuning switches: an MDG_* environment variable read once (see api.hip: mdg_tuning_reload) ----
+#include <atomic>
+extern std::atomic<int> g_mdg_env_generation;
+struct MdgEnvInt {
+  const char* name;
+  int dflt;
+  int gen = -1;
+  int val = 0;
+  int get();
+};
+
 // ---- device helpers ----------------------------------------------------------------------
 // hi/lo bf16 split of an fp32 value: x ~= hi + lo with |x - hi - lo| <= 2^-18 |x|.
 __device__ __forceinline__ void mdg_split_bf16(float x, __bf16& hi, __bf16& lo) {

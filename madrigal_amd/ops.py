@@ -723,13 +723,13 @@ def dropout(x: torch.Tensor, p: float, seed: int) -> torch.Tensor:
 
 
 def batchnorm_train_fwd(x: torch.Tensor, gamma, beta, running_mean, running_var, eps: float, momentum: float, act=None):
-    """-> (y, stats[4N]); updates the running statistics in place (nn.BatchNorm1d training semantics)."""
+    """-> (y, stats[5N]); updates the running statistics in place (nn.BatchNorm1d training semantics)."""
     x = _f32_cuda(x, "x", 2)
     R, C = x.shape
     if R < 2:
         raise ValueError("Expected more than 1 value per channel when training")      # torch's message
     y = torch.empty_like(x)
-    stats = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+    stats = torch.empty(5 * C, dtype=torch.float32, device=x.device)
     nbytes = lib().mdg_batchnorm_workspace_bytes(_c64(R), _c64(C))
     ws = _workspace(nbytes, x.device)
     check(lib().mdg_batchnorm_train_fwd(_ptr(x), _c64(C), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(y),
@@ -1195,14 +1195,14 @@ def _col_reduce(x, y, center, rstd, mode: int) -> torch.Tensor:
 
 def sync_batchnorm_train_fwd(x: torch.Tensor, gamma, beta, running_mean, running_var, eps: float, momentum: float, act, reduce_):
     """BatchNorm1d training forward with statistics over all ranks: ``reduce_(t)`` sums a small device tensor over ranks
-    in place.  The total row count stays on the device (no host read inside the step).  -> (y, stats[4C], count_dev[1])."""
+    in place.  The total row count stays on the device (no host read inside the step).  -> (y, stats[5C], count_dev[1])."""
     x = _f32_cuda(x, "x", 2)
     R, C = x.shape
     cnt = torch.tensor([float(R)], dtype=torch.float64).to(x.device, non_blocking=True)
     s = _col_reduce(x, None, None, None, 0)
     reduce_(s)
     reduce_(cnt)
-    stats = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+    stats = torch.empty(5 * C, dtype=torch.float32, device=x.device)
     fin = lib().mdg_batchnorm_finalize
     check(fin(_ptr(s), _ptr(None), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(stats), ctypes.c_double(0.0), _ptr(cnt),
               _c64(C), _f(eps), _f(momentum), _c(0), _stream(x)), "mdg_batchnorm_finalize")

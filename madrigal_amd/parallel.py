@@ -146,6 +146,19 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
     flush()
 
 
+_BUCKET_GROUPS = {}          # (ranks, backend) -> the bucket communicator (never re-created per step object)
+
+
+def destroy_bucket_groups() -> None:
+    """Release the bucket communicators (call before dist.destroy_process_group() in a long-lived process)."""
+    for g in _BUCKET_GROUPS.values():
+        try:
+            dist.destroy_process_group(g)
+        except Exception:
+            pass
+    _BUCKET_GROUPS.clear()
+
+
 class GradientBuckets:
     """Bucketed gradient all-reduce that overlaps the backward pass (the reference is single-GPU; torch DDP's scheme, restated
     for this step: parameters in REVERSE registration order -- roughly the order their gradients become final -- are cut
@@ -159,18 +172,30 @@ class GradientBuckets:
     xGMI rings are per-link bound (about 153 GB/s per link): buckets default to 64 MB -- 20 to 80 M fp32 parameters make
     2 to 5 collectives per step, each long enough to run at link rate, the last ones hidden under the encoders' backward."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20):
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20, overlap: Optional[bool] = None):
         # A communicator of its own: bucket collectives are issued from gradient hooks BETWEEN the collectives the backward
         # pass itself issues (SyncBatchNorm sums, the embedding reduce-scatter); on a rank that lacks some gradient a bucket
-        # moves to finish(), i.e. to another position in that rank's stream of collectives.  Collectives of different
-        # communicators need no common order, so the buckets (fixed order among themselves) cannot pair up with the wrong
-        # partner.  (Constructed on every rank, like the step objects that own it.)
+        # moves to finish(), i.e. to another position in that rank's stream of collectives.  NON-BLOCKING collectives of
+        # different communicators need no common order, so the buckets (fixed order among themselves) cannot pair up with the
+        # wrong partner.  (Constructed on every rank, like the step objects that own it; one communicator per set of ranks and
+        # backend is kept for the life of the process and shared by every GradientBuckets over it.)
+        self.params = [p for p in params if p.requires_grad]
+        blocking = False
         if dist.is_initialized() and dist.get_world_size(group) > 1:
-            ranks = list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group)
-            group = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
+            backend = dist.get_backend(group)
+            ranks = tuple(range(dist.get_world_size())) if group is None else tuple(dist.get_process_group_ranks(group))
+            key = (ranks, backend)
+            if key not in _BUCKET_GROUPS:
+                _BUCKET_GROUPS[key] = dist.new_group(ranks=list(ranks), backend=backend)
+            group = _BUCKET_GROUPS[key]
+            # gloo on device tensors is staged through the host and BLOCKS: a bucket issued from a hook on one rank while
+            # another rank (which lacks one of the bucket's gradients and defers it to finish()) blocks in a SyncBatchNorm
+            # all-reduce of the default group would leave each waiting for the other.  A blocking transport issues every
+            # bucket in finish(), after the backward pass, in the one fixed order.
+            blocking = backend == "gloo" and any(p.is_cuda for p in self.params)
+        self.overlap = (not blocking) if overlap is None else (bool(overlap) and not blocking)
         self.group = group
         self.bucket_bytes = bucket_bytes
-        self.params = [p for p in params if p.requires_grad]
         self.cold = frozenset()                          # parameters that had a gradient on NO rank in the last step
         self._hooks = []
         self._armed = False
@@ -217,6 +242,8 @@ class GradientBuckets:
         self.seen.add(i)
         b = self.bucket_of[i]
         self.ready[b] += 1
+        if not self.overlap:
+            return
         while self.next_bucket < len(self.buckets) and self.ready[self.next_bucket] == len(self.buckets[self.next_bucket]):
             self._issue(self.next_bucket)
             self.next_bucket += 1

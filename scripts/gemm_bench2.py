@@ -38,11 +38,11 @@ if "check" in sys.argv:
     for (M, N, K) in [(1024, 256 * 48, 64), (1500, 256 * 40 + 36, 100), (4096 + 77, 3072 + 4, 2048), (22464, 2048, 2048), (2048, 6144, 128), (1024 * 50, 256, 192)]:
         x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5
         b = torch.randn(N, device="cuda"); r = torch.randn(M, N, device="cuda")
-        os.environ["MDG_LINEAR_TILE"] = "256"
+        os.environ["MDG_LINEAR_TILE"] = "256"; lib().mdg_tuning_reload()
         y1 = ops.linear(x, w, b, act="gelu", residual=r, precision=prec, cache_weight=False)
-        os.environ["MDG_LINEAR_TILE"] = "128"
+        os.environ["MDG_LINEAR_TILE"] = "128"; lib().mdg_tuning_reload()
         y0 = ops.linear(x, w, b, act="gelu", residual=r, precision=prec, cache_weight=False)
-        os.environ.pop("MDG_LINEAR_TILE")
+        os.environ.pop("MDG_LINEAR_TILE"); lib().mdg_tuning_reload()
         rows = torch.randint(0, M, (64,), device="cuda"); rows[0] = M - 1; rows[1] = 0
         ref = torch.nn.functional.gelu(x[rows].double() @ w.double().T + b.double()) + r[rows].double()
         err = float((y1[rows].double() - ref).abs().max() / ref.abs().max())

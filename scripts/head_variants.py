@@ -17,13 +17,16 @@ z = torch.randn(a.n, 128, generator=g).cuda()
 w = ops.symmetrize((torch.randn(a.labels, 128, 128, generator=g) / 128 ** 0.5).cuda())
 out = torch.empty(a.labels, a.n, a.n, device="cuda")
 stamps = torch.zeros(2 * a.labels * ((a.n + 255) // 256), dtype=torch.int64, device="cuda")       # in-kernel clock stamps (diagnostics)
-os.environ["MDG_BILINEAR_STAMPS"] = hex(stamps.data_ptr())
+import ctypes
+from madrigal_amd._lib import lib
+lib().mdg_debug_bilinear_stamps(ctypes.c_void_p(stamps.data_ptr()), ctypes.c_int64(stamps.numel()))
 res = {}
 for prec in a.precisions.split(","):
     ref = None
     for var in [v + "s" + y for y in a.sym.split(",") for v in (a.variants.split(",") if y == "0" else ["-"])]:
         os.environ["MDG_BILINEAR_VARIANT"] = var[0] if var[0] != "-" else "0"
         os.environ["MDG_BILINEAR_SYMMETRIC"] = var[-1]
+        lib().mdg_tuning_reload()
         for _ in range(2):
             ops.bilinear_allpairs(z, z, w, precision=prec, out=out)
         torch.cuda.synchronize()

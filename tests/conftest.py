@@ -21,3 +21,15 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     return load
+
+
+@pytest.fixture(autouse=True)
+def _fresh_tuning_switches():
+    """The library caches its MDG_* switches; a test that flipped one (helpers.set_switch) must not leak it into the next."""
+    yield
+    try:
+        from madrigal_amd import _lib
+        if _lib._lib is not None:
+            _lib._lib.mdg_tuning_reload()
+    except Exception:
+        pass

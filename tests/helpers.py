@@ -158,3 +158,11 @@ def model_shapes_for_case(case, kg, L):
 
 
 from oracle.pipeline import oracle_pipeline  # noqa: E402,F401  (whole-path CPU oracle)
+
+
+def set_switch(monkeypatch, name: str, value: str) -> None:
+    """Flip one of the library's MDG_* tuning switches for the following launches: the library reads a switch once, so the
+    environment change is followed by mdg_tuning_reload() (conftest's autouse fixture reloads again after the test)."""
+    from madrigal_amd._lib import lib
+    monkeypatch.setenv(name, value)
+    lib().mdg_tuning_reload()

@@ -110,6 +110,14 @@ def test_pretraining_checkpoint_seeds_a_finetune_encoder(small, tmp_path):
                 assert k in msg.missing_keys, k
     with pytest.raises(KeyError):
         CK.load_pretrained_encoder(path, overrides={"feat_dim": 64})
+    # utils.py:281-295 filters whatever else the checkpoint holds: one without 'epoch' loads the same weights ...
+    no_epoch = {k: v for k, v in raw.items() if k != "epoch"}
+    enc2, cfg2, msg2 = CK.load_pretrained_encoder(no_epoch)
+    assert not msg2.unexpected_keys and cfg2["use_modality_pretrain"] == cfg["use_modality_pretrain"]
+    assert all(torch.equal(v, sim.base_encoder.state_dict()[k]) for k, v in enc2.state_dict().items() if k.startswith(("str_encoder.", "cv_encoder.")))
+    # ... and a state dict with no base_encoder.* entry (a finetune checkpoint) is refused instead of returning random weights
+    with pytest.raises(ValueError, match="base_encoder"):
+        CK.load_pretrained_encoder({**no_epoch, "state_dict": {k[len("base_encoder."):]: v for k, v in raw["state_dict"].items() if k.startswith("base_encoder.")}})
 
 
 def test_shipped_unimodal_weight_files_load_strictly(golden, tmp_path, monkeypatch):

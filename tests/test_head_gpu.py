@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import rel_err, t
+from helpers import rel_err, set_switch, t
 
 pytestmark = pytest.mark.gpu
 
@@ -16,7 +16,7 @@ TOL = {"f32": 2e-5, "bf16x3": 1e-4, "bf16": 3e-2, "f16": 4e-3}
 @pytest.fixture(params=["0", "1", "2"], ids=["burst_stores", "spread_stores", "lds_transposed_16B_stores"])
 def variant(request, monkeypatch):
     """MDG_BILINEAR_VARIANT: the store schedules of the kernel (same products, same accumulation order, same bytes)."""
-    monkeypatch.setenv("MDG_BILINEAR_VARIANT", request.param)
+    set_switch(monkeypatch, "MDG_BILINEAR_VARIANT", request.param)
     return request.param
 
 
@@ -94,7 +94,7 @@ def test_store_schedules_write_identical_bits(ops, monkeypatch, nh, nt):
     for prec in ("f32", "bf16x3", "bf16", "f16"):
         outs = []
         for var in ("0", "1", "2"):
-            monkeypatch.setenv("MDG_BILINEAR_VARIANT", var)
+            set_switch(monkeypatch, "MDG_BILINEAR_VARIANT", var)
             out = torch.full((5, nh, nt), float("nan"), device="cuda")
             ops.bilinear_allpairs(zh, zt, w, precision=prec, out=out)
             outs.append(out)
@@ -102,15 +102,15 @@ def test_store_schedules_write_identical_bits(ops, monkeypatch, nh, nt):
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), prec
     sg = []
     for var in ("0", "1", "2"):
-        monkeypatch.setenv("MDG_BILINEAR_VARIANT", var)
+        set_switch(monkeypatch, "MDG_BILINEAR_VARIANT", var)
         sg.append(ops.bilinear_allpairs(zh, zt, w, precision="bf16x3", epilogue=ops.EPI_STORE_SIGMOID))
     assert torch.equal(sg[0], sg[1]) and torch.equal(sg[0], sg[2])
     # a view that starts 4 bytes into a row group: not 16-byte aligned, the launcher must fall back
-    monkeypatch.setenv("MDG_BILINEAR_VARIANT", "2")
+    set_switch(monkeypatch, "MDG_BILINEAR_VARIANT", "2")
     buf = torch.full((5 * nh * nt + 1,), float("nan"), device="cuda")
     view = buf[1:].view(5, nh, nt)
     ops.bilinear_allpairs(zh, zt, w, precision="bf16x3", out=view)
-    monkeypatch.setenv("MDG_BILINEAR_VARIANT", "0")
+    set_switch(monkeypatch, "MDG_BILINEAR_VARIANT", "0")
     assert torch.equal(view, ops.bilinear_allpairs(zh, zt, w, precision="bf16x3")) and bool(torch.isnan(buf[0]))
 
 
@@ -124,10 +124,10 @@ def test_symmetric_sweep_for_one_drug_set(ops, monkeypatch, prec, N, L):
     (not a multiple of 256 / 64), odd numbers of row blocks and the sigmoid epilogue included."""
     z = _rand((N, 128), 60).cuda()
     w = ops.symmetrize(_rand((L, 128, 128), 61, 1 / np.sqrt(128)).cuda())
-    monkeypatch.setenv("MDG_BILINEAR_SYMMETRIC", "0")
+    set_switch(monkeypatch, "MDG_BILINEAR_SYMMETRIC", "0")
     gen = ops.bilinear_allpairs(z, z, w, precision=prec)
     gen_sig = ops.bilinear_allpairs(z, z, w, precision=prec, epilogue=ops.EPI_STORE_SIGMOID)
-    monkeypatch.setenv("MDG_BILINEAR_SYMMETRIC", "1")
+    set_switch(monkeypatch, "MDG_BILINEAR_SYMMETRIC", "1")
     out = torch.full((L, N, N), float("nan"), device="cuda")
     ops.bilinear_allpairs(z, z, w, precision=prec, out=out)
     assert not bool(torch.isnan(out).any())

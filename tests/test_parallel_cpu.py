@@ -226,3 +226,78 @@ def test_gradient_buckets_issued_from_hooks_equal_the_flat_allreduce():
         # first bucket (the module only rank 0 ran), so everything waits for finish() there -- correct, only not overlapped
         assert early >= 1 if r == 0 else early == 0
         assert all(nobody_none) and not any(only0_none)
+
+
+class _SumOverRanksInBackward(torch.autograd.Function):
+    """A blocking default-group collective inside the backward pass (what a SyncBatchNorm layer's backward issues)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.clone()
+        dist.all_reduce(g)
+        return g
+
+
+def _bucket_sync_worker(rank, world, port, overlap, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from madrigal_amd.parallel import GradientBuckets, allreduce_gradients, destroy_bucket_groups
+        torch.manual_seed(0)
+        l1, l2, l3 = torch.nn.Linear(12, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 4)
+        side = torch.nn.Linear(16, 16)                 # MID-order parameters with a gradient on rank 0 only (rank 1 has no such rows)
+        params = list(l1.parameters()) + list(side.parameters()) + list(l2.parameters()) + list(l3.parameters())
+        x = torch.randn(8, 12, generator=torch.Generator().manual_seed(3 + rank))
+
+        def loss():
+            h = torch.relu(l1(x))
+            h = _SumOverRanksInBackward.apply(h)        # blocking collective of the default group between the buckets
+            h2 = l2(h)
+            if rank == 0:
+                h2 = h2 + side(h)
+            return (l3(torch.relu(h2)) ** 2).mean()
+        for p in params:
+            p.grad = None
+        loss().backward()
+        allreduce_gradients(params)
+        want = [p.grad.clone() for p in params]
+        outs = []
+        for _step in range(2):
+            for p in params:
+                p.grad = None
+            gb = GradientBuckets(params, bucket_bytes=600, overlap=overlap)
+            gb.arm()
+            loss().backward()
+            early = gb.next_bucket
+            gb.finish()
+            outs.append(all(torch.allclose(a, p.grad, rtol=0, atol=1e-7) for a, p in zip(want, params)))
+        ret[rank] = (outs, early, len(gb.buckets), id(gb.group))
+        destroy_bucket_groups()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_gradient_buckets_beside_a_blocking_collective_and_a_rank_without_a_mid_order_gradient(overlap):
+    """one rank lacks the gradient of a mid-order parameter (no uni-modal rows) and the backward pass itself issues a
+    blocking all-reduce (SyncBatchNorm): with a blocking bucket transport every bucket must wait for finish() (overlap=False is
+    what GradientBuckets selects by itself for gloo + device tensors); the non-blocking transport may overlap.  Either way the
+    sums equal the flat all-reduce, twice (the second step object reuses the process-wide bucket communicator)."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_sync_worker, args=(r, 2, port, overlap, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, "deadlock or crash"
+    for r in range(2):
+        outs, early, n_buckets, _ = ret[r]
+        assert all(outs) and n_buckets >= 3
+        if not overlap:
+            assert early == 0
