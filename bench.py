@@ -22,7 +22,13 @@ JSON line; it states the world size RCCL saw and a checksum of the all-gathered 
 
 Also in the line (N = 1 unless noted): "roofline_cfg5" -- BASELINE configs[4], 100 352 drugs x 1 024 outcomes = 1.03e13
 scores through the fp16 head with the row-statistics epilogue (nothing materialised), priced against the dense 16-bit
-MFMA peak (outcome-sharded over the ranks at N > 1); "finetune" -- DDI-finetune steps/s.
+MFMA peak (outcome-sharded over the ranks at N > 1); "finetune" -- DDI-finetune steps/s; "ranks" -- the rank normalisation
+of the score tensor the headline just produced (notebooks/normalize_scores.py) and the 5-seed ensembling on a subset;
+"pretrain" -- contrastive-pretraining steps/s.
+
+`python bench.py --gpus N` WITHOUT a launcher (no WORLD_SIZE in the environment) starts its N ranks itself: N fresh child
+processes of this script, created before this process has made any GPU call, each with RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR=127.0.0.1 / MASTER_PORT set; rank 0's line is this process's output and its exit code the worst child's.
 """
 from __future__ import annotations
 
@@ -276,6 +282,79 @@ def cpu_finetune_step(params, batch, bkg, config: str, n_outcomes: int, triples,
             "kg_edges_kept": f"1/{kg_edge_keep}", "loss": float(loss.detach())}
 
 
+def ranks_leg(scores, args):
+    """The product of the reference's scoring job is the normalised-rank tensor (notebooks/normalize_scores.py:36-85; README.md:43):
+    per outcome, the strict lower triangle of the [N,N] score slice ranked (1-based, ascending), divided by N(N-1)/2, mirrored.
+    Here: ``ops.rank_normalize`` over the outcomes the headline just scored (HIP events on the launch stream; the sort scratch is
+    bounded, so the call walks the outcomes in chunks), then the 5-seed ensembling of generate_embeddings.ipynb cells 18-20
+    (geometric mean of five rank tensors, ranked again) on a stated subset.  Algorithmic bytes per outcome: the M = N(N-1)/2 kept
+    scores read once (4 B each) and the N^2 normalised ranks written once (4 B each); the radix sort between them moves more
+    (DESIGN.md 4), which is exactly what the roofline fraction is there to show."""
+    import torch
+    from madrigal_amd import ops
+    L_all, N, _ = scores.shape
+    L = L_all if args.rank_outcomes < 0 else min(L_all, args.rank_outcomes)
+    s = scores[:L]
+    out = torch.empty_like(s)
+    ops.rank_normalize(s[:2], out=out[:2])                               # warm-up (code load, workspace)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    ops.rank_normalize(s, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = e0.elapsed_time(e1)
+    M = N * (N - 1) // 2
+    # size-independent checks inside the run: a permutation of 1..M per outcome (sum of ranks), symmetric, zero diagonal
+    denom = N * (N - 1) / 2
+    chk = out[: min(L, 4)].double()
+    want = M * (M + 1) / 2
+    perm_err = float(((chk.sum(dim=(1, 2)) / 2 * denom - want).abs() / want).max())
+    sym = bool(torch.equal(out[0], out[0].T)) and float(out[0].diagonal().abs().max()) == 0.0
+    alg = (M * 4.0 + N * N * 4.0) * L
+    res = {"metric": "rank-normalised scores/sec (normalize_scores)", "value": float(L) * N * N / (ms * 1e-3), "unit": "scores/s", "outcomes": L, "drugs": N,
+           "ms_total": ms, "ms_per_outcome": ms / L, "wall_ms": wall * 1e3, "dtype": "u32 order-preserving keys of fp32 scores, u32 ranks, f64 divide -> f32",
+           "checks": {"rank_sum_rel_err": perm_err, "symmetric_zero_diagonal": sym},
+           "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "mdg_rank_normalize (extract + 4 x 8-bit stable LSD radix passes + blocked rank store)",
+                        "algorithmic_bytes_per_outcome": alg / L, "formula": "(M x 4 B keys read + N^2 x 4 B ranks written) x outcomes / launch time"}}
+    del chk
+    # seed ensembling on a subset: 5 rank tensors of `sub` outcomes each (disjoint outcome slices of this run stand in for the seeds)
+    sub = max(1, min(8, L // 5))
+    seeds = [out[k * sub:(k + 1) * sub] for k in range(5)] if L >= 5 else [out[:1]] * 5
+    ops.ensemble_ranks([t_[:1] for t_ in seeds])
+    torch.cuda.synchronize()
+    e0.record()
+    ens = ops.ensemble_ranks(seeds)
+    e1.record()
+    torch.cuda.synchronize()
+    res["ensemble"] = {"seeds": 5, "outcomes": int(ens.shape[0]), "ms": e0.elapsed_time(e1), "ms_per_outcome": e0.elapsed_time(e1) / int(ens.shape[0]),
+                       "what": "gmean of 5 normalised-rank tensors then rank_normalize (generate_embeddings.ipynb cells 18-20)"}
+    del ens, out
+    if not args.no_cpu_baseline:
+        try:
+            import multiprocessing as mp
+            from oracle.bench_workers import rank_one
+            cores = host_threads()
+            n_proc = max(1, min(cores, 16))
+            ctx = mp.get_context("spawn")
+            t0 = time.perf_counter()
+            with ctx.Pool(n_proc) as pool:
+                dts = pool.map(rank_one, [(100 + i, N) for i in range(n_proc)])
+            wall_pool = time.perf_counter() - t0
+            per = sorted(d for d, _ in dts)[len(dts) // 2]
+            res["cpu_baseline"] = {"value": n_proc * float(N) * N / max(d for d, _ in dts), "unit": "scores/s", "cores": n_proc, "kind": "port",
+                                   "seconds_per_outcome_one_core": per, "pool_wall_s_incl_spawn": wall_pool,
+                                   "sample": f"the reference's run_slice (interval 1: mask, one default argsort + inverse permutation over all N^2 entries, divide, mirror) "
+                                             f"restated in numpy, {n_proc} outcomes of {N} x {N} on {n_proc} processes (one outcome per process, as its Pool().map); "
+                                             f"value = {n_proc} x N^2 / slowest worker's time"}
+        except Exception as e:
+            res["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+    return res
+
+
 def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend="nccl", precision="bf16"):
     """DDI-finetune steps/s on the same model and batch (train_ddi_batch.py:275-350, 'full_full' mode): zero_grad ->
     encode head and tail side (training mode: dropout, BatchNorm batch statistics) -> scores of the labelled triples
@@ -337,19 +416,27 @@ def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend
         x = torch.randn(live, d, device=dev)
         w = torch.randn(d, d, device=dev) * d ** -0.5
         with torch.no_grad():
-            for _ in range(2):
-                ops.linear(x, w, precision=precision, cache_weight=False)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                ops.linear(x, w, precision=precision, cache_weight=False)
-            e1.record()
-            torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
+            def timed(fn, reps=7):
+                for _ in range(2):
+                    fn()
+                ts = []
+                for _ in range(reps):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                return sorted(ts)[len(ts) // 2]
+            img = ops.pack_operand(x, precision)
+            if img is not None and d % 64 == 0:
+                # the kernel alone: in the step its x arrives packed by the producer (LayerNorm / the previous block's epilogue)
+                ms = timed(lambda: ops.linear_packed(img, live, w, precision=precision))
+            else:
+                ms = timed(lambda: ops.linear(x, w, precision=precision))
+            ms_call = timed(lambda: ops.linear(x, w, precision=precision, cache_weight=False))       # + the operand pre-pass of x and w
         ach = 2.0 * live * d * d / (ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
-                           "traffic": None, "kernel": "linear_kernel (wide fusion-transformer GEMM, operand pack included)", "kernel_ms": ms,
-                           "shape": [live, d, d], "formula": "2 M N K flop / launch time; peak = dense bf16 MFMA"
+                           "traffic": None, "kernel": "linear_pp_kernel (256 x 256 ping-pong dense block, wide fusion-transformer GEMM)", "kernel_ms": ms,
+                           "with_operand_prepass_ms": ms_call, "with_operand_prepass_tflops": 2.0 * live * d * d / (ms_call * 1e-3) / 1e12,
+                           "shape": [live, d, d], "formula": "2 M N K flop / kernel launch time (median of 7, HIP events); peak = dense bf16 MFMA"
                            + ("; the split-bf16 mode issues 3 products per element" if precision == "bf16x3" else "")}
     return out
 
@@ -418,9 +505,29 @@ def main():
     ap.add_argument("--stress-precision", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--finetune-precision", default="bf16", choices=["bf16", "bf16x3", "f32"], help="BASELINE configs[1] names bf16 for the "
                     "finetune step; the line also carries the bf16x3 (fp32-grade) step under finetune.fp32_grade")
+    ap.add_argument("--rank-outcomes", type=int, default=-1, help="ranks leg (N = 1): rank-normalise this many outcomes of the score tensor the "
+                    "headline produced; -1 = all of them, 0 = skip")
     ap.add_argument("--finetune-triples", type=int, default=1_000_000, help="positive triples; with 2 negatives each and both "
                     "directions (the reference's collation) 6x as many labelled triples per step")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: be the launcher.  This process has not touched the GPU (torch is not even imported yet) and never will:
+        # it starts one child per rank -- fresh processes, nothing is exec'ed from a process that initialised HIP -- and waits.
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=None if r == 0 else subprocess.DEVNULL))
+        codes = [p_.wait() for p_ in procs]
+        raise SystemExit(max(abs(c) for c in codes))
 
     import torch
     import torch.distributed as dist
@@ -459,7 +566,7 @@ def main():
         bkg = {"data": bkg["data"].to(dev), "drug_index_map": bkg["drug_index_map"].to(dev)}
         filler = torch.randn(N, 128, device=dev, generator=torch.Generator(device=dev).manual_seed(5))   # drugs absent from the KG (always masked)
 
-    def headline(mode: str) -> dict:
+    def headline(mode: str, keep_scores: bool = False) -> dict:
         """K timed steps of the whole job in one sharding mode -> timings of this rank (+ max over ranks)."""
         if mode == "strong":                          # ONE model of L outcomes, rank r scores outcomes [lo_l, hi_l)
             lo_l, hi_l = (rank * L) // world, ((rank + 1) * L) // world
@@ -476,7 +583,7 @@ def main():
         else:
             with torch.no_grad():
                 model.decoder.parametrizations.weight.original.copy_(w_orig)
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]       # start | encoded | gathered | scored
         keep = {}
 
         @torch.no_grad()
@@ -484,19 +591,22 @@ def main():
             if i is not None:
                 ev[i][0].record()
             if args.head_only:
+                if i is not None:
+                    ev[i][1].record()
                 z = all_gather_rows(z_shard, N, rank, world) if world > 1 else z_shard
                 ops.symmetrize(w_orig, out=w_sym)
                 if i is not None:
-                    ev[i][1].record()
+                    ev[i][2].record()
                 ops.bilinear_allpairs(z, z, w_sym[lo_l:hi_l], precision=args.precision, out=out)
             else:
-                z = generate_embeddings(model, batch, bkg, rank=rank, world=world, kg_filler=filler)
+                z = generate_embeddings(model, batch, bkg, rank=rank, world=world, kg_filler=filler,
+                                        on_encoded=None if i is None else ev[i][1].record)
                 model.decoder.symmetric_weight()          # W_sym (cached until the parameter changes)
                 if i is not None:
-                    ev[i][1].record()
+                    ev[i][2].record()
                 model.decoder(z, z, (lo_l, hi_l), out=out)
             if i is not None:
-                ev[i][2].record()
+                ev[i][3].record()
             keep["z"] = z
 
         for _ in range(args.warmup):
@@ -526,15 +636,37 @@ def main():
             coll.update(world_size_seen=dist.get_world_size(), z_checksum_spread_over_ranks=float(both[0] + both[1]),
                         z_block_checksums=[float(z[slice(*shard_range(N, r, world))].double().sum()) for r in range(world)],
                         op="all_gather_into_tensor of [N/G,128] fp32 blocks")
+        mean = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in ev) / args.steps
+        phases = [mean(0, 1), mean(1, 2), mean(2, 3)]        # this rank: encode+fuse of its drug block | all-gather(z) (+ W_sym) | head
+        if world > 1:                                        # every rank's phases in the line: the curve explains itself
+            allp = torch.tensor(phases, dtype=torch.float64, device=dev if backend != "gloo" else "cpu").repeat(world, 1) * 0
+            allp[rank] = torch.tensor(phases, dtype=torch.float64)
+            dist.all_reduce(allp)
+            per_rank = allp.cpu().tolist()
+        else:
+            per_rank = [phases]
         res = {"mode": mode, "dt": dt, "Lr": Lr, "L_total": L if mode == "strong" else L * world, "collective": coll,
-               "enc_ms": sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps,
-               "head_ms": sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps}     # head launch (+ its two operand-split pre-passes)
-        del out
+               "enc_ms": mean(0, 2),                          # encode+fuse incl. the exchange step
+               "head_ms": mean(2, 3),                         # head launch (+ its two operand-split pre-passes)
+               "phases_ms_per_rank": {"columns": ["encode_fuse_own_block", "all_gather_z", "head_own_outcomes"], "rows": per_rank}}
+        if keep_scores:
+            res["scores"] = out
+        else:
+            del out
         torch.cuda.empty_cache()
         return res
 
     main_mode = args.scaling if world > 1 else "strong"
-    h = headline(main_mode)
+    want_ranks = world == 1 and args.rank_outcomes != 0
+    h = headline(main_mode, keep_scores=want_ranks)
+    ranks = None
+    if want_ranks:
+        try:
+            ranks = ranks_leg(h.pop("scores"), args)
+        except Exception as e:
+            ranks = {"metric": "rank-normalised scores/sec", "value": None, "error": f"{type(e).__name__}: {e}"[:400]}
+        h.pop("scores", None)
+        torch.cuda.empty_cache()
     other = headline("weak" if main_mode == "strong" else "strong") if world > 1 else None
 
     finetune = None
@@ -592,6 +724,7 @@ def main():
                     # matrix-core ISSUE rate: the split-bf16 mode issues 3 products per score element
                     "mfma_issue_frac_16bit": per_launch * FLOP_PER_SCORE * nprod / (head_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
         roof.update({"kernel": HEAD_KERNEL[args.precision], "kernel_ms": head_ms, "traffic_source": traffic_src,
+                     "traffic_from_profile": traffic is not None,       # PMC passes cannot run inside this process: read from profiles/, not measured in this run
                      "algorithmic_bytes_per_launch": per_launch * BYTES_PER_SCORE,
                      "head_only_scores_per_s": per_launch / (head_ms * 1e-3), "encode_fuse_ms": enc_ms})
         per_gpu = f"{h['Lr']} of {L} outcomes per GPU (fixed job)" if main_mode == "strong" else f"{L} outcomes per GPU"
@@ -618,6 +751,9 @@ def main():
             line["roofline_cfg5"] = stress
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, L, encode=cpu_inputs)
+        line["phases_ms_per_rank"] = h["phases_ms_per_rank"]
+        if ranks is not None:
+            line["ranks"] = ranks
         if finetune is not None:
             line["finetune"] = finetune
         if pretrain is not None:

@@ -8,19 +8,34 @@
 //
 // Implementation: stable LSD radix sort, 4 passes x 8 bits, of (order-preserving uint32 key, position p
 // in the row-major enumeration of the lower triangle), all outcomes of a chunk in one launch per kernel
-// (blockIdx.y = outcome).  Per pass: per-tile digit histogram -> exclusive scan in (digit, tile) order ->
-// scatter with a stable in-tile rank built from wave ballots.  The last pass does not write the sorted
-// pairs: position q of payload p IS rank q+1, which is written to out[i,j] and out[j,i] directly.
+// (blockIdx.y = outcome).  Tiles of 8192 keys per 512-thread workgroup.  Per pass: per-tile digit histogram
+// (the first one inside the key-extraction pass) -> exclusive scan in (digit, tile) order -> scatter.
+// The scatter SORTS ITS TILE IN LDS first (stable): every wave owns 1024 consecutive keys and ranks them
+// 64 at a time against wave-private digit counters -- lanes holding the same digit find each other with 8
+// ballots, no barrier inside the loop -- then the tile leaves as runs of equal digits, consecutive lanes
+// writing consecutive addresses (32 keys = 128 B per run on average) instead of one 4-byte store per lane
+// and cache line.  The last pass does not write the sorted pairs: position q of payload p IS rank q+1, which is
+// written to out[i,j] and out[j,i] directly.
 // Ties: stable in p (= flat row-major index); numpy's default argsort in the reference is unstable, so
 // tie order there is implementation-defined ("Ties in rank normalisation").
-// HBM-bound integer work: ~ (4 + 4*16 + 8) bytes moved per score.
+// HBM-bound integer work, per key: extract 4 + 4, passes 4 + (4|8) + 8 each, last pass 8 of scattered
+// rank stores = 80 B (algorithmic bytes are the M key reads and the N^2 rank stores).
 #include "mdg_common.h"
 
 namespace {
 
-constexpr int TPB = 256;            // threads per block
-constexpr int ITEMS = 16;           // keys per thread
+#ifndef MDG_RANK_TPB
+#define MDG_RANK_TPB 512
+#endif
+#ifndef MDG_RANK_ITEMS
+#define MDG_RANK_ITEMS 16
+#endif
+constexpr int TPB = MDG_RANK_TPB;   // threads per block
+constexpr int WAVES = TPB / 64;
+constexpr int ITEMS = MDG_RANK_ITEMS;   // keys per thread
 constexpr int TILE = TPB * ITEMS;   // keys per block
+constexpr int WSPAN = TILE / WAVES; // consecutive keys ranked by one wave
+constexpr uint32_t NO_PAY = 0xFFFFFFFFu;   // payload of the padding behind the last key of the last tile
 
 __device__ __forceinline__ uint32_t order_key(float f) {
   const uint32_t u = __builtin_bit_cast(uint32_t, f);
@@ -36,58 +51,144 @@ __device__ __forceinline__ void tri_decode(int64_t p, int& i, int& j) {
   j = static_cast<int>(p - r * (r - 1) / 2);
 }
 
-__global__ __launch_bounds__(TPB) void extract_keys_kernel(const float* __restrict__ scores, uint32_t* __restrict__ keys, int N,
-                                                           int64_t M) {
-  const int64_t p = static_cast<int64_t>(blockIdx.x) * TPB + threadIdx.x;
-  if (p >= M) return;
-  const int64_t seg = blockIdx.y;
-  int i, j;
-  tri_decode(p, i, j);
-  keys[seg * M + p] = order_key(scores[(seg * N + i) * static_cast<int64_t>(N) + j]);
+// lanes of the wave that hold the same 8-bit digit as this lane (all 64 lanes take part)
+__device__ __forceinline__ uint64_t match_digit(uint32_t dg) {
+  uint64_t peers = ~0ull;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool bit = (dg >> b) & 1u;
+    const uint64_t bal = __ballot(bit);
+    peers &= bit ? bal : ~bal;
+  }
+  return peers;
 }
 
-// hist[(seg * 256 + digit) * nblk + blk]
-__global__ __launch_bounds__(TPB) void histogram_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ hist, int64_t M,
-                                                        int nblk, int shift) {
-  __shared__ uint32_t h[256];
-  h[threadIdx.x] = 0;
-  __syncthreads();
-  const int64_t seg = blockIdx.y;
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * TILE;
+// Digit counts of the wave's 1024 keys into its private counters cnt[256]; rank_out[k] = number of EARLIER keys of the wave
+// (in p order) with the same digit.  Wave-private LDS, in-order LDS queue: no barrier.
+template <bool WANT_RANK>
+__device__ __forceinline__ void wave_digit_ranks(const uint32_t (&key)[ITEMS], int shift, uint32_t* cnt, int lane, uint32_t (&rank_out)[ITEMS]) {
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
-    const int64_t p = base + k * TPB + threadIdx.x;
-    if (p < M) atomicAdd(&h[(keys[seg * M + p] >> shift) & 255u], 1u);
+    const uint32_t dg = (key[k] >> shift) & 255u;
+    const uint64_t peers = match_digit(dg);
+    const uint32_t before = __popcll(peers & lt);
+    const uint32_t old = cnt[dg];
+    if (before == 0) cnt[dg] = old + __popcll(peers);      // one leader per digit
+    if (WANT_RANK) rank_out[k] = old + before;
+    __builtin_amdgcn_wave_barrier();                       // keep the rounds' counter updates in program order
   }
-  __syncthreads();
-  hist[(seg * 256 + threadIdx.x) * nblk + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan of the 256*nblk counters of one outcome, in place; one workgroup per outcome
-__global__ __launch_bounds__(TPB) void scan_kernel(uint32_t* __restrict__ hist, int nblk) {
-  __shared__ uint32_t part[TPB];
-  uint32_t* h = hist + static_cast<int64_t>(blockIdx.x) * 256 * nblk;
-  const int64_t total = static_cast<int64_t>(256) * nblk;
-  const int64_t per = (total + TPB - 1) / TPB;
-  const int64_t a = threadIdx.x * per, b = (a + per < total) ? a + per : total;
-  uint32_t s = 0;
-  for (int64_t t = a; t < b; ++t) s += h[t];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (int t = 0; t < TPB; ++t) {
-      const uint32_t v = part[t];
-      part[t] = run;
-      run += v;
-    }
+// Digit counts only (no ranks): no-return LDS atomics on the wave's private counters.  Lanes sharing a digit serialise inside one
+// instruction (n lanes on a counter = n LDS cycles), which even for a wave of equal digits costs less than the 8-ballot match.
+__device__ __forceinline__ void wave_digit_counts(const uint32_t (&key)[ITEMS], int shift, uint32_t* cnt) {
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) __hip_atomic_fetch_add(&cnt[(key[k] >> shift) & 255u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// hist[(seg * 256 + digit) * nblk + blk] from the per-wave counters (valid keys only: the padding of the last tile was counted
+// as digit 255 and is taken out again)
+__device__ __forceinline__ void store_tile_histogram(const uint32_t (*cnt)[256], uint32_t* __restrict__ hist, int64_t seg, int nblk, int64_t base, int64_t M) {
+  const int d = threadIdx.x;
+  if (d < 256) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) c += cnt[w][d];
+    if (d == 255 && base + TILE > M) c -= static_cast<uint32_t>(base + TILE - M);
+    hist[(seg * 256 + d) * nblk + blockIdx.x] = c;
   }
+}
+
+// keys of the strict lower triangle in p order + the tile histogram of the lowest digit
+__global__ __launch_bounds__(TPB) void extract_keys_kernel(const float* __restrict__ scores, uint32_t* __restrict__ keys, uint32_t* __restrict__ hist,
+                                                           int N, int64_t M, int nblk) {
+  __shared__ uint32_t cnt[WAVES][256];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
   __syncthreads();
-  uint32_t run = part[threadIdx.x];
-  for (int64_t t = a; t < b; ++t) {
-    const uint32_t v = h[t];
-    h[t] = run;
-    run += v;
+  const int64_t seg = blockIdx.y, base = static_cast<int64_t>(blockIdx.x) * TILE;
+  const float* sc = scores + seg * static_cast<int64_t>(N) * N;
+  uint32_t key[ITEMS];
+  // (i, j) of the wave's first position by the closed form, once; every later position by stepping along the rows
+  int wi, wj;
+  {
+    const int64_t pw = base + wave * WSPAN < M ? base + wave * WSPAN : M - 1;
+    tri_decode(pw, wi, wj);
+    wi = __builtin_amdgcn_readfirstlane(wi);
+    wj = __builtin_amdgcn_readfirstlane(wj);
+  }
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int64_t p = base + wave * WSPAN + k * 64 + lane;
+    key[k] = 0xFFFFFFFFu;
+    int i = wi, j = wj + lane;                             // row i holds i entries
+    while (j >= i) { j -= i; ++i; }
+    if (p < M) {
+      key[k] = order_key(sc[static_cast<int64_t>(i) * N + j]);
+      keys[seg * M + p] = key[k];
+    }
+    wj += 64;                                              // the wave's next 64 positions (wave-uniform walk)
+    while (wj >= wi) { wj -= wi; ++wi; }
+  }
+  wave_digit_counts(key, 0, cnt[wave]);
+  __syncthreads();
+  store_tile_histogram(cnt, hist, seg, nblk, base, M);
+}
+
+__global__ __launch_bounds__(TPB) void histogram_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ hist, int64_t M,
+                                                        int nblk, int shift) {
+  __shared__ uint32_t cnt[WAVES][256];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
+  __syncthreads();
+  const int64_t seg = blockIdx.y, base = static_cast<int64_t>(blockIdx.x) * TILE;
+  uint32_t key[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int64_t p = base + wave * WSPAN + k * 64 + lane;
+    key[k] = p < M ? keys[seg * M + p] : 0xFFFFFFFFu;
+  }
+  wave_digit_counts(key, shift, cnt[wave]);
+  __syncthreads();
+  store_tile_histogram(cnt, hist, seg, nblk, base, M);
+}
+
+// exclusive scan of the 256*nblk counters of one outcome, in place; one workgroup per outcome, coalesced: every wave owns a
+// contiguous range and walks it 256 counters (16 bytes per lane) at a time, the next group's load issued before the scan of this one
+__global__ __launch_bounds__(1024) void scan_kernel(uint32_t* __restrict__ hist, int nblk) {
+  __shared__ uint32_t part[16];
+  u32x4* h = reinterpret_cast<u32x4*>(hist + static_cast<int64_t>(blockIdx.x) * 256 * nblk);
+  const int total = 64 * nblk;                                  // groups of 4 counters
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per = ((total + 15) / 16 + 63) / 64 * 64;           // groups per wave, a multiple of 64
+  const int a = wave * per, b = (a + per < total) ? a + per : total;
+  uint32_t s = 0;
+  for (int t = a + lane; t < b; t += 64) {
+    const u32x4 v = h[t];
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) part[wave] = s;
+  __syncthreads();
+  uint32_t run = 0;
+  for (int w = 0; w < wave; ++w) run += part[w];
+  u32x4 nxt = (a + lane < b) ? h[a + lane] : u32x4{0u, 0u, 0u, 0u};
+  for (int t0 = a; t0 < b; t0 += 64) {
+    const int t = t0 + lane;
+    const u32x4 v = nxt;
+    if (t0 + 64 < b) nxt = (t + 64 < b) ? h[t + 64] : u32x4{0u, 0u, 0u, 0u};
+    const uint32_t own = (v[0] + v[1]) + (v[2] + v[3]);
+    uint32_t inc = own;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
+    }
+    const uint32_t e0 = run + inc - own;
+    if (t < b) h[t] = u32x4{e0, e0 + v[0], e0 + v[0] + v[1], e0 + v[0] + v[1] + v[2]};
+    run += __shfl(inc, 63, 64);
   }
 }
 
@@ -96,62 +197,244 @@ __global__ __launch_bounds__(TPB) void scatter_kernel(const uint32_t* __restrict
                                                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ pay_out,
                                                       const uint32_t* __restrict__ offsets, float* __restrict__ out, int N,
                                                       int64_t M, int nblk, int shift, double denom) {
-  __shared__ uint32_t wave_hist[4][256];
-  __shared__ uint32_t counter[256];
+  __shared__ uint32_t cnt[WAVES][256];     // per-wave digit counts, then their exclusive prefix over the waves
+  __shared__ uint32_t dstart[256];         // first slot of digit d in the sorted tile
+  __shared__ uint32_t gofs[256];           // global position of slot 0 of digit d's run, minus dstart[d]
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t skey[TILE];
+  __shared__ uint32_t spay[TILE];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t seg = blockIdx.y;
-  counter[tid] = offsets[(seg * 256 + tid) * nblk + blockIdx.x];
-#pragma unroll
-  for (int w = 0; w < 4; ++w) wave_hist[w][tid] = 0;
+  for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
   __syncthreads();
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * TILE;
-  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int64_t seg = blockIdx.y, base = static_cast<int64_t>(blockIdx.x) * TILE;
+  uint32_t key[ITEMS], pay[ITEMS], rk[ITEMS];
+#pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
-    const int64_t p = base + k * TPB + tid;
+    const int64_t p = base + wave * WSPAN + k * 64 + lane;
     const bool valid = p < M;
-    const uint32_t key = valid ? keys_in[seg * M + p] : 0xFFFFFFFFu;
-    const uint32_t pay = FIRST ? static_cast<uint32_t>(p) : (valid ? pay_in[seg * M + p] : 0u);
-    const uint32_t dg = (key >> shift) & 255u;
-    uint64_t peers = __ballot(valid);
+    key[k] = valid ? keys_in[seg * M + p] : 0xFFFFFFFFu;          // padding: digit 255 in every pass, behind every real key of the tile
+    pay[k] = valid ? (FIRST ? static_cast<uint32_t>(p) : pay_in[seg * M + p]) : NO_PAY;
+  }
+  wave_digit_ranks<true>(key, shift, cnt[wave], lane, rk);
+  __syncthreads();
+  if (tid < 256) {                         // thread d: prefix over the waves, then over the digits
+    uint32_t run = 0;
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const bool bit = (dg >> b) & 1u;
-      const uint64_t bal = __ballot(bit);
-      peers &= bit ? bal : ~bal;
+    for (int w = 0; w < WAVES; ++w) {
+      const uint32_t c = cnt[w][tid];
+      cnt[w][tid] = run;
+      run += c;
     }
-    const uint32_t rank_in_wave = __popcll(peers & lt);
-    if (valid && rank_in_wave == 0) wave_hist[wave][dg] = __popcll(peers);      // one leader per (wave, digit)
-    __syncthreads();
-    uint32_t pos = 0;
-    if (valid) {
-      pos = counter[dg] + rank_in_wave;
-      for (int w = 0; w < wave; ++w) pos += wave_hist[w][dg];
-    }
-    __syncthreads();
-    {   // thread t owns digit t: advance the running counter, clear the per-wave counts
-      counter[tid] += wave_hist[0][tid] + wave_hist[1][tid] + wave_hist[2][tid] + wave_hist[3][tid];
+    uint32_t inc = run;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) wave_hist[w][tid] = 0;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
     }
-    if (valid) {
-      if constexpr (LAST) {
-        int i, j;
-        tri_decode(pay, i, j);
-        const float v = static_cast<float>(static_cast<double>(pos + 1) / denom);
-        float* o = out + seg * static_cast<int64_t>(N) * N;
-        o[static_cast<int64_t>(i) * N + j] = v;
-        o[static_cast<int64_t>(j) * N + i] = v;
-      } else {
-        keys_out[seg * M + pos] = key;
-        pay_out[seg * M + pos] = pay;
-      }
+    if (lane == 63) wsum[wave] = inc;
+    dstart[tid] = inc - run;               // exclusive within the wave's 64 digits
+  }
+  __syncthreads();
+  if (tid < 256) {
+    uint32_t add = 0;
+    for (int w = 0; w < wave; ++w) add += wsum[w];
+    const uint32_t ds = dstart[tid] + add;
+    dstart[tid] = ds;
+    gofs[tid] = offsets[(seg * 256 + tid) * nblk + blockIdx.x] - ds;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const uint32_t dg = (key[k] >> shift) & 255u;
+    const uint32_t pos = dstart[dg] + cnt[wave][dg] + rk[k];
+    skey[pos] = key[k];
+    spay[pos] = pay[k];
+  }
+  __syncthreads();
+  float* o = LAST ? out + seg * static_cast<int64_t>(N) * N : nullptr;
+#pragma unroll 4
+  for (int k = 0; k < ITEMS; ++k) {
+    const int idx = k * TPB + tid;
+    const uint32_t kk = skey[idx], pp = spay[idx];
+    if (pp == NO_PAY) continue;
+    const uint32_t g = gofs[(kk >> shift) & 255u] + static_cast<uint32_t>(idx);
+    if constexpr (LAST) {
+      int i, j;
+      tri_decode(pp, i, j);
+      const float v = static_cast<float>(static_cast<double>(g + 1u) / denom);
+      o[static_cast<int64_t>(i) * N + j] = v;
+      o[static_cast<int64_t>(j) * N + i] = v;
+    } else {
+      keys_out[seg * M + g] = kk;
+      pay_out[seg * M + g] = pp;
     }
-    __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(TPB) void zero_diag_kernel(float* __restrict__ out, int N) {
-  const int i = blockIdx.x * TPB + threadIdx.x;
+// ---- last pass, blocked: ranks delivered to 128 x 128 blocks of the lower triangle instead of one 4-byte store per entry ----
+// The last digit's scatter needs no data movement: the global position g of an element IS its rank - 1.  Writing it straight to
+// out[i,j] and out[j,i] costs two random 4-byte stores per pair (a 32-64 byte memory transaction each: 0.21 of the 0.49 ms per
+// 4096^2 outcome).  Instead the tile's (g, position inside the block) pairs are sorted IN LDS by the 128 x 128 block (bi >= bj) of
+// (i, j) they belong to -- no order needed inside a block, so LDS atomics hand out the slots -- and appended to that block's
+// region of the pair buffer (room reserved with one global atomic per tile and non-empty block; every block's size is known in
+// closed form, so the regions need no histogram).  A second kernel owns one block: it places the block's ranks in an LDS tile
+// and writes the rows of out[i, j] and of the mirrored out[j, i] as whole 512-byte pieces (the diagonal of out included).
+constexpr int BB = 128;                    // block edge
+constexpr int MAX_BLOCKS = 8192;           // LDS budget of the sorting kernel: N <= 16256; larger N take the direct scatter
+
+// first pair slot of block (bi, bj), bj <= bi: all rows above block row bi, then the blocks left of it
+__device__ __forceinline__ uint32_t block_base(int bi, int bj, int N) {
+  const int64_t r0 = static_cast<int64_t>(bi) * BB;
+  const int rcount = N - r0 < BB ? static_cast<int>(N - r0) : BB;
+  return static_cast<uint32_t>(r0 * (r0 - 1) / 2 + static_cast<int64_t>(bj) * rcount * BB);
+}
+
+__global__ __launch_bounds__(TPB) void rank_blocks_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ pay_in,
+                                                          const uint32_t* __restrict__ offsets, u32x2* __restrict__ pairs,
+                                                          uint32_t* __restrict__ fill, int N, int64_t M, int nblk, int n_blocks) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];            // [TILE] pairs (u32x2) | bcnt[n_blocks] | bdst[n_blocks]
+  __shared__ uint32_t cnt[WAVES][256];
+  __shared__ uint32_t gbase[256];
+  __shared__ uint32_t wsum[WAVES];
+  u32x2* spair = reinterpret_cast<u32x2*>(dyn);
+  uint32_t* bcnt = dyn + 2 * TILE;
+  uint32_t* bdst = bcnt + n_blocks;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
+  for (int i = tid; i < n_blocks; i += TPB) bcnt[i] = 0;
+  __syncthreads();
+  const int64_t seg = blockIdx.y, base = static_cast<int64_t>(blockIdx.x) * TILE;
+  uint32_t key[ITEMS], pay[ITEMS], rk[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int64_t p = base + wave * WSPAN + k * 64 + lane;
+    const bool valid = p < M;
+    key[k] = valid ? keys_in[seg * M + p] : 0xFFFFFFFFu;
+    pay[k] = valid ? pay_in[seg * M + p] : NO_PAY;
+  }
+  wave_digit_ranks<true>(key, 24, cnt[wave], lane, rk);
+  __syncthreads();
+  if (tid < 256) {
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      const uint32_t c = cnt[w][tid];
+      cnt[w][tid] = run;
+      run += c;
+    }
+    gbase[tid] = offsets[(seg * 256 + tid) * nblk + blockIdx.x];
+  }
+  __syncthreads();
+  uint32_t blk[ITEMS], slot[ITEMS];                       // key[] is reused for g, pay[] for the position inside the block
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    blk[k] = 0xFFFFFFFFu;
+    if (pay[k] == NO_PAY) continue;
+    const uint32_t dg = key[k] >> 24;
+    key[k] = gbase[dg] + cnt[wave][dg] + rk[k];
+    int i, j;
+    tri_decode(pay[k], i, j);
+    const int bi = i >> 7, bj = j >> 7;
+    blk[k] = static_cast<uint32_t>(bi * (bi + 1) / 2 + bj);
+    pay[k] = static_cast<uint32_t>(((i & 127) << 7) | (j & 127));
+    slot[k] = atomicAdd(&bcnt[blk[k]], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of bcnt in place (a contiguous run of blocks per thread) + room in every non-empty block's region
+  {
+    const int per = (n_blocks + TPB - 1) / TPB;
+    const int a = tid * per, b = a + per < n_blocks ? a + per : n_blocks;
+    uint32_t s = 0;
+    for (int t = a; t < b; ++t) s += bcnt[t];
+    uint32_t inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - s;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    for (int t = a; t < b; ++t) {
+      const uint32_t c = bcnt[t];
+      bcnt[t] = run;
+      if (c) {
+        int bi = static_cast<int>((sqrtf(8.0f * static_cast<float>(t) + 1.0f) - 1.0f) * 0.5f);
+        while (bi * (bi + 1) / 2 > t) --bi;
+        while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+        const int bj = t - bi * (bi + 1) / 2;
+        bdst[t] = block_base(bi, bj, N) + atomicAdd(&fill[seg * n_blocks + t], c) - run;
+      }
+      run += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k)
+    if (blk[k] != 0xFFFFFFFFu) spair[bcnt[blk[k]] + slot[k]] = u32x2{key[k], pay[k] | (blk[k] << 14)};
+  __syncthreads();
+  const int n_valid = static_cast<int>(M - base < TILE ? M - base : TILE);
+  u32x2* dst = pairs + seg * M;
+#pragma unroll 4
+  for (int k = 0; k < ITEMS; ++k) {
+    const int idx = k * TPB + tid;
+    if (idx >= n_valid) break;
+    const u32x2 v = spair[idx];
+    dst[bdst[v[1] >> 14] + static_cast<uint32_t>(idx)] = u32x2{v[0], v[1] & 16383u};
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(TPB) void rank_block_write_kernel(const u32x2* __restrict__ pairs, float* __restrict__ out, int N, int64_t M,
+                                                               int n_blocks, double denom) {
+  __shared__ float tile[BB][BB + 1];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int64_t seg = blockIdx.y;
+  int bi = static_cast<int>((sqrtf(8.0f * static_cast<float>(t) + 1.0f) - 1.0f) * 0.5f);
+  while (bi * (bi + 1) / 2 > t) --bi;
+  while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+  const int bj = t - bi * (bi + 1) / 2;
+  const int r0 = bi * BB, c0 = bj * BB;
+  const int rcount = N - r0 < BB ? N - r0 : BB;
+  const bool diag = bi == bj;
+  const int count = diag ? rcount * (rcount - 1) / 2 : rcount * BB;
+  if (diag) {
+    for (int e = tid; e < BB; e += TPB) tile[e][e] = 0.f;
+  }
+  const u32x2* src = pairs + seg * M + block_base(bi, bj, N);
+  for (int e = tid; e < count; e += TPB) {
+    const u32x2 v = src[e];
+    const float val = static_cast<float>(static_cast<double>(v[0] + 1u) / denom);
+    const int r = v[1] >> 7, c = v[1] & 127;
+    tile[r][c] = val;
+    if (diag) tile[c][r] = val;
+  }
+  __syncthreads();
+  float* o = out + seg * static_cast<int64_t>(N) * N;
+  const int q = tid & 31, rr = tid >> 5;                   // 32 lanes x 4 columns cover a 128-wide row; 16 rows per sweep
+  const int ccount = diag ? rcount : BB;
+  // rows of out[i, j]
+  for (int r = rr; r < rcount; r += TPB / 32) {
+    float* row = o + static_cast<int64_t>(r0 + r) * N + c0;
+    if (VEC && 4 * q + 3 < ccount) *reinterpret_cast<f32x4*>(row + 4 * q) = f32x4{tile[r][4 * q], tile[r][4 * q + 1], tile[r][4 * q + 2], tile[r][4 * q + 3]};
+    else
+      for (int e = 0; e < 4; ++e)
+        if (4 * q + e < ccount) row[4 * q + e] = tile[r][4 * q + e];
+  }
+  if (diag) return;
+  // rows of the mirrored block out[j, i]
+  for (int c = rr; c < BB; c += TPB / 32) {
+    float* row = o + static_cast<int64_t>(c0 + c) * N + r0;
+    if (VEC && 4 * q + 3 < rcount) *reinterpret_cast<f32x4*>(row + 4 * q) = f32x4{tile[4 * q][c], tile[4 * q + 1][c], tile[4 * q + 2][c], tile[4 * q + 3][c]};
+    else
+      for (int e = 0; e < 4; ++e)
+        if (4 * q + e < rcount) row[4 * q + e] = tile[4 * q + e][c];
+  }
+}
+
+__global__ __launch_bounds__(256) void zero_diag_kernel(float* __restrict__ out, int N) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < N) out[(static_cast<int64_t>(blockIdx.y) * N + i) * N + i] = 0.f;
 }
 
@@ -187,7 +470,9 @@ extern "C" size_t mdg_rank_normalize_workspace_bytes(int64_t n_outcomes, int64_t
   if (n_outcomes <= 0 || N < 2) return 0;
   const size_t M = static_cast<size_t>(N) * (N - 1) / 2;
   const size_t nblk = (M + TILE - 1) / TILE;
-  return 4 * a256(static_cast<size_t>(n_outcomes) * M * 4) + a256(static_cast<size_t>(n_outcomes) * 256 * nblk * 4);
+  const size_t nb = (static_cast<size_t>(N) + BB - 1) / BB;
+  return 4 * a256(static_cast<size_t>(n_outcomes) * M * 4) + a256(static_cast<size_t>(n_outcomes) * 256 * nblk * 4) +
+         a256(static_cast<size_t>(n_outcomes) * (nb * (nb + 1) / 2) * 4);
 }
 
 extern "C" int mdg_rank_normalize(const float* scores, float* out, int64_t n_outcomes, int64_t N, void* workspace,
@@ -197,7 +482,7 @@ extern "C" int mdg_rank_normalize(const float* scores, float* out, int64_t n_out
   MDG_CHECK_ARG(scores && out, "mdg_rank_normalize: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned L = static_cast<unsigned>(n_outcomes);
-  hipLaunchKernelGGL(zero_diag_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N, TPB)), L), dim3(TPB), 0, st, out, static_cast<int>(N));
+  hipLaunchKernelGGL(zero_diag_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N, 256)), L), dim3(256), 0, st, out, static_cast<int>(N));
   if (N < 2) { MDG_CHECK_LAUNCH("mdg_rank_normalize"); return MDG_OK; }
   const int64_t M = N * (N - 1) / 2;
   const int nblk = static_cast<int>(mdg_cdiv(M, TILE));
@@ -208,25 +493,39 @@ extern "C" int mdg_rank_normalize(const float* scores, float* out, int64_t n_out
   }
   char* ws = static_cast<char*>(workspace);
   const size_t kb = a256(static_cast<size_t>(n_outcomes) * M * 4);
-  uint32_t* k0 = reinterpret_cast<uint32_t*>(ws);
-  uint32_t* k1 = reinterpret_cast<uint32_t*>(ws + kb);
-  uint32_t* p0 = reinterpret_cast<uint32_t*>(ws + 2 * kb);
+  uint32_t* k0 = reinterpret_cast<uint32_t*>(ws);          // k0 | p0 adjacent: together they hold the last pass's (rank, position) pairs
+  uint32_t* p0 = reinterpret_cast<uint32_t*>(ws + kb);
+  uint32_t* k1 = reinterpret_cast<uint32_t*>(ws + 2 * kb);
   uint32_t* p1 = reinterpret_cast<uint32_t*>(ws + 3 * kb);
   uint32_t* hist = reinterpret_cast<uint32_t*>(ws + 4 * kb);
+  uint32_t* fill = reinterpret_cast<uint32_t*>(ws + 4 * kb + a256(static_cast<size_t>(n_outcomes) * 256 * nblk * 4));
+  const int64_t nbr = mdg_cdiv(N, BB), n_blocks = nbr * (nbr + 1) / 2;
+  static MdgEnvInt direct_sw{"MDG_RANKS_DIRECT", 0};        // 1: the last pass stores the ranks one by one (the large-N path) at any N
+  const bool blocked = n_blocks <= MAX_BLOCKS && !direct_sw.get();
   const double denom = static_cast<double>(N) * static_cast<double>(N - 1) / 2.0;
-  hipLaunchKernelGGL(extract_keys_kernel, dim3(static_cast<unsigned>(mdg_cdiv(M, TPB)), L), dim3(TPB), 0, st, scores, k0, static_cast<int>(N), M);
   const dim3 grid(static_cast<unsigned>(nblk), L);
+  hipLaunchKernelGGL(extract_keys_kernel, grid, dim3(TPB), 0, st, scores, k0, hist, static_cast<int>(N), M, nblk);
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 8 * pass;
     uint32_t* kin = (pass & 1) ? k1 : k0;
     uint32_t* kout = (pass & 1) ? k0 : k1;
     uint32_t* pin = (pass & 1) ? p1 : p0;
     uint32_t* pout = (pass & 1) ? p0 : p1;
-    hipLaunchKernelGGL(histogram_kernel, grid, dim3(TPB), 0, st, kin, hist, M, nblk, shift);
-    hipLaunchKernelGGL(scan_kernel, dim3(L), dim3(TPB), 0, st, hist, nblk);
+    if (pass > 0) hipLaunchKernelGGL(histogram_kernel, grid, dim3(TPB), 0, st, kin, hist, M, nblk, shift);
+    hipLaunchKernelGGL(scan_kernel, dim3(L), dim3(1024), 0, st, hist, nblk);
     if (pass == 0)
       hipLaunchKernelGGL((scatter_kernel<true, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, static_cast<int>(N), M, nblk, shift, denom);
-    else if (pass == 3)
+    else if (pass == 3 && blocked) {
+      (void)hipMemsetAsync(fill, 0, static_cast<size_t>(n_outcomes) * n_blocks * 4, st);
+      u32x2* pairs = reinterpret_cast<u32x2*>(k0);            // pass 3 reads k1 / p1
+      const size_t lds = static_cast<size_t>(2 * TILE + 2 * n_blocks) * 4;
+      hipLaunchKernelGGL(rank_blocks_kernel, grid, dim3(TPB), lds, st, kin, pin, hist, pairs, fill, static_cast<int>(N), M, nblk, static_cast<int>(n_blocks));
+      const dim3 bgrid(static_cast<unsigned>(n_blocks), L);
+      if (N % 4 == 0 && mdg_aligned16(out))
+        hipLaunchKernelGGL(rank_block_write_kernel<true>, bgrid, dim3(TPB), 0, st, pairs, out, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
+      else
+        hipLaunchKernelGGL(rank_block_write_kernel<false>, bgrid, dim3(TPB), 0, st, pairs, out, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
+    } else if (pass == 3)
       hipLaunchKernelGGL((scatter_kernel<false, true>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, static_cast<int>(N), M, nblk, shift, denom);
     else
       hipLaunchKernelGGL((scatter_kernel<false, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, static_cast<int>(N), M, nblk, shift, denom);

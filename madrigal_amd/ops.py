@@ -181,6 +181,24 @@ def packed_weight_image(w: torch.Tensor, prec: int):
     return img
 
 
+def pack_operand(x: torch.Tensor, precision="bf16x3") -> Optional[torch.Tensor]:
+    """Operand image of a 2-D fp32 activation for ``linear_packed`` (what mdg_linear's own pre-pass writes); None where the
+    arithmetic mode takes the tensor as it is."""
+    x = _f32_cuda(x, "x", 2)
+    M, K = x.shape
+    if K % 4 or x.stride(1) != 1 or x.stride(0) % 4:
+        x = _pad_last(x).contiguous()
+        K = x.shape[1]
+    prec = _prec(precision)
+    nbytes = int(lib().mdg_pack_operand_bytes(_c64(M), _c64(K), _c(prec)))
+    if nbytes == 0:
+        return None
+    img = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(lib().mdg_pack_operand(_ptr(x), _c64(x.stride(0)), _c64(M), _c64(K), _c(prec), _ptr(img), ctypes.c_size_t(nbytes), _stream(x)),
+          "mdg_pack_operand")
+    return img
+
+
 def _rows2d(x: torch.Tensor, name: str):
     """[..., K] fp32 cuda tensor -> (2-D view/copy with unit inner stride and ld % 4 == 0, leading shape)."""
     x = _f32_cuda(x, name)

@@ -48,13 +48,17 @@ def slice_batch(batch: dict, lo: int, hi: int) -> dict:
 
 @torch.no_grad()
 def generate_embeddings(model, batch: dict, batch_kg: dict, masks: Optional[torch.Tensor] = None, rank: int = 0,
-                        world: int = 1, kg_filler: Optional[torch.Tensor] = None) -> torch.Tensor:
+                        world: int = 1, kg_filler: Optional[torch.Tensor] = None, on_encoded=None) -> torch.Tensor:
     """z[N,128] for every drug of ``batch`` (``model.encoder`` on all drugs, generate_embeddings.ipynb raw
-    line 226).  With ``world > 1`` each rank encodes its block and the blocks are all-gathered."""
+    line 226).  With ``world > 1`` each rank encodes its block and the blocks are all-gathered.  ``on_encoded``: called
+    (no arguments) between the rank's own encode+fuse and the exchange step -- bench.py records a HIP event there."""
     masks = batch["masks"] if masks is None else masks
     n = int(batch["drugs"].shape[0])
     if world == 1:
-        return model.encoder(batch["drugs"], masks, batch["strs"], batch_kg, batch["cv"], batch["tx"], kg_filler=kg_filler)
+        z = model.encoder(batch["drugs"], masks, batch["strs"], batch_kg, batch["cv"], batch["tx"], kg_filler=kg_filler)
+        if on_encoded is not None:
+            on_encoded()
+        return z
     lo, hi = shard_range(n, rank, world)
     local = batch.get("_shards", {}).get((lo, hi))
     if local is None:
@@ -66,6 +70,8 @@ def generate_embeddings(model, batch: dict, batch_kg: dict, masks: Optional[torc
     kg_shard = (rank, world, None) if os.environ.get("MDG_SHARD_KG", "1") != "0" else None
     z_local = model.encoder(local["drugs"], masks[lo:hi], local["strs"], batch_kg, local["cv"], local["tx"], kg_filler=kg_filler,
                             kg_shard=kg_shard)
+    if on_encoded is not None:
+        on_encoded()
     return all_gather_rows(z_local.contiguous(), n, rank, world)
 
 
