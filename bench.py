@@ -295,7 +295,7 @@ def ranks_leg(scores, args):
     L_all, N, _ = scores.shape
     L = L_all if args.rank_outcomes < 0 else min(L_all, args.rank_outcomes)
     s = scores[:L]
-    out = torch.empty_like(s)
+    out = ops.empty_scores(L, N, N, s.device)
     ops.rank_normalize(s[:2], out=out[:2])                               # warm-up (code load, workspace)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -575,7 +575,7 @@ def main():
             lo_l, hi_l, w_seed = 0, L, 1000 + rank
         w_orig = (torch.randn(L, 128, 128, generator=torch.Generator().manual_seed(w_seed)) / 128 ** 0.5).to(dev)
         Lr = hi_l - lo_l
-        out = torch.empty(Lr, N, N, dtype=torch.float32, device=dev)
+        out = ops.empty_scores(Lr, N, N, dev)          # rows on 128-byte lines: a plain contiguous tensor when N % 32 == 0
         if args.head_only:
             lo, hi = shard_range(N, rank, world)
             z_shard = torch.randn(N, 128, generator=torch.Generator().manual_seed(0))[lo:hi].to(dev)

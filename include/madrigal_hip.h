@@ -97,6 +97,13 @@ size_t mdg_bilinear_allpairs_workspace_bytes(int64_t n_head, int64_t n_tail, int
 int mdg_bilinear_allpairs(const float* z_head, const float* z_tail, const float* w_sym, float* out,
                           int64_t n_head, int64_t n_tail, int64_t n_labels, int64_t D, int precision,
                           int epilogue, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with a row pitch: out[(l * n_head + i) * ldo + j], ldo >= n_tail floats.  The MI355X-native layout of a score tensor
+ * whose n_tail is not a multiple of 32: with ldo = n_tail rounded up to 32 every row starts on a 128-byte line and the head's
+ * 16-byte stores stay whole-line (a contiguous [L,N,N] with such an N is written correctly but with cache-line-straddling
+ * stores, 2-3x slower).  The padding columns [n_tail, ldo) may be overwritten with unspecified values. */
+int mdg_bilinear_allpairs_ld(const float* z_head, const float* z_tail, const float* w_sym, float* out, int64_t ldo, int64_t n_head,
+                             int64_t n_tail, int64_t n_labels, int64_t D, int precision, int epilogue, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------ dense blocks ---- */
 
@@ -239,6 +246,9 @@ size_t mdg_rank_normalize_workspace_bytes(int64_t n_outcomes, int64_t N);
  * mask value). */
 int mdg_rank_normalize(const float* scores, float* out, int64_t n_outcomes, int64_t N, void* workspace, size_t workspace_bytes,
                        void* stream);
+/* The same on row-pitched tensors (mdg_bilinear_allpairs_ld): scores[(l * N + i) * lds + j], out[(l * N + i) * ldo + j]. */
+int mdg_rank_normalize_ld(const float* scores, int64_t lds, float* out, int64_t ldo, int64_t n_outcomes, int64_t N, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* Elementwise geometric mean of K <= 8 equally shaped fp32 tensors (the 5-seed ensembling of normalised ranks,
  * scipy.stats.mstats.gmean in notebooks/generate_embeddings.ipynb): out = exp(mean_k log x_k) in fp32; 0 where any

@@ -42,6 +42,9 @@ struct BilinearArgs {
   TileSrc w;          // W_sym (all labels); nrows = D
   float* out;
   int64_t n_head, n_tail, n_labels;
+  int64_t ldo;          // row pitch of out in floats (n_tail)
+  const float* zt_raw;  // z_tail and W_sym as the caller passed them (fp32): the column strip of the symmetric sweep rounds them itself
+  const float* w_raw;
   int stagger;          // per-workgroup sweep start (HBM channel spreading)
   int stagger_waves;    // counted pipeline: younger half of the waves stores one stage late
   int loaders;          // conservative pipeline: waves that issue the LDS-DMA (1, 2 or 4)
@@ -378,10 +381,10 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
   if (p.stamps && tid == 0) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
   const int nst = static_cast<int>((p.n_tail + BN - 1) / BN);
   const int64_t slab_rows = (p.n_head - row0) < BM ? (p.n_head - row0) : BM;
-  float* const out_slab = (EPI == MDG_EPI_ROWSTATS) ? nullptr : p.out + (l * p.n_head + row0) * p.n_tail;
+  float* const out_slab = (EPI == MDG_EPI_ROWSTATS) ? nullptr : p.out + (l * p.n_head + row0) * p.ldo;
   __amdgpu_buffer_rsrc_t rsrc;
   if constexpr (EPI != MDG_EPI_ROWSTATS)
-    rsrc = __builtin_amdgcn_make_buffer_rsrc(out_slab, 0, static_cast<int>(slab_rows * p.n_tail * 4), 0x00020000);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(out_slab, 0, static_cast<int>(slab_rows * p.ldo * 4), 0x00020000);
   f32x16 rsum, rmax, rsum2, rmax2;       // (second pair: row block 1 when RB == 2)
   if constexpr (EPI == MDG_EPI_ROWSTATS) {
 #pragma unroll
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
       } else {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-          const int64_t e = static_cast<int64_t>(wave * 32 + acc_row(v, h)) * p.n_tail + col;
+          const int64_t e = static_cast<int64_t>(wave * 32 + acc_row(v, h)) * p.ldo + col;
           const unsigned off = col_ok ? static_cast<unsigned>(e * 4) : 0xFFFFFFFFu;   // out of range => dropped
           float val = acc[t][v];
           if constexpr (EPI == MDG_EPI_STORE_SIGMOID) val = 1.0f / (1.0f + expf(-val));
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
       u32x4 o[8];
       auto out_store = [&](int q, int64_t col0) {                     // rows 4q .. 4q+3 of the wave's tile, 1 KB
         const int64_t col = col0 + scol;
-        const int64_t e = static_cast<int64_t>(wave * 32 + 4 * q + srow) * p.n_tail + col;
+        const int64_t e = static_cast<int64_t>(wave * 32 + 4 * q + srow) * p.ldo + col;
         const unsigned off = col < p.n_tail ? static_cast<unsigned>(e * 4) : 0xFFFFFFFFu;       // out of range => dropped
         u32x4 v = o[q];
         if constexpr (EPI == MDG_EPI_STORE_SIGMOID) {
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_kernel(const Bil
         compute_tile_spread<MODE>(At, cur, r, h, acc, [&](int k) {
           const int t = k >> 4, v = k & 15;
           const int64_t col = hc0 + 32 * t + r;
-          const int64_t e = static_cast<int64_t>(wave * 32 + acc_row(v, h)) * p.n_tail + col;
+          const int64_t e = static_cast<int64_t>(wave * 32 + acc_row(v, h)) * p.ldo + col;
           const unsigned off = col < p.n_tail ? static_cast<unsigned>(e * 4) : 0xFFFFFFFFu;    // out of range => dropped
           float val = held[t][v];
           if constexpr (EPI == MDG_EPI_STORE_SIGMOID) val = 1.0f / (1.0f + expf(-val));
@@ -910,14 +913,19 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_sym_kernel(const
   // clock under that form, MI355X_MICROARCH.md DVFS give-back (7)); exact fp32 stays on 32x32x2
   constexpr bool M16 = (MODE != MDG_PREC_F32);
   char* const stg = smem + 2 * STAGE_BYTES + wave * 8192;
-  const int64_t l = blockIdx.y, N = p.n_tail;
+  const int64_t l = blockIdx.y, N = p.n_tail, ld = p.ldo;
+  // Every store writes 4 consecutive columns.  With a row pitch that leaves room (ld >= N rounded up to 4: the pitched layout,
+  // rows 128-byte aligned) the last group of a row runs into the padding.  In the contiguous layout (ld == N) with N % 4 != 0
+  // that group is dropped here and the N % 4 last columns come from bilinear_strip_kernel; rows then start at any 4-byte
+  // alignment, the 16-byte stores are unaligned and straddle cache lines (correct, 2-3x slower: partial-line writes).
+  const int64_t N4 = (ld >= ((N + 3) & ~static_cast<int64_t>(3))) ? N : (N & ~static_cast<int64_t>(3));
   const int nst = static_cast<int>((N + BN - 1) / BN);
   const int nb = static_cast<int>((N + BM - 1) / BM);
   const int srow = lane >> 4, scol = 4 * (lane & 15);            // row-major store role: row in a group of 4, first of 4 columns
   const int mrow = lane >> 3, mchunk = lane & 7;                 // mirrored store role: tile column in a group of 8, 16-B chunk of 32 rows
-  float* const out_l = p.out + l * N * N;
-  // whole [N,N] slab of this outcome (N * N * 4 < 2^32 is checked by the launcher): the mirrored stores land anywhere in it
-  const __amdgpu_buffer_rsrc_t rs_all = __builtin_amdgcn_make_buffer_rsrc(out_l, 0, static_cast<int>(static_cast<unsigned>(N * N * 4)), 0x00020000);
+  float* const out_l = p.out + l * N * ld;
+  // whole [N,ld] slab of this outcome (N * ld * 4 < 2^32 is checked by the launcher): the mirrored stores land anywhere in it
+  const __amdgpu_buffer_rsrc_t rs_all = __builtin_amdgcn_make_buffer_rsrc(out_l, 0, static_cast<int>(static_cast<unsigned>(N * ld * 4)), 0x00020000);
   auto sig = [&](u32x4 v) {
     if constexpr (EPI == MDG_EPI_STORE_SIGMOID) {
       const f32x4 x = __builtin_bit_cast(f32x4, v);
@@ -983,17 +991,17 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_sym_kernel(const
     const int start = p.stagger ? static_cast<int>((blockIdx.x * 5u + blockIdx.y * 3u) % static_cast<unsigned>(nt)) : 0;
     auto tile_of = [&](int s) { int t = s + start; return t0 + (t >= nt ? t - nt : t); };
     const int64_t slab_rows = (N - row0) < BM ? (N - row0) : BM;
-    const __amdgpu_buffer_rsrc_t rs_rows = __builtin_amdgcn_make_buffer_rsrc(out_l + row0 * N, 0, static_cast<int>(slab_rows * N * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_rows = __builtin_amdgcn_make_buffer_rsrc(out_l + row0 * ld, 0, static_cast<int>(slab_rows * ld * 4), 0x00020000);
     u32x4 o[8];
     auto store_rows = [&](int q, int64_t col0) {                      // rows 4q..4q+3 of the wave's tile: 4 x 256 B
       const int64_t col = col0 + scol;
-      const int64_t e = static_cast<int64_t>(wave * 32 + 4 * q + srow) * N + col;
-      const unsigned off = col < N ? static_cast<unsigned>(e * 4) : 0xFFFFFFFFu;              // out of range => dropped
+      const int64_t e = static_cast<int64_t>(wave * 32 + 4 * q + srow) * ld + col;
+      const unsigned off = col < N4 ? static_cast<unsigned>(e * 4) : 0xFFFFFFFFu;             // out of range => dropped
       __builtin_amdgcn_raw_buffer_store_b128(sig(o[q]), rs_rows, off, 0, AUX);
     };
     auto store_mirror = [&](int q, int64_t col0, bool on) {           // tile columns 8q..8q+7 as rows of the mirrored block: 8 x 128 B
       const int64_t mr = col0 + 8 * q + mrow, mc = row0 + wave * 32 + 4 * mchunk;
-      const unsigned off = (on && mr < N && mc < N) ? static_cast<unsigned>((mr * N + mc) * 4) : 0xFFFFFFFFu;
+      const unsigned off = (on && mr < N && mc < N4) ? static_cast<unsigned>((mr * ld + mc) * 4) : 0xFFFFFFFFu;
       __builtin_amdgcn_raw_buffer_store_b128(sig(o[q]), rs_all, off, 0, AUX);
     };
     stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, buf0, wave, lane, NW);
@@ -1081,6 +1089,58 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_sym_kernel(const
   }
 }
 
+// ---- the N % 4 last columns of the symmetric sweep's matrix ------------------------------------------------------------
+// The sweep stores groups of 4 columns; for N % 4 != 0 the columns [N4, N) of every row are left to this kernel:
+// S[l, i, t] = z_i . (W_l z_t) -- W_l is symmetric, so this is the association the sweep's MIRRORED entries carry.  One workgroup
+// per (256 rows, outcome); U_t = W_l z_t (at most 3 vectors of 128) is recomputed by every workgroup, then one row per thread.
+// Operand roundings of the arithmetic mode are applied as the sweep applies them (16-bit modes: W, z rounded once, the
+// intermediate vector rounded once; the split-bf16 mode is fp32-grade and runs in plain fp32); the fp32 summation order differs
+// from the matrix cores', i.e. the strip agrees with the general kernel to the mode's accumulation noise, not bit for bit.
+template <int MODE>
+__device__ __forceinline__ float round_operand(float v) {
+  if constexpr (MODE == MDG_PREC_BF16) return static_cast<float>(static_cast<__bf16>(v));
+  else if constexpr (MODE == MDG_PREC_F16) return static_cast<float>(static_cast<_Float16>(v));
+  else return v;
+}
+
+template <int MODE, int EPI>
+__global__ __launch_bounds__(256) void bilinear_strip_kernel(const BilinearArgs p) {
+  __shared__ float U[3][D];
+  const int64_t l = blockIdx.y, N = p.n_tail, N4 = N & ~static_cast<int64_t>(3);
+  const int nt = static_cast<int>(N - N4), tid = threadIdx.x;
+  const float* W = p.w_raw + l * D * D;
+  for (int e = tid; e < nt * D; e += 256) {
+    const int t = e / D, k = e - t * D;
+    const float* wr = W + static_cast<int64_t>(k) * D;
+    const float* zt = p.zt_raw + (N4 + t) * D;
+    float s = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < D; j += 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(wr + j), b = *reinterpret_cast<const f32x4*>(zt + j);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s += round_operand<MODE>(a[c]) * round_operand<MODE>(b[c]);
+    }
+    U[t][k] = round_operand<MODE>(s);
+  }
+  __syncthreads();
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + tid;
+  if (i >= N) return;
+  const float* zi = p.z_head + i * D;
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int k = 0; k < D; k += 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(zi + k);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float av = round_operand<MODE>(a[c]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] += av * U[t < nt ? t : 0][k + c];
+    }
+  }
+  float* o = p.out + (l * N + i) * p.ldo + N4;
+  for (int t = 0; t < nt; ++t) o[t] = (EPI == MDG_EPI_STORE_SIGMOID) ? 1.0f / (1.0f + expf(-acc[t])) : acc[t];
+}
+
 // ---- pre-passes ---------------------------------------------------------------------------
 __global__ void symmetrize_kernel(const float* __restrict__ w, float* __restrict__ ws, int64_t L, int D_) {
   const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1133,15 +1193,15 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
   static MdgEnvInt variant_sw{"MDG_BILINEAR_VARIANT", 0};
   int variant = variant_sw.get();
   if (variant < 0 || variant > 2 || a.pipeline != 0) variant = 0;
-  if (variant == 2 && ((a.n_tail & 3) != 0 || !mdg_aligned16(a.out))) variant = 0;     // 16-byte stores need aligned rows
+  if (variant == 2 && ((a.ldo & 3) != 0 || a.ldo < ((a.n_tail + 3) & ~static_cast<int64_t>(3)) || !mdg_aligned16(a.out))) variant = 0;     // 16-byte stores need aligned rows
   const size_t lds2 = lds + static_cast<size_t>(NW) * 8192;
   // Symmetric sweep (z_head and z_tail are the same matrix): half the matrix work, every off-diagonal tile stored twice.
   // Default for that case; MDG_BILINEAR_SYMMETRIC=0 switches it off.
   if constexpr (NW == 8) {
     static MdgEnvInt sym_sw{"MDG_BILINEAR_SYMMETRIC", 1};
     const bool want = sym_sw.get() != 0;
-    if (want && a.symmetric && a.pipeline == 0 && (epilogue == MDG_EPI_STORE || epilogue == MDG_EPI_STORE_SIGMOID) && (a.n_tail & 3) == 0 &&
-        mdg_aligned16(a.out) && a.n_tail * a.n_tail * 4 < (int64_t(1) << 32) && a.n_tail > 256) {
+    if (want && a.symmetric && a.pipeline == 0 && (epilogue == MDG_EPI_STORE || epilogue == MDG_EPI_STORE_SIGMOID) &&
+        a.n_tail * a.ldo * 4 < (int64_t(1) << 32) && a.n_tail > 256) {
       const int nb = static_cast<int>(mdg_cdiv(a.n_tail, 256));
       const dim3 gsym(static_cast<unsigned>((nb + 1) / 2), static_cast<unsigned>(a.n_labels));
       // write-through score stores keep z_tail L2-resident (FETCH 11.3 -> 0.8 GB per launch at 4096^2 x 896); measured faster for
@@ -1155,6 +1215,12 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
         hipLaunchKernelGGL((bilinear_allpairs_sym_kernel<MODE, MDG_EPI_STORE_SIGMOID, 8>), gsym, block, lds2, st, a);
       }
       MDG_CHECK_LAUNCH("mdg_bilinear_allpairs(symmetric)");
+      if ((a.n_tail & 3) && a.ldo < ((a.n_tail + 3) & ~static_cast<int64_t>(3))) {      // contiguous rows: the last N % 4 columns of every row
+        const dim3 gs(static_cast<unsigned>(mdg_cdiv(a.n_tail, 256)), static_cast<unsigned>(a.n_labels));
+        if (epilogue == MDG_EPI_STORE) hipLaunchKernelGGL((bilinear_strip_kernel<MODE, MDG_EPI_STORE>), gs, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((bilinear_strip_kernel<MODE, MDG_EPI_STORE_SIGMOID>), gs, dim3(256), 0, st, a);
+        MDG_CHECK_LAUNCH("mdg_bilinear_allpairs(strip)");
+      }
       return MDG_OK;
     }
   }
@@ -1246,10 +1312,18 @@ extern "C" size_t mdg_bilinear_allpairs_workspace_bytes(int64_t n_head, int64_t 
 extern "C" int mdg_bilinear_allpairs(const float* z_head, const float* z_tail, const float* w_sym, float* out,
                                      int64_t n_head, int64_t n_tail, int64_t n_labels, int64_t D_, int precision,
                                      int epilogue, void* workspace, size_t workspace_bytes, void* stream) {
+  return mdg_bilinear_allpairs_ld(z_head, z_tail, w_sym, out, n_tail, n_head, n_tail, n_labels, D_, precision, epilogue, workspace,
+                                  workspace_bytes, stream);
+}
+
+extern "C" int mdg_bilinear_allpairs_ld(const float* z_head, const float* z_tail, const float* w_sym, float* out, int64_t ldo,
+                                        int64_t n_head, int64_t n_tail, int64_t n_labels, int64_t D_, int precision,
+                                        int epilogue, void* workspace, size_t workspace_bytes, void* stream) {
   MDG_CHECK_ARG(D_ == D, "mdg_bilinear_allpairs: D must be %d (got %lld)", D, (long long)D_);
+  MDG_CHECK_ARG(epilogue == MDG_EPI_ROWSTATS || ldo >= n_tail, "mdg_bilinear_allpairs: row pitch %lld < n_tail %lld", (long long)ldo, (long long)n_tail);
   MDG_CHECK_ARG(n_head >= 0 && n_tail >= 0 && n_labels >= 0, "mdg_bilinear_allpairs: negative size");
   MDG_CHECK_ARG(n_labels <= 65535, "mdg_bilinear_allpairs: n_labels %lld > 65535 per call", (long long)n_labels);
-  MDG_CHECK_ARG(n_tail * 256 * 4 < (int64_t(1) << 31), "mdg_bilinear_allpairs: n_tail %lld too large", (long long)n_tail);
+  MDG_CHECK_ARG((ldo > n_tail ? ldo : n_tail) * 256 * 4 < (int64_t(1) << 31), "mdg_bilinear_allpairs: n_tail / row pitch %lld too large", (long long)ldo);
   if (n_head == 0 || n_tail == 0 || n_labels == 0) return MDG_OK;
   MDG_CHECK_ARG(z_head && z_tail && w_sym && out, "mdg_bilinear_allpairs: null pointer");
   MDG_CHECK_ARG(mdg_aligned16(z_head) && mdg_aligned16(z_tail) && mdg_aligned16(w_sym),
@@ -1261,6 +1335,9 @@ extern "C" int mdg_bilinear_allpairs(const float* z_head, const float* z_tail, c
   a.z_head = z_head;
   a.out = out;
   a.n_head = n_head; a.n_tail = n_tail; a.n_labels = n_labels;
+  a.ldo = epilogue == MDG_EPI_ROWSTATS ? n_tail : ldo;
+  a.zt_raw = z_tail;
+  a.w_raw = w_sym;
   a.zt.nrows = n_tail;
   a.symmetric = (z_head == z_tail && n_head == n_tail) ? 1 : 0;
   a.stagger = 1;

@@ -101,14 +101,14 @@ __device__ __forceinline__ void store_tile_histogram(const uint32_t (*cnt)[256],
 }
 
 // keys of the strict lower triangle in p order + the tile histogram of the lowest digit
-__global__ __launch_bounds__(TPB) void extract_keys_kernel(const float* __restrict__ scores, uint32_t* __restrict__ keys, uint32_t* __restrict__ hist,
-                                                           int N, int64_t M, int nblk) {
+__global__ __launch_bounds__(TPB) void extract_keys_kernel(const float* __restrict__ scores, int64_t lds, uint32_t* __restrict__ keys,
+                                                           uint32_t* __restrict__ hist, int N, int64_t M, int nblk) {
   __shared__ uint32_t cnt[WAVES][256];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
   __syncthreads();
   const int64_t seg = blockIdx.y, base = static_cast<int64_t>(blockIdx.x) * TILE;
-  const float* sc = scores + seg * static_cast<int64_t>(N) * N;
+  const float* sc = scores + seg * static_cast<int64_t>(N) * lds;
   uint32_t key[ITEMS];
   // (i, j) of the wave's first position by the closed form, once; every later position by stepping along the rows
   int wi, wj;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(TPB) void extract_keys_kernel(const float* __restri
     int i = wi, j = wj + lane;                             // row i holds i entries
     while (j >= i) { j -= i; ++i; }
     if (p < M) {
-      key[k] = order_key(sc[static_cast<int64_t>(i) * N + j]);
+      key[k] = order_key(sc[static_cast<int64_t>(i) * lds + j]);
       keys[seg * M + p] = key[k];
     }
     wj += 64;                                              // the wave's next 64 positions (wave-uniform walk)
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(uint32_t* __restrict__ hist,
 template <bool FIRST, bool LAST>
 __global__ __launch_bounds__(TPB) void scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ pay_in,
                                                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ pay_out,
-                                                      const uint32_t* __restrict__ offsets, float* __restrict__ out, int N,
+                                                      const uint32_t* __restrict__ offsets, float* __restrict__ out, int64_t ldo, int N,
                                                       int64_t M, int nblk, int shift, double denom) {
   __shared__ uint32_t cnt[WAVES][256];     // per-wave digit counts, then their exclusive prefix over the waves
   __shared__ uint32_t dstart[256];         // first slot of digit d in the sorted tile
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(TPB) void scatter_kernel(const uint32_t* __restrict
     spay[pos] = pay[k];
   }
   __syncthreads();
-  float* o = LAST ? out + seg * static_cast<int64_t>(N) * N : nullptr;
+  float* o = LAST ? out + seg * static_cast<int64_t>(N) * ldo : nullptr;
 #pragma unroll 4
   for (int k = 0; k < ITEMS; ++k) {
     const int idx = k * TPB + tid;
@@ -262,8 +262,8 @@ __global__ __launch_bounds__(TPB) void scatter_kernel(const uint32_t* __restrict
       int i, j;
       tri_decode(pp, i, j);
       const float v = static_cast<float>(static_cast<double>(g + 1u) / denom);
-      o[static_cast<int64_t>(i) * N + j] = v;
-      o[static_cast<int64_t>(j) * N + i] = v;
+      o[static_cast<int64_t>(i) * ldo + j] = v;
+      o[static_cast<int64_t>(j) * ldo + i] = v;
     } else {
       keys_out[seg * M + g] = kk;
       pay_out[seg * M + g] = pp;
@@ -386,8 +386,8 @@ __global__ __launch_bounds__(TPB) void rank_blocks_kernel(const uint32_t* __rest
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(TPB) void rank_block_write_kernel(const u32x2* __restrict__ pairs, float* __restrict__ out, int N, int64_t M,
-                                                               int n_blocks, double denom) {
+__global__ __launch_bounds__(TPB) void rank_block_write_kernel(const u32x2* __restrict__ pairs, float* __restrict__ out, int64_t ldo, int N,
+                                                               int64_t M, int n_blocks, double denom) {
   __shared__ float tile[BB][BB + 1];
   const int t = blockIdx.x, tid = threadIdx.x;
   const int64_t seg = blockIdx.y;
@@ -411,12 +411,12 @@ __global__ __launch_bounds__(TPB) void rank_block_write_kernel(const u32x2* __re
     if (diag) tile[c][r] = val;
   }
   __syncthreads();
-  float* o = out + seg * static_cast<int64_t>(N) * N;
+  float* o = out + seg * static_cast<int64_t>(N) * ldo;
   const int q = tid & 31, rr = tid >> 5;                   // 32 lanes x 4 columns cover a 128-wide row; 16 rows per sweep
   const int ccount = diag ? rcount : BB;
   // rows of out[i, j]
   for (int r = rr; r < rcount; r += TPB / 32) {
-    float* row = o + static_cast<int64_t>(r0 + r) * N + c0;
+    float* row = o + static_cast<int64_t>(r0 + r) * ldo + c0;
     if (VEC && 4 * q + 3 < ccount) *reinterpret_cast<f32x4*>(row + 4 * q) = f32x4{tile[r][4 * q], tile[r][4 * q + 1], tile[r][4 * q + 2], tile[r][4 * q + 3]};
     else
       for (int e = 0; e < 4; ++e)
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(TPB) void rank_block_write_kernel(const u32x2* __re
   if (diag) return;
   // rows of the mirrored block out[j, i]
   for (int c = rr; c < BB; c += TPB / 32) {
-    float* row = o + static_cast<int64_t>(c0 + c) * N + r0;
+    float* row = o + static_cast<int64_t>(c0 + c) * ldo + r0;
     if (VEC && 4 * q + 3 < rcount) *reinterpret_cast<f32x4*>(row + 4 * q) = f32x4{tile[4 * q][c], tile[4 * q + 1][c], tile[4 * q + 2][c], tile[4 * q + 3][c]};
     else
       for (int e = 0; e < 4; ++e)
@@ -433,9 +433,9 @@ __global__ __launch_bounds__(TPB) void rank_block_write_kernel(const u32x2* __re
   }
 }
 
-__global__ __launch_bounds__(256) void zero_diag_kernel(float* __restrict__ out, int N) {
+__global__ __launch_bounds__(256) void zero_diag_kernel(float* __restrict__ out, int64_t ldo, int N) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < N) out[(static_cast<int64_t>(blockIdx.y) * N + i) * N + i] = 0.f;
+  if (i < N) out[(static_cast<int64_t>(blockIdx.y) * N + i) * ldo + i] = 0.f;
 }
 
 inline size_t a256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
@@ -477,12 +477,18 @@ extern "C" size_t mdg_rank_normalize_workspace_bytes(int64_t n_outcomes, int64_t
 
 extern "C" int mdg_rank_normalize(const float* scores, float* out, int64_t n_outcomes, int64_t N, void* workspace,
                                   size_t workspace_bytes, void* stream) {
+  return mdg_rank_normalize_ld(scores, N, out, N, n_outcomes, N, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mdg_rank_normalize_ld(const float* scores, int64_t lds, float* out, int64_t ldo, int64_t n_outcomes, int64_t N, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(lds >= N && ldo >= N, "mdg_rank_normalize: row pitches must be >= N");
   MDG_CHECK_ARG(n_outcomes >= 0 && N >= 0 && N <= 65535 && n_outcomes <= 65535, "mdg_rank_normalize: bad sizes (outcomes per call and N <= 65535)");
   if (n_outcomes == 0 || N == 0) return MDG_OK;
   MDG_CHECK_ARG(scores && out, "mdg_rank_normalize: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned L = static_cast<unsigned>(n_outcomes);
-  hipLaunchKernelGGL(zero_diag_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N, 256)), L), dim3(256), 0, st, out, static_cast<int>(N));
+  hipLaunchKernelGGL(zero_diag_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N, 256)), L), dim3(256), 0, st, out, ldo, static_cast<int>(N));
   if (N < 2) { MDG_CHECK_LAUNCH("mdg_rank_normalize"); return MDG_OK; }
   const int64_t M = N * (N - 1) / 2;
   const int nblk = static_cast<int>(mdg_cdiv(M, TILE));
@@ -504,7 +510,7 @@ extern "C" int mdg_rank_normalize(const float* scores, float* out, int64_t n_out
   const bool blocked = n_blocks <= MAX_BLOCKS && !direct_sw.get();
   const double denom = static_cast<double>(N) * static_cast<double>(N - 1) / 2.0;
   const dim3 grid(static_cast<unsigned>(nblk), L);
-  hipLaunchKernelGGL(extract_keys_kernel, grid, dim3(TPB), 0, st, scores, k0, hist, static_cast<int>(N), M, nblk);
+  hipLaunchKernelGGL(extract_keys_kernel, grid, dim3(TPB), 0, st, scores, lds, k0, hist, static_cast<int>(N), M, nblk);
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 8 * pass;
     uint32_t* kin = (pass & 1) ? k1 : k0;
@@ -514,21 +520,21 @@ extern "C" int mdg_rank_normalize(const float* scores, float* out, int64_t n_out
     if (pass > 0) hipLaunchKernelGGL(histogram_kernel, grid, dim3(TPB), 0, st, kin, hist, M, nblk, shift);
     hipLaunchKernelGGL(scan_kernel, dim3(L), dim3(1024), 0, st, hist, nblk);
     if (pass == 0)
-      hipLaunchKernelGGL((scatter_kernel<true, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, static_cast<int>(N), M, nblk, shift, denom);
+      hipLaunchKernelGGL((scatter_kernel<true, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, ldo, static_cast<int>(N), M, nblk, shift, denom);
     else if (pass == 3 && blocked) {
       (void)hipMemsetAsync(fill, 0, static_cast<size_t>(n_outcomes) * n_blocks * 4, st);
       u32x2* pairs = reinterpret_cast<u32x2*>(k0);            // pass 3 reads k1 / p1
       const size_t lds = static_cast<size_t>(2 * TILE + 2 * n_blocks) * 4;
       hipLaunchKernelGGL(rank_blocks_kernel, grid, dim3(TPB), lds, st, kin, pin, hist, pairs, fill, static_cast<int>(N), M, nblk, static_cast<int>(n_blocks));
       const dim3 bgrid(static_cast<unsigned>(n_blocks), L);
-      if (N % 4 == 0 && mdg_aligned16(out))
-        hipLaunchKernelGGL(rank_block_write_kernel<true>, bgrid, dim3(TPB), 0, st, pairs, out, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
+      if (ldo % 4 == 0 && mdg_aligned16(out))
+        hipLaunchKernelGGL(rank_block_write_kernel<true>, bgrid, dim3(TPB), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
       else
-        hipLaunchKernelGGL(rank_block_write_kernel<false>, bgrid, dim3(TPB), 0, st, pairs, out, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
+        hipLaunchKernelGGL(rank_block_write_kernel<false>, bgrid, dim3(TPB), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
     } else if (pass == 3)
-      hipLaunchKernelGGL((scatter_kernel<false, true>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, static_cast<int>(N), M, nblk, shift, denom);
+      hipLaunchKernelGGL((scatter_kernel<false, true>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, ldo, static_cast<int>(N), M, nblk, shift, denom);
     else
-      hipLaunchKernelGGL((scatter_kernel<false, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, static_cast<int>(N), M, nblk, shift, denom);
+      hipLaunchKernelGGL((scatter_kernel<false, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, ldo, static_cast<int>(N), M, nblk, shift, denom);
   }
   MDG_CHECK_LAUNCH("mdg_rank_normalize");
   return MDG_OK;

@@ -98,9 +98,12 @@ def bilinear_allpairs(z_head: torch.Tensor, z_tail: torch.Tensor, w_sym: torch.T
     if out is None:
         out = torch.empty(shape, dtype=torch.float32, device=zh.device)
     else:
-        out = _f32_cuda(out, "out")
-        if tuple(out.shape) != shape or not out.is_contiguous():
-            raise ValueError(f"out: expected contiguous {shape}, got {tuple(out.shape)}")
+        if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.float32):
+            raise ValueError("out: expected a float32 GPU tensor")
+        # contiguous, or a view of row-padded storage (empty_scores): unit inner stride and one pitch for every row
+        if tuple(out.shape) != shape or (out.numel() and (out.stride(2) != 1 or out.stride(1) < shape[2] or out.stride(0) != shape[1] * out.stride(1))):
+            raise ValueError(f"out: expected {shape}, contiguous or row-pitched (empty_scores), got {tuple(out.shape)} strides {tuple(out.stride())}")
+    ldo = out.stride(1) if out.numel() else shape[2]
     if isinstance(precision, str) and precision not in HEAD_PRECISIONS:
         raise ValueError(f"unknown precision {precision!r}; expected one of {sorted(HEAD_PRECISIONS)}")
     prec = HEAD_PRECISIONS[precision] if isinstance(precision, str) else int(precision)
@@ -112,11 +115,20 @@ def bilinear_allpairs(z_head: torch.Tensor, z_tail: torch.Tensor, w_sym: torch.T
             break
         nbytes = L_.mdg_bilinear_allpairs_workspace_bytes(_c64(Nh), _c64(Nt), _c64(hi - lo), _c64(D), prec)
         ws = _workspace(nbytes, zh.device)
-        check(L_.mdg_bilinear_allpairs(_ptr(zh), _ptr(zt), _vp(w.data_ptr() + lo * D * D * 4),
-                                       _vp(out.data_ptr() + lo * out.stride(0) * 4), _c64(Nh), _c64(Nt), _c64(hi - lo),
-                                       _c64(D), prec, int(epilogue), _ptr(ws), ctypes.c_size_t(nbytes), _stream(zh)),
+        check(L_.mdg_bilinear_allpairs_ld(_ptr(zh), _ptr(zt), _vp(w.data_ptr() + lo * D * D * 4),
+                                          _vp(out.data_ptr() + lo * out.stride(0) * 4), _c64(ldo), _c64(Nh), _c64(Nt), _c64(hi - lo),
+                                          _c64(D), prec, int(epilogue), _ptr(ws), ctypes.c_size_t(nbytes), _stream(zh)),
               "mdg_bilinear_allpairs")
     return out
+
+
+def empty_scores(L: int, Nh: int, Nt: int, device) -> torch.Tensor:
+    """An uninitialised [L,Nh,Nt] fp32 score (or rank) tensor in the layout the head writes fastest: rows padded to a multiple of
+    32 floats, so that every row starts on a 128-byte line whatever Nt is (the real drug counts -- 11 607 in
+    generate_embeddings.ipynb -- are not multiples of anything).  For Nt % 32 == 0 this is a plain contiguous tensor; otherwise a
+    [:, :, :Nt] view of the padded storage: same values and indexing, ``.contiguous()`` compacts it."""
+    pitch = (Nt + 31) // 32 * 32
+    return torch.empty((L, Nh, pitch), dtype=torch.float32, device=device)[:, :, :Nt]
 
 
 # ------------------------------------------------------------------------------- dense blocks
@@ -621,16 +633,29 @@ def gather_bce(scores: torch.Tensor, labels: torch.Tensor, heads: torch.Tensor, 
 
 
 # ------------------------------------------------------------------------------- rank normalisation
+def _scores3(t: torch.Tensor, name: str) -> torch.Tensor:
+    """[L,N,N] fp32 GPU tensor, contiguous or row-pitched (empty_scores); anything else is made contiguous."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 3):
+        return _f32_cuda(t, name, 3)
+    if t.numel() and (t.stride(2) != 1 or t.stride(1) < t.shape[2] or t.stride(0) != t.shape[1] * t.stride(1)):
+        return t.contiguous()
+    return t
+
+
 def rank_normalize(scores: torch.Tensor, out: Optional[torch.Tensor] = None, max_workspace_bytes: int = 8 << 30) -> torch.Tensor:
     """Normalised ranks per outcome (notebooks/normalize_scores.py:36-74): [L,N,N] fp32 -> [L,N,N] fp32.
-    Outcomes are processed in chunks sized to ``max_workspace_bytes`` of sort scratch."""
-    s = _f32_cuda(scores, "scores", 3)
+    Outcomes are processed in chunks sized to ``max_workspace_bytes`` of sort scratch.  ``scores`` / ``out`` may be row-pitched
+    (``empty_scores``); without ``out`` the result has the layout of ``scores``."""
+    s = _scores3(scores, "scores")
     L, N, N2 = s.shape
     if N != N2:
         raise ValueError("scores: expected [L,N,N]")
-    out = torch.empty_like(s) if out is None else _f32_cuda(out, "out", 3)
-    if out.shape != s.shape or out.data_ptr() == s.data_ptr():
-        raise ValueError("out: same shape as scores, and not aliasing it")
+    if out is None:
+        out = empty_scores(L, N, N, s.device) if (N and s.stride(1) != N) else torch.empty((L, N, N), dtype=torch.float32, device=s.device)
+    else:
+        o2 = _scores3(out, "out")
+        if o2 is not out or out.shape != s.shape or out.data_ptr() == s.data_ptr():
+            raise ValueError("out: an fp32 GPU tensor of the shape of scores (contiguous or row-pitched), not aliasing it")
     if L == 0 or N == 0:
         return out
     lb = lib()
@@ -640,8 +665,8 @@ def rank_normalize(scores: torch.Tensor, out: Optional[torch.Tensor] = None, max
         hi = min(L, lo + chunk)
         nbytes = lb.mdg_rank_normalize_workspace_bytes(_c64(hi - lo), _c64(N))
         ws = _workspace(nbytes, s.device)
-        check(lb.mdg_rank_normalize(_vp(s.data_ptr() + lo * N * N * 4), _vp(out.data_ptr() + lo * N * N * 4), _c64(hi - lo), _c64(N),
-                                    _ptr(ws), ctypes.c_size_t(nbytes), _stream(s)), "mdg_rank_normalize")
+        check(lb.mdg_rank_normalize_ld(_vp(s.data_ptr() + lo * s.stride(0) * 4), _c64(s.stride(1)), _vp(out.data_ptr() + lo * out.stride(0) * 4),
+                                       _c64(out.stride(1)), _c64(hi - lo), _c64(N), _ptr(ws), ctypes.c_size_t(nbytes), _stream(s)), "mdg_rank_normalize")
     return out
 
 

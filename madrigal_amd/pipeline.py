@@ -87,12 +87,14 @@ def score_all_pairs(model, z: torch.Tensor, label_range: Optional[Tuple[int, int
     L_all = dec.parametrizations.weight.original.shape[0] if hasattr(dec, "parametrizations") else dec.weight.shape[0]
     lo, hi = (0, L_all) if label_range is None else label_range
     N = z.shape[0]
-    if out is None or isinstance(out, torch.Tensor):
+    if out is None:
+        out = ops.empty_scores(hi - lo, N, N, z.device)      # rows on 128-byte lines whatever N is (a [:, :, :N] view when N % 32 != 0)
+    if isinstance(out, torch.Tensor):
         return dec(z, z, (lo, hi), epilogue=epilogue, out=out)
     if tuple(out.shape) != (hi - lo, N, N) or out.dtype != np.float32:
         raise ValueError(f"out: expected float32 array of shape {(hi - lo, N, N)}")
     copy_stream = torch.cuda.Stream(device=z.device)
-    dev_buf = [torch.empty((host_chunk, N, N), dtype=torch.float32, device=z.device) for _ in range(2)]
+    dev_buf = [ops.empty_scores(host_chunk, N, N, z.device) for _ in range(2)]     # row-pitched on the device, compacted by the copy
     pin_buf = [torch.empty((host_chunk, N, N), dtype=torch.float32, pin_memory=True) for _ in range(2)]
     done = [None, None]
     pending = [None, None]

@@ -115,13 +115,15 @@ def test_store_schedules_write_identical_bits(ops, monkeypatch, nh, nt):
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16", "f16"])
-@pytest.mark.parametrize("N,L", [(1024, 3), (1000, 2), (516, 2), (2304, 1)])
+@pytest.mark.parametrize("N,L", [(1024, 3), (1000, 2), (516, 2), (2304, 1), (1001, 2), (771, 2), (1283, 1)])
 def test_symmetric_sweep_for_one_drug_set(ops, monkeypatch, prec, N, L):
     """decoder(z, z, ...) (predict.py:428): the same matrix on both sides runs the symmetric sweep -- tiles on / right of the
     block diagonal computed, every off-diagonal tile stored twice.  Against the general kernel (MDG_BILINEAR_SYMMETRIC=0):
     the computed half is the same arithmetic in the same order => identical bits; the mirrored half is its exact transpose
     and within the mode's tolerance of what the general kernel computes there (the other association order).  Ragged N
-    (not a multiple of 256 / 64), odd numbers of row blocks and the sigmoid epilogue included."""
+    (not a multiple of 256 / 64 / 4: rows of the score matrix then start at any 4-byte alignment and the sweep's 16-byte stores
+    are unaligned; the last N % 4 columns come from a strip launch of the general kernel), odd numbers of row blocks and the
+    sigmoid epilogue included."""
     z = _rand((N, 128), 60).cuda()
     w = ops.symmetrize(_rand((L, 128, 128), 61, 1 / np.sqrt(128)).cuda())
     set_switch(monkeypatch, "MDG_BILINEAR_SYMMETRIC", "0")
@@ -134,15 +136,31 @@ def test_symmetric_sweep_for_one_drug_set(ops, monkeypatch, prec, N, L):
     blk = torch.arange(N, device="cuda") // 256
     upper = (blk[None, :] >= blk[:, None])                                   # on / right of the block diagonal: computed
     scale = float(gen.abs().max())
+    n4 = N - N % 4
+    strip = torch.zeros(N, N, dtype=torch.bool, device="cuda")
+    strip[n4:, :] = True                                                       # mirror images of the strip columns [n4, N)
+    swept = upper & ~strip.T                                                   # computed by the sweep itself (not the column strip)
     if prec == "f32":                       # same instruction, same order: identical bits
-        assert torch.equal(out[:, upper], gen[:, upper])
+        assert torch.equal(out[:, swept], gen[:, swept])
     else:                                   # 16-bit operand modes sweep on v_mfma 16x16x32 (general kernel: 32x32x16): same products,
-        assert float((out[:, upper] - gen[:, upper]).abs().max()) < 2e-6 * scale      # fp32 sums grouped 32 instead of 16 deep
+        assert float((out[:, swept] - gen[:, swept]).abs().max()) < 2e-6 * scale      # fp32 sums grouped 32 instead of 16 deep
     lower = ~upper
-    assert torch.equal(out[:, lower], out.transpose(1, 2)[:, lower])          # the mirrored half: exact transpose
+    outT = out.transpose(1, 2)
+    assert torch.equal(out[:, lower & ~strip], outT[:, lower & ~strip])        # the mirrored half: exact transpose
+    if n4 != N:                                # the strip (its own small kernel, fp32 sums in another order) against the general kernel
+        noise = {"f32": 2e-6, "bf16x3": 1e-5, "bf16": 1e-2, "f16": 1.5e-3}[prec] * scale       # and against its mirror image from the sweep
+        assert float((out[:, :, n4:] - gen[:, :, n4:]).abs().max()) < noise
+        assert float((out[:, lower & strip] - outT[:, lower & strip]).abs().max()) < noise
     assert float((out - gen).abs().max()) < max(TOL[prec], 1e-6) * scale
     sg = ops.bilinear_allpairs(z, z, w, precision=prec, epilogue=ops.EPI_STORE_SIGMOID)
-    assert float((sg[:, upper] - gen_sig[:, upper]).abs().max()) < 2e-6 and torch.equal(sg[:, lower], sg.transpose(1, 2)[:, lower])
+    assert float((sg[:, swept] - gen_sig[:, swept]).abs().max()) < 2e-6 and torch.equal(sg[:, lower & ~strip], sg.transpose(1, 2)[:, lower & ~strip])
+    # the row-pitched layout (ops.empty_scores: rows on 128-byte lines, no strip launch, whole-line stores): the sweep's own bits everywhere
+    pit = ops.empty_scores(L, N, N, "cuda")
+    pit.fill_(float("nan"))
+    assert pit.stride(1) % 32 == 0 and ops.bilinear_allpairs(z, z, w, precision=prec, out=pit) is pit
+    assert not bool(torch.isnan(pit).any())
+    assert torch.equal(pit[:, ~strip & ~strip.T], out[:, ~strip & ~strip.T]) and torch.equal(pit[:, lower], pit.transpose(1, 2)[:, lower])
+    assert float((pit - gen).abs().max()) < max(TOL[prec], 1e-6) * scale
     assert torch.equal(sg, torch.sigmoid(out)) or float((sg - 1.0 / (1.0 + torch.exp(-out))).abs().max()) < 1e-6
     # a different tensor with the same values is not "the same matrix": the general kernel runs, bit for bit
     assert torch.equal(ops.bilinear_allpairs(z, z.clone(), w, precision=prec), gen)
@@ -309,3 +327,21 @@ def test_repeated_launches_are_bit_identical(ops, prec, nh, nt, L, variant):
             first = out
         else:
             assert torch.equal(out, first), f"launch {it} differs from launch 0"
+
+
+@pytest.mark.parametrize("N,L", [(4003, 3), (11607, 1)])
+def test_real_drug_counts_on_the_symmetric_sweep(ops, N, L):
+    """SURVEY 8(d)'s ragged input (4 003 drugs) and the drug count of the reference's own scoring run (11 607,
+    generate_embeddings.ipynb): contiguous [L,N,N] (unaligned rows + column strip) and row-pitched output against the oracle on
+    sampled head rows, and against each other."""
+    z = _rand((N, 128), 70).cuda()
+    w0 = _rand((L, 128, 128), 71, 1 / np.sqrt(128))
+    w = ops.symmetrize(w0.cuda())
+    out = ops.bilinear_allpairs(z, z, w, precision="bf16x3")
+    pit = ops.bilinear_allpairs(z, z, w, precision="bf16x3", out=ops.empty_scores(L, N, N, "cuda"))
+    assert out.is_contiguous() and not pit.is_contiguous()
+    rows = torch.tensor([0, 1, 255, 256, 257, N // 2, N - 5, N - 4, N - 3, N - 2, N - 1])
+    ref = _oracle(z.cpu()[rows], z.cpu(), w0)
+    assert rel_err(out[:, rows.cuda()].cpu(), ref) < TOL["bf16x3"] and rel_err(pit[:, rows.cuda()].cpu(), ref) < TOL["bf16x3"]
+    assert float((out - pit).abs().max()) < 1e-5 * float(out.abs().max())
+    assert float((pit[0] - pit[0].T).abs().max()) < 1e-5 * float(out.abs().max())
