@@ -137,6 +137,7 @@ int mdg_layernorm(const float* x, int64_t ldx, const float* gamma, const float* 
  * image: the norm -> projection pairs of nn.TransformerEncoderLayer (models.py:366) without the pre-pass in between. */
 int mdg_layernorm_packed(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy, int64_t rows,
                          int64_t d, float eps, int precision, void* y_packed, size_t y_packed_bytes, void* stream);
+size_t mdg_linear_packed_x_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision, int w_is_packed);
 int mdg_linear_packed_x(const void* x_packed, int64_t M, int64_t K, const float* w, int64_t ldw, const void* w_packed, float* y,
                         int64_t ldy, int64_t N, const float* bias, int act, const float* residual, int64_t ldr, float alpha,
                         float beta, int precision, void* workspace, size_t workspace_bytes, void* stream);

@@ -266,14 +266,15 @@ struct LinearArgs {
   int tiles_x, tiles_y, swizzle;   // swizzle: XCD-aware tile order (see tile_of)
   int vec_y, vec_r;                // y / residual rows may be accessed 16 B at a time (alignment and row stride)
   const int64_t* tiles;            // grouped launch: [n_tiles][kGroupTileWords] tile descriptors (device), else null
+  int sk_tiles;                    // 256-tile kernel, stream-K hybrid: the last sk_tiles tiles are shared k tile by k tile (0: one tile per workgroup)
+  char* sk_ws;                     // its workspace: accumulator slots | flags
 };
 
 // Workgroups are dealt to the 8 XCDs round-robin in dispatch order, and each XCD has its own L2.  With the plain
 // blockIdx -> tile map the ~32 workgroups resident on one XCD are spread over the whole tile grid and share few operand
 // bands.  Swizzled map: XCD x owns a contiguous run of the tile sequence, and that sequence walks the grid in groups of
 // 8 tile-rows, column by column, so that the resident set is an ~8 x 4 patch: 12 operand bands feed 32 tiles.
-__device__ __forceinline__ bool tile_of(const LinearArgs& p, int& tx, int& ty) {
-  const int id = blockIdx.x;
+__device__ __forceinline__ bool tile_of(const LinearArgs& p, int id, int& tx, int& ty) {
   if (!p.swizzle) { tx = id % p.tiles_x; ty = id / p.tiles_x; return ty < p.tiles_y; }
   const int total = p.tiles_x * p.tiles_y;
   const int per_xcd = (total + 7) >> 3;
@@ -285,6 +286,19 @@ __device__ __forceinline__ bool tile_of(const LinearArgs& p, int& tx, int& ty) {
   ty = group * GM + in % rows;
   tx = in / rows;
   return true;
+}
+
+// The same walk for the persistent (stream-K) launch, where every id in [0, total) must name a tile: the XCD runs are cut
+// bijectively (the first total % 8 XCDs own one more tile).
+__device__ __forceinline__ void tile_of_bijective(const LinearArgs& p, int id, int& tx, int& ty) {
+  const int total = p.tiles_x * p.tiles_y;
+  const int q = total >> 3, r = total & 7, xcd = id & 7;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  constexpr int GM = 8;
+  const int group = t / (GM * p.tiles_x), in = t - group * GM * p.tiles_x;
+  const int rows = p.tiles_y - group * GM < GM ? p.tiles_y - group * GM : GM;
+  ty = group * GM + in % rows;
+  tx = in / rows;
 }
 
 // the part of the next tile's LDS-DMA that goes out at issue slot `slot` of the current tile's MFMA sequence
@@ -440,7 +454,7 @@ __global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs 
     p.beta = __builtin_bit_cast(float, static_cast<unsigned>(ab >> 32));
   } else {
     int tx, ty;
-    if (!tile_of(p, tx, ty)) return;                        // workgroup-uniform
+    if (!tile_of(p, static_cast<int>(blockIdx.x), tx, ty)) return;   // workgroup-uniform
     col0 = static_cast<int64_t>(tx) * S::BN;
     row0 = static_cast<int64_t>(ty) * S::BM;
   }
@@ -533,160 +547,272 @@ __device__ __forceinline__ void glds16_so(const char* sbase, unsigned voff, unsi
 }
 }  // namespace pp
 
-template <int MODE, bool GROUPED = false>
+// Work decomposition.  One workgroup per CU and a tile that takes tens of microseconds: with T tiles over P workgroups the last
+// of ceil(T / P) rounds runs partly empty (704 tiles of the [22464, 2048] blocks: 2.75 rounds cost 3; the 352 tiles of the FFN's
+// first block: 1.4 cost 2).  Stream-K hybrid (p.sk_tiles > 0, grid = P persistent workgroups): the first T - sk_tiles tiles
+// -- whole rounds -- are dealt out tile by tile, then the k tiles of the remaining sk_tiles tiles are laid end to end and cut into
+// P equal runs.  A workgroup whose run starts INSIDE a tile computes that piece first and leaves its accumulators in its slot
+// of the workspace (the only piece it ever publishes); the workgroup that owns a tile's k = 0 computes its piece last, adds the
+// slots of the workgroups after it that cover the rest of the tile -- they finished those pieces long before, at the head of
+// their runs -- and runs the epilogue.  A workgroup only ever waits for HIGHER-numbered workgroups, none of which waits for
+// it; the grid is at most the number of CUs (one workgroup fits a CU), so every workgroup is resident as soon as a CU is free.
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md, in-launch split-K reduction): write-through
+// (sc1) 16-byte stores of the slot -> every wave waits vmcnt(0) -> barrier -> one lane: relaxed agent-scope flag store; consumer:
+// one lane polls the flag (relaxed, agent scope, s_sleep between polls, bounded), agent-scope acquire fence, vmcnt(0), barrier,
+// plain loads.
+// The split tiles' sums are grouped differently from an unsplit tile's (fp32 rounding of the last place); the cut points depend
+// on the shape and P only, so a call is reproducible bit for bit.
+namespace pp {
+constexpr int SLOT_FLOATS = BM * BN;                       // one workgroup's accumulators
+constexpr int MAX_WG = 256;
+constexpr unsigned SPIN_LIMIT = 1u << 21;                  // ~2 s of polling: a lost hand-off must not hang the card
+inline size_t sk_bytes() { return static_cast<size_t>(MAX_WG) * SLOT_FLOATS * 4 + 4096; }   // slots | flags[MAX_WG] | error word
+}  // namespace pp
+
+template <int MODE, bool SK>
 __global__ __launch_bounds__(pp::THREADS, 2) void linear_pp_kernel(const LinearArgs pk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A0 | B0 | B1 | A1]; reused as [wave][64][64] fp32 by the epilogue
   static_assert(MODE == MDG_PREC_BF16 || MODE == MDG_PREC_BF16X3, "16-bit operand modes");
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  LinearArgs p = pk;
-  int tx, ty;
-  if (!tile_of(p, tx, ty)) return;                            // workgroup-uniform
-  const int64_t col0 = static_cast<int64_t>(tx) * pp::BN, row0 = static_cast<int64_t>(ty) * pp::BM;
+  const LinearArgs& p = pk;
   const int nk = static_cast<int>(MODE == MDG_PREC_BF16 ? p.K / 64 : p.K / 32);
-
-  // ---- LDS-DMA sources: piece i of this wave covers LDS rows 8 (2 wave + i) .. + 7 of a half-tile; lane -> (row, chunk) ----
-  // offsets are relative to the tile's first image row (32 bits: 256 rows x a row of at most a few hundred KB)
-  unsigned off_a[2][2], off_b[2][2];                          // [half][piece]
-  const int64_t a_rows = p.A.nrows - row0, b_rows = p.B.nrows - col0;   // rows of the image at / below the tile origin (>= 1)
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = 8 * (2 * wave + i) + (lane >> 3);
-    const unsigned chunk = static_cast<unsigned>((lane & 7) ^ ((r >> 1) & 7)) << 4;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int64_t ta = 128 * (r >> 6) + 64 * h + (r & 63), tb = 64 * (r >> 5) + 32 * h + (r & 31);
-      ta = ta < a_rows ? ta : a_rows - 1;                     // rows past the end re-read the last row (never stored)
-      tb = tb < b_rows ? tb : b_rows - 1;
-      off_a[h][i] = static_cast<unsigned>(ta * p.A.ld_bytes) + chunk;
-      off_b[h][i] = static_cast<unsigned>(tb * p.B.ld_bytes) + chunk;
-    }
-  }
-  const char* const a_base = p.A.p0 + row0 * p.A.ld_bytes;
-  const char* const b_base = p.B.p0 + col0 * p.B.ld_bytes;
-  const unsigned lds0 = lds_addr(smem) + static_cast<unsigned>(wave) * 2048u;
-  // half-tile q (0 A0, 1 B0, 2 B1, 3 A1) of k tile kt
-  auto dma = [&](auto qc, int kt) {
-    constexpr int q = decltype(qc)::value;
-    constexpr int off = q == 0 ? pp::OFF_A0 : q == 1 ? pp::OFF_B0 : q == 2 ? pp::OFF_B1 : pp::OFF_A1;
-    const char* sb = ((q == 0 || q == 3) ? a_base : b_base) + static_cast<int64_t>(kt) * 128;
-    const unsigned dst = lds0 + static_cast<unsigned>((kt & 1) * pp::STAGE + off);
-    const unsigned o0 = q == 0 ? off_a[0][0] : q == 3 ? off_a[1][0] : q == 1 ? off_b[0][0] : off_b[1][0];
-    const unsigned o1 = q == 0 ? off_a[0][1] : q == 3 ? off_a[1][1] : q == 1 ? off_b[0][1] : off_b[1][1];
-    pp::glds16_so(sb, o0, dst);
-    pp::glds16_so(sb, o1, dst + 1024u);
-  };
   using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
   using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
-
-  // ---- fragment addresses: lane (c = row / column in a 16-wide tile, g = 16-byte k chunk) ----
-  const int c = lane & 15, g = lane >> 4, x = (c >> 1) & 7;
-  const int fo0 = c * 128 + ((g ^ x) << 4), fo1 = c * 128 + (((4 + g) ^ x) << 4);       // chunk g / 4 + g of row c, swizzled
-  const char* const fa = smem + (64 * wr) * 128;              // + OFF_A{mh} + mt * 2048
-  const char* const fb = smem + (32 * wc) * 128;              // + OFF_B{nh} + nt * 2048
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  // Lane-dependent values (fragment offsets, DMA offsets, roles) are derived afresh inside every piece from an opaque copy of the
+  // thread id: kept live across the persistent launch's outer loop they cost 30 spilled VGPRs, and a kernel that touches scratch
+  // ran its tiles at half speed.
+  struct Lane { int tid, lane, wave, wr, wc, c, g, fo0, fo1, fa, fb; unsigned lds0; };
+  auto lane_roles = [&]() {
+    Lane L;
+    int t = threadIdx.x;
+    if constexpr (SK) asm volatile("" : "+v"(t));
+    L.tid = t; L.lane = t & 63;
+    L.wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    L.wr = L.wave >> 2; L.wc = L.wave & 3;
+    L.c = L.lane & 15; L.g = L.lane >> 4;                     // lane (c = row / column in a 16-wide tile, g = 16-byte k chunk)
+    const int x = (L.c >> 1) & 7;
+    L.fo0 = L.c * 128 + ((L.g ^ x) << 4); L.fo1 = L.c * 128 + (((4 + L.g) ^ x) << 4);   // chunk g / 4 + g of row c, swizzled
+    L.fa = (64 * L.wr) * 128; L.fb = (32 * L.wc) * 128;         // + OFF_{A,B}{half} + tile * 2048
+    L.lds0 = lds_addr(smem) + static_cast<unsigned>(L.wave) * 2048u;
+    return L;
+  };
 
   f32x4 acc[8][4];
-#pragma unroll
-  for (int a = 0; a < 8; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 af[4][2], b0f[2][2], b1f[2][2];                      // [tile][k chunk group: bf16 k 0..31 / 32..63, bf16x3 hi / lo]
 
-  auto read_a = [&](const char* st, int off) {
+  // accumulators of tile (tx, ty) over k tiles [kb, ke)
+  auto run_piece = [&](int tx, int ty, int kb, int ke) {
+    const Lane L = lane_roles();
+    const int lane = L.lane, wave = L.wave, wr = L.wr, fo0 = L.fo0, fo1 = L.fo1, fa = L.fa, fb = L.fb;
+    const unsigned lds0 = L.lds0;
+    const int64_t col0 = static_cast<int64_t>(tx) * pp::BN, row0 = static_cast<int64_t>(ty) * pp::BM;
+    // LDS-DMA sources: piece i of this wave covers LDS rows 8 (2 wave + i) .. + 7 of a half-tile; lane -> (row, chunk).  Offsets
+    // are relative to the tile's first image row (32 bits: 256 rows x a row of at most a few hundred KB)
+    unsigned off_a[2][2], off_b[2][2];                        // [half][piece]
+    const int64_t a_rows = p.A.nrows - row0, b_rows = p.B.nrows - col0;   // rows of the image at / below the tile origin (>= 1)
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      af[mt][0] = *reinterpret_cast<const bf16x8*>(st + off + (fa - smem) + mt * 2048 + fo0);
-      af[mt][1] = *reinterpret_cast<const bf16x8*>(st + off + (fa - smem) + mt * 2048 + fo1);
+    for (int i = 0; i < 2; ++i) {
+      const int r = 8 * (2 * wave + i) + (lane >> 3);
+      const unsigned chunk = static_cast<unsigned>((lane & 7) ^ ((r >> 1) & 7)) << 4;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int64_t ta = 128 * (r >> 6) + 64 * h + (r & 63), tb = 64 * (r >> 5) + 32 * h + (r & 31);
+        ta = ta < a_rows ? ta : a_rows - 1;                   // rows past the end re-read the last row (never stored)
+        tb = tb < b_rows ? tb : b_rows - 1;
+        off_a[h][i] = static_cast<unsigned>(ta * p.A.ld_bytes) + chunk;
+        off_b[h][i] = static_cast<unsigned>(tb * p.B.ld_bytes) + chunk;
+      }
     }
-  };
-  auto read_b = [&](const char* st, int off, bf16x8 (&bf)[2][2]) {
+    const char* const a_base = p.A.p0 + row0 * p.A.ld_bytes;
+    const char* const b_base = p.B.p0 + col0 * p.B.ld_bytes;
+    // half-tile q (0 A0, 1 B0, 2 B1, 3 A1) of k tile kt; the stage is the parity of the tile's index WITHIN the piece
+    auto dma = [&](auto qc, int kt) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int off = q == 0 ? pp::OFF_A0 : q == 1 ? pp::OFF_B0 : q == 2 ? pp::OFF_B1 : pp::OFF_A1;
+      const char* sb = ((q == 0 || q == 3) ? a_base : b_base) + static_cast<int64_t>(kt) * 128;
+      const unsigned dst = lds0 + static_cast<unsigned>(((kt - kb) & 1) * pp::STAGE + off);
+      const unsigned o0 = q == 0 ? off_a[0][0] : q == 3 ? off_a[1][0] : q == 1 ? off_b[0][0] : off_b[1][0];
+      const unsigned o1 = q == 0 ? off_a[0][1] : q == 3 ? off_a[1][1] : q == 1 ? off_b[0][1] : off_b[1][1];
+      pp::glds16_so(sb, o0, dst);
+      pp::glds16_so(sb, o1, dst + 1024u);
+    };
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      bf[nt][0] = *reinterpret_cast<const bf16x8*>(st + off + (fb - smem) + nt * 2048 + fo0);
-      bf[nt][1] = *reinterpret_cast<const bf16x8*>(st + off + (fb - smem) + nt * 2048 + fo1);
-    }
-  };
-  auto quadrant = [&](auto mhc, auto nhc, const bf16x8 (&bf)[2][2]) {
-    constexpr int mh = decltype(mhc)::value, nh = decltype(nhc)::value;
-    __builtin_amdgcn_s_setprio(1);
-    if constexpr (MODE == MDG_PREC_BF16) {
+    for (int a = 0; a < 8; ++a)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4][2], b0f[2][2], b1f[2][2];                    // [tile][k chunk group: bf16 k 0..31 / 32..63, bf16x3 hi / lo]
+    auto read_a = [&](const char* st, int off) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+      for (int mt = 0; mt < 4; ++mt) {
+        af[mt][0] = *reinterpret_cast<const bf16x8*>(st + off + fa + mt * 2048 + fo0);
+        af[mt][1] = *reinterpret_cast<const bf16x8*>(st + off + fa + mt * 2048 + fo1);
+      }
+    };
+    auto read_b = [&](const char* st, int off, bf16x8 (&bf)[2][2]) {
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[4 * mh + mt][2 * nh + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][ks], bf[nt][ks], acc[4 * mh + mt][2 * nh + nt], 0, 0, 0);
-    } else {
+      for (int nt = 0; nt < 2; ++nt) {
+        bf[nt][0] = *reinterpret_cast<const bf16x8*>(st + off + fb + nt * 2048 + fo0);
+        bf[nt][1] = *reinterpret_cast<const bf16x8*>(st + off + fb + nt * 2048 + fo1);
+      }
+    };
+    auto quadrant = [&](auto mhc, auto nhc, const bf16x8 (&bf)[2][2]) {
+      constexpr int mh = decltype(mhc)::value, nh = decltype(nhc)::value;
+      __builtin_amdgcn_s_setprio(1);
+      if constexpr (MODE == MDG_PREC_BF16) {
 #pragma unroll
-      for (int pr = 0; pr < 3; ++pr)                          // lo.hi, hi.lo, hi.hi: per element the order of the 128-tile kernel
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+          for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[4 * mh + mt][2 * nh + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][pr == 0 ? 1 : 0], bf[nt][pr == 1 ? 1 : 0],
-                                                                                    acc[4 * mh + mt][2 * nh + nt], 0, 0, 0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-  };
-  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+            for (int nt = 0; nt < 2; ++nt)
+              acc[4 * mh + mt][2 * nh + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][ks], bf[nt][ks], acc[4 * mh + mt][2 * nh + nt], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)                        // lo.hi, hi.lo, hi.hi: per element the order of the 128-tile kernel
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              acc[4 * mh + mt][2 * nh + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][pr == 0 ? 1 : 0], bf[nt][pr == 1 ? 1 : 0],
+                                                                                      acc[4 * mh + mt][2 * nh + nt], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    };
 
-  // ---- prologue: all of tile 0, A0 / B0 of tile 1 ----
-  dma(Q0{}, 0); dma(Q1{}, 0); dma(Q2{}, 0); dma(Q3{}, 0);
-  if (nk > 1) { dma(Q0{}, 1); dma(Q1{}, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();                  // the late half runs one barrier behind
-
-  for (int t = 0; t < nk; ++t) {
-    const char* const st = smem + (t & 1) * pp::STAGE;
-    // P1
-    read_b(st, pp::OFF_B0, b0f);
-    __builtin_amdgcn_sched_barrier(0);
-    read_a(st, pp::OFF_A0);
-    if (t + 1 < nk) dma(Q2{}, t + 1);
-    __builtin_amdgcn_s_barrier();
-    quadrant(I0{}, I0{}, b0f);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // P2
-    read_b(st, pp::OFF_B1, b1f);
-    if (t + 1 < nk) dma(Q3{}, t + 1);
-    __builtin_amdgcn_s_barrier();
-    quadrant(I0{}, I1{}, b1f);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // P3
-    read_a(st, pp::OFF_A1);
-    if (t + 2 < nk) dma(Q0{}, t + 2);
-    __builtin_amdgcn_s_barrier();
-    quadrant(I1{}, I1{}, b1f);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // P4
-    if (t + 2 < nk) { dma(Q1{}, t + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    // prologue: all of the first k tile, A0 / B0 of the second
+    dma(Q0{}, kb); dma(Q1{}, kb); dma(Q2{}, kb); dma(Q3{}, kb);
+    if (kb + 1 < ke) { dma(Q0{}, kb + 1); dma(Q1{}, kb + 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    quadrant(I1{}, I0{}, b0f);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-  }
-  if (wr == 0) __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();                // the late half runs one barrier behind
 
-  // ---- epilogue: as the 128-tile kernel (64 x 64 patches through 16 KB of LDS per wave, row-major 16-byte stores) ----
-  __syncthreads();
-  float* const slab = reinterpret_cast<float*>(smem) + wave * 4096;
-  const int64_t pm0 = row0 + wr * 128, pn0 = col0 + wc * 64;
+    for (int t = kb; t < ke; ++t) {
+      const char* const st = smem + ((t - kb) & 1) * pp::STAGE;
+      // P1
+      read_b(st, pp::OFF_B0, b0f);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(st, pp::OFF_A0);
+      if (t + 1 < ke) dma(Q2{}, t + 1);
+      __builtin_amdgcn_s_barrier();
+      quadrant(I0{}, I0{}, b0f);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // P2
+      read_b(st, pp::OFF_B1, b1f);
+      if (t + 1 < ke) dma(Q3{}, t + 1);
+      __builtin_amdgcn_s_barrier();
+      quadrant(I0{}, I1{}, b1f);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // P3
+      read_a(st, pp::OFF_A1);
+      if (t + 2 < ke) dma(Q0{}, t + 2);
+      __builtin_amdgcn_s_barrier();
+      quadrant(I1{}, I1{}, b1f);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // P4
+      if (t + 2 < ke) { dma(Q1{}, t + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      quadrant(I1{}, I0{}, b0f);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    __syncthreads();                                          // every wave is done with the stages (the epilogue / the next piece reuses them)
+  };
+
+  // epilogue: as the 128-tile kernel (64 x 64 patches through 16 KB of LDS per wave, row-major 16-byte stores)
+  auto epilogue = [&](int tx, int ty) {
+    const Lane L = lane_roles();
+    const int lane = L.lane, wave = L.wave, wr = L.wr, wc = L.wc, c = L.c, g = L.g;
+    float* const slab = reinterpret_cast<float*>(smem) + wave * 4096;
+    const int64_t pm0 = static_cast<int64_t>(ty) * pp::BM + wr * 128, pn0 = static_cast<int64_t>(tx) * pp::BN + wc * 64;
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+      for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) slab[slab_off(mt * 16 + 4 * g + v, nt * 16 + c)] = acc[pass * 4 + mt][nt][v];
-    slab_to_global(p, slab, pm0 + pass * 64, pn0, lane);
+          for (int v = 0; v < 4; ++v) slab[slab_off(mt * 16 + 4 * g + v, nt * 16 + c)] = acc[pass * 4 + mt][nt][v];
+      slab_to_global(p, slab, pm0 + pass * 64, pn0, lane);
+    }
+  };
+
+  if constexpr (!SK) {                                        // one tile per workgroup
+    int tx, ty;
+    if (!tile_of(p, static_cast<int>(blockIdx.x), tx, ty)) return;          // workgroup-uniform
+    run_piece(tx, ty, 0, nk);
+    epilogue(tx, ty);
+    return;
+  }
+  // ---- stream-K launch: the workgroup's pieces are whole tiles first (me, me + P, ...), then its run of the shared k tiles.
+  // ONE instance of the main loop serves all of them. ----
+  const int P = static_cast<int>(gridDim.x), me = static_cast<int>(blockIdx.x);
+  const int total = p.tiles_x * p.tiles_y, dp_tiles = total - p.sk_tiles;
+  unsigned* const flags = reinterpret_cast<unsigned*>(p.sk_ws + static_cast<size_t>(pp::MAX_WG) * pp::SLOT_FLOATS * 4);
+  const int64_t units = static_cast<int64_t>(p.sk_tiles) * nk;
+  const auto run_start = [&](int w) { return units * w / P; };
+  int64_t u = run_start(me);
+  const int64_t u_end = run_start(me + 1);
+  int dp_id = me;
+  for (;;) {
+    int tx, ty, kb = 0, ke = nk, st = 0;
+    if (dp_id < dp_tiles) {
+      tile_of_bijective(p, dp_id, tx, ty);
+      dp_id += P;
+    } else if (u < u_end) {
+      st = static_cast<int>(u / nk);
+      kb = static_cast<int>(u - static_cast<int64_t>(st) * nk);
+      const int64_t left = u_end - static_cast<int64_t>(st) * nk;
+      ke = static_cast<int>(left < nk ? left : nk);
+      tile_of_bijective(p, dp_tiles + st, tx, ty);
+      u += ke - kb;
+    } else {
+      break;
+    }
+    run_piece(tx, ty, kb, ke);
+    const int tid = lane_roles().tid;
+    if (kb != 0) {
+      // not the tile's first piece: publish the accumulators (this workgroup's only published piece: its run starts here).
+      // Write-through (sc1) stores: no release fence -- which would write back every dirty line of this XCD's L2, the output
+      // tiles of its 32 workgroups included -- just the stores' own completion before the flag.
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.sk_ws + static_cast<size_t>(me) * pp::SLOT_FLOATS * 4, 0, pp::SLOT_FLOATS * 4, 0x00020000);
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[a][b]), rs, static_cast<unsigned>(((a * 4 + b) * pp::THREADS + tid) * 16), 0, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(&flags[me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      // the tile's first piece; when it stops short of the tile's end, add the pieces of the workgroups behind this one
+      int covered = ke;
+      for (int w = me + 1; covered < nk && w < P; ++w) {
+        const int64_t ws0 = run_start(w), ws1 = run_start(w + 1);
+        const int64_t tile_end = static_cast<int64_t>(st + 1) * nk;
+        const int len = static_cast<int>((ws1 < tile_end ? ws1 : tile_end) - ws0);
+        if (len <= 0) continue;                               // an empty run (more workgroups than k tiles)
+        if (tid == 0) {
+          unsigned spins = 0;
+          while (__hip_atomic_load(&flags[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < pp::SPIN_LIMIT) __builtin_amdgcn_s_sleep(32);
+          if (spins >= pp::SPIN_LIMIT) __hip_atomic_store(&flags[pp::MAX_WG], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // error word
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        const f32x4* theirs = reinterpret_cast<const f32x4*>(p.sk_ws) + static_cast<size_t>(w) * (pp::SLOT_FLOATS / 4);
+#pragma unroll
+        for (int a = 0; a < 8; ++a)                           // (fully unrolled: a runtime index would put acc in scratch)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] += theirs[(a * 4 + b) * pp::THREADS + tid];
+        covered += len;
+      }
+      epilogue(tx, ty);
+    }
+    __syncthreads();                                          // slab / slot traffic done before the next piece's LDS-DMA
   }
 }
 
@@ -887,12 +1013,27 @@ static void set_operand(Operand& o, const float* raw, int64_t ld, const char* im
   set_image(o, image, rows, pad_k(K, precision), precision);
 }
 
-static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t N, hipStream_t st) {
+// workgroups a persistent launch may count on being resident together: one 128-KB-LDS workgroup per CU
+static int resident_workgroups() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = pp::MAX_WG;
+    return cus < pp::MAX_WG ? cus : pp::MAX_WG;
+  }();
+  return n;
+}
+
+static bool pp_shape(int precision, int64_t M, int64_t N) {
+  return precision != MDG_PREC_F32 && N >= 256 && M >= 1024 && mdg_cdiv(M, pp::BM) * mdg_cdiv(N, pp::BN) >= 192;
+}
+
+// sk_ws / sk_avail: what is left of the caller's workspace behind the operand images (the stream-K slots and flags)
+static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t N, hipStream_t st, char* sk_ws = nullptr, size_t sk_avail = 0) {
   a.vec_y = mdg_aligned16(a.y) && a.ldy % 4 == 0;
   a.vec_r = a.res && mdg_aligned16(a.res) && a.ldr % 4 == 0;
   // tile shape: the 256x256 / 8-wave shape once the problem fills the chip with it, else 128x128 / 4 waves
   // (measured on the fusion GEMMs: bf16x3 -9 % time with the big tile, fp32 +6 %: the fp32 MFMA wants two workgroups per CU)
-  bool big = (precision != MDG_PREC_F32 && N >= 256 && M >= 1024 && mdg_cdiv(M, pp::BM) * mdg_cdiv(N, pp::BN) >= 192);
+  bool big = pp_shape(precision, M, N);
   static MdgEnvInt tile_sw{"MDG_LINEAR_TILE", 0};
   if (tile_sw.get() == 256) big = true;
   else if (tile_sw.get() == 128) big = false;
@@ -910,9 +1051,35 @@ static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t 
   static MdgEnvInt mfma_sw{"MDG_LINEAR_MFMA", 16};
   const bool m16 = mfma_sw.get() != 32;
   if (big) {
-    const dim3 grid = grid_for(pp::BM, pp::BN);
-    if (precision == MDG_PREC_BF16X3) hipLaunchKernelGGL((linear_pp_kernel<MDG_PREC_BF16X3>), grid, dim3(pp::THREADS), pp::LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((linear_pp_kernel<MDG_PREC_BF16>), grid, dim3(pp::THREADS), pp::LDS_BYTES, st, a);
+    dim3 grid = grid_for(pp::BM, pp::BN);
+    // stream-K hybrid when the last round of tiles would leave CUs idle (see the kernel): needs the slots in the workspace
+    // Measured: OFF by default.  A persistent workgroup pays for what the hardware's own dispatch hides --
+    // the epilogue's store drain in front of the next tile's first counted wait (stores and LDS-DMA share vmcnt), the pipeline
+    // fill of every piece, the slot round trip -- about +11 us per 65-us tile, which is what the saved part of a round is worth
+    // at these sizes ([22464, 2048] x 2048: 216-233 us plain, 251 us hybrid).  MDG_LINEAR_STREAMK=1 switches it on, 2 runs the
+    // persistent loop without shared tiles.
+    static MdgEnvInt sk_sw{"MDG_LINEAR_STREAMK", 0};
+    const int total = a.tiles_x * a.tiles_y, P = resident_workgroups();
+    const int rem = total % P;
+    const int64_t nk = a.K / (precision == MDG_PREC_BF16 ? 64 : 32);
+    a.sk_tiles = 0;
+    a.sk_ws = nullptr;
+    if (sk_sw.get() && sk_ws && sk_avail >= pp::sk_bytes() && (reinterpret_cast<uintptr_t>(sk_ws) & 15u) == 0 && rem != 0 && rem * 20 <= P * 17 &&
+        nk >= 8 && static_cast<int64_t>(rem) * nk >= P) {
+      a.sk_tiles = rem;
+      a.sk_ws = sk_ws;
+      (void)hipMemsetAsync(sk_ws + static_cast<size_t>(pp::MAX_WG) * pp::SLOT_FLOATS * 4, 0, 4096, st);       // flags | error word
+      grid = dim3(static_cast<unsigned>(P));
+    }
+    const bool persistent = a.sk_tiles != 0 || (sk_sw.get() == 2 && sk_ws && sk_avail >= pp::sk_bytes());   // 2: persistent loop without shared tiles (diagnostics)
+    if (persistent && !a.sk_tiles) { a.sk_ws = sk_ws; grid = dim3(static_cast<unsigned>(P)); }
+    if (persistent) {
+      if (precision == MDG_PREC_BF16X3) hipLaunchKernelGGL((linear_pp_kernel<MDG_PREC_BF16X3, true>), grid, dim3(pp::THREADS), pp::LDS_BYTES, st, a);
+      else hipLaunchKernelGGL((linear_pp_kernel<MDG_PREC_BF16, true>), grid, dim3(pp::THREADS), pp::LDS_BYTES, st, a);
+    } else {
+      if (precision == MDG_PREC_BF16X3) hipLaunchKernelGGL((linear_pp_kernel<MDG_PREC_BF16X3, false>), grid, dim3(pp::THREADS), pp::LDS_BYTES, st, a);
+      else hipLaunchKernelGGL((linear_pp_kernel<MDG_PREC_BF16, false>), grid, dim3(pp::THREADS), pp::LDS_BYTES, st, a);
+    }
     return;
   }
   using S = Small;
@@ -947,7 +1114,12 @@ extern "C" int mdg_pack_operand(const float* src, int64_t ld, int64_t rows, int6
 
 extern "C" size_t mdg_linear_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision, int w_is_packed) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return image_bytes(M, K, precision) + (w_is_packed ? 0 : image_bytes(N, K, precision));
+  return image_bytes(M, K, precision) + (w_is_packed ? 0 : image_bytes(N, K, precision)) + (pp_shape(precision, M, N) ? pp::sk_bytes() : 0);
+}
+
+extern "C" size_t mdg_linear_packed_x_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision, int w_is_packed) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return (w_is_packed ? 0 : image_bytes(N, K, precision)) + (pp_shape(precision, M, N) ? pp::sk_bytes() : 0);
 }
 
 extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const void* w_packed, float* y, int64_t ldy,
@@ -970,7 +1142,7 @@ extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t l
   const size_t xb = image_bytes(M, K, precision), wb = image_bytes(N, K, precision);
   const bool w_ready = w_packed != nullptr || wb == 0;      // fp32 with K % 32 == 0 needs no image at all
   MDG_CHECK_ARG(w || w_ready, "mdg_linear: raw w missing");
-  const size_t need = xb + (w_ready ? 0 : wb);
+  const size_t need = xb + (w_ready ? 0 : wb);          // (+ the stream-K slots where the shape takes them: optional, used when present)
   if (need && (!workspace || workspace_bytes < need || !mdg_aligned16(workspace))) {
     mdg_set_error("mdg_linear: workspace of %zu bytes (16-byte aligned) required, got %zu", need, workspace_bytes);
     return MDG_EWORKSPACE;
@@ -987,7 +1159,7 @@ extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t l
   a.alpha = alpha; a.beta = beta; a.act = act; a.M = M; a.N = N; a.K = pad_k(K, precision);
   set_operand(a.A, x, ldx, ximg, M, K, precision);
   set_operand(a.B, w, ldw, wb == 0 ? nullptr : (w_packed ? static_cast<const char*>(w_packed) : wimg), N, K, precision);
-  launch_linear_core(a, precision, M, N, st);
+  launch_linear_core(a, precision, M, N, st, workspace ? ws + need : nullptr, workspace_bytes > need ? workspace_bytes - need : 0);
   MDG_CHECK_LAUNCH("mdg_linear");
   return MDG_OK;
 }
@@ -1043,7 +1215,7 @@ static size_t image_bytes_t(int64_t rows, int64_t inner, int precision) {      /
 }
 
 extern "C" size_t mdg_linear_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision) {
-  return image_bytes_t(N, M, precision) + image_bytes_t(K, M, precision);
+  return image_bytes_t(N, M, precision) + image_bytes_t(K, M, precision) + (pp_shape(precision, N, K) ? pp::sk_bytes() : 0);
 }
 
 extern "C" int mdg_linear_tn(const float* g, int64_t ldg, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K,
@@ -1071,7 +1243,7 @@ extern "C" int mdg_linear_tn(const float* g, int64_t ldg, const float* x, int64_
   a.y = y; a.ldy = ldy; a.alpha = 1.f; a.beta = 0.f; a.act = MDG_ACT_NONE; a.M = N; a.N = K; a.K = Mp;
   set_image(a.A, aimg, N, Mp, precision);
   set_image(a.B, bimg, K, Mp, precision);
-  launch_linear_core(a, precision, N, K, st);
+  launch_linear_core(a, precision, N, K, st, aimg + ab + bb, workspace_bytes - ab - bb);
   MDG_CHECK_LAUNCH("mdg_linear_tn");
   return MDG_OK;
 }
@@ -1148,7 +1320,11 @@ extern "C" int mdg_linear_packed_x(const void* x_packed, int64_t M, int64_t K, c
   a.y = y; a.ldy = ldy; a.bias = bias; a.res = residual; a.ldr = ldr; a.alpha = alpha; a.beta = beta; a.act = act; a.M = M; a.N = N; a.K = K;
   set_operand(a.A, nullptr, 0, static_cast<const char*>(x_packed), M, K, precision);
   set_operand(a.B, w, ldw, w_packed ? static_cast<const char*>(w_packed) : wimg, N, K, precision);
-  launch_linear_core(a, precision, M, N, st);
+  {
+    const size_t used = w_packed ? 0 : wb;
+    char* wsb = static_cast<char*>(workspace);
+    launch_linear_core(a, precision, M, N, st, (wsb && workspace_bytes > used) ? wsb + used : nullptr, workspace_bytes > used ? workspace_bytes - used : 0);
+  }
   MDG_CHECK_LAUNCH("mdg_linear_packed_x");
   return MDG_OK;
 }

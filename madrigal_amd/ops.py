@@ -309,9 +309,11 @@ def linear_packed(x_img: torch.Tensor, M: int, weight: torch.Tensor, bias: Optio
                 raise ValueError(f"residual: expected [{M},{N}] or [{N}]")
             ldr = residual.stride(0)
     wimg = packed_weight_image(w, prec)
+    nbytes = lib().mdg_linear_packed_x_workspace_bytes(_c64(M), _c64(N), _c64(K), _c(prec), _c(1))        # the stream-K slots of the 256-tile kernel
+    ws = _workspace(nbytes, x_img.device)
     check(lib().mdg_linear_packed_x(_ptr(x_img), _c64(M), _c64(K), _ptr(w), _c64(w.stride(0)), _ptr(wimg), _ptr(out), _c64(out.stride(0)), _c64(N),
                                     _ptr(None if bias is None else bias.detach().contiguous()), _c(ACTS[act]), _ptr(residual), _c64(ldr),
-                                    _f(alpha), _f(beta), _c(prec), _ptr(None), ctypes.c_size_t(0), _stream(x_img)), "mdg_linear_packed_x")
+                                    _f(alpha), _f(beta), _c(prec), _ptr(ws), ctypes.c_size_t(nbytes), _stream(x_img)), "mdg_linear_packed_x")
     return out
 
 

@@ -38,18 +38,27 @@ if "check" in sys.argv:
     for (M, N, K) in [(1024, 256 * 48, 64), (1500, 256 * 40 + 36, 100), (4096 + 77, 3072 + 4, 2048), (22464, 2048, 2048), (2048, 6144, 128), (1024 * 50, 256, 192)]:
         x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5
         b = torch.randn(N, device="cuda"); r = torch.randn(M, N, device="cuda")
-        os.environ["MDG_LINEAR_TILE"] = "256"; lib().mdg_tuning_reload()
-        y1 = ops.linear(x, w, b, act="gelu", residual=r, precision=prec, cache_weight=False)
-        os.environ["MDG_LINEAR_TILE"] = "128"; lib().mdg_tuning_reload()
-        y0 = ops.linear(x, w, b, act="gelu", residual=r, precision=prec, cache_weight=False)
-        os.environ.pop("MDG_LINEAR_TILE"); lib().mdg_tuning_reload()
+        def run(tile, sk):
+            os.environ["MDG_LINEAR_TILE"] = tile; os.environ["MDG_LINEAR_STREAMK"] = sk; lib().mdg_tuning_reload()
+            return ops.linear(x, w, b, act="gelu", residual=r, precision=prec, cache_weight=False)
+        y0 = run("128", "0")
+        y1 = run("256", "0")                 # one tile per workgroup: the 128-tile kernel's sums, bit for bit
+        y2 = run("256", "1")                 # stream-K hybrid (where the shape takes it): split tiles group their sums differently
+        y3 = run("256", "1")
+        for k_ in ("MDG_LINEAR_TILE", "MDG_LINEAR_STREAMK"):
+            os.environ.pop(k_)
+        lib().mdg_tuning_reload()
         rows = torch.randint(0, M, (64,), device="cuda"); rows[0] = M - 1; rows[1] = 0
         ref = torch.nn.functional.gelu(x[rows].double() @ w.double().T + b.double()) + r[rows].double()
-        err = float((y1[rows].double() - ref).abs().max() / ref.abs().max())
+        err = float((y2[rows].double() - ref).abs().max() / ref.abs().max())
         same = bool(torch.equal(y0, y1))
+        sk_diff = float((y2 - y1).abs().max() / y1.abs().max())
+        repro = bool(torch.equal(y2, y3))
+        changed = float((y2 != y1).float().mean())
         worst = max(worst, err)
-        print(f"{prec} M={M} N={N} K={K}: 256-tile vs fp64 rel err {err:.2e}; bit-identical to the 128-tile kernel: {same}", flush=True)
-        assert same and err < (3e-2 if prec == "bf16" else 2e-5)
+        print(f"{prec} M={M} N={N} K={K}: vs fp64 rel err {err:.2e}; 256-tile == 128-tile bits: {same}; stream-K vs plain: max rel diff {sk_diff:.1e} "
+              f"({changed:.1%} of entries differ), reproducible: {repro}", flush=True)
+        assert same and repro and sk_diff < 2e-6 and err < (3e-2 if prec == "bf16" else 2e-5)
     print("check ok")
     sys.exit(0)
 
