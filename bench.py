@@ -456,13 +456,17 @@ def pretrain_leg(model, bkg, masks_all, args, precision="bf16x3"):
     # the first B drugs of the bench's drug table: their KG membership is a property of the bench's KG (drug_index_map)
     avail = masks_all[:B].clone().cpu()
     avail[:, 2] = torch.where(avail[:, 1:].all(dim=1), torch.zeros(B, dtype=torch.bool), avail[:, 2])       # every drug owns a second modality
-    batch, _ = D.make_batch(B, 0, kg=bkg["data"].to("cpu"), masks=avail)
+    bkg_cpu = {"data": bkg["data"].to("cpu"), "drug_index_map": bkg["drug_index_map"].cpu()}
+    batch, _ = D.make_batch(B, 0, kg=bkg_cpu["data"], masks=avail)
     np.random.seed(0)
     sim = SimCLR_NovelDDI(model.encoder, dim=128, mlp_dim=512, T=0.1, raw_encoder_output=True).to(dev).train()
     b = D.batch_to(batch, dev)
     kgc = bkg
     draw = MK.StrCenterUniSampler(MK.get_pretrain_masks(list(range(B)), avail.numpy().astype(np.int64), "str_center_uni", False, 0.2))
-    step = PretrainStep(sim, AdamW(sim.parameters(), lr=1e-5, weight_decay=1e-2))
+    from madrigal_amd.optim import PretrainSchedule
+    # pretrain.py:65: the rate is set per iteration (madrigal/utils.py:680-692); a 100-iteration epoch, one warm-up epoch of ten
+    sched = PretrainSchedule(lr=1e-5, warmup_epochs=1, num_epochs=10, iters_per_epoch=100, start_epoch=1)
+    step = PretrainStep(sim, AdamW(sim.parameters(), lr=1e-5, weight_decay=1e-2), scheduler=sched)
     data = (b["strs"], kgc, b["cv"], b["tx"])
     losses = []
     with M.precision(precision):
@@ -474,11 +478,95 @@ def pretrain_leg(model, bkg, masks_all, args, precision="bf16x3"):
             losses.append(step.step(batch["drugs"], m1, m2, None, data))
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.pretrain_steps
-    return {"metric": "contrastive-pretraining steps/sec", "value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "drugs_per_s": B / dt,
-            "n_gpus": 1, "steps": args.pretrain_steps, "warmup": 2, "batch": B, "dtype": "f32 via split-bf16 (bf16x3) MFMA",
-            "loss_first_last": [float(losses[0]), float(losses[-1])],
-            "config": {"workload": "BASELINE configs[2] as shipped: SimCLR_NovelDDI(raw_encoder_output=True), 'str_center_uni' views drawn per "
-                                   "iteration on the host, separate predictors, T=0.1, mlp_dim=512, AdamW; the bench's KG"}}
+    out = {"metric": "contrastive-pretraining steps/sec", "value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "drugs_per_s": B / dt,
+           "n_gpus": 1, "steps": args.pretrain_steps, "warmup": 2, "batch": B, "dtype": "f32 via split-bf16 (bf16x3) MFMA",
+           "loss_first_last": [float(losses[0]), float(losses[-1])], "lr_last": sched.last_lr,
+           "config": {"workload": "BASELINE configs[2] as shipped: SimCLR_NovelDDI(raw_encoder_output=True), 'str_center_uni' views drawn per "
+                                  "iteration on the host, separate predictors, T=0.1, mlp_dim=512, AdamW with the per-iteration "
+                                  "warm-up / cosine rate of pretrain.py:65; the bench's KG"}}
+    # roofline of the step's dominant kernel family, the KG edge attention (forward + two backward kernels: a quarter of the step's
+    # kernel time, profiles/): the forward launch over every destination type of the first conv, HIP events on its own stream.
+    # per edge one 512-byte key row and one 512-byte value row are gathered plus the 8-byte source index; per
+    # destination node one 512-byte query row is read and one 512-byte row written.
+    try:
+        conv = model.encoder.kg_encoder.convs[0]
+        probe = {"start": torch.cuda.Event(enable_timing=True), "end": torch.cuda.Event(enable_timing=True)}
+        ms_all = []
+        sim.eval()
+        with torch.no_grad(), M.precision(precision):
+            for _ in range(4):
+                conv.__dict__["_attention_probe"] = probe
+                conv(kgc["data"].x_dict, kgc["data"].edge_index_dict)
+                torch.cuda.synchronize()
+                ms_all.append(probe["start"].elapsed_time(probe["end"]))
+        conv.__dict__.pop("_attention_probe", None)
+        ms = sorted(ms_all[1:])[1]
+        # bytes that must cross HBM once: the projection buffer (queries, keys', values' of every node), the edge list, the output
+        # rows; the rows GATHERED per edge (two 512-byte rows + the 8-byte index) are mostly re-reads served by L2 / the
+        # Infinity Cache -- both rates are reported
+        unique = probe["buffer_floats"] * 4.0 + probe["edges"] * 8.0 + probe["dst_rows"] * 512.0
+        gathered = probe["edges"] * (1024.0 + 8.0) + probe["dst_rows"] * 1024.0
+        out["roofline"] = {"bound": "hbm", "achieved": unique / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": unique / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "traffic": None, "kernel": "hgt_attention_kernel (edge softmax + weighted value sum, all destination types of one conv)",
+                           "kernel_ms": ms, "edges": probe["edges"], "destination_rows": probe["dst_rows"], "gathered_row_rate_GBps": gathered / (ms * 1e-3) / 1e9,
+                           "algorithmic_bytes": unique,
+                           "formula": "(projection buffer once + edges x 8 B + destination rows x 512 B) / launch time; gathered_row_rate = "
+                                      "(edges x (2 x 512 B + 8 B) + destination rows x 1024 B) / launch time (cache-served re-reads included)"}
+    except Exception as e:
+        out["roofline"] = {"bound": "hbm", "achieved": None, "error": f"{type(e).__name__}: {e}"[:300]}
+    finally:
+        sim.train()
+    if not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_pretrain_step({k: v.detach().cpu() for k, v in sim.state_dict().items()}, batch, bkg_cpu, avail, B)
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
+def cpu_pretrain_step(params, batch, bkg, avail, B: int, sample: int = 96, kg_edge_keep: int = 16):
+    """One contrastive-pretraining iteration of the oracle on the host (oracle.pipeline.oracle_simclr under training-mode batch
+    statistics + torch CPU autograd: pretrain.py:59-93 is exactly that over the reference's modules) on a bounded sample: the first
+    ``sample`` drugs, one 'str_center_uni' view pair, the KG thinned to every ``kg_edge_keep``-th edge.  Scaled to the full step:
+    the per-drug stages x B / sample, the KG encoder (run once per view, as the reference does) x kg_edge_keep."""
+    import numpy as np
+    import torch
+    from madrigal_amd import data as D, masks as MK
+    from madrigal_amd.pipeline import slice_batch
+    from oracle import madrigal_oracle as O
+    from oracle.pipeline import oracle_simclr
+    torch.set_num_threads(host_threads())
+    n = min(sample, B)
+    b = slice_batch(batch, 0, n)
+    kg = bkg["data"]
+    thin = {"data": D.KGData(kg.x_dict, {k: v[:, ::kg_edge_keep].contiguous() for k, v in kg.edge_index_dict.items()}, list(kg.node_types), list(kg.edge_types)),
+            "drug_index_map": bkg["drug_index_map"]}
+    np.random.seed(1)
+    draw = MK.StrCenterUniSampler(MK.get_pretrain_masks(list(range(n)), avail[:n].numpy().astype(np.int64), "str_center_uni", False, 0.2))
+    m1, m2 = draw(range(n))
+    pr = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in params.items()}
+    filler = torch.zeros(max(int(b["drugs"].max()) + 1, int(bkg["drug_index_map"].max()) + 1), 128)
+    # the KG encoder alone (twice per step in the reference: once per view) to split the time
+    enc = O._sub({"encoder." + k: v for k, v in O._sub(pr, "base_encoder.").items()}, "encoder.")
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.hgt_forward(O._sub(enc, "kg_encoder."), thin["data"].x_dict, thin["data"].edge_index_dict, thin["data"].node_types, thin["data"].edge_types,
+                      num_layers=2, heads=4, hidden=128)
+        t_kg = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with O.batch_statistics():
+        ref = oracle_simclr(pr, b, thin, m1, m2, None, 0.1, filler)
+    t_fwd = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ref["loss"].backward()
+    t_bwd = time.perf_counter() - t0
+    ratio = t_bwd / max(t_fwd, 1e-9)
+    kg_fwd = 2 * t_kg
+    est = ((t_fwd - kg_fwd) * B / n + kg_fwd * kg_edge_keep) * (1.0 + ratio)
+    return {"value": 1.0 / est, "unit": "steps/s", "cores": host_threads(), "kind": "port",
+            "sample": f"oracle SimCLR step (torch CPU autograd, fp32) on {n} drugs, one view pair, KG thinned to 1/{kg_edge_keep} of its edges; "
+                      f"scaled to {B} drugs and the full KG (per-drug stages x {B / n:.1f}, KG encoder x {kg_edge_keep})",
+            "detail": {"forward_s": t_fwd, "backward_s": t_bwd, "kg_forward_once_s": t_kg, "step_s_extrapolated": est, "loss": float(ref["loss"].detach())}}
 
 
 def main():

@@ -569,16 +569,27 @@ class HGTConv(nn.Module):
         big_b = torch.cat([bq.reshape(-1), torch.stack([bK, bV], dim=1).reshape(-1)], 0).index_select(0, perm)
         return big_w, big_b, offs
 
-    def _forward_train(self, x_dict, edge_index_dict, needed_types=None):
+    def _forward_train(self, x_dict, edge_index_dict, needed_types=None, shard=None):
         """Differentiated pass on the same flat projection layout as inference: one composite GEMM per node type writes
         q | k'_r v'_r ... into the flat buffer (ag.hgt_project), edge attention of all destination types reads queries, keys
         and values from it and returns ONE gradient buffer (ag.hgt_attention_flat), then GELU, output projection and the
-        sigmoid(skip) gate.  The composite weights are rebuilt from the live parameters each call."""
+        sigmoid(skip) gate.  The composite weights are rebuilt from the live parameters each call.
+
+        ``shard`` = (rank, world, group): the destination-partitioned conv of the data-parallel steps.  The projections (one
+        GEMM per node type over all nodes) run on every rank; the edge attention -- every KG edge -- and the output stage only
+        for this rank's block of each destination type; the blocks of all ranks and types travel in ONE all-gather whose
+        backward is the reverse exchange (all-reduce of the gathered rows' gradients, own block kept: parallel.py).  A rank's
+        backward pass then holds the gradient contributions of the edges INTO its blocks only; they are partial sums of the
+        parameter gradients, which the step's gradient all-reduce completes like every other data-parallel partial."""
         F, H = self.out_channels, self.heads
         dev = next(iter(x_dict.values())).device
         sizes = {t: int(x.shape[0]) for t, x in x_dict.items()}
         want = set(self.dst_node_types if needed_types is None else needed_types)
-        plan = self._plan(edge_index_dict, sizes, dev, want)
+        dst_range = None
+        if shard is not None and shard[1] > 1:
+            from .parallel import shard_range
+            dst_range = {t: shard_range(sizes[t], shard[0], shard[1]) for t in sizes}
+        plan = self._plan(edge_index_dict, sizes, dev, want, dst_range)
         types = [t for t in x_dict if not ((plan["nrel"][t] == 0 and t not in want) or sizes[t] == 0)]
         layout = [(plan["base"][t], sizes[t], plan["width"][t]) for t in types]
         spec = dict(zip(types, layout))
@@ -590,14 +601,39 @@ class HGTConv(nn.Module):
             mk_all, mv_all = self._relation_blocks_train()
             ws, bs = zip(*(self._composite_projection_train(t, plan, mk_all, mv_all) for t in types)) if types else ((), ())
             flat = ag.hgt_project(layout, plan["total_floats"], _state["precision"], xs, list(ws), list(bs))
-        dst_types = [t for t in self.node_types if t in self.dst_node_types and t in x_dict and t in want and sizes[t] > 0]
-        pres = ag.hgt_attention_flat(flat, H, [plan["per_dst"][t] for t in dst_types], [spec[t] for t in dst_types])
+        rng = {t: ((0, sizes[t]) if dst_range is None else dst_range[t]) for t in sizes}
+        dst_all = [t for t in self.node_types if t in self.dst_node_types and t in x_dict and t in want and sizes[t] > 0]
+        dst_types = [t for t in dst_all if rng[t][1] > rng[t][0]]        # (a rank's block of a small type may be empty)
+
+        def block(t):                                                  # this rank's rows of type t inside the flat buffer
+            off, _, width = spec[t]
+            return (off + rng[t][0] * width, rng[t][1] - rng[t][0], width)
+        pres = ag.hgt_attention_flat(flat, H, [plan["per_dst"][t] for t in dst_types], [block(t) for t in dst_types]) if dst_types else ()
         out = {}
         for t, pre in zip(dst_types, pres):
             lin = self.out_lin.lins[t]
             o = _linT(ag.activation(pre, "gelu"), lin.weight, lin.bias)
-            out[t] = ag.gated_residual(o, x_dict[t].float(), self.skip[t]) if x_dict[t].shape[-1] == F else o
-        return out
+            xr = x_dict[t].float()
+            out[t] = ag.gated_residual(o, xr[rng[t][0]:rng[t][1]] if dst_range is not None else xr, self.skip[t]) if x_dict[t].shape[-1] == F else o
+        if dst_range is None:
+            return out
+        # one exchange step for every destination type (as the inference conv): each rank's blocks back to back, gathered with a
+        # gradient, re-cut per type
+        from .parallel import all_gather_rows_grad, shard_range
+        rank, world, group = shard
+        per_rank = [[shard_range(sizes[t], r, world)[1] - shard_range(sizes[t], r, world)[0] for t in dst_all] for r in range(world)]
+        parts = [out[t] if t in out else torch.zeros((0, F), dtype=torch.float32, device=dev) for t in dst_all]
+        local = torch.cat(parts, dim=0) if parts else torch.zeros(0, F, device=dev)
+        totals = [sum(v) for v in per_rank]
+        full = all_gather_rows_grad(local, sum(totals), rank, world, group, sizes=totals)
+        res, start = {}, [sum(totals[:r]) for r in range(world)]
+        for ti, t in enumerate(dst_all):
+            cut = []
+            for r in range(world):
+                off = start[r] + sum(per_rank[r][:ti])
+                cut.append(full[off: off + per_rank[r][ti]])
+            res[t] = torch.cat(cut, dim=0)
+        return res
 
     def _forward_grouped(self, x_dict, plan, sizes, want, dev):
         """Inference conv with the per-node-type layers grouped: the composite projections of all node types are ONE launch
@@ -670,7 +706,13 @@ class HGTConv(nn.Module):
         drow, rows_dst = tabs["drow"], tabs["rows_dst"]
         agg_all = torch.empty((rows_dst, F), dtype=torch.float32, device=dev)
         if tabs["att"] is not None:
+            probe = self.__dict__.get("_attention_probe")            # bench.py: HIP events around this launch + its edge count
+            if probe is not None:
+                probe["start"].record(torch.cuda.current_stream(dev))
             ops.hgt_attention_rows(buf, tabs["att"], self.heads, agg_all, apply_gelu=True)
+            if probe is not None:
+                probe["end"].record(torch.cuda.current_stream(dev))
+                probe["edges"], probe["dst_rows"], probe["buffer_floats"] = int(tabs["att"]["col"].numel()), int(rows_dst), int(plan["total_floats"])
         alphas = tuple(self._skip_alpha(t) if gated else 1.0 for t in dst_types)
         if tabs["out"] is None or tabs["alphas"] != alphas:             # the gates sit in the table: rebuilt when a skip parameter changes
             groups = [dict(m_base=drow[t], rows=sizes[t], n_base=F * i, n=F, y_off=drow[t] * F, ldy=F, alpha=a, beta=1.0 - a,
@@ -698,9 +740,7 @@ class HGTConv(nn.Module):
         and the output projection only for this rank's block of each destination type, then the blocks of all ranks and types
         travel in ONE all-gather.  Rows come out bit-identical to the unpartitioned conv."""
         if _train_path(self) or ag.needs_grad(*x_dict.values()):
-            if shard is not None and shard[1] > 1:
-                raise NotImplementedError("the destination-partitioned KG conv is an inference path (training keeps the KG encoder replicated)")
-            return self._forward_train(x_dict, edge_index_dict, needed_types)
+            return self._forward_train(x_dict, edge_index_dict, needed_types, shard)
         F = self.out_channels
         dev = next(iter(x_dict.values())).device
         sizes = {t: int(x.shape[0]) for t, x in x_dict.items()}

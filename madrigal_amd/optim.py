@@ -154,6 +154,36 @@ class LinearWarmupCosineDecaySchedule(torch.optim.lr_scheduler._LRScheduler):
         return [b * f for b in self.base_lrs]
 
 
+def adjust_learning_rate(optimizer, cur_epoch: float, lr: float, warmup_epochs: float, num_epochs: float) -> float:
+    """madrigal/utils.py:680-692: the contrastive loop's schedule -- linear warm-up to ``lr`` over ``warmup_epochs``, then one
+    half-cosine down to 0 at ``num_epochs``; ONE rate for every parameter group (the reference's TODO stands), written into the
+    groups and returned.  ``cur_epoch`` is fractional: pretrain.py:65 passes epoch + i / iters_per_epoch, every iteration."""
+    if cur_epoch < warmup_epochs:
+        lr = lr * cur_epoch / warmup_epochs
+    else:
+        lr = lr * 0.5 * (1. + math.cos(math.pi * (cur_epoch - warmup_epochs) / (num_epochs - warmup_epochs)))
+    for group in optimizer.param_groups:
+        group['lr'] = lr
+    return lr
+
+
+class PretrainSchedule:
+    """The per-iteration rate of pretrain.py:59-66 as a hook for ``train.PretrainStep(scheduler=...)``: called with the optimizer
+    before every step, it counts the iterations itself (``iters_per_epoch`` of them to an epoch) and applies
+    ``adjust_learning_rate`` with hparams['pretrain_lr'], ['warmup_epochs'], ['pretrain_num_epochs']."""
+
+    def __init__(self, lr: float, warmup_epochs: float, num_epochs: float, iters_per_epoch: int, start_epoch: int = 0):
+        self.lr, self.warmup_epochs, self.num_epochs, self.iters_per_epoch = lr, warmup_epochs, num_epochs, int(iters_per_epoch)
+        self.iteration = int(start_epoch) * self.iters_per_epoch
+        self.last_lr = None
+
+    def __call__(self, optimizer) -> float:
+        epoch, i = divmod(self.iteration, self.iters_per_epoch)
+        self.last_lr = adjust_learning_rate(optimizer, epoch + i / self.iters_per_epoch, self.lr, self.warmup_epochs, self.num_epochs)
+        self.iteration += 1
+        return self.last_lr
+
+
 def parameter_names_outside(model: nn.Module, forbidden: tuple, prefix: str = "") -> List[str]:
     """Names of the parameters that do not live inside a module of a ``forbidden`` type (the reference's
     get_parameter_names, madrigal/utils.py:446-460, including its exclusion of the encoder's own cls / bottleneck

@@ -35,7 +35,8 @@ class FinetuneStep:
     """``step(...)`` = one optimizer step of the reference's 'full_full' / 'double_random' modes;
     ``accumulate(...)`` = one ``loss.backward()`` of the multi-pass modes (call it per mask pair, then ``apply()``)."""
 
-    def __init__(self, model, optimizer, loss_readout: str = "mean", scheduler=None, rank: int = 0, world: int = 1, group=None):
+    def __init__(self, model, optimizer, loss_readout: str = "mean", scheduler=None, rank: int = 0, world: int = 1, group=None,
+                 shard_kg: bool = True):
         """``world > 1``: data-parallel step over one process per GPU (the reference is single-GPU).  Every rank
         holds the full model and the full batch description; rank r encodes a contiguous block of drugs on both sides
         (SyncBatchNorm statistics over all ranks; the KG encoder is per-graph and runs replicated, once per step), the
@@ -43,6 +44,9 @@ class FinetuneStep:
         for the gathered head, and the parameter gradients are summed in flat buckets before the identical AdamW update."""
         self.model, self.optimizer, self.loss_readout, self.scheduler = model, optimizer, loss_readout, scheduler
         self.rank, self.world, self.group = rank, world, group
+        # data-parallel: the KG encoder's convs run destination-partitioned (HGTConv._forward_train(shard=...)): every KG edge is
+        # attended to on exactly one rank instead of on all of them; False keeps the KG encoder replicated
+        self.shard_kg = bool(shard_kg) and world > 1
         _refuse_rank_local_batchnorm(model.encoder, world)
         # single-pass steps overlap the gradient all-reduce with the backward pass (buckets issued from gradient hooks);
         # the multi-pass modes (accumulate() ... apply()) sum the finished gradients in flat buckets afterwards
@@ -83,7 +87,9 @@ class FinetuneStep:
         model, rank, world, group = self.model, self.rank, self.world, self.group
         ag.set_batchnorm_sync(lambda t: all_reduce_sum_(t, group))
         try:
-            kw = dict(kwargs, kg_share={}) if 'kg_share' not in kwargs else kwargs
+            kw = dict(kwargs, kg_share={}) if 'kg_share' not in kwargs else dict(kwargs)
+            if self.shard_kg:
+                kw['kg_shard'] = (rank, world, group)
             sides = []
             for side, batch, masks in (("head", batch_head, masks_head), ("tail", batch_tail, masks_tail)):
                 b, m, n = self._shard(batch, masks, side)
@@ -173,8 +179,11 @@ class PretrainStep:
     order; their sizes follow from the full mask tensors every rank holds ('str_center_uni' views: exactly one row per drug).
     With dropout off the sharded step reproduces the single-process step."""
 
-    def __init__(self, model, optimizer, rank: int = 0, world: int = 1, group=None):
-        self.model, self.optimizer, self.rank, self.world, self.group = model, optimizer, rank, world, group
+    def __init__(self, model, optimizer, rank: int = 0, world: int = 1, group=None, scheduler=None, shard_kg: bool = True):
+        """``shard_kg`` (world > 1): destination-partitioned KG convs, as in ``FinetuneStep``.  ``scheduler``: called with the optimizer at the top of every step, before ``zero_grad`` -- pretrain.py:65 adjusts the
+        learning rate per ITERATION (``optim.PretrainSchedule`` mirrors madrigal/utils.py:680-692); None keeps the rates."""
+        self.model, self.optimizer, self.rank, self.world, self.group, self.scheduler = model, optimizer, rank, world, group, scheduler
+        self.shard_kg = bool(shard_kg) and world > 1
         _refuse_rank_local_batchnorm(model.base_encoder, world)
         self._buckets = GradientBuckets(model.parameters(), group) if world > 1 else None
         self._last = None               # (key, sliced batch, batch_data): the slice of the LAST batch only (a DataLoader
@@ -198,6 +207,8 @@ class PretrainStep:
     def step(self, drug_indices, mask1, mask2, too_hard_neg, batch_data) -> torch.Tensor:
         model = self.model
         model.train()
+        if self.scheduler is not None:
+            self.scheduler(self.optimizer)
         self.optimizer.zero_grad(set_to_none=True)
         if self.world == 1:
             _, _, (_, _, loss) = model(drug_indices, mask1, mask2, too_hard_neg, batch_data)
@@ -217,7 +228,8 @@ class PretrainStep:
             views = []
             for masks, pred in ((mask1, p1), (mask2, p2)):
                 sizes = self._row_blocks(masks, B) if raw else None
-                e = model.base_encoder(b["drugs"], masks[lo:hi], b["strs"], kg, b["cv"], b["tx"], raw_encoder_output=raw, kg_share=share)
+                e = model.base_encoder(b["drugs"], masks[lo:hi], b["strs"], kg, b["cv"], b["tx"], raw_encoder_output=raw, kg_share=share,
+                                       **({"kg_shard": (self.rank, self.world, group)} if self.shard_kg else {}))
                 views.append(all_gather_rows_grad(_run_sequential_train(pred, e), sum(sizes) if raw else B, self.rank, self.world, group, sizes))
             _, _, loss = model.contrastive_loss(views[0], views[1], too_hard_neg)
             self._buckets.arm()                     # gradient buckets are all-reduced from hooks while backward still runs

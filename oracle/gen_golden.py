@@ -539,6 +539,25 @@ def gen_param_groups(M, C):
     save("param_groups", **out)
 
 
+def gen_pretrain_lr():
+    """The contrastive loop's per-ITERATION learning rate (pretrain.py:65 calls madrigal/utils.py:680-692 adjust_learning_rate
+    with cur_epoch = epoch + i / iters_per_epoch): the reference function itself on a two-group optimizer, over three epochs of
+    7 iterations with one warm-up epoch, and over a run whose warm-up is zero epochs long."""
+    import madrigal.utils as U
+    out = {}
+    for tag, (lr, warm, total, ipe) in {"a": (3e-4, 1, 3, 7), "b": (1e-3, 0, 2, 5), "c": (5e-5, 2, 10, 4)}.items():
+        ps = [torch.nn.Parameter(torch.zeros(1)) for _ in range(2)]
+        opt = torch.optim.AdamW([{"params": [ps[0]], "lr": 9.0}, {"params": [ps[1]], "lr": 7.0}])
+        got = []
+        for epoch in range(total):
+            for i in range(ipe):
+                ret = U.adjust_learning_rate(opt, epoch + i / ipe, lr, warm, total)
+                got.append([ret] + [g["lr"] for g in opt.param_groups])
+        out[f"{tag}_lrs"] = np.asarray(got, dtype=np.float64)
+        out[f"{tag}_cfg"] = np.asarray([lr, warm, total, ipe], dtype=np.float64)
+    save("pretrain_lr", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -552,6 +571,7 @@ def main():
         "pretrain_views": gen_pretrain_views, "simclr_raw": lambda: gen_simclr_raw(M, S, C),
         "checkpoints": lambda: gen_checkpoint_fixtures(args.ref, M, S, C), "ranks": lambda: gen_ranks(args.ref),
         "bce": gen_bce, "eval_masks": gen_eval_masks_and_schedule, "param_groups": lambda: gen_param_groups(M, C),
+        "pretrain_lr": gen_pretrain_lr,
     }
     only = [g for g in args.only.split(",") if g]
     for name, fn in groups.items():

@@ -162,6 +162,39 @@ def test_warmup_cosine_schedule_matches_reference(golden):
     assert np.allclose(np.asarray(lrs), g["lrs"], rtol=1e-12, atol=0)
 
 
+def test_pretrain_lr_schedule_matches_reference_per_iteration(golden):
+    """pretrain.py:65 + madrigal/utils.py:680-692: the contrastive loop sets ONE rate on every parameter group before every
+    iteration, from the fractional epoch.  ``optim.PretrainSchedule`` as the hook of ``train.PretrainStep`` against the rates the
+    reference function produced (tests/golden/pretrain_lr.npz), through the step object itself."""
+    import numpy as np
+    import torch
+    from madrigal_amd.optim import PretrainSchedule, adjust_learning_rate
+    from madrigal_amd.train import PretrainStep
+    g = golden("pretrain_lr")
+
+    class Toy(torch.nn.Module):                    # the step only needs model(...) -> (_, _, (_, _, loss)) and .base_encoder
+        def __init__(self):
+            super().__init__()
+            self.base_encoder = torch.nn.Linear(3, 3)
+            self.head = torch.nn.Linear(3, 1)
+
+        def forward(self, drug_indices, m1, m2, hard, data):
+            return None, None, (None, None, self.head(self.base_encoder(data)).pow(2).mean())
+    for tag in "abc":
+        lr, warm, total, ipe = (float(v) for v in g[f"{tag}_cfg"])
+        want = g[f"{tag}_lrs"]
+        model = Toy()
+        opt = torch.optim.AdamW([{"params": model.base_encoder.parameters(), "lr": 9.0}, {"params": model.head.parameters(), "lr": 7.0}])
+        step = PretrainStep(model, opt, scheduler=PretrainSchedule(lr, warm, total, int(ipe)))
+        seen = []
+        for _ in range(int(total) * int(ipe)):
+            step.step(None, None, None, None, torch.ones(2, 3))
+            seen.append([step.scheduler.last_lr] + [q["lr"] for q in opt.param_groups])
+        assert np.allclose(np.asarray(seen), want, rtol=1e-13, atol=0), tag
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    assert adjust_learning_rate(opt, 0.5, 2e-3, 1, 4) == 1e-3 and opt.param_groups[0]["lr"] == 1e-3
+
+
 def test_average_precision_matches_sklearn():
     import numpy as np
     import torch

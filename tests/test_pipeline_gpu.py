@@ -68,11 +68,26 @@ def test_full_baseline_shape_against_the_oracle_on_samples(prec, tol):
     samples = [(0, 0, 0), (L - 1, N - 160, N - 224), (L - 1, 0, N - 224), (0, N - 160, 0)]
     samples += [(int(rng.integers(0, L)), int(rng.integers(0, N - 160)), int(rng.integers(0, N - 224))) for _ in range(28)]
     worst = 0.0
+    refs, gots = [], []
     for l, i0, j0 in samples:
         ref = O.bilinear_scores(z[i0:i0 + 160], z[j0:j0 + 224], w[l:l + 1])
         got = out[l:l + 1, i0:i0 + 160, j0:j0 + 224].cpu()
         worst = max(worst, float((got - ref).abs().max()) / max(float(ref.abs().max()), 128 ** 0.5))
+        refs.append(ref.double().flatten())
+        gots.append(got.double().flatten())
     assert worst < tol, worst
+    # The same 1.1e6 sampled entries ELEMENTWISE.  BASELINE's "1e-4 relative" is read norm-wise above (logits cross zero: an entry
+    # of magnitude 1e-3 beside a score scale of 50 cannot carry 1e-4 of itself in any fp32 evaluation of a 128 x 128 form); here
+    # is the per-entry picture that reading rests on: every entry within 1e-4 of itself plus 1e-4 of the rms score, and the
+    # share of entries that meet the bare per-entry 1e-4 (reported; the rest are the near-zero logits).
+    ref, got = torch.cat(refs), torch.cat(gots)
+    rms = float(ref.pow(2).mean().sqrt())
+    d = (got - ref).abs()
+    mixed = float((d <= 1e-4 * ref.abs() + 1e-4 * rms).double().mean())
+    bare = float((d <= 1e-4 * ref.abs()).double().mean())
+    print(f"{prec}: {ref.numel()} sampled entries, rms score {rms:.2f}: |d| <= 1e-4 |ref| + 1e-4 rms for {mixed:.6f} of them; "
+          f"|d| <= 1e-4 |ref| for {bare:.6f}; median |d| / |ref| {float((d / ref.abs().clamp_min(1e-30)).median()):.2e}")
+    assert mixed == 1.0 and bare > (0.95 if prec == "bf16x3" else 0.995), (mixed, bare)      # measured 0.9607 / 0.9988
     for l in (0, 447, L - 1):
         s = out[l]
         assert not bool(torch.isnan(s).any())

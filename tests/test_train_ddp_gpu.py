@@ -45,7 +45,7 @@ def _build(seed, n, L):
     return model, b, kgc, trip, filler
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, shard_kg=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -55,7 +55,7 @@ def _worker(rank, world, port, ret):
         n, L, seed = 101, 12, 21                       # odd drug count: uneven shards
         M.set_precision("f32")
         model, b, kgc, (lab, hd, tl, y), filler = _build(seed, n, L)
-        fs = FinetuneStep(model, AdamW(model.parameters(), lr=1e-4, weight_decay=0.0), rank=rank, world=world)
+        fs = FinetuneStep(model, AdamW(model.parameters(), lr=1e-4, weight_decay=0.0), rank=rank, world=world, shard_kg=shard_kg)
         model.zero_grad(set_to_none=True)
         loss = fs.accumulate(b, b, b["masks"], b["masks"], kgc, lab, hd, tl, y, kg_filler=filler)
         from madrigal_amd.parallel import allreduce_gradients
@@ -67,33 +67,49 @@ def _worker(rank, world, port, ret):
         fs1 = FinetuneStep(ref, AdamW(ref.parameters(), lr=1e-4, weight_decay=0.0))
         ref.zero_grad(set_to_none=True)
         loss1 = fs1.accumulate(b2, b2, b2["masks"], b2["masks"], kgc2, lab, hd, tl, y, kg_filler=filler)
-        worst = (0.0, "")
+        worst, worst2 = (0.0, ""), (0.0, "")
         gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
         for k, p in ref.named_parameters():
             if p.grad is None:
                 continue
             err = float((grads[k] - p.grad).abs().max()) / max(float(p.grad.abs().max()), 1e-2 * gmax)
             worst = max(worst, (err, k))
+            # per tensor in the 2-norm: a ReLU whose pre-activation sits at rounding distance of zero flips its derivative when the
+            # SyncBatchNorm sums are formed in another order (three ranks instead of one) and moves a handful of entries by percents
+            l2 = float((grads[k] - p.grad).norm()) / max(float(p.grad.norm()), 1e-3 * gmax * p.grad.numel() ** 0.5)
+            worst2 = max(worst2, (l2, k))
+        worst = (worst[0], worst[1], worst2)
         berr = max(float((bufs[k] - v).abs().max()) / max(float(v.abs().max()), 1e-6) for k, v in ref.named_buffers() if "running" in k)
+        kg_l2 = max(float((grads[k] - p.grad).norm()) / max(float(p.grad.norm()), 1e-30) for k, p in ref.named_parameters() if p.grad is not None and "kg_encoder" in k)
+        worst = worst + (("kg_encoder worst l2", kg_l2),)
         ret[rank] = (abs(float(loss) - float(loss1)) / abs(float(loss1)), worst, berr, len(grads))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_finetune_step_equals_single_process_step():
+@pytest.mark.parametrize("world,shard_kg", [(2, False), (2, True), (3, False), (3, True)],
+                         ids=["2ranks_kg_replicated", "2ranks_kg_partitioned", "3ranks_kg_replicated", "3ranks_kg_partitioned"])
+def test_two_rank_finetune_step_equals_single_process_step(world, shard_kg):
+    """``shard_kg``: the KG encoder's convs destination-partitioned over the ranks in TRAINING (every KG edge attended to on one
+    rank; one all-gather per conv forward, the reverse exchange backward) against the single-process step, as the replicated
+    KG encoder is: same loss, same summed gradients, same BatchNorm statistics."""
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, shard_kg)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(600)
         assert p.exitcode == 0
-    for r in range(2):
+    for r in range(world):
         lerr, worst, berr, n_grads = ret[r]
         assert lerr < 1e-5, (r, lerr)
-        assert worst[0] < 2e-3, (r, worst)           # fp32 summation order + ReLU flips at rounding distance
+        # fp32 summation order + ReLU flips at rounding distance: at three ranks one structure-encoder pre-activation flips (the
+        # replicated and the partitioned KG variants show the identical 2.4 % / 1.1 % on the same GIN tensor), so the structure
+        # encoder gets the looser bound there; the KG encoder's own gradients agree to 4e-6 in either variant
+        assert worst[0] < (2e-3 if world == 2 else 5e-2) and worst[2][0] < (5e-3 if world == 2 else 2e-2), (r, worst)
+        assert worst[3][1] < 1e-4, (r, worst)
         assert berr < 1e-4, (r, berr)                # BatchNorm running statistics = full-batch statistics on every rank
         assert n_grads > 150
 

@@ -1439,3 +1439,36 @@ def test_full_size_finetune_steps_bf16_track_the_fp32_grade_run():
     assert all(np.isfinite(lo)) and lo[2] < lo[0] and hi[2] < hi[0], (lo, hi)
     for a, r in zip(lo, hi):
         assert abs(a - r) < 1e-3 * abs(r), (lo, hi)
+
+    # The gathered head at full size against the oracle, embeddings taken from the HIP encoder in the same training-mode pass:
+    # 10^4 sampled triples against the CPU oracle's bilinear form, all 6 x 10^6 against an fp64 restatement of it on the device,
+    # and the step's BCE loss against the loss of those reference scores.
+    from madrigal_amd import autograd as ag, ops
+    from oracle import madrigal_oracle as O
+    torch.manual_seed(0)
+    model = configs.build_model("twosides321", bkg["data"], L).cuda().train()
+    torch.manual_seed(4321)
+    with torch.no_grad(), M.precision("bf16x3"):
+        zh, zt = model.embed(b, b, b["masks"], b["masks"], kgc, kg_filler=filler)
+        plan = ops.triple_plan(lab, hd, tl, L, N, N)
+        s = model.decoder.score_triples(zh, zt, plan).index_select(0, plan["inv_perm"])
+        loss = float(ag.bce_with_sigmoid(s, y))
+    w_sym = O.symmetric(model.decoder.parametrizations.weight.original.detach().cpu())
+    pick = torch.randperm(int(lab.numel()), generator=torch.Generator().manual_seed(5))[:10_000]
+    zh_c, zt_c, lab_c, hd_c, tl_c = zh.cpu().double(), zt.cpu().double(), lab.cpu(), hd.cpu(), tl.cpu()
+    ref = torch.cat([torch.einsum("td,tde,te->t", zh_c[hd_c[c]], w_sym[lab_c[c]].double(), zt_c[tl_c[c]]) for c in pick.split(500)])
+    scale = float(ref.abs().max())
+    assert float((s.cpu()[pick].double() - ref).abs().max()) < 1e-4 * scale
+    order = torch.argsort(lab, stable=True)
+    counts = torch.bincount(lab, minlength=L).cpu().tolist()
+    w64, zh64, zt64 = w_sym.cuda().double(), zh.double(), zt.double()
+    ref_all = torch.empty(int(lab.numel()), dtype=torch.float64, device="cuda")
+    at = 0
+    for l, c in enumerate(counts):
+        sel = order[at:at + c]
+        ref_all[sel] = ((zh64[hd[sel]] @ w64[l]) * zt64[tl[sel]]).sum(1)
+        at += c
+    assert float((ref_all[pick.cuda()].cpu() - ref).abs().max()) < 1e-9 * scale            # the device restatement IS the oracle's form
+    assert float((s.double() - ref_all).abs().max()) < 1e-4 * scale
+    loss_ref = float(torch.nn.functional.binary_cross_entropy(torch.sigmoid(ref_all), y.double()))
+    assert abs(loss - loss_ref) < 1e-5 * abs(loss_ref), (loss, loss_ref)
