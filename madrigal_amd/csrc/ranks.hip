@@ -24,17 +24,17 @@
 
 namespace {
 
-#ifndef MDG_RANK_TPB
-#define MDG_RANK_TPB 512
-#endif
-#ifndef MDG_RANK_ITEMS
-#define MDG_RANK_ITEMS 16
-#endif
-constexpr int TPB = MDG_RANK_TPB;   // threads per block
-constexpr int WAVES = TPB / 64;
-constexpr int ITEMS = MDG_RANK_ITEMS;   // keys per thread
-constexpr int TILE = TPB * ITEMS;   // keys per block
-constexpr int WSPAN = TILE / WAVES; // consecutive keys ranked by one wave
+// Tile shape of the sort: the scatter leaves a tile as runs of equal digits, TILE / 256 keys long on average -- the larger the
+// tile, the longer the contiguous stores (measured per 4096^2 outcome: 4096-key tiles 0.42 ms, 8192 0.31 ms, 16384 0.28 ms).
+// Big: one 1024-thread workgroup per CU with 146 KB of LDS; the blocked last pass then has room for <= 1400 blocks (N <= 6784),
+// beyond that the 8192-key shape (two workgroups per CU) serves up to N = 16256.
+template <int TPB_, int ITEMS_>
+struct RankCfg {
+  static constexpr int TPB = TPB_, ITEMS = ITEMS_, WAVES = TPB_ / 64, TILE = TPB_ * ITEMS_, WSPAN = TILE / WAVES;
+};
+using CfgBig = RankCfg<1024, 16>;
+using CfgStd = RankCfg<512, 16>;
+#define MDG_RANK_USING(C) constexpr int TPB = C::TPB, ITEMS = C::ITEMS, WAVES = C::WAVES, TILE = C::TILE, WSPAN = C::WSPAN; (void)TPB; (void)ITEMS; (void)WAVES; (void)TILE; (void)WSPAN
 constexpr uint32_t NO_PAY = 0xFFFFFFFFu;   // payload of the padding behind the last key of the last tile
 
 __device__ __forceinline__ uint32_t order_key(float f) {
@@ -65,7 +65,7 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t dg) {
 
 // Digit counts of the wave's 1024 keys into its private counters cnt[256]; rank_out[k] = number of EARLIER keys of the wave
 // (in p order) with the same digit.  Wave-private LDS, in-order LDS queue: no barrier.
-template <bool WANT_RANK>
+template <bool WANT_RANK, int ITEMS>
 __device__ __forceinline__ void wave_digit_ranks(const uint32_t (&key)[ITEMS], int shift, uint32_t* cnt, int lane, uint32_t (&rank_out)[ITEMS]) {
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
@@ -82,6 +82,7 @@ __device__ __forceinline__ void wave_digit_ranks(const uint32_t (&key)[ITEMS], i
 
 // Digit counts only (no ranks): no-return LDS atomics on the wave's private counters.  Lanes sharing a digit serialise inside one
 // instruction (n lanes on a counter = n LDS cycles), which even for a wave of equal digits costs less than the 8-ballot match.
+template <int ITEMS>
 __device__ __forceinline__ void wave_digit_counts(const uint32_t (&key)[ITEMS], int shift, uint32_t* cnt) {
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) __hip_atomic_fetch_add(&cnt[(key[k] >> shift) & 255u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -89,7 +90,9 @@ __device__ __forceinline__ void wave_digit_counts(const uint32_t (&key)[ITEMS], 
 
 // hist[(seg * 256 + digit) * nblk + blk] from the per-wave counters (valid keys only: the padding of the last tile was counted
 // as digit 255 and is taken out again)
+template <class C>
 __device__ __forceinline__ void store_tile_histogram(const uint32_t (*cnt)[256], uint32_t* __restrict__ hist, int64_t seg, int nblk, int64_t base, int64_t M) {
+  MDG_RANK_USING(C);
   const int d = threadIdx.x;
   if (d < 256) {
     uint32_t c = 0;
@@ -101,8 +104,10 @@ __device__ __forceinline__ void store_tile_histogram(const uint32_t (*cnt)[256],
 }
 
 // keys of the strict lower triangle in p order + the tile histogram of the lowest digit
-__global__ __launch_bounds__(TPB) void extract_keys_kernel(const float* __restrict__ scores, int64_t lds, uint32_t* __restrict__ keys,
+template <class C>
+__global__ __launch_bounds__(C::TPB) void extract_keys_kernel(const float* __restrict__ scores, int64_t lds, uint32_t* __restrict__ keys,
                                                            uint32_t* __restrict__ hist, int N, int64_t M, int nblk) {
+  MDG_RANK_USING(C);
   __shared__ uint32_t cnt[WAVES][256];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
@@ -133,11 +138,13 @@ __global__ __launch_bounds__(TPB) void extract_keys_kernel(const float* __restri
   }
   wave_digit_counts(key, 0, cnt[wave]);
   __syncthreads();
-  store_tile_histogram(cnt, hist, seg, nblk, base, M);
+  store_tile_histogram<C>(cnt, hist, seg, nblk, base, M);
 }
 
-__global__ __launch_bounds__(TPB) void histogram_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ hist, int64_t M,
-                                                        int nblk, int shift) {
+template <class C>
+__global__ __launch_bounds__(C::TPB) void histogram_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ hist, int64_t M,
+                                                           int nblk, int shift) {
+  MDG_RANK_USING(C);
   __shared__ uint32_t cnt[WAVES][256];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(TPB) void histogram_kernel(const uint32_t* __restri
   }
   wave_digit_counts(key, shift, cnt[wave]);
   __syncthreads();
-  store_tile_histogram(cnt, hist, seg, nblk, base, M);
+  store_tile_histogram<C>(cnt, hist, seg, nblk, base, M);
 }
 
 // exclusive scan of the 256*nblk counters of one outcome, in place; one workgroup per outcome, coalesced: every wave owns a
@@ -192,11 +199,12 @@ __global__ __launch_bounds__(1024) void scan_kernel(uint32_t* __restrict__ hist,
   }
 }
 
-template <bool FIRST, bool LAST>
-__global__ __launch_bounds__(TPB) void scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ pay_in,
+template <class C, bool FIRST, bool LAST>
+__global__ __launch_bounds__(C::TPB) void scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ pay_in,
                                                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ pay_out,
                                                       const uint32_t* __restrict__ offsets, float* __restrict__ out, int64_t ldo, int N,
                                                       int64_t M, int nblk, int shift, double denom) {
+  MDG_RANK_USING(C);
   __shared__ uint32_t cnt[WAVES][256];     // per-wave digit counts, then their exclusive prefix over the waves
   __shared__ uint32_t dstart[256];         // first slot of digit d in the sorted tile
   __shared__ uint32_t gofs[256];           // global position of slot 0 of digit d's run, minus dstart[d]
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(TPB) void scatter_kernel(const uint32_t* __restrict
     key[k] = valid ? keys_in[seg * M + p] : 0xFFFFFFFFu;          // padding: digit 255 in every pass, behind every real key of the tile
     pay[k] = valid ? (FIRST ? static_cast<uint32_t>(p) : pay_in[seg * M + p]) : NO_PAY;
   }
-  wave_digit_ranks<true>(key, shift, cnt[wave], lane, rk);
+  wave_digit_ranks<true, ITEMS>(key, shift, cnt[wave], lane, rk);
   __syncthreads();
   if (tid < 256) {                         // thread d: prefix over the waves, then over the digits
     uint32_t run = 0;
@@ -289,9 +297,11 @@ __device__ __forceinline__ uint32_t block_base(int bi, int bj, int N) {
   return static_cast<uint32_t>(r0 * (r0 - 1) / 2 + static_cast<int64_t>(bj) * rcount * BB);
 }
 
-__global__ __launch_bounds__(TPB) void rank_blocks_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ pay_in,
+template <class C>
+__global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ pay_in,
                                                           const uint32_t* __restrict__ offsets, u32x2* __restrict__ pairs,
                                                           uint32_t* __restrict__ fill, int N, int64_t M, int nblk, int n_blocks) {
+  MDG_RANK_USING(C);
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];            // [TILE] pairs (u32x2) | bcnt[n_blocks] | bdst[n_blocks]
   __shared__ uint32_t cnt[WAVES][256];
   __shared__ uint32_t gbase[256];
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(TPB) void rank_blocks_kernel(const uint32_t* __rest
     key[k] = valid ? keys_in[seg * M + p] : 0xFFFFFFFFu;
     pay[k] = valid ? pay_in[seg * M + p] : NO_PAY;
   }
-  wave_digit_ranks<true>(key, 24, cnt[wave], lane, rk);
+  wave_digit_ranks<true, ITEMS>(key, 24, cnt[wave], lane, rk);
   __syncthreads();
   if (tid < 256) {
     uint32_t run = 0;
@@ -386,8 +396,9 @@ __global__ __launch_bounds__(TPB) void rank_blocks_kernel(const uint32_t* __rest
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(TPB) void rank_block_write_kernel(const u32x2* __restrict__ pairs, float* __restrict__ out, int64_t ldo, int N,
+__global__ __launch_bounds__(512) void rank_block_write_kernel(const u32x2* __restrict__ pairs, float* __restrict__ out, int64_t ldo, int N,
                                                                int64_t M, int n_blocks, double denom) {
+  constexpr int TPB = 512;
   __shared__ float tile[BB][BB + 1];
   const int t = blockIdx.x, tid = threadIdx.x;
   const int64_t seg = blockIdx.y;
@@ -466,13 +477,25 @@ __global__ __launch_bounds__(256) void gmean_kernel(const GmeanArgs a, float* __
 
 }  // namespace
 
+static int64_t rank_blocks_of(int64_t N) { const int64_t nb = mdg_cdiv(N, BB); return nb * (nb + 1) / 2; }
+// the 16384-key tiles while the blocked last pass fits beside them in LDS
+static bool rank_use_big(int64_t N) {
+  static MdgEnvInt tile_sw{"MDG_RANKS_TILE", 0};           // 8192 / 16384: force a tile shape (diagnostics)
+  if (tile_sw.get() == 8192) return false;
+  return rank_blocks_of(N) <= 1400;
+}
+
+template <class C>
+static size_t rank_workspace_bytes(int64_t n_outcomes, int64_t N) {
+  const size_t M = static_cast<size_t>(N) * (N - 1) / 2;
+  const size_t nblk = (M + C::TILE - 1) / C::TILE;
+  return 4 * a256(static_cast<size_t>(n_outcomes) * M * 4) + a256(static_cast<size_t>(n_outcomes) * 256 * nblk * 4) +
+         a256(static_cast<size_t>(n_outcomes) * static_cast<size_t>(rank_blocks_of(N)) * 4);
+}
+
 extern "C" size_t mdg_rank_normalize_workspace_bytes(int64_t n_outcomes, int64_t N) {
   if (n_outcomes <= 0 || N < 2) return 0;
-  const size_t M = static_cast<size_t>(N) * (N - 1) / 2;
-  const size_t nblk = (M + TILE - 1) / TILE;
-  const size_t nb = (static_cast<size_t>(N) + BB - 1) / BB;
-  return 4 * a256(static_cast<size_t>(n_outcomes) * M * 4) + a256(static_cast<size_t>(n_outcomes) * 256 * nblk * 4) +
-         a256(static_cast<size_t>(n_outcomes) * (nb * (nb + 1) / 2) * 4);
+  return rank_use_big(N) ? rank_workspace_bytes<CfgBig>(n_outcomes, N) : rank_workspace_bytes<CfgStd>(n_outcomes, N);
 }
 
 extern "C" int mdg_rank_normalize(const float* scores, float* out, int64_t n_outcomes, int64_t N, void* workspace,
@@ -480,19 +503,14 @@ extern "C" int mdg_rank_normalize(const float* scores, float* out, int64_t n_out
   return mdg_rank_normalize_ld(scores, N, out, N, n_outcomes, N, workspace, workspace_bytes, stream);
 }
 
-extern "C" int mdg_rank_normalize_ld(const float* scores, int64_t lds, float* out, int64_t ldo, int64_t n_outcomes, int64_t N, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
-  MDG_CHECK_ARG(lds >= N && ldo >= N, "mdg_rank_normalize: row pitches must be >= N");
-  MDG_CHECK_ARG(n_outcomes >= 0 && N >= 0 && N <= 65535 && n_outcomes <= 65535, "mdg_rank_normalize: bad sizes (outcomes per call and N <= 65535)");
-  if (n_outcomes == 0 || N == 0) return MDG_OK;
-  MDG_CHECK_ARG(scores && out, "mdg_rank_normalize: null pointer");
-  hipStream_t st = static_cast<hipStream_t>(stream);
+template <class C>
+static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int64_t ldo, int64_t n_outcomes, int64_t N, void* workspace,
+                               size_t workspace_bytes, hipStream_t st) {
+  constexpr int TPB = C::TPB, TILE = C::TILE;
   const unsigned L = static_cast<unsigned>(n_outcomes);
-  hipLaunchKernelGGL(zero_diag_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N, 256)), L), dim3(256), 0, st, out, ldo, static_cast<int>(N));
-  if (N < 2) { MDG_CHECK_LAUNCH("mdg_rank_normalize"); return MDG_OK; }
   const int64_t M = N * (N - 1) / 2;
   const int nblk = static_cast<int>(mdg_cdiv(M, TILE));
-  const size_t need = mdg_rank_normalize_workspace_bytes(n_outcomes, N);
+  const size_t need = rank_workspace_bytes<C>(n_outcomes, N);
   if (!workspace || workspace_bytes < need || !mdg_aligned16(workspace)) {
     mdg_set_error("mdg_rank_normalize: workspace of %zu bytes required, got %zu", need, workspace_bytes);
     return MDG_EWORKSPACE;
@@ -505,39 +523,52 @@ extern "C" int mdg_rank_normalize_ld(const float* scores, int64_t lds, float* ou
   uint32_t* p1 = reinterpret_cast<uint32_t*>(ws + 3 * kb);
   uint32_t* hist = reinterpret_cast<uint32_t*>(ws + 4 * kb);
   uint32_t* fill = reinterpret_cast<uint32_t*>(ws + 4 * kb + a256(static_cast<size_t>(n_outcomes) * 256 * nblk * 4));
-  const int64_t nbr = mdg_cdiv(N, BB), n_blocks = nbr * (nbr + 1) / 2;
+  const int64_t n_blocks = rank_blocks_of(N);
   static MdgEnvInt direct_sw{"MDG_RANKS_DIRECT", 0};        // 1: the last pass stores the ranks one by one (the large-N path) at any N
-  const bool blocked = n_blocks <= MAX_BLOCKS && !direct_sw.get();
+  const size_t blocks_lds = static_cast<size_t>(2 * TILE + 2 * n_blocks) * 4;
+  const bool blocked = n_blocks <= MAX_BLOCKS && !direct_sw.get() && blocks_lds + C::WAVES * 1024 + 2048 <= 160 * 1024;
   const double denom = static_cast<double>(N) * static_cast<double>(N - 1) / 2.0;
   const dim3 grid(static_cast<unsigned>(nblk), L);
-  hipLaunchKernelGGL(extract_keys_kernel, grid, dim3(TPB), 0, st, scores, lds, k0, hist, static_cast<int>(N), M, nblk);
+  hipLaunchKernelGGL(extract_keys_kernel<C>, grid, dim3(TPB), 0, st, scores, lds, k0, hist, static_cast<int>(N), M, nblk);
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 8 * pass;
     uint32_t* kin = (pass & 1) ? k1 : k0;
     uint32_t* kout = (pass & 1) ? k0 : k1;
     uint32_t* pin = (pass & 1) ? p1 : p0;
     uint32_t* pout = (pass & 1) ? p0 : p1;
-    if (pass > 0) hipLaunchKernelGGL(histogram_kernel, grid, dim3(TPB), 0, st, kin, hist, M, nblk, shift);
+    if (pass > 0) hipLaunchKernelGGL(histogram_kernel<C>, grid, dim3(TPB), 0, st, kin, hist, M, nblk, shift);
     hipLaunchKernelGGL(scan_kernel, dim3(L), dim3(1024), 0, st, hist, nblk);
     if (pass == 0)
-      hipLaunchKernelGGL((scatter_kernel<true, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, ldo, static_cast<int>(N), M, nblk, shift, denom);
+      hipLaunchKernelGGL((scatter_kernel<C, true, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, ldo, static_cast<int>(N), M, nblk, shift, denom);
     else if (pass == 3 && blocked) {
       (void)hipMemsetAsync(fill, 0, static_cast<size_t>(n_outcomes) * n_blocks * 4, st);
       u32x2* pairs = reinterpret_cast<u32x2*>(k0);            // pass 3 reads k1 / p1
-      const size_t lds = static_cast<size_t>(2 * TILE + 2 * n_blocks) * 4;
-      hipLaunchKernelGGL(rank_blocks_kernel, grid, dim3(TPB), lds, st, kin, pin, hist, pairs, fill, static_cast<int>(N), M, nblk, static_cast<int>(n_blocks));
+      hipLaunchKernelGGL(rank_blocks_kernel<C>, grid, dim3(TPB), blocks_lds, st, kin, pin, hist, pairs, fill, static_cast<int>(N), M, nblk, static_cast<int>(n_blocks));
       const dim3 bgrid(static_cast<unsigned>(n_blocks), L);
       if (ldo % 4 == 0 && mdg_aligned16(out))
-        hipLaunchKernelGGL(rank_block_write_kernel<true>, bgrid, dim3(TPB), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
+        hipLaunchKernelGGL(rank_block_write_kernel<true>, bgrid, dim3(512), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
       else
-        hipLaunchKernelGGL(rank_block_write_kernel<false>, bgrid, dim3(TPB), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
+        hipLaunchKernelGGL(rank_block_write_kernel<false>, bgrid, dim3(512), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
     } else if (pass == 3)
-      hipLaunchKernelGGL((scatter_kernel<false, true>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, ldo, static_cast<int>(N), M, nblk, shift, denom);
+      hipLaunchKernelGGL((scatter_kernel<C, false, true>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, ldo, static_cast<int>(N), M, nblk, shift, denom);
     else
-      hipLaunchKernelGGL((scatter_kernel<false, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, ldo, static_cast<int>(N), M, nblk, shift, denom);
+      hipLaunchKernelGGL((scatter_kernel<C, false, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, ldo, static_cast<int>(N), M, nblk, shift, denom);
   }
   MDG_CHECK_LAUNCH("mdg_rank_normalize");
   return MDG_OK;
+}
+
+extern "C" int mdg_rank_normalize_ld(const float* scores, int64_t lds, float* out, int64_t ldo, int64_t n_outcomes, int64_t N, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(lds >= N && ldo >= N, "mdg_rank_normalize: row pitches must be >= N");
+  MDG_CHECK_ARG(n_outcomes >= 0 && N >= 0 && N <= 65535 && n_outcomes <= 65535, "mdg_rank_normalize: bad sizes (outcomes per call and N <= 65535)");
+  if (n_outcomes == 0 || N == 0) return MDG_OK;
+  MDG_CHECK_ARG(scores && out, "mdg_rank_normalize: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(zero_diag_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N, 256)), static_cast<unsigned>(n_outcomes)), dim3(256), 0, st, out, ldo, static_cast<int>(N));
+  if (N < 2) { MDG_CHECK_LAUNCH("mdg_rank_normalize"); return MDG_OK; }
+  return rank_use_big(N) ? rank_normalize_impl<CfgBig>(scores, lds, out, ldo, n_outcomes, N, workspace, workspace_bytes, st)
+                         : rank_normalize_impl<CfgStd>(scores, lds, out, ldo, n_outcomes, N, workspace, workspace_bytes, st);
 }
 
 extern "C" int mdg_gmean(const float* const* inputs_host, int K, float* out, int64_t n, void* stream) {

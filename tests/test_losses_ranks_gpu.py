@@ -79,14 +79,27 @@ def test_ranks_golden_bit_exact(ops, golden):
     assert np.array_equal(out, g["normalized"])                      # rank ordering and fp32 values bit exact
 
 
-@pytest.mark.parametrize("N,L", [(300, 5), (2, 3), (1, 2), (97, 1), (1025, 2)])
-def test_ranks_vs_oracle(ops, N, L):
+@pytest.mark.parametrize("path", ["default", "tile8192", "direct"])
+@pytest.mark.parametrize("N,L", [(300, 5), (2, 3), (1, 2), (97, 1), (1025, 2), (1283, 1)])
+def test_ranks_vs_oracle(ops, monkeypatch, N, L, path):
+    """Every path of the sort: 16384-key tiles (default at these N) and 8192-key tiles, the blocked last pass and the direct one
+    (the large-N path), contiguous and row-pitched tensors; ragged N (not a multiple of 128 / 4)."""
+    from helpers import set_switch
     from oracle import madrigal_oracle as O
+    if path == "tile8192":
+        set_switch(monkeypatch, "MDG_RANKS_TILE", "8192")
+    if path == "direct":
+        set_switch(monkeypatch, "MDG_RANKS_DIRECT", "1")
     rng = np.random.default_rng(N)
     s = rng.standard_normal((L, N, N)).astype(np.float32) * 7
+    ref = O.rank_normalize(s)
     out = ops.rank_normalize(torch.from_numpy(s).cuda()).cpu().numpy()
-    assert np.array_equal(out, O.rank_normalize(s))
+    assert np.array_equal(out, ref)
     assert np.array_equal(out, out.transpose(0, 2, 1))
+    pit = ops.empty_scores(L, N, N, "cuda")
+    pit.copy_(torch.from_numpy(s))
+    got = ops.rank_normalize(pit)
+    assert got.stride(1) == pit.stride(1) and np.array_equal(got.cpu().numpy(), ref)
 
 
 def test_ranks_ties_are_stable_in_flat_index(ops):
