@@ -26,8 +26,8 @@ namespace {
 
 // Tile shape of the sort: the scatter leaves a tile as runs of equal digits, TILE / 256 keys long on average -- the larger the
 // tile, the longer the contiguous stores (measured per 4096^2 outcome: 4096-key tiles 0.42 ms, 8192 0.31 ms, 16384 0.28 ms).
-// Big: one 1024-thread workgroup per CU with 146 KB of LDS; the blocked last pass then has room for <= 1400 blocks (N <= 6784),
-// beyond that the 8192-key shape (two workgroups per CU) serves up to N = 16256.
+// Big (passes 0-2): one 1024-thread workgroup per CU with 146 KB of LDS.  The last pass -- no digit sort, LDS holds the pair
+// exchange and the block tables instead -- always runs on 8192-key tiles (two workgroups per CU).
 template <int TPB_, int ITEMS_>
 struct RankCfg {
   static constexpr int TPB = TPB_, ITEMS = ITEMS_, WAVES = TPB_ / 64, TILE = TPB_ * ITEMS_, WSPAN = TILE / WAVES;
@@ -478,17 +478,17 @@ __global__ __launch_bounds__(256) void gmean_kernel(const GmeanArgs a, float* __
 }  // namespace
 
 static int64_t rank_blocks_of(int64_t N) { const int64_t nb = mdg_cdiv(N, BB); return nb * (nb + 1) / 2; }
-// the 16384-key tiles while the blocked last pass fits beside them in LDS
+// 16384-key tiles for the first three passes (MDG_RANKS_TILE=8192: the smaller shape everywhere)
 static bool rank_use_big(int64_t N) {
   static MdgEnvInt tile_sw{"MDG_RANKS_TILE", 0};           // 8192 / 16384: force a tile shape (diagnostics)
-  if (tile_sw.get() == 8192) return false;
-  return rank_blocks_of(N) <= 1400;
+  (void)N;
+  return tile_sw.get() != 8192;
 }
 
 template <class C>
 static size_t rank_workspace_bytes(int64_t n_outcomes, int64_t N) {
   const size_t M = static_cast<size_t>(N) * (N - 1) / 2;
-  const size_t nblk = (M + C::TILE - 1) / C::TILE;
+  const size_t nblk = (M + CfgStd::TILE - 1) / CfgStd::TILE;          // the last pass always runs on 8192-key tiles (the finer table)
   return 4 * a256(static_cast<size_t>(n_outcomes) * M * 4) + a256(static_cast<size_t>(n_outcomes) * 256 * nblk * 4) +
          a256(static_cast<size_t>(n_outcomes) * static_cast<size_t>(rank_blocks_of(N)) * 4);
 }
@@ -522,11 +522,15 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
   uint32_t* k1 = reinterpret_cast<uint32_t*>(ws + 2 * kb);
   uint32_t* p1 = reinterpret_cast<uint32_t*>(ws + 3 * kb);
   uint32_t* hist = reinterpret_cast<uint32_t*>(ws + 4 * kb);
-  uint32_t* fill = reinterpret_cast<uint32_t*>(ws + 4 * kb + a256(static_cast<size_t>(n_outcomes) * 256 * nblk * 4));
+  const int nblk3 = static_cast<int>(mdg_cdiv(M, CfgStd::TILE));
+  uint32_t* fill = reinterpret_cast<uint32_t*>(ws + 4 * kb + a256(static_cast<size_t>(n_outcomes) * 256 * nblk3 * 4));
   const int64_t n_blocks = rank_blocks_of(N);
   static MdgEnvInt direct_sw{"MDG_RANKS_DIRECT", 0};        // 1: the last pass stores the ranks one by one (the large-N path) at any N
-  const size_t blocks_lds = static_cast<size_t>(2 * TILE + 2 * n_blocks) * 4;
-  const bool blocked = n_blocks <= MAX_BLOCKS && !direct_sw.get() && blocks_lds + C::WAVES * 1024 + 2048 <= 160 * 1024;
+  // the blocked last pass on 8192-key tiles whatever the other passes use: two workgroups per CU there beat one of 16384 keys
+  // (48 against 63 us per 4096^2 outcome); its histogram and scan use the same tiling
+  const size_t blocks_lds = static_cast<size_t>(2 * CfgStd::TILE + 2 * n_blocks) * 4;
+  const bool blocked = n_blocks <= MAX_BLOCKS && !direct_sw.get();
+  const dim3 grid3(static_cast<unsigned>(nblk3), L);
   const double denom = static_cast<double>(N) * static_cast<double>(N - 1) / 2.0;
   const dim3 grid(static_cast<unsigned>(nblk), L);
   hipLaunchKernelGGL(extract_keys_kernel<C>, grid, dim3(TPB), 0, st, scores, lds, k0, hist, static_cast<int>(N), M, nblk);
@@ -536,14 +540,16 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
     uint32_t* kout = (pass & 1) ? k0 : k1;
     uint32_t* pin = (pass & 1) ? p1 : p0;
     uint32_t* pout = (pass & 1) ? p0 : p1;
-    if (pass > 0) hipLaunchKernelGGL(histogram_kernel<C>, grid, dim3(TPB), 0, st, kin, hist, M, nblk, shift);
-    hipLaunchKernelGGL(scan_kernel, dim3(L), dim3(1024), 0, st, hist, nblk);
+    const bool std3 = pass == 3 && blocked;
+    if (std3) hipLaunchKernelGGL(histogram_kernel<CfgStd>, grid3, dim3(CfgStd::TPB), 0, st, kin, hist, M, nblk3, shift);
+    else if (pass > 0) hipLaunchKernelGGL(histogram_kernel<C>, grid, dim3(TPB), 0, st, kin, hist, M, nblk, shift);
+    hipLaunchKernelGGL(scan_kernel, dim3(L), dim3(1024), 0, st, hist, std3 ? nblk3 : nblk);
     if (pass == 0)
       hipLaunchKernelGGL((scatter_kernel<C, true, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, ldo, static_cast<int>(N), M, nblk, shift, denom);
     else if (pass == 3 && blocked) {
       (void)hipMemsetAsync(fill, 0, static_cast<size_t>(n_outcomes) * n_blocks * 4, st);
       u32x2* pairs = reinterpret_cast<u32x2*>(k0);            // pass 3 reads k1 / p1
-      hipLaunchKernelGGL(rank_blocks_kernel<C>, grid, dim3(TPB), blocks_lds, st, kin, pin, hist, pairs, fill, static_cast<int>(N), M, nblk, static_cast<int>(n_blocks));
+      hipLaunchKernelGGL(rank_blocks_kernel<CfgStd>, grid3, dim3(CfgStd::TPB), blocks_lds, st, kin, pin, hist, pairs, fill, static_cast<int>(N), M, nblk3, static_cast<int>(n_blocks));
       const dim3 bgrid(static_cast<unsigned>(n_blocks), L);
       if (ldo % 4 == 0 && mdg_aligned16(out))
         hipLaunchKernelGGL(rank_block_write_kernel<true>, bgrid, dim3(512), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
