@@ -106,7 +106,7 @@ __device__ __forceinline__ void store_tile_histogram(const uint32_t (*cnt)[256],
 // keys of the strict lower triangle in p order + the tile histogram of the lowest digit
 template <class C>
 __global__ __launch_bounds__(C::TPB) void extract_keys_kernel(const float* __restrict__ scores, int64_t lds, uint32_t* __restrict__ keys,
-                                                           uint32_t* __restrict__ hist, int N, int64_t M, int nblk) {
+                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ ghist, int N, int64_t M, int nblk) {
   MDG_RANK_USING(C);
   __shared__ uint32_t cnt[WAVES][256];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -136,9 +136,28 @@ __global__ __launch_bounds__(C::TPB) void extract_keys_kernel(const float* __res
     wj += 64;                                              // the wave's next 64 positions (wave-uniform walk)
     while (wj >= wi) { wj -= wi; ++wi; }
   }
-  wave_digit_counts(key, 0, cnt[wave]);
-  __syncthreads();
-  store_tile_histogram<C>(cnt, hist, seg, nblk, base, M);
+  if (ghist) {
+    // look-back passes: the outcome's digit totals of ALL FOUR passes (a digit histogram does not depend on the order of the keys):
+    // wave-private counters, one atomic per tile, pass and digit.  ghist[(pass * outcomes + seg) * 256 + d]
+    const int64_t n_seg = gridDim.y;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+      wave_digit_counts(key, 8 * pass, cnt[wave]);
+      __syncthreads();
+      if (tid < 256) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) { c += cnt[w][tid]; cnt[w][tid] = 0; }
+        if (tid == 255 && base + TILE > M) c -= static_cast<uint32_t>(base + TILE - M);
+        if (c) atomicAdd(&ghist[(pass * n_seg + seg) * 256 + tid], c);
+      }
+      __syncthreads();
+    }
+  } else {
+    wave_digit_counts(key, 0, cnt[wave]);
+    __syncthreads();
+    store_tile_histogram<C>(cnt, hist, seg, nblk, base, M);
+  }
 }
 
 template <class C>
@@ -159,6 +178,54 @@ __global__ __launch_bounds__(C::TPB) void histogram_kernel(const uint32_t* __res
   wave_digit_counts(key, shift, cnt[wave]);
   __syncthreads();
   store_tile_histogram<C>(cnt, hist, seg, nblk, base, M);
+}
+
+// ---- tile offsets without the histogram / scan launches: decoupled look-back ------------------------------------------------
+// A scatter needs, per digit d, the number of keys with digit d in the tiles before it.  Instead of a histogram kernel + a scan
+// kernel per pass (a fourth of the bytes of a pass, two launches), every tile publishes its own digit counts in status[tile][d]
+// (flag AGGREGATE), walks back over its predecessors adding their counts until it meets one that already knows its inclusive
+// prefix (flag INCLUSIVE), then publishes its own inclusive prefix.  One 32-bit word carries flag and value, written and read
+// with relaxed agent-scope atomics (sc1: L2-coherent, no fence needed for a self-contained word: MI355X_MICROARCH.md, granules).
+// A tile waits only for tiles with a LOWER index of the same outcome, which were dispatched before it (blockIdx.x fastest) and wait
+// only for still lower ones; polls are bounded (a lost word must not hang the card: the result is then wrong, loudly, in the tests).
+// The digit totals of a pass (its exclusive scan over the 256 digits = where each digit's run starts) come from a global
+// histogram the PREVIOUS pass (the key extraction for pass 0) accumulates with one atomic per tile and digit.
+constexpr uint32_t LB_AGG = 1u << 30, LB_INC = 2u << 30, LB_VAL = (1u << 30) - 1;
+constexpr unsigned LB_SPIN_LIMIT = 1u << 22;
+
+// step 1, as early as the tile knows its digit counts (a cheap counting sweep in front of the ranking): successors can add them
+__device__ __forceinline__ void lookback_publish(uint32_t* __restrict__ status_seg, int blk, int d, uint32_t local) {
+  __hip_atomic_store(status_seg + static_cast<int64_t>(blk) * 256 + d, local | (blk == 0 ? LB_INC : LB_AGG), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// step 2, as late as the offsets are needed (after the ranking): by then the predecessors published long ago and most of them
+// already hold their inclusive prefix, so the walk is one or two loads deep instead of as deep as the set of co-resident tiles
+__device__ __forceinline__ uint32_t lookback_walk(uint32_t* __restrict__ status_seg, int blk, int d, uint32_t local) {
+  if (blk == 0) return 0;
+  uint32_t prefix = 0;
+  for (int t = blk - 1; t >= 0; --t) {
+    const uint32_t* theirs = status_seg + static_cast<int64_t>(t) * 256 + d;
+    uint32_t v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while ((v >> 30) == 0 && ++spins < LB_SPIN_LIMIT) {
+      __builtin_amdgcn_s_sleep(2);
+      v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    prefix += v & LB_VAL;
+    if ((v >> 30) == 2u) break;
+  }
+  __hip_atomic_store(status_seg + static_cast<int64_t>(blk) * 256 + d, (prefix + local) | LB_INC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return prefix;
+}
+
+// exclusive scan over the 256 digits held one per thread by threads 0..255 (4 waves): step 1 inside a wave ...
+__device__ __forceinline__ uint32_t wave_inclusive(uint32_t v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = __shfl_up(v, o, 64);
+    if (lane >= o) v += u;
+  }
+  return v;
 }
 
 // exclusive scan of the 256*nblk counters of one outcome, in place; one workgroup per outcome, coalesced: every wave owns a
@@ -203,12 +270,14 @@ template <class C, bool FIRST, bool LAST>
 __global__ __launch_bounds__(C::TPB) void scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ pay_in,
                                                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ pay_out,
                                                       const uint32_t* __restrict__ offsets, float* __restrict__ out, int64_t ldo, int N,
-                                                      int64_t M, int nblk, int shift, double denom) {
+                                                      int64_t M, int nblk, int shift, double denom, uint32_t* __restrict__ status,
+                                                      const uint32_t* __restrict__ ghist) {
+  // offsets != null: tile offsets from the histogram + scan launches; else look-back (status, this pass's digit totals ghist)
   MDG_RANK_USING(C);
   __shared__ uint32_t cnt[WAVES][256];     // per-wave digit counts, then their exclusive prefix over the waves
   __shared__ uint32_t dstart[256];         // first slot of digit d in the sorted tile
   __shared__ uint32_t gofs[256];           // global position of slot 0 of digit d's run, minus dstart[d]
-  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t wsum[4], wsum2[4];
   __shared__ uint32_t skey[TILE];
   __shared__ uint32_t spay[TILE];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -223,32 +292,53 @@ __global__ __launch_bounds__(C::TPB) void scatter_kernel(const uint32_t* __restr
     key[k] = valid ? keys_in[seg * M + p] : 0xFFFFFFFFu;          // padding: digit 255 in every pass, behind every real key of the tile
     pay[k] = valid ? (FIRST ? static_cast<uint32_t>(p) : pay_in[seg * M + p]) : NO_PAY;
   }
+  uint32_t* const status_seg = offsets ? nullptr : status + seg * static_cast<int64_t>(nblk) * 256;
+  if (!offsets) {                           // (uniform) look-back: count first, publish, count again with ranks
+    wave_digit_counts(key, shift, cnt[wave]);
+    __syncthreads();
+    if (tid < 256) {
+      uint32_t c = 0;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) c += cnt[w][tid];
+      if (tid == 255 && base + TILE > M) c -= static_cast<uint32_t>(base + TILE - M);
+      lookback_publish(status_seg, static_cast<int>(blockIdx.x), tid, c);
+    }
+    __syncthreads();
+    for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+  }
   wave_digit_ranks<true, ITEMS>(key, shift, cnt[wave], lane, rk);
   __syncthreads();
+  uint32_t run = 0, gh = 0, gh_inc = 0;    // thread d < 256: the tile's count of digit d; the outcome's count of digit d
   if (tid < 256) {                         // thread d: prefix over the waves, then over the digits
-    uint32_t run = 0;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) {
       const uint32_t c = cnt[w][tid];
       cnt[w][tid] = run;
       run += c;
     }
-    uint32_t inc = run;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t u = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += u;
-    }
+    const uint32_t inc = wave_inclusive(run, lane);
     if (lane == 63) wsum[wave] = inc;
     dstart[tid] = inc - run;               // exclusive within the wave's 64 digits
+    if (!offsets) {
+      gh = ghist[seg * 256 + tid];
+      gh_inc = wave_inclusive(gh, lane);
+      if (lane == 63) wsum2[wave] = gh_inc;
+    }
   }
   __syncthreads();
   if (tid < 256) {
-    uint32_t add = 0;
-    for (int w = 0; w < wave; ++w) add += wsum[w];
+    uint32_t add = 0, add2 = 0;
+    for (int w = 0; w < wave; ++w) { add += wsum[w]; add2 += wsum2[w]; }
     const uint32_t ds = dstart[tid] + add;
     dstart[tid] = ds;
-    gofs[tid] = offsets[(seg * 256 + tid) * nblk + blockIdx.x] - ds;
+    if (offsets) {
+      gofs[tid] = offsets[(seg * 256 + tid) * nblk + blockIdx.x] - ds;
+    } else {
+      const uint32_t pad = (tid == 255 && base + TILE > M) ? static_cast<uint32_t>(base + TILE - M) : 0u;
+      const uint32_t before = lookback_walk(status_seg, static_cast<int>(blockIdx.x), tid, run - pad);
+      gofs[tid] = (gh_inc - gh + add2) + before - ds;
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -300,12 +390,13 @@ __device__ __forceinline__ uint32_t block_base(int bi, int bj, int N) {
 template <class C>
 __global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ pay_in,
                                                           const uint32_t* __restrict__ offsets, u32x2* __restrict__ pairs,
-                                                          uint32_t* __restrict__ fill, int N, int64_t M, int nblk, int n_blocks) {
+                                                          uint32_t* __restrict__ fill, int N, int64_t M, int nblk, int n_blocks,
+                                                          uint32_t* __restrict__ status, const uint32_t* __restrict__ ghist) {
   MDG_RANK_USING(C);
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];            // [TILE] pairs (u32x2) | bcnt[n_blocks] | bdst[n_blocks]
   __shared__ uint32_t cnt[WAVES][256];
   __shared__ uint32_t gbase[256];
-  __shared__ uint32_t wsum[WAVES];
+  __shared__ uint32_t wsum[WAVES], wsum2[4];
   u32x2* spair = reinterpret_cast<u32x2*>(dyn);
   uint32_t* bcnt = dyn + 2 * TILE;
   uint32_t* bdst = bcnt + n_blocks;
@@ -322,17 +413,49 @@ __global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const uint32_t* __r
     key[k] = valid ? keys_in[seg * M + p] : 0xFFFFFFFFu;
     pay[k] = valid ? pay_in[seg * M + p] : NO_PAY;
   }
+  uint32_t* const status_seg = offsets ? nullptr : status + seg * static_cast<int64_t>(nblk) * 256;
+  if (!offsets) {                           // (uniform) look-back: see scatter_kernel
+    wave_digit_counts(key, 24, cnt[wave]);
+    __syncthreads();
+    if (tid < 256) {
+      uint32_t c = 0;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) c += cnt[w][tid];
+      if (tid == 255 && base + TILE > M) c -= static_cast<uint32_t>(base + TILE - M);
+      lookback_publish(status_seg, static_cast<int>(blockIdx.x), tid, c);
+    }
+    __syncthreads();
+    for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+  }
   wave_digit_ranks<true, ITEMS>(key, 24, cnt[wave], lane, rk);
   __syncthreads();
-  if (tid < 256) {
-    uint32_t run = 0;
+  {
+    uint32_t run = 0, gh = 0, gh_inc = 0;
+    if (tid < 256) {
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-      const uint32_t c = cnt[w][tid];
-      cnt[w][tid] = run;
-      run += c;
+      for (int w = 0; w < WAVES; ++w) {
+        const uint32_t c = cnt[w][tid];
+        cnt[w][tid] = run;
+        run += c;
+      }
+      if (offsets) {
+        gbase[tid] = offsets[(seg * 256 + tid) * nblk + blockIdx.x];
+      } else {
+        gh = ghist[seg * 256 + tid];
+        gh_inc = wave_inclusive(gh, lane);
+        if (lane == 63) wsum2[wave] = gh_inc;
+      }
     }
-    gbase[tid] = offsets[(seg * 256 + tid) * nblk + blockIdx.x];
+    if (!offsets) {                                        // (uniform) look-back: see scatter_kernel
+      __syncthreads();
+      if (tid < 256) {
+        uint32_t add2 = 0;
+        for (int w = 0; w < wave; ++w) add2 += wsum2[w];
+        const uint32_t pad = (tid == 255 && base + TILE > M) ? static_cast<uint32_t>(base + TILE - M) : 0u;
+        gbase[tid] = (gh_inc - gh + add2) + lookback_walk(status_seg, static_cast<int>(blockIdx.x), tid, run - pad);
+      }
+    }
   }
   __syncthreads();
   uint32_t blk[ITEMS], slot[ITEMS];                       // key[] is reused for g, pay[] for the position inside the block
@@ -489,8 +612,9 @@ template <class C>
 static size_t rank_workspace_bytes(int64_t n_outcomes, int64_t N) {
   const size_t M = static_cast<size_t>(N) * (N - 1) / 2;
   const size_t nblk = (M + CfgStd::TILE - 1) / CfgStd::TILE;          // the last pass always runs on 8192-key tiles (the finer table)
-  return 4 * a256(static_cast<size_t>(n_outcomes) * M * 4) + a256(static_cast<size_t>(n_outcomes) * 256 * nblk * 4) +
-         a256(static_cast<size_t>(n_outcomes) * static_cast<size_t>(rank_blocks_of(N)) * 4);
+  // keys / payloads x 2 | per-tile digit table (histogram path: one; look-back: one status table per pass) | block fill counters | digit totals
+  return 4 * a256(static_cast<size_t>(n_outcomes) * M * 4) + 4 * a256(static_cast<size_t>(n_outcomes) * 256 * nblk * 4) +
+         a256(static_cast<size_t>(n_outcomes) * static_cast<size_t>(rank_blocks_of(N)) * 4) + a256(static_cast<size_t>(n_outcomes) * 4 * 256 * 4);
 }
 
 extern "C" size_t mdg_rank_normalize_workspace_bytes(int64_t n_outcomes, int64_t N) {
@@ -523,9 +647,17 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
   uint32_t* p1 = reinterpret_cast<uint32_t*>(ws + 3 * kb);
   uint32_t* hist = reinterpret_cast<uint32_t*>(ws + 4 * kb);
   const int nblk3 = static_cast<int>(mdg_cdiv(M, CfgStd::TILE));
-  uint32_t* fill = reinterpret_cast<uint32_t*>(ws + 4 * kb + a256(static_cast<size_t>(n_outcomes) * 256 * nblk3 * 4));
+  const size_t hb = a256(static_cast<size_t>(n_outcomes) * 256 * nblk3 * 4);       // one per-tile digit table
+  uint32_t* fill = reinterpret_cast<uint32_t*>(ws + 4 * kb + 4 * hb);
+  const size_t fb = a256(static_cast<size_t>(n_outcomes) * static_cast<size_t>(rank_blocks_of(N)) * 4);
+  uint32_t* ghist = reinterpret_cast<uint32_t*>(ws + 4 * kb + 4 * hb + fb);        // [4 passes][outcomes][256]
   const int64_t n_blocks = rank_blocks_of(N);
   static MdgEnvInt direct_sw{"MDG_RANKS_DIRECT", 0};        // 1: the last pass stores the ranks one by one (the large-N path) at any N
+  // Tile offsets from histogram + scan launches (default) or by decoupled look-back (1).  Measured on 4096^2 outcomes: the
+  // look-back saves the 37 us of histogram / scan launches per outcome and gives 35 us back inside the scatters (every walk step is
+  // a cross-XCD sc1 load, ~2 us, in front of the tile's write phase; 4 digit histograms in the extraction): 0.26 ms either way.
+  static MdgEnvInt lb_sw{"MDG_RANKS_LOOKBACK", 0};
+  const bool lb = lb_sw.get() != 0;
   // the blocked last pass on 8192-key tiles whatever the other passes use: two workgroups per CU there beat one of 16384 keys
   // (48 against 63 us per 4096^2 outcome); its histogram and scan use the same tiling
   const size_t blocks_lds = static_cast<size_t>(2 * CfgStd::TILE + 2 * n_blocks) * 4;
@@ -533,7 +665,10 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
   const dim3 grid3(static_cast<unsigned>(nblk3), L);
   const double denom = static_cast<double>(N) * static_cast<double>(N - 1) / 2.0;
   const dim3 grid(static_cast<unsigned>(nblk), L);
-  hipLaunchKernelGGL(extract_keys_kernel<C>, grid, dim3(TPB), 0, st, scores, lds, k0, hist, static_cast<int>(N), M, nblk);
+  const auto status_of = [&](int pass) { return reinterpret_cast<uint32_t*>(ws + 4 * kb + pass * hb); };
+  const auto ghist_of = [&](int pass) { return ghist + static_cast<size_t>(pass) * n_outcomes * 256; };
+  if (lb) (void)hipMemsetAsync(ws + 4 * kb, 0, 4 * hb + fb + a256(static_cast<size_t>(n_outcomes) * 4 * 256 * 4), st);   // status tables, block fill counters, digit totals
+  hipLaunchKernelGGL(extract_keys_kernel<C>, grid, dim3(TPB), 0, st, scores, lds, k0, hist, lb ? ghist : nullptr, static_cast<int>(N), M, nblk);
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 8 * pass;
     uint32_t* kin = (pass & 1) ? k1 : k0;
@@ -541,24 +676,29 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
     uint32_t* pin = (pass & 1) ? p1 : p0;
     uint32_t* pout = (pass & 1) ? p0 : p1;
     const bool std3 = pass == 3 && blocked;
-    if (std3) hipLaunchKernelGGL(histogram_kernel<CfgStd>, grid3, dim3(CfgStd::TPB), 0, st, kin, hist, M, nblk3, shift);
-    else if (pass > 0) hipLaunchKernelGGL(histogram_kernel<C>, grid, dim3(TPB), 0, st, kin, hist, M, nblk, shift);
-    hipLaunchKernelGGL(scan_kernel, dim3(L), dim3(1024), 0, st, hist, std3 ? nblk3 : nblk);
+    const uint32_t* offs = lb ? nullptr : hist;
+    uint32_t* stat = lb ? status_of(pass) : nullptr;
+    const uint32_t* gcur = lb ? ghist_of(pass) : nullptr;
+    if (!lb) {
+      if (std3) hipLaunchKernelGGL(histogram_kernel<CfgStd>, grid3, dim3(CfgStd::TPB), 0, st, kin, hist, M, nblk3, shift);
+      else if (pass > 0) hipLaunchKernelGGL(histogram_kernel<C>, grid, dim3(TPB), 0, st, kin, hist, M, nblk, shift);
+      hipLaunchKernelGGL(scan_kernel, dim3(L), dim3(1024), 0, st, hist, std3 ? nblk3 : nblk);
+    }
     if (pass == 0)
-      hipLaunchKernelGGL((scatter_kernel<C, true, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, ldo, static_cast<int>(N), M, nblk, shift, denom);
+      hipLaunchKernelGGL((scatter_kernel<C, true, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, offs, out, ldo, static_cast<int>(N), M, nblk, shift, denom, stat, gcur);
     else if (pass == 3 && blocked) {
-      (void)hipMemsetAsync(fill, 0, static_cast<size_t>(n_outcomes) * n_blocks * 4, st);
+      if (!lb) (void)hipMemsetAsync(fill, 0, static_cast<size_t>(n_outcomes) * n_blocks * 4, st);
       u32x2* pairs = reinterpret_cast<u32x2*>(k0);            // pass 3 reads k1 / p1
-      hipLaunchKernelGGL(rank_blocks_kernel<CfgStd>, grid3, dim3(CfgStd::TPB), blocks_lds, st, kin, pin, hist, pairs, fill, static_cast<int>(N), M, nblk3, static_cast<int>(n_blocks));
+      hipLaunchKernelGGL(rank_blocks_kernel<CfgStd>, grid3, dim3(CfgStd::TPB), blocks_lds, st, kin, pin, offs, pairs, fill, static_cast<int>(N), M, nblk3, static_cast<int>(n_blocks), stat, gcur);
       const dim3 bgrid(static_cast<unsigned>(n_blocks), L);
       if (ldo % 4 == 0 && mdg_aligned16(out))
         hipLaunchKernelGGL(rank_block_write_kernel<true>, bgrid, dim3(512), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
       else
         hipLaunchKernelGGL(rank_block_write_kernel<false>, bgrid, dim3(512), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
     } else if (pass == 3)
-      hipLaunchKernelGGL((scatter_kernel<C, false, true>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, ldo, static_cast<int>(N), M, nblk, shift, denom);
+      hipLaunchKernelGGL((scatter_kernel<C, false, true>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, offs, out, ldo, static_cast<int>(N), M, nblk, shift, denom, stat, gcur);
     else
-      hipLaunchKernelGGL((scatter_kernel<C, false, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, ldo, static_cast<int>(N), M, nblk, shift, denom);
+      hipLaunchKernelGGL((scatter_kernel<C, false, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, offs, out, ldo, static_cast<int>(N), M, nblk, shift, denom, stat, gcur);
   }
   MDG_CHECK_LAUNCH("mdg_rank_normalize");
   return MDG_OK;

@@ -79,7 +79,7 @@ def test_ranks_golden_bit_exact(ops, golden):
     assert np.array_equal(out, g["normalized"])                      # rank ordering and fp32 values bit exact
 
 
-@pytest.mark.parametrize("path", ["default", "tile8192", "direct"])
+@pytest.mark.parametrize("path", ["default", "tile8192", "direct", "lookback"])
 @pytest.mark.parametrize("N,L", [(300, 5), (2, 3), (1, 2), (97, 1), (1025, 2), (1283, 1)])
 def test_ranks_vs_oracle(ops, monkeypatch, N, L, path):
     """Every path of the sort: 16384-key tiles (default at these N) and 8192-key tiles, the blocked last pass and the direct one
@@ -90,6 +90,8 @@ def test_ranks_vs_oracle(ops, monkeypatch, N, L, path):
         set_switch(monkeypatch, "MDG_RANKS_TILE", "8192")
     if path == "direct":
         set_switch(monkeypatch, "MDG_RANKS_DIRECT", "1")
+    if path == "lookback":                       # tile offsets by decoupled look-back instead of the histogram / scan launches
+        set_switch(monkeypatch, "MDG_RANKS_LOOKBACK", "1")
     rng = np.random.default_rng(N)
     s = rng.standard_normal((L, N, N)).astype(np.float32) * 7
     ref = O.rank_normalize(s)
