@@ -253,7 +253,7 @@ int mdg_rank_normalize_ld(const float* scores, int64_t lds, float* out, int64_t 
 
 /* Elementwise geometric mean of K <= 8 equally shaped fp32 tensors (the 5-seed ensembling of normalised ranks,
  * scipy.stats.mstats.gmean in notebooks/generate_embeddings.ipynb): out = exp(mean_k log x_k) in fp32; 0 where any
- * x_k <= 0.  inputs_host is a HOST array of K device pointers; n (elements) must be a multiple of 4. */
+ * x_k <= 0.  inputs_host is a HOST array of K device pointers (16-byte aligned); n = elements of each tensor. */
 int mdg_gmean(const float* const* inputs_host, int K, float* out, int64_t n, void* stream);
 
 /* mdg_hgt_attention that also returns the softmax statistics stats [n_dst, heads, 2] = (max logit, denominator) the

@@ -579,8 +579,20 @@ inline size_t a256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 // give 0.  (generate_embeddings.ipynb, the 5-seed ensembling cell.)
 struct GmeanArgs { const float* in[8]; int K; };
 
-__global__ __launch_bounds__(256) void gmean_kernel(const GmeanArgs a, float* __restrict__ out, int64_t n4) {
+__global__ __launch_bounds__(256) void gmean_kernel(const GmeanArgs a, float* __restrict__ out, int64_t n4, int64_t n) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i == 0) {                                            // the n % 4 last elements (an odd N^2 in a contiguous tensor)
+    for (int64_t j = 4 * n4; j < n; ++j) {
+      float acc = 0.f;
+      bool pos = true;
+      for (int k = 0; k < a.K; ++k) {
+        const float v = a.in[k][j];
+        pos = pos && v > 0.f;
+        acc += logf(v > 0.f ? v : 1.f);
+      }
+      out[j] = pos ? expf(acc / static_cast<float>(a.K)) : 0.f;
+    }
+  }
   if (i >= n4) return;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   bool pos[4] = {true, true, true, true};
@@ -718,7 +730,7 @@ extern "C" int mdg_rank_normalize_ld(const float* scores, int64_t lds, float* ou
 }
 
 extern "C" int mdg_gmean(const float* const* inputs_host, int K, float* out, int64_t n, void* stream) {
-  MDG_CHECK_ARG(inputs_host && out && K >= 1 && K <= 8 && n >= 0 && n % 4 == 0, "mdg_gmean: 1 <= K <= 8 tensors of n (multiple of 4) floats");
+  MDG_CHECK_ARG(inputs_host && out && K >= 1 && K <= 8 && n >= 0, "mdg_gmean: 1 <= K <= 8 tensors of n floats");
   if (n == 0) return MDG_OK;
   GmeanArgs a{};
   a.K = K;
@@ -727,7 +739,7 @@ extern "C" int mdg_gmean(const float* const* inputs_host, int K, float* out, int
     a.in[k] = inputs_host[k];
   }
   MDG_CHECK_ARG(mdg_aligned16(out), "mdg_gmean: out not 16-byte aligned");
-  hipLaunchKernelGGL(gmean_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n / 4, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), a, out, n / 4);
+  hipLaunchKernelGGL(gmean_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n / 4 > 0 ? n / 4 : 1, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), a, out, n / 4, n);
   MDG_CHECK_LAUNCH("mdg_gmean");
   return MDG_OK;
 }

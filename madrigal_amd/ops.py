@@ -673,16 +673,27 @@ def rank_normalize(scores: torch.Tensor, out: Optional[torch.Tensor] = None, max
 
 
 def gmean(tensors) -> torch.Tensor:
-    """Elementwise geometric mean of up to 8 equally shaped fp32 tensors (5-seed rank ensembling)."""
-    ts = [_f32_cuda(t, f"tensors[{i}]") for i, t in enumerate(tensors)]
+    """Elementwise geometric mean of up to 8 equally shaped fp32 tensors (5-seed rank ensembling).  Row-pitched rank tensors
+    (``empty_scores``) of one pitch are averaged in place of their padded storage: the result has the same layout."""
+    ts = list(tensors)
     if not 1 <= len(ts) <= 8 or any(t.shape != ts[0].shape for t in ts):
         raise ValueError("gmean: 1..8 tensors of identical shape")
-    n = ts[0].numel()
-    if n % 4:
-        raise ValueError("gmean: element count must be a multiple of 4")
+    t0 = ts[0]
+    pitched = (t0.dim() == 3 and t0.is_cuda and t0.dtype == torch.float32 and t0.numel() > 0 and t0.stride(2) == 1 and t0.stride(1) > t0.shape[2]
+               and all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.stride() == t0.stride() for t in ts)
+               and t0.stride(0) == t0.shape[1] * t0.stride(1))
+    if pitched:
+        L, N, _ = t0.shape
+        P = t0.stride(1)
+        full = [t.as_strided((L, N, P), (N * P, P, 1)) for t in ts]          # the padded storage itself: contiguous, n % 4 == 0
+        out_full = torch.empty((L, N, P), dtype=torch.float32, device=t0.device)
+        arr = (ctypes.c_void_p * len(full))(*[t.data_ptr() for t in full])
+        check(lib().mdg_gmean(arr, _c(len(full)), _ptr(out_full), _c64(L * N * P), _stream(out_full)), "mdg_gmean")
+        return out_full[:, :, :t0.shape[2]]
+    ts = [_f32_cuda(t, f"tensors[{i}]") for i, t in enumerate(ts)]
     out = torch.empty_like(ts[0])
     arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-    check(lib().mdg_gmean(arr, _c(len(ts)), _ptr(out), _c64(n), _stream(out)), "mdg_gmean")
+    check(lib().mdg_gmean(arr, _c(len(ts)), _ptr(out), _c64(ts[0].numel()), _stream(out)), "mdg_gmean")
     return out
 
 

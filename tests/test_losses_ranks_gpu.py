@@ -137,11 +137,13 @@ def test_ranks_full_size_properties(ops):
         assert int(torch.unique(r).numel()) == M
 
 
-def test_gmean_and_seed_ensembling(ops):
-    """5-seed ensembling: gmean of normalised ranks (fp32, as scipy.stats.mstats.gmean on float32) then re-ranked."""
+@pytest.mark.parametrize("N", [64, 45])
+def test_gmean_and_seed_ensembling(ops, N):
+    """5-seed ensembling: gmean of normalised ranks (fp32, as scipy.stats.mstats.gmean on float32) then re-ranked.  N = 45: an odd
+    element count (the tail of the vectorised kernel) and, for the row-pitched layout, rank tensors that are [:, :, :N] views."""
     from oracle import madrigal_oracle as O
     rng = np.random.default_rng(3)
-    N, L, K = 64, 3, 5
+    L, K = 3, 5
     ranks = [O.rank_normalize(rng.standard_normal((L, N, N)).astype(np.float32)) for _ in range(K)]
     with np.errstate(divide="ignore"):
         ref = np.exp(np.mean(np.log(np.stack(ranks, -1)), axis=-1, dtype=np.float32)).astype(np.float32)
@@ -153,3 +155,11 @@ def test_gmean_and_seed_ensembling(ops):
     assert np.array_equal(ens, O.rank_normalize(g.cpu().numpy()))
     assert float(np.abs(ens - O.rank_normalize(ref)).max()) < 5.0 / (N * (N - 1) / 2)
     assert np.array_equal(ens, ens.transpose(0, 2, 1))
+    pit = []
+    for r in ranks:                                  # the same through row-pitched tensors: identical bits
+        p_ = ops.empty_scores(L, N, N, "cuda")
+        p_.copy_(torch.from_numpy(r))
+        pit.append(p_)
+    gp = ops.gmean(pit)
+    assert gp.stride(1) == pit[0].stride(1) and torch.equal(gp, g)
+    assert np.array_equal(ops.ensemble_ranks(pit).cpu().numpy(), ens)
