@@ -13,7 +13,7 @@ out = {"command": "rocprofv3 --pmc WRITE_SIZE (and, separately, --pmc FETCH_SIZE
        "workload": {"drugs": 4096, "outcomes": 896, "precision": "bf16x3"},
        "note": "per-dispatch averages; counters are in KiB; gfx950: FETCH_SIZE tallies 128-B requests at 64 B, so read bytes = 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM); WRITE_SIZE is exact for these stores",
        "kernels": {}}
-keep = ("bilinear", "linear_kernel", "hgt_attention", "fusion_attention", "csr_aggregate", "prep_operands")
+keep = ("bilinear", "linear_kernel", "linear_pp_kernel", "hgt_attention", "fusion_attention", "csr_aggregate", "prep_operands")
 kt = {r["Name"]: r for r in csv.DictReader(open(glob.glob(f"{root}/kt/*/*_kernel_stats.csv")[0]))}
 for sub, cname in (("pmc_w", "WRITE_SIZE"), ("pmc_r", "FETCH_SIZE")):
     agg = collections.defaultdict(list)
