@@ -266,6 +266,8 @@ struct LinearArgs {
   int tiles_x, tiles_y, swizzle;   // swizzle: XCD-aware tile order (see tile_of)
   int vec_y, vec_r;                // y / residual rows may be accessed 16 B at a time (alignment and row stride)
   const int64_t* tiles;            // grouped launch: [n_tiles][kGroupTileWords] tile descriptors (device), else null
+  const float* a_raw;              // 128-tile kernel, 16-bit modes: x itself (fp32 rows, stride a_ldx floats, a_k valid columns) when no
+  int64_t a_ldx, a_k;              // operand image of it exists -- the kernel rounds / splits it while staging (no pre-pass over x)
   int sk_tiles;                    // 256-tile kernel, stream-K hybrid: the last sk_tiles tiles are shared k tile by k tile (0: one tile per workgroup)
   char* sk_ws;                     // its workspace: accumulator slots | flags
 };
@@ -320,10 +322,69 @@ __device__ __forceinline__ void issue(const Operand& A, const Operand& B, int64_
 // Pipeline: one raw barrier per k-tile.  Top of tile kt: wait for this wave's DMA pieces of tile kt (the only
 // vector-memory ops in flight), barrier (=> every wave's pieces landed, every wave finished reading tile kt-1),
 // issue the DMA of tile kt+1 into the other buffer, then the MFMAs of tile kt run under that DMA.
-template <int MODE, class S, int MF, class Mma>
+// the B half of `issue` (the A operand comes from registers in the raw-x variant)
+template <int MODE, class S, int MF>
+__device__ __forceinline__ void issue_b(const Operand& A, const Operand& B, int64_t col0, int64_t k0, char* lds, int wave, int lane, int slot) {
+  if constexpr (MF == 16 && MODE == MDG_PREC_BF16X3) { if (slot < 4) dma_slot<MODE, S, MF>(A, B, 0, col0, k0, lds, wave, lane, 4 + slot); }
+  else if constexpr (MF == 16) { if (slot < 2) dma_slot<MODE, S, MF>(A, B, 0, col0, k0, lds, wave, lane, 4 + 2 * slot); }
+  else if (slot == 0) dma_stage<MODE, S, MF, 1>(A, B, 0, col0, k0, lds, wave, lane);
+}
+
+template <int MODE, class S, int MF, bool ARAW, class Mma>
 __device__ __forceinline__ void k_loop(const LinearArgs& p, int64_t row0, int64_t col0, char* smem, int wave, int lane, Mma&& mma) {
   const int nk = static_cast<int>(p.K / BK);
+  if constexpr (ARAW) {
+    // x itself is the A operand: thread (row = tid / 2, half = tid & 1) loads its 16 floats of the next k tile straight from
+    // the fp32 rows while the current tile multiplies, then rounds / splits them (what the pre-pass would have written: same
+    // values, same results bit for bit) into the other stage's bf16 tile.  The weights stay an LDS-DMA of their cached image.
+    static_assert(S::THREADS == 256 && S::BM == 128 && MODE != MDG_PREC_F32, "one half row per thread");
+    const int tid = wave * 64 + lane, arow = tid >> 1, ahalf = tid & 1;
+    int64_t gr = row0 + arow;
+    gr = gr < p.A.nrows ? gr : p.A.nrows - 1;
+    const float* const src = p.a_raw + gr * p.a_ldx + 16 * ahalf;
+    const int64_t kvalid = p.a_k - 16 * ahalf;               // floats of this thread's half row that exist
+    f32x4 st[4];
+    const auto load_a = [&](int kt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t k = static_cast<int64_t>(kt) * BK + 4 * i;
+        st[i] = k < kvalid ? *reinterpret_cast<const f32x4*>(src + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    const auto store_a = [&](char* la) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          __bf16 a_, b_;
+          mdg_split_bf16(st[2 * c + (e >> 2)][e & 3], a_, b_);
+          hi[e] = a_;
+          lo[e] = b_;
+        }
+        const int off = MF == 16 ? off_bf16_m16(arow, 2 * ahalf + c) : off_bf16(arow, 2 * ahalf + c);
+        *reinterpret_cast<bf16x8*>(la + off) = hi;
+        if constexpr (MODE == MDG_PREC_BF16X3) *reinterpret_cast<bf16x8*>(la + S::A_LO + off) = lo;
+      }
+    };
+    load_a(0);
+    dma_stage<MODE, S, MF, 1>(p.A, p.B, 0, col0, 0, smem, wave, lane);
+    store_a(smem);
+    for (int kt = 0; kt < nk; ++kt) {
+      char* const cur = smem + (kt & 1) * S::STAGE;
+      char* const nxt = smem + ((kt + 1) & 1) * S::STAGE;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's weight DMA and its A-tile writes
+      __builtin_amdgcn_s_barrier();
+      const bool more = kt + 1 < nk;
+      const int64_t kn = static_cast<int64_t>(kt + 1) * BK;
+      if (more) load_a(kt + 1);
+      mma(cur, cur + kBOffset<MODE, S>, [&](int slot) { if (more) issue_b<MODE, S, MF>(p.A, p.B, col0, kn, nxt, wave, lane, slot); });
+      if (more) store_a(nxt);
+    }
+    return;
+  }
   if constexpr (kStages<MODE> == 4) {
+
     // four-stage ring, three k tiles in flight.  Every wave issues exactly 4 LDS-DMA pieces per tile (static_assert), its only
     // vector-memory operations, and they retire in issue order: `vmcnt(8)` at the top of tile kt leaves the pieces of tiles
     // kt+1 and kt+2 in flight.  The buffer refilled at the top of kt held tile kt-1, which every wave finished reading before
@@ -427,7 +488,7 @@ __device__ __forceinline__ void slab_to_global(const LinearArgs& p, const float*
 //          6 y_off   7 ldy   8 res_off (-1: none)  9 ldr   10 alpha (float bits) | beta (float bits) << 32
 constexpr int kGroupTileWords = 12;
 
-template <int MODE, class S, int MF, bool GROUPED = false>
+template <int MODE, class S, int MF, bool GROUPED = false, bool ARAW = false>
 __global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs pk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [stages][A tile | B tile]; reused as [wave][64][64] fp32 by the epilogue
   constexpr int MT = S::MT, NT_ = S::NT_;
@@ -468,8 +529,8 @@ __global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs 
     for (int a = 0; a < 2 * MT; ++a)
 #pragma unroll
       for (int b = 0; b < 2 * NT_; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    k_loop<MODE, S, MF>(p, row0, col0, smem, wave, lane,
-                        [&](const char* la, const char* lb, auto&& mid) { mma_stage16<MODE, S>(la, lb, wr, wc, c, g, acc, mid); });
+    k_loop<MODE, S, MF, ARAW>(p, row0, col0, smem, wave, lane,
+                              [&](const char* la, const char* lb, auto&& mid) { mma_stage16<MODE, S>(la, lb, wr, wc, c, g, acc, mid); });
     __syncthreads();                                      // every wave is done with the staging buffers
 #pragma unroll
     for (int pass = 0; pass < MT / 2; ++pass) {
@@ -490,8 +551,8 @@ __global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs 
       for (int b = 0; b < NT_; ++b)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
-    k_loop<MODE, S, MF>(p, row0, col0, smem, wave, lane,
-                        [&](const char* la, const char* lb, auto&& mid) { mma_stage<MODE, S>(la, lb, wr, wc, r, h, acc, mid); });
+    k_loop<MODE, S, MF, ARAW && MODE != MDG_PREC_F32>(p, row0, col0, smem, wave, lane,
+                                                      [&](const char* la, const char* lb, auto&& mid) { mma_stage<MODE, S>(la, lb, wr, wc, r, h, acc, mid); });
     __syncthreads();
 #pragma unroll
     for (int pass = 0; pass < MT / 2; ++pass) {
@@ -1027,16 +1088,27 @@ static bool pp_shape(int precision, int64_t M, int64_t N) {
   return precision != MDG_PREC_F32 && N >= 256 && M >= 1024 && mdg_cdiv(M, pp::BM) * mdg_cdiv(N, pp::BN) >= 192;
 }
 
+// tile shape: the 256x256 / 8-wave shape once the problem fills the chip with it, else 128x128 / 4 waves
+// (measured on the fusion GEMMs: bf16x3 -9 % time with the big tile, fp32 +6 %: the fp32 MFMA wants two workgroups per CU)
+static bool choose_big(int precision, int64_t M, int64_t N) {
+  bool big = pp_shape(precision, M, N);
+  static MdgEnvInt tile_sw{"MDG_LINEAR_TILE", 0};
+  if (tile_sw.get() == 256) big = precision != MDG_PREC_F32;
+  else if (tile_sw.get() == 128) big = false;
+  return big;
+}
+
+// 128-tile kernel, 16-bit modes: x is rounded / split while it is staged, no pre-pass over it (MDG_LINEAR_RAWX=0: pre-pass)
+static bool raw_x_ok(int precision, bool big) {
+  static MdgEnvInt raw_sw{"MDG_LINEAR_RAWX", 1};
+  return !big && precision != MDG_PREC_F32 && raw_sw.get() != 0;
+}
+
 // sk_ws / sk_avail: what is left of the caller's workspace behind the operand images (the stream-K slots and flags)
 static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t N, hipStream_t st, char* sk_ws = nullptr, size_t sk_avail = 0) {
   a.vec_y = mdg_aligned16(a.y) && a.ldy % 4 == 0;
   a.vec_r = a.res && mdg_aligned16(a.res) && a.ldr % 4 == 0;
-  // tile shape: the 256x256 / 8-wave shape once the problem fills the chip with it, else 128x128 / 4 waves
-  // (measured on the fusion GEMMs: bf16x3 -9 % time with the big tile, fp32 +6 %: the fp32 MFMA wants two workgroups per CU)
-  bool big = pp_shape(precision, M, N);
-  static MdgEnvInt tile_sw{"MDG_LINEAR_TILE", 0};
-  if (tile_sw.get() == 256) big = true;
-  else if (tile_sw.get() == 128) big = false;
+  const bool big = choose_big(precision, M, N);
   // 1-D grid; the kernel maps the linear workgroup id to a tile (XCD-aware order once there are enough tiles to matter)
   static MdgEnvInt swz_sw{"MDG_LINEAR_SWIZZLE", -1};
   const int swz_env = swz_sw.get();
@@ -1086,7 +1158,15 @@ static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t 
   const dim3 grid = grid_for(S::BM, S::BN);
   const size_t lds = 2 * S::STAGE;
   if (precision == MDG_PREC_F32) hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, S, 32>), grid, dim3(S::THREADS), lds, st, a);
-  else if (precision == MDG_PREC_BF16X3) {
+  else if (a.a_raw) {                                         // x straight from its fp32 rows
+    if (precision == MDG_PREC_BF16X3) {
+      if (m16) hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, S, 16, false, true>), grid, dim3(S::THREADS), lds, st, a);
+      else hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, S, 32, false, true>), grid, dim3(S::THREADS), lds, st, a);
+    } else {
+      if (m16) hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, S, 16, false, true>), grid, dim3(S::THREADS), lds, st, a);
+      else hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, S, 32, false, true>), grid, dim3(S::THREADS), lds, st, a);
+    }
+  } else if (precision == MDG_PREC_BF16X3) {
     if (m16) hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, S, 16>), grid, dim3(S::THREADS), lds, st, a);
     else hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, S, 32>), grid, dim3(S::THREADS), lds, st, a);
   } else {
@@ -1139,7 +1219,8 @@ extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t l
   MDG_CHECK_ARG(mdg_cdiv(M, Small::BM) * mdg_cdiv(N, Small::BN) < (1ll << 31) - 8, "mdg_linear: too many tiles for one launch");
   MDG_CHECK_ARG(precision == MDG_PREC_F32 || precision == MDG_PREC_BF16X3 || precision == MDG_PREC_BF16, "mdg_linear: unknown precision %d", precision);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const size_t xb = image_bytes(M, K, precision), wb = image_bytes(N, K, precision);
+  const bool rawx = raw_x_ok(precision, choose_big(precision, M, N));
+  const size_t xb = rawx ? 0 : image_bytes(M, K, precision), wb = image_bytes(N, K, precision);
   const bool w_ready = w_packed != nullptr || wb == 0;      // fp32 with K % 32 == 0 needs no image at all
   MDG_CHECK_ARG(w || w_ready, "mdg_linear: raw w missing");
   const size_t need = xb + (w_ready ? 0 : wb);          // (+ the stream-K slots where the shape takes them: optional, used when present)
@@ -1158,6 +1239,7 @@ extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t l
   a.y = y; a.ldy = ldy; a.bias = bias; a.scale = scale; a.shift = shift; a.res = residual; a.ldr = ldr;
   a.alpha = alpha; a.beta = beta; a.act = act; a.M = M; a.N = N; a.K = pad_k(K, precision);
   set_operand(a.A, x, ldx, ximg, M, K, precision);
+  if (rawx) { a.a_raw = x; a.a_ldx = ldx; a.a_k = K; a.A.nrows = M; }
   set_operand(a.B, w, ldw, wb == 0 ? nullptr : (w_packed ? static_cast<const char*>(w_packed) : wimg), N, K, precision);
   launch_linear_core(a, precision, M, N, st, workspace ? ws + need : nullptr, workspace_bytes > need ? workspace_bytes - need : 0);
   MDG_CHECK_LAUNCH("mdg_linear");
@@ -1185,11 +1267,12 @@ extern "C" int mdg_linear_grouped(const float* x, int64_t ldx, int64_t rows_tota
   const size_t xb = image_bytes(rows_total, K, precision), wb = image_bytes(w_rows_total, K, precision);
   MDG_CHECK_ARG(wb == 0 ? (w != nullptr && ldw >= K && ldw % 4 == 0 && mdg_aligned16(w)) : w_packed != nullptr,
                 "mdg_linear_grouped: the stacked weights must come packed (mdg_pack_operand), or raw where the mode needs no image");
-  if (xb && (!workspace || workspace_bytes < xb || !mdg_aligned16(workspace))) {
+  if (xb && !raw_x_ok(precision, false) && (!workspace || workspace_bytes < xb || !mdg_aligned16(workspace))) {
     mdg_set_error("mdg_linear_grouped: workspace of %zu bytes (16-byte aligned) required, got %zu", xb, workspace_bytes);
     return MDG_EWORKSPACE;
   }
-  char* ximg = xb ? static_cast<char*>(workspace) : nullptr;
+  const bool rawx = raw_x_ok(precision, false);
+  char* ximg = (xb && !rawx) ? static_cast<char*>(workspace) : nullptr;
   if (ximg) launch_prep(x, ldx, rows_total, ximg, nullptr, 0, 0, nullptr, K, precision, st);
   LinearArgs a{};
   a.y = y; a.ldy = 0; a.bias = bias; a.res = residual; a.ldr = 0; a.alpha = 1.f; a.beta = 1.f; a.act = act;
@@ -1197,10 +1280,13 @@ extern "C" int mdg_linear_grouped(const float* x, int64_t ldx, int64_t rows_tota
   a.vec_y = 1; a.vec_r = residual ? 1 : 0;               // the table's offsets and strides are multiples of 4 floats (checked by the caller's builder)
   a.tiles = tiles;
   set_operand(a.A, x, ldx, ximg, rows_total, K, precision);
+  if (rawx) { a.a_raw = x; a.a_ldx = ldx; a.a_k = K; }
   set_operand(a.B, w, ldw, wb == 0 ? nullptr : static_cast<const char*>(w_packed), w_rows_total, K, precision);
   const dim3 grid(static_cast<unsigned>(n_tiles));
   const size_t lds = 2 * Small::STAGE;
   if (precision == MDG_PREC_F32) hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, Small, 32, true>), grid, dim3(Small::THREADS), lds, st, a);
+  else if (rawx && precision == MDG_PREC_BF16X3) hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, Small, 16, true, true>), grid, dim3(Small::THREADS), lds, st, a);
+  else if (rawx) hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, Small, 16, true, true>), grid, dim3(Small::THREADS), lds, st, a);
   else if (precision == MDG_PREC_BF16X3) hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, Small, 16, true>), grid, dim3(Small::THREADS), lds, st, a);
   else hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, Small, 16, true>), grid, dim3(Small::THREADS), lds, st, a);
   MDG_CHECK_LAUNCH("mdg_linear_grouped");
