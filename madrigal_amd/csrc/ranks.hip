@@ -67,6 +67,17 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t dg) {
 // (in p order) with the same digit.  Wave-private LDS, in-order LDS queue: no barrier.
 template <bool WANT_RANK, int ITEMS>
 __device__ __forceinline__ void wave_digit_ranks(const uint32_t (&key)[ITEMS], int shift, uint32_t* cnt, int lane, uint32_t (&rank_out)[ITEMS]) {
+#ifdef MDG_RANK_ATOMIC_ORDER
+  // EXPERIMENT: one returning LDS atomic per key.  Stable only if the LDS serves the lanes of one instruction that hit the same
+  // counter in ascending lane order (not an architectural promise) -- see DESIGN.md 4c for what the tie tests said.
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const uint32_t old = __hip_atomic_fetch_add(&cnt[(key[k] >> shift) & 255u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (WANT_RANK) rank_out[k] = old;
+    __builtin_amdgcn_wave_barrier();
+  }
+  (void)lane;
+#else
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
@@ -78,6 +89,7 @@ __device__ __forceinline__ void wave_digit_ranks(const uint32_t (&key)[ITEMS], i
     if (WANT_RANK) rank_out[k] = old + before;
     __builtin_amdgcn_wave_barrier();                       // keep the rounds' counter updates in program order
   }
+#endif
 }
 
 // Digit counts only (no ranks): no-return LDS atomics on the wave's private counters.  Lanes sharing a digit serialise inside one
@@ -160,8 +172,10 @@ __global__ __launch_bounds__(C::TPB) void extract_keys_kernel(const float* __res
   }
 }
 
-template <class C>
-__global__ __launch_bounds__(C::TPB) void histogram_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ hist, int64_t M,
+// KT: what the previous pass left of the key -- the bits below the current digit are sorted already and are not carried along:
+// pass 1 writes the upper 16 bits (uint16_t), pass 2 the upper 8 (uint8_t); `shift` = position of the current digit inside a KT
+template <class C, class KT>
+__global__ __launch_bounds__(C::TPB) void histogram_kernel(const KT* __restrict__ keys, uint32_t* __restrict__ hist, int64_t M,
                                                            int nblk, int shift) {
   MDG_RANK_USING(C);
   __shared__ uint32_t cnt[WAVES][256];
@@ -173,7 +187,7 @@ __global__ __launch_bounds__(C::TPB) void histogram_kernel(const uint32_t* __res
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     const int64_t p = base + wave * WSPAN + k * 64 + lane;
-    key[k] = p < M ? keys[seg * M + p] : 0xFFFFFFFFu;
+    key[k] = p < M ? static_cast<uint32_t>(keys[seg * M + p]) : 0xFFFFFFFFu;
   }
   wave_digit_counts(key, shift, cnt[wave]);
   __syncthreads();
@@ -266,9 +280,11 @@ __global__ __launch_bounds__(1024) void scan_kernel(uint32_t* __restrict__ hist,
   }
 }
 
-template <class C, bool FIRST, bool LAST>
-__global__ __launch_bounds__(C::TPB) void scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ pay_in,
-                                                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ pay_out,
+// KIN / KOUT: key representation read / written (see histogram_kernel): the output drops the digit this pass sorts by when
+// KOUT is narrower than KIN (`shift` must then be 0 within KIN ... the current digit is its low byte, or bits 8..15 for pass 1)
+template <class C, bool FIRST, bool LAST, class KIN = uint32_t, class KOUT = uint32_t>
+__global__ __launch_bounds__(C::TPB) void scatter_kernel(const KIN* __restrict__ keys_in, const uint32_t* __restrict__ pay_in,
+                                                      KOUT* __restrict__ keys_out, uint32_t* __restrict__ pay_out,
                                                       const uint32_t* __restrict__ offsets, float* __restrict__ out, int64_t ldo, int N,
                                                       int64_t M, int nblk, int shift, double denom, uint32_t* __restrict__ status,
                                                       const uint32_t* __restrict__ ghist) {
@@ -289,7 +305,7 @@ __global__ __launch_bounds__(C::TPB) void scatter_kernel(const uint32_t* __restr
   for (int k = 0; k < ITEMS; ++k) {
     const int64_t p = base + wave * WSPAN + k * 64 + lane;
     const bool valid = p < M;
-    key[k] = valid ? keys_in[seg * M + p] : 0xFFFFFFFFu;          // padding: digit 255 in every pass, behind every real key of the tile
+    key[k] = valid ? static_cast<uint32_t>(keys_in[seg * M + p]) : 0xFFFFFFFFu;   // padding: digit 255 in every pass, behind every real key of the tile
     pay[k] = valid ? (FIRST ? static_cast<uint32_t>(p) : pay_in[seg * M + p]) : NO_PAY;
   }
   uint32_t* const status_seg = offsets ? nullptr : status + seg * static_cast<int64_t>(nblk) * 256;
@@ -363,7 +379,7 @@ __global__ __launch_bounds__(C::TPB) void scatter_kernel(const uint32_t* __restr
       o[static_cast<int64_t>(i) * ldo + j] = v;
       o[static_cast<int64_t>(j) * ldo + i] = v;
     } else {
-      keys_out[seg * M + g] = kk;
+      keys_out[seg * M + g] = static_cast<KOUT>(kk >> (8 * (static_cast<int>(sizeof(KIN)) - static_cast<int>(sizeof(KOUT)))));
       pay_out[seg * M + g] = pp;
     }
   }
@@ -387,8 +403,8 @@ __device__ __forceinline__ uint32_t block_base(int bi, int bj, int N) {
   return static_cast<uint32_t>(r0 * (r0 - 1) / 2 + static_cast<int64_t>(bj) * rcount * BB);
 }
 
-template <class C>
-__global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ pay_in,
+template <class C, class KIN>
+__global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const KIN* __restrict__ keys_in, const uint32_t* __restrict__ pay_in,
                                                           const uint32_t* __restrict__ offsets, u32x2* __restrict__ pairs,
                                                           uint32_t* __restrict__ fill, int N, int64_t M, int nblk, int n_blocks,
                                                           uint32_t* __restrict__ status, const uint32_t* __restrict__ ghist) {
@@ -410,12 +426,13 @@ __global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const uint32_t* __r
   for (int k = 0; k < ITEMS; ++k) {
     const int64_t p = base + wave * WSPAN + k * 64 + lane;
     const bool valid = p < M;
-    key[k] = valid ? keys_in[seg * M + p] : 0xFFFFFFFFu;
+    key[k] = valid ? static_cast<uint32_t>(keys_in[seg * M + p]) : 0xFFFFFFFFu;
     pay[k] = valid ? pay_in[seg * M + p] : NO_PAY;
   }
+  constexpr int SH = 8 * (static_cast<int>(sizeof(KIN)) - 1);          // the last digit = the top byte of what is left of the key
   uint32_t* const status_seg = offsets ? nullptr : status + seg * static_cast<int64_t>(nblk) * 256;
   if (!offsets) {                           // (uniform) look-back: see scatter_kernel
-    wave_digit_counts(key, 24, cnt[wave]);
+    wave_digit_counts(key, SH, cnt[wave]);
     __syncthreads();
     if (tid < 256) {
       uint32_t c = 0;
@@ -428,7 +445,7 @@ __global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const uint32_t* __r
     for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
     __syncthreads();
   }
-  wave_digit_ranks<true, ITEMS>(key, 24, cnt[wave], lane, rk);
+  wave_digit_ranks<true, ITEMS>(key, SH, cnt[wave], lane, rk);
   __syncthreads();
   {
     uint32_t run = 0, gh = 0, gh_inc = 0;
@@ -463,7 +480,7 @@ __global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const uint32_t* __r
   for (int k = 0; k < ITEMS; ++k) {
     blk[k] = 0xFFFFFFFFu;
     if (pay[k] == NO_PAY) continue;
-    const uint32_t dg = key[k] >> 24;
+    const uint32_t dg = (key[k] >> SH) & 255u;
     key[k] = gbase[dg] + cnt[wave][dg] + rk[k];
     int i, j;
     tri_decode(pay[k], i, j);
@@ -682,7 +699,6 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
   if (lb) (void)hipMemsetAsync(ws + 4 * kb, 0, 4 * hb + fb + a256(static_cast<size_t>(n_outcomes) * 4 * 256 * 4), st);   // status tables, block fill counters, digit totals
   hipLaunchKernelGGL(extract_keys_kernel<C>, grid, dim3(TPB), 0, st, scores, lds, k0, hist, lb ? ghist : nullptr, static_cast<int>(N), M, nblk);
   for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 8 * pass;
     uint32_t* kin = (pass & 1) ? k1 : k0;
     uint32_t* kout = (pass & 1) ? k0 : k1;
     uint32_t* pin = (pass & 1) ? p1 : p0;
@@ -691,26 +707,39 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
     const uint32_t* offs = lb ? nullptr : hist;
     uint32_t* stat = lb ? status_of(pass) : nullptr;
     const uint32_t* gcur = lb ? ghist_of(pass) : nullptr;
+    // keys narrow as the passes go: pass 0 and 1 read all 32 bits, pass 1 leaves the upper 16, pass 2 the upper 8 (the bits below
+    // the current digit are sorted already): 15 of 96 bytes per key less to move
+    typedef uint16_t u16;
+    typedef uint8_t u8;
     if (!lb) {
-      if (std3) hipLaunchKernelGGL(histogram_kernel<CfgStd>, grid3, dim3(CfgStd::TPB), 0, st, kin, hist, M, nblk3, shift);
-      else if (pass > 0) hipLaunchKernelGGL(histogram_kernel<C>, grid, dim3(TPB), 0, st, kin, hist, M, nblk, shift);
+      if (std3) hipLaunchKernelGGL((histogram_kernel<CfgStd, u8>), grid3, dim3(CfgStd::TPB), 0, st, reinterpret_cast<const u8*>(kin), hist, M, nblk3, 0);
+      else if (pass == 3) hipLaunchKernelGGL((histogram_kernel<C, u8>), grid, dim3(TPB), 0, st, reinterpret_cast<const u8*>(kin), hist, M, nblk, 0);
+      else if (pass == 2) hipLaunchKernelGGL((histogram_kernel<C, u16>), grid, dim3(TPB), 0, st, reinterpret_cast<const u16*>(kin), hist, M, nblk, 0);
+      else if (pass == 1) hipLaunchKernelGGL((histogram_kernel<C, uint32_t>), grid, dim3(TPB), 0, st, kin, hist, M, nblk, 8);
       hipLaunchKernelGGL(scan_kernel, dim3(L), dim3(1024), 0, st, hist, std3 ? nblk3 : nblk);
     }
     if (pass == 0)
-      hipLaunchKernelGGL((scatter_kernel<C, true, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, offs, out, ldo, static_cast<int>(N), M, nblk, shift, denom, stat, gcur);
-    else if (pass == 3 && blocked) {
+      hipLaunchKernelGGL((scatter_kernel<C, true, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, offs, out, ldo, static_cast<int>(N), M, nblk, 0, denom, stat, gcur);
+    else if (pass == 1)
+      hipLaunchKernelGGL((scatter_kernel<C, false, false, uint32_t, u16>), grid, dim3(TPB), 0, st, kin, pin, reinterpret_cast<u16*>(kout), pout, offs, out, ldo,
+                         static_cast<int>(N), M, nblk, 8, denom, stat, gcur);
+    else if (pass == 2)
+      hipLaunchKernelGGL((scatter_kernel<C, false, false, u16, u8>), grid, dim3(TPB), 0, st, reinterpret_cast<const u16*>(kin), pin, reinterpret_cast<u8*>(kout), pout,
+                         offs, out, ldo, static_cast<int>(N), M, nblk, 0, denom, stat, gcur);
+    else if (blocked) {
       if (!lb) (void)hipMemsetAsync(fill, 0, static_cast<size_t>(n_outcomes) * n_blocks * 4, st);
       u32x2* pairs = reinterpret_cast<u32x2*>(k0);            // pass 3 reads k1 / p1
-      hipLaunchKernelGGL(rank_blocks_kernel<CfgStd>, grid3, dim3(CfgStd::TPB), blocks_lds, st, kin, pin, offs, pairs, fill, static_cast<int>(N), M, nblk3, static_cast<int>(n_blocks), stat, gcur);
+      hipLaunchKernelGGL((rank_blocks_kernel<CfgStd, u8>), grid3, dim3(CfgStd::TPB), blocks_lds, st, reinterpret_cast<const u8*>(kin), pin, offs, pairs, fill,
+                         static_cast<int>(N), M, nblk3, static_cast<int>(n_blocks), stat, gcur);
       const dim3 bgrid(static_cast<unsigned>(n_blocks), L);
       if (ldo % 4 == 0 && mdg_aligned16(out))
         hipLaunchKernelGGL(rank_block_write_kernel<true>, bgrid, dim3(512), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
       else
         hipLaunchKernelGGL(rank_block_write_kernel<false>, bgrid, dim3(512), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
-    } else if (pass == 3)
-      hipLaunchKernelGGL((scatter_kernel<C, false, true>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, offs, out, ldo, static_cast<int>(N), M, nblk, shift, denom, stat, gcur);
-    else
-      hipLaunchKernelGGL((scatter_kernel<C, false, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, offs, out, ldo, static_cast<int>(N), M, nblk, shift, denom, stat, gcur);
+    } else {
+      hipLaunchKernelGGL((scatter_kernel<C, false, true, u8, u8>), grid, dim3(TPB), 0, st, reinterpret_cast<const u8*>(kin), pin, reinterpret_cast<u8*>(kout), pout, offs,
+                         out, ldo, static_cast<int>(N), M, nblk, 0, denom, stat, gcur);
+    }
   }
   MDG_CHECK_LAUNCH("mdg_rank_normalize");
   return MDG_OK;
