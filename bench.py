@@ -282,7 +282,7 @@ def cpu_finetune_step(params, batch, bkg, config: str, n_outcomes: int, triples,
             "kg_edges_kept": f"1/{kg_edge_keep}", "loss": float(loss.detach())}
 
 
-def ranks_leg(scores, args):
+def ranks_leg(scores, args, model=None, z=None):
     """The product of the reference's scoring job is the normalised-rank tensor (notebooks/normalize_scores.py:36-85; README.md:43):
     per outcome, the strict lower triangle of the [N,N] score slice ranked (1-based, ascending), divided by N(N-1)/2, mirrored.
     Here: ``ops.rank_normalize`` over the outcomes the headline just scored (HIP events on the launch stream; the sort scratch is
@@ -332,7 +332,31 @@ def ranks_leg(scores, args):
     torch.cuda.synchronize()
     res["ensemble"] = {"seeds": 5, "outcomes": int(ens.shape[0]), "ms": e0.elapsed_time(e1), "ms_per_outcome": e0.elapsed_time(e1) / int(ens.shape[0]),
                        "what": "gmean of 5 normalised-rank tensors then rank_normalize (generate_embeddings.ipynb cells 18-20)"}
-    del ens, out
+    del ens
+    if model is not None and z is not None and L == L_all:
+        # the same product without the score tensor: the head writes the order keys of the strict lower triangle only (EPI_TRIKEYS: half
+        # the store stream) into the rank tensor's own memory and the sort puts the ranks over them (pipeline.rank_all_pairs)
+        from madrigal_amd import models as M
+        from madrigal_amd.pipeline import rank_all_pairs
+        ref = out[:2].clone()
+        with torch.no_grad(), M.precision(args.precision):
+            dec = model.decoder
+            keys = out.view(torch.int32)
+            dec(z, z, (0, 2), epilogue=ops.EPI_TRIKEYS, out=keys[:2])          # warm-up
+            torch.cuda.synchronize()
+            ek = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ek[0].record()
+            dec(z, z, (0, L), epilogue=ops.EPI_TRIKEYS, out=keys)
+            ek[1].record()
+            got = ops.rank_normalize(keys)
+            ek[2].record()
+            torch.cuda.synchronize()
+        res["from_head_keys"] = {"head_keys_ms": ek[0].elapsed_time(ek[1]), "ranks_ms": ek[1].elapsed_time(ek[2]),
+                                 "ms_per_outcome_head_plus_ranks": ek[0].elapsed_time(ek[2]) / L,
+                                 "equal_to_ranks_of_materialised_scores": bool(torch.equal(got[:2], ref)),
+                                 "what": "head with the lower-triangle-keys epilogue (half the store stream, no score tensor) + rank_normalize over the keys in place"}
+        del got, keys, ref
+    del out
     if not args.no_cpu_baseline:
         try:
             import multiprocessing as mp
@@ -750,6 +774,7 @@ def main():
                "phases_ms_per_rank": {"columns": ["encode_fuse_own_block", "all_gather_z", "head_own_outcomes"], "rows": per_rank}}
         if keep_scores:
             res["scores"] = out
+            res["z"] = z
         else:
             del out
         torch.cuda.empty_cache()
@@ -761,10 +786,11 @@ def main():
     ranks = None
     if want_ranks:
         try:
-            ranks = ranks_leg(h.pop("scores"), args)
+            ranks = ranks_leg(h.pop("scores"), args, None if args.head_only else model, h.pop("z", None))
         except Exception as e:
             ranks = {"metric": "rank-normalised scores/sec", "value": None, "error": f"{type(e).__name__}: {e}"[:400]}
         h.pop("scores", None)
+        h.pop("z", None)
         torch.cuda.empty_cache()
     other = headline("weak" if main_mode == "strong" else "strong") if world > 1 else None
 

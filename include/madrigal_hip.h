@@ -49,8 +49,15 @@ enum mdg_precision {
 enum mdg_bilinear_epilogue {
   MDG_EPI_STORE = 0,         /* out[l,i,j] = S            (raw logits, as the reference returns) */
   MDG_EPI_STORE_SIGMOID = 1, /* out[l,i,j] = sigmoid(S)   (train_ddi_batch.py:285)               */
-  MDG_EPI_ROWSTATS = 2       /* nothing is materialised: stats[l,i,0] = sum_j S, stats[l,i,1] =
+  MDG_EPI_ROWSTATS = 2,      /* nothing is materialised: stats[l,i,0] = sum_j S, stats[l,i,1] =
                                 max_j S (roofline stress runs whose [L,N,N] cannot exist)        */
+  MDG_EPI_TRIKEYS = 3        /* for callers whose product is ranks (notebooks/normalize_scores.py:36-85 reads
+                                the strict lower triangle only): out[l,i,j] for j < i = the order-preserving
+                                uint32 key of S[l,i,j] (the bits mdg_rank_normalize sorts), the same value the
+                                STORE epilogue puts there; entries with j >= i are unspecified (never written
+                                outside the 256 x 256 blocks on the diagonal): half the store stream.
+                                Symmetric sweep only (z_head == z_tail, symmetric W, row pitch >= n rounded
+                                up to 4); consumed by mdg_rank_normalize_keys_ld.                          */
 };
 
 /* Activation fused into mdg_linear's epilogue (madrigal/models/models.py:31, actn2actfunc). */
@@ -250,6 +257,11 @@ int mdg_rank_normalize(const float* scores, float* out, int64_t n_outcomes, int6
 /* The same on row-pitched tensors (mdg_bilinear_allpairs_ld): scores[(l * N + i) * lds + j], out[(l * N + i) * ldo + j]. */
 int mdg_rank_normalize_ld(const float* scores, int64_t lds, float* out, int64_t ldo, int64_t n_outcomes, int64_t N, void* workspace,
                           size_t workspace_bytes, void* stream);
+/* The same from the order keys of the strict lower triangle as mdg_bilinear_allpairs_ld(..., MDG_EPI_TRIKEYS) writes them
+ * (keys[(l * N + i) * ldk + j] for j < i; nothing else of `keys` is read): the head's store stream is halved and the
+ * ranks equal those of the materialised scores bit for bit.  out may be the memory of keys (n_outcomes of one call). */
+int mdg_rank_normalize_keys_ld(const uint32_t* keys, int64_t ldk, float* out, int64_t ldo, int64_t n_outcomes, int64_t N,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* Elementwise geometric mean of K <= 8 equally shaped fp32 tensors (the 5-seed ensembling of normalised ranks,
  * scipy.stats.mstats.gmean in notebooks/generate_embeddings.ipynb): out = exp(mean_k log x_k) in fp32; 0 where any

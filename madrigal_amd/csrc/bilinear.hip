@@ -903,7 +903,10 @@ template <int MODE, int EPI, int NW, int SC1 = 0>
 __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_sym_kernel(const BilinearArgs p) {
   static_assert(NW == 8, "256-row blocks: 8 waves of 32 rows");
   constexpr int AUX = SC1 ? 16 : 0;                     // gfx940+ cache-policy immediate: bit 4 = sc1
-  static_assert(EPI == MDG_EPI_STORE || EPI == MDG_EPI_STORE_SIGMOID, "materialising epilogues only");
+  static_assert(EPI == MDG_EPI_STORE || EPI == MDG_EPI_STORE_SIGMOID || EPI == MDG_EPI_TRIKEYS, "materialising epilogues only");
+  // TRIKEYS: the sort keys of the strict lower triangle.  A tile right of the diagonal block leaves through its mirrored stores only
+  // (those ARE the lower triangle); the diagonal block is written in full, its upper half is ignored by the reader
+  constexpr bool TRI = (EPI == MDG_EPI_TRIKEYS);
   constexpr int BM = 32 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const buf0 = smem;
@@ -933,6 +936,9 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_sym_kernel(const
       y[0] = 1.0f / (1.0f + expf(-x[0])); y[1] = 1.0f / (1.0f + expf(-x[1]));
       y[2] = 1.0f / (1.0f + expf(-x[2])); y[3] = 1.0f / (1.0f + expf(-x[3]));
       return __builtin_bit_cast(u32x4, y);
+    } else if constexpr (TRI) {
+      const f32x4 x = __builtin_bit_cast(f32x4, v);
+      return u32x4{mdg_order_key(x[0]), mdg_order_key(x[1]), mdg_order_key(x[2]), mdg_order_key(x[3])};
     } else {
       return v;
     }
@@ -993,10 +999,10 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_sym_kernel(const
     const int64_t slab_rows = (N - row0) < BM ? (N - row0) : BM;
     const __amdgpu_buffer_rsrc_t rs_rows = __builtin_amdgcn_make_buffer_rsrc(out_l + row0 * ld, 0, static_cast<int>(slab_rows * ld * 4), 0x00020000);
     u32x4 o[8];
-    auto store_rows = [&](int q, int64_t col0) {                      // rows 4q..4q+3 of the wave's tile: 4 x 256 B
+    auto store_rows = [&](int q, int64_t col0, bool on) {             // rows 4q..4q+3 of the wave's tile: 4 x 256 B
       const int64_t col = col0 + scol;
       const int64_t e = static_cast<int64_t>(wave * 32 + 4 * q + srow) * ld + col;
-      const unsigned off = col < N4 ? static_cast<unsigned>(e * 4) : 0xFFFFFFFFu;             // out of range => dropped
+      const unsigned off = (on && col < N4) ? static_cast<unsigned>(e * 4) : 0xFFFFFFFFu;     // out of range => dropped
       __builtin_amdgcn_raw_buffer_store_b128(sig(o[q]), rs_rows, off, 0, AUX);
     };
     auto store_mirror = [&](int q, int64_t col0, bool on) {           // tile columns 8q..8q+7 as rows of the mirrored block: 8 x 128 B
@@ -1007,6 +1013,8 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_sym_kernel(const
     stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(0)) * BN, buf0, wave, lane, NW);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int64_t prev_col0 = N;                                            // first stage: the slab is empty, 8 dropped stores
+    bool prev_rows = true;                                            // TRIKEYS: the previous tile has row stores (diagonal block)
+    bool stage_rows = true;                                           // ... and the last stage issued them
     // Per stage and wave the vector-memory stream is [LDS-DMA of tile s+1][8 row stores of tile s-1][8 mirrored stores of
     // tile s]: `s_waitcnt vmcnt(16)` at the top of the next stage retires the DMA and leaves 16 stores in flight (loads,
     // stores -- dropped ones included -- and LDS-DMA retire in issue order; exactly 16 stores per wave and stage).
@@ -1015,14 +1023,19 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_sym_kernel(const
       const int64_t tcol0 = static_cast<int64_t>(tile) * BN;
       char* const cur = (s & 1) ? buf1 : buf0;
       char* const nxt = (s & 1) ? buf0 : buf1;
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      // TRIKEYS: a stage whose previous tile lies right of the diagonal block has no row stores at all (8 stores per wave, not 16)
+      if (TRI && !stage_rows) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       stage_dma<MODE>(p.zt, static_cast<int64_t>(tile_of(s + 1 < nt ? s + 1 : s)) * BN, nxt, wave, lane, NW);
       const int64_t pc0 = prev_col0;
       const bool mirror = tile >= t_diag_end;
+      const bool pr = prev_rows;
+      stage_rows = pr;
       auto hook = [&](int k) {
+        if (TRI && !pr) return;
         if (k < 8) o[k] = *reinterpret_cast<const u32x4*>(stg + (4 * k + srow) * 256 + scol * 4);
-        else if (k >= 16 && (k & 1) == 0) store_rows((k - 16) >> 1, pc0);
+        else if (k >= 16 && (k & 1) == 0) store_rows((k - 16) >> 1, pc0, true);
       };
       if constexpr (M16) {
         f32x4v acc[2][4];
@@ -1042,13 +1055,15 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_sym_kernel(const
 #pragma unroll
         for (int q = 0; q < 8; ++q) store_mirror(q, tcol0, mirror);
         // tile s, row-major, for the row stores of the next stage (the reads above are older LDS operations of this wave)
+        if (!TRI || !mirror) {
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+          for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              *reinterpret_cast<float*>(stg + (16 * rt + 4 * g4 + i) * 256 + (16 * ct + c16) * 4) = acc[rt][ct][i];
+              for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<float*>(stg + (16 * rt + 4 * g4 + i) * 256 + (16 * ct + c16) * 4) = acc[rt][ct][i];
+        }
       } else {
         f32x16 acc[2];
 #pragma unroll
@@ -1067,18 +1082,23 @@ __global__ __launch_bounds__(64 * NW, 2) void bilinear_allpairs_sym_kernel(const
         for (int q = 0; q < 8; ++q) o[q] = *reinterpret_cast<const u32x4*>(stg + (8 * q + mrow) * 128 + mchunk * 16);
 #pragma unroll
         for (int q = 0; q < 8; ++q) store_mirror(q, tcol0, mirror);
+        if (!TRI || !mirror) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int v = 0; v < 16; ++v)
-            *reinterpret_cast<float*>(stg + acc_row(v, h) * 256 + (32 * t + r) * 4) = acc[t][v];
+            for (int v = 0; v < 16; ++v)
+              *reinterpret_cast<float*>(stg + acc_row(v, h) * 256 + (32 * t + r) * 4) = acc[t][v];
+        }
       }
       prev_col0 = tcol0;
+      if constexpr (TRI) prev_rows = !mirror;
     }
+    if (!TRI || prev_rows) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) o[q] = *reinterpret_cast<const u32x4*>(stg + (4 * q + srow) * 256 + scol * 4);
+      for (int q = 0; q < 8; ++q) o[q] = *reinterpret_cast<const u32x4*>(stg + (4 * q + srow) * 256 + scol * 4);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) store_rows(q, prev_col0);
+      for (int q = 0; q < 8; ++q) store_rows(q, prev_col0, true);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                  // the next row block's prologue reuses the stage buffers
   }
@@ -1200,8 +1220,22 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
   if constexpr (NW == 8) {
     static MdgEnvInt sym_sw{"MDG_BILINEAR_SYMMETRIC", 1};
     const bool want = sym_sw.get() != 0;
+    if (epilogue == MDG_EPI_TRIKEYS) {        // keys of the lower triangle: a product of the symmetric sweep only
+      MDG_CHECK_ARG(a.symmetric, "mdg_bilinear_allpairs: MDG_EPI_TRIKEYS needs z_head == z_tail (one drug set against itself)");
+      MDG_CHECK_ARG((a.ldo & 3) == 0 && a.ldo >= ((a.n_tail + 3) & ~static_cast<int64_t>(3)) && a.n_tail * a.ldo * 4 < (int64_t(1) << 32),
+                    "mdg_bilinear_allpairs: MDG_EPI_TRIKEYS needs a row pitch that is a multiple of 4 >= n_tail and n_tail * pitch < 2^30 (got %lld, %lld)",
+                    (long long)a.n_tail, (long long)a.ldo);
+      const int nb = static_cast<int>(mdg_cdiv(a.n_tail, 256));
+      const dim3 gsym(static_cast<unsigned>((nb + 1) / 2), static_cast<unsigned>(a.n_labels));
+      static MdgEnvInt sc1k_sw{"MDG_BILINEAR_SC1", -1};
+      const bool sc1 = sc1k_sw.get() >= 0 ? sc1k_sw.get() != 0 : (MODE == MDG_PREC_BF16X3);
+      if (sc1) hipLaunchKernelGGL((bilinear_allpairs_sym_kernel<MODE, MDG_EPI_TRIKEYS, 8, 1>), gsym, block, lds2, st, a);
+      else hipLaunchKernelGGL((bilinear_allpairs_sym_kernel<MODE, MDG_EPI_TRIKEYS, 8, 0>), gsym, block, lds2, st, a);
+      MDG_CHECK_LAUNCH("mdg_bilinear_allpairs(lower-triangle keys)");
+      return MDG_OK;
+    }
     if (want && a.symmetric && a.pipeline == 0 && (epilogue == MDG_EPI_STORE || epilogue == MDG_EPI_STORE_SIGMOID) &&
-        a.n_tail * a.ldo * 4 < (int64_t(1) << 32) && a.n_tail > 256) {
+        a.n_tail * a.ldo * 4 < (int64_t(1) << 32)) {
       const int nb = static_cast<int>(mdg_cdiv(a.n_tail, 256));
       const dim3 gsym(static_cast<unsigned>((nb + 1) / 2), static_cast<unsigned>(a.n_labels));
       // write-through score stores keep z_tail L2-resident (FETCH 11.3 -> 0.8 GB per launch at 4096^2 x 896); measured faster for
@@ -1275,7 +1309,7 @@ template <int MODE>
 int launch_allpairs(const BilinearArgs& a, int epilogue, hipStream_t st) {
   static MdgEnvInt nw_sw{"MDG_BILINEAR_WAVES", 8};
   const int nw = nw_sw.get();
-  if (nw == 8) return launch_allpairs_nw<MODE, 8>(a, epilogue, st);
+  if (nw == 8 || epilogue == MDG_EPI_TRIKEYS) return launch_allpairs_nw<MODE, 8>(a, epilogue, st);
   return launch_allpairs_nw<MODE, 4>(a, epilogue, st);
 }
 

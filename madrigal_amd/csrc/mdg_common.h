@@ -63,6 +63,13 @@ __device__ __forceinline__ float mdg_sigmoid(float x) { return 1.0f / (1.0f + __
 
 __device__ __forceinline__ float mdg_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
+// order-preserving 32-bit key of an fp32 score (ascending unsigned order = ascending float order; -0 < +0): the rank
+// normalisation sorts these, and the all-pairs head can write them instead of the scores (MDG_EPI_TRIKEYS)
+__device__ __forceinline__ uint32_t mdg_order_key(float f) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
 // counter-based random bits (splitmix64 finaliser, high word): dropout masks are a pure function of (seed, index),
 // so the backward pass regenerates them instead of storing them.
 __device__ __forceinline__ uint32_t mdg_mix32(uint64_t z) {

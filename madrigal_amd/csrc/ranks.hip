@@ -37,11 +37,6 @@ using CfgStd = RankCfg<512, 16>;
 #define MDG_RANK_USING(C) constexpr int TPB = C::TPB, ITEMS = C::ITEMS, WAVES = C::WAVES, TILE = C::TILE, WSPAN = C::WSPAN; (void)TPB; (void)ITEMS; (void)WAVES; (void)TILE; (void)WSPAN
 constexpr uint32_t NO_PAY = 0xFFFFFFFFu;   // payload of the padding behind the last key of the last tile
 
-__device__ __forceinline__ uint32_t order_key(float f) {
-  const uint32_t u = __builtin_bit_cast(uint32_t, f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
 // p -> (i, j) with i > j, p = i(i-1)/2 + j
 __device__ __forceinline__ void tri_decode(int64_t p, int& i, int& j) {
   int64_t r = static_cast<int64_t>((1.0 + sqrt(1.0 + 8.0 * static_cast<double>(p))) * 0.5);
@@ -118,7 +113,8 @@ __device__ __forceinline__ void store_tile_histogram(const uint32_t (*cnt)[256],
 // keys of the strict lower triangle in p order + the tile histogram of the lowest digit
 template <class C>
 __global__ __launch_bounds__(C::TPB) void extract_keys_kernel(const float* __restrict__ scores, int64_t lds, uint32_t* __restrict__ keys,
-                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ ghist, int N, int64_t M, int nblk) {
+                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ ghist, int N, int64_t M, int nblk,
+                                                           int src_is_keys) {
   MDG_RANK_USING(C);
   __shared__ uint32_t cnt[WAVES][256];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -142,7 +138,8 @@ __global__ __launch_bounds__(C::TPB) void extract_keys_kernel(const float* __res
     int i = wi, j = wj + lane;                             // row i holds i entries
     while (j >= i) { j -= i; ++i; }
     if (p < M) {
-      key[k] = order_key(sc[static_cast<int64_t>(i) * lds + j]);
+      const float v = sc[static_cast<int64_t>(i) * lds + j];
+      key[k] = src_is_keys ? __builtin_bit_cast(uint32_t, v) : mdg_order_key(v);      // MDG_EPI_TRIKEYS wrote the keys themselves
       keys[seg * M + p] = key[k];
     }
     wj += 64;                                              // the wave's next 64 positions (wave-uniform walk)
@@ -658,7 +655,7 @@ extern "C" int mdg_rank_normalize(const float* scores, float* out, int64_t n_out
 
 template <class C>
 static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int64_t ldo, int64_t n_outcomes, int64_t N, void* workspace,
-                               size_t workspace_bytes, hipStream_t st) {
+                               size_t workspace_bytes, hipStream_t st, int src_is_keys) {
   constexpr int TPB = C::TPB, TILE = C::TILE;
   const unsigned L = static_cast<unsigned>(n_outcomes);
   const int64_t M = N * (N - 1) / 2;
@@ -697,7 +694,7 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
   const auto status_of = [&](int pass) { return reinterpret_cast<uint32_t*>(ws + 4 * kb + pass * hb); };
   const auto ghist_of = [&](int pass) { return ghist + static_cast<size_t>(pass) * n_outcomes * 256; };
   if (lb) (void)hipMemsetAsync(ws + 4 * kb, 0, 4 * hb + fb + a256(static_cast<size_t>(n_outcomes) * 4 * 256 * 4), st);   // status tables, block fill counters, digit totals
-  hipLaunchKernelGGL(extract_keys_kernel<C>, grid, dim3(TPB), 0, st, scores, lds, k0, hist, lb ? ghist : nullptr, static_cast<int>(N), M, nblk);
+  hipLaunchKernelGGL(extract_keys_kernel<C>, grid, dim3(TPB), 0, st, scores, lds, k0, hist, lb ? ghist : nullptr, static_cast<int>(N), M, nblk, src_is_keys);
   for (int pass = 0; pass < 4; ++pass) {
     uint32_t* kin = (pass & 1) ? k1 : k0;
     uint32_t* kout = (pass & 1) ? k0 : k1;
@@ -745,17 +742,29 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
   return MDG_OK;
 }
 
-extern "C" int mdg_rank_normalize_ld(const float* scores, int64_t lds, float* out, int64_t ldo, int64_t n_outcomes, int64_t N, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
+static int rank_normalize_entry(const float* src, int64_t lds, float* out, int64_t ldo, int64_t n_outcomes, int64_t N, void* workspace,
+                                size_t workspace_bytes, void* stream, int src_is_keys) {
   MDG_CHECK_ARG(lds >= N && ldo >= N, "mdg_rank_normalize: row pitches must be >= N");
   MDG_CHECK_ARG(n_outcomes >= 0 && N >= 0 && N <= 65535 && n_outcomes <= 65535, "mdg_rank_normalize: bad sizes (outcomes per call and N <= 65535)");
   if (n_outcomes == 0 || N == 0) return MDG_OK;
-  MDG_CHECK_ARG(scores && out, "mdg_rank_normalize: null pointer");
+  MDG_CHECK_ARG(src && out, "mdg_rank_normalize: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(zero_diag_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N, 256)), static_cast<unsigned>(n_outcomes)), dim3(256), 0, st, out, ldo, static_cast<int>(N));
   if (N < 2) { MDG_CHECK_LAUNCH("mdg_rank_normalize"); return MDG_OK; }
-  return rank_use_big(N) ? rank_normalize_impl<CfgBig>(scores, lds, out, ldo, n_outcomes, N, workspace, workspace_bytes, st)
-                         : rank_normalize_impl<CfgStd>(scores, lds, out, ldo, n_outcomes, N, workspace, workspace_bytes, st);
+  return rank_use_big(N) ? rank_normalize_impl<CfgBig>(src, lds, out, ldo, n_outcomes, N, workspace, workspace_bytes, st, src_is_keys)
+                         : rank_normalize_impl<CfgStd>(src, lds, out, ldo, n_outcomes, N, workspace, workspace_bytes, st, src_is_keys);
+}
+
+extern "C" int mdg_rank_normalize_ld(const float* scores, int64_t lds, float* out, int64_t ldo, int64_t n_outcomes, int64_t N, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  return rank_normalize_entry(scores, lds, out, ldo, n_outcomes, N, workspace, workspace_bytes, stream, 0);
+}
+
+// the strict lower triangle of `keys` [n_outcomes, N, ldk] holds the order keys of the scores (mdg_bilinear_allpairs_ld with
+// MDG_EPI_TRIKEYS); the rest of the tensor is never read.  out may be the same memory (the keys leave in the first kernel).
+extern "C" int mdg_rank_normalize_keys_ld(const uint32_t* keys, int64_t ldk, float* out, int64_t ldo, int64_t n_outcomes, int64_t N, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  return rank_normalize_entry(reinterpret_cast<const float*>(keys), ldk, out, ldo, n_outcomes, N, workspace, workspace_bytes, stream, 1);
 }
 
 extern "C" int mdg_gmean(const float* const* inputs_host, int K, float* out, int64_t n, void* stream) {

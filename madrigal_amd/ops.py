@@ -16,7 +16,7 @@ from ._lib import check, lib
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
 PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 HEAD_PRECISIONS = dict(PRECISIONS, f16=PREC_F16)          # the all-pairs head also runs on the fp16 matrix cores
-EPI_STORE, EPI_STORE_SIGMOID, EPI_ROWSTATS = 0, 1, 2
+EPI_STORE, EPI_STORE_SIGMOID, EPI_ROWSTATS, EPI_TRIKEYS = 0, 1, 2, 3
 
 _c64 = ctypes.c_int64
 _vp = ctypes.c_void_p
@@ -86,7 +86,11 @@ def symmetrize(w_original: torch.Tensor, out: Optional[torch.Tensor] = None) -> 
 def bilinear_allpairs(z_head: torch.Tensor, z_tail: torch.Tensor, w_sym: torch.Tensor, *, precision="bf16x3",
                       epilogue: int = EPI_STORE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """All-pairs scores S[l,i,j] = z_head[i]^T W_sym[l] z_tail[j]  -> [L,Nh,Nt] fp32
-    (or [L,Nh,2] row statistics with ``EPI_ROWSTATS``).  madrigal/models/models.py:537-547."""
+    (or [L,Nh,2] row statistics with ``EPI_ROWSTATS``).  madrigal/models/models.py:537-547.
+
+    ``EPI_TRIKEYS`` (one drug set against itself, ``z_head is z_tail``): an int32 tensor whose strict lower triangle holds the
+    order keys of the scores, for ``rank_normalize`` (which reads nothing else); everything above the diagonal blocks is left
+    unwritten -- half the store stream of ``EPI_STORE``."""
     zh, zt, w = _f32_cuda(z_head, "z_head", 2), _f32_cuda(z_tail, "z_tail", 2), _f32_cuda(w_sym, "w_sym", 3)
     D = zh.shape[1]
     if zt.shape[1] != D or w.shape[1] != D or w.shape[2] != D:
@@ -95,11 +99,12 @@ def bilinear_allpairs(z_head: torch.Tensor, z_tail: torch.Tensor, w_sym: torch.T
         raise ValueError("z_head, z_tail and w_sym must be on the same device")
     L, Nh, Nt = w.shape[0], zh.shape[0], zt.shape[0]
     shape = (L, Nh, 2) if epilogue == EPI_ROWSTATS else (L, Nh, Nt)
+    out_dtype = torch.int32 if epilogue == EPI_TRIKEYS else torch.float32
     if out is None:
-        out = torch.empty(shape, dtype=torch.float32, device=zh.device)
+        out = empty_scores(L, Nh, Nt, zh.device).view(torch.int32) if epilogue == EPI_TRIKEYS else torch.empty(shape, dtype=torch.float32, device=zh.device)
     else:
-        if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.float32):
-            raise ValueError("out: expected a float32 GPU tensor")
+        if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == out_dtype):
+            raise ValueError(f"out: expected a {out_dtype} GPU tensor")
         # contiguous, or a view of row-padded storage (empty_scores): unit inner stride and one pitch for every row
         if tuple(out.shape) != shape or (out.numel() and (out.stride(2) != 1 or out.stride(1) < shape[2] or out.stride(0) != shape[1] * out.stride(1))):
             raise ValueError(f"out: expected {shape}, contiguous or row-pitched (empty_scores), got {tuple(out.shape)} strides {tuple(out.stride())}")
@@ -647,28 +652,42 @@ def _scores3(t: torch.Tensor, name: str) -> torch.Tensor:
 def rank_normalize(scores: torch.Tensor, out: Optional[torch.Tensor] = None, max_workspace_bytes: int = 8 << 30) -> torch.Tensor:
     """Normalised ranks per outcome (notebooks/normalize_scores.py:36-74): [L,N,N] fp32 -> [L,N,N] fp32.
     Outcomes are processed in chunks sized to ``max_workspace_bytes`` of sort scratch.  ``scores`` / ``out`` may be row-pitched
-    (``empty_scores``); without ``out`` the result has the layout of ``scores``."""
-    s = _scores3(scores, "scores")
+    (``empty_scores``); without ``out`` the result has the layout of ``scores``.
+
+    ``scores`` of dtype int32 = the lower-triangle order keys of ``bilinear_allpairs(..., epilogue=EPI_TRIKEYS)``: same ranks,
+    and without ``out`` they are written over the keys (the returned fp32 tensor shares the keys' memory)."""
+    from_keys = isinstance(scores, torch.Tensor) and scores.dtype == torch.int32
+    if from_keys:
+        if not (scores.is_cuda and scores.dim() == 3 and (scores.numel() == 0 or (scores.stride(2) == 1 and scores.stride(1) >= scores.shape[2]
+                                                                                  and scores.stride(0) == scores.shape[1] * scores.stride(1)))):
+            raise ValueError("keys: expected the int32 GPU tensor bilinear_allpairs(..., epilogue=EPI_TRIKEYS) returned")
+        s = scores.view(torch.float32)
+    else:
+        s = _scores3(scores, "scores")
     L, N, N2 = s.shape
     if N != N2:
         raise ValueError("scores: expected [L,N,N]")
     if out is None:
-        out = empty_scores(L, N, N, s.device) if (N and s.stride(1) != N) else torch.empty((L, N, N), dtype=torch.float32, device=s.device)
+        if from_keys:
+            out = s
+        else:
+            out = empty_scores(L, N, N, s.device) if (N and s.stride(1) != N) else torch.empty((L, N, N), dtype=torch.float32, device=s.device)
     else:
         o2 = _scores3(out, "out")
-        if o2 is not out or out.shape != s.shape or out.data_ptr() == s.data_ptr():
+        if o2 is not out or out.shape != s.shape or (out.data_ptr() == s.data_ptr() and not from_keys):
             raise ValueError("out: an fp32 GPU tensor of the shape of scores (contiguous or row-pitched), not aliasing it")
     if L == 0 or N == 0:
         return out
     lb = lib()
+    entry = lb.mdg_rank_normalize_keys_ld if from_keys else lb.mdg_rank_normalize_ld
     per = max(lb.mdg_rank_normalize_workspace_bytes(_c64(1), _c64(N)), 1)
     chunk = int(max(1, min(L, 65535, max_workspace_bytes // per)))
     for lo in range(0, L, chunk):
         hi = min(L, lo + chunk)
         nbytes = lb.mdg_rank_normalize_workspace_bytes(_c64(hi - lo), _c64(N))
         ws = _workspace(nbytes, s.device)
-        check(lb.mdg_rank_normalize_ld(_vp(s.data_ptr() + lo * s.stride(0) * 4), _c64(s.stride(1)), _vp(out.data_ptr() + lo * out.stride(0) * 4),
-                                       _c64(out.stride(1)), _c64(hi - lo), _c64(N), _ptr(ws), ctypes.c_size_t(nbytes), _stream(s)), "mdg_rank_normalize")
+        check(entry(_vp(s.data_ptr() + lo * s.stride(0) * 4), _c64(s.stride(1)), _vp(out.data_ptr() + lo * out.stride(0) * 4),
+                    _c64(out.stride(1)), _c64(hi - lo), _c64(N), _ptr(ws), ctypes.c_size_t(nbytes), _stream(s)), "mdg_rank_normalize")
     return out
 
 

@@ -122,3 +122,23 @@ def score_all_pairs(model, z: torch.Tensor, label_range: Optional[Tuple[int, int
             ps, pe = pending[b]
             out[ps - lo:pe - lo] = pin_buf[b][: pe - ps].numpy()
     return out
+
+
+@torch.no_grad()
+def rank_all_pairs(model, z: torch.Tensor, label_range: Optional[Tuple[int, int]] = None, out: Optional[torch.Tensor] = None,
+                   max_workspace_bytes: int = 8 << 30) -> torch.Tensor:
+    """Normalised ranks of every drug pair per outcome -> [L',N,N] fp32, for callers whose product is the ranks (the reference
+    materialises the raw scores into a memmap, predict.py:410-429, and ranks them afterwards on the CPU, notebooks/normalize_scores.py:
+    36-85).  The head writes only the order keys of the strict lower triangle -- all the rank normalisation reads -- and the sort puts
+    the ranks over them: half the head's store stream and no score tensor next to the rank tensor.  Bit-identical to
+    ``ops.rank_normalize(score_all_pairs(...))``."""
+    dec = model.decoder
+    L_all = dec.parametrizations.weight.original.shape[0] if hasattr(dec, "parametrizations") else dec.weight.shape[0]
+    lo, hi = (0, L_all) if label_range is None else label_range
+    N = z.shape[0]
+    if out is None:
+        out = ops.empty_scores(hi - lo, N, N, z.device)
+    elif not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == (hi - lo, N, N)):
+        raise ValueError(f"out: expected a float32 GPU tensor of shape {(hi - lo, N, N)} (ops.empty_scores)")
+    keys = dec(z, z, (lo, hi), epilogue=ops.EPI_TRIKEYS, out=out.view(torch.int32))
+    return ops.rank_normalize(keys, max_workspace_bytes=max_workspace_bytes)

@@ -79,6 +79,69 @@ def test_ranks_golden_bit_exact(ops, golden):
     assert np.array_equal(out, g["normalized"])                      # rank ordering and fp32 values bit exact
 
 
+def _order_keys(x: np.ndarray) -> np.ndarray:
+    """The radix key of an fp32 score (ascending unsigned = ascending float), as int32 bits."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    return np.where(u & np.uint32(0x80000000), ~u, u | np.uint32(0x80000000)).astype(np.uint32).view(np.int32)
+
+
+def test_ranks_from_lower_triangle_keys_golden_bit_exact(ops, golden):
+    """The key entry (what the head's EPI_TRIKEYS epilogue feeds): keys of the reference fixture's scores in the strict lower
+    triangle, garbage everywhere else (never read) -> the fixture's normalised ranks, written over the keys."""
+    g = golden("ranks")
+    sc = g["scores"]
+    L, N, _ = sc.shape
+    keys = _order_keys(sc).reshape(L, N, N).copy()
+    iu = np.triu_indices(N)
+    keys[:, iu[0], iu[1]] = np.random.default_rng(0).integers(-2 ** 31, 2 ** 31 - 1, size=(L, iu[0].size), dtype=np.int64).astype(np.int32)
+    dev = ops.empty_scores(L, N, N, "cuda").view(torch.int32)
+    dev.copy_(torch.from_numpy(keys))
+    out = ops.rank_normalize(dev)
+    assert out.dtype == torch.float32 and out.data_ptr() == dev.data_ptr()
+    assert np.array_equal(out.cpu().numpy(), g["normalized"])
+    out2 = torch.empty(L, N, N, device="cuda")
+    dev.copy_(torch.from_numpy(keys))
+    ops.rank_normalize(dev, out=out2)
+    assert np.array_equal(out2.cpu().numpy(), g["normalized"])
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "f32", "bf16"])
+@pytest.mark.parametrize("N,L", [(300, 3), (130, 2), (1001, 2), (2048, 1)])
+def test_head_lower_triangle_keys_rank_like_the_materialised_scores(ops, N, L, prec):
+    """EPI_TRIKEYS: the head writes the order keys of the strict lower triangle only; they are the keys of the scores EPI_STORE puts
+    there, and the ranks from them equal the ranks of the materialised scores and of the oracle on those scores, bit for bit."""
+    from oracle import madrigal_oracle as O
+    gen = torch.Generator().manual_seed(N + L)
+    z = torch.randn(N, 128, generator=gen).cuda()
+    w = torch.randn(L, 128, 128, generator=gen) / 128 ** 0.5
+    w = (0.5 * (w + w.transpose(1, 2))).contiguous().cuda()
+    scores = ops.bilinear_allpairs(z, z, w, precision=prec, out=ops.empty_scores(L, N, N, "cuda"))
+    keys = ops.bilinear_allpairs(z, z, w, precision=prec, epilogue=ops.EPI_TRIKEYS)
+    assert keys.dtype == torch.int32 and keys.shape == (L, N, N)
+    il = np.tril_indices(N, k=-1)
+    sc = scores.cpu().numpy()
+    assert np.array_equal(keys.cpu().numpy()[:, il[0], il[1]], _order_keys(sc[:, il[0], il[1]]))
+    want = ops.rank_normalize(scores).cpu().numpy()
+    got = ops.rank_normalize(keys)
+    assert got.data_ptr() == keys.data_ptr()
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(want, O.rank_normalize(sc))
+    with pytest.raises(ValueError):                                   # two different drug sets have no triangle
+        ops.bilinear_allpairs(z, z.clone(), w, precision=prec, epilogue=ops.EPI_TRIKEYS)
+
+
+def test_rank_all_pairs_equals_ranks_of_score_all_pairs():
+    from madrigal_amd import models as M, ops as _ops
+    from madrigal_amd.pipeline import rank_all_pairs, score_all_pairs
+    from test_pipeline_gpu import _Scorer
+    model = _Scorer(M, 9, 3).cuda().eval()
+    z = torch.randn(771, 128, generator=torch.Generator().manual_seed(5)).cuda()
+    with M.precision("bf16x3"):
+        want = _ops.rank_normalize(score_all_pairs(model, z, (2, 8)))
+        got = rank_all_pairs(model, z, (2, 8))
+    assert got.shape == (6, 771, 771) and torch.equal(got, want)
+
+
 @pytest.mark.parametrize("path", ["default", "tile8192", "direct", "lookback"])
 @pytest.mark.parametrize("N,L", [(300, 5), (2, 3), (1, 2), (97, 1), (1025, 2), (1283, 1)])
 def test_ranks_vs_oracle(ops, monkeypatch, N, L, path):
