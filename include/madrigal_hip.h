@@ -342,6 +342,12 @@ int mdg_adamw_multi(const int64_t* chunk_ptrs, const int32_t* chunk_lens, const 
 size_t mdg_grad_weight_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int mdg_grad_weight(const float* g, int64_t ldg, const float* x, int64_t ldx, float* dw, float* dbias, int64_t M, int64_t N,
                     int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+/* The same in the arithmetic mode of the step's dense blocks.  MDG_PREC_F32: the exact kernel above.  MDG_PREC_BF16 / BF16X3 (N, K, ldg,
+ * ldx multiples of 4, 16-byte aligned operands; anything else takes the exact kernel): g and x rounded to bf16 (bf16x3: split hi + lo,
+ * three products) while they are staged, fp32 accumulation on v_mfma_f32_16x16x32_bf16 -- what mdg_linear_tn does for large outputs,
+ * here for the small ones whose cost is reading g and x once.  dbias is summed from the fp32 g in every mode. */
+int mdg_grad_weight_prec(const float* g, int64_t ldg, const float* x, int64_t ldx, float* dw, float* dbias, int64_t M, int64_t N,
+                         int64_t K, int precision, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Grouped dense block: G independent products y_g = alpha_g * act(x_g W_g^T + b_g) + beta_g * r_g sharing K, in ONE launch.
  * Replaces the per-node-type linear layers of PyG HGTConv (kqv_lin / out_lin, a HeteroDictLinear each: one GEMM per node

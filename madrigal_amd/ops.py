@@ -1201,8 +1201,9 @@ def grad_weight(g: torch.Tensor, x: torch.Tensor, precision="f32", want_bias: bo
     """dW [N,K] = g^T x for g [M,N], x [M,K] (row-major, unit inner stride; rows may be strided); with ``want_bias`` also
     db [N] = column sums of g -> (dW, db).
 
-    Small outputs (the usual case: 128..512-wide layers over 10^4..10^6 rows) run the split-reduction fp32 kernel, which
-    produces the bias gradient on the side.  Outputs with >= 96 tiles of 128x128 (the 2048-wide fusion transformer)
+    Small outputs (the usual case: 128..512-wide layers over 10^4..10^6 rows) run a split-reduction kernel, which produces the bias
+    gradient on the side: exact fp32 matrix cores for "f32", operands rounded (bf16) / split (bf16x3) while staged for the 16-bit
+    modes (mdg_grad_weight_prec).  Outputs with >= 96 tiles of 128x128 (the 2048-wide fusion transformer)
     already fill the chip tile-wise: in the bf16 modes they go through the forward GEMM kernel on transposed operands,
     ~5x the fp32 matrix-core rate."""
     if out is not None:                         # (dW, db | None): contiguous fp32 tensors to write into (row blocks of a stacked gradient)
@@ -1241,8 +1242,8 @@ def grad_weight(g: torch.Tensor, x: torch.Tensor, precision="f32", want_bias: bo
     db = (torch.empty(N, dtype=torch.float32, device=g.device) if out is None else out[1]) if want_bias else None
     nbytes = lib().mdg_grad_weight_workspace_bytes(_c64(M), _c64(N), _c64(K))
     ws = _workspace(nbytes, g.device)
-    check(lib().mdg_grad_weight(_ptr(g), _c64(g.stride(0)), _ptr(x), _c64(x.stride(0)), _ptr(dw), _ptr(db), _c64(M), _c64(N), _c64(K),
-                                _ptr(ws), ctypes.c_size_t(nbytes), _stream(g)), "mdg_grad_weight")
+    check(lib().mdg_grad_weight_prec(_ptr(g), _c64(g.stride(0)), _ptr(x), _c64(x.stride(0)), _ptr(dw), _ptr(db), _c64(M), _c64(N), _c64(K),
+                                     _c(_prec(precision)), _ptr(ws), ctypes.c_size_t(nbytes), _stream(g)), "mdg_grad_weight")
     return (dw, db) if want_bias else dw
 
 

@@ -1408,6 +1408,28 @@ def test_wide_weight_gradient_tn_product(M, N, K, prec, tol):
     _close(db, g.double().sum(0), 1e-5, "db")
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-6), ("bf16x3", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("M,N,K", [(5000, 128, 128), (33, 128, 68), (257, 384, 128), (4096, 512, 1024), (70001, 128, 256), (1, 4, 4), (300, 130, 67)])
+def test_small_weight_gradient_in_the_arithmetic_mode_of_the_step(M, N, K, prec, tol):
+    """dW = g^T x of the narrow layers (mdg_grad_weight_prec): the exact fp32 kernel for "f32", operands rounded / split to bf16 while
+    staged and transposed by the LDS read for the 16-bit modes (N, K multiples of 4; the last case falls back to the exact kernel).
+    Ragged M (not a multiple of the 32-row chunk or of the split), N / K not multiples of the 128-wide tile, strided rows; the bias
+    gradient is summed from the fp32 g in every mode."""
+    from madrigal_amd import ops
+    g = _rand(M, N + 8, seed=3)[:, :N]            # strided rows, 16-byte aligned
+    x = _rand(M, K, seed=4)
+    ref = g.double().T @ x.double()
+    got, db = ops.grad_weight(g.to(DEV), x.to(DEV), prec, want_bias=True)
+    assert got.shape == (N, K)
+    _close(got, ref, tol, "dW")
+    _close(db, g.double().sum(0), 1e-5, "db")
+    only = ops.grad_weight(g.to(DEV), x.to(DEV), prec)
+    assert torch.equal(only, got)
+    if prec == "bf16" and N % 4 == 0 and K % 4 == 0:      # the rounding is the dense block's: exact products of the rounded operands
+        rb = g.to(torch.bfloat16).double().T @ x.to(torch.bfloat16).double()
+        _close(got, rb, 2e-6, "dW of the rounded operands")
+
+
 def test_full_size_finetune_steps_bf16_track_the_fp32_grade_run():
     """BASELINE configs[1] at full size (4096 drugs, 896 outcomes, 6e6 labelled triples, the TWOSIDES model over a 130k-node /
     8M-edge KG): three finetune steps with bf16 GEMM operands (what bench.py times) against the same steps in the fp32-grade
