@@ -299,13 +299,16 @@ def ranks_leg(scores, args, model=None, z=None):
     ops.rank_normalize(s[:2], out=out[:2])                               # warm-up (code load, workspace)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    ops.rank_normalize(s, out=out)
-    e1.record()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    ms = e0.elapsed_time(e1)
+    passes, walls = [], []
+    for _ in range(2):            # two passes over all outcomes, the faster one reported: the first touches 60 GB of fresh rank tensor
+        t0 = time.perf_counter()
+        e0.record()
+        ops.rank_normalize(s, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+        passes.append(e0.elapsed_time(e1))
+    ms, wall = min(passes), min(walls)
     M = N * (N - 1) // 2
     # size-independent checks inside the run: a permutation of 1..M per outcome (sum of ranks), symmetric, zero diagonal
     denom = N * (N - 1) / 2
@@ -315,7 +318,7 @@ def ranks_leg(scores, args, model=None, z=None):
     sym = bool(torch.equal(out[0], out[0].T)) and float(out[0].diagonal().abs().max()) == 0.0
     alg = (M * 4.0 + N * N * 4.0) * L
     res = {"metric": "rank-normalised scores/sec (normalize_scores)", "value": float(L) * N * N / (ms * 1e-3), "unit": "scores/s", "outcomes": L, "drugs": N,
-           "ms_total": ms, "ms_per_outcome": ms / L, "wall_ms": wall * 1e3, "dtype": "u32 order-preserving keys of fp32 scores, u32 ranks, f64 divide -> f32",
+           "ms_total": ms, "passes_ms": passes, "ms_per_outcome": ms / L, "wall_ms": wall * 1e3, "dtype": "u32 order-preserving keys of fp32 scores, u32 ranks, f64 divide -> f32",
            "checks": {"rank_sum_rel_err": perm_err, "symmetric_zero_diagonal": sym},
            "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": None, "kernel": "mdg_rank_normalize (extract + 4 x 8-bit stable LSD radix passes + blocked rank store)",
