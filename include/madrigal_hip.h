@@ -374,6 +374,18 @@ size_t mdg_linear_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int precis
 int mdg_linear_tn(const float* g, int64_t ldg, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K,
                   int precision, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward of a wide dense block y = x W^T + b from ONE pass over g = dL/dy [M,N] (16-bit operand modes): the pass writes the operand
+ * image of g (for dx = g W through mdg_linear_packed_x with K = N; NULL to skip), the image of g^T (for dW through
+ * mdg_linear_tn_packed_g) and dbias = column sums of the fp32 g (NULL to skip).  The separate calls (mdg_linear on g, mdg_linear_tn,
+ * mdg_colsum) read g three times.  mdg_linear_backward_pack_bytes(M, N, precision, which): 0 = bytes of the row image, 1 = of the
+ * transposed image, 2 = of the workspace (partial column sums). */
+size_t mdg_linear_backward_pack_bytes(int64_t M, int64_t N, int precision, int which);
+int mdg_linear_backward_pack(const float* g, int64_t ldg, int64_t M, int64_t N, int precision, void* row_image, void* t_image,
+                             float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+size_t mdg_linear_tn_packed_g_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision);
+int mdg_linear_tn_packed_g(const void* gt_image, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                           int precision, void* workspace, size_t workspace_bytes, void* stream);
+
 /* out[c, r] = in[r, c]   (dW = dY^T X and dX = dY W are mdg_linear calls on transposed operands) */
 int mdg_transpose(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t rows, int64_t cols, void* stream);
 

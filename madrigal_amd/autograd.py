@@ -29,14 +29,23 @@ class _Linear(Function):
     """y = act(x W^T + b);  dX = g W,  dW = g^T X,  db = colsum(g),  g = dy * act'(pre)."""
 
     @staticmethod
+    def _is_parameter(w) -> bool:
+        """A leaf whose storage address identifies it across the step (the image caches are keyed by address + in-place version)."""
+        return w.is_leaf and w.requires_grad and w.dim() == 2 and w.shape[1] % 4 == 0 and w.is_contiguous() and \
+            not (w.is_cuda and torch.cuda.is_current_stream_capturing())
+
+    @staticmethod
     def forward(ctx, x, w, b, act, precision):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
+        # a parameter's operand image is kept per in-place version (both sides / views of a step use it); anything else is packed
+        # inside the call (a temporary must not enter the per-storage cache)
+        keep = _Linear._is_parameter(w)
         if act in (None, "none", "relu"):
-            y = ops.linear(x2, w, b, act=act, precision=precision, cache_weight=False)
+            y = ops.linear(x2, w, b, act=act, precision=precision, cache_weight=keep)
             pre = y if act == "relu" else None
         else:
-            pre = ops.linear(x2, w, b, precision=precision, cache_weight=False)
+            pre = ops.linear(x2, w, b, precision=precision, cache_weight=keep)
             y = ops.activation_fwd(pre, act)
         ctx.save_for_backward(x2, w, pre)
         ctx.act, ctx.precision, ctx.has_bias, ctx.lead = act, precision, b is not None, lead
@@ -51,11 +60,25 @@ class _Linear(Function):
         if pre is not None:
             g = ops.activation_bwd(g, pre, ctx.act)
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wt = ops.weight_transposed(w) if (w.is_leaf and w.requires_grad) else ops.transpose(w)
-            dx = ops.linear(g, wt, precision=ctx.precision, cache_weight=False)[:, :x2.shape[1]]
-            dx = dx.reshape(*ctx.lead, x2.shape[1])
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        N, K = w.shape[0], x2.shape[1]
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ctx.precision in ("bf16", "bf16x3") and N % 64 == 0 and ops.wide_weight_gradient(N, K) \
+                and g.shape[0] > 0 and g.data_ptr() % 16 == 0 and x2.stride(1) == 1:
+            # wide block: ONE pass over g makes its operand image (dx GEMM), the image of its transpose (dW GEMM) and the bias gradient
+            row_img, t_img, db = ops.linear_backward_pack(g, ctx.precision, want_bias=want_db)
+            wt, wt_img = ops.transposed_weight_image(w, ctx.precision) if _Linear._is_parameter(w) else (ops.transpose(w), None)
+            dx = ops.linear_packed(row_img, g.shape[0], wt, precision=ctx.precision, weight_image=wt_img, cache_weight=False)[:, :K]
+            dw = ops.linear_tn_packed_g(t_img, x2, N, ctx.precision)
+            return dx.reshape(*ctx.lead, K), dw, db, None, None
+        if ctx.needs_input_grad[0]:
+            if _Linear._is_parameter(w):
+                wt, wt_img = ops.transposed_weight_image(w, ctx.precision)
+            elif w.is_leaf and w.requires_grad:
+                wt, wt_img = ops.weight_transposed(w), None
+            else:
+                wt, wt_img = ops.transpose(w), None
+            dx = ops.linear(g, wt, precision=ctx.precision, cache_weight=False, weight_image=wt_img)[:, :x2.shape[1]]
+            dx = dx.reshape(*ctx.lead, x2.shape[1])
         if ctx.needs_input_grad[1]:
             dw = ops.grad_weight(g, x2, ctx.precision, want_bias=want_db)
             if want_db:

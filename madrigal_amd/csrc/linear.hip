@@ -972,6 +972,81 @@ __global__ __launch_bounds__(256) void prep_transposed_kernel(const PrepTArgs p)
   }
 }
 
+// Backward pre-pass of a wide dense block, ONE read of g = dL/dy [M, N]: (a) its row image (A operand of dx = g W: inner index n,
+// padded to Np), (b) its transposed image (A operand of dW = g^T x: rows n, inner index m padded to Mp), (c) partial column sums
+// (bias gradient) per 64-row block: part[block][n].  The separate launches read g three times (prep_operands_kernel,
+// prep_transposed_kernel, colsum_partial_kernel).  64 x 64 tiles through LDS; grid = (Mp / 64, Np / 64).
+struct PrepBArgs {
+  const float* g; int64_t ld;
+  int64_t M, N, Np, Mp;
+  char* row_img; char* t_img; float* part;
+  int x3;
+};
+
+__global__ __launch_bounds__(256) void prep_backward_kernel(const PrepBArgs p) {
+  __shared__ float tile[64][65];
+  __shared__ float red[4][64];
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * 64, c0 = static_cast<int64_t>(blockIdx.y) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  float cs = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t m = m0 + ty + 4 * i, c = c0 + tx;
+    const float v = (m < p.M && c < p.N) ? p.g[m * p.ld + c] : 0.f;
+    tile[ty + 4 * i][tx] = v;
+    cs += v;
+  }
+  red[ty][tx] = cs;
+  __syncthreads();
+  if (p.part && ty == 0 && c0 + tx < p.N) p.part[static_cast<int64_t>(blockIdx.x) * p.N + c0 + tx] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+  const int rl = threadIdx.x >> 4, q4 = (threadIdx.x & 15) * 4;          // 16 rows x 16 quads per pass
+  auto put = [&](char* img, int64_t row, int64_t inner, int64_t pitch, const f32x4 v) {
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      __bf16 a, b;
+      mdg_split_bf16(v[e], a, b);
+      hi[e] = a;
+      lo[e] = b;
+    }
+    if (p.x3) {
+      char* d = img + img_off_x3(row, inner, pitch);
+      *reinterpret_cast<bf16x4*>(d) = hi;
+      *reinterpret_cast<bf16x4*>(d + 64) = lo;
+    } else {
+      *reinterpret_cast<bf16x4*>(img + (row * pitch + inner) * 2) = hi;
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int l = rl + 16 * i;
+    if (p.row_img && m0 + l < p.M) {                                  // row image: row m, 4 consecutive n (zeros in the padding up to Np)
+      const f32x4 v = {tile[l][q4], tile[l][q4 + 1], tile[l][q4 + 2], tile[l][q4 + 3]};
+      put(p.row_img, m0 + l, c0 + q4, p.Np, v);
+    }
+    if (c0 + l < p.N) {                                               // transposed image: row n, 4 consecutive m
+      const f32x4 v = {tile[q4][l], tile[q4 + 1][l], tile[q4 + 2][l], tile[q4 + 3][l]};
+      put(p.t_img, c0 + l, m0 + q4, p.Mp, v);
+    }
+  }
+}
+
+// out[n] = sum over blocks of part[block][n], fixed order (four interleaved accumulators per column)
+__global__ __launch_bounds__(256) void prep_backward_bias_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t nblocks, int64_t N) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int64_t b = 0;
+  for (; b + 3 < nblocks; b += 4) {
+    s0 += part[b * N + n];
+    s1 += part[(b + 1) * N + n];
+    s2 += part[(b + 2) * N + n];
+    s3 += part[(b + 3) * N + n];
+  }
+  for (; b < nblocks; ++b) s0 += part[b * N + n];
+  out[n] = (s0 + s1) + (s2 + s3);
+}
+
 inline size_t al256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 inline int64_t pad64(int64_t k) { return (k + 63) / 64 * 64; }
 inline int64_t pad32(int64_t k) { return (k + 31) / 32 * 32; }
@@ -1331,6 +1406,69 @@ extern "C" int mdg_linear_tn(const float* g, int64_t ldg, const float* x, int64_
   set_image(a.B, bimg, K, Mp, precision);
   launch_linear_core(a, precision, N, K, st, aimg + ab + bb, workspace_bytes - ab - bb);
   MDG_CHECK_LAUNCH("mdg_linear_tn");
+  return MDG_OK;
+}
+
+// ---- backward of a wide dense block from ONE pass over g (see prep_backward_kernel) -------------------------------------------
+extern "C" size_t mdg_linear_backward_pack_bytes(int64_t M, int64_t N, int precision, int which) {
+  if (M <= 0 || N <= 0 || (precision != MDG_PREC_BF16 && precision != MDG_PREC_BF16X3)) return 0;
+  if (which == 0) return image_bytes(M, N, precision);                    // row image of g
+  if (which == 1) return image_bytes_t(N, M, precision);                  // image of g^T
+  return al256(static_cast<size_t>(pad64(M) / 64) * N * sizeof(float));   // workspace: partial column sums
+}
+
+extern "C" int mdg_linear_backward_pack(const float* g, int64_t ldg, int64_t M, int64_t N, int precision, void* row_image, void* t_image,
+                                        float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(M > 0 && N > 0 && g && ldg >= N, "mdg_linear_backward_pack: empty operand / short row stride");
+  MDG_CHECK_ARG(precision == MDG_PREC_BF16 || precision == MDG_PREC_BF16X3, "mdg_linear_backward_pack: a 16-bit operand mode");
+  MDG_CHECK_ARG(t_image && mdg_aligned16(t_image) && (!row_image || mdg_aligned16(row_image)), "mdg_linear_backward_pack: null / misaligned image");
+  MDG_CHECK_ARG(pad64(M) / 64 < (1ll << 31) && pad64(N) / 64 < 65536, "mdg_linear_backward_pack: too many tiles");
+  const size_t need = dbias ? mdg_linear_backward_pack_bytes(M, N, precision, 2) : 0;
+  if (need && (!workspace || workspace_bytes < need)) {
+    mdg_set_error("mdg_linear_backward_pack: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return MDG_EWORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PrepBArgs a{g, ldg, M, N, pad64(N), pad64(M), static_cast<char*>(row_image), static_cast<char*>(t_image), dbias ? static_cast<float*>(workspace) : nullptr,
+              precision == MDG_PREC_BF16X3 ? 1 : 0};
+  hipLaunchKernelGGL(prep_backward_kernel, dim3(static_cast<unsigned>(a.Mp / 64), static_cast<unsigned>(a.Np / 64)), dim3(256), 0, st, a);
+  if (dbias)
+    hipLaunchKernelGGL(prep_backward_bias_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N, 256))), dim3(256), 0, st, static_cast<const float*>(workspace), dbias,
+                       a.Mp / 64, N);
+  MDG_CHECK_LAUNCH("mdg_linear_backward_pack");
+  return MDG_OK;
+}
+
+extern "C" size_t mdg_linear_tn_packed_g_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision) {
+  return image_bytes_t(K, M, precision) + (pp_shape(precision, N, K) ? pp::sk_bytes() : 0);
+}
+
+// dW [N, K] = g^T x with the image of g^T already made (mdg_linear_backward_pack); x [M, K] is re-laid out here.
+extern "C" int mdg_linear_tn_packed_g(const void* gt_image, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                                      int precision, void* workspace, size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(M > 0 && N > 0 && K > 0, "mdg_linear_tn_packed_g: empty operand");
+  MDG_CHECK_ARG(gt_image && mdg_aligned16(gt_image) && x && y && ldx >= K && ldy >= K, "mdg_linear_tn_packed_g: null pointer / short row stride");
+  MDG_CHECK_ARG(precision == MDG_PREC_BF16X3 || precision == MDG_PREC_BF16, "mdg_linear_tn_packed_g: a 16-bit operand mode");
+  MDG_CHECK_ARG(mdg_cdiv(N, Small::BM) * mdg_cdiv(K, Small::BN) < (1ll << 31) - 8 && mdg_cdiv(K, 64) < 65536, "mdg_linear_tn_packed_g: too many tiles");
+  const size_t bb = image_bytes_t(K, M, precision);
+  if (!workspace || workspace_bytes < bb || !mdg_aligned16(workspace)) {
+    mdg_set_error("mdg_linear_tn_packed_g: workspace of %zu bytes (16-byte aligned) required, got %zu", bb, workspace_bytes);
+    return MDG_EWORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* bimg = static_cast<char*>(workspace);
+  const int64_t Mp = pad64(M);
+  PrepTArgs pa{};
+  pa.src[0] = x; pa.ld[0] = ldx; pa.C[0] = K; pa.dst0[0] = bimg;
+  pa.src[1] = x; pa.ld[1] = ldx; pa.C[1] = 0; pa.dst0[1] = bimg;
+  pa.M = M; pa.Mp = Mp; pa.bf16 = 1; pa.x3 = precision == MDG_PREC_BF16X3 ? 1 : 0;
+  hipLaunchKernelGGL(prep_transposed_kernel, dim3(static_cast<unsigned>(Mp / 64), static_cast<unsigned>(mdg_cdiv(K, 64)), 1), dim3(256), 0, st, pa);
+  LinearArgs a{};
+  a.y = y; a.ldy = ldy; a.alpha = 1.f; a.beta = 0.f; a.act = MDG_ACT_NONE; a.M = N; a.N = K; a.K = Mp;
+  set_image(a.A, static_cast<const char*>(gt_image), N, Mp, precision);
+  set_image(a.B, bimg, K, Mp, precision);
+  launch_linear_core(a, precision, N, K, st, bimg + bb, workspace_bytes - bb);
+  MDG_CHECK_LAUNCH("mdg_linear_tn_packed_g");
   return MDG_OK;
 }
 

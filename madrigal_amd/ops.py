@@ -225,12 +225,14 @@ def _rows2d(x: torch.Tensor, name: str):
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, scale=None, shift=None,
            act=None, residual: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 1.0,
-           precision="bf16x3", out: Optional[torch.Tensor] = None, cache_weight: bool = True) -> torch.Tensor:
+           precision="bf16x3", out: Optional[torch.Tensor] = None, cache_weight: bool = True,
+           weight_image: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = alpha * act((x W^T + b) * scale + shift) + beta * residual   (nn.Linear layout W [N,K]).
 
     ``x`` may be a strided 2-D view (row stride a multiple of 4); ``residual`` may be [N] / [1,N]
     (broadcast over rows) or [M,N].  ``cache_weight``: keep the packed image of ``weight`` (hi/lo bf16 planes, K
-    padded) and reuse it while the tensor is unchanged; pass False for one-shot "weights" (e.g. InfoNCE's F F^T)."""
+    padded) and reuse it while the tensor is unchanged; pass False for one-shot "weights" (e.g. InfoNCE's F F^T).
+    ``weight_image``: the (padded) weight's image when the caller keeps one (transposed_weight_image)."""
     forward_only(x, weight, bias, residual)
     if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.shape[1] % 4 == 0 and x.data_ptr() % 16 == 0 \
             and x.is_cuda and x.dtype == torch.float32:
@@ -264,7 +266,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         if t is not None and (t.numel() != N or not t.is_cuda or t.dtype != torch.float32):
             raise ValueError(f"{nm}: expected fp32 cuda [{N}]")
     prec = _prec(precision)
-    wimg = packed_weight_image(w, prec) if cache_weight else None
+    wimg = weight_image if weight_image is not None else (packed_weight_image(w, prec) if cache_weight else None)
     nbytes = lib().mdg_linear_workspace_bytes(_c64(M), _c64(N), _c64(K), _c(prec), _c(1 if wimg is not None else 0))
     ws = _workspace(nbytes, x2.device)
     check(lib().mdg_linear(_ptr(x2), _c64(x2.stride(0)), _ptr(w), _c64(w.stride(0)), _ptr(wimg), _ptr(out), _c64(out.stride(0)),
@@ -296,8 +298,10 @@ def layernorm_packed(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, 
 
 def linear_packed(x_img: torch.Tensor, M: int, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act=None,
                   residual: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 1.0, precision="bf16x3",
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """linear() on an input that already exists as an operand image (layernorm_packed): no pre-pass over x."""
+                  out: Optional[torch.Tensor] = None, weight_image: Optional[torch.Tensor] = None, cache_weight: bool = True) -> torch.Tensor:
+    """linear() on an input that already exists as an operand image (layernorm_packed, linear_backward_pack): no pre-pass over x.
+    ``weight_image``: the weight's own image if the caller keeps one (transposed_weight_image); ``cache_weight=False``: pack the
+    weight inside the call (a one-shot tensor must not enter the per-storage image cache)."""
     w = padded_weight(_f32_cuda(weight, "weight", 2))
     N, K = w.shape
     if act not in ACTS:
@@ -313,8 +317,8 @@ def linear_packed(x_img: torch.Tensor, M: int, weight: torch.Tensor, bias: Optio
             if residual.dim() != 2 or residual.shape != (M, N) or residual.stride(1) != 1:
                 raise ValueError(f"residual: expected [{M},{N}] or [{N}]")
             ldr = residual.stride(0)
-    wimg = packed_weight_image(w, prec)
-    nbytes = lib().mdg_linear_packed_x_workspace_bytes(_c64(M), _c64(N), _c64(K), _c(prec), _c(1))        # the stream-K slots of the 256-tile kernel
+    wimg = weight_image if weight_image is not None else (packed_weight_image(w, prec) if cache_weight else None)
+    nbytes = lib().mdg_linear_packed_x_workspace_bytes(_c64(M), _c64(N), _c64(K), _c(prec), _c(1 if wimg is not None else 0))    # (+ the stream-K slots of the 256-tile kernel)
     ws = _workspace(nbytes, x_img.device)
     check(lib().mdg_linear_packed_x(_ptr(x_img), _c64(M), _c64(K), _ptr(w), _c64(w.stride(0)), _ptr(wimg), _ptr(out), _c64(out.stride(0)), _c64(N),
                                     _ptr(None if bias is None else bias.detach().contiguous()), _c(ACTS[act]), _ptr(residual), _c64(ldr),
@@ -756,6 +760,74 @@ def weight_transposed(w: torch.Tensor) -> torch.Tensor:
     t = transpose(w.detach())
     _wt_cache[k] = (w._version, t, w)
     return t
+
+
+_wt_img_cache = {}
+
+
+def transposed_weight_image(w: torch.Tensor, precision):
+    """(transpose(w), its operand image) of a parameter, kept per (storage, in-place version, arithmetic mode) like
+    ``weight_transposed``: both sides / views of a step multiply their output gradients by the same W.  Image None where the mode
+    takes the tensor as it is."""
+    prec = _prec(precision)
+    if w.is_cuda and torch.cuda.is_current_stream_capturing():
+        return transpose(w.detach()), None
+    k = (w.data_ptr(), tuple(w.shape), str(w.device), prec)
+    hit = _wt_img_cache.get(k)
+    if hit is not None and hit[0] == w._version:
+        return hit[1], hit[2]
+    wt = weight_transposed(w)
+    nbytes = int(lib().mdg_pack_operand_bytes(_c64(wt.shape[0]), _c64(wt.shape[1]), _c(prec)))
+    img = None
+    if nbytes:
+        img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        check(lib().mdg_pack_operand(_ptr(wt), _c64(wt.stride(0)), _c64(wt.shape[0]), _c64(wt.shape[1]), _c(prec), _ptr(img), ctypes.c_size_t(nbytes),
+                                     _stream(wt)), "mdg_pack_operand")
+    _wt_img_cache[k] = (w._version, wt, img, w)
+    return wt, img
+
+
+def wide_weight_gradient(N: int, K: int) -> bool:
+    """dW [N,K] with >= 96 tiles of 128 x 128 fills the chip tile-wise: the 16-bit modes run it as a tile GEMM on transposed images."""
+    return ((N + 127) // 128) * ((K + 127) // 128) >= 96
+
+
+def linear_backward_pack(g: torch.Tensor, precision, want_bias: bool = False, want_row_image: bool = True):
+    """One pass over g = dL/dy [M,N] (contiguous rows, 16-bit operand mode) -> (operand image of g | None, image of g^T, column sums
+    of g | None): what the dx GEMM, the dW GEMM and the bias gradient of a wide dense block read (mdg_linear_backward_pack)."""
+    if g.dim() != 2 or not g.is_cuda or g.dtype != torch.float32 or g.stride(1) != 1:
+        raise ValueError("linear_backward_pack: g must be a 2-D fp32 cuda tensor with unit inner stride")
+    prec = _prec(precision)
+    M, N = g.shape
+    L_ = lib()
+    rb = int(L_.mdg_linear_backward_pack_bytes(_c64(M), _c64(N), _c(prec), _c(0)))
+    tb = int(L_.mdg_linear_backward_pack_bytes(_c64(M), _c64(N), _c(prec), _c(1)))
+    if tb == 0:
+        raise ValueError("linear_backward_pack: a 16-bit operand mode (bf16 / bf16x3) and a non-empty g")
+    row_img = torch.empty(rb, dtype=torch.uint8, device=g.device) if want_row_image else None
+    t_img = torch.empty(tb, dtype=torch.uint8, device=g.device)
+    db = torch.empty(N, dtype=torch.float32, device=g.device) if want_bias else None
+    nbytes = int(L_.mdg_linear_backward_pack_bytes(_c64(M), _c64(N), _c(prec), _c(2))) if want_bias else 0
+    ws = _workspace(nbytes, g.device)
+    check(L_.mdg_linear_backward_pack(_ptr(g), _c64(g.stride(0)), _c64(M), _c64(N), _c(prec), _ptr(row_img), _ptr(t_img), _ptr(db), _ptr(ws),
+                                      ctypes.c_size_t(nbytes), _stream(g)), "mdg_linear_backward_pack")
+    return row_img, t_img, db
+
+
+def linear_tn_packed_g(gt_img: torch.Tensor, x: torch.Tensor, N: int, precision, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dW [N,K] = g^T x from the image of g^T (linear_backward_pack) and the layer input x [M,K]."""
+    if x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32 or x.stride(1) != 1:
+        raise ValueError("linear_tn_packed_g: x must be a 2-D fp32 cuda tensor with unit inner stride")
+    M, K = x.shape
+    prec = _prec(precision)
+    dw = torch.empty((N, K), dtype=torch.float32, device=x.device) if out is None else out
+    if tuple(dw.shape) != (N, K) or not dw.is_contiguous() or dw.dtype != torch.float32:
+        raise ValueError("linear_tn_packed_g: out must be contiguous fp32 [N,K]")
+    nbytes = lib().mdg_linear_tn_packed_g_workspace_bytes(_c64(M), _c64(N), _c64(K), _c(prec))
+    ws = _workspace(nbytes, x.device)
+    check(lib().mdg_linear_tn_packed_g(_ptr(gt_img), _ptr(x), _c64(x.stride(0)), _ptr(dw), _c64(K), _c64(M), _c64(N), _c64(K), _c(prec), _ptr(ws),
+                                       ctypes.c_size_t(nbytes), _stream(x)), "mdg_linear_tn_packed_g")
+    return dw
 
 
 def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, beta: float = 0.0) -> torch.Tensor:
@@ -1225,7 +1297,7 @@ def grad_weight(g: torch.Tensor, x: torch.Tensor, precision="f32", want_bias: bo
     if g.shape[0] != x.shape[0]:
         raise ValueError("grad_weight: g and x disagree in the number of rows")
     M, N, K = g.shape[0], g.shape[1], x.shape[1]
-    if _prec(precision) != PREC_F32 and ((N + 127) // 128) * ((K + 127) // 128) >= 96:
+    if _prec(precision) != PREC_F32 and wide_weight_gradient(N, K):
         prec = _prec(precision)
         dw = torch.empty((N, K), dtype=torch.float32, device=g.device) if out is None else out[0]
         nbytes = lib().mdg_linear_tn_workspace_bytes(_c64(M), _c64(N), _c64(K), _c(prec))

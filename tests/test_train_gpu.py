@@ -1494,3 +1494,38 @@ def test_full_size_finetune_steps_bf16_track_the_fp32_grade_run():
     assert float((s.double() - ref_all).abs().max()) < 1e-4 * scale
     loss_ref = float(torch.nn.functional.binary_cross_entropy(torch.sigmoid(ref_all), y.double()))
     assert abs(loss - loss_ref) < 1e-5 * abs(loss_ref), (loss, loss_ref)
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("M,N,K", [(1000, 1280, 1300), (4097, 2048, 1024), (63, 1536, 1100)])
+def test_wide_block_backward_from_one_pass_over_g(M, N, K, prec, tol):
+    """A wide dense block's backward (mdg_linear_backward_pack): one pass over g writes its operand image, the image of its transpose
+    and the bias gradient; dx and dW from those equal the separate launches (same roundings, same tile GEMMs: bit-identical) and the
+    fp64 reference to the mode's tolerance.  Through autograd: the _Linear node takes this path for N % 64 == 0."""
+    from madrigal_amd import autograd as ag, ops
+    g = _rand(M, N, seed=5).to(DEV)
+    x = _rand(M, K, seed=6).to(DEV)
+    w = _rand(N, K, seed=7, scale=0.05).to(DEV)
+    row_img, t_img, db = ops.linear_backward_pack(g, prec, want_bias=True)
+    wt = ops.transpose(w)
+    dx = ops.linear_packed(row_img, M, wt, precision=prec, cache_weight=False)[:, :K]
+    dw = ops.linear_tn_packed_g(t_img, x, N, prec)
+    assert torch.equal(dx, ops.linear(g, wt, precision=prec, cache_weight=False)[:, :K])
+    dw_sep, db_sep = ops.grad_weight(g, x, prec, want_bias=True)
+    assert torch.equal(dw, dw_sep)
+    _close(db, g.double().sum(0), 1e-5, "db")
+    _close(db, db_sep, 2e-6, "db vs colsum")
+    _close(dx, g.double() @ w.double(), tol, "dx")
+    _close(dw, g.double().T @ x.double(), tol, "dW")
+    # the autograd node
+    xr = x.clone().requires_grad_(True)
+    wp = torch.nn.Parameter(w.clone())
+    bp = torch.nn.Parameter(torch.zeros(N, device=DEV))
+    y = ag.linear(xr, wp, bp, None, prec)
+    y.backward(g)
+    assert torch.equal(xr.grad, dx) and torch.equal(wp.grad, dw) and torch.equal(bp.grad, db)
+    y2 = ag.linear(xr, wp, bp, None, prec)        # second use of the same parameter version: cached images, same bits
+    xr.grad = None
+    wp.grad = None
+    y2.backward(g)
+    assert torch.equal(xr.grad, dx) and torch.equal(wp.grad, dw)
