@@ -38,6 +38,9 @@ class _Linear(Function):
     def forward(ctx, x, w, b, act, precision):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
+        ctx.k_in = x2.shape[1]
+        if ctx.k_in % 4:            # 978 genes, 559 viability features, 67 atom features: zero columns up to a multiple of 4, once, so that
+            x2 = ops._pad_last(x2)  # the forward GEMM and the weight gradient both read 16-byte aligned rows
         # a parameter's operand image is kept per in-place version (both sides / views of a step use it); anything else is packed
         # inside the call (a temporary must not enter the per-storage cache)
         keep = _Linear._is_parameter(w)
@@ -61,9 +64,9 @@ class _Linear(Function):
             g = ops.activation_bwd(g, pre, ctx.act)
         dx = dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        N, K = w.shape[0], x2.shape[1]
-        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ctx.precision in ("bf16", "bf16x3") and N % 64 == 0 and ops.wide_weight_gradient(N, K) \
-                and g.shape[0] > 0 and g.data_ptr() % 16 == 0 and x2.stride(1) == 1:
+        N, K = w.shape[0], ctx.k_in
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ctx.precision in ("bf16", "bf16x3") and N % 64 == 0 and K % 4 == 0 \
+                and ops.wide_weight_gradient(N, K) and g.shape[0] > 0 and g.data_ptr() % 16 == 0 and x2.stride(1) == 1:
             # wide block: ONE pass over g makes its operand image (dx GEMM), the image of its transpose (dW GEMM) and the bias gradient
             row_img, t_img, db = ops.linear_backward_pack(g, ctx.precision, want_bias=want_db)
             wt, wt_img = ops.transposed_weight_image(w, ctx.precision) if _Linear._is_parameter(w) else (ops.transpose(w), None)
@@ -77,12 +80,14 @@ class _Linear(Function):
                 wt, wt_img = ops.weight_transposed(w), None
             else:
                 wt, wt_img = ops.transpose(w), None
-            dx = ops.linear(g, wt, precision=ctx.precision, cache_weight=False, weight_image=wt_img)[:, :x2.shape[1]]
-            dx = dx.reshape(*ctx.lead, x2.shape[1])
+            dx = ops.linear(g, wt, precision=ctx.precision, cache_weight=False, weight_image=wt_img)[:, :K]
+            dx = dx.reshape(*ctx.lead, K)
         if ctx.needs_input_grad[1]:
             dw = ops.grad_weight(g, x2, ctx.precision, want_bias=want_db)
             if want_db:
                 dw, db = dw
+            if dw.shape[1] != K:                          # the zero columns x was padded with
+                dw = dw[:, :K].contiguous()
         elif want_db:
             db = ops.colsum(g)
         return dx, dw, db, None, None
