@@ -132,6 +132,12 @@ int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const v
                int64_t N, int64_t K, const float* bias, const float* scale, const float* shift, int activation,
                const float* residual, int64_t ldr, float alpha, float beta, int precision, void* workspace,
                size_t workspace_bytes, void* stream);
+/* Training form: y = dropout(act(x W^T + b), drop_p, drop_seed) + beta * residual in the same epilogue (nn.TransformerEncoderLayer's
+ * x + dropout1(out_proj(...)), x + dropout2(linear2(...)), dropout(activation(linear1(x)))): the mask and scale are exactly those of
+ * mdg_dropout(seed) on the contiguous [M,N] result, so the fused block equals the three separate launches bit for bit. */
+int mdg_linear_dropout(const float* x, int64_t ldx, const float* w, int64_t ldw, const void* w_packed, float* y, int64_t ldy,
+                       int64_t M, int64_t N, int64_t K, const float* bias, int act, const float* residual, int64_t ldr, float beta,
+                       float drop_p, uint64_t drop_seed, int precision, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Row-wise LayerNorm (nn.LayerNorm, biased variance): y = (x - mean) / sqrt(var + eps) * gamma + beta.
  * norm1/norm2 and the x-attn norms of the fusion transformer, models.py:366,372-373; LayerNorm inside
@@ -381,7 +387,9 @@ int mdg_linear_tn(const float* g, int64_t ldg, const float* x, int64_t ldx, floa
  * transposed image, 2 = of the workspace (partial column sums). */
 size_t mdg_linear_backward_pack_bytes(int64_t M, int64_t N, int precision, int which);
 int mdg_linear_backward_pack(const float* g, int64_t ldg, int64_t M, int64_t N, int precision, void* row_image, void* t_image,
-                             float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+                             float* dbias, float drop_p, uint64_t drop_seed, void* workspace, size_t workspace_bytes, void* stream);
+/* (drop_p > 0: g is first passed through the backward of the dropout mdg_linear_dropout applied with the same p and seed --
+ * element (m, n) kept iff the counter-based hash of (seed, m * N + n) says so, scaled by 1 / (1 - p) -- on load, no pass of its own.) */
 size_t mdg_linear_tn_packed_g_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision);
 int mdg_linear_tn_packed_g(const void* gt_image, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K,
                            int precision, void* workspace, size_t workspace_bytes, void* stream);
@@ -397,6 +405,10 @@ int mdg_colsum(const float* x, int64_t ldx, float* out, int64_t rows, int64_t co
 /* y = act(pre) and dx = dy * act'(pre), elementwise over n contiguous floats (training keeps the pre-activation). */
 int mdg_activation_fwd(const float* pre, float* y, int64_t n, int activation, void* stream);
 int mdg_activation_bwd(const float* dy, const float* pre, float* dx, int64_t n, int activation, void* stream);
+/* y = dropout(act(pre), p, seed) and its backward dx = act'(pre) * dropout-backward(dy) in one pass each (the FFN's
+ * dropout(activation(linear1(x))) of nn.TransformerEncoderLayer in training mode); same mask as mdg_dropout(seed). */
+int mdg_activation_dropout_fwd(const float* pre, float* y, int64_t n, int activation, float p, uint64_t seed, void* stream);
+int mdg_activation_dropout_bwd(const float* dy, const float* pre, float* dx, int64_t n, int activation, float p, uint64_t seed, void* stream);
 
 /* out[i] = alpha * a[i] + beta * b[i mod nb] (residual adds of the training path; nb < n broadcasts a row over rows). */
 int mdg_axpby(const float* a, const float* b, float* out, int64_t n, int64_t nb, float alpha, float beta, void* stream);

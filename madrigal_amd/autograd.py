@@ -26,7 +26,10 @@ def next_seed() -> int:
 
 
 class _Linear(Function):
-    """y = act(x W^T + b);  dX = g W,  dW = g^T X,  db = colsum(g),  g = dy * act'(pre)."""
+    """y = drop(act(x W^T + b)) + residual;  dX = g W,  dW = g^T X,  db = colsum(g),  g = drop'(dy) * act'(pre),  d residual = dy.
+    ``drop`` = inverted dropout (p, seed) or the identity (p = 0); with it the block is nn.TransformerEncoderLayer's
+    ``x + dropout(linear(...))`` / ``dropout(activation(linear(x)))`` in one node: the mask is applied in the GEMM's epilogue (no
+    activation) or together with the activation, and its backward while the incoming gradient is packed for the two backward GEMMs."""
 
     @staticmethod
     def _is_parameter(w) -> bool:
@@ -35,7 +38,7 @@ class _Linear(Function):
             not (w.is_cuda and torch.cuda.is_current_stream_capturing())
 
     @staticmethod
-    def forward(ctx, x, w, b, act, precision):
+    def forward(ctx, x, w, b, act, precision, p=0.0, seed=0, residual=None):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
         ctx.k_in = x2.shape[1]
@@ -44,15 +47,32 @@ class _Linear(Function):
         # a parameter's operand image is kept per in-place version (both sides / views of a step use it); anything else is packed
         # inside the call (a temporary must not enter the per-storage cache)
         keep = _Linear._is_parameter(w)
-        if act in (None, "none", "relu"):
-            y = ops.linear(x2, w, b, act=act, precision=precision, cache_weight=keep)
+        N = w.shape[0]
+        res2 = None
+        if residual is not None:
+            if tuple(residual.shape) != tuple(lead) + (N,):
+                raise ValueError("linear: residual must have the shape of the output")
+            res2 = residual.reshape(-1, N)
+            res2 = res2 if res2.is_contiguous() else res2.contiguous()
+        plain = act in (None, "none")
+        if p > 0.0 and not plain:
+            if res2 is not None:
+                raise ValueError("linear: activation + dropout + residual in one block is not a layer of the reference")
+            pre = ops.linear(x2, w, b, precision=precision, cache_weight=keep)
+            y = ops.activation_dropout_fwd(pre, act, p, seed)
+        elif act in (None, "none", "relu"):
+            y = ops.linear(x2, w, b, act=act, precision=precision, cache_weight=keep, residual=res2, dropout_p=p if plain else 0.0, dropout_seed=seed)
             pre = y if act == "relu" else None
+            if act == "relu" and res2 is not None:
+                raise ValueError("linear: relu + residual in one block is not a layer of the reference")
         else:
             pre = ops.linear(x2, w, b, precision=precision, cache_weight=keep)
             y = ops.activation_fwd(pre, act)
+            if res2 is not None:
+                y = ops.axpby(y, res2)
         ctx.save_for_backward(x2, w, pre)
-        ctx.act, ctx.precision, ctx.has_bias, ctx.lead = act, precision, b is not None, lead
-        return y.view(*lead, w.shape[0])
+        ctx.act, ctx.precision, ctx.has_bias, ctx.lead, ctx.p, ctx.seed, ctx.has_res = act, precision, b is not None, lead, p, seed, residual is not None
+        return y.view(*lead, N)
 
     @staticmethod
     @once_differentiable
@@ -60,19 +80,26 @@ class _Linear(Function):
         x2, w, pre = ctx.saved_tensors
         g = dy.reshape(-1, w.shape[0])
         g = g if g.is_contiguous() else g.contiguous()
+        d_res = dy if (ctx.has_res and ctx.needs_input_grad[7]) else None
+        mask_p = ctx.p                                   # dropout backward still to be applied to g
         if pre is not None:
-            g = ops.activation_bwd(g, pre, ctx.act)
+            if ctx.p > 0.0:
+                g, mask_p = ops.activation_dropout_bwd(g, pre, ctx.act, ctx.p, ctx.seed), 0.0
+            else:
+                g = ops.activation_bwd(g, pre, ctx.act)
         dx = dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         N, K = w.shape[0], ctx.k_in
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ctx.precision in ("bf16", "bf16x3") and N % 64 == 0 and K % 4 == 0 \
                 and ops.wide_weight_gradient(N, K) and g.shape[0] > 0 and g.data_ptr() % 16 == 0 and x2.stride(1) == 1:
             # wide block: ONE pass over g makes its operand image (dx GEMM), the image of its transpose (dW GEMM) and the bias gradient
-            row_img, t_img, db = ops.linear_backward_pack(g, ctx.precision, want_bias=want_db)
+            row_img, t_img, db = ops.linear_backward_pack(g, ctx.precision, want_bias=want_db, dropout_p=mask_p, dropout_seed=ctx.seed)
             wt, wt_img = ops.transposed_weight_image(w, ctx.precision) if _Linear._is_parameter(w) else (ops.transpose(w), None)
             dx = ops.linear_packed(row_img, g.shape[0], wt, precision=ctx.precision, weight_image=wt_img, cache_weight=False)[:, :K]
             dw = ops.linear_tn_packed_g(t_img, x2, N, ctx.precision)
-            return dx.reshape(*ctx.lead, K), dw, db, None, None
+            return dx.reshape(*ctx.lead, K), dw, db, None, None, None, None, d_res
+        if mask_p > 0.0:
+            g = ops.dropout(g, mask_p, ctx.seed)
         if ctx.needs_input_grad[0]:
             if _Linear._is_parameter(w):
                 wt, wt_img = ops.transposed_weight_image(w, ctx.precision)
@@ -90,11 +117,21 @@ class _Linear(Function):
                 dw = dw[:, :K].contiguous()
         elif want_db:
             db = ops.colsum(g)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None, None, d_res
 
 
 def linear(x, w, b=None, act=None, precision="bf16x3"):
     return _Linear.apply(x, w, b, act, precision)
+
+
+def linear_dropout(x, w, b, act, precision, p: float, training: bool = True, residual=None, seed: Optional[int] = None):
+    """``residual + dropout(act(x W^T + b), p)`` as ONE node (dropout inside the dense block's epilogue / activation pass, its backward
+    inside the gradient's packing pass); identical, bit for bit, to ``add(residual, dropout(linear(x, w, b, act), p, seed=seed))``."""
+    if not training or p == 0.0:
+        return _Linear.apply(x, w, b, act, precision, 0.0, 0, residual)
+    if p >= 1.0:
+        raise ValueError("dropout p must be < 1")
+    return _Linear.apply(x, w, b, act, precision, float(p), next_seed() if seed is None else seed, residual)
 
 
 class _LayerNorm(Function):

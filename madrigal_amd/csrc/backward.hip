@@ -154,6 +154,62 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
   y[i] = keep ? x[i] * (1.0f / (1.0f - p)) : 0.f;
 }
 
+// Elementwise passes of the training step over 16-byte aligned tensors, four elements per thread (n % 4 == 0).  MODE 0: y = dropout(x);
+// 1: y = act(pre); 2: dx = dy act'(pre); 3: y = dropout(act(pre)); 4: dx = act'(pre) dropout-backward(dy).  Same expressions per element as
+// the scalar kernels (dropout_kernel, act_fwd_kernel, act_bwd_kernel) and as their compositions: a fused pass equals the two separate ones.
+template <int MODE>
+__global__ __launch_bounds__(256) void elementwise4_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n4,
+                                                           int act, float p, uint64_t seed) {
+  const int64_t q = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (q >= n4) return;
+  const f32x4 va = reinterpret_cast<const f32x4*>(a)[q];
+  f32x4 vb = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (MODE == 2 || MODE == 4) vb = reinterpret_cast<const f32x4*>(b)[q];
+  const uint32_t thr = mdg_drop_threshold(p);
+  const float scale = 1.0f / (1.0f - p);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint64_t i = static_cast<uint64_t>(q) * 4 + e;
+    if constexpr (MODE == 0) o[e] = mdg_keep(seed, i, thr) ? va[e] * scale : 0.f;
+    else if constexpr (MODE == 1) o[e] = act_fwd(va[e], act);
+    else if constexpr (MODE == 2) o[e] = va[e] * act_grad(vb[e], act);
+    else if constexpr (MODE == 3) { const float y = act_fwd(va[e], act); o[e] = mdg_keep(seed, i, thr) ? y * scale : 0.f; }
+    else { const float g = mdg_keep(seed, i, thr) ? va[e] * scale : 0.f; o[e] = g * act_grad(vb[e], act); }
+  }
+  reinterpret_cast<f32x4*>(out)[q] = o;
+}
+
+__global__ __launch_bounds__(256) void act_dropout_fwd_kernel(const float* __restrict__ pre, float* __restrict__ y, int64_t n, int act, float p, uint64_t seed) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = act_fwd(pre[i], act);
+  y[i] = mdg_keep(seed, static_cast<uint64_t>(i), mdg_drop_threshold(p)) ? v * (1.0f / (1.0f - p)) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dx, int64_t n,
+                                                              int act, float p, uint64_t seed) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float g = mdg_keep(seed, static_cast<uint64_t>(i), mdg_drop_threshold(p)) ? dy[i] * (1.0f / (1.0f - p)) : 0.f;
+  dx[i] = g * act_grad(pre[i], act);
+}
+
+__global__ __launch_bounds__(256) void axpby4_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n4, float alpha,
+                                                     float beta) {
+  const int64_t q = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (q >= n4) return;
+  const f32x4 va = reinterpret_cast<const f32x4*>(a)[q], vb = reinterpret_cast<const f32x4*>(b)[q];
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = alpha * va[e] + beta * vb[e];
+  reinterpret_cast<f32x4*>(out)[q] = o;
+}
+
+static inline bool vec4_ok(int64_t n, const void* a, const void* b, const void* c) {
+  return n % 4 == 0 && mdg_aligned16(a) && (!b || mdg_aligned16(b)) && mdg_aligned16(c);
+}
+
 
 // ---- generalised column reductions for BatchNorm1d in training mode (torchdrug MLP / chemCPA MLP batch_norm) ------
 //   mode 0: sum_r x                      mode 1: sum_r (x - center[c])^2
@@ -455,7 +511,11 @@ extern "C" int mdg_activation_fwd(const float* pre, float* y, int64_t n, int act
   MDG_CHECK_ARG(n >= 0 && activation >= MDG_ACT_NONE && activation <= MDG_ACT_SELU, "mdg_activation_fwd: bad arguments");
   if (n == 0) return MDG_OK;
   MDG_CHECK_ARG(pre && y, "mdg_activation_fwd: null pointer");
-  hipLaunchKernelGGL(act_fwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), pre, y, n, activation);
+  if (vec4_ok(n, pre, nullptr, y))
+    hipLaunchKernelGGL(elementwise4_kernel<1>, dim3(static_cast<unsigned>(mdg_cdiv(n / 4, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), pre, nullptr, y, n / 4,
+                       activation, 0.f, 0);
+  else
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), pre, y, n, activation);
   MDG_CHECK_LAUNCH("mdg_activation_fwd");
   return MDG_OK;
 }
@@ -464,8 +524,38 @@ extern "C" int mdg_activation_bwd(const float* dy, const float* pre, float* dx, 
   MDG_CHECK_ARG(n >= 0 && activation >= MDG_ACT_NONE && activation <= MDG_ACT_SELU, "mdg_activation_bwd: bad arguments");
   if (n == 0) return MDG_OK;
   MDG_CHECK_ARG(dy && pre && dx, "mdg_activation_bwd: null pointer");
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), dy, pre, dx, n, activation);
+  if (vec4_ok(n, dy, pre, dx))
+    hipLaunchKernelGGL(elementwise4_kernel<2>, dim3(static_cast<unsigned>(mdg_cdiv(n / 4, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), dy, pre, dx, n / 4,
+                       activation, 0.f, 0);
+  else
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), dy, pre, dx, n, activation);
   MDG_CHECK_LAUNCH("mdg_activation_bwd");
+  return MDG_OK;
+}
+
+extern "C" int mdg_activation_dropout_fwd(const float* pre, float* y, int64_t n, int activation, float p, uint64_t seed, void* stream) {
+  MDG_CHECK_ARG(n >= 0 && activation >= MDG_ACT_NONE && activation <= MDG_ACT_SELU && p >= 0.f && p < 1.f, "mdg_activation_dropout_fwd: bad arguments");
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(pre && y, "mdg_activation_dropout_fwd: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (vec4_ok(n, pre, nullptr, y))
+    hipLaunchKernelGGL(elementwise4_kernel<3>, dim3(static_cast<unsigned>(mdg_cdiv(n / 4, 256))), dim3(256), 0, st, pre, nullptr, y, n / 4, activation, p, seed);
+  else
+    hipLaunchKernelGGL(act_dropout_fwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, st, pre, y, n, activation, p, seed);
+  MDG_CHECK_LAUNCH("mdg_activation_dropout_fwd");
+  return MDG_OK;
+}
+
+extern "C" int mdg_activation_dropout_bwd(const float* dy, const float* pre, float* dx, int64_t n, int activation, float p, uint64_t seed, void* stream) {
+  MDG_CHECK_ARG(n >= 0 && activation >= MDG_ACT_NONE && activation <= MDG_ACT_SELU && p >= 0.f && p < 1.f, "mdg_activation_dropout_bwd: bad arguments");
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(dy && pre && dx, "mdg_activation_dropout_bwd: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (vec4_ok(n, dy, pre, dx))
+    hipLaunchKernelGGL(elementwise4_kernel<4>, dim3(static_cast<unsigned>(mdg_cdiv(n / 4, 256))), dim3(256), 0, st, dy, pre, dx, n / 4, activation, p, seed);
+  else
+    hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, st, dy, pre, dx, n, activation, p, seed);
+  MDG_CHECK_LAUNCH("mdg_activation_dropout_bwd");
   return MDG_OK;
 }
 
@@ -473,7 +563,11 @@ extern "C" int mdg_dropout(const float* x, float* y, int64_t n, float p, uint64_
   MDG_CHECK_ARG(n >= 0 && p >= 0.f && p < 1.f, "mdg_dropout: p must be in [0,1)");
   if (n == 0) return MDG_OK;
   MDG_CHECK_ARG(x && y, "mdg_dropout: null pointer");
-  hipLaunchKernelGGL(dropout_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n, p, seed);
+  if (vec4_ok(n, x, nullptr, y))
+    hipLaunchKernelGGL(elementwise4_kernel<0>, dim3(static_cast<unsigned>(mdg_cdiv(n / 4, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), x, nullptr, y, n / 4, 0, p,
+                       seed);
+  else
+    hipLaunchKernelGGL(dropout_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n, p, seed);
   MDG_CHECK_LAUNCH("mdg_dropout");
   return MDG_OK;
 }
@@ -611,8 +705,11 @@ extern "C" int mdg_axpby(const float* a, const float* b, float* out, int64_t n, 
   MDG_CHECK_ARG(n >= 0 && nb > 0 && (n % nb) == 0, "mdg_axpby: numel(b) must divide numel(a)");
   if (n == 0) return MDG_OK;
   MDG_CHECK_ARG(a && b && out, "mdg_axpby: null pointer");
-  hipLaunchKernelGGL(axpby_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, out, n, nb,
-                     alpha, beta);
+  if (nb == n && vec4_ok(n, a, b, out))
+    hipLaunchKernelGGL(axpby4_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n / 4, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, out, n / 4, alpha, beta);
+  else
+    hipLaunchKernelGGL(axpby_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, out, n, nb,
+                       alpha, beta);
   MDG_CHECK_LAUNCH("mdg_axpby");
   return MDG_OK;
 }

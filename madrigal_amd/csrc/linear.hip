@@ -270,6 +270,9 @@ struct LinearArgs {
   int64_t a_ldx, a_k;              // operand image of it exists -- the kernel rounds / splits it while staging (no pre-pass over x)
   int sk_tiles;                    // 256-tile kernel, stream-K hybrid: the last sk_tiles tiles are shared k tile by k tile (0: one tile per workgroup)
   char* sk_ws;                     // its workspace: accumulator slots | flags
+  // training: dropout of the activated output inside the epilogue (before the residual is added): element (m, n) is kept iff
+  // mdg_keep(drop_seed, m * N + n, drop_thr) -- the mask mdg_dropout applies to a contiguous [M, N] tensor -- and scaled by drop_scale
+  uint64_t drop_seed; uint32_t drop_thr; float drop_scale;
 };
 
 // Workgroups are dealt to the 8 XCDs round-robin in dispatch order, and each XCD has its own L2.  With the plain
@@ -457,6 +460,11 @@ __device__ __forceinline__ void slab_to_global(const LinearArgs& p, const float*
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = finish(p, a[e], bias[e], scale[e], shift[e]);
+    if (p.drop_thr) {
+      const uint64_t i0 = static_cast<uint64_t>(m) * static_cast<uint64_t>(p.N) + static_cast<uint64_t>(n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = mdg_keep(p.drop_seed, i0 + e, p.drop_thr) ? o[e] * p.drop_scale : 0.f;
+    }
     if (p.res) {
       const float* rr = p.res + m * p.ldr + n;
       if (full && p.vec_r) {
@@ -981,6 +989,7 @@ struct PrepBArgs {
   int64_t M, N, Np, Mp;
   char* row_img; char* t_img; float* part;
   int x3;
+  uint64_t drop_seed; uint32_t drop_thr; float drop_scale;      // g = dropout-backward of the incoming gradient (mask of element m * N + n), applied on load
 };
 
 __global__ __launch_bounds__(256) void prep_backward_kernel(const PrepBArgs p) {
@@ -992,7 +1001,8 @@ __global__ __launch_bounds__(256) void prep_backward_kernel(const PrepBArgs p) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int64_t m = m0 + ty + 4 * i, c = c0 + tx;
-    const float v = (m < p.M && c < p.N) ? p.g[m * p.ld + c] : 0.f;
+    float v = (m < p.M && c < p.N) ? p.g[m * p.ld + c] : 0.f;
+    if (p.drop_thr) v = mdg_keep(p.drop_seed, static_cast<uint64_t>(m) * static_cast<uint64_t>(p.N) + static_cast<uint64_t>(c), p.drop_thr) ? v * p.drop_scale : 0.f;
     tile[ty + 4 * i][tx] = v;
     cs += v;
   }
@@ -1277,11 +1287,12 @@ extern "C" size_t mdg_linear_packed_x_workspace_bytes(int64_t M, int64_t N, int6
   return (w_is_packed ? 0 : image_bytes(N, K, precision)) + (pp_shape(precision, M, N) ? pp::sk_bytes() : 0);
 }
 
-extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const void* w_packed, float* y, int64_t ldy,
-                          int64_t M, int64_t N, int64_t K, const float* bias, const float* scale, const float* shift, int act,
-                          const float* residual, int64_t ldr, float alpha, float beta, int precision, void* workspace,
-                          size_t workspace_bytes, void* stream) {
+static int linear_impl(const float* x, int64_t ldx, const float* w, int64_t ldw, const void* w_packed, float* y, int64_t ldy,
+                       int64_t M, int64_t N, int64_t K, const float* bias, const float* scale, const float* shift, int act,
+                       const float* residual, int64_t ldr, float alpha, float beta, int precision, void* workspace,
+                       size_t workspace_bytes, void* stream, float drop_p, uint64_t drop_seed) {
   MDG_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "mdg_linear: negative size");
+  MDG_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "mdg_linear: dropout p must be in [0,1)");
   if (M == 0 || N == 0) return MDG_OK;
   MDG_CHECK_ARG(x && (w || w_packed) && y, "mdg_linear: null pointer");
   MDG_CHECK_ARG(K > 0 && K % 4 == 0 && ldx % 4 == 0 && ldx >= K && (w_packed || (ldw % 4 == 0 && ldw >= K)),
@@ -1316,9 +1327,30 @@ extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t l
   set_operand(a.A, x, ldx, ximg, M, K, precision);
   if (rawx) { a.a_raw = x; a.a_ldx = ldx; a.a_k = K; a.A.nrows = M; }
   set_operand(a.B, w, ldw, wb == 0 ? nullptr : (w_packed ? static_cast<const char*>(w_packed) : wimg), N, K, precision);
+  if (drop_p > 0.f) {
+    const double thr = static_cast<double>(drop_p) * 4294967296.0;      // mdg_drop_threshold on the host
+    a.drop_thr = static_cast<uint32_t>(thr);
+    a.drop_seed = drop_seed;
+    a.drop_scale = 1.0f / (1.0f - drop_p);
+  }
   launch_linear_core(a, precision, M, N, st, workspace ? ws + need : nullptr, workspace_bytes > need ? workspace_bytes - need : 0);
   MDG_CHECK_LAUNCH("mdg_linear");
   return MDG_OK;
+}
+
+extern "C" int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const void* w_packed, float* y, int64_t ldy,
+                          int64_t M, int64_t N, int64_t K, const float* bias, const float* scale, const float* shift, int act,
+                          const float* residual, int64_t ldr, float alpha, float beta, int precision, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  return linear_impl(x, ldx, w, ldw, w_packed, y, ldy, M, N, K, bias, scale, shift, act, residual, ldr, alpha, beta, precision, workspace, workspace_bytes,
+                     stream, 0.f, 0);
+}
+
+extern "C" int mdg_linear_dropout(const float* x, int64_t ldx, const float* w, int64_t ldw, const void* w_packed, float* y, int64_t ldy,
+                                  int64_t M, int64_t N, int64_t K, const float* bias, int act, const float* residual, int64_t ldr, float beta,
+                                  float drop_p, uint64_t drop_seed, int precision, void* workspace, size_t workspace_bytes, void* stream) {
+  return linear_impl(x, ldx, w, ldw, w_packed, y, ldy, M, N, K, bias, nullptr, nullptr, act, residual, ldr, 1.0f, beta, precision, workspace,
+                     workspace_bytes, stream, drop_p, drop_seed);
 }
 
 // ---- grouped launch: see the GROUPED kernel variant -------------------------------------------------------------------------
@@ -1418,7 +1450,8 @@ extern "C" size_t mdg_linear_backward_pack_bytes(int64_t M, int64_t N, int preci
 }
 
 extern "C" int mdg_linear_backward_pack(const float* g, int64_t ldg, int64_t M, int64_t N, int precision, void* row_image, void* t_image,
-                                        float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+                                        float* dbias, float drop_p, uint64_t drop_seed, void* workspace, size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "mdg_linear_backward_pack: dropout p must be in [0,1)");
   MDG_CHECK_ARG(M > 0 && N > 0 && g && ldg >= N, "mdg_linear_backward_pack: empty operand / short row stride");
   MDG_CHECK_ARG(precision == MDG_PREC_BF16 || precision == MDG_PREC_BF16X3, "mdg_linear_backward_pack: a 16-bit operand mode");
   MDG_CHECK_ARG(t_image && mdg_aligned16(t_image) && (!row_image || mdg_aligned16(row_image)), "mdg_linear_backward_pack: null / misaligned image");
@@ -1430,7 +1463,12 @@ extern "C" int mdg_linear_backward_pack(const float* g, int64_t ldg, int64_t M, 
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   PrepBArgs a{g, ldg, M, N, pad64(N), pad64(M), static_cast<char*>(row_image), static_cast<char*>(t_image), dbias ? static_cast<float*>(workspace) : nullptr,
-              precision == MDG_PREC_BF16X3 ? 1 : 0};
+              precision == MDG_PREC_BF16X3 ? 1 : 0, 0, 0, 1.f};
+  if (drop_p > 0.f) {
+    a.drop_thr = static_cast<uint32_t>(static_cast<double>(drop_p) * 4294967296.0);
+    a.drop_seed = drop_seed;
+    a.drop_scale = 1.0f / (1.0f - drop_p);
+  }
   hipLaunchKernelGGL(prep_backward_kernel, dim3(static_cast<unsigned>(a.Mp / 64), static_cast<unsigned>(a.Np / 64)), dim3(256), 0, st, a);
   if (dbias)
     hipLaunchKernelGGL(prep_backward_bias_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N, 256))), dim3(256), 0, st, static_cast<const float*>(workspace), dbias,

@@ -69,6 +69,11 @@ def _linT(x, w, b=None, act=None):
     return ag.linear(x, w, b, act, _state["precision"])
 
 
+def _linT_drop(x, w, b, act, drop: nn.Dropout, residual=None):
+    """residual + drop(act(x W^T + b)) as one autograd node (dropout inside the dense block: autograd._Linear)."""
+    return ag.linear_dropout(x, w, b, act, _state["precision"], drop.p, drop.training, residual)
+
+
 def _require_eval(m: nn.Module) -> None:
     """Guard of the few modules that have no differentiated / training-mode path (stand-alone position encoders, the
     SimCLR projection head): refuse rather than return tensors without a graph."""
@@ -1116,22 +1121,22 @@ class TransformerFusion(nn.Module):
             att = attend(_linT(x, sa.in_proj_weight, sa.in_proj_bias), p_att)
             return att
 
-        def ff_block(x):
-            u = ag.dropout(_linT(x, L.linear1.weight, L.linear1.bias, self.actn), L.dropout.p, L.dropout.training)
-            return ag.dropout(_linT(u, L.linear2.weight, L.linear2.bias), L.dropout2.p, L.dropout2.training)
+        # the three dropouts live inside their dense blocks (GEMM epilogue / activation pass; backward inside the gradient's packing
+        # pass) and the residual adds inside the epilogues: x + dropout(linear(...)) is one node and one launch
+        def ff_block(x, residual):
+            u = _linT_drop(x, L.linear1.weight, L.linear1.bias, self.actn, L.dropout)
+            return _linT_drop(u, L.linear2.weight, L.linear2.bias, None, L.dropout2, residual)
         if self.norm_first:
             att = sa_block(ag.layernorm(h, L.norm1.weight, L.norm1.bias, L.norm1.eps))
             if keep_rows is not None:
                 att, h = att.index_select(0, keep_rows), h.index_select(0, keep_rows)
-            o = ag.dropout(_linT(att, sa.out_proj.weight, sa.out_proj.bias), L.dropout1.p, L.dropout1.training)
-            h = ag.add(h, o)
-            return ag.add(h, ff_block(ag.layernorm(h, L.norm2.weight, L.norm2.bias, L.norm2.eps)))
+            h = _linT_drop(att, sa.out_proj.weight, sa.out_proj.bias, None, L.dropout1, h)
+            return ff_block(ag.layernorm(h, L.norm2.weight, L.norm2.bias, L.norm2.eps), h)
         att = sa_block(h)
         if keep_rows is not None:
             att, h = att.index_select(0, keep_rows), h.index_select(0, keep_rows)
-        o = ag.dropout(_linT(att, sa.out_proj.weight, sa.out_proj.bias), L.dropout1.p, L.dropout1.training)
-        h = ag.layernorm(ag.add(h, o), L.norm1.weight, L.norm1.bias, L.norm1.eps)
-        return ag.layernorm(ag.add(h, ff_block(h)), L.norm2.weight, L.norm2.bias, L.norm2.eps)
+        h = ag.layernorm(_linT_drop(att, sa.out_proj.weight, sa.out_proj.bias, None, L.dropout1, h), L.norm1.weight, L.norm1.bias, L.norm1.eps)
+        return ag.layernorm(ff_block(h, h), L.norm2.weight, L.norm2.bias, L.norm2.eps)
 
     def _x_attn_pool_train(self, h_keys, n, Tk):
         d, H, dh = self.latent_dim, self.num_heads, self.head_dim

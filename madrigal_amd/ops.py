@@ -226,13 +226,15 @@ def _rows2d(x: torch.Tensor, name: str):
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, scale=None, shift=None,
            act=None, residual: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 1.0,
            precision="bf16x3", out: Optional[torch.Tensor] = None, cache_weight: bool = True,
-           weight_image: Optional[torch.Tensor] = None) -> torch.Tensor:
+           weight_image: Optional[torch.Tensor] = None, dropout_p: float = 0.0, dropout_seed: int = 0) -> torch.Tensor:
     """y = alpha * act((x W^T + b) * scale + shift) + beta * residual   (nn.Linear layout W [N,K]).
 
     ``x`` may be a strided 2-D view (row stride a multiple of 4); ``residual`` may be [N] / [1,N]
     (broadcast over rows) or [M,N].  ``cache_weight``: keep the packed image of ``weight`` (hi/lo bf16 planes, K
     padded) and reuse it while the tensor is unchanged; pass False for one-shot "weights" (e.g. InfoNCE's F F^T).
-    ``weight_image``: the (padded) weight's image when the caller keeps one (transposed_weight_image)."""
+    ``weight_image``: the (padded) weight's image when the caller keeps one (transposed_weight_image).
+    ``dropout_p`` > 0 (training): y = dropout(act(x W^T + b)) + beta * residual, the mask of ``dropout(.., p, seed)`` on the contiguous
+    result applied inside the epilogue (mdg_linear_dropout; no scale / shift, alpha = 1)."""
     forward_only(x, weight, bias, residual)
     if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.shape[1] % 4 == 0 and x.data_ptr() % 16 == 0 \
             and x.is_cuda and x.dtype == torch.float32:
@@ -269,6 +271,14 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     wimg = weight_image if weight_image is not None else (packed_weight_image(w, prec) if cache_weight else None)
     nbytes = lib().mdg_linear_workspace_bytes(_c64(M), _c64(N), _c64(K), _c(prec), _c(1 if wimg is not None else 0))
     ws = _workspace(nbytes, x2.device)
+    if dropout_p > 0.0:
+        if scale is not None or shift is not None or alpha != 1.0 or not out.is_contiguous():
+            raise ValueError("linear: the dropout epilogue takes no scale / shift / alpha and a contiguous result")
+        check(lib().mdg_linear_dropout(_ptr(x2), _c64(x2.stride(0)), _ptr(w), _c64(w.stride(0)), _ptr(wimg), _ptr(out), _c64(out.stride(0)),
+                                       _c64(M), _c64(N), _c64(K), _ptr(None if bias is None else bias.detach().contiguous()), _c(ACTS[act]),
+                                       _ptr(residual), _c64(ldr), _f(beta), _f(dropout_p), ctypes.c_uint64(dropout_seed & (2 ** 64 - 1)), _c(prec),
+                                       _ptr(ws), ctypes.c_size_t(nbytes), _stream(x2)), "mdg_linear_dropout")
+        return out.view(*lead, N) if len(lead) != 1 or lead[0] != M else out
     check(lib().mdg_linear(_ptr(x2), _c64(x2.stride(0)), _ptr(w), _c64(w.stride(0)), _ptr(wimg), _ptr(out), _c64(out.stride(0)),
                            _c64(M), _c64(N), _c64(K), _ptr(None if bias is None else bias.detach().contiguous()),
                            _ptr(None if scale is None else scale.contiguous()), _ptr(None if shift is None else shift.contiguous()),
@@ -792,9 +802,11 @@ def wide_weight_gradient(N: int, K: int) -> bool:
     return ((N + 127) // 128) * ((K + 127) // 128) >= 96
 
 
-def linear_backward_pack(g: torch.Tensor, precision, want_bias: bool = False, want_row_image: bool = True):
+def linear_backward_pack(g: torch.Tensor, precision, want_bias: bool = False, want_row_image: bool = True, dropout_p: float = 0.0,
+                         dropout_seed: int = 0):
     """One pass over g = dL/dy [M,N] (contiguous rows, 16-bit operand mode) -> (operand image of g | None, image of g^T, column sums
-    of g | None): what the dx GEMM, the dW GEMM and the bias gradient of a wide dense block read (mdg_linear_backward_pack)."""
+    of g | None): what the dx GEMM, the dW GEMM and the bias gradient of a wide dense block read (mdg_linear_backward_pack).
+    ``dropout_p`` > 0: g is the incoming gradient of a block that ended in dropout(p, seed); the mask is applied while g is read."""
     if g.dim() != 2 or not g.is_cuda or g.dtype != torch.float32 or g.stride(1) != 1:
         raise ValueError("linear_backward_pack: g must be a 2-D fp32 cuda tensor with unit inner stride")
     prec = _prec(precision)
@@ -809,8 +821,11 @@ def linear_backward_pack(g: torch.Tensor, precision, want_bias: bool = False, wa
     db = torch.empty(N, dtype=torch.float32, device=g.device) if want_bias else None
     nbytes = int(L_.mdg_linear_backward_pack_bytes(_c64(M), _c64(N), _c(prec), _c(2))) if want_bias else 0
     ws = _workspace(nbytes, g.device)
-    check(L_.mdg_linear_backward_pack(_ptr(g), _c64(g.stride(0)), _c64(M), _c64(N), _c(prec), _ptr(row_img), _ptr(t_img), _ptr(db), _ptr(ws),
-                                      ctypes.c_size_t(nbytes), _stream(g)), "mdg_linear_backward_pack")
+    if dropout_p > 0.0 and g.stride(0) != N:
+        raise ValueError("linear_backward_pack: the dropout mask is indexed by the contiguous [M,N] position")
+    check(L_.mdg_linear_backward_pack(_ptr(g), _c64(g.stride(0)), _c64(M), _c64(N), _c(prec), _ptr(row_img), _ptr(t_img), _ptr(db), _f(dropout_p),
+                                      ctypes.c_uint64(dropout_seed & (2 ** 64 - 1)), _ptr(ws), ctypes.c_size_t(nbytes), _stream(g)),
+          "mdg_linear_backward_pack")
     return row_img, t_img, db
 
 
@@ -867,6 +882,26 @@ def dropout(x: torch.Tensor, p: float, seed: int) -> torch.Tensor:
     y = torch.empty_like(x)
     check(lib().mdg_dropout(_ptr(x), _ptr(y), _c64(x.numel()), _f(p), ctypes.c_uint64(seed & (2 ** 64 - 1)), _stream(x)), "mdg_dropout")
     return y
+
+
+def activation_dropout_fwd(pre: torch.Tensor, act, p: float, seed: int) -> torch.Tensor:
+    """dropout(act(pre), p, seed) in one pass (same mask as ``dropout``)."""
+    pre = _f32_cuda(pre, "pre")
+    y = torch.empty_like(pre)
+    check(lib().mdg_activation_dropout_fwd(_ptr(pre), _ptr(y), _c64(pre.numel()), _c(ACTS[act]), _f(p), ctypes.c_uint64(seed & (2 ** 64 - 1)), _stream(pre)),
+          "mdg_activation_dropout_fwd")
+    return y
+
+
+def activation_dropout_bwd(dy: torch.Tensor, pre: torch.Tensor, act, p: float, seed: int) -> torch.Tensor:
+    """act'(pre) * dropout-backward(dy) in one pass."""
+    dy, pre = _f32_cuda(dy, "dy"), _f32_cuda(pre, "pre")
+    if dy.shape != pre.shape:
+        raise ValueError("activation_dropout_bwd: shape mismatch")
+    dx = torch.empty_like(dy)
+    check(lib().mdg_activation_dropout_bwd(_ptr(dy), _ptr(pre), _ptr(dx), _c64(dy.numel()), _c(ACTS[act]), _f(p), ctypes.c_uint64(seed & (2 ** 64 - 1)),
+                                           _stream(dy)), "mdg_activation_dropout_bwd")
+    return dx
 
 
 def batchnorm_train_fwd(x: torch.Tensor, gamma, beta, running_mean, running_var, eps: float, momentum: float, act=None):

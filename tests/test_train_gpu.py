@@ -1529,3 +1529,46 @@ def test_wide_block_backward_from_one_pass_over_g(M, N, K, prec, tol):
     wp.grad = None
     y2.backward(g)
     assert torch.equal(xr.grad, dx) and torch.equal(wp.grad, dw)
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16", "f32"])
+@pytest.mark.parametrize("M,N,K,act,with_res", [(300, 128, 64, None, True), (1000, 1280, 1300, None, True), (513, 1024, 2048, "gelu", False),
+                                                (70, 96, 40, "relu", False), (257, 2048, 1024, None, False)])
+def test_dense_block_with_dropout_and_residual_inside_equals_the_separate_nodes(M, N, K, act, with_res, prec):
+    """autograd.linear_dropout: residual + dropout(act(x W^T + b)) as ONE node -- the mask applied in the GEMM epilogue (or with the
+    activation), its backward while the gradient is packed for the backward GEMMs (wide blocks) -- against the reference's
+    composition add(residual, dropout(linear(...))) through the separate nodes with the same seed: values and every gradient
+    bit-identical (narrow and wide blocks, activation or not)."""
+    from madrigal_amd import autograd as ag
+    x0, w0, b0 = _rand(M, K, seed=11).to(DEV), _rand(N, K, seed=12, scale=0.05).to(DEV), _rand(N, seed=13).to(DEV)
+    r0 = _rand(M, N, seed=14).to(DEV) if with_res else None
+    dy = _rand(M, N, seed=15).to(DEV)
+    p, seed = 0.3, 12345
+
+    def run(fused):
+        x = x0.clone().requires_grad_(True)
+        w, b = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(b0.clone())
+        r = r0.clone().requires_grad_(True) if with_res else None
+        if fused:
+            y = ag.linear_dropout(x, w, b, act, prec, p, True, r, seed=seed)
+        else:
+            y = ag.dropout(ag.linear(x, w, b, act, prec), p, True, seed=seed)
+            if with_res:
+                y = ag.add(r, y)
+        y.backward(dy)
+        return y.detach(), x.grad, w.grad, b.grad, (r.grad if with_res else None)
+    got, ref = run(True), run(False)
+    for a, b_, nm in zip(got, ref, ("y", "dx", "dW", "db", "d residual")):
+        if a is None:
+            assert b_ is None
+            continue
+        if nm == "db" and N % 64 == 0 and prec != "f32" and ((N + 127) // 128) * ((K + 127) // 128) >= 96:
+            _close(a, b_, 2e-6, nm)                   # the wide path sums the bias gradient in 64-row blocks (other order)
+        else:
+            assert torch.equal(a, b_), nm
+    zero_frac = float((got[0] - (r0 if with_res else 0) == 0).float().mean())
+    assert 0.2 < zero_frac < 0.4 or act == "relu"          # p = 0.3 of the block's output is dropped
+    # eval mode / p = 0: the plain block
+    y_eval = ag.linear_dropout(x0, w0, b0, act, prec, p, False, r0)
+    y_plain = ag.linear(x0, w0, b0, act, prec)
+    assert torch.equal(y_eval, y_plain + r0 if with_res else y_plain)
