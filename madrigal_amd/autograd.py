@@ -636,14 +636,16 @@ class _GatherRows(Function):
         # the index tensor of an embedding lookup is fixed for a run (cell-line ids of the tx stack): its sort is kept per
         # (storage, version, table size); the entry holds the tensor, so the address cannot be recycled under it
         key = (idx.data_ptr(), idx._version, idx.numel(), ctx.n_rows)
-        hit = _gather_plan.get("last")
-        if hit is None or hit[0] != key:
+        hit = _gather_plan.get(key)
+        if hit is None:
             order = torch.argsort(idx, stable=True)
             # row pointers by binary search in the sorted indices: no host synchronisation (torch.bincount reads the maximum
             # back to the host, which would stall the launch queue in the middle of the backward pass)
             rowptr = torch.searchsorted(idx[order], torch.arange(ctx.n_rows + 1, device=idx.device))
             hit = (key, order.contiguous(), rowptr, idx)
-            _gather_plan["last"] = hit
+            while len(_gather_plan) >= 8:                 # a handful of lookup sites per model (head / tail side, views): oldest out
+                _gather_plan.pop(next(iter(_gather_plan)))
+            _gather_plan[key] = hit
         order, rowptr = hit[1], hit[2]
         return ops.csr_aggregate(dout, rowptr, order)[:, :dout.shape[1]], None
 
