@@ -273,6 +273,9 @@ struct LinearArgs {
   // training: dropout of the activated output inside the epilogue (before the residual is added): element (m, n) is kept iff
   // mdg_keep(drop_seed, m * N + n, drop_thr) -- the mask mdg_dropout applies to a contiguous [M, N] tensor -- and scaled by drop_scale
   uint64_t drop_seed; uint32_t drop_thr; float drop_scale;
+  // 128-tile kernel, split-K (ks_count > 1, grid.y = splits): split z multiplies the k range [z * ks_len, min(K, (z + 1) * ks_len)) and
+  // writes the plain partial product to y + z * ks_stride (no bias / activation / residual: mdg_linear_tn sums the partials afterwards)
+  int ks_count; int64_t ks_len, ks_stride;
 };
 
 // Workgroups are dealt to the 8 XCDs round-robin in dispatch order, and each XCD has its own L2.  With the plain
@@ -526,6 +529,15 @@ __global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs 
     if (!tile_of(p, static_cast<int>(blockIdx.x), tx, ty)) return;   // workgroup-uniform
     col0 = static_cast<int64_t>(tx) * S::BN;
     row0 = static_cast<int64_t>(ty) * S::BM;
+    if (pk.ks_count > 1) {                                           // split-K: this workgroup's k range and partial result
+      const int64_t z = blockIdx.y, k_begin = z * pk.ks_len;
+      p.K = pk.K - k_begin < pk.ks_len ? pk.K - k_begin : pk.ks_len;
+      p.A.p0 += k_begin * p.A.kb;
+      p.B.p0 += k_begin * p.B.kb;
+      if (p.A.p1) p.A.p1 += k_begin * p.A.kb;
+      if (p.B.p1) p.B.p1 += k_begin * p.B.kb;
+      p.y += z * pk.ks_stride;
+    }
   }
   float* const slab = reinterpret_cast<float*>(smem) + wave * 4096;
   const int64_t pm0 = row0 + wr * 32 * MT, pn0 = col0 + wc * 64;
@@ -1240,7 +1252,8 @@ static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t 
     return;
   }
   using S = Small;
-  const dim3 grid = grid_for(S::BM, S::BN);
+  dim3 grid = grid_for(S::BM, S::BN);
+  if (a.ks_count > 1) grid.y = static_cast<unsigned>(mdg_cdiv(a.K, a.ks_len));
   const size_t lds = 2 * S::STAGE;
   if (precision == MDG_PREC_F32) hipLaunchKernelGGL((linear_kernel<MDG_PREC_F32, S, 32>), grid, dim3(S::THREADS), lds, st, a);
   else if (a.a_raw) {                                         // x straight from its fp32 rows
@@ -1407,8 +1420,51 @@ static size_t image_bytes_t(int64_t rows, int64_t inner, int precision) {      /
   return al256(static_cast<size_t>(rows) * Mp * (precision == MDG_PREC_BF16 ? 2 : 4));
 }
 
+// y[i] = sum_z part[z][i] (split-K partials of mdg_linear_tn), 16 bytes per thread, fixed order
+__global__ __launch_bounds__(256) void ksplit_sum_kernel(const float* __restrict__ part, float* __restrict__ y, int64_t n4, int64_t stride, int splits) {
+  const int64_t q = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (q >= n4) return;
+  f32x4 s = reinterpret_cast<const f32x4*>(part)[q];
+  for (int z = 1; z < splits; ++z) s += reinterpret_cast<const f32x4*>(part + z * stride)[q];
+  reinterpret_cast<f32x4*>(y)[q] = s;
+}
+
+// Weight-gradient products with few output tiles (dW [2048, 1024] over 22 016 rows: 128 tiles of 128 x 128, half the CUs idle for the
+// whole K loop): the K range is split over grid.y so that ~256 workgroups run, partial products summed afterwards.
+static int tn_splits(int precision, int64_t N, int64_t K, int64_t Mp) {
+  static MdgEnvInt sw{"MDG_LINEAR_TN_SPLITK", 1};
+  if (!sw.get() || choose_big(precision, N, K) || K % 4 != 0) return 1;
+  const int64_t tiles = mdg_cdiv(N, Small::BM) * mdg_cdiv(K, Small::BN);
+  if (tiles >= 192 || Mp < 4096) return 1;
+  int64_t s = 256 / tiles;
+  if (s > 8) s = 8;
+  while (s > 1 && Mp / s < 1024) --s;
+  return static_cast<int>(s < 1 ? 1 : s);
+}
+static size_t tn_split_bytes(int precision, int64_t N, int64_t K, int64_t Mp) {
+  const int s = tn_splits(precision, N, K, Mp);
+  return s > 1 ? al256(static_cast<size_t>(s) * N * K * sizeof(float)) : 0;
+}
+// launches the TN product a (A = g^T image, B = x^T image, K = Mp) into y [N, ldy = K]: split over k when that fills the chip
+static void launch_tn(LinearArgs& a, int precision, int64_t N, int64_t K, int64_t Mp, hipStream_t st, char* ws, size_t ws_bytes) {
+  const int s = tn_splits(precision, N, K, Mp);
+  const size_t pb = s > 1 ? al256(static_cast<size_t>(s) * N * K * sizeof(float)) : 0;
+  if (s > 1 && ws && ws_bytes >= pb && a.ldy == K && mdg_aligned16(ws)) {
+    float* const y = a.y;
+    a.y = reinterpret_cast<float*>(ws);
+    a.ks_count = s;
+    a.ks_len = pad64(mdg_cdiv(Mp, s));
+    a.ks_stride = N * K;
+    launch_linear_core(a, precision, N, K, st, nullptr, 0);
+    hipLaunchKernelGGL(ksplit_sum_kernel, dim3(static_cast<unsigned>(mdg_cdiv(N * K / 4, 256))), dim3(256), 0, st, reinterpret_cast<const float*>(ws), y, N * K / 4,
+                       N * K, static_cast<int>(mdg_cdiv(Mp, a.ks_len)));
+    return;
+  }
+  launch_linear_core(a, precision, N, K, st, ws, ws_bytes);
+}
+
 extern "C" size_t mdg_linear_tn_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision) {
-  return image_bytes_t(N, M, precision) + image_bytes_t(K, M, precision) + (pp_shape(precision, N, K) ? pp::sk_bytes() : 0);
+  return image_bytes_t(N, M, precision) + image_bytes_t(K, M, precision) + (pp_shape(precision, N, K) ? pp::sk_bytes() : 0) + tn_split_bytes(precision, N, K, pad64(M));
 }
 
 extern "C" int mdg_linear_tn(const float* g, int64_t ldg, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K,
@@ -1436,7 +1492,8 @@ extern "C" int mdg_linear_tn(const float* g, int64_t ldg, const float* x, int64_
   a.y = y; a.ldy = ldy; a.alpha = 1.f; a.beta = 0.f; a.act = MDG_ACT_NONE; a.M = N; a.N = K; a.K = Mp;
   set_image(a.A, aimg, N, Mp, precision);
   set_image(a.B, bimg, K, Mp, precision);
-  launch_linear_core(a, precision, N, K, st, aimg + ab + bb, workspace_bytes - ab - bb);
+  if (precision == MDG_PREC_F32) launch_linear_core(a, precision, N, K, st, aimg + ab + bb, workspace_bytes - ab - bb);
+  else launch_tn(a, precision, N, K, Mp, st, aimg + ab + bb, workspace_bytes - ab - bb);
   MDG_CHECK_LAUNCH("mdg_linear_tn");
   return MDG_OK;
 }
@@ -1478,7 +1535,7 @@ extern "C" int mdg_linear_backward_pack(const float* g, int64_t ldg, int64_t M, 
 }
 
 extern "C" size_t mdg_linear_tn_packed_g_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision) {
-  return image_bytes_t(K, M, precision) + (pp_shape(precision, N, K) ? pp::sk_bytes() : 0);
+  return image_bytes_t(K, M, precision) + (pp_shape(precision, N, K) ? pp::sk_bytes() : 0) + tn_split_bytes(precision, N, K, pad64(M));
 }
 
 // dW [N, K] = g^T x with the image of g^T already made (mdg_linear_backward_pack); x [M, K] is re-laid out here.
@@ -1505,7 +1562,7 @@ extern "C" int mdg_linear_tn_packed_g(const void* gt_image, const float* x, int6
   a.y = y; a.ldy = ldy; a.alpha = 1.f; a.beta = 0.f; a.act = MDG_ACT_NONE; a.M = N; a.N = K; a.K = Mp;
   set_image(a.A, static_cast<const char*>(gt_image), N, Mp, precision);
   set_image(a.B, bimg, K, Mp, precision);
-  launch_linear_core(a, precision, N, K, st, bimg + bb, workspace_bytes - bb);
+  launch_tn(a, precision, N, K, Mp, st, bimg + bb, workspace_bytes - bb);
   MDG_CHECK_LAUNCH("mdg_linear_tn_packed_g");
   return MDG_OK;
 }
