@@ -168,14 +168,15 @@ __global__ __launch_bounds__(256) void elementwise4_kernel(const float* __restri
   const uint32_t thr = mdg_drop_threshold(p);
   const float scale = 1.0f / (1.0f - p);
   f32x4 o;
+  uint64_t word = 0;
+  if constexpr (MODE == 0 || MODE == 3 || MODE == 4) word = mdg_keep_word(seed, static_cast<uint64_t>(q));      // elements 4q .. 4q+3: one hash
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const uint64_t i = static_cast<uint64_t>(q) * 4 + e;
-    if constexpr (MODE == 0) o[e] = mdg_keep(seed, i, thr) ? va[e] * scale : 0.f;
+    if constexpr (MODE == 0) o[e] = mdg_keep_field(word, e, thr) ? va[e] * scale : 0.f;
     else if constexpr (MODE == 1) o[e] = act_fwd(va[e], act);
     else if constexpr (MODE == 2) o[e] = va[e] * act_grad(vb[e], act);
-    else if constexpr (MODE == 3) { const float y = act_fwd(va[e], act); o[e] = mdg_keep(seed, i, thr) ? y * scale : 0.f; }
-    else { const float g = mdg_keep(seed, i, thr) ? va[e] * scale : 0.f; o[e] = g * act_grad(vb[e], act); }
+    else if constexpr (MODE == 3) { const float y = act_fwd(va[e], act); o[e] = mdg_keep_field(word, e, thr) ? y * scale : 0.f; }
+    else { const float g = mdg_keep_field(word, e, thr) ? va[e] * scale : 0.f; o[e] = g * act_grad(vb[e], act); }
   }
   reinterpret_cast<f32x4*>(out)[q] = o;
 }

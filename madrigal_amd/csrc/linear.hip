@@ -463,10 +463,16 @@ __device__ __forceinline__ void slab_to_global(const LinearArgs& p, const float*
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = finish(p, a[e], bias[e], scale[e], shift[e]);
-    if (p.drop_thr) {
+    if (p.drop_scale != 0.f) {
       const uint64_t i0 = static_cast<uint64_t>(m) * static_cast<uint64_t>(p.N) + static_cast<uint64_t>(n);
+      if ((p.N & 3) == 0) {                               // n is a multiple of 4: the lane's four columns are one hash group
+        const uint64_t word = mdg_keep_word(p.drop_seed, i0 >> 2);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = mdg_keep(p.drop_seed, i0 + e, p.drop_thr) ? o[e] * p.drop_scale : 0.f;
+        for (int e = 0; e < 4; ++e) o[e] = mdg_keep_field(word, e, p.drop_thr) ? o[e] * p.drop_scale : 0.f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = mdg_keep(p.drop_seed, i0 + e, p.drop_thr) ? o[e] * p.drop_scale : 0.f;
+      }
     }
     if (p.res) {
       const float* rr = p.res + m * p.ldr + n;
@@ -1014,7 +1020,7 @@ __global__ __launch_bounds__(256) void prep_backward_kernel(const PrepBArgs p) {
   for (int i = 0; i < 16; ++i) {
     const int64_t m = m0 + ty + 4 * i, c = c0 + tx;
     float v = (m < p.M && c < p.N) ? p.g[m * p.ld + c] : 0.f;
-    if (p.drop_thr) v = mdg_keep(p.drop_seed, static_cast<uint64_t>(m) * static_cast<uint64_t>(p.N) + static_cast<uint64_t>(c), p.drop_thr) ? v * p.drop_scale : 0.f;
+    if (p.drop_scale != 0.f) v = mdg_keep(p.drop_seed, static_cast<uint64_t>(m) * static_cast<uint64_t>(p.N) + static_cast<uint64_t>(c), p.drop_thr) ? v * p.drop_scale : 0.f;
     tile[ty + 4 * i][tx] = v;
     cs += v;
   }
@@ -1341,8 +1347,7 @@ static int linear_impl(const float* x, int64_t ldx, const float* w, int64_t ldw,
   if (rawx) { a.a_raw = x; a.a_ldx = ldx; a.a_k = K; a.A.nrows = M; }
   set_operand(a.B, w, ldw, wb == 0 ? nullptr : (w_packed ? static_cast<const char*>(w_packed) : wimg), N, K, precision);
   if (drop_p > 0.f) {
-    const double thr = static_cast<double>(drop_p) * 4294967296.0;      // mdg_drop_threshold on the host
-    a.drop_thr = static_cast<uint32_t>(thr);
+    a.drop_thr = mdg_drop_threshold(drop_p);
     a.drop_seed = drop_seed;
     a.drop_scale = 1.0f / (1.0f - drop_p);
   }
@@ -1520,9 +1525,9 @@ extern "C" int mdg_linear_backward_pack(const float* g, int64_t ldg, int64_t M, 
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   PrepBArgs a{g, ldg, M, N, pad64(N), pad64(M), static_cast<char*>(row_image), static_cast<char*>(t_image), dbias ? static_cast<float*>(workspace) : nullptr,
-              precision == MDG_PREC_BF16X3 ? 1 : 0, 0, 0, 1.f};
+              precision == MDG_PREC_BF16X3 ? 1 : 0, 0, 0, 0.f};
   if (drop_p > 0.f) {
-    a.drop_thr = static_cast<uint32_t>(static_cast<double>(drop_p) * 4294967296.0);
+    a.drop_thr = mdg_drop_threshold(drop_p);
     a.drop_seed = drop_seed;
     a.drop_scale = 1.0f / (1.0f - drop_p);
   }

@@ -70,17 +70,21 @@ __device__ __forceinline__ uint32_t mdg_order_key(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// counter-based random bits (splitmix64 finaliser, high word): dropout masks are a pure function of (seed, index),
-// so the backward pass regenerates them instead of storing them.
-__device__ __forceinline__ uint32_t mdg_mix32(uint64_t z) {
+// counter-based random bits (splitmix64 finaliser): dropout masks are a pure function of (seed, index), so the backward pass
+// regenerates them instead of storing them.  One 64-bit hash serves FOUR consecutive elements (16 bits each: the drop probability is
+// resolved to 1/65536): element `index` is kept iff field (index & 3) of the hash of (seed, index >> 2) reaches the threshold.  A thread
+// that owns an aligned group of four (16-byte elementwise passes, the dense block's epilogue) hashes once: mdg_keep_word + mdg_keep_field.
+__device__ __forceinline__ uint64_t mdg_mix64(uint64_t z) {
   z += 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return static_cast<uint32_t>((z ^ (z >> 31)) >> 32);
+  return z ^ (z >> 31);
 }
-__device__ __forceinline__ uint32_t mdg_drop_threshold(float p) { return static_cast<uint32_t>(static_cast<double>(p) * 4294967296.0); }
+__host__ __device__ __forceinline__ uint32_t mdg_drop_threshold(float p) { return static_cast<uint32_t>(static_cast<double>(p) * 65536.0); }
+__device__ __forceinline__ uint64_t mdg_keep_word(uint64_t seed, uint64_t group) { return mdg_mix64(seed * 0x100000001B3ull + group); }
+__device__ __forceinline__ bool mdg_keep_field(uint64_t word, int e, uint32_t thr) { return ((word >> (16 * e)) & 0xFFFFull) >= thr; }
 __device__ __forceinline__ bool mdg_keep(uint64_t seed, uint64_t index, uint32_t thr) {
-  return mdg_mix32(seed * 0x100000001B3ull + index) >= thr;
+  return mdg_keep_field(mdg_keep_word(seed, index >> 2), static_cast<int>(index & 3), thr);
 }
 
 // wave-wide reductions over all 64 lanes
