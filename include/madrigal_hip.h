@@ -312,6 +312,14 @@ int mdg_bilinear_gather_bwd(const float* z_head, const float* z_tail, const floa
                             const int64_t* chunk_start, int64_t n_chunks, const int64_t* label_chunk_ptr, int64_t n_labels,
                             const float* dscore, float* gz_head_rows, float* gz_tail_rows, float* dw_partial, float* dw, int64_t D,
                             void* stream);
+/* The same with the arithmetic mode of the step: in the 16-bit modes dW runs on the split-bf16 matrix cores (three products of the
+ * hi / lo halves of ds * z_head and z_tail, fp32 accumulation: fp32-grade, ~4e-6 of max) as a TN product over the gathered rows;
+ * MDG_PREC_F32 = the exact fp32 MFMA kernel of mdg_bilinear_gather_bwd.  The per-triple gradient rows are exact fp32 either way. */
+int mdg_bilinear_gather_bwd_prec(const float* z_head, const float* z_tail, const float* w, const float* w_t, const int64_t* head,
+                                 const int64_t* tail, const int64_t* tile_start, const int64_t* tile_label, int64_t n_tiles,
+                                 const int64_t* chunk_start, int64_t n_chunks, const int64_t* label_chunk_ptr, int64_t n_labels,
+                                 const float* dscore, float* gz_head_rows, float* gz_tail_rows, float* dw_partial, float* dw,
+                                 int64_t D, int precision, void* stream);
 /* Pair-compressed gathered head (same sums as mdg_bilinear_gather / _bwd, grouped per (label, drug) PAIR before the 128 x 128
  * products: the finetune batch holds more labelled triples than (outcome, drug) pairs, train_ddi_batch.py:285-288).
  *   mdg_bilinear_matvec_rows: rows_out[p] = W[tile_label] z[row_index[p]] for pairs cut into tiles of <= 32 pairs of one label

@@ -459,10 +459,10 @@ class _BilinearGather(Function):
     pairs: one 128 x 128 product per pair forward, one backward (ops.bilinear_gather_pairs).  ``w_sym`` is symmetric."""
 
     @staticmethod
-    def forward(ctx, z_head, z_tail, w_sym, plan):
+    def forward(ctx, z_head, z_tail, w_sym, plan, precision="f32"):
         score, V = ops.bilinear_gather_pairs(z_head, z_tail, w_sym, plan)
         ctx.save_for_backward(z_head, z_tail, w_sym, V)
-        ctx.plan = plan
+        ctx.plan, ctx.precision = plan, precision
         return score
 
     @staticmethod
@@ -470,12 +470,14 @@ class _BilinearGather(Function):
     def backward(ctx, ds):
         z_head, z_tail, w_sym, V = ctx.saved_tensors
         dzh, dzt, dw = ops.bilinear_gather_pairs_bwd(z_head, z_tail, w_sym, ctx.plan, ds if ds.is_contiguous() else ds.contiguous(), V,
-                                                     need_dw=ctx.needs_input_grad[2])
-        return (dzh if ctx.needs_input_grad[0] else None), (dzt if ctx.needs_input_grad[1] else None), dw, None
+                                                     need_dw=ctx.needs_input_grad[2], precision=ctx.precision)
+        return (dzh if ctx.needs_input_grad[0] else None), (dzt if ctx.needs_input_grad[1] else None), dw, None, None
 
 
-def bilinear_gather(z_head, z_tail, w_sym, plan):
-    return _BilinearGather.apply(z_head, z_tail, w_sym, plan)
+def bilinear_gather(z_head, z_tail, w_sym, plan, precision="f32"):
+    """``precision``: the step's arithmetic mode.  The scores and the embedding gradients are exact fp32 in every mode; in the 16-bit
+    modes the weight gradient (one 128 x 128 outer-product sum per label) runs on the split-bf16 matrix cores (fp32-grade)."""
+    return _BilinearGather.apply(z_head, z_tail, w_sym, plan, precision)
 
 
 class _BCEWithSigmoid(Function):

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 namespace {
+#include "tn16.h"           // the 16-bit TN kernel with gathered rows: dW of the head on the split-bf16 matrix cores
 
 constexpr int HD = 128;     // embedding width of every shipped config
 
@@ -323,12 +324,28 @@ extern "C" int mdg_bilinear_gather(const float* z_head, const float* z_tail, con
   return MDG_OK;
 }
 
+extern "C" int mdg_bilinear_gather_bwd_prec(const float* z_head, const float* z_tail, const float* w, const float* w_t, const int64_t* head,
+                                            const int64_t* tail, const int64_t* tile_start, const int64_t* tile_label, int64_t n_tiles,
+                                            const int64_t* chunk_start, int64_t n_chunks, const int64_t* label_chunk_ptr, int64_t n_labels,
+                                            const float* dscore, float* gz_head_rows, float* gz_tail_rows, float* dw_partial, float* dw,
+                                            int64_t D, int precision, void* stream);
+
 extern "C" int mdg_bilinear_gather_bwd(const float* z_head, const float* z_tail, const float* w, const float* w_t, const int64_t* head,
                                        const int64_t* tail, const int64_t* tile_start, const int64_t* tile_label, int64_t n_tiles,
                                        const int64_t* chunk_start, int64_t n_chunks, const int64_t* label_chunk_ptr, int64_t n_labels,
                                        const float* dscore, float* gz_head_rows, float* gz_tail_rows, float* dw_partial, float* dw,
                                        int64_t D, void* stream) {
+  return mdg_bilinear_gather_bwd_prec(z_head, z_tail, w, w_t, head, tail, tile_start, tile_label, n_tiles, chunk_start, n_chunks, label_chunk_ptr, n_labels,
+                                      dscore, gz_head_rows, gz_tail_rows, dw_partial, dw, D, MDG_PREC_F32, stream);
+}
+
+extern "C" int mdg_bilinear_gather_bwd_prec(const float* z_head, const float* z_tail, const float* w, const float* w_t, const int64_t* head,
+                                            const int64_t* tail, const int64_t* tile_start, const int64_t* tile_label, int64_t n_tiles,
+                                            const int64_t* chunk_start, int64_t n_chunks, const int64_t* label_chunk_ptr, int64_t n_labels,
+                                            const float* dscore, float* gz_head_rows, float* gz_tail_rows, float* dw_partial, float* dw,
+                                            int64_t D, int precision, void* stream) {
   if (int rc = gather_check("mdg_bilinear_gather_bwd", z_head, z_tail, w, head, tail, tile_start, tile_label, n_tiles, D)) return rc;
+  MDG_CHECK_ARG(precision == MDG_PREC_F32 || precision == MDG_PREC_BF16 || precision == MDG_PREC_BF16X3, "mdg_bilinear_gather_bwd: unknown precision %d", precision);
   MDG_CHECK_ARG(n_chunks >= 0 && n_labels >= 0, "mdg_bilinear_gather_bwd: negative size");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (n_tiles > 0) {
@@ -339,7 +356,13 @@ extern "C" int mdg_bilinear_gather_bwd(const float* z_head, const float* z_tail,
   }
   if (dw) {
     MDG_CHECK_ARG(label_chunk_ptr && (n_chunks == 0 || (chunk_start && dw_partial)), "mdg_bilinear_gather_bwd: dW needs the chunk tables and scratch");
-    if (n_chunks > 0)
+    static MdgEnvInt dw16_sw{"MDG_HEAD_DW_16", 1};
+    if (n_chunks > 0 && precision != MDG_PREC_F32 && dw16_sw.get() != 0 && mdg_aligned16(z_head) && mdg_aligned16(z_tail)) {
+      // the chunk's outer-product sum as a TN product of gathered rows on the split-bf16 matrix cores (fp32-grade: three products of
+      // the hi / lo halves, fp32 accumulation) -- in every 16-bit mode of the step: the head stays fp32-grade
+      GwArgs a{z_head, HD, z_tail, HD, dw_partial, nullptr, 0, 0, HD, HD, head, tail, dscore, chunk_start};
+      hipLaunchKernelGGL((grad_weight16_kernel<MDG_PREC_BF16X3, true>), dim3(1, 1, static_cast<unsigned>(n_chunks)), dim3(256), 2 * 2 * 2 * G16_PLANE, st, a);
+    } else if (n_chunks > 0)
       hipLaunchKernelGGL(bilinear_gather_dw_kernel, dim3(static_cast<unsigned>(n_chunks)), dim3(256), 0, st, z_head, z_tail, head, tail, dscore,
                          chunk_start, dw_partial);
     if (n_labels > 0)

@@ -1384,7 +1384,7 @@ class BilinearDDIScorer(nn.Bilinear):
         """Extension (finetune step): scores of the plan's (label, head, tail) triples only, in the plan's
         label-sorted order, differentiable w.r.t. both embeddings and the weight (train_ddi_batch.py:285-286
         reads exactly these entries of the dense result)."""
-        return ag.bilinear_gather(input1, input2, self.weight, plan)
+        return ag.bilinear_gather(input1, input2, self.weight, plan, _state["precision"])
 
     def forward(self, input1, input2, label_range: tuple = None, epilogue=ops.EPI_STORE, out=None):
         if ag.needs_grad(input1, input2) or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):

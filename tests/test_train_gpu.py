@@ -437,8 +437,11 @@ def _triples(T, L, Nh, Nt, seed, skew=True):
     return labels, torch.randint(0, Nh, (T,), generator=g), torch.randint(0, Nt, (T,), generator=g)
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
 @pytest.mark.parametrize("T,L,Nh,Nt", [(1, 3, 2, 2), (33, 1, 5, 7), (5000, 40, 300, 200), (20000, 7, 64, 64)])
-def test_gathered_head_forward_backward_match_torch(T, L, Nh, Nt):
+def test_gathered_head_forward_backward_match_torch(T, L, Nh, Nt, prec):
+    """``prec``: the step's arithmetic mode -- scores and embedding gradients are exact fp32 in all of them; the weight gradient runs on
+    the split-bf16 matrix cores in the 16-bit modes (gathered TN product, fp32-grade)."""
     from madrigal_amd import autograd as ag, ops
     labels, heads, tails = _triples(T, L, Nh, Nt, seed=T)
     zh, zt = _rand(Nh, 128, seed=1), _rand(Nt, 128, seed=2)
@@ -451,7 +454,7 @@ def test_gathered_head_forward_backward_match_torch(T, L, Nh, Nt):
     plan = ops.triple_plan(labels.to(DEV), heads.to(DEV), tails.to(DEV), L, Nh, Nt)
     assert torch.equal(labels[plan["perm"].cpu()], labels.sort(stable=True).values)
     zg, tg, wg = (v.to(DEV).requires_grad_(True) for v in (zh, zt, w0))
-    s = ag.bilinear_gather(zg, tg, ag.symmetrize(wg), plan)
+    s = ag.bilinear_gather(zg, tg, ag.symmetrize(wg), plan, prec)
     _close(s[plan["inv_perm"]], sr, 2e-5, "gathered scores")
     s.backward(ds.to(DEV)[plan["perm"]])
     _close(zg.grad, zr.grad, 2e-5, "dz_head")
@@ -463,7 +466,7 @@ def test_gathered_head_forward_backward_match_torch(T, L, Nh, Nt):
     _close(s.detach()[plan["inv_perm"]], dense[labels.to(DEV), heads.to(DEV), tails.to(DEV)], 2e-5, "vs dense head")
     # bit-identical re-run (no atomics anywhere)
     zg2, tg2, wg2 = (v.to(DEV).requires_grad_(True) for v in (zh, zt, w0))
-    ag.bilinear_gather(zg2, tg2, ag.symmetrize(wg2), plan).backward(ds.to(DEV)[plan["perm"]])
+    ag.bilinear_gather(zg2, tg2, ag.symmetrize(wg2), plan, prec).backward(ds.to(DEV)[plan["perm"]])
     assert torch.equal(zg.grad, zg2.grad) and torch.equal(tg.grad, tg2.grad) and torch.equal(wg.grad, wg2.grad)
 
 
