@@ -1562,11 +1562,13 @@ class NovelDDIEncoder(nn.Module):
         over ten node types: replayed as graphs they cost the host two launches and the GPU no launch gaps.  Parameters are read at
         replay time (the optimizer updates them in place), gradients come back in static buffers.  Off (None) under data-parallel
         SyncBatchNorm reductions or for CPU tensors; a capture failure falls back to eager launches.
-        OPT-IN (MDG_KG_GRAPH=1): measured on one MI355X (scripts/kg_graph_probe.py) the replay costs the host 2.7 ms instead of
-        8.5 ms per forward+backward but the GPU 11.3 ms instead of ~9 ms (hipGraph nodes are dispatched no faster than eager
-        launches here), so it helps the host-bound contrastive step (17.9 -> 16.9 ms) and hurts the GPU-bound finetune step
-        (51.3 -> 52.4 ms)."""
-        if dev.type != 'cuda' or os.environ.get("MDG_KG_GRAPH", "0") != "1" or ag._bn_sync["reduce"] is not None:
+        Per step kind (``encoder.kg_graph``; MDG_KG_GRAPH=0/1 overrides): measured on one MI355X (scripts/kg_graph_probe.py) the
+        replay costs the host 2.7 ms instead of 8.5 ms per forward+backward but the GPU 11.3 ms instead of ~9 ms (hipGraph nodes are
+        dispatched no faster than eager launches here), so it helps the host-bound contrastive step (17.7-19.8 -> 16.0 ms: PretrainStep
+        switches it on) and hurts the GPU-bound finetune step (51.3 -> 52.4 ms: FinetuneStep leaves it off)."""
+        want = os.environ.get("MDG_KG_GRAPH")                 # "0" / "1" overrides the step's own preference (kg_graph attribute)
+        want = (want == "1") if want in ("0", "1") else bool(getattr(self, "kg_graph", False))
+        if dev.type != 'cuda' or not want or ag._bn_sync["reduce"] is not None:
             return None
         params = list(self.kg_encoder.parameters())
         key = (id(kg_data), _state["precision"], tuple(p.requires_grad for p in params), torch.is_grad_enabled())

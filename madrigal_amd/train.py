@@ -47,6 +47,7 @@ class FinetuneStep:
         # data-parallel: the KG encoder's convs run destination-partitioned (HGTConv._forward_train(shard=...)): every KG edge is
         # attended to on exactly one rank instead of on all of them; False keeps the KG encoder replicated
         self.shard_kg = bool(shard_kg) and world > 1
+        model.encoder.kg_graph = False          # (the finetune step is GPU-bound: captured KG graphs cost it 1 ms; see NovelDDIEncoder._kg_graphed)
         _refuse_rank_local_batchnorm(model.encoder, world)
         # single-pass steps overlap the gradient all-reduce with the backward pass (buckets issued from gradient hooks);
         # the multi-pass modes (accumulate() ... apply()) sum the finished gradients in flat buckets afterwards
@@ -179,11 +180,15 @@ class PretrainStep:
     order; their sizes follow from the full mask tensors every rank holds ('str_center_uni' views: exactly one row per drug).
     With dropout off the sharded step reproduces the single-process step."""
 
-    def __init__(self, model, optimizer, rank: int = 0, world: int = 1, group=None, scheduler=None, shard_kg: bool = True):
-        """``shard_kg`` (world > 1): destination-partitioned KG convs, as in ``FinetuneStep``.  ``scheduler``: called with the optimizer at the top of every step, before ``zero_grad`` -- pretrain.py:65 adjusts the
+    def __init__(self, model, optimizer, rank: int = 0, world: int = 1, group=None, scheduler=None, shard_kg: bool = True, kg_graph: bool = True):
+        """``kg_graph`` (single process): the KG encoder's forward and backward replay as two captured hipGraphs
+        (NovelDDIEncoder._kg_graphed: the contrastive step is bound by the host's launch rate, ~1 000 small launches per step, 40 %
+        of them the KG pass; 17.7-19.8 -> 16.0 ms per 2048-drug step).  ``shard_kg`` (world > 1): destination-partitioned KG convs,
+        as in ``FinetuneStep``.  ``scheduler``: called with the optimizer at the top of every step, before ``zero_grad`` -- pretrain.py:65 adjusts the
         learning rate per ITERATION (``optim.PretrainSchedule`` mirrors madrigal/utils.py:680-692); None keeps the rates."""
         self.model, self.optimizer, self.rank, self.world, self.group, self.scheduler = model, optimizer, rank, world, group, scheduler
         self.shard_kg = bool(shard_kg) and world > 1
+        model.base_encoder.kg_graph = bool(kg_graph) and world == 1
         _refuse_rank_local_batchnorm(model.base_encoder, world)
         self._buckets = GradientBuckets(model.parameters(), group) if world > 1 else None
         self._last = None               # (key, sliced batch, batch_data): the slice of the LAST batch only (a DataLoader
