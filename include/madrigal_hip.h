@@ -329,6 +329,13 @@ int mdg_bilinear_gather_bwd_prec(const float* z_head, const float* z_tail, const
  * means weight 1 (the dW sum over pairs). */
 int mdg_bilinear_matvec_rows(const float* z, const float* w, const int64_t* row_index, const int64_t* tile_start, const int64_t* tile_label,
                              int64_t n_tiles, float* rows_out, int64_t D, void* stream);
+/* The per-pair products in the step's arithmetic mode: MDG_PREC_F32 = the call above; the 16-bit modes run them on the split-bf16
+ * matrix cores (z rows split in registers, W from hi / lo bf16 images made inside the call in `workspace`: three products, fp32
+ * accumulation -- fp32-grade, ~4e-6 of max).  w [n_labels,128,128]. */
+size_t mdg_bilinear_matvec_rows_workspace_bytes(int64_t n_labels, int precision);
+int mdg_bilinear_matvec_rows_prec(const float* z, const float* w, int64_t n_labels, const int64_t* row_index, const int64_t* tile_start,
+                                  const int64_t* tile_label, int64_t n_tiles, float* rows_out, int64_t D, int precision, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 int mdg_gather_rowdot(const float* a, const int64_t* ia, const float* b, const int64_t* ib, float* out, int64_t n, int64_t D, void* stream);
 
 /* nn.BCELoss(sigmoid(score), target) per element (log clamp at -100) and/or its gradient w.r.t. the logit times

@@ -460,7 +460,7 @@ class _BilinearGather(Function):
 
     @staticmethod
     def forward(ctx, z_head, z_tail, w_sym, plan, precision="f32"):
-        score, V = ops.bilinear_gather_pairs(z_head, z_tail, w_sym, plan)
+        score, V = ops.bilinear_gather_pairs(z_head, z_tail, w_sym, plan, precision=precision)
         ctx.save_for_backward(z_head, z_tail, w_sym, V)
         ctx.plan, ctx.precision = plan, precision
         return score
@@ -475,8 +475,9 @@ class _BilinearGather(Function):
 
 
 def bilinear_gather(z_head, z_tail, w_sym, plan, precision="f32"):
-    """``precision``: the step's arithmetic mode.  The scores and the embedding gradients are exact fp32 in every mode; in the 16-bit
-    modes the weight gradient (one 128 x 128 outer-product sum per label) runs on the split-bf16 matrix cores (fp32-grade)."""
+    """``precision``: the step's arithmetic mode.  "f32": exact fp32 matrix cores throughout.  In the 16-bit modes the head stays
+    fp32-GRADE: its 128 x 128 products (per (label, drug) pair forward and backward, the weight gradient's outer-product sums) run on
+    the split-bf16 matrix cores -- three products of hi / lo halves, fp32 accumulation, ~4e-6 of max."""
     return _BilinearGather.apply(z_head, z_tail, w_sym, plan, precision)
 
 

@@ -126,6 +126,140 @@ __global__ __launch_bounds__(256) void bilinear_matvec_rows_kernel(const GatherA
     }
 }
 
+// ---- the same per-pair products on the split-bf16 matrix cores (the step's 16-bit modes; fp32-grade: ~4e-6 of max) ----------
+// rows[t][i] = sum_k W_l[i][k] z[index[t]][k] is Z_tile W_l^T with BOTH operands k-contiguous in memory, which is exactly how
+// v_mfma_f32_16x16x32_bf16 wants them: no LDS and no barrier.  A wave owns a tile of <= 32 pairs: its z rows are loaded once
+// (lane (row, k group): 2 x 16 B of fp32 per 32-k step, split hi / lo in registers, 64 VGPRs), W_l comes from hi / lo bf16 images
+// made once per call (16 B per lane and plane: the four k groups of a row are 64 contiguous bytes), three products per tile pair
+// (lo.hi + hi.lo + hi.hi).  192 MFMAs of 16 cycles per tile against 256 of 64 cycles for the exact kernel.
+__global__ __launch_bounds__(256) void split_rows_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ hi, __bf16* __restrict__ lo, int64_t n4) {
+  const int64_t q = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (q >= n4) return;
+  const f32x4 v = reinterpret_cast<const f32x4*>(x)[q];
+  bf16x4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    __bf16 a, b;
+    mdg_split_bf16(v[e], a, b);
+    h[e] = a;
+    l[e] = b;
+  }
+  reinterpret_cast<bf16x4*>(hi)[q] = h;
+  reinterpret_cast<bf16x4*>(lo)[q] = l;
+}
+
+struct Matvec16Args {
+  const float* z; const __bf16* whi; const __bf16* wlo;
+  const int64_t* row_index; const int64_t* tile_start; const int64_t* tile_label;
+  int64_t n_tiles; float* out;
+};
+
+// A workgroup takes 16 consecutive tiles (4 per wave).  Tiles are sorted by label, so 5 groups in 6 carry one label: then W_l's
+// two images (64 KB) are staged ONCE into LDS for the 16 tiles -- straight from L2 the kernel re-read them per tile (4.9 GB per
+// call: it ran at the L2's 8.6 TB/s, not at the matrix cores' rate).  LDS image: row i, 16-byte chunk c at chunk c ^ (i & 15) of
+// the row's 256 bytes: the 16 lanes of a ds_read_b128 group (16 rows, one chunk index) cover all 64 banks.
+constexpr int MV16_TILES = 16;
+
+template <bool LDS_W>
+__device__ __forceinline__ void matvec16_tile(const Matvec16Args& p, int64_t tile, const char* lds_w, int lane) {
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int64_t t0 = p.tile_start[tile];
+  const int cnt = static_cast<int>(p.tile_start[tile + 1] - t0);
+  if (cnt <= 0) return;
+  const int64_t l = p.tile_label[tile];
+  // A operand: lane (c16, g4) holds row 16 tt + c16 of the tile, k = 32 ks + 8 g4 .. + 7
+  bf16x8 ahi[2][4], alo[2][4];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int r = 16 * tt + c16;
+    const int64_t t = t0 + (r < cnt ? r : cnt - 1);          // rows past the tile repeat its last row; never stored
+    const float* zr = p.z + (p.row_index ? p.row_index[t] : t) * HD + 8 * g4;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(zr + 32 * ks), v1 = *reinterpret_cast<const f32x4*>(zr + 32 * ks + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        __bf16 a, b;
+        mdg_split_bf16(e < 4 ? v0[e] : v1[e - 4], a, b);
+        ahi[tt][ks][e] = a;
+        alo[tt][ks][e] = b;
+      }
+    }
+  }
+  // B operand: lane (c16, g4) holds W_l[16 nt + c16][32 ks + 8 g4 .. + 7]
+  const __bf16* const wh = p.whi + l * HD * HD + static_cast<int64_t>(c16) * HD + 8 * g4;
+  const __bf16* const wl = p.wlo + l * HD * HD + static_cast<int64_t>(c16) * HD + 8 * g4;
+  f32x4 acc[2][8];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    bf16x8 bh[4], bl[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if constexpr (LDS_W) {
+        const int off = (16 * nt + c16) * 256 + (((4 * ks + g4) ^ c16) << 4);
+        bh[ks] = *reinterpret_cast<const bf16x8*>(lds_w + off);
+        bl[ks] = *reinterpret_cast<const bf16x8*>(lds_w + 32768 + off);
+      } else {
+        bh[ks] = *reinterpret_cast<const bf16x8*>(wh + 16 * nt * HD + 32 * ks);
+        bl[ks] = *reinterpret_cast<const bf16x8*>(wl + 16 * nt * HD + 32 * ks);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        acc[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[tt][ks], bh[ks], acc[tt][nt], 0, 0, 0);
+        acc[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[tt][ks], bl[ks], acc[tt][nt], 0, 0, 0);
+        acc[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[tt][ks], bh[ks], acc[tt][nt], 0, 0, 0);
+      }
+  }
+  // acc[tt][nt][i]: tile row 16 tt + 4 g4 + i, output feature 16 nt + c16
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 16 * tt + 4 * g4 + i;
+      if (r < cnt) {
+        float* o = p.out + (t0 + r) * HD + c16;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) o[16 * nt] = acc[tt][nt][i];
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void bilinear_matvec_rows16_kernel(const Matvec16Args p) {
+  extern __shared__ __attribute__((aligned(16))) char lds_w[];     // hi image | lo image of one W_l, 32 KB each
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * MV16_TILES;
+  const int64_t last = base + MV16_TILES - 1 < p.n_tiles ? base + MV16_TILES - 1 : p.n_tiles - 1;
+  const int64_t mine = base + (tid & 15) < p.n_tiles ? base + (tid & 15) : p.n_tiles - 1;
+  const int64_t l0 = p.tile_label[base];
+  const bool shared_w = __syncthreads_and(p.tile_label[mine] == l0) != 0 && last > base;      // every tile of the group carries label l0
+  if (shared_w) {
+    const char* gh = reinterpret_cast<const char*>(p.whi + l0 * HD * HD);
+    const char* gl = reinterpret_cast<const char*>(p.wlo + l0 * HD * HD);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                          // 2048 chunks of 16 B per image, 8 per thread
+      const int q = tid + 256 * i, row = q >> 4, ch = q & 15;
+      const int off = row * 256 + ((ch ^ (row & 15)) << 4);
+      *reinterpret_cast<u32x4*>(lds_w + off) = *reinterpret_cast<const u32x4*>(gh + q * 16);
+      *reinterpret_cast<u32x4*>(lds_w + 32768 + off) = *reinterpret_cast<const u32x4*>(gl + q * 16);
+    }
+    __syncthreads();
+  }
+#pragma unroll 1
+  for (int j = 0; j < MV16_TILES / 4; ++j) {
+    const int64_t tile = base + 4 * j + wave;
+    if (tile >= p.n_tiles) break;
+    if (shared_w) matvec16_tile<true>(p, tile, lds_w, lane);
+    else matvec16_tile<false>(p, tile, lds_w, lane);
+  }
+}
+
 // MODE 0: scores; MODE 1: both per-triple gradient rows; MODE 2: rows[t] = W[l] z_tail[tail[t]] only (one matrix-vector product
 // per "triple" -- the (label, drug) PAIRS of the pair-compressed path, whose inputs are rows of z or of a per-pair sum).
 template <int MODE>
@@ -385,6 +519,37 @@ extern "C" int mdg_bilinear_matvec_rows(const float* z, const float* w, const in
   const bool old_path = old_sw.get() != 0;
   if (old_path) hipLaunchKernelGGL(bilinear_gather_kernel<2>, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   else hipLaunchKernelGGL(bilinear_matvec_rows_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  MDG_CHECK_LAUNCH("mdg_bilinear_matvec_rows");
+  return MDG_OK;
+}
+
+extern "C" size_t mdg_bilinear_matvec_rows_workspace_bytes(int64_t n_labels, int precision) {
+  return (precision == MDG_PREC_F32 || n_labels <= 0) ? 0 : static_cast<size_t>(n_labels) * HD * HD * 2 * sizeof(__bf16);
+}
+
+extern "C" int mdg_bilinear_matvec_rows_prec(const float* z, const float* w, int64_t n_labels, const int64_t* row_index, const int64_t* tile_start,
+                                             const int64_t* tile_label, int64_t n_tiles, float* rows_out, int64_t D, int precision, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(precision == MDG_PREC_F32 || precision == MDG_PREC_BF16 || precision == MDG_PREC_BF16X3, "mdg_bilinear_matvec_rows: unknown precision %d", precision);
+  static MdgEnvInt mv16_sw{"MDG_HEAD_MATVEC_16", 1};
+  if (precision == MDG_PREC_F32 || mv16_sw.get() == 0) return mdg_bilinear_matvec_rows(z, w, row_index, tile_start, tile_label, n_tiles, rows_out, D, stream);
+  MDG_CHECK_ARG(D == HD, "mdg_bilinear_matvec_rows: D must be 128 (got %lld)", (long long)D);
+  MDG_CHECK_ARG(n_tiles >= 0 && n_labels > 0, "mdg_bilinear_matvec_rows: bad sizes");
+  if (n_tiles == 0) return MDG_OK;
+  MDG_CHECK_ARG(z && w && tile_start && tile_label && rows_out && mdg_aligned16(z) && mdg_aligned16(w) && mdg_aligned16(rows_out),
+                "mdg_bilinear_matvec_rows: null / misaligned pointer");
+  const size_t need = mdg_bilinear_matvec_rows_workspace_bytes(n_labels, precision);
+  if (!workspace || workspace_bytes < need || !mdg_aligned16(workspace)) {
+    mdg_set_error("mdg_bilinear_matvec_rows: workspace of %zu bytes (16-byte aligned) required, got %zu", need, workspace_bytes);
+    return MDG_EWORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  __bf16* whi = static_cast<__bf16*>(workspace);
+  __bf16* wlo = whi + n_labels * HD * HD;
+  const int64_t n4 = n_labels * HD * HD / 4;
+  hipLaunchKernelGGL(split_rows_bf16_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n4, 256))), dim3(256), 0, st, w, whi, wlo, n4);
+  Matvec16Args a{z, whi, wlo, row_index, tile_start, tile_label, n_tiles, rows_out};
+  hipLaunchKernelGGL(bilinear_matvec_rows16_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, MV16_TILES))), dim3(256), 65536, st, a);
   MDG_CHECK_LAUNCH("mdg_bilinear_matvec_rows");
   return MDG_OK;
 }

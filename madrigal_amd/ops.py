@@ -1160,7 +1160,19 @@ def bilinear_gather_bwd(z_head, z_tail, w, plan: dict, dscore: torch.Tensor, w_t
     return dzh, dzt, dw
 
 
-def bilinear_gather_pairs(z_head: torch.Tensor, z_tail: torch.Tensor, w: torch.Tensor, plan: dict, w_t: Optional[torch.Tensor] = None):
+def _matvec_rows(z, w, row_index, pp, out, precision):
+    """rows[p] = W[label of p] z[row_index[p]] per (label, drug) pair, in the step's arithmetic mode (exact fp32 / split-bf16 matrix cores)."""
+    L_ = lib()
+    prec = _prec(precision)
+    nbytes = L_.mdg_bilinear_matvec_rows_workspace_bytes(_c64(w.shape[0]), _c(prec))
+    ws = _workspace(nbytes, z.device)
+    check(L_.mdg_bilinear_matvec_rows_prec(_ptr(z), _ptr(w), _c64(w.shape[0]), _ptr(row_index), _ptr(pp["tile_start"]), _ptr(pp["tile_label"]),
+                                           _c64(pp["n_tiles"]), _ptr(out), _c64(128), _c(prec), _ptr(ws), ctypes.c_size_t(nbytes), _stream(z)),
+          "mdg_bilinear_matvec_rows")
+
+
+def bilinear_gather_pairs(z_head: torch.Tensor, z_tail: torch.Tensor, w: torch.Tensor, plan: dict, w_t: Optional[torch.Tensor] = None,
+                          precision="f32"):
     """The scores of bilinear_gather through the (label, head drug) pairs: V[p] = W[l_p]^T z_head[i_p] once per pair (the 128 x 128
     product), then score[t] = V[pair(t)] . z_tail[t_t].  -> (score [T] in the plan's order, V [P,128] for the backward pass)."""
     zh, zt, w = _f32_cuda(z_head, "z_head", 2), _f32_cuda(z_tail, "z_tail", 2), _f32_cuda(w, "w", 3)
@@ -1173,8 +1185,7 @@ def bilinear_gather_pairs(z_head: torch.Tensor, z_tail: torch.Tensor, w: torch.T
     wt = w if w_t is None else _f32_cuda(w_t, "w_t", 3)
     V = torch.empty((pp["P"], 128), dtype=torch.float32, device=zh.device)
     L_ = lib()
-    check(L_.mdg_bilinear_matvec_rows(_ptr(zh), _ptr(wt), _ptr(pp["drug"]), _ptr(pp["tile_start"]), _ptr(pp["tile_label"]), _c64(pp["n_tiles"]),
-                                      _ptr(V), _c64(128), _stream(zh)), "mdg_bilinear_matvec_rows")
+    _matvec_rows(zh, wt, pp["drug"], pp, V, precision)
     check(L_.mdg_gather_rowdot(_ptr(V), _ptr(pp["of_triple"]), _ptr(zt), _ptr(plan["tails"]), _ptr(score), _c64(plan["T"]), _c64(128),
                                _stream(zh)), "mdg_gather_rowdot")
     return score, V
@@ -1200,8 +1211,7 @@ def bilinear_gather_pairs_bwd(z_head, z_tail, w, plan: dict, dscore: torch.Tenso
     u = csr_aggregate(zt, pp["ptr"], pp["tails_by_pair"], edge_weight=ds)
     R = torch.empty((pp["P"], 128), dtype=torch.float32, device=dev)
     L_ = lib()
-    check(L_.mdg_bilinear_matvec_rows(_ptr(u), _ptr(w), _ptr(None), _ptr(pp["tile_start"]), _ptr(pp["tile_label"]), _c64(pp["n_tiles"]), _ptr(R),
-                                      _c64(128), _stream(zh)), "mdg_bilinear_matvec_rows")
+    _matvec_rows(u, w, None, pp, R, precision)
     dzh = _sum_rows(R, pp["drug_ptr"], pp["drug_rows"], pp.get("drug_pieces"))
     dw = None
     if need_dw:
