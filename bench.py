@@ -387,7 +387,8 @@ def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend
     encode head and tail side (training mode: dropout, BatchNorm batch statistics) -> scores of the labelled triples
     (gathered head) -> BCE -> backward through every encoder -> AdamW over the reference's parameter groups.
     ``precision``: BASELINE configs[1] names bf16 for this step -- GEMM operands rounded to bf16, fp32 accumulation, fp32 master
-    weights, optimizer state and gathered head; "bf16x3" is the fp32-grade arithmetic of the inference headline.
+    weights and optimizer state, the gathered head fp32-grade on the split-bf16 matrix cores; "bf16x3" is the fp32-grade arithmetic of the
+    inference headline.
     world > 1: the SAME step data-parallel (strong scaling): drug-sharded encoders with SyncBatchNorm, all-gather of the
     embeddings, triples dealt to the ranks, flat all-reduce of the gradients (madrigal_amd/train.py)."""
     import torch
@@ -439,7 +440,7 @@ def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend
            "scaling": "strong", "steps": args.finetune_steps, "warmup": 1, "triples_per_step": T, "drugs": N, "outcomes": L,
            "timing": "median of the steps' own times (HIP events between back-to-back steps)" if world == 1 else "timed region / steps, max over ranks",
            "step_ms": step_ms, "ms_per_step_mean_of_timed_region": mean_dt * 1e3,
-           "dtype": {"bf16": "bf16 GEMM operands, fp32 accumulate / master weights / optimizer / gathered head", "bf16x3": "f32 via split-bf16 (bf16x3) MFMA",
+           "dtype": {"bf16": "bf16 GEMM operands, fp32 accumulate / master weights / optimizer; gathered head fp32-grade (split-bf16 products)", "bf16x3": "f32 via split-bf16 (bf16x3) MFMA",
                      "f32": "f32"}[precision],
            "loss_first_last": [float(losses[0]), float(losses[-1])],
            "parallelism": "single GPU" if world == 1 else
