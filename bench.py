@@ -798,44 +798,52 @@ def main():
         torch.cuda.empty_cache()
     other = headline("weak" if main_mode == "strong" else "strong") if world > 1 else None
 
-    finetune = None
-    if args.finetune_steps > 0 and not args.head_only:
-        try:
-            finetune = finetune_leg(model, batch, bkg, filler, N, L, args, rank, world, backend, precision=args.finetune_precision)
-            if args.finetune_precision != "bf16x3":
-                second = finetune_leg(model, batch, bkg, filler, N, L, args, rank, world, backend, precision="bf16x3")
-                finetune["fp32_grade"] = {k: second[k] for k in ("value", "unit", "ms_per_step", "dtype", "loss_first_last")}
-            if world == 1 and not args.no_cpu_baseline and cpu_inputs is not None:
-                try:
-                    trip = tuple(t.cpu() for t in D.make_labelled_triples(N, L, args.finetune_triples, 0))
-                    c = cpu_finetune_step(cpu_inputs[0], cpu_inputs[1], cpu_inputs[2], args.config, L, trip)
-                    finetune["cpu_baseline"] = {"value": c["steps_per_s"], "unit": "steps/s", "cores": host_threads(), "kind": "port",
-                                                "sample": f"oracle training step (torch CPU autograd, fp32) on {c['sample_drugs']} drugs per side, "
-                                                          f"{c['sample_triples']} labelled triples, KG thinned to {c['kg_edges_kept']} of its edges; scaled to "
-                                                          f"{N} drugs / {finetune['triples_per_step']} triples / the full KG", "detail": c}
-                except Exception as e:
-                    finetune["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
-        except Exception as e:          # the headline line must survive a failure of the secondary leg
-            finetune = {"metric": "DDI-finetune steps/sec", "value": None, "error": f"{type(e).__name__}: {e}"[:400]}
-    pretrain = None
-    if args.pretrain_steps > 0 and world == 1 and not args.head_only:
-        try:
-            pretrain = pretrain_leg(model, bkg, batch["masks"], args)
-        except Exception as e:
-            pretrain = {"metric": "contrastive-pretraining steps/sec", "value": None, "error": f"{type(e).__name__}: {e}"[:400]}
-    stress = None
-    if args.stress_drugs > 0:
-        model = batch = bkg = None
-        torch.cuda.empty_cache()
-        try:
-            stress = stress_leg(args, rank, world, dev, backend)
-        except Exception as e:
-            stress = {"bound": "mfma", "achieved": None, "error": f"{type(e).__name__}: {e}"[:400]}
+    def secondary_legs():
+        """Finetune / pretraining / cfg5 legs -> (finetune, pretrain, stress) blocks (each survives its own failure)."""
+        nonlocal model, batch, bkg
+        finetune = None
+        if args.finetune_steps > 0 and not args.head_only:
+            try:
+                finetune = finetune_leg(model, batch, bkg, filler, N, L, args, rank, world, backend, precision=args.finetune_precision)
+                if args.finetune_precision != "bf16x3":
+                    second = finetune_leg(model, batch, bkg, filler, N, L, args, rank, world, backend, precision="bf16x3")
+                    finetune["fp32_grade"] = {k: second[k] for k in ("value", "unit", "ms_per_step", "dtype", "loss_first_last")}
+                if world == 1 and not args.no_cpu_baseline and cpu_inputs is not None:
+                    try:
+                        trip = tuple(t.cpu() for t in D.make_labelled_triples(N, L, args.finetune_triples, 0))
+                        c = cpu_finetune_step(cpu_inputs[0], cpu_inputs[1], cpu_inputs[2], args.config, L, trip)
+                        finetune["cpu_baseline"] = {"value": c["steps_per_s"], "unit": "steps/s", "cores": host_threads(), "kind": "port",
+                                                    "sample": f"oracle training step (torch CPU autograd, fp32) on {c['sample_drugs']} drugs per side, "
+                                                              f"{c['sample_triples']} labelled triples, KG thinned to {c['kg_edges_kept']} of its edges; scaled to "
+                                                              f"{N} drugs / {finetune['triples_per_step']} triples / the full KG", "detail": c}
+                    except Exception as e:
+                        finetune["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+            except Exception as e:          # the headline line must survive a failure of the secondary leg
+                finetune = {"metric": "DDI-finetune steps/sec", "value": None, "error": f"{type(e).__name__}: {e}"[:400]}
+        pretrain = None
+        if args.pretrain_steps > 0 and world == 1 and not args.head_only:
+            try:
+                pretrain = pretrain_leg(model, bkg, batch["masks"], args)
+            except Exception as e:
+                pretrain = {"metric": "contrastive-pretraining steps/sec", "value": None, "error": f"{type(e).__name__}: {e}"[:400]}
+        stress = None
+        if args.stress_drugs > 0:
+            model = batch = bkg = None
+            torch.cuda.empty_cache()
+            try:
+                stress = stress_leg(args, rank, world, dev, backend)
+            except Exception as e:
+                stress = {"bound": "mfma", "achieved": None, "error": f"{type(e).__name__}: {e}"[:400]}
+
+        return finetune, pretrain, stress
 
     def scores_per_s(r):
         return float(r["L_total"]) * N * N * args.steps / r["dt"]
 
-    if rank == 0:
+    def emit(finetune, pretrain, stress):
+        """Rank 0 prints THE line of the run."""
+        if rank != 0:
+            return
         per_launch = float(h["Lr"]) * N * N
         head_ms, enc_ms = h["head_ms"], h["enc_ms"]
         traffic, traffic_src = pmc_traffic(N, h["Lr"], args.precision)
@@ -887,7 +895,31 @@ def main():
             line["finetune"] = finetune
         if pretrain is not None:
             line["pretrain"] = pretrain
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    if world == 1:
+        emit(*secondary_legs())
+    else:
+        # N > 1: the line (the scaling curve's point) leaves FIRST.  The data-parallel finetune step and the sharded cfg5 stress run
+        # have never executed over RCCL (one GPU in the build box): they run afterwards under a watchdog, and report to stderr and
+        # gpurun_out/bench_ddp_legs_n<N>.json -- a hang or a crash there cannot take the headline with it.
+        emit(None, None, None)
+        import threading
+        limit = float(os.environ.get("MDG_BENCH_DDP_LEGS_SECONDS", "420"))
+        if limit > 0:
+            dog = threading.Timer(limit, lambda: (sys.stderr.write(f"[bench] secondary legs exceeded {limit:.0f} s on rank {rank}: leaving\n"), sys.stderr.flush(), os._exit(0)))
+            dog.daemon = True
+            dog.start()
+            ft, pt, st_ = secondary_legs()
+            dog.cancel()
+            if rank == 0:
+                side = {"n_gpus": world, "finetune": ft, "pretrain": pt, "roofline_cfg5": st_}
+                sys.stderr.write("[bench] secondary legs: " + json.dumps(side) + "\n")
+                try:
+                    os.makedirs("gpurun_out", exist_ok=True)
+                    with open(os.path.join("gpurun_out", f"bench_ddp_legs_n{world}.json"), "w") as fh:
+                        json.dump(side, fh)
+                except OSError:
+                    pass
     if world > 1:
         dist.destroy_process_group()
 
