@@ -127,6 +127,10 @@ int mdg_bilinear_allpairs_ld(const float* z_head, const float* z_tail, const flo
 size_t mdg_pack_operand_bytes(int64_t rows, int64_t K, int precision);        /* 0: the raw fp32 tensor is used as is */
 int mdg_pack_operand(const float* src, int64_t ld, int64_t rows, int64_t K, int precision, void* dst, size_t dst_bytes,
                      void* stream);
+/* Image of src^T from src [rows, cols] in one transposing pass (16-bit modes; mdg_pack_operand_bytes(cols, rows, precision) bytes):
+ * the weight image of the backward product dx = g W (a dense block with weight W^T) without materialising W^T. */
+int mdg_pack_operand_transposed(const float* src, int64_t ld, int64_t rows, int64_t cols, int precision, void* dst, size_t dst_bytes,
+                                void* stream);
 size_t mdg_linear_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision, int w_is_packed);
 int mdg_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const void* w_packed, float* y, int64_t ldy, int64_t M,
                int64_t N, int64_t K, const float* bias, const float* scale, const float* shift, int activation,

@@ -1296,6 +1296,29 @@ extern "C" int mdg_pack_operand(const float* src, int64_t ld, int64_t rows, int6
   return MDG_OK;
 }
 
+// Operand image of src^T straight from src [rows, cols] (16-bit modes): what mdg_pack_operand(transpose(src)) writes, in one
+// transposing pass -- the backward pass multiplies by W^T (dx = g W as a dense block with weight W^T [K, N]) and W changes every step.
+extern "C" int mdg_pack_operand_transposed(const float* src, int64_t ld, int64_t rows, int64_t cols, int precision, void* dst, size_t dst_bytes,
+                                           void* stream) {
+  MDG_CHECK_ARG(rows > 0 && cols > 0 && ld >= cols, "mdg_pack_operand_transposed: bad shape");
+  MDG_CHECK_ARG(precision == MDG_PREC_BF16 || precision == MDG_PREC_BF16X3, "mdg_pack_operand_transposed: a 16-bit operand mode");
+  MDG_CHECK_ARG(pad64(rows) / 64 < (1ll << 31) && mdg_cdiv(cols, 64) < 65536, "mdg_pack_operand_transposed: too many tiles");
+  const size_t need = image_bytes(cols, rows, precision);
+  MDG_CHECK_ARG(src, "mdg_pack_operand_transposed: null source");
+  if (!dst || dst_bytes < need || !mdg_aligned16(dst)) {
+    mdg_set_error("mdg_pack_operand_transposed: destination of %zu bytes required, got %zu", need, dst_bytes);
+    return MDG_EWORKSPACE;
+  }
+  PrepTArgs pa{};
+  pa.src[0] = src; pa.ld[0] = ld; pa.C[0] = cols; pa.dst0[0] = static_cast<char*>(dst);
+  pa.src[1] = src; pa.ld[1] = ld; pa.C[1] = 0; pa.dst0[1] = static_cast<char*>(dst);
+  pa.M = rows; pa.Mp = pad64(rows); pa.bf16 = 1; pa.x3 = precision == MDG_PREC_BF16X3 ? 1 : 0;
+  hipLaunchKernelGGL(prep_transposed_kernel, dim3(static_cast<unsigned>(pa.Mp / 64), static_cast<unsigned>(mdg_cdiv(cols, 64)), 1), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), pa);
+  MDG_CHECK_LAUNCH("mdg_pack_operand_transposed");
+  return MDG_OK;
+}
+
 extern "C" size_t mdg_linear_workspace_bytes(int64_t M, int64_t N, int64_t K, int precision, int w_is_packed) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   return image_bytes(M, K, precision) + (w_is_packed ? 0 : image_bytes(N, K, precision)) + (pp_shape(precision, M, N) ? pp::sk_bytes() : 0);

@@ -224,6 +224,16 @@ def _rows2d(x: torch.Tensor, name: str):
     return x.reshape(-1, x.shape[-1]), lead
 
 
+class PackedWeight:
+    """A dense block's weight that exists only as its operand image (``shape`` = [rows N, inner K] of the fp32 tensor it stands for):
+    accepted by ``linear`` / ``linear_packed`` in place of the tensor.  ``transposed_weight_image`` makes W^T this way in the 16-bit
+    modes -- the backward pass never needs W^T itself, only its image."""
+    __slots__ = ("shape", "image", "device")
+
+    def __init__(self, shape, image):
+        self.shape, self.image, self.device = tuple(int(v) for v in shape), image, image.device
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, scale=None, shift=None,
            act=None, residual: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 1.0,
            precision="bf16x3", out: Optional[torch.Tensor] = None, cache_weight: bool = True,
@@ -244,9 +254,14 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         x2, lead = _rows2d(x, "x")
         if x2.shape[1] % 4:
             x2 = _pad_last(x2)
-    w = padded_weight(_f32_cuda(weight, "weight", 2))
-    M, K, N = x2.shape[0], x2.shape[1], w.shape[0]
-    if w.shape[1] != K:
+    if isinstance(weight, PackedWeight):
+        w, weight_image, w_ld = None, weight.image, 0
+        wshape = weight.shape
+    else:
+        w = padded_weight(_f32_cuda(weight, "weight", 2))
+        wshape, w_ld = tuple(w.shape), w.stride(0)
+    M, K, N = x2.shape[0], x2.shape[1], wshape[0]
+    if wshape[1] != K:
         raise ValueError(f"linear: x has inner dim {x.shape[-1]} but weight is {tuple(weight.shape)}")
     if act not in ACTS:
         raise ValueError(f"unknown activation {act!r}")
@@ -270,17 +285,19 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
             raise ValueError(f"{nm}: expected fp32 cuda [{N}]")
     prec = _prec(precision)
     wimg = weight_image if weight_image is not None else (packed_weight_image(w, prec) if cache_weight else None)
+    if w is None and (wimg is None or prec == PREC_F32):
+        raise ValueError("linear: a PackedWeight needs its image and a 16-bit arithmetic mode")
     nbytes = lib().mdg_linear_workspace_bytes(_c64(M), _c64(N), _c64(K), _c(prec), _c(1 if wimg is not None else 0))
     ws = _workspace(nbytes, x2.device)
     if dropout_p > 0.0:
         if scale is not None or shift is not None or alpha != 1.0 or not out.is_contiguous():
             raise ValueError("linear: the dropout epilogue takes no scale / shift / alpha and a contiguous result")
-        check(lib().mdg_linear_dropout(_ptr(x2), _c64(x2.stride(0)), _ptr(w), _c64(w.stride(0)), _ptr(wimg), _ptr(out), _c64(out.stride(0)),
+        check(lib().mdg_linear_dropout(_ptr(x2), _c64(x2.stride(0)), _ptr(w), _c64(w_ld), _ptr(wimg), _ptr(out), _c64(out.stride(0)),
                                        _c64(M), _c64(N), _c64(K), _ptr(None if bias is None else bias.detach().contiguous()), _c(ACTS[act]),
                                        _ptr(residual), _c64(ldr), _f(beta), _f(dropout_p), ctypes.c_uint64(dropout_seed & (2 ** 64 - 1)), _c(prec),
                                        _ptr(ws), ctypes.c_size_t(nbytes), _stream(x2)), "mdg_linear_dropout")
         return out.view(*lead, N) if len(lead) != 1 or lead[0] != M else out
-    check(lib().mdg_linear(_ptr(x2), _c64(x2.stride(0)), _ptr(w), _c64(w.stride(0)), _ptr(wimg), _ptr(out), _c64(out.stride(0)),
+    check(lib().mdg_linear(_ptr(x2), _c64(x2.stride(0)), _ptr(w), _c64(w_ld), _ptr(wimg), _ptr(out), _c64(out.stride(0)),
                            _c64(M), _c64(N), _c64(K), _ptr(None if bias is None else bias.detach().contiguous()),
                            _ptr(None if scale is None else scale.contiguous()), _ptr(None if shift is None else shift.contiguous()),
                            _c(ACTS[act]), _ptr(residual), _c64(ldr), _f(alpha), _f(beta), _c(prec), _ptr(ws),
@@ -313,8 +330,13 @@ def linear_packed(x_img: torch.Tensor, M: int, weight: torch.Tensor, bias: Optio
     """linear() on an input that already exists as an operand image (layernorm_packed, linear_backward_pack): no pre-pass over x.
     ``weight_image``: the weight's own image if the caller keeps one (transposed_weight_image); ``cache_weight=False``: pack the
     weight inside the call (a one-shot tensor must not enter the per-storage image cache)."""
-    w = padded_weight(_f32_cuda(weight, "weight", 2))
-    N, K = w.shape
+    if isinstance(weight, PackedWeight):
+        w, weight_image, w_ld = None, weight.image, 0
+        N, K = weight.shape
+    else:
+        w = padded_weight(_f32_cuda(weight, "weight", 2))
+        N, K = w.shape
+        w_ld = w.stride(0)
     if act not in ACTS:
         raise ValueError(f"unknown activation {act!r}")
     prec = _prec(precision)
@@ -331,7 +353,7 @@ def linear_packed(x_img: torch.Tensor, M: int, weight: torch.Tensor, bias: Optio
     wimg = weight_image if weight_image is not None else (packed_weight_image(w, prec) if cache_weight else None)
     nbytes = lib().mdg_linear_packed_x_workspace_bytes(_c64(M), _c64(N), _c64(K), _c(prec), _c(1 if wimg is not None else 0))    # (+ the stream-K slots of the 256-tile kernel)
     ws = _workspace(nbytes, x_img.device)
-    check(lib().mdg_linear_packed_x(_ptr(x_img), _c64(M), _c64(K), _ptr(w), _c64(w.stride(0)), _ptr(wimg), _ptr(out), _c64(out.stride(0)), _c64(N),
+    check(lib().mdg_linear_packed_x(_ptr(x_img), _c64(M), _c64(K), _ptr(w), _c64(w_ld), _ptr(wimg), _ptr(out), _c64(out.stride(0)), _c64(N),
                                     _ptr(None if bias is None else bias.detach().contiguous()), _c(ACTS[act]), _ptr(residual), _c64(ldr),
                                     _f(alpha), _f(beta), _c(prec), _ptr(ws), ctypes.c_size_t(nbytes), _stream(x_img)), "mdg_linear_packed_x")
     return out
@@ -787,6 +809,17 @@ def transposed_weight_image(w: torch.Tensor, precision):
     hit = _wt_img_cache.get(k)
     if hit is not None and hit[0] == w._version:
         return hit[1], hit[2]
+    if prec != PREC_F32 and w.is_contiguous():
+        # 16-bit modes: W^T is only ever read as an operand image: one transposing pack of W, no fp32 transpose
+        N, K = w.shape
+        nbytes = int(lib().mdg_pack_operand_bytes(_c64(K), _c64(_ceil4(N)), _c(prec)))
+        img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        wd = w.detach()
+        check(lib().mdg_pack_operand_transposed(_ptr(wd), _c64(wd.stride(0)), _c64(N), _c64(K), _c(prec), _ptr(img), ctypes.c_size_t(nbytes), _stream(wd)),
+              "mdg_pack_operand_transposed")
+        wt = PackedWeight((K, _ceil4(N)), img)
+        _wt_img_cache[k] = (w._version, wt, img, w)
+        return wt, img
     wt = weight_transposed(w)
     nbytes = int(lib().mdg_pack_operand_bytes(_c64(wt.shape[0]), _c64(wt.shape[1]), _c(prec)))
     img = None
