@@ -38,10 +38,12 @@ class _Linear(Function):
             not (w.is_cuda and torch.cuda.is_current_stream_capturing())
 
     @staticmethod
-    def forward(ctx, x, w, b, act, precision, p=0.0, seed=0, residual=None):
+    def forward(ctx, x, w, b, act, precision, p=0.0, seed=0, residual=None, x_image=None):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
         ctx.k_in = x2.shape[1]
+        if x_image is not None and (precision not in ("bf16", "bf16x3") or ctx.k_in % 64 != 0):
+            x_image = None              # (the producer's operand image of x: layernorm_packed; only the 16-bit modes read images)
         if ctx.k_in % 4:            # 978 genes, 559 viability features, 67 atom features: zero columns up to a multiple of 4, once, so that
             x2 = ops._pad_last(x2)  # the forward GEMM and the weight gradient both read 16-byte aligned rows
         # a parameter's operand image is kept per in-place version (both sides / views of a step use it); anything else is packed
@@ -55,18 +57,26 @@ class _Linear(Function):
             res2 = residual.reshape(-1, N)
             res2 = res2 if res2.is_contiguous() else res2.contiguous()
         plain = act in (None, "none")
+
+        def gemm(act_=None, residual_=None):             # the block's GEMM without dropout: from the producer's image of x when there is one
+            if x_image is not None:
+                return ops.linear_packed(x_image, x2.shape[0], w, b, act=act_, residual=residual_, precision=precision, cache_weight=keep)
+            return ops.linear(x2, w, b, act=act_, precision=precision, cache_weight=keep, residual=residual_)
         if p > 0.0 and not plain:
             if res2 is not None:
                 raise ValueError("linear: activation + dropout + residual in one block is not a layer of the reference")
-            pre = ops.linear(x2, w, b, precision=precision, cache_weight=keep)
+            pre = gemm()
             y = ops.activation_dropout_fwd(pre, act, p, seed)
         elif act in (None, "none", "relu"):
-            y = ops.linear(x2, w, b, act=act, precision=precision, cache_weight=keep, residual=res2, dropout_p=p if plain else 0.0, dropout_seed=seed)
+            if p > 0.0:
+                y = ops.linear(x2, w, b, act=act, precision=precision, cache_weight=keep, residual=res2, dropout_p=p, dropout_seed=seed)
+            else:
+                y = gemm(act, res2)
             pre = y if act == "relu" else None
             if act == "relu" and res2 is not None:
                 raise ValueError("linear: relu + residual in one block is not a layer of the reference")
         else:
-            pre = ops.linear(x2, w, b, precision=precision, cache_weight=keep)
+            pre = gemm()
             y = ops.activation_fwd(pre, act)
             if res2 is not None:
                 y = ops.axpby(y, res2)
@@ -97,7 +107,7 @@ class _Linear(Function):
             wt, wt_img = ops.transposed_weight_image(w, ctx.precision) if _Linear._is_parameter(w) else (ops.transpose(w), None)
             dx = ops.linear_packed(row_img, g.shape[0], wt, precision=ctx.precision, weight_image=wt_img, cache_weight=False)[:, :K]
             dw = ops.linear_tn_packed_g(t_img, x2, N, ctx.precision)
-            return dx.reshape(*ctx.lead, K), dw, db, None, None, None, None, d_res
+            return dx.reshape(*ctx.lead, K), dw, db, None, None, None, None, d_res, None
         if mask_p > 0.0:
             g = ops.dropout(g, mask_p, ctx.seed)
         if ctx.needs_input_grad[0]:
@@ -117,21 +127,23 @@ class _Linear(Function):
                 dw = dw[:, :K].contiguous()
         elif want_db:
             db = ops.colsum(g)
-        return dx, dw, db, None, None, None, None, d_res
+        return dx, dw, db, None, None, None, None, d_res, None
 
 
-def linear(x, w, b=None, act=None, precision="bf16x3"):
-    return _Linear.apply(x, w, b, act, precision)
+def linear(x, w, b=None, act=None, precision="bf16x3", x_image=None):
+    """``x_image``: the operand image of ``x`` its producer wrote on the side (``layernorm(..., image_precision=...)``): the forward GEMM
+    reads it instead of packing ``x`` again; ``x`` itself is what the backward pass differentiates."""
+    return _Linear.apply(x, w, b, act, precision, 0.0, 0, None, x_image)
 
 
-def linear_dropout(x, w, b, act, precision, p: float, training: bool = True, residual=None, seed: Optional[int] = None):
+def linear_dropout(x, w, b, act, precision, p: float, training: bool = True, residual=None, seed: Optional[int] = None, x_image=None):
     """``residual + dropout(act(x W^T + b), p)`` as ONE node (dropout inside the dense block's epilogue / activation pass, its backward
     inside the gradient's packing pass); identical, bit for bit, to ``add(residual, dropout(linear(x, w, b, act), p, seed=seed))``."""
     if not training or p == 0.0:
-        return _Linear.apply(x, w, b, act, precision, 0.0, 0, residual)
+        return _Linear.apply(x, w, b, act, precision, 0.0, 0, residual, x_image)
     if p >= 1.0:
         raise ValueError("dropout p must be < 1")
-    return _Linear.apply(x, w, b, act, precision, float(p), next_seed() if seed is None else seed, residual)
+    return _Linear.apply(x, w, b, act, precision, float(p), next_seed() if seed is None else seed, residual, x_image)
 
 
 class _LayerNorm(Function):
@@ -150,8 +162,34 @@ class _LayerNorm(Function):
         return dx, dg, db, None
 
 
-def layernorm(x, weight, bias, eps=1e-5):
-    return _LayerNorm.apply(x, weight, bias, eps)
+class _LayerNormImage(Function):
+    """LayerNorm whose kernel also writes y as the operand image of the dense block that consumes it (ops.layernorm_packed): the
+    image is a side output without a gradient; y carries the graph."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, precision):
+        ctx.save_for_backward(x, weight)
+        ctx.eps = eps
+        y, img = ops.layernorm_packed(x, weight, bias, eps, precision, want_fp32=True)
+        ctx.mark_non_differentiable(img)
+        return y, img
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, _dimg):
+        x, weight = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(dy if dy.is_contiguous() else dy.contiguous(), x, weight, ctx.eps)
+        return dx, dg, db, None, None
+
+
+def layernorm(x, weight, bias, eps=1e-5, image_precision=None):
+    """``image_precision`` ("bf16" / "bf16x3"): -> (y, operand image of y | None) -- the image for ``linear(..., x_image=...)`` of the
+    block that follows, written by the LayerNorm kernel itself (2-D contiguous x whose width is a multiple of 64)."""
+    if image_precision is None:
+        return _LayerNorm.apply(x, weight, bias, eps)
+    if image_precision in ("bf16", "bf16x3") and x.dim() == 2 and x.is_contiguous() and x.shape[1] % 64 == 0 and x.shape[0] > 0:
+        return _LayerNormImage.apply(x, weight, bias, eps, image_precision)
+    return _LayerNorm.apply(x, weight, bias, eps), None
 
 
 _bn_sync = {"reduce": None}

@@ -65,13 +65,13 @@ def _train_path(m: nn.Module) -> bool:
     return m.training or (torch.is_grad_enabled() and any(p.requires_grad for p in m.parameters()))
 
 
-def _linT(x, w, b=None, act=None):
-    return ag.linear(x, w, b, act, _state["precision"])
+def _linT(x, w, b=None, act=None, x_image=None):
+    return ag.linear(x, w, b, act, _state["precision"], x_image)
 
 
-def _linT_drop(x, w, b, act, drop: nn.Dropout, residual=None):
+def _linT_drop(x, w, b, act, drop: nn.Dropout, residual=None, x_image=None):
     """residual + drop(act(x W^T + b)) as one autograd node (dropout inside the dense block: autograd._Linear)."""
-    return ag.linear_dropout(x, w, b, act, _state["precision"], drop.p, drop.training, residual)
+    return ag.linear_dropout(x, w, b, act, _state["precision"], drop.p, drop.training, residual, x_image=x_image)
 
 
 def _require_eval(m: nn.Module) -> None:
@@ -1117,21 +1117,24 @@ class TransformerFusion(nn.Module):
         sa = L.self_attn
         p_att = sa.dropout if sa.training else 0.0
 
-        def sa_block(x):
-            att = attend(_linT(x, sa.in_proj_weight, sa.in_proj_bias), p_att)
+        def sa_block(x, x_image=None):
+            att = attend(_linT(x, sa.in_proj_weight, sa.in_proj_bias, x_image=x_image), p_att)
             return att
 
         # the three dropouts live inside their dense blocks (GEMM epilogue / activation pass; backward inside the gradient's packing
         # pass) and the residual adds inside the epilogues: x + dropout(linear(...)) is one node and one launch
-        def ff_block(x, residual):
-            u = _linT_drop(x, L.linear1.weight, L.linear1.bias, self.actn, L.dropout)
+        def ff_block(x, residual, x_image=None):
+            u = _linT_drop(x, L.linear1.weight, L.linear1.bias, self.actn, L.dropout, x_image=x_image)
             return _linT_drop(u, L.linear2.weight, L.linear2.bias, None, L.dropout2, residual)
         if self.norm_first:
-            att = sa_block(ag.layernorm(h, L.norm1.weight, L.norm1.bias, L.norm1.eps))
+            # the norms write the operand image of the block they feed on the side (no packing pass over their output)
+            prec = _state["precision"]
+            att = sa_block(*ag.layernorm(h, L.norm1.weight, L.norm1.bias, L.norm1.eps, image_precision=prec))
             if keep_rows is not None:
                 att, h = att.index_select(0, keep_rows), h.index_select(0, keep_rows)
             h = _linT_drop(att, sa.out_proj.weight, sa.out_proj.bias, None, L.dropout1, h)
-            return ff_block(ag.layernorm(h, L.norm2.weight, L.norm2.bias, L.norm2.eps), h)
+            y2, img2 = ag.layernorm(h, L.norm2.weight, L.norm2.bias, L.norm2.eps, image_precision=prec)
+            return ff_block(y2, h, img2)
         att = sa_block(h)
         if keep_rows is not None:
             att, h = att.index_select(0, keep_rows), h.index_select(0, keep_rows)
