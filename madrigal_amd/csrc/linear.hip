@@ -1448,6 +1448,7 @@ static size_t image_bytes_t(int64_t rows, int64_t inner, int precision) {      /
   return al256(static_cast<size_t>(rows) * Mp * (precision == MDG_PREC_BF16 ? 2 : 4));
 }
 
+namespace {
 // y[i] = sum_z part[z][i] (split-K partials of mdg_linear_tn), 16 bytes per thread, fixed order
 __global__ __launch_bounds__(256) void ksplit_sum_kernel(const float* __restrict__ part, float* __restrict__ y, int64_t n4, int64_t stride, int splits) {
   const int64_t q = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -1456,6 +1457,8 @@ __global__ __launch_bounds__(256) void ksplit_sum_kernel(const float* __restrict
   for (int z = 1; z < splits; ++z) s += reinterpret_cast<const f32x4*>(part + z * stride)[q];
   reinterpret_cast<f32x4*>(y)[q] = s;
 }
+
+}  // namespace
 
 // Weight-gradient products with few output tiles (dW [2048, 1024] over 22 016 rows: 128 tiles of 128 x 128, half the CUs idle for the
 // whole K loop): the K range is split over grid.y so that ~256 workgroups run, partial products summed afterwards.
