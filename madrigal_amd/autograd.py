@@ -49,6 +49,10 @@ class _Linear(Function):
         # a parameter's operand image is kept per in-place version (both sides / views of a step use it); anything else is packed
         # inside the call (a temporary must not enter the per-storage cache)
         keep = _Linear._is_parameter(w)
+        w_img = None
+        if keep and ctx.needs_input_grad[0] and precision in ("bf16", "bf16x3"):
+            both = ops.parameter_images(w, precision)          # W's image and W^T's (for dx) from one pass over W, per parameter version
+            w_img = None if both is None else both[0]
         N = w.shape[0]
         res2 = None
         if residual is not None:
@@ -60,8 +64,9 @@ class _Linear(Function):
 
         def gemm(act_=None, residual_=None):             # the block's GEMM without dropout: from the producer's image of x when there is one
             if x_image is not None:
-                return ops.linear_packed(x_image, x2.shape[0], w, b, act=act_, residual=residual_, precision=precision, cache_weight=keep)
-            return ops.linear(x2, w, b, act=act_, precision=precision, cache_weight=keep, residual=residual_)
+                return ops.linear_packed(x_image, x2.shape[0], w, b, act=act_, residual=residual_, precision=precision, cache_weight=keep,
+                                         weight_image=w_img)
+            return ops.linear(x2, w, b, act=act_, precision=precision, cache_weight=keep, residual=residual_, weight_image=w_img)
         if p > 0.0 and not plain:
             if res2 is not None:
                 raise ValueError("linear: activation + dropout + residual in one block is not a layer of the reference")
@@ -69,7 +74,8 @@ class _Linear(Function):
             y = ops.activation_dropout_fwd(pre, act, p, seed)
         elif act in (None, "none", "relu"):
             if p > 0.0:
-                y = ops.linear(x2, w, b, act=act, precision=precision, cache_weight=keep, residual=res2, dropout_p=p, dropout_seed=seed)
+                y = ops.linear(x2, w, b, act=act, precision=precision, cache_weight=keep, residual=res2, dropout_p=p, dropout_seed=seed,
+                               weight_image=w_img)
             else:
                 y = gemm(act, res2)
             pre = y if act == "relu" else None

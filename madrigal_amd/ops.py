@@ -796,6 +796,34 @@ def weight_transposed(w: torch.Tensor) -> torch.Tensor:
 
 
 _wt_img_cache = {}
+_param_img_cache = {}
+
+
+def parameter_images(w: torch.Tensor, precision):
+    """(operand image of W, PackedWeight of W^T) of a parameter [N,K] from ONE pass over it (mdg_linear_backward_pack: the kernel that
+    packs a gradient both ways), kept per (storage, in-place version, mode): a training step needs both -- W for the forward block,
+    W^T for dx -- once per optimizer update.  None in the modes / shapes that take the tensor as it is (callers fall back to the
+    separate packs)."""
+    prec = _prec(precision)
+    if prec == PREC_F32 or w.dim() != 2 or not w.is_contiguous() or w.shape[1] % 4 or w.data_ptr() % 16 or \
+            (w.is_cuda and torch.cuda.is_current_stream_capturing()):
+        return None
+    k = (w.data_ptr(), tuple(w.shape), str(w.device), prec)
+    hit = _param_img_cache.get(k)
+    if hit is not None and hit[0] == w._version:
+        return hit[1], hit[2]
+    N, K = w.shape
+    L_ = lib()
+    rb = int(L_.mdg_linear_backward_pack_bytes(_c64(N), _c64(K), _c(prec), _c(0)))
+    tb = int(L_.mdg_linear_backward_pack_bytes(_c64(N), _c64(K), _c(prec), _c(1)))
+    img = torch.empty(rb, dtype=torch.uint8, device=w.device)
+    timg = torch.empty(tb, dtype=torch.uint8, device=w.device)
+    wd = w.detach()
+    check(L_.mdg_linear_backward_pack(_ptr(wd), _c64(K), _c64(N), _c64(K), _c(prec), _ptr(img), _ptr(timg), _ptr(None), _f(0.0), ctypes.c_uint64(0),
+                                      _ptr(None), ctypes.c_size_t(0), _stream(wd)), "mdg_linear_backward_pack")
+    wt = PackedWeight((K, _ceil4(N)), timg)
+    _param_img_cache[k] = (w._version, img, wt, w)
+    return img, wt
 
 
 def transposed_weight_image(w: torch.Tensor, precision):
@@ -806,6 +834,9 @@ def transposed_weight_image(w: torch.Tensor, precision):
     if w.is_cuda and torch.cuda.is_current_stream_capturing():
         return transpose(w.detach()), None
     k = (w.data_ptr(), tuple(w.shape), str(w.device), prec)
+    hit = _param_img_cache.get(k)
+    if hit is not None and hit[0] == w._version:           # made together with W's own image by the forward pass
+        return hit[2], hit[2].image
     hit = _wt_img_cache.get(k)
     if hit is not None and hit[0] == w._version:
         return hit[1], hit[2]
