@@ -518,6 +518,11 @@ size_t mdg_layernorm_bwd_workspace_bytes(int64_t rows, int64_t d);
 int mdg_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, float* dx, int64_t lddx,
                       float* dgamma, float* dbeta, int64_t rows, int64_t d, float eps, void* workspace, size_t workspace_bytes,
                       void* stream);
+/* dx = LayerNorm-backward(dy) + extra: x feeds the norm AND a residual connection (pre-norm transformer blocks), `extra` is the
+ * gradient that arrives through the residual; added while dx is written instead of by a pass of its own. */
+int mdg_layernorm_bwd_add(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* extra,
+                          int64_t ldextra, float* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int64_t d, float eps,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

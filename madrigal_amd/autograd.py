@@ -188,6 +188,42 @@ class _LayerNormImage(Function):
         return dx, dg, db, None, None
 
 
+class _LayerNormFork(Function):
+    """x feeds a LayerNorm AND a residual connection (pre-norm transformer blocks): -> (LayerNorm(x), its operand image | None, x as
+    the residual branch).  One node instead of two consumers of x: the backward pass adds the residual branch's gradient while the
+    norm's dx is written (mdg_layernorm_bwd_add) instead of leaving the sum to a pass of the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, precision):
+        ctx.save_for_backward(x, weight)
+        ctx.eps = eps
+        ctx.set_materialize_grads(False)
+        img = None
+        if precision in ("bf16", "bf16x3") and x.dim() == 2 and x.is_contiguous() and x.shape[1] % 64 == 0 and x.shape[0] > 0:
+            y, img = ops.layernorm_packed(x, weight, bias, eps, precision, want_fp32=True)
+            ctx.mark_non_differentiable(img)
+        else:
+            y = ops.layernorm(x if x.is_contiguous() else x.contiguous(), weight, bias, eps)
+        return y, img, x.view_as(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, _dimg, dres):
+        x, weight = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None, None
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        if dres is not None and not dres.is_contiguous():
+            dres = dres.contiguous()
+        dx, dg, db = ops.layernorm_bwd(dy, x if x.is_contiguous() else x.contiguous(), weight, ctx.eps, extra=dres)
+        return dx, dg, db, None, None
+
+
+def layernorm_fork(x, weight, bias, eps=1e-5, image_precision=None):
+    """-> (LayerNorm(x), operand image of it | None, x for the residual connection): see _LayerNormFork."""
+    return _LayerNormFork.apply(x, weight, bias, eps, image_precision)
+
+
 def layernorm(x, weight, bias, eps=1e-5, image_precision=None):
     """``image_precision`` ("bf16" / "bf16x3"): -> (y, operand image of y | None) -- the image for ``linear(..., x_image=...)`` of the
     block that follows, written by the LayerNorm kernel itself (2-D contiguous x whose width is a multiple of 64)."""

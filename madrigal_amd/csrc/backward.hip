@@ -305,7 +305,8 @@ constexpr int LN_DMAX = 2048;    // 64 lanes x LN_MAXJ columns; instantiated for
 template <int LN_MAXJ>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
                                                             const float* __restrict__ gamma, float* __restrict__ dx, int64_t lddx,
-                                                            float* __restrict__ part, int64_t rows, int d, float eps) {
+                                                            float* __restrict__ part, int64_t rows, int d, float eps,
+                                                            const float* __restrict__ extra, int64_t ldextra) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nj = (d + 63) >> 6;
   float dg[LN_MAXJ], db[LN_MAXJ];
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < LN_MAXJ; ++j) {
       const int c = lane + 64 * j;
-      if (j < nj && c < d) dx[r * lddx + c] = rstd * (gv[j] - s1 - xv[j] * s2);
+      if (j < nj && c < d) dx[r * lddx + c] = rstd * (gv[j] - s1 - xv[j] * s2) + (extra ? extra[r * ldextra + c] : 0.f);
     }
   }
   // block partials: part[block][0][c] = dgamma, part[block][1][c] = dbeta
@@ -378,7 +379,8 @@ constexpr int LN_VEC_ROWS = 32;
 template <int MAXJ>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
                                                                 const float* __restrict__ gamma, float* __restrict__ dx, int64_t lddx,
-                                                                float* __restrict__ part, int64_t rows, int d, float eps) {
+                                                                float* __restrict__ part, int64_t rows, int d, float eps,
+                                                                const float* __restrict__ extra, int64_t ldextra) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 dg[MAXJ], db[MAXJ];
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
   for (int i = wave; i < LN_VEC_ROWS; i += 4) {
     const int64_t r = r0 + i;
     if (r >= rows) break;
-    f32x4 xv[MAXJ], gv[MAXJ];
+    f32x4 xv[MAXJ], gv[MAXJ], ev[MAXJ];
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
@@ -397,6 +399,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
       const bool ok = c < d;
       xv[j] = ok ? *reinterpret_cast<const f32x4*>(x + r * ldx + c) : zero;
       gv[j] = ok ? *reinterpret_cast<const f32x4*>(dy + r * lddy + c) : zero;
+      ev[j] = (ok && extra) ? *reinterpret_cast<const f32x4*>(extra + r * ldextra + c) : zero;      // (travels with the other two rows)
       s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
     }
     const float mean = mdg_wave_sum(s) * inv_d;
@@ -439,6 +442,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rstd * (gv[j][e] - s1 - xv[j][e] * s2);
+        if (extra) o += ev[j];                              // the gradient of the other consumer of x
         *reinterpret_cast<f32x4*>(dx + r * lddx + c) = o;
       }
     }
@@ -647,15 +651,16 @@ extern "C" size_t mdg_layernorm_bwd_workspace_bytes(int64_t rows, int64_t d) {
   return rows <= 0 || d <= 0 ? 0 : static_cast<size_t>(mdg_cdiv(rows, LN_VEC_ROWS)) * 2 * d * sizeof(float);
 }
 
-extern "C" int mdg_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, float* dx, int64_t lddx,
-                                 float* dgamma, float* dbeta, int64_t rows, int64_t d, float eps, void* workspace, size_t workspace_bytes,
-                                 void* stream) {
+static int layernorm_bwd_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, float* dx, int64_t lddx,
+                              float* dgamma, float* dbeta, int64_t rows, int64_t d, float eps, void* workspace, size_t workspace_bytes,
+                              void* stream, const float* extra, int64_t ldextra) {
+  MDG_CHECK_ARG(!extra || ldextra >= d, "mdg_layernorm_bwd: row stride of the added gradient shorter than d");
   MDG_CHECK_ARG(rows >= 0 && d > 0 && d <= LN_DMAX, "mdg_layernorm_bwd: d must be in [1,%d]", LN_DMAX);
   MDG_CHECK_ARG(lddy >= d && ldx >= d && lddx >= d, "mdg_layernorm_bwd: row strides shorter than d");
   MDG_CHECK_ARG(gamma && dgamma && dbeta, "mdg_layernorm_bwd: null parameter pointers");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool vec = d % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && mdg_aligned16(dy) && mdg_aligned16(x) && mdg_aligned16(dx) &&
-                   mdg_aligned16(gamma);
+                   mdg_aligned16(gamma) && (!extra || (ldextra % 4 == 0 && mdg_aligned16(extra)));
   const int64_t nb = mdg_cdiv(rows, vec ? LN_VEC_ROWS : 64);
   const size_t need = mdg_layernorm_bwd_workspace_bytes(rows, d);
   if (need && (!workspace || workspace_bytes < need)) {
@@ -669,16 +674,16 @@ extern "C" int mdg_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
     const dim3 grid(static_cast<unsigned>(nb));
     const int di = static_cast<int>(d);
     if (vec) {
-      if (d <= 256) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<1>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps);
-      else if (d <= 512) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<2>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps);
-      else if (d <= 1024) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<4>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps);
-      else hipLaunchKernelGGL(layernorm_bwd_vec_kernel<8>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps);
+      if (d <= 256) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<1>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps, extra, ldextra);
+      else if (d <= 512) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<2>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps, extra, ldextra);
+      else if (d <= 1024) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<4>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps, extra, ldextra);
+      else hipLaunchKernelGGL(layernorm_bwd_vec_kernel<8>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps, extra, ldextra);
     } else if (d <= 128)
-      hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps);
+      hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps, extra, ldextra);
     else if (d <= 512)
-      hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps);
+      hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps, extra, ldextra);
     else
-      hipLaunchKernelGGL(layernorm_bwd_kernel<32>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps);
+      hipLaunchKernelGGL(layernorm_bwd_kernel<32>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps, extra, ldextra);
   }
   // dgamma = sum of partial rows [nb, 2d] -> first d columns, dbeta the next d
   hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(d, 64))), dim3(256), 0, st, static_cast<const float*>(workspace),
@@ -687,6 +692,19 @@ extern "C" int mdg_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
                      static_cast<const float*>(workspace) + d, 2 * d, dbeta, nb, d, 0.f);
   MDG_CHECK_LAUNCH("mdg_layernorm_bwd");
   return MDG_OK;
+}
+
+extern "C" int mdg_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, float* dx, int64_t lddx,
+                                 float* dgamma, float* dbeta, int64_t rows, int64_t d, float eps, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  return layernorm_bwd_impl(dy, lddy, x, ldx, gamma, dx, lddx, dgamma, dbeta, rows, d, eps, workspace, workspace_bytes, stream, nullptr, 0);
+}
+
+extern "C" int mdg_layernorm_bwd_add(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* extra,
+                                     int64_t ldextra, float* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int64_t d, float eps,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  MDG_CHECK_ARG(extra, "mdg_layernorm_bwd_add: null gradient to add");
+  return layernorm_bwd_impl(dy, lddy, x, ldx, gamma, dx, lddx, dgamma, dbeta, rows, d, eps, workspace, workspace_bytes, stream, extra, ldextra);
 }
 
 // y = act(x * scale[c] + shift[c])   (eval-mode BatchNorm under autograd; shift may be null: the backward pass)

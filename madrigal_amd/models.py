@@ -1128,12 +1128,14 @@ class TransformerFusion(nn.Module):
             return _linT_drop(u, L.linear2.weight, L.linear2.bias, None, L.dropout2, residual)
         if self.norm_first:
             # the norms write the operand image of the block they feed on the side (no packing pass over their output)
+            # ... and hand x on to the residual connection, so that the two gradients of x meet inside the norm's backward kernel
             prec = _state["precision"]
-            att = sa_block(*ag.layernorm(h, L.norm1.weight, L.norm1.bias, L.norm1.eps, image_precision=prec))
+            y1, img1, h = ag.layernorm_fork(h, L.norm1.weight, L.norm1.bias, L.norm1.eps, image_precision=prec)
+            att = sa_block(y1, img1)
             if keep_rows is not None:
                 att, h = att.index_select(0, keep_rows), h.index_select(0, keep_rows)
             h = _linT_drop(att, sa.out_proj.weight, sa.out_proj.bias, None, L.dropout1, h)
-            y2, img2 = ag.layernorm(h, L.norm2.weight, L.norm2.bias, L.norm2.eps, image_precision=prec)
+            y2, img2, h = ag.layernorm_fork(h, L.norm2.weight, L.norm2.bias, L.norm2.eps, image_precision=prec)
             return ff_block(y2, h, img2)
         att = sa_block(h)
         if keep_rows is not None:

@@ -1006,8 +1006,9 @@ def batchnorm_train_bwd(dy: torch.Tensor, x: torch.Tensor, stats: torch.Tensor):
     return dx, dg, db
 
 
-def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-5):
-    """-> (dx, dweight, dbias); ``x`` is the LayerNorm input (statistics are recomputed)."""
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-5, extra: Optional[torch.Tensor] = None):
+    """-> (dx, dweight, dbias); ``x`` is the LayerNorm input (statistics are recomputed).  ``extra``: a gradient of ``x`` that arrives
+    through another consumer (the residual connection of a pre-norm block): dx = LayerNorm-backward(dy) + extra in the same pass."""
     d = x.shape[-1]
     x2 = x.reshape(-1, d) if x.stride(-1) == 1 and x.dim() == 2 else _f32_cuda(x, "x").reshape(-1, d)
     dy2 = dy.reshape(-1, d) if dy.stride(-1) == 1 and dy.dim() == 2 else _f32_cuda(dy, "dy").reshape(-1, d)
@@ -1017,6 +1018,14 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, eps: 
     db = torch.empty_like(dg)
     nbytes = lib().mdg_layernorm_bwd_workspace_bytes(_c64(R), _c64(d))
     ws = _workspace(nbytes, x2.device)
+    if extra is not None:
+        e2 = extra.reshape(-1, d) if extra.stride(-1) == 1 and extra.dim() == 2 else _f32_cuda(extra, "extra").reshape(-1, d)
+        if e2.shape[0] != R:
+            raise ValueError("layernorm_bwd: extra must have the shape of x")
+        check(lib().mdg_layernorm_bwd_add(_ptr(dy2), _c64(dy2.stride(0)), _ptr(x2), _c64(x2.stride(0)), _ptr(weight.detach().contiguous()), _ptr(e2),
+                                          _c64(e2.stride(0)), _ptr(dx), _c64(d), _ptr(dg), _ptr(db), _c64(R), _c64(d), _f(eps), _ptr(ws),
+                                          ctypes.c_size_t(nbytes), _stream(x2)), "mdg_layernorm_bwd_add")
+        return dx.view(x.shape), dg, db
     check(lib().mdg_layernorm_bwd(_ptr(dy2), _c64(dy2.stride(0)), _ptr(x2), _c64(x2.stride(0)), _ptr(weight.detach().contiguous()), _ptr(dx),
                                   _c64(d), _ptr(dg), _ptr(db), _c64(R), _c64(d), _f(eps), _ptr(ws), ctypes.c_size_t(nbytes), _stream(x2)),
           "mdg_layernorm_bwd")

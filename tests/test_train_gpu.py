@@ -1575,3 +1575,35 @@ def test_dense_block_with_dropout_and_residual_inside_equals_the_separate_nodes(
     y_eval = ag.linear_dropout(x0, w0, b0, act, prec, p, False, r0)
     y_plain = ag.linear(x0, w0, b0, act, prec)
     assert torch.equal(y_eval, y_plain + r0 if with_res else y_plain)
+
+
+@pytest.mark.parametrize("R,d,prec", [(300, 256, "bf16x3"), (70, 2048, "bf16"), (33, 100, "f32"), (5, 64, None)])
+def test_layernorm_fork_adds_the_residual_gradient_inside_the_norm_backward(R, d, prec):
+    """x feeds a LayerNorm and a residual connection: autograd.layernorm_fork returns both branches from one node, whose backward adds
+    the residual branch's gradient while the norm's dx is written.  Values, the operand image's effect and every gradient equal the
+    two separate consumers of x, bit for bit; an unused branch costs nothing."""
+    from madrigal_amd import autograd as ag
+    x0, w0, b0 = _rand(R, d, seed=21).to(DEV), (1 + 0.1 * _rand(d, seed=22)).to(DEV), _rand(d, seed=23).to(DEV)
+    g_ln, g_res = _rand(R, d, seed=24).to(DEV), _rand(R, d, seed=25).to(DEV)
+
+    def leafs():
+        return x0.clone().requires_grad_(True), torch.nn.Parameter(w0.clone()), torch.nn.Parameter(b0.clone())
+    x, w, b = leafs()
+    y, img, xr = ag.layernorm_fork(x, w, b, 1e-5, prec)
+    assert torch.equal(xr, x0) and (img is None) == (prec in (None, "f32") or d % 64 != 0)
+    torch.autograd.backward([y, xr], [g_ln, g_res])
+    xs, ws, bs = leafs()
+    ys = ag.layernorm(xs, ws, bs, 1e-5)
+    torch.autograd.backward([ys, xs * 1.0], [g_ln, g_res])
+    assert torch.equal(y, ys) and torch.equal(x.grad, xs.grad) and torch.equal(w.grad, ws.grad) and torch.equal(b.grad, bs.grad)
+    # only one branch used
+    x, w, b = leafs()
+    y, _, xr = ag.layernorm_fork(x, w, b, 1e-5, prec)
+    xr.backward(g_res)
+    assert torch.equal(x.grad, g_res) and w.grad is None
+    x, w, b = leafs()
+    y, _, xr = ag.layernorm_fork(x, w, b, 1e-5, prec)
+    y.backward(g_ln)
+    xs, ws, bs = leafs()
+    ag.layernorm(xs, ws, bs, 1e-5).backward(g_ln)
+    assert torch.equal(x.grad, xs.grad) and torch.equal(w.grad, ws.grad)
