@@ -40,6 +40,36 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   if (ty == 0 && c < cols) part[static_cast<int64_t>(blockIdx.y) * cols + c] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
+// BatchNorm backward: modes 0 (sum dy -> dbeta) and 2 (sum dy xhat -> dgamma) of the kernel above in ONE pass over dy (same rows per
+// thread, same order of additions: the same bits as the two launches).  part0 / part2: [parts][cols] each.
+__global__ __launch_bounds__(256) void colreduce_bn_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
+                                                               const float* __restrict__ center, const float* __restrict__ rstd, float* __restrict__ part0,
+                                                               float* __restrict__ part2, int64_t rows, int64_t cols) {
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
+  const int ty = threadIdx.x >> 6;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * 256;
+  float s0 = 0.f, s2 = 0.f;
+  if (c < cols) {
+    const float mu = center[c], rs = rstd[c];
+    for (int i = 0; i < 64; ++i) {
+      const int64_t r = r0 + ty + 4 * i;
+      if (r >= rows) break;
+      const float v = dy[r * lddy + c];
+      s0 += v;
+      s2 += v * ((x[r * ldx + c] - mu) * rs);
+    }
+  }
+  __shared__ float sh[2][4][64];
+  sh[0][ty][threadIdx.x & 63] = s0;
+  sh[1][ty][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (ty == 0 && c < cols) {
+    const int e = threadIdx.x;
+    part0[static_cast<int64_t>(blockIdx.y) * cols + c] = (sh[0][0][e] + sh[0][1][e]) + (sh[0][2][e] + sh[0][3][e]);
+    part2[static_cast<int64_t>(blockIdx.y) * cols + c] = (sh[1][0][e] + sh[1][1][e]) + (sh[1][2][e] + sh[1][3][e]);
+  }
+}
+
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int64_t ldp, float* __restrict__ out,
                                                            int64_t nparts, int64_t cols, float beta) {
   // 64 columns per block, the partials interleaved over the four thread rows, combined through LDS in a fixed order
@@ -579,7 +609,7 @@ extern "C" int mdg_dropout(const float* x, float* y, int64_t n, float p, uint64_
 
 // ------------------------------------------------------------------------------------------------- BatchNorm1d (train)
 extern "C" size_t mdg_batchnorm_workspace_bytes(int64_t rows, int64_t cols) {
-  return rows <= 0 || cols <= 0 ? 0 : (static_cast<size_t>(mdg_cdiv(rows, 256)) + 2) * cols * sizeof(float);
+  return rows <= 0 || cols <= 0 ? 0 : (2 * static_cast<size_t>(mdg_cdiv(rows, 256)) + 2) * cols * sizeof(float);
 }
 
 static int colreduce(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* center, const float* rstd, float* out,
@@ -637,9 +667,21 @@ extern "C" int mdg_batchnorm_train_bwd(const float* dy, const float* x, const fl
     return MDG_EWORKSPACE;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // both column reductions from one pass over dy: partials of dbeta in the workspace's first half, of dgamma in its second
   float* part = static_cast<float*>(workspace) + 2 * cols;
-  colreduce(dy, cols, nullptr, 0, nullptr, nullptr, dbeta, rows, cols, 0, part, st);
-  colreduce(dy, cols, x, cols, stats, stats + cols, dgamma, rows, cols, 2, part, st);
+  const int64_t nparts = mdg_cdiv(rows, 256);
+  if (workspace_bytes >= (2 * static_cast<size_t>(nparts) + 2) * cols * sizeof(float)) {
+    float* part2 = part + nparts * cols;
+    hipLaunchKernelGGL(colreduce_bn_bwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64)), static_cast<unsigned>(nparts)), dim3(256), 0, st, dy, cols, x, cols,
+                       stats, stats + cols, part, part2, rows, cols);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64))), dim3(256), 0, st, static_cast<const float*>(part), cols, dbeta, nparts,
+                       cols, 0.f);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64))), dim3(256), 0, st, static_cast<const float*>(part2), cols, dgamma, nparts,
+                       cols, 0.f);
+  } else {
+    colreduce(dy, cols, nullptr, 0, nullptr, nullptr, dbeta, rows, cols, 0, part, st);
+    colreduce(dy, cols, x, cols, stats, stats + cols, dgamma, rows, cols, 2, part, st);
+  }
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(static_cast<unsigned>(mdg_cdiv(rows * cols, 256))), dim3(256), 0, st, dy, x, stats, dbeta, dgamma,
                      dx, rows, cols, static_cast<float>(rows));
   MDG_CHECK_LAUNCH("mdg_batchnorm_train_bwd");
