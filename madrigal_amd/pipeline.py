@@ -140,5 +140,16 @@ def rank_all_pairs(model, z: torch.Tensor, label_range: Optional[Tuple[int, int]
         out = ops.empty_scores(hi - lo, N, N, z.device)
     elif not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == (hi - lo, N, N)):
         raise ValueError(f"out: expected a float32 GPU tensor of shape {(hi - lo, N, N)} (ops.empty_scores)")
+    pitch = out.stride(1) if out.numel() else N
+    if N * pitch * 4 >= 2 ** 32 or pitch % 4:
+        # beyond the symmetric sweep's 32-bit slab offsets (N > 32 767) or on an unpadded tensor: scores first, ranks over them in place of
+        # a second tensor is not possible (rank_normalize reads what it overwrites) -- one outcome chunk of scores at a time
+        chunk = max(1, min(hi - lo, (8 << 30) // max(N * pitch * 4, 1)))
+        tmp = ops.empty_scores(chunk, N, N, z.device)
+        for s in range(lo, hi, chunk):
+            e = min(hi, s + chunk)
+            dec(z, z, (s, e), out=tmp[: e - s])
+            ops.rank_normalize(tmp[: e - s], out=out[s - lo: e - lo], max_workspace_bytes=max_workspace_bytes)
+        return out
     keys = dec(z, z, (lo, hi), epilogue=ops.EPI_TRIKEYS, out=out.view(torch.int32))
     return ops.rank_normalize(keys, max_workspace_bytes=max_workspace_bytes)

@@ -140,6 +140,11 @@ def test_rank_all_pairs_equals_ranks_of_score_all_pairs():
         want = _ops.rank_normalize(score_all_pairs(model, z, (2, 8)))
         got = rank_all_pairs(model, z, (2, 8))
     assert got.shape == (6, 771, 771) and torch.equal(got, want)
+    # a caller's own contiguous tensor (rows not on 16-byte boundaries): scores chunk by chunk, ranks into it -- same ranks
+    mine = torch.empty(6, 771, 771, device="cuda")
+    with M.precision("bf16x3"):
+        assert rank_all_pairs(model, z, (2, 8), out=mine) is mine
+    assert torch.equal(mine, want.contiguous())
 
 
 @pytest.mark.parametrize("path", ["default", "tile8192", "direct", "lookback"])
