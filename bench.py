@@ -411,7 +411,10 @@ def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend
     fs = FinetuneStep(model, create_optimizer(model, hp), rank=rank, world=world)
     torch.manual_seed(4321 + rank)
     with M.precision(precision):
-        losses = [float(fs.step(batch, batch, batch["masks"], batch["masks"], bkg, lab, hd, tl, y, kg_filler=filler))]     # warm-up
+        # warm-up: one step per triple set -- each set has its own tensor sizes (pair counts, tile tables), whose first allocation from the
+        # device is slow (a 45-ms step then takes 60-100 ms); afterwards the caching allocator holds them.  The timed steps still build the
+        # plan of a DIFFERENT set than the step before them, every step.
+        losses = [float(fs.step(batch, batch, batch["masks"], batch["masks"], bkg, *sets[k_], kg_filler=filler)) for k_ in (1, 2, 0)][-1:]
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -437,7 +440,7 @@ def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend
     med = sorted(step_ms)[len(step_ms) // 2] * 1e-3
     mean_dt, dt = dt, (med if world == 1 else dt)
     out = {"metric": "DDI-finetune steps/sec", "value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "n_gpus": world,
-           "scaling": "strong", "steps": args.finetune_steps, "warmup": 1, "triples_per_step": T, "drugs": N, "outcomes": L,
+           "scaling": "strong", "steps": args.finetune_steps, "warmup": 3, "triples_per_step": T, "drugs": N, "outcomes": L,
            "timing": "median of the steps' own times (HIP events between back-to-back steps)" if world == 1 else "timed region / steps, max over ranks",
            "step_ms": step_ms, "ms_per_step_mean_of_timed_region": mean_dt * 1e3,
            "dtype": {"bf16": "bf16 GEMM operands, fp32 accumulate / master weights / optimizer; gathered head fp32-grade (split-bf16 products)", "bf16x3": "f32 via split-bf16 (bf16x3) MFMA",
