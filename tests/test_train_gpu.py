@@ -1607,3 +1607,30 @@ def test_layernorm_fork_adds_the_residual_gradient_inside_the_norm_backward(R, d
     xs, ws, bs = leafs()
     ag.layernorm(xs, ws, bs, 1e-5).backward(g_ln)
     assert torch.equal(x.grad, xs.grad) and torch.equal(w.grad, ws.grad)
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("N,K", [(128, 128), (384, 68), (1000, 512), (2048, 2048), (67, 128)])
+def test_parameter_images_equal_the_separate_packs(N, K, prec):
+    """ops.parameter_images: W's operand image and the image of W^T from ONE pass over W (per parameter version) -- dense blocks run
+    from them give the bits of the separately packed W and of the fp32 transpose; the images follow the parameter's in-place updates."""
+    from madrigal_amd import ops
+    w = torch.nn.Parameter(_rand(N, K, seed=31, scale=0.05).to(DEV))
+    x = _rand(257, K, seed=32).to(DEV)
+    g = _rand(257, N, seed=33).to(DEV)
+    both = ops.parameter_images(w, prec)
+    assert both is not None
+    img, wt = both
+    assert torch.equal(ops.linear(x, w.detach(), precision=prec, cache_weight=False, weight_image=img), ops.linear(x, w.detach(), precision=prec, cache_weight=False))
+    ref_dx = ops.linear(g, ops.transpose(w.detach()), precision=prec, cache_weight=False)[:, :K]
+    assert torch.equal(ops.linear(g, wt, precision=prec)[:, :K], ref_dx)
+    wt2, img2 = ops.transposed_weight_image(w, prec)                 # the backward pass finds the forward pass's image
+    assert wt2 is wt and img2 is wt.image
+    with torch.no_grad():
+        w.mul_(1.5)                                                  # optimizer update: new version, new images
+    img_b, wt_b = ops.parameter_images(w, prec)
+    assert wt_b is not wt
+    assert torch.equal(ops.linear(g, wt_b, precision=prec)[:, :K], ops.linear(g, ops.transpose(w.detach()), precision=prec, cache_weight=False)[:, :K])
+    if N % 64 == 0:                                                  # the image form of W^T also feeds the packed-x entry (wide blocks' dx)
+        row_img, _, _ = ops.linear_backward_pack(g, prec)
+        assert torch.equal(ops.linear_packed(row_img, 257, wt_b, precision=prec)[:, :K], ops.linear(g, wt_b, precision=prec)[:, :K])
