@@ -907,6 +907,42 @@ def hgt_project_rows(layout, total_floats, precision, xs, big_w, big_b, offs):
     return _HgtProjectRows.apply(tuple(layout), total_floats, precision, tuple(offs), big_w, big_b, *xs)
 
 
+_hgt_lanes = {}
+
+
+class _type_lanes:
+    """The destination types of a conv are independent launches (every type reads the shared projection buffer and writes its own
+    rows / its own relations' column blocks): they are dealt to a few side streams that fork from the current stream and join it
+    again, so that the small types' kernels run beside the large ones instead of in a chain of launch gaps.  MDG_HGT_LANES=1 (or a
+    stream capture in progress, or a CPU tensor) keeps the plain loop."""
+
+    def __init__(self, ref: torch.Tensor, n_items: int):
+        import os
+        want = int(os.environ.get("MDG_HGT_LANES", "2"))
+        self.cur = self.lanes = None
+        if ref.is_cuda and want > 1 and n_items > 1 and not torch.cuda.is_current_stream_capturing():
+            self.cur = torch.cuda.current_stream(ref.device)
+            key = (ref.device, self.cur.cuda_stream, want)
+            if key not in _hgt_lanes:
+                _hgt_lanes[key] = [torch.cuda.Stream(device=ref.device) for _ in range(want)]
+            self.lanes = _hgt_lanes[key]
+            for st in self.lanes:
+                st.wait_stream(self.cur)
+
+    def lane(self, i: int):
+        import contextlib
+        return contextlib.nullcontext() if self.lanes is None else torch.cuda.stream(self.lanes[i % len(self.lanes)])
+
+    def join(self, *tensors):
+        if self.lanes is None:
+            return
+        for st in self.lanes:
+            self.cur.wait_stream(st)
+        for t in tensors:
+            if isinstance(t, torch.Tensor):
+                t.record_stream(self.cur)
+
+
 class _HgtAttentionFlat(Function):
     """Edge attention of every destination type, queries read from / query gradients written to the flat buffer itself:
     one gradient tensor for the whole projection buffer, no per-type scatter of dq."""
@@ -916,11 +952,14 @@ class _HgtAttentionFlat(Function):
         from .graph_plans import hgt_reverse_plan
         outs, stats = [], []
         f1 = flat.view(-1)
-        for pd, (off, rows, width) in zip(plans, qspec):
+        lanes = _type_lanes(flat, len(plans))
+        for i, (pd, (off, rows, width)) in enumerate(zip(plans, qspec)):
             q = f1[off:off + rows * width].view(rows, width)[:, 0:128]
-            o, s = ops.hgt_attention_stats(q, flat, pd, heads)
+            with lanes.lane(i):
+                o, s = ops.hgt_attention_stats(q, flat, pd, heads)
             outs.append(o)
             stats.append(s)
+        lanes.join(*outs, *stats)
         ctx.heads, ctx.plans, ctx.qspec, ctx.n = heads, plans, qspec, len(plans)
         ctx.revs = [hgt_reverse_plan(pd) for pd in plans]
         ctx.save_for_backward(flat, *outs, *stats)
@@ -933,10 +972,14 @@ class _HgtAttentionFlat(Function):
         flat, outs, stats = ctx.saved_tensors[0], ctx.saved_tensors[1:1 + n], ctx.saved_tensors[1 + n:1 + 2 * n]
         dflat = torch.zeros_like(flat)
         f1, d1 = flat.view(-1), dflat.view(-1)
-        for pd, rev, (off, rows, width), o, s, g in zip(ctx.plans, ctx.revs, ctx.qspec, outs, stats, douts):
+        gs = [g if g.is_contiguous() else g.contiguous() for g in douts]
+        lanes = _type_lanes(flat, n)                  # (after dflat's zero fill and the gradients' copies: the lanes wait for them)
+        for i, (pd, rev, (off, rows, width), o, s, g) in enumerate(zip(ctx.plans, ctx.revs, ctx.qspec, outs, stats, gs)):
             q = f1[off:off + rows * width].view(rows, width)[:, 0:128]
             dq = d1[off:off + rows * width].view(rows, width)[:, 0:128]
-            ops.hgt_attention_bwd(q, flat, pd, rev, ctx.heads, g if g.is_contiguous() else g.contiguous(), o, s, dflat, dq_out=dq)
+            with lanes.lane(i):
+                ops.hgt_attention_bwd(q, flat, pd, rev, ctx.heads, g, o, s, dflat, dq_out=dq)
+        lanes.join()
         return dflat, None, None, None
 
 
