@@ -626,6 +626,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pretrain-steps", type=int, default=5, help="contrastive-pretraining leg (BASELINE configs[2]); 0 disables; single GPU only")
     ap.add_argument("--pretrain-batch", type=int, default=2048)
+    ap.add_argument("--ddp-legs", action="store_true", help="N > 1: after the line, also run the data-parallel finetune step and the sharded cfg5 "
+                    "run (untested over RCCL; results to stderr and gpurun_out/bench_ddp_legs_n<N>.json)")
     ap.add_argument("--finetune-steps", type=int, default=5, help="second half of BASELINE's metric: DDI-finetune steps/s "
                     "(encode both sides + gathered head + BCE + backward + AdamW), timed at N=1 after the headline; 0 = skip")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: strong = the fixed drugs^2 x outcomes job "
@@ -903,12 +905,13 @@ def main():
         emit(*secondary_legs())
     else:
         # N > 1: the line (the scaling curve's point) leaves FIRST.  The data-parallel finetune step and the sharded cfg5 stress run
-        # have never executed over RCCL (one GPU in the build box): they run afterwards under a watchdog, and report to stderr and
-        # gpurun_out/bench_ddp_legs_n<N>.json -- a hang or a crash there cannot take the headline with it.
+        # have never executed over RCCL (one GPU in the build box): they are OPT-IN there (--ddp-legs / MDG_BENCH_DDP_LEGS=1), run after
+        # the line under a watchdog, and report to stderr and gpurun_out/bench_ddp_legs_n<N>.json -- a hang or a crash in them cannot
+        # take the headline with it, and a default driver run cannot end on a non-zero exit code because of them.
         emit(None, None, None)
         import threading
         limit = float(os.environ.get("MDG_BENCH_DDP_LEGS_SECONDS", "420"))
-        if limit > 0:
+        if limit > 0 and (args.ddp_legs or os.environ.get("MDG_BENCH_DDP_LEGS", "0") == "1"):
             dog = threading.Timer(limit, lambda: (sys.stderr.write(f"[bench] secondary legs exceeded {limit:.0f} s on rank {rank}: leaving\n"), sys.stderr.flush(), os._exit(0)))
             dog.daemon = True
             dog.start()
