@@ -284,14 +284,20 @@ class GraphIsomorphismNetwork(nn.Module):
     (parameter layout = modality_pretraining/str/GIN_256x4_muv.pt).  PARITY UNPINNED against the real
     wheel (absent from the image): restated from the GIN paper + torchdrug's layer semantics.
 
-    Per layer: agg_v = (1+eps) h_v + sum_{u->v} w_uv (h_u + edge_linear(e_uv)); h' = ReLU(BN(MLP(agg))).
-    ``edge_linear`` is applied once per destination to the summed bond features (linearity), so the
-    per-edge work is a pure row gather (mdg_csr_aggregate); the MLP runs through mdg_linear with the
-    eval BatchNorm and ReLU fused into the last layer's epilogue; read-out = segment mean / sum."""
+    Per layer (the path torchdrug 0.2.1 executes: ``MessagePassingBase.forward`` -> ``GraphIsomorphismConv.
+    message_and_aggregate``): update_v = sum_{u->v} w_uv h_u + edge_linear(sum_{u->v} w_uv e_uv) -- the bond features are
+    summed per destination atom first and ``edge_linear`` (weight AND bias) is applied ONCE per atom, atoms without
+    bonds included; h' = ReLU(BN(MLP((1+eps) h_v + update_v))).  The per-edge work is a pure row gather
+    (mdg_csr_aggregate); the MLP runs through mdg_linear with the eval BatchNorm and ReLU fused into the last layer's
+    epilogue; read-out = segment mean / sum.  ``edge_bias_per_edge=True`` (not a torchdrug argument) selects the
+    un-fused ``message()`` reading instead: sum_{u->v} w_uv (h_u + edge_linear(e_uv)), i.e. the bias times the weighted
+    in-degree (rounds 1-3 of this build; differs by (1 - deg_v) b_e per atom)."""
 
     def __init__(self, input_dim=None, hidden_dims=None, edge_input_dim=None, num_mlp_layer=2, eps=0, learn_eps=False,
-                 short_cut=False, batch_norm=False, activation="relu", concat_hidden=False, readout="sum"):
+                 short_cut=False, batch_norm=False, activation="relu", concat_hidden=False, readout="sum",
+                 edge_bias_per_edge=False):
         super().__init__()
+        self.edge_bias_per_edge = bool(edge_bias_per_edge)
         if short_cut or concat_hidden:
             raise NotImplementedError("short_cut / concat_hidden are not used by Madrigal")
         if readout not in ("sum", "mean"):
@@ -315,6 +321,15 @@ class GraphIsomorphismNetwork(nn.Module):
             layer.edge_linear = nn.Linear(edge_input_dim, self.dims[i]) if edge_input_dim else None
             self.layers.append(layer)
 
+    def _bond_sums(self, plan):
+        """[A, pad4(fe + 1)]: per destination atom the (weighted) sum of its bonds' features, then the column that meets
+        ``edge_linear.bias``: ones for EVERY atom (torchdrug applies edge_linear once per atom to the summed features),
+        or, under ``edge_bias_per_edge``, the weighted in-degree the aggregation of the edges' ones column leaves there."""
+        esum = ops.csr_aggregate(plan["edge_feat_aug"], plan["rowptr"], None, edge_weight=plan["w"])
+        if not self.edge_bias_per_edge:
+            esum[:, plan["edge_feat_dim"]] = 1.0
+        return esum
+
     def _forward_train(self, graph, input):
         """Training-mode / differentiated pass: the same kernels through the autograd nodes; BatchNorm uses batch
         statistics over the atoms; the backward of every aggregation is mdg_csr_aggregate on the reversed edges."""
@@ -335,9 +350,9 @@ class GraphIsomorphismNetwork(nn.Module):
                 agg = agg[:, :k_in]
             if layer.edge_linear is not None:
                 if esum is None:
-                    esum = ops.csr_aggregate(plan["edge_feat_aug"], plan["rowptr"], None, edge_weight=plan["w"])
+                    esum = self._bond_sums(plan)
                 fe = plan["edge_feat_dim"]
-                el = layer.edge_linear             # [W_e | b_e | 0] against [sum_e e_uv | weighted degree | 0]
+                el = layer.edge_linear             # [W_e | b_e | 0] against [sum_e e_uv | 1 (per_edge: weighted degree) | 0]
                 we = torch.cat([el.weight, el.bias.unsqueeze(1), el.weight.new_zeros(k_in, esum.shape[1] - fe - 1)], dim=1)
                 agg = ag.add(agg, _linT(esum, we, None))
             u = agg
@@ -362,8 +377,8 @@ class GraphIsomorphismNetwork(nn.Module):
             agg = ops.csr_aggregate(h, plan["rowptr"], plan["col"], edge_weight=plan["w"], x_self=h,
                                     self_coef_dev=layer.eps.detach(), self_coef_add=1.0)        # [A, pad4(k_in)]
             if layer.edge_linear is not None:
-                if esum is None:       # per-atom sum of (weighted) bond features + weighted in-degree: layer independent
-                    esum = ops.csr_aggregate(plan["edge_feat_aug"], plan["rowptr"], None, edge_weight=plan["w"])
+                if esum is None:       # per-atom sum of (weighted) bond features + the bias column: layer independent
+                    esum = self._bond_sums(plan)
                 fe = plan["edge_feat_dim"]
 
                 def build(layer=layer, rows=agg.shape[1], cols=esum.shape[1], fe=fe, k_in=k_in, dev=h.device):
@@ -372,7 +387,7 @@ class GraphIsomorphismNetwork(nn.Module):
                     we[:k_in, fe] = layer.edge_linear.bias.detach()
                     return we
                 we = _cached(layer.edge_linear, ("aug", agg.shape[1], esum.shape[1]), (layer.edge_linear.weight, layer.edge_linear.bias), build)
-                agg = _lin(esum, we, None, residual=agg)                 # + W_e sum_e(e_uv) + deg_v * b_e
+                agg = _lin(esum, we, None, residual=agg)                 # + W_e sum_e(e_uv) + b_e
             u = agg
             n_mlp = len(layer.mlp.layers)
             for j, lin in enumerate(layer.mlp.layers):

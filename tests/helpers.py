@@ -166,3 +166,26 @@ def set_switch(monkeypatch, name: str, value: str) -> None:
     from madrigal_amd._lib import lib
     monkeypatch.setenv(name, value)
     lib().mdg_tuning_reload()
+
+
+def gin_bias_case():
+    """One molecule that separates the two readings of torchdrug's GIN edge-linear bias (oracle.gin_forward's docstring):
+    atom 0 has three incoming bonds, atoms 1-3 one each, atom 4 none (isolated), atom 5 one (from atom 3).  Positive one-hot
+    features, a one-layer conv whose MLP is the identity and whose edge_linear has a small positive weight and the bias
+    ``b``: every pre-activation is positive (ReLU = identity), so the node outputs of the per-edge reading minus those of the
+    per-atom reading are EXACTLY (deg_v - 1) b.  -> (MoleculeBatch, params, b, in-degree)"""
+    import torch
+    from madrigal_amd import data as D
+    dim, fe = 8, 18
+    src = torch.tensor([1, 2, 3, 0, 0, 0, 3])
+    dst = torch.tensor([0, 0, 0, 1, 2, 3, 5])
+    g = torch.Generator().manual_seed(77)
+    x = torch.zeros(6, dim)
+    x[torch.arange(6), torch.randint(0, dim, (6,), generator=g)] = 1.0
+    ef = torch.zeros(7, fe)
+    ef[torch.arange(7), torch.randint(0, fe, (7,), generator=g)] = 1.0
+    mols = D.MoleculeBatch(x, torch.stack([src, dst, torch.zeros(7, dtype=torch.int64)], 1), ef, torch.zeros(6, dtype=torch.int64), 1)
+    b = torch.rand(dim, generator=g) + 0.25
+    p = {"layers.0.eps": torch.tensor([0.0]), "layers.0.mlp.layers.0.weight": torch.eye(dim), "layers.0.mlp.layers.0.bias": torch.zeros(dim),
+         "layers.0.edge_linear.weight": torch.rand(dim, fe, generator=g) * 0.125, "layers.0.edge_linear.bias": b}
+    return mols, p, b, torch.bincount(dst, minlength=6).float()

@@ -288,3 +288,35 @@ def test_bundle_and_duck_typed_sources_give_identical_embeddings(M, tmp_path):
     b3 = dict(batch, strs=D.as_molecule_batch(packed))
     kg3 = {"data": D.as_kg_data(hetero), "drug_index_map": bkg["drug_index_map"]}
     assert torch.equal(encode(b3, kg3), z0)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_gin_edge_bias_enters_once_per_atom(M, prec):
+    """The HIP structure encoder follows torchdrug's executed path (message_and_aggregate: edge_linear once per atom on the
+    summed bond features, isolated atoms included); ``edge_bias_per_edge=True`` is the other reading, (deg - 1) b away."""
+    from helpers import gin_bias_case
+    from oracle import madrigal_oracle as O
+    mols, p, b, deg = gin_bias_case()
+    kw = dict(num_layers=1, num_mlp_layer=1, batch_norm=False, readout="sum")
+    outs = {}
+    for per_edge in (False, True):
+        m = M.GraphIsomorphismNetwork(input_dim=8, hidden_dims=[8], edge_input_dim=18, num_mlp_layer=1, eps=0, batch_norm=False,
+                                      activation="relu", readout="sum", edge_bias_per_edge=per_edge)
+        m.load_state_dict(p)
+        m = m.cuda().eval()
+        mg = mols.cuda()
+        with torch.no_grad(), M.precision(prec):
+            got = m(mg, mg.node_feature)
+        want = O.gin_forward(p, mols.node_feature, mols.edge_list, mols.edge_feature, mols.node2graph, 1,
+                             edge_bias="per_edge" if per_edge else "per_atom", **kw)
+        assert rel_err(got["node_feature"].cpu()[:, :8], want["node_feature"]) < TOL[prec]
+        assert rel_err(got["graph_feature"].cpu(), want["graph_feature"]) < TOL[prec]
+        outs[per_edge] = got["node_feature"].cpu()[:, :8]
+        # training-mode path (the autograd nodes): same reading
+        m.train()
+        with M.precision(prec):
+            tr = m(mg, mg.node_feature)["node_feature"].detach().cpu()[:, :8]
+        assert rel_err(tr, want["node_feature"]) < TOL[prec]
+    d = outs[True] - outs[False]
+    assert torch.allclose(d, (deg - 1).unsqueeze(1) * b.unsqueeze(0), atol=2e-5)
+    assert torch.allclose(outs[False][4], mols.node_feature[4] + b, atol=2e-5)          # isolated atom: bias once

@@ -325,3 +325,22 @@ def test_simclr_raw_encoder_output_as_shipped(golden, shared, basal):
     keep = np.abs(g[tag + "_logits"]) < 1e8
     assert rel_err(got["logits"].numpy()[keep], g[tag + "_logits"][keep]) < 5e-5
     assert abs(float(got["loss"]) - float(g[tag + "_loss"])) < 2e-5 * abs(float(g[tag + "_loss"]))
+
+
+def test_gin_edge_bias_enters_once_per_atom():
+    """torchdrug 0.2.1 runs GraphIsomorphismConv.message_and_aggregate: bond features summed per atom, edge_linear applied
+    once (bias once, isolated atoms included).  The per-edge reading (rounds 1-3) differs by exactly (deg - 1) b."""
+    from helpers import gin_bias_case
+    mols, p, b, deg = gin_bias_case()
+    kw = dict(num_layers=1, num_mlp_layer=1, batch_norm=False, readout="sum")
+    a = O.gin_forward(p, mols.node_feature, mols.edge_list, mols.edge_feature, mols.node2graph, 1, **kw)["node_feature"]
+    e = O.gin_forward(p, mols.node_feature, mols.edge_list, mols.edge_feature, mols.node2graph, 1, edge_bias="per_edge", **kw)["node_feature"]
+    assert float(deg[0]) == 3 and float(deg[4]) == 0
+    assert torch.allclose(e - a, (deg - 1).unsqueeze(1) * b.unsqueeze(0), atol=1e-6)
+    # the isolated atom: (1 + eps) h + W_e 0 + b
+    assert torch.allclose(a[4], mols.node_feature[4] + b, atol=1e-6)
+    # the degree-3 atom by hand
+    src, dst = mols.edge_list[:, 0], mols.edge_list[:, 1]
+    inc = dst == 0
+    want = mols.node_feature[0] + mols.node_feature[src[inc]].sum(0) + p["layers.0.edge_linear.weight"] @ mols.edge_feature[inc].sum(0) + b
+    assert torch.allclose(a[0], want, atol=1e-6)

@@ -522,16 +522,21 @@ def test_bce_with_sigmoid_matches_torch_including_saturation(reduction):
 # ---------------------------------------------------------------------------------------------- structure / tx encoders
 def _torch_gin(ref, mols, x):
     """GIN layer semantics restated on torch ops (same statement as oracle.gin_forward; torchdrug 0.2.1 is not in the
-    image): agg_v = (1+eps) h_v + sum_{u->v} w_uv (h_u + edge_linear(e_uv)); h' = act(BN(MLP(agg))); read-out."""
+    image): update_v = sum_{u->v} w_uv h_u + edge_linear(sum_{u->v} w_uv e_uv) (bias once per atom; with
+    ``ref.edge_bias_per_edge``: sum_{u->v} w_uv (h_u + edge_linear(e_uv))); h' = act(BN(MLP((1+eps) h_v + update_v)))."""
     src, dst = mols.edge_list[:, 0], mols.edge_list[:, 1]
     w = mols.edge_weight.double().unsqueeze(1)
     h = x
     act = {"relu": torch.relu, "gelu": torch.nn.functional.gelu}[ref.activation]
     for layer in ref.layers:
-        msg = h[src]
-        if layer.edge_linear is not None:
-            msg = msg + layer.edge_linear(mols.edge_feature.double())
-        agg = torch.zeros_like(h).index_add(0, dst, msg * w) + (1.0 + layer.eps.double()) * h
+        if layer.edge_linear is None:
+            upd = torch.zeros_like(h).index_add(0, dst, h[src] * w)
+        elif getattr(ref, "edge_bias_per_edge", False):
+            upd = torch.zeros_like(h).index_add(0, dst, (h[src] + layer.edge_linear(mols.edge_feature.double())) * w)
+        else:
+            esum = torch.zeros(h.shape[0], mols.edge_feature.shape[1], dtype=h.dtype).index_add(0, dst, mols.edge_feature.double() * w)
+            upd = torch.zeros_like(h).index_add(0, dst, h[src] * w) + layer.edge_linear(esum)
+        agg = upd + (1.0 + layer.eps.double()) * h
         u = agg
         for j, lin in enumerate(layer.mlp.layers):
             u = lin(u)
@@ -547,15 +552,16 @@ def _torch_gin(ref, mols, x):
     return g
 
 
-@pytest.mark.parametrize("batch_norm,readout,weighted", [(True, "mean", False), (False, "sum", True)])
-def test_gin_training_gradients_match_torch(batch_norm, readout, weighted):
+@pytest.mark.parametrize("batch_norm,readout,weighted,per_edge", [(True, "mean", False, False), (False, "sum", True, False),
+                                                                  (False, "mean", True, True)])
+def test_gin_training_gradients_match_torch(batch_norm, readout, weighted, per_edge):
     from madrigal_amd import data, models as M
     torch.manual_seed(5)
     mols = data.make_molecules(40, seed=3)
     if weighted:
         mols.edge_weight = torch.rand(mols.num_edge, generator=torch.Generator().manual_seed(1)) + 0.5
     m = M.GraphIsomorphismNetwork(input_dim=67, hidden_dims=[128, 128], edge_input_dim=18, num_mlp_layer=3, eps=0.1,
-                                  batch_norm=batch_norm, activation="gelu", readout=readout)
+                                  batch_norm=batch_norm, activation="gelu", readout=readout, edge_bias_per_edge=per_edge)
     ref = copy.deepcopy(m).double().train()
     m = m.to(DEV).train()
     xr = mols.node_feature.double()
