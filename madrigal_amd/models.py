@@ -226,8 +226,11 @@ def _run_sequential_train(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------- MLPs
-class MLPEncoder(nn.Module):
-    """madrigal/models/models.py:121-180 (cv encoder; also tx_encoder='mlp')."""
+class _MLPStack(nn.Module):
+    """Shared body of MLPEncoder and MLPAdaptor.  The two are SIBLINGS, as in the reference (models.py:121 / :459 are
+    unrelated classes): its create_optimizer (madrigal/utils.py:467-479) sorts parameters into learning-rate groups with
+    ``isinstance(child, MLPEncoder)`` / ``isinstance(child, MLPAdaptor)``, and an adaptor that IS an encoder would drop
+    uni_projector / uni_fuser out of the fusion group (oracle/check_dropin.py)."""
 
     def __init__(self, in_dim: int, hidden_dims: list, output_dim: int, p: float, norm: str, actn: str, order: str = 'nd'):
         super().__init__()
@@ -266,8 +269,12 @@ class MLPEncoder(nn.Module):
         return run(self.fc, x.reshape(-1, x.shape[-1])).reshape(*lead, -1)
 
 
-class MLPAdaptor(MLPEncoder):
-    """madrigal/models/models.py:459-518 (uni_projector / uni_fuser); same structure as MLPEncoder."""
+class MLPEncoder(_MLPStack):
+    """madrigal/models/models.py:121-180 (cv encoder; also tx_encoder='mlp')."""
+
+
+class MLPAdaptor(_MLPStack):
+    """madrigal/models/models.py:459-518 (uni_projector / uni_fuser); same structure as MLPEncoder, not a subclass of it."""
 
 
 class VAE(nn.Module):
