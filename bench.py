@@ -907,12 +907,13 @@ def main():
         # N > 1: the line (the scaling curve's point) leaves FIRST.  The data-parallel finetune step and the sharded cfg5 stress run
         # have never executed over RCCL (one GPU in the build box): they are OPT-IN there (--ddp-legs / MDG_BENCH_DDP_LEGS=1), run after
         # the line under a watchdog, and report to stderr and gpurun_out/bench_ddp_legs_n<N>.json -- a hang or a crash in them cannot
-        # take the headline with it, and a default driver run cannot end on a non-zero exit code because of them.
+        # take the headline with it (it is printed by then); a default driver run does not execute them at all.  A hang in an
+        # opted-in run ends the rank with exit code 3: it must not read as success.
         emit(None, None, None)
         import threading
         limit = float(os.environ.get("MDG_BENCH_DDP_LEGS_SECONDS", "420"))
         if limit > 0 and (args.ddp_legs or os.environ.get("MDG_BENCH_DDP_LEGS", "0") == "1"):
-            dog = threading.Timer(limit, lambda: (sys.stderr.write(f"[bench] secondary legs exceeded {limit:.0f} s on rank {rank}: leaving\n"), sys.stderr.flush(), os._exit(0)))
+            dog = threading.Timer(limit, lambda: (sys.stderr.write(f"[bench] secondary legs exceeded {limit:.0f} s on rank {rank}: leaving\n"), sys.stderr.flush(), os._exit(3)))
             dog.daemon = True
             dog.start()
             ft, pt, st_ = secondary_legs()

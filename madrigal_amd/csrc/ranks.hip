@@ -114,9 +114,10 @@ __device__ __forceinline__ void store_tile_histogram(const uint32_t (*cnt)[256],
 template <class C>
 __global__ __launch_bounds__(C::TPB) void extract_keys_kernel(const float* __restrict__ scores, int64_t lds, uint32_t* __restrict__ keys,
                                                            uint32_t* __restrict__ hist, uint32_t* __restrict__ ghist, int N, int64_t M, int nblk,
-                                                           int src_is_keys) {
+                                                           int src_is_keys, const uint32_t* __restrict__ only) {
   MDG_RANK_USING(C);
   __shared__ uint32_t cnt[WAVES][256];
+  if (only && !only[blockIdx.y]) return;      // LSD fallback behind the MSD fast path: flagged outcomes only
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
   __syncthreads();
@@ -173,9 +174,10 @@ __global__ __launch_bounds__(C::TPB) void extract_keys_kernel(const float* __res
 // pass 1 writes the upper 16 bits (uint16_t), pass 2 the upper 8 (uint8_t); `shift` = position of the current digit inside a KT
 template <class C, class KT>
 __global__ __launch_bounds__(C::TPB) void histogram_kernel(const KT* __restrict__ keys, uint32_t* __restrict__ hist, int64_t M,
-                                                           int nblk, int shift) {
+                                                           int nblk, int shift, const uint32_t* __restrict__ only) {
   MDG_RANK_USING(C);
   __shared__ uint32_t cnt[WAVES][256];
+  if (only && !only[blockIdx.y]) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
   __syncthreads();
@@ -241,8 +243,9 @@ __device__ __forceinline__ uint32_t wave_inclusive(uint32_t v, int lane) {
 
 // exclusive scan of the 256*nblk counters of one outcome, in place; one workgroup per outcome, coalesced: every wave owns a
 // contiguous range and walks it 256 counters (16 bytes per lane) at a time, the next group's load issued before the scan of this one
-__global__ __launch_bounds__(1024) void scan_kernel(uint32_t* __restrict__ hist, int nblk) {
+__global__ __launch_bounds__(1024) void scan_kernel(uint32_t* __restrict__ hist, int nblk, const uint32_t* __restrict__ only) {
   __shared__ uint32_t part[16];
+  if (only && !only[blockIdx.x]) return;
   u32x4* h = reinterpret_cast<u32x4*>(hist + static_cast<int64_t>(blockIdx.x) * 256 * nblk);
   const int total = 64 * nblk;                                  // groups of 4 counters
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -284,9 +287,10 @@ __global__ __launch_bounds__(C::TPB) void scatter_kernel(const KIN* __restrict__
                                                       KOUT* __restrict__ keys_out, uint32_t* __restrict__ pay_out,
                                                       const uint32_t* __restrict__ offsets, float* __restrict__ out, int64_t ldo, int N,
                                                       int64_t M, int nblk, int shift, double denom, uint32_t* __restrict__ status,
-                                                      const uint32_t* __restrict__ ghist) {
+                                                      const uint32_t* __restrict__ ghist, const uint32_t* __restrict__ only) {
   // offsets != null: tile offsets from the histogram + scan launches; else look-back (status, this pass's digit totals ghist)
   MDG_RANK_USING(C);
+  if (only && !only[blockIdx.y]) return;
   __shared__ uint32_t cnt[WAVES][256];     // per-wave digit counts, then their exclusive prefix over the waves
   __shared__ uint32_t dstart[256];         // first slot of digit d in the sorted tile
   __shared__ uint32_t gofs[256];           // global position of slot 0 of digit d's run, minus dstart[d]
@@ -404,8 +408,10 @@ template <class C, class KIN>
 __global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const KIN* __restrict__ keys_in, const uint32_t* __restrict__ pay_in,
                                                           const uint32_t* __restrict__ offsets, u32x2* __restrict__ pairs,
                                                           uint32_t* __restrict__ fill, int N, int64_t M, int nblk, int n_blocks,
-                                                          uint32_t* __restrict__ status, const uint32_t* __restrict__ ghist) {
+                                                          uint32_t* __restrict__ status, const uint32_t* __restrict__ ghist,
+                                                          const uint32_t* __restrict__ only) {
   MDG_RANK_USING(C);
+  if (only && !only[blockIdx.y]) return;
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];            // [TILE] pairs (u32x2) | bcnt[n_blocks] | bdst[n_blocks]
   __shared__ uint32_t cnt[WAVES][256];
   __shared__ uint32_t gbase[256];
@@ -532,11 +538,573 @@ __global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const KIN* __restri
   }
 }
 
+// ================================================================================================================================
+// Fast path (round 4): ONE adaptive MSD partition + an in-LDS counting sort per bucket, instead of four global LSD passes.
+//
+//   msd_hist_kernel      read the keys once: histogram of their top 14 bits per outcome (16 384 coarse bins: sign, exponent, 5
+//                        mantissa bits -- a bin spans 1/32 of a binade, over which any smooth score density is flat)
+//   msd_table_kernel     per outcome: prefix of the coarse counts; a coarse bin with more than Q/8 keys is cut into 2^lg equal
+//                        sub-ranges of its low bits.  bucket(key) = (prefix[c] + sub(key) * (n_c >> lg)) >> log2(Q): monotone in the
+//                        key, ~Q keys per bucket whatever the shape of the distribution (bell-shaped scores put 0.4 % of all keys
+//                        in one coarse bin), with room for 1.5 Q (CAP) keys reserved per bucket
+//   msd_partition_kernel a 16 384-key tile leaves as one run per bucket (sorted by bucket in LDS: slots handed out by LDS atomics,
+//                        no digit matching; run positions inside the bucket's segment by one global atomic per tile and bucket)
+//   msd_offsets_kernel   exclusive scan of the buckets' actual sizes = the rank of each bucket's first key
+//   msd_bucket_kernel    one bucket (<= CAP keys) per workgroup: counting sort on 2 CAP fine bins of the bucket's own key range
+//                        (one returning LDS atomic per key, ~0.5 keys per bin), keys that share a fine bin ordered by (key,
+//                        position) explicitly -- this is what makes ties stable although neither partition nor counting preserves
+//                        arrival order -- then the (rank, position) pairs binned by 128 x 128 output block exactly as the last LSD
+//                        pass did, and rank_block_write_kernel writes whole rows.
+//
+// Bytes per key: 4 (histogram) + 4 + 8 (partition) + 8 + 8 (bucket sort) + 8 + 8 (block write) = 48, against ~80 for the four LSD
+// passes, and the kernels run on a FEW outcomes at a time (MDG_RANKS_GROUP) in a workspace that is reused, so that the 67 MB a pass
+// writes per outcome are still in the 256 MB Infinity Cache when the next pass reads them.
+//
+// The payload is q = (i << 16) | j instead of the triangle index p: the same order as p, and no square root to get back (i, j).
+//
+// What the fast path cannot sort it hands back: a bucket that overflows its segment (a point mass of equal keys, a score
+// distribution that is not smooth inside a coarse bin) or a fine bin with more than MSD_TIE_LIMIT keys raises the outcome's flag;
+// flagged outcomes are skipped by the bucket / block-write kernels and sorted by the LSD kernels (launched for every chunk, each
+// workgroup leaving at once unless its outcome is flagged).  Either way the ranks are the same bits.
+constexpr int MSD_CB = 14, MSD_NC = 1 << MSD_CB, MSD_LB = 32 - MSD_CB;
+constexpr int MSD_NB_MAX = 2048;          // buckets per outcome: a 16 384-key tile then leaves as runs of >= 8 pairs = 64 B on average (measured,
+                                          // scripts/micro/run_scatter_bw.hip: runs of 64 B and longer store at 4.7-6.4 TB/s, runs of 32 B at 1.6-2.3)
+constexpr int MSD_QLG = 12, MSD_NF = 8192;   // ~4096 keys per bucket; fine bins of the bucket sort
+// Every counter that many workgroups add to is SHARDED: returning global atomics of all tiles onto one outcome's 2048 bucket counters
+// (8 KB) or 528 block counters (2 KB) ran at the contended rate of the guide's "every workgroup into ONE row" case and WERE the
+// kernels' duration (first version: partition 60 us, bucket sort 111 us per outcome).  A bucket's segment is 8 shards (by tile
+// index), an output block's pair region 32 shards (by bucket index), the coarse histogram 8 copies (by workgroup index).
+constexpr int MSD_SH = 8, MSD_SCAP = 768, MSD_CAP = MSD_SH * MSD_SCAP;     // pairs per shard of a bucket: 8 x 768 = 6144 = 1.5 Q
+constexpr int MSD_BSH = 32, MSD_BREGION = 20480;   // shards of a block's pair region (at most; a power of two with >= 8 buckets per shard) and its
+                                                   // room: 1.25 x the 16384 pairs of a full 128 x 128 block, cut evenly (32 shards: 640 each, 512 +- 22 used)
+constexpr int MSD_TILE = 16384;           // keys per partition tile (1024 threads x 16)
+constexpr int MSD_TIE_LIMIT = 128;        // keys per fine bin ordered in place; more: LSD fallback
+constexpr int MSD_BUCKET_TPB = 1024;      // threads of the bucket sort (two workgroups per CU: 8 waves per SIMD hide the LDS round trips)
+constexpr int MSD_MAX_BLOCKS = 1536;      // output blocks per outcome on the fast path (3 per thread of the bucket sort)
+constexpr uint32_t MSD_F_SEG = 1u, MSD_F_TOTAL = 2u, MSD_F_TIES = 4u, MSD_F_BLOCK = 8u;      // why an outcome was handed back
+constexpr uint32_t MSD_SKIP = 0xFFFFFFFFu;
+
+struct TriWalk {                          // wave-uniform walk along the rows of the strict lower triangle, 64 positions per step
+  int wi, wj;
+  __device__ __forceinline__ void start(int64_t p, int64_t M) {
+    int i, j;
+    tri_decode(p < M ? p : M - 1, i, j);
+    wi = __builtin_amdgcn_readfirstlane(i);
+    wj = __builtin_amdgcn_readfirstlane(j);
+  }
+  __device__ __forceinline__ void lane_pos(int lane, int& i, int& j) const {
+    i = wi;
+    j = wj + lane;
+    while (j >= i) { j -= i; ++i; }
+  }
+  __device__ __forceinline__ void step() {
+    wj += 64;
+    while (wj >= wi) { wj -= wi; ++wi; }
+  }
+};
+
+// hist[(outcome * MSD_SH + workgroup % MSD_SH) * MSD_NC + top 14 bits of the key]
+__global__ __launch_bounds__(1024) void msd_hist_kernel(const float* __restrict__ scores, int64_t lds, uint32_t* __restrict__ hist, int N, int64_t M,
+                                                       int64_t span, int src_is_keys) {
+  __shared__ uint32_t cnt[MSD_NC];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int c = tid; c < MSD_NC; c += 1024) cnt[c] = 0;
+  __syncthreads();
+  const int64_t seg = blockIdx.y, wspan = span / 16, base = static_cast<int64_t>(blockIdx.x) * span + wave * wspan;
+  const float* sc = scores + seg * static_cast<int64_t>(N) * lds;
+  if (base < M) {
+    TriWalk w;
+    w.start(base, M);
+    const int steps = static_cast<int>(wspan / 64);
+#pragma unroll 8
+    for (int k = 0; k < steps; ++k) {
+      const int64_t p = base + k * 64 + lane;
+      int i, j;
+      w.lane_pos(lane, i, j);
+      if (p < M) {
+        const float v = sc[static_cast<int64_t>(i) * lds + j];
+        const uint32_t key = src_is_keys ? __builtin_bit_cast(uint32_t, v) : mdg_order_key(v);
+        __hip_atomic_fetch_add(&cnt[key >> MSD_LB], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      w.step();
+    }
+  }
+  __syncthreads();
+  uint32_t* h = hist + (seg * MSD_SH + (blockIdx.x % MSD_SH)) * MSD_NC;
+  for (int c = tid; c < MSD_NC; c += 1024) {
+    const uint32_t v = cnt[c];
+    if (v) atomicAdd(&h[c], v);
+  }
+}
+
+// table[c] = {keys in the coarse bins before c, (n_c >> lg) << 5 | lg}
+__global__ __launch_bounds__(1024) void msd_table_kernel(const uint32_t* __restrict__ hist, u32x2* __restrict__ table, int qlg) {
+  __shared__ uint32_t wsum[16];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t seg = blockIdx.x;
+  uint32_t n[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) n[e] = 0;
+  for (int sh = 0; sh < MSD_SH; ++sh) {
+    const u32x4* h = reinterpret_cast<const u32x4*>(hist + (seg * MSD_SH + sh) * MSD_NC) + tid * 4;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const u32x4 x = h[v];
+      n[4 * v] += x[0]; n[4 * v + 1] += x[1]; n[4 * v + 2] += x[2]; n[4 * v + 3] += x[3];
+    }
+  }
+  uint32_t tot = 0;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) tot += n[e];
+  const uint32_t inc = wave_inclusive(tot, lane);
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t run = inc - tot;
+  for (int w = 0; w < wave; ++w) run += wsum[w];
+  const uint32_t unit = 1u << (qlg - 3);                 // sub-ranges of at most Q / 8 keys
+  u32x2* t = table + seg * MSD_NC + tid * 16;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    uint32_t lg = 0;
+    if (n[e] > unit) {
+      const uint32_t parts = (n[e] + unit - 1) >> (qlg - 3);
+      lg = 32 - __builtin_clz(parts - 1);              // ceil(log2(parts)), parts >= 2
+      if (lg > MSD_LB) lg = MSD_LB;
+    }
+    t[e] = u32x2{run, ((n[e] >> lg) << 5) | lg};
+    run += n[e];
+  }
+}
+
+__device__ __forceinline__ uint32_t msd_bucket_of(uint32_t key, const u32x2* __restrict__ table, int qlg) {
+  const u32x2 ent = table[key >> MSD_LB];
+  const uint32_t lg = ent[1] & 31u;
+  const uint32_t sub = lg ? ((key << MSD_CB) >> (32 - lg)) : 0u;     // the lg bits below the coarse prefix
+  return (ent[0] + sub * (ent[1] >> 5)) >> qlg;
+}
+
+// Persistent: workgroup x of outcome y takes tiles x, x + gridDim.x, ...; the next tile's scores are in flight (registers) while
+// this one is bucketed.  fill[(outcome * MSD_SH + tile % MSD_SH) * nbs + bucket]; segs[((outcome * nb + bucket) * MSD_SH + shard) * MSD_SCAP + .]
+__global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __restrict__ scores, int64_t lds, const u32x2* __restrict__ table,
+                                                            uint32_t* __restrict__ fill, u32x2* __restrict__ segs, uint32_t* __restrict__ flags,
+                                                            int N, int64_t M, int nb, int nbs, int qlg, int n_tiles, int src_is_keys) {
+  constexpr int TPB = 1024, ITEMS = 16, BPT = MSD_NB_MAX / TPB;
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];       // spair[MSD_TILE] (u32x2) | bcnt[MSD_NB_MAX]
+  __shared__ uint32_t wsum[16];
+  u32x2* spair = reinterpret_cast<u32x2*>(dyn);
+  uint32_t* bcnt = dyn + 2 * MSD_TILE;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t seg = blockIdx.y;
+  const float* sc = scores + seg * static_cast<int64_t>(N) * lds;
+  const u32x2* tab = table + seg * MSD_NC;
+  u32x2* dst = segs + seg * static_cast<int64_t>(nb) * MSD_CAP;
+  float raw[ITEMS];
+  const auto load_tile = [&](int t) {
+    const int64_t base = static_cast<int64_t>(t) * MSD_TILE + wave * (MSD_TILE / 16);
+    TriWalk w;
+    w.start(base, M);
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      int i, j;
+      w.lane_pos(lane, i, j);
+      raw[k] = (base + k * 64 + lane < M) ? sc[static_cast<int64_t>(i) * lds + j] : 0.f;
+      w.step();
+    }
+  };
+  int t = blockIdx.x;
+  if (t < n_tiles) load_tile(t);
+  for (; t < n_tiles; t += gridDim.x) {
+    const int64_t base = static_cast<int64_t>(t) * MSD_TILE;
+    const int shard = t % MSD_SH;
+    for (int b = tid; b < MSD_NB_MAX; b += TPB) bcnt[b] = 0;
+    uint32_t key[ITEMS], q[ITEMS], sb[ITEMS];             // sb = slot in the tile's run | bucket << 16
+    {
+      TriWalk w;                                           // the walk again, for the positions (the loads took it one tile ahead)
+      w.start(base + wave * (MSD_TILE / 16), M);
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) {
+        int i, j;
+        w.lane_pos(lane, i, j);
+        key[k] = src_is_keys ? __builtin_bit_cast(uint32_t, raw[k]) : mdg_order_key(raw[k]);
+        q[k] = (static_cast<uint32_t>(i) << 16) | static_cast<uint32_t>(j);
+        w.step();
+      }
+    }
+    if (t + static_cast<int>(gridDim.x) < n_tiles) load_tile(t + gridDim.x);
+    __syncthreads();                                       // bcnt zeroed (and the previous tile's copy-out done with it)
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int64_t p = base + wave * (MSD_TILE / 16) + k * 64 + lane;
+      sb[k] = MSD_SKIP;
+      if (p < M) {
+        const uint32_t b = msd_bucket_of(key[k], tab, qlg);
+        sb[k] = atomicAdd(&bcnt[b], 1u) | (b << 16);
+      }
+    }
+    __syncthreads();
+    // exclusive scan of the bucket counts, BPT per thread; room for this tile's run in every non-empty bucket's shard: the atomics
+    // are issued here and their results are needed only after the placement
+    uint32_t c4[BPT], st[BPT], old[BPT];
+    {
+      uint32_t tot = 0;
+#pragma unroll
+      for (int e = 0; e < BPT; ++e) { c4[e] = bcnt[BPT * tid + e]; tot += c4[e]; }
+      const uint32_t inc = wave_inclusive(tot, lane);
+      if (lane == 63) wsum[wave] = inc;
+      __syncthreads();
+      uint32_t run = inc - tot;
+      for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+      for (int e = 0; e < BPT; ++e) {
+        st[e] = run;
+        bcnt[BPT * tid + e] = run;
+        run += c4[e];
+        old[e] = c4[e] ? atomicAdd(&fill[(seg * MSD_SH + shard) * nbs + BPT * tid + e], c4[e]) : 0u;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k)
+      if (sb[k] != MSD_SKIP) spair[bcnt[sb[k] >> 16] + (sb[k] & 0xFFFFu)] = u32x2{key[k], q[k]};
+    __syncthreads();
+    // bcnt[b] becomes (position in the bucket's shard) - (position in LDS)
+#pragma unroll
+    for (int e = 0; e < BPT; ++e)
+      if (c4[e]) {
+        if (old[e] + c4[e] > static_cast<uint32_t>(MSD_SCAP)) atomicOr(&flags[seg], MSD_F_SEG);
+        bcnt[BPT * tid + e] = old[e] - st[e];
+      }
+    __syncthreads();
+    const int n_valid = static_cast<int>(M - base < MSD_TILE ? M - base : MSD_TILE);
+#pragma unroll 4
+    for (int k = 0; k < ITEMS; ++k) {
+      const int idx = k * TPB + tid;
+      if (idx >= n_valid) break;
+      const u32x2 v = spair[idx];
+      const uint32_t b = msd_bucket_of(v[0], tab, qlg);
+      const uint32_t pos = bcnt[b] + static_cast<uint32_t>(idx);
+      if (pos < static_cast<uint32_t>(MSD_SCAP)) dst[(static_cast<int64_t>(b) * MSD_SH + shard) * MSD_SCAP + pos] = v;
+    }
+    __syncthreads();                                       // spair / bcnt are read: the next tile may overwrite them
+  }
+}
+
+// rbase[b] = keys in the buckets before b; a shard beyond its room or a total that is not M raises the flag
+__global__ __launch_bounds__(1024) void msd_offsets_kernel(const uint32_t* __restrict__ fill, uint32_t* __restrict__ rbase, uint32_t* __restrict__ flags,
+                                                          int nb, int nbs, int64_t M) {
+  __shared__ uint32_t wsum[16];
+  constexpr int BPT = MSD_NB_MAX / 1024;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t seg = blockIdx.x;
+  uint32_t c4[BPT], tot = 0;
+  bool over = false;
+#pragma unroll
+  for (int e = 0; e < BPT; ++e) {
+    const int b = BPT * tid + e;
+    c4[e] = 0;
+    if (b < nb)
+      for (int sh = 0; sh < MSD_SH; ++sh) {
+        const uint32_t c = fill[(seg * MSD_SH + sh) * nbs + b];
+        over = over || c > static_cast<uint32_t>(MSD_SCAP);
+        c4[e] += c;
+      }
+    tot += c4[e];
+  }
+  const uint32_t inc = wave_inclusive(tot, lane);
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t run = inc - tot;
+  for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+  for (int e = 0; e < BPT; ++e) {
+    const int b = BPT * tid + e;
+    if (b < nb) rbase[seg * nbs + b] = run;
+    run += c4[e];
+  }
+  if (over) atomicOr(&flags[seg], MSD_F_SEG);
+  if (tid == 1023 && static_cast<int64_t>(run) != M) atomicOr(&flags[seg], MSD_F_TOTAL);
+}
+
+// Persistent: workgroup x of outcome y takes buckets x, x + gridDim.x, ...; the next bucket's pairs are in flight (registers) while
+// this one is sorted, its shard sizes were fetched one bucket earlier still.
+// pairs[((outcome * n_blocks + block) * MSD_BSH + bucket % MSD_BSH) * MSD_BCAP + .]; blockfill[(outcome * MSD_BSH + shard) * n_blocks + block]
+template <int NF, int TPB, bool PF>
+__global__ __launch_bounds__(TPB, TPB / 128) void msd_bucket_kernel(const u32x2* __restrict__ segs, const uint32_t* __restrict__ fill, const uint32_t* __restrict__ rbase,
+                                                         u32x2* __restrict__ pairs, uint32_t* __restrict__ blockfill, uint32_t* __restrict__ flags,
+                                                         int N, int nb, int nbs, int n_blocks, int bsh) {
+  constexpr int CAP = MSD_CAP, ITEMS = CAP / TPB, WPT = NF / 2 / TPB, WAVES = TPB / 64;     // NF fine bins, two u16 counters per word
+  constexpr int LGNF = 31 - __builtin_clz(NF), BPT = (MSD_MAX_BLOCKS + TPB - 1) / TPB;
+  static_assert(CAP % TPB == 0 && (NF & (NF - 1)) == 0 && NF % (2 * TPB) == 0 && CAP < 65536, "bucket sort shape");
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];       // sorted[CAP] (u32x2) | fc[NF / 2] | bcnt[n_blocks] | bdst[n_blocks]
+  __shared__ uint32_t wsum[WAVES], krange[2];
+  u32x2* sorted = reinterpret_cast<u32x2*>(dyn);
+  uint32_t* fc = dyn + 2 * CAP;
+  uint32_t* bcnt = fc + NF / 2;
+  uint32_t* bdst = bcnt + n_blocks;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t seg = blockIdx.y;
+  const int stride = gridDim.x;
+  // shard sizes of a bucket as exclusive prefix sums ps[0..SH] (ps[SH] = the bucket's size, clamped shard by shard)
+  const auto shard_sizes = [&](int b, uint32_t (&ps)[MSD_SH + 1]) {
+    ps[0] = 0;
+#pragma unroll
+    for (int sh = 0; sh < MSD_SH; ++sh) {
+      uint32_t c = b < nb ? fill[(seg * MSD_SH + sh) * nbs + b] : 0u;
+      c = c < static_cast<uint32_t>(MSD_SCAP) ? c : static_cast<uint32_t>(MSD_SCAP);
+      ps[sh + 1] = ps[sh] + c;
+    }
+  };
+  const auto load_bucket = [&](int b, const uint32_t (&ps)[MSD_SH + 1], u32x2 (&v)[ITEMS]) {
+    const u32x2* src = segs + (seg * nb + b) * static_cast<int64_t>(CAP);
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const uint32_t idx = static_cast<uint32_t>(k * TPB + tid);
+      v[k] = u32x2{0u, 0u};
+      if (idx < ps[MSD_SH]) {
+        int sh = 0;
+#pragma unroll
+        for (int e = 1; e < MSD_SH; ++e) sh += idx >= ps[e] ? 1 : 0;
+        v[k] = src[sh * MSD_SCAP + (idx - ps[sh])];
+      }
+    }
+  };
+  uint32_t ps_cur[MSD_SH + 1], ps_nxt[MSD_SH + 1];
+  u32x2 cur[ITEMS];
+  int b = blockIdx.x;
+  if (b >= nb) return;
+  if constexpr (PF) {
+    shard_sizes(b, ps_cur);
+    load_bucket(b, ps_cur, cur);
+    shard_sizes(b + stride, ps_nxt);
+  }
+  for (; b < nb; b += stride) {
+    if constexpr (!PF) {
+      shard_sizes(b, ps_cur);
+      load_bucket(b, ps_cur, cur);
+    }
+    const int n = static_cast<int>(ps_cur[MSD_SH]);
+    uint32_t key[ITEMS], q[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) { key[k] = cur[k][0]; q[k] = cur[k][1]; }
+    const uint32_t rb = rbase[seg * nbs + b];
+    for (int i = tid; i < NF / 2; i += TPB) fc[i] = 0;
+    for (int i = tid; i < n_blocks; i += TPB) bcnt[i] = 0;
+    if (tid == 0) { krange[0] = 0xFFFFFFFFu; krange[1] = 0u; }
+    __syncthreads();
+    // ---- output blocks first: their room in the pair buffer comes from global atomics whose results are needed at the very end
+    // per key: its slot in the bucket's run of its output block (low half) and, later, its slot in its fine bin (high half); the
+    // block and the fine bin themselves are recomputed from q / key where they are needed (registers: two workgroups per CU)
+    uint32_t ss[ITEMS];
+    const auto block_of = [](uint32_t qq) -> uint32_t {
+      const uint32_t bi = qq >> 23, bj = (qq & 0xFFFFu) >> 7;
+      return bi * (bi + 1u) / 2u + bj;
+    };
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int idx = k * TPB + tid;
+      ss[k] = 0u;
+      if (idx < n) {
+        ss[k] = atomicAdd(&bcnt[block_of(q[k])], 1u);
+        kmin = kmin < key[k] ? kmin : key[k];
+        kmax = kmax > key[k] ? kmax : key[k];
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t a = __shfl_xor(kmin, o, 64), c = __shfl_xor(kmax, o, 64);
+      kmin = kmin < a ? kmin : a;
+      kmax = kmax > c ? kmax : c;
+    }
+    if (lane == 0 && n > 0) { atomicMin(&krange[0], kmin); atomicMax(&krange[1], kmax); }
+    __syncthreads();
+    uint32_t g_old[BPT], g_run[BPT], g_cnt[BPT];
+    {
+      const int a = tid * BPT;
+      uint32_t s = 0;
+#pragma unroll
+      for (int e = 0; e < BPT; ++e) { g_cnt[e] = a + e < n_blocks ? bcnt[a + e] : 0u; s += g_cnt[e]; }
+      const uint32_t inc = wave_inclusive(s, lane);
+      if (lane == 63) wsum[wave] = inc;
+      __syncthreads();
+      uint32_t run = inc - s;
+      for (int v = 0; v < wave; ++v) run += wsum[v];
+#pragma unroll
+      for (int e = 0; e < BPT; ++e) {
+        g_run[e] = run;
+        if (a + e < n_blocks) bcnt[a + e] = run;
+        g_old[e] = g_cnt[e] ? atomicAdd(&blockfill[(seg * MSD_BSH + (b & (bsh - 1))) * n_blocks + a + e], g_cnt[e]) : 0u;
+        run += g_cnt[e];
+      }
+    }
+    // ---- counting sort on the fine bins of the bucket's own key range
+    const uint32_t lo = krange[0], range = krange[1] - lo;
+    const int sh = (n > 0 && (range >> LGNF)) ? (32 - __builtin_clz(range) - LGNF) : 0;     // (range >> sh) < NF
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int idx = k * TPB + tid;
+      if (idx < n) {
+        const uint32_t fi = (key[k] - lo) >> sh;
+        const int hs = 16 * (fi & 1u);
+        ss[k] |= ((atomicAdd(&fc[fi >> 1], 1u << hs) >> hs) & 0xFFFFu) << 16;
+      }
+    }
+    __syncthreads();
+    {   // exclusive scan of the NF u16 counters in place (a contiguous run of WPT words per thread): fc holds each bin's first slot
+      uint32_t w[WPT], tot = 0;
+#pragma unroll
+      for (int e = 0; e < WPT; ++e) { w[e] = fc[tid * WPT + e]; tot += (w[e] & 0xFFFFu) + (w[e] >> 16); }
+      const uint32_t inc = wave_inclusive(tot, lane);
+      if (lane == 63) wsum[wave] = inc;                    // (the block scan's readers of wsum are behind the barrier above)
+      __syncthreads();
+      uint32_t run = inc - tot;
+      for (int v = 0; v < wave; ++v) run += wsum[v];
+#pragma unroll
+      for (int e = 0; e < WPT; ++e) {
+        const uint32_t c0 = w[e] & 0xFFFFu, c1 = w[e] >> 16;
+        fc[tid * WPT + e] = run | ((run + c0) << 16);
+        run += c0 + c1;
+      }
+    }
+    __syncthreads();
+    const auto fstart = [&](uint32_t f) -> uint32_t { return f >= static_cast<uint32_t>(NF) ? static_cast<uint32_t>(n) : (fc[f >> 1] >> (16 * (f & 1u))) & 0xFFFFu; };
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int idx = k * TPB + tid;
+      if (idx < n) sorted[fstart((key[k] - lo) >> sh) + (ss[k] >> 16)] = u32x2{key[k], q[k]};
+    }
+    __syncthreads();
+    // keys that share a fine bin: their order is (key, position); everything else is in place already
+    bool too_many = false;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int idx = k * TPB + tid;
+      if (idx < n) {
+        const uint32_t fi = (key[k] - lo) >> sh, s0 = fstart(fi), c = fstart(fi + 1u) - s0;
+        uint32_t r = 0;
+        if (c > 1u) {
+          if (c > static_cast<uint32_t>(MSD_TIE_LIMIT)) too_many = true;
+          else
+            for (uint32_t m = 0; m < c; ++m) {
+              const u32x2 o = sorted[s0 + m];
+              r += (o[0] < key[k] || (o[0] == key[k] && o[1] < q[k])) ? 1u : 0u;
+            }
+        }
+        key[k] = rb + s0 + r;                              // rank - 1
+      }
+    }
+    if (too_many) atomicOr(&flags[seg], MSD_F_TIES);
+    // ---- (rank, position in block) pairs, block by block, through `sorted` (free now) into the blocks' shards
+    {
+      const int a = tid * BPT;
+#pragma unroll
+      for (int e = 0; e < BPT; ++e)
+        if (g_cnt[e]) {
+          const uint32_t bcap = static_cast<uint32_t>(MSD_BREGION / bsh);
+          const bool fits = g_old[e] + g_cnt[e] <= bcap;
+          if (!fits) atomicOr(&flags[seg], MSD_F_BLOCK);
+          bdst[a + e] = fits ? static_cast<uint32_t>(a + e) * MSD_BREGION + static_cast<uint32_t>(b & (bsh - 1)) * bcap + g_old[e] - g_run[e] : MSD_SKIP;
+        }
+    }
+    __syncthreads();                                       // fix-up reads of `sorted` done; bdst written
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k)
+      if (k * TPB + tid < n) {
+        const uint32_t i = q[k] >> 16, j = q[k] & 0xFFFFu, blk = block_of(q[k]);
+        sorted[bcnt[blk] + (ss[k] & 0xFFFFu)] = u32x2{key[k], (((i & 127u) << 7) | (j & 127u)) | (blk << 14)};
+      }
+    // the per-key registers are dead: the next bucket's pairs leave now (in flight across the copy-out and the next bucket's
+    // block counting), the sizes of the bucket after it too
+    if constexpr (PF) {
+      if (b + stride < nb) load_bucket(b + stride, ps_nxt, cur);
+#pragma unroll
+      for (int e = 0; e <= MSD_SH; ++e) ps_cur[e] = ps_nxt[e];
+      shard_sizes(b + 2 * stride, ps_nxt);
+    }
+    __syncthreads();
+    u32x2* dst = pairs + seg * static_cast<int64_t>(n_blocks) * MSD_BREGION;
+#pragma unroll 4
+    for (int k = 0; k < ITEMS; ++k) {
+      const int idx = k * TPB + tid;
+      if (idx >= n) break;
+      const u32x2 v = sorted[idx];
+      const uint32_t d = bdst[v[1] >> 14];
+      if (d != MSD_SKIP) dst[d + static_cast<uint32_t>(idx)] = u32x2{v[0], v[1] & 16383u};
+    }
+    __syncthreads();                                       // sorted / bcnt / bdst are read: the next bucket may overwrite them
+  }
+}
+
+// one 128 x 128 block of the lower triangle from the MSD_BSH shards of its pair region: ranks into an LDS tile, then whole rows of
+// out[i, j] and of the mirrored block (as rank_block_write_kernel)
 template <bool VEC>
-__global__ __launch_bounds__(512) void rank_block_write_kernel(const u32x2* __restrict__ pairs, float* __restrict__ out, int64_t ldo, int N,
-                                                               int64_t M, int n_blocks, double denom) {
+__global__ __launch_bounds__(512) void msd_block_write_kernel(const u32x2* __restrict__ pairs, const uint32_t* __restrict__ blockfill, float* __restrict__ out,
+                                                              int64_t ldo, int N, int n_blocks, double denom, const uint32_t* __restrict__ flags, int bsh) {
   constexpr int TPB = 512;
   __shared__ float tile[BB][BB + 1];
+  const int64_t seg = blockIdx.y;
+  if (flags[seg]) return;                                  // handed to the LSD kernels (no writer of the flags runs beside this kernel)
+  const int t = blockIdx.x, tid = threadIdx.x;
+  int bi = static_cast<int>((sqrtf(8.0f * static_cast<float>(t) + 1.0f) - 1.0f) * 0.5f);
+  while (bi * (bi + 1) / 2 > t) --bi;
+  while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+  const int bj = t - bi * (bi + 1) / 2;
+  const int r0 = bi * BB, c0 = bj * BB;
+  const int rcount = N - r0 < BB ? N - r0 : BB;
+  const bool diag = bi == bj;
+  if (diag)
+    for (int e = tid; e < BB; e += TPB) tile[e][e] = 0.f;
+  const u32x2* src = pairs + (seg * n_blocks + t) * static_cast<int64_t>(MSD_BREGION);
+  const int bcap = MSD_BREGION / bsh, parts = (bcap + TPB - 1) / TPB;
+  __shared__ uint32_t scnt[MSD_BSH];
+  if (tid < MSD_BSH) scnt[tid] = tid < bsh ? blockfill[(seg * MSD_BSH + tid) * n_blocks + t] : 0u;
+  __syncthreads();
+  // the whole region in one flat sweep, two slots (16 B) per load and ten loads in flight per thread: a launch covers few outcomes
+  // (~2 workgroups per CU), so a thread's own loads are what hides the memory latency.  bcap is even: a load never straddles shards.
+  const u32x4* src4 = reinterpret_cast<const u32x4*>(src);
+  (void)parts;
+#pragma unroll 10
+  for (int x = tid; x < MSD_BREGION / 2; x += TPB) {
+    const int sh = (2 * x) / bcap, off = 2 * x - sh * bcap, c = static_cast<int>(scnt[sh]);
+    if (off < c) {
+      const u32x4 v = src4[x];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (off + h < c) {
+          const float val = static_cast<float>(static_cast<double>(v[2 * h] + 1u) / denom);
+          const int r = v[2 * h + 1] >> 7, cc = v[2 * h + 1] & 127;
+          tile[r][cc] = val;
+          if (diag) tile[cc][r] = val;
+        }
+    }
+  }
+  __syncthreads();
+  float* o = out + seg * static_cast<int64_t>(N) * ldo;
+  const int q = tid & 31, rr = tid >> 5;
+  const int ccount = diag ? rcount : BB;
+  for (int r = rr; r < rcount; r += TPB / 32) {
+    float* row = o + static_cast<int64_t>(r0 + r) * ldo + c0;
+    if (VEC && 4 * q + 3 < ccount) *reinterpret_cast<f32x4*>(row + 4 * q) = f32x4{tile[r][4 * q], tile[r][4 * q + 1], tile[r][4 * q + 2], tile[r][4 * q + 3]};
+    else
+      for (int e = 0; e < 4; ++e)
+        if (4 * q + e < ccount) row[4 * q + e] = tile[r][4 * q + e];
+  }
+  if (diag) return;
+  for (int c = rr; c < BB; c += TPB / 32) {
+    float* row = o + static_cast<int64_t>(c0 + c) * ldo + r0;
+    if (VEC && 4 * q + 3 < rcount) *reinterpret_cast<f32x4*>(row + 4 * q) = f32x4{tile[4 * q][c], tile[4 * q + 1][c], tile[4 * q + 2][c], tile[4 * q + 3][c]};
+    else
+      for (int e = 0; e < 4; ++e)
+        if (4 * q + e < rcount) row[4 * q + e] = tile[4 * q + e][c];
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(512) void rank_block_write_kernel(const u32x2* __restrict__ pairs, float* __restrict__ out, int64_t ldo, int N,
+                                                               int64_t M, int n_blocks, double denom, const uint32_t* __restrict__ flags, int want) {
+  constexpr int TPB = 512;
+  __shared__ float tile[BB][BB + 1];
+  if (flags && (flags[blockIdx.y] != 0u) != (want != 0)) return;      // MSD fast path: unflagged outcomes; LSD fallback behind it: flagged ones
   const int t = blockIdx.x, tid = threadIdx.x;
   const int64_t seg = blockIdx.y;
   int bi = static_cast<int>((sqrtf(8.0f * static_cast<float>(t) + 1.0f) - 1.0f) * 0.5f);
@@ -634,8 +1202,44 @@ static bool rank_use_big(int64_t N) {
   return tile_sw.get() != 8192;
 }
 
+// ---- MSD fast path: eligibility, workspace ------------------------------------------------------------------------------------
+struct MsdPlan {
+  bool on;
+  int group;                 // outcomes per launch group (the group's buffers are reused by the next group: Infinity-Cache resident)
+  int nb, nbs, n_blocks, bsh;   // buckets per outcome; counter stride; output blocks; shards of a block's pair region
+  size_t seg_bytes, pair_bytes, hist_bytes, table_bytes, fill_bytes, rbase_bytes, blockfill_bytes;      // per outcome
+  size_t group_bytes(int g) const { return a256(g * seg_bytes) + a256(g * pair_bytes) + a256(g * table_bytes) + a256(g * rbase_bytes) + a256(g * hist_bytes) +
+                                           a256(g * fill_bytes) + a256(g * blockfill_bytes); }
+};
+
+static MsdPlan msd_plan(int64_t n_outcomes, int64_t N) {
+  static MdgEnvInt msd_sw{"MDG_RANKS_MSD", 1};             // 0: the four-pass LSD sort for everything
+  static MdgEnvInt group_sw{"MDG_RANKS_GROUP", 8};         // measured at 4096^2: 1: 249 us per outcome, 2: 216, 8: 184, 16: 188, 32: 198 (LSD: 239)
+  MsdPlan pl{};
+  const int64_t M = N * (N - 1) / 2;
+  const int64_t nb = (M >> MSD_QLG) + 1;
+  pl.on = msd_sw.get() != 0 && N >= 2 && nb <= MSD_NB_MAX && rank_blocks_of(N) <= MSD_MAX_BLOCKS;
+  if (!pl.on) return pl;
+  int g = group_sw.get();
+  g = g < 1 ? 1 : g;
+  pl.group = static_cast<int>(g < n_outcomes ? g : n_outcomes);
+  pl.nb = static_cast<int>(nb);
+  pl.nbs = (pl.nb + 63) & ~63;
+  pl.n_blocks = static_cast<int>(rank_blocks_of(N));
+  pl.seg_bytes = static_cast<size_t>(pl.nb) * MSD_CAP * 8;
+  pl.pair_bytes = static_cast<size_t>(pl.n_blocks) * MSD_BREGION * 8;
+  pl.bsh = 1;
+  while (pl.bsh < MSD_BSH && pl.nb / (2 * pl.bsh) >= 8) pl.bsh *= 2;          // >= 8 buckets per shard of a block's pair region
+  pl.hist_bytes = static_cast<size_t>(MSD_SH) * MSD_NC * 4;
+  pl.table_bytes = static_cast<size_t>(MSD_NC) * 8;
+  pl.fill_bytes = static_cast<size_t>(MSD_SH) * pl.nbs * 4;
+  pl.rbase_bytes = static_cast<size_t>(pl.nbs) * 4;
+  pl.blockfill_bytes = static_cast<size_t>(MSD_BSH) * pl.n_blocks * 4;
+  return pl;
+}
+
 template <class C>
-static size_t rank_workspace_bytes(int64_t n_outcomes, int64_t N) {
+static size_t lsd_workspace_bytes(int64_t n_outcomes, int64_t N) {
   const size_t M = static_cast<size_t>(N) * (N - 1) / 2;
   const size_t nblk = (M + CfgStd::TILE - 1) / CfgStd::TILE;          // the last pass always runs on 8192-key tiles (the finer table)
   // keys / payloads x 2 | per-tile digit table (histogram path: one; look-back: one status table per pass) | block fill counters | digit totals
@@ -643,14 +1247,88 @@ static size_t rank_workspace_bytes(int64_t n_outcomes, int64_t N) {
          a256(static_cast<size_t>(n_outcomes) * static_cast<size_t>(rank_blocks_of(N)) * 4) + a256(static_cast<size_t>(n_outcomes) * 4 * 256 * 4);
 }
 
+// flags (one per outcome, live from the fast path to the fallback) | max(LSD scratch of all outcomes, fast-path scratch of one group)
+template <class C>
+static size_t rank_workspace_bytes(int64_t n_outcomes, int64_t N) {
+  const size_t lsd = lsd_workspace_bytes<C>(n_outcomes, N);
+  const MsdPlan pl = msd_plan(n_outcomes, N);
+  if (!pl.on) return lsd;
+  const size_t fast = pl.group_bytes(pl.group);
+  return a256(static_cast<size_t>(n_outcomes) * 4) + (lsd > fast ? lsd : fast);
+}
+
 extern "C" size_t mdg_rank_normalize_workspace_bytes(int64_t n_outcomes, int64_t N) {
   if (n_outcomes <= 0 || N < 2) return 0;
   return rank_use_big(N) ? rank_workspace_bytes<CfgBig>(n_outcomes, N) : rank_workspace_bytes<CfgStd>(n_outcomes, N);
 }
 
+extern "C" int mdg_rank_normalize_fast_path(int64_t n_outcomes, int64_t N) {
+  return (n_outcomes > 0 && N >= 2 && msd_plan(n_outcomes, N).on) ? 1 : 0;
+}
+
 extern "C" int mdg_rank_normalize(const float* scores, float* out, int64_t n_outcomes, int64_t N, void* workspace,
                                   size_t workspace_bytes, void* stream) {
   return mdg_rank_normalize_ld(scores, N, out, N, n_outcomes, N, workspace, workspace_bytes, stream);
+}
+
+// the fast path over all outcomes of the call, `group` at a time; raises flags[outcome] for what it leaves to the LSD kernels
+static void msd_run(const MsdPlan& pl, const float* scores, int64_t lds, float* out, int64_t ldo, int64_t n_outcomes, int64_t N, char* ws,
+                    uint32_t* flags, hipStream_t st, int src_is_keys) {
+  const int64_t M = N * (N - 1) / 2;
+  const int n_blocks = pl.n_blocks;
+  const double denom = static_cast<double>(N) * static_cast<double>(N - 1) / 2.0;
+  const int G = pl.group;
+  char* p = ws;
+  u32x2* segs = reinterpret_cast<u32x2*>(p); p += a256(G * pl.seg_bytes);
+  u32x2* pairs = reinterpret_cast<u32x2*>(p); p += a256(G * pl.pair_bytes);
+  u32x2* table = reinterpret_cast<u32x2*>(p); p += a256(G * pl.table_bytes);
+  uint32_t* rbase = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.rbase_bytes);
+  char* zero0 = p;                                                                  // hist | fill | blockfill: zeroed per group
+  uint32_t* hist = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.hist_bytes);
+  uint32_t* fill = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.fill_bytes);
+  uint32_t* blockfill = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.blockfill_bytes);
+  const size_t zero_bytes = static_cast<size_t>(p - zero0);
+  const int n_tiles = static_cast<int>(mdg_cdiv(M, MSD_TILE));
+  static MdgEnvInt hwg_sw{"MDG_RANKS_HIST_WGS", 512};
+  // bucket sort: 2 = 512 threads, one bucket per workgroup (default: 184 us per 4096^2 outcome); 0 = 1024 threads, persistent, the next
+  // bucket prefetched (201); 1 = 512 + prefetch; 3 = 1024, one bucket per workgroup
+  static MdgEnvInt variant_sw{"MDG_RANKS_BUCKET_VARIANT", 2};
+  const size_t part_lds = static_cast<size_t>(2 * MSD_TILE + MSD_NB_MAX) * 4;
+  const size_t bucket_lds = static_cast<size_t>(2 * MSD_CAP + MSD_NF / 2 + 2 * n_blocks) * 4;
+  const bool vec = ldo % 4 == 0 && mdg_aligned16(out);
+  static MdgEnvInt pwg_sw{"MDG_RANKS_PART_WGS", 256}, bwg_sw{"MDG_RANKS_BUCKET_WGS", 512};   // persistent workgroups of a launch (all outcomes of the group)
+  for (int64_t s0 = 0; s0 < n_outcomes; s0 += G) {
+    const unsigned g = static_cast<unsigned>(n_outcomes - s0 < G ? n_outcomes - s0 : G);
+    const float* sc = scores + s0 * N * lds;
+    float* o = out + s0 * N * ldo;
+    uint32_t* fl = flags + s0;
+    unsigned pw = static_cast<unsigned>(mdg_cdiv(pwg_sw.get(), g)), bw = static_cast<unsigned>(mdg_cdiv(bwg_sw.get(), g));
+    pw = pw < 1u ? 1u : (pw > static_cast<unsigned>(n_tiles) ? static_cast<unsigned>(n_tiles) : pw);
+    bw = bw < 1u ? 1u : (bw > static_cast<unsigned>(pl.nb) ? static_cast<unsigned>(pl.nb) : bw);
+    (void)hipMemsetAsync(zero0, 0, zero_bytes, st);
+    // two histogram workgroups per CU over the whole group: a wave keeps 8 x 256 B of scores in flight, a CU then 64 KB
+    int64_t hw = mdg_cdiv(hwg_sw.get(), g);
+    hw = hw < 1 ? 1 : (hw > mdg_cdiv(M, 1024) ? mdg_cdiv(M, 1024) : hw);
+    const int64_t span = (mdg_cdiv(M, hw) + 1023) & ~static_cast<int64_t>(1023);
+    hipLaunchKernelGGL(msd_hist_kernel, dim3(static_cast<unsigned>(hw), g), dim3(1024), 0, st, sc, lds, hist, static_cast<int>(N), M, span, src_is_keys);
+    hipLaunchKernelGGL(msd_table_kernel, dim3(g), dim3(1024), 0, st, hist, table, MSD_QLG);
+    hipLaunchKernelGGL(msd_partition_kernel, dim3(pw, g), dim3(1024), part_lds, st, sc, lds, table, fill, segs, fl, static_cast<int>(N), M, pl.nb, pl.nbs,
+                       MSD_QLG, n_tiles, src_is_keys);
+    hipLaunchKernelGGL(msd_offsets_kernel, dim3(g), dim3(1024), 0, st, fill, rbase, fl, pl.nb, pl.nbs, M);
+    switch (variant_sw.get()) {
+#define MDG_BUCKET_LAUNCH(T, P, GRID)                                                                                                                       \
+  hipLaunchKernelGGL((msd_bucket_kernel<MSD_NF, T, P>), dim3(GRID, g), dim3(T), bucket_lds, st, segs, fill, rbase, pairs, blockfill, fl, static_cast<int>(N), pl.nb, \
+                     pl.nbs, n_blocks, pl.bsh)
+      case 0: MDG_BUCKET_LAUNCH(1024, true, bw); break;
+      case 1: MDG_BUCKET_LAUNCH(512, true, bw); break;
+      case 3: MDG_BUCKET_LAUNCH(1024, false, static_cast<unsigned>(pl.nb)); break;
+      default: MDG_BUCKET_LAUNCH(512, false, static_cast<unsigned>(pl.nb)); break;
+#undef MDG_BUCKET_LAUNCH
+    }
+    const dim3 bgrid(static_cast<unsigned>(n_blocks), g);
+    if (vec) hipLaunchKernelGGL(msd_block_write_kernel<true>, bgrid, dim3(512), 0, st, pairs, blockfill, o, ldo, static_cast<int>(N), n_blocks, denom, fl, pl.bsh);
+    else hipLaunchKernelGGL(msd_block_write_kernel<false>, bgrid, dim3(512), 0, st, pairs, blockfill, o, ldo, static_cast<int>(N), n_blocks, denom, fl, pl.bsh);
+  }
 }
 
 template <class C>
@@ -666,6 +1344,27 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
     return MDG_EWORKSPACE;
   }
   char* ws = static_cast<char*>(workspace);
+  // MSD fast path first (round 4); `only` = its per-outcome flags: the LSD kernels below then touch the flagged outcomes alone
+  const uint32_t* only = nullptr;
+  const MsdPlan pl = msd_plan(n_outcomes, N);
+  if (pl.on) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_bucket_kernel<MSD_NF, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_bucket_kernel<MSD_NF, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_bucket_kernel<MSD_NF, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_bucket_kernel<MSD_NF, 512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr_done = true;
+    }
+    uint32_t* flags = reinterpret_cast<uint32_t*>(ws);
+    ws += a256(static_cast<size_t>(n_outcomes) * 4);
+    (void)hipMemsetAsync(flags, 0, static_cast<size_t>(n_outcomes) * 4, st);
+    msd_run(pl, scores, lds, out, ldo, n_outcomes, N, ws, flags, st, src_is_keys);
+    only = flags;
+    static MdgEnvInt nofb_sw{"MDG_RANKS_NO_FALLBACK", 0};   // diagnostics (timing the fast path alone): flagged outcomes are then left unranked
+    if (nofb_sw.get()) { MDG_CHECK_LAUNCH("mdg_rank_normalize"); return MDG_OK; }
+  }
   const size_t kb = a256(static_cast<size_t>(n_outcomes) * M * 4);
   uint32_t* k0 = reinterpret_cast<uint32_t*>(ws);          // k0 | p0 adjacent: together they hold the last pass's (rank, position) pairs
   uint32_t* p0 = reinterpret_cast<uint32_t*>(ws + kb);
@@ -694,7 +1393,7 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
   const auto status_of = [&](int pass) { return reinterpret_cast<uint32_t*>(ws + 4 * kb + pass * hb); };
   const auto ghist_of = [&](int pass) { return ghist + static_cast<size_t>(pass) * n_outcomes * 256; };
   if (lb) (void)hipMemsetAsync(ws + 4 * kb, 0, 4 * hb + fb + a256(static_cast<size_t>(n_outcomes) * 4 * 256 * 4), st);   // status tables, block fill counters, digit totals
-  hipLaunchKernelGGL(extract_keys_kernel<C>, grid, dim3(TPB), 0, st, scores, lds, k0, hist, lb ? ghist : nullptr, static_cast<int>(N), M, nblk, src_is_keys);
+  hipLaunchKernelGGL(extract_keys_kernel<C>, grid, dim3(TPB), 0, st, scores, lds, k0, hist, lb ? ghist : nullptr, static_cast<int>(N), M, nblk, src_is_keys, only);
   for (int pass = 0; pass < 4; ++pass) {
     uint32_t* kin = (pass & 1) ? k1 : k0;
     uint32_t* kout = (pass & 1) ? k0 : k1;
@@ -709,33 +1408,33 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
     typedef uint16_t u16;
     typedef uint8_t u8;
     if (!lb) {
-      if (std3) hipLaunchKernelGGL((histogram_kernel<CfgStd, u8>), grid3, dim3(CfgStd::TPB), 0, st, reinterpret_cast<const u8*>(kin), hist, M, nblk3, 0);
-      else if (pass == 3) hipLaunchKernelGGL((histogram_kernel<C, u8>), grid, dim3(TPB), 0, st, reinterpret_cast<const u8*>(kin), hist, M, nblk, 0);
-      else if (pass == 2) hipLaunchKernelGGL((histogram_kernel<C, u16>), grid, dim3(TPB), 0, st, reinterpret_cast<const u16*>(kin), hist, M, nblk, 0);
-      else if (pass == 1) hipLaunchKernelGGL((histogram_kernel<C, uint32_t>), grid, dim3(TPB), 0, st, kin, hist, M, nblk, 8);
-      hipLaunchKernelGGL(scan_kernel, dim3(L), dim3(1024), 0, st, hist, std3 ? nblk3 : nblk);
+      if (std3) hipLaunchKernelGGL((histogram_kernel<CfgStd, u8>), grid3, dim3(CfgStd::TPB), 0, st, reinterpret_cast<const u8*>(kin), hist, M, nblk3, 0, only);
+      else if (pass == 3) hipLaunchKernelGGL((histogram_kernel<C, u8>), grid, dim3(TPB), 0, st, reinterpret_cast<const u8*>(kin), hist, M, nblk, 0, only);
+      else if (pass == 2) hipLaunchKernelGGL((histogram_kernel<C, u16>), grid, dim3(TPB), 0, st, reinterpret_cast<const u16*>(kin), hist, M, nblk, 0, only);
+      else if (pass == 1) hipLaunchKernelGGL((histogram_kernel<C, uint32_t>), grid, dim3(TPB), 0, st, kin, hist, M, nblk, 8, only);
+      hipLaunchKernelGGL(scan_kernel, dim3(L), dim3(1024), 0, st, hist, std3 ? nblk3 : nblk, only);
     }
     if (pass == 0)
-      hipLaunchKernelGGL((scatter_kernel<C, true, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, offs, out, ldo, static_cast<int>(N), M, nblk, 0, denom, stat, gcur);
+      hipLaunchKernelGGL((scatter_kernel<C, true, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, offs, out, ldo, static_cast<int>(N), M, nblk, 0, denom, stat, gcur, only);
     else if (pass == 1)
       hipLaunchKernelGGL((scatter_kernel<C, false, false, uint32_t, u16>), grid, dim3(TPB), 0, st, kin, pin, reinterpret_cast<u16*>(kout), pout, offs, out, ldo,
-                         static_cast<int>(N), M, nblk, 8, denom, stat, gcur);
+                         static_cast<int>(N), M, nblk, 8, denom, stat, gcur, only);
     else if (pass == 2)
       hipLaunchKernelGGL((scatter_kernel<C, false, false, u16, u8>), grid, dim3(TPB), 0, st, reinterpret_cast<const u16*>(kin), pin, reinterpret_cast<u8*>(kout), pout,
-                         offs, out, ldo, static_cast<int>(N), M, nblk, 0, denom, stat, gcur);
+                         offs, out, ldo, static_cast<int>(N), M, nblk, 0, denom, stat, gcur, only);
     else if (blocked) {
       if (!lb) (void)hipMemsetAsync(fill, 0, static_cast<size_t>(n_outcomes) * n_blocks * 4, st);
       u32x2* pairs = reinterpret_cast<u32x2*>(k0);            // pass 3 reads k1 / p1
       hipLaunchKernelGGL((rank_blocks_kernel<CfgStd, u8>), grid3, dim3(CfgStd::TPB), blocks_lds, st, reinterpret_cast<const u8*>(kin), pin, offs, pairs, fill,
-                         static_cast<int>(N), M, nblk3, static_cast<int>(n_blocks), stat, gcur);
+                         static_cast<int>(N), M, nblk3, static_cast<int>(n_blocks), stat, gcur, only);
       const dim3 bgrid(static_cast<unsigned>(n_blocks), L);
       if (ldo % 4 == 0 && mdg_aligned16(out))
-        hipLaunchKernelGGL(rank_block_write_kernel<true>, bgrid, dim3(512), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
+        hipLaunchKernelGGL(rank_block_write_kernel<true>, bgrid, dim3(512), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom, only, 1);
       else
-        hipLaunchKernelGGL(rank_block_write_kernel<false>, bgrid, dim3(512), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom);
+        hipLaunchKernelGGL(rank_block_write_kernel<false>, bgrid, dim3(512), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom, only, 1);
     } else {
       hipLaunchKernelGGL((scatter_kernel<C, false, true, u8, u8>), grid, dim3(TPB), 0, st, reinterpret_cast<const u8*>(kin), pin, reinterpret_cast<u8*>(kout), pout, offs,
-                         out, ldo, static_cast<int>(N), M, nblk, 0, denom, stat, gcur);
+                         out, ldo, static_cast<int>(N), M, nblk, 0, denom, stat, gcur, only);
     }
   }
   MDG_CHECK_LAUNCH("mdg_rank_normalize");

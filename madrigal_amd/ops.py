@@ -686,13 +686,17 @@ def _scores3(t: torch.Tensor, name: str) -> torch.Tensor:
     return t
 
 
-def rank_normalize(scores: torch.Tensor, out: Optional[torch.Tensor] = None, max_workspace_bytes: int = 8 << 30) -> torch.Tensor:
+def rank_normalize(scores: torch.Tensor, out: Optional[torch.Tensor] = None, max_workspace_bytes: int = 8 << 30,
+                   fallback_flags: Optional[list] = None) -> torch.Tensor:
     """Normalised ranks per outcome (notebooks/normalize_scores.py:36-74): [L,N,N] fp32 -> [L,N,N] fp32.
     Outcomes are processed in chunks sized to ``max_workspace_bytes`` of sort scratch.  ``scores`` / ``out`` may be row-pitched
     (``empty_scores``); without ``out`` the result has the layout of ``scores``.
 
     ``scores`` of dtype int32 = the lower-triangle order keys of ``bilinear_allpairs(..., epilogue=EPI_TRIKEYS)``: same ranks,
-    and without ``out`` they are written over the keys (the returned fp32 tensor shares the keys' memory)."""
+    and without ``out`` they are written over the keys (the returned fp32 tensor shares the keys' memory).
+
+    ``fallback_flags`` (diagnostics): a list that receives, per chunk that took the MSD fast path, an int32 tensor with one entry
+    per outcome -- non-zero where the fast path handed the outcome to the four-pass LSD sort (same ranks either way)."""
     from_keys = isinstance(scores, torch.Tensor) and scores.dtype == torch.int32
     if from_keys:
         if not (scores.is_cuda and scores.dim() == 3 and (scores.numel() == 0 or (scores.stride(2) == 1 and scores.stride(1) >= scores.shape[2]
@@ -725,6 +729,8 @@ def rank_normalize(scores: torch.Tensor, out: Optional[torch.Tensor] = None, max
         ws = _workspace(nbytes, s.device)
         check(entry(_vp(s.data_ptr() + lo * s.stride(0) * 4), _c64(s.stride(1)), _vp(out.data_ptr() + lo * out.stride(0) * 4),
                     _c64(out.stride(1)), _c64(hi - lo), _c64(N), _ptr(ws), ctypes.c_size_t(nbytes), _stream(s)), "mdg_rank_normalize")
+        if fallback_flags is not None and lb.mdg_rank_normalize_fast_path(_c64(hi - lo), _c64(N)):
+            fallback_flags.append(ws[: 4 * (hi - lo)].view(torch.int32).clone())
     return out
 
 

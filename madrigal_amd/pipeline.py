@@ -12,7 +12,9 @@ Multi-GPU (one process per GPU): encode+fuse is independent per drug, so rank r 
 block of drugs (the KG encoder, which is per-graph rather than per-drug, runs destination-partitioned:
 every rank computes its block of every node type and one all-gather per conv reassembles them); one
 all-gather of the [N/G,128] blocks over RCCL gives every rank z[N,128]; the head is sharded by
-outcome (rank-local rank normalisation afterwards) or by head row.
+outcome (``label_range``: rank-local rank normalisation afterwards; what bench.py and the rank pipeline use)
+or by head row (``head_rows``: BASELINE configs[3]'s "row-sharded" -- rank r owns S[:, rows_r, :]; the rank
+normalisation of a row-sharded tensor would need a global sort, so it is for callers that want raw scores).
 """
 from __future__ import annotations
 
@@ -77,8 +79,12 @@ def generate_embeddings(model, batch: dict, batch_kg: dict, masks: Optional[torc
 
 @torch.no_grad()
 def score_all_pairs(model, z: torch.Tensor, label_range: Optional[Tuple[int, int]] = None, out=None,
-                    host_chunk: int = 16, epilogue: int = ops.EPI_STORE):
+                    host_chunk: int = 16, epilogue: int = ops.EPI_STORE, head_rows: Optional[Tuple[int, int]] = None):
     """Scores of every ordered drug pair for outcomes ``label_range`` (default: all) -> [L',N,N] fp32.
+
+    ``head_rows`` = (r0, r1): the row-sharded head -- only head drugs [r0, r1) against ALL tail drugs -> [L', r1 - r0, N]
+    (``decoder(z[r0:r1], z, ...)``, the general sweep; HBM destination only).  ``shard_range(N, rank, world)`` gives a rank's rows;
+    the row blocks of the ranks concatenate along dim 1 to the full tensor (no collective touches the scores).
 
     ``out`` None / a CUDA tensor: one head launch writes the whole tensor into HBM.
     ``out`` a numpy array or ``np.memmap`` (the reference's destination, predict.py:410-429): outcome chunks
@@ -87,6 +93,17 @@ def score_all_pairs(model, z: torch.Tensor, label_range: Optional[Tuple[int, int
     L_all = dec.parametrizations.weight.original.shape[0] if hasattr(dec, "parametrizations") else dec.weight.shape[0]
     lo, hi = (0, L_all) if label_range is None else label_range
     N = z.shape[0]
+    if head_rows is not None:
+        r0, r1 = head_rows
+        if not (0 <= r0 <= r1 <= N):
+            raise ValueError(f"head_rows {head_rows} outside [0, {N}]")
+        if out is None:
+            out = ops.empty_scores(hi - lo, r1 - r0, N, z.device)
+        if not isinstance(out, torch.Tensor):
+            raise ValueError("head_rows: HBM destination only")
+        if r1 == r0:
+            return out
+        return dec(z[r0:r1], z, (lo, hi), epilogue=epilogue, out=out)
     if out is None:
         out = ops.empty_scores(hi - lo, N, N, z.device)      # rows on 128-byte lines whatever N is (a [:, :, :N] view when N % 32 != 0)
     if isinstance(out, torch.Tensor):

@@ -147,18 +147,24 @@ def test_rank_all_pairs_equals_ranks_of_score_all_pairs():
     assert torch.equal(mine, want.contiguous())
 
 
-@pytest.mark.parametrize("path", ["default", "tile8192", "direct", "lookback"])
+@pytest.mark.parametrize("path", ["msd", "msd_group1", "msd_group5", "lsd", "lsd_tile8192", "lsd_direct", "lsd_lookback"])
 @pytest.mark.parametrize("N,L", [(300, 5), (2, 3), (1, 2), (97, 1), (1025, 2), (1283, 1)])
 def test_ranks_vs_oracle(ops, monkeypatch, N, L, path):
-    """Every path of the sort: 16384-key tiles (default at these N) and 8192-key tiles, the blocked last pass and the direct one
-    (the large-N path), contiguous and row-pitched tensors; ragged N (not a multiple of 128 / 4)."""
+    """Every path of the sort.  msd*: the adaptive MSD partition + in-LDS bucket sort (the default up to N = 4096), 2 / 1 / 5
+    outcomes per launch group.  lsd*: the four-pass LSD sort (larger N, and whatever the fast path hands back): 16384-key
+    tiles and 8192-key tiles, the blocked last pass and the direct one (the large-N path), tile offsets by look-back.
+    Contiguous and row-pitched tensors; ragged N (not a multiple of 128 / 4)."""
     from helpers import set_switch
     from oracle import madrigal_oracle as O
-    if path == "tile8192":
+    if path.startswith("lsd"):
+        set_switch(monkeypatch, "MDG_RANKS_MSD", "0")
+    if path.startswith("msd_group"):
+        set_switch(monkeypatch, "MDG_RANKS_GROUP", path[len("msd_group"):])
+    if path == "lsd_tile8192":
         set_switch(monkeypatch, "MDG_RANKS_TILE", "8192")
-    if path == "direct":
+    if path == "lsd_direct":
         set_switch(monkeypatch, "MDG_RANKS_DIRECT", "1")
-    if path == "lookback":                       # tile offsets by decoupled look-back instead of the histogram / scan launches
+    if path == "lsd_lookback":                   # tile offsets by decoupled look-back instead of the histogram / scan launches
         set_switch(monkeypatch, "MDG_RANKS_LOOKBACK", "1")
     rng = np.random.default_rng(N)
     s = rng.standard_normal((L, N, N)).astype(np.float32) * 7
@@ -170,6 +176,66 @@ def test_ranks_vs_oracle(ops, monkeypatch, N, L, path):
     pit.copy_(torch.from_numpy(s))
     got = ops.rank_normalize(pit)
     assert got.stride(1) == pit.stride(1) and np.array_equal(got.cpu().numpy(), ref)
+
+
+def _score_shapes(kind, rng, L, N):
+    if kind == "gauss":
+        return rng.standard_normal((L, N, N)) * 7
+    if kind == "uniform":
+        return rng.uniform(-3, 5, (L, N, N))
+    if kind == "narrow":                         # every key shares its top 14 bits: one coarse bin cut into equal sub-ranges
+        return 1.0 + rng.uniform(0, 1e-3, (L, N, N))
+    if kind == "lognormal":                      # dozens of binades, positive only (below the reference's mask value 1e7)
+        return np.minimum(np.exp(rng.standard_normal((L, N, N)) * 4), 9e6)
+    if kind == "cauchy":                         # heavy tails: a few keys in far-away coarse bins
+        return np.clip(rng.standard_cauchy((L, N, N)), -9e6, 9e6)
+    if kind == "tiny":                           # around zero, denormals included: the bucket that straddles the sign
+        return rng.standard_normal((L, N, N)) * 1e-38
+    if kind == "small_ties":                     # 65 536 values, 4 ... 17 copies of each: tie groups inside fine bins, ordered by position
+        return rng.integers(0, 65536, (L, N, N)) * 2.0 ** -10      # (the support ends ON a binade: see the bucket function's limits below)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["gauss", "uniform", "narrow", "lognormal", "cauchy", "tiny", "small_ties"])
+@pytest.mark.parametrize("N", [700, 1500])
+def test_ranks_fast_path_over_score_distributions(ops, monkeypatch, kind, N):
+    """The MSD fast path keeps ~4096 keys per bucket whatever the distribution of the scores (the bucket boundaries come from the
+    outcome's own histogram); same bits as the oracle and as the LSD sort, and NO outcome handed back to the LSD kernels for
+    these shapes (``fallback_flags``), small tie groups included -- except "narrow", which must be handed back."""
+    from helpers import set_switch
+    from oracle import madrigal_oracle as O
+    L = 2
+    s = _score_shapes(kind, np.random.default_rng(11 + N), L, N).astype(np.float32)
+    dev = torch.from_numpy(s).cuda()
+    flags = []
+    out = ops.rank_normalize(dev, fallback_flags=flags)
+    handed = sum(int((f != 0).sum()) for f in flags)
+    # "narrow": 8 389 distinct fp32 values inside ONE coarse bin -- the equal sub-ranges of that bin's low bits are mostly empty,
+    # the rest overflow: the documented limit of the bucket function (smooth inside 1/32 of a binade; a support that ends with a
+    # dense step in the middle of such a bin is the other case); handed back, same bits
+    assert flags and handed == (L if kind == "narrow" else 0), (kind, [f.tolist() for f in flags])
+    assert np.array_equal(out.cpu().numpy(), O.rank_normalize(s))
+    set_switch(monkeypatch, "MDG_RANKS_MSD", "0")
+    flags2 = []
+    assert torch.equal(ops.rank_normalize(dev, fallback_flags=flags2), out) and not flags2
+
+
+def test_ranks_fast_path_hands_point_masses_to_the_lsd_sort(ops):
+    """Outcomes the fast path cannot bucket (all scores equal; half of them on one value; 7 distinct values) are flagged per
+    outcome and sorted by the LSD kernels, beside outcomes of the same call that stay on the fast path: same bits as the oracle."""
+    from oracle import madrigal_oracle as O
+    N = 900
+    rng = np.random.default_rng(3)
+    s = rng.standard_normal((6, N, N)).astype(np.float32)
+    s[1] = 0.25
+    s[3] = np.where(rng.random((N, N)) < 0.5, np.float32(1.5), s[3])
+    s[4] = rng.integers(-3, 4, (N, N)).astype(np.float32)
+    flags = []
+    out = ops.rank_normalize(torch.from_numpy(s).cuda(), fallback_flags=flags).cpu().numpy()
+    f = torch.cat(flags).cpu().numpy() != 0
+    assert f.tolist() == [False, True, False, True, True, False], f.tolist()
+    ref = O.rank_normalize(s)
+    assert np.array_equal(out, ref)
 
 
 def test_ranks_ties_are_stable_in_flat_index(ops):

@@ -94,3 +94,38 @@ def test_full_baseline_shape_against_the_oracle_on_samples(prec, tol):
         assert float((s - s.T).abs().max()) < tol * float(s.abs().max())
     # every outcome slab was written (no NaN left anywhere), checked by a reduction per outcome
     assert bool(torch.isfinite(out.view(L, -1).sum(dim=1)).all())
+
+
+@pytest.mark.parametrize("N,L,world", [(300, 7, 2), (517, 5, 3), (4003, 3, 8)])
+def test_row_sharded_head_concatenates_to_the_full_tensor(N, L, world):
+    """BASELINE configs[3] "row-sharded": rank r scores its block of head drugs against all tail drugs
+    (score_all_pairs(head_rows=shard_range(N, r, world))); no collective touches the scores, so the ranks are run one after
+    the other here.  Their blocks concatenate to the full tensor: against the CPU oracle, and against the one-launch symmetric
+    sweep within the fp32 rounding of the two association orders; ragged N and ragged blocks included."""
+    from madrigal_amd import models as M
+    from madrigal_amd.parallel import shard_range
+    from madrigal_amd.pipeline import score_all_pairs
+    from oracle import madrigal_oracle as O
+    model = _Scorer(M, L, 4).cuda().eval()
+    z = torch.randn(N, 128, generator=torch.Generator().manual_seed(2))
+    zc = z.cuda()
+    with M.precision("bf16x3"):
+        full = score_all_pairs(model, zc)
+        blocks = []
+        for r in range(world):
+            lo, hi = shard_range(N, r, world)
+            b = score_all_pairs(model, zc, head_rows=(lo, hi))
+            assert tuple(b.shape) == (L, hi - lo, N)
+            blocks.append(b)
+        got = torch.cat(blocks, dim=1)
+        part = score_all_pairs(model, zc, (1, 3), head_rows=shard_range(N, world - 1, world))
+    assert tuple(got.shape) == (L, N, N)
+    assert rel_err(got.cpu(), full.cpu()) < 2e-5
+    lo, hi = shard_range(N, world - 1, world)
+    assert torch.equal(part, blocks[-1][1:3])
+    w = model.decoder.parametrizations.weight.original.detach().cpu()
+    rows = slice(0, min(N, 200))
+    ref = O.bilinear_scores(z[rows], z, w)
+    assert rel_err(got[:, rows].cpu(), ref) < 1e-4
+    with pytest.raises(ValueError):
+        score_all_pairs(model, zc, head_rows=(5, N + 1))
