@@ -114,6 +114,20 @@ def pmc_traffic(n_drugs: int, n_outcomes: int, precision: str):
     return None, None
 
 
+def rank_pmc_traffic(n_drugs: int):
+    """HBM bytes per OUTCOME of the rank normalisation from the committed PMC passes (sum over its kernels of WRITE_SIZE + 2 x
+    FETCH_SIZE per launch, divided by the outcomes per launch), if a profile at this drug count exists under profiles/."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*rank*pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload", {}).get("drugs") == n_drugs and d.get("hbm_bytes_per_outcome_corrected") is not None:
+            return d["hbm_bytes_per_outcome_corrected"], os.path.basename(f)
+    return None, None
+
+
 def host_threads() -> int:
     """Threads for the CPU baselines: the cores this process may actually use (cgroup CPU quota and affinity mask; os.cpu_count()
     reports every core of the host, and torch's index / scatter ops collapse when oversubscribed 16x)."""
@@ -282,6 +296,54 @@ def cpu_finetune_step(params, batch, bkg, config: str, n_outcomes: int, triples,
             "kg_edges_kept": f"1/{kg_edge_keep}", "loss": float(loss.detach())}
 
 
+def f32_exact_leg(model, z, scores, enc_ms, args):
+    """The exact-fp32 head (v_mfma_f32_32x32x2_f32, no operand splitting) beside the headline's mode, on the embeddings the headline
+    just encoded: kernel time by HIP events on the launch stream, the whole-job rate it would give (the headline's encode+fuse time +
+    this head), its share of the 157 TFLOP/s fp32 matrix peak -- nominal (256 flop per score) and as executed (the symmetric sweep
+    computes the tiles on / right of the block diagonal: (nb + 1) / (2 nb) of them) -- and the per-entry picture of the headline's
+    mode against it on a seeded sample of entries (both tensors live in HBM at once: 2 x 60 GB at the default shape)."""
+    import torch
+    from madrigal_amd import models as M, ops
+    L, N, _ = scores.shape
+    out = ops.empty_scores(L, N, N, scores.device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    times = []
+    with torch.no_grad(), M.precision("f32"):
+        model.decoder(z, z, (0, L), out=out)                      # warm-up
+        torch.cuda.synchronize()
+        for _ in range(3):
+            e0.record()
+            model.decoder(z, z, (0, L), out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1))
+    ms = sum(times) / len(times)
+    per_launch = float(L) * N * N
+    nb = -(-N // 256)
+    executed = (nb + 1) / (2.0 * nb)
+    tf = per_launch * FLOP_PER_SCORE / (ms * 1e-3) / 1e12
+    g = torch.Generator(device=scores.device).manual_seed(17)
+    n_s = 4_000_000
+    li = torch.randint(0, L, (n_s,), device=scores.device, generator=g)
+    ii = torch.randint(0, N, (n_s,), device=scores.device, generator=g)
+    jj = torch.randint(0, N, (n_s,), device=scores.device, generator=g)
+    ref, got = out[li, ii, jj].double(), scores[li, ii, jj].double()
+    d, rms = (got - ref).abs(), float(ref.pow(2).mean().sqrt())
+    res = {"kernel": HEAD_KERNEL["f32"], "kernel_ms": ms, "kernel_ms_runs": times, "whole_job_scores_per_s": per_launch / ((enc_ms + ms) * 1e-3),
+           "head_only_scores_per_s": per_launch / (ms * 1e-3), "tflops_nominal": tf, "tflops_executed": tf * executed,
+           "frac_of_fp32_mfma_peak_nominal": tf / MFMA_F32_PEAK_TFLOPS, "frac_of_fp32_mfma_peak_executed": tf * executed / MFMA_F32_PEAK_TFLOPS,
+           "executed_share_of_tiles": executed, "peak_tflops": MFMA_F32_PEAK_TFLOPS,
+           "headline_mode_vs_exact": {"mode": args.precision, "sampled_entries": n_s, "rms_score": rms,
+                                      "max_abs_diff_over_max_abs": float(d.max() / ref.abs().max()),
+                                      "share_within_1e-4_rel_plus_1e-4_rms": float((d <= 1e-4 * ref.abs() + 1e-4 * rms).double().mean()),
+                                      "share_within_1e-4_rel": float((d <= 1e-4 * ref.abs()).double().mean()),
+                                      "median_rel_diff": float((d / ref.abs().clamp_min(1e-30)).median())},
+           "what": "same embeddings, same W_sym, exact fp32 products; encode+fuse time taken from the headline's timed steps"}
+    del out, ref, got, d
+    torch.cuda.empty_cache()
+    return res
+
+
 def ranks_leg(scores, args, model=None, z=None):
     """The product of the reference's scoring job is the normalised-rank tensor (notebooks/normalize_scores.py:36-85; README.md:43):
     per outcome, the strict lower triangle of the [N,N] score slice ranked (1-based, ascending), divided by N(N-1)/2, mirrored.
@@ -303,12 +365,15 @@ def ranks_leg(scores, args, model=None, z=None):
     for _ in range(2):            # two passes over all outcomes, the faster one reported: the first touches 60 GB of fresh rank tensor
         t0 = time.perf_counter()
         e0.record()
-        ops.rank_normalize(s, out=out)
+        flags = []
+        ops.rank_normalize(s, out=out, fallback_flags=flags)
         e1.record()
         torch.cuda.synchronize()
         walls.append(time.perf_counter() - t0)
         passes.append(e0.elapsed_time(e1))
     ms, wall = min(passes), min(walls)
+    handed = int(sum(int((f != 0).sum()) for f in flags))
+    rank_traffic, rank_traffic_src = rank_pmc_traffic(N)
     M = N * (N - 1) // 2
     # size-independent checks inside the run: a permutation of 1..M per outcome (sum of ranks), symmetric, zero diagonal
     denom = N * (N - 1) / 2
@@ -321,7 +386,10 @@ def ranks_leg(scores, args, model=None, z=None):
            "ms_total": ms, "passes_ms": passes, "ms_per_outcome": ms / L, "wall_ms": wall * 1e3, "dtype": "u32 order-preserving keys of fp32 scores, u32 ranks, f64 divide -> f32",
            "checks": {"rank_sum_rel_err": perm_err, "symmetric_zero_diagonal": sym},
            "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None, "kernel": "mdg_rank_normalize (extract + 4 x 8-bit stable LSD radix passes + blocked rank store)",
+                        "traffic": None if rank_traffic is None else rank_traffic * L, "traffic_source": rank_traffic_src,
+                        "kernel": "mdg_rank_normalize: adaptive MSD path (coarse histogram -> equal-depth bucket table -> one partition -> in-LDS counting sort per "
+                                  "bucket + block binning -> blocked rank store); outcomes it hands back take the 4 x 8-bit LSD passes",
+                        "outcomes_handed_to_lsd": handed,
                         "algorithmic_bytes_per_outcome": alg / L, "formula": "(M x 4 B keys read + N^2 x 4 B ranks written) x outcomes / launch time"}}
     del chk
     # seed ensembling on a subset: 5 rank tensors of `sub` outcomes each (disjoint outcome slices of this run stand in for the seeds)
@@ -624,6 +692,7 @@ def main():
     ap.add_argument("--kg-edges", type=int, default=8000000)
     ap.add_argument("--head-only", action="store_true", help="time the scoring stage alone (embeddings given)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-exact", action="store_true", help="skip the exact-fp32 head beside the headline's mode (N = 1)")
     ap.add_argument("--pretrain-steps", type=int, default=5, help="contrastive-pretraining leg (BASELINE configs[2]); 0 disables; single GPU only")
     ap.add_argument("--pretrain-batch", type=int, default=2048)
     ap.add_argument("--ddp-legs", action="store_true", help="N > 1: after the line, also run the data-parallel finetune step and the sharded cfg5 "
@@ -791,7 +860,15 @@ def main():
 
     main_mode = args.scaling if world > 1 else "strong"
     want_ranks = world == 1 and args.rank_outcomes != 0
-    h = headline(main_mode, keep_scores=want_ranks)
+    want_exact = world == 1 and not args.head_only and args.precision != "f32" and not args.no_f32_exact
+    h = headline(main_mode, keep_scores=want_ranks or want_exact)
+    f32_exact = None
+    if want_exact:
+        try:
+            f32_exact = f32_exact_leg(model, h["z"], h["scores"], h["enc_ms"], args)
+        except Exception as e:
+            f32_exact = {"kernel_ms": None, "error": f"{type(e).__name__}: {e}"[:400]}
+        torch.cuda.empty_cache()
     ranks = None
     if want_ranks:
         try:
@@ -889,6 +966,8 @@ def main():
             line[f"{other['mode']}_scaling"] = {"value": scores_per_s(other), "unit": "scores/s", "ms_per_step": other["dt"] / args.steps * 1e3,
                                                 "outcomes_per_gpu": other["Lr"], "outcomes_total": other["L_total"], "scaling": other["mode"],
                                                 "head_ms": other["head_ms"], "encode_fuse_ms": other["enc_ms"]}
+        if f32_exact is not None:
+            line["f32_exact"] = f32_exact
         if stress is not None:
             line["roofline_cfg5"] = stress
         if world == 1 and not args.no_cpu_baseline:
