@@ -387,9 +387,10 @@ def ranks_leg(scores, args, model=None, z=None):
            "checks": {"rank_sum_rel_err": perm_err, "symmetric_zero_diagonal": sym},
            "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": None if rank_traffic is None else rank_traffic * L, "traffic_source": rank_traffic_src,
-                        "kernel": "mdg_rank_normalize: adaptive MSD path (coarse histogram -> equal-depth bucket table -> one partition -> in-LDS counting sort per "
-                                  "bucket + block binning -> blocked rank store); outcomes it hands back take the 4 x 8-bit LSD passes",
-                        "outcomes_handed_to_lsd": handed,
+                        "kernel": "mdg_rank_normalize (extract + 4 x 8-bit stable LSD radix passes on LDS-sorted 16384-key tiles + blocked rank store)" if not flags else
+                                  "mdg_rank_normalize, MDG_RANKS_MSD=1: adaptive MSD path (histogram -> bucket table -> one partition -> in-LDS counting sort per bucket "
+                                  "-> blocked rank store); outcomes it hands back take the LSD passes",
+                        "outcomes_handed_to_lsd": handed if flags else None,
                         "algorithmic_bytes_per_outcome": alg / L, "formula": "(M x 4 B keys read + N^2 x 4 B ranks written) x outcomes / launch time"}}
     del chk
     # seed ensembling on a subset: 5 rank tensors of `sub` outcomes each (disjoint outcome slices of this run stand in for the seeds)

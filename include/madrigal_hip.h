@@ -255,10 +255,10 @@ int mdg_gather_bce(const float* scores, int64_t n_labels, int64_t n_head, int64_
 /* ---------------------------------------------------------------------- rank normalisation ---- */
 
 size_t mdg_rank_normalize_workspace_bytes(int64_t n_outcomes, int64_t N);
-/* 1 when a call of this size takes the adaptive MSD fast path (one partition + an in-LDS sort per bucket; ranks.hip), 0 when
- * it runs the four-pass LSD sort only.  On the fast path the first n_outcomes uint32 words of the workspace hold, after the
- * call, one flag per outcome: non-zero = the fast path handed that outcome to the LSD kernels (point masses of equal
- * scores, a score distribution that is not smooth inside 1/32 of a binade).  Diagnostics: the ranks are the same bits. */
+/* 1 when a call of this size takes the opt-in adaptive MSD path first (MDG_RANKS_MSD=1: one partition + an in-LDS sort per bucket;
+ * ranks.hip), 0 when it runs the four-pass LSD sort only (the default).  On the MSD path the first n_outcomes uint32 words of the
+ * workspace hold, after the call, one flag per outcome: non-zero = that outcome was handed to the LSD kernels (point masses of
+ * equal scores, scores that are not smooth inside a coarse bin, row-structured tensors).  Diagnostics: the ranks are the same bits. */
 int mdg_rank_normalize_fast_path(int64_t n_outcomes, int64_t N);
 
 /* Per outcome l: out[l,i,j] = out[l,j,i] = rank(scores[l,i,j] among the strict lower triangle i > j, ascending,

@@ -539,7 +539,13 @@ __global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const KIN* __restri
 }
 
 // ================================================================================================================================
-// Fast path (round 4): ONE adaptive MSD partition + an in-LDS counting sort per bucket, instead of four global LSD passes.
+// OPT-IN path (round 4, MDG_RANKS_MSD=1; OFF by default): ONE adaptive MSD partition + an in-LDS counting sort per bucket, instead of
+// four global LSD passes.  Measured on one MI355X (profiles/r04_rank_msd_experiment.txt): 184 us per 4096^2 outcome on
+// i.i.d. scores against 243 us for the LSD sort -- and SLOWER than it on the bench's own score tensor, because nearly every outcome is
+// handed back: a drug's scores sit around the drug's own level, so (i) they fill two or three of the fixed top-bit coarse bins
+// unevenly and (ii) a bucket draws its keys from the tiles of a few dozen rows, which overflows the per-tile-shard segments that
+// keep the global atomics uncontended.  Capacity-based layouts do not survive row-structured scores; the exact (count + scan)
+// layout of the LSD passes does.  Kept as a tested, bit-exact path for smooth i.i.d.-like score tensors.
 //
 //   msd_hist_kernel      read the keys once: histogram of their top 14 bits per outcome (16 384 coarse bins: sign, exponent, 5
 //                        mantissa bits -- a bin spans 1/32 of a binade, over which any smooth score density is flat)
@@ -1213,7 +1219,7 @@ struct MsdPlan {
 };
 
 static MsdPlan msd_plan(int64_t n_outcomes, int64_t N) {
-  static MdgEnvInt msd_sw{"MDG_RANKS_MSD", 1};             // 0: the four-pass LSD sort for everything
+  static MdgEnvInt msd_sw{"MDG_RANKS_MSD", 0};             // 1: the adaptive MSD path first, the LSD sort for what it hands back (see the header above)
   static MdgEnvInt group_sw{"MDG_RANKS_GROUP", 8};         // measured at 4096^2: 1: 249 us per outcome, 2: 216, 8: 184, 16: 188, 32: 198 (LSD: 239)
   MsdPlan pl{};
   const int64_t M = N * (N - 1) / 2;

@@ -12,12 +12,13 @@ python3 - $out $tag $N $L <<'PY'
 import collections, csv, glob, json, os, shutil, sys
 root, tag, N, L = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 ktf = glob.glob(f"{root}/kt/*/*_kernel_stats.csv")[0]
-shutil.copy(ktf, f"profiles/{tag}_rank_normalize_kernel_stats.csv")
+name = os.environ.get("RANK_PROFILE_NAME", "rank_normalize")
+shutil.copy(ktf, f"profiles/{tag}_{name}_kernel_stats.csv")
 kt = {r["Name"]: r for r in csv.DictReader(open(ktf))}
 keep = ("msd_", "rank_block", "scatter_kernel", "extract_keys", "histogram_kernel", "scan_kernel", "rank_blocks", "zero_diag", "fillBuffer")
 calls_per_run = 4                                   # rank_bench.py: one warm-up call on 4 outcomes + three timed calls on L outcomes
 out = {"command": f"rocprofv3 --pmc WRITE_SIZE (and, separately, --pmc FETCH_SIZE) --output-format csv -- python3 scripts/rank_bench.py {N} {L} --no-oracle",
-       "workload": {"drugs": N, "outcomes_per_call": L, "what": "ops.rank_normalize on randn scores, default path (MDG_RANKS_MSD=1)"},
+       "workload": {"drugs": N, "outcomes_per_call": L, "what": "ops.rank_normalize on randn scores, MDG_RANKS_MSD=" + os.environ.get("MDG_RANKS_MSD", "0 (default: the LSD sort)")},
        "note": "per-dispatch averages over the run (one warm-up call on 4 outcomes + three calls on L outcomes); counters in KiB; gfx950: read bytes = 2 x FETCH_SIZE "
                "(MI355X_MICROARCH.md, HBM); FETCH / WRITE count fabric requests: bytes served by the Infinity Cache are included, so this is traffic past the L2, "
                "an upper bound on HBM bytes", "kernels": {}}
@@ -48,7 +49,7 @@ out["write_bytes_per_outcome"] = tot_w / outcomes
 out["read_bytes_per_outcome_corrected"] = tot_r / outcomes
 out["algorithmic_bytes_per_outcome"] = M * 4.0 + N * N * 4.0
 out["traffic_over_algorithmic"] = out["hbm_bytes_per_outcome_corrected"] / out["algorithmic_bytes_per_outcome"]
-json.dump(out, open(f"profiles/{tag}_rank_normalize_pmc_traffic.json", "w"), indent=1)
+json.dump(out, open(f"profiles/{tag}_{name}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("hbm_bytes_per_outcome_corrected", "write_bytes_per_outcome", "read_bytes_per_outcome_corrected", "algorithmic_bytes_per_outcome", "traffic_over_algorithmic")}))
 for k, d in sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("kernel_trace_avg_us", 0) * kv[1].get("kernel_trace_calls", 0)):
     print(f"{k[:60]:60s} avg {d.get('kernel_trace_avg_us', 0):8.1f} us x {d.get('kernel_trace_calls', 0):4d}  write {d['write_bytes'] / 1e6:8.1f} MB  read {d['read_bytes_corrected'] / 1e6:8.1f} MB  {d.get('tb_per_s_past_l2', 0):5.2f} TB/s")

@@ -150,14 +150,13 @@ def test_rank_all_pairs_equals_ranks_of_score_all_pairs():
 @pytest.mark.parametrize("path", ["msd", "msd_group1", "msd_group5", "lsd", "lsd_tile8192", "lsd_direct", "lsd_lookback"])
 @pytest.mark.parametrize("N,L", [(300, 5), (2, 3), (1, 2), (97, 1), (1025, 2), (1283, 1)])
 def test_ranks_vs_oracle(ops, monkeypatch, N, L, path):
-    """Every path of the sort.  msd*: the adaptive MSD partition + in-LDS bucket sort (the default up to N = 4096), 2 / 1 / 5
-    outcomes per launch group.  lsd*: the four-pass LSD sort (larger N, and whatever the fast path hands back): 16384-key
+    """Every path of the sort.  msd*: the opt-in adaptive MSD partition + in-LDS bucket sort (MDG_RANKS_MSD=1, up to N = 4096), 8 / 1 /
+    5 outcomes per launch group.  lsd*: the four-pass LSD sort (the default; also whatever the MSD path hands back): 16384-key
     tiles and 8192-key tiles, the blocked last pass and the direct one (the large-N path), tile offsets by look-back.
     Contiguous and row-pitched tensors; ragged N (not a multiple of 128 / 4)."""
     from helpers import set_switch
     from oracle import madrigal_oracle as O
-    if path.startswith("lsd"):
-        set_switch(monkeypatch, "MDG_RANKS_MSD", "0")
+    set_switch(monkeypatch, "MDG_RANKS_MSD", "0" if path.startswith("lsd") else "1")
     if path.startswith("msd_group"):
         set_switch(monkeypatch, "MDG_RANKS_GROUP", path[len("msd_group"):])
     if path == "lsd_tile8192":
@@ -199,7 +198,7 @@ def _score_shapes(kind, rng, L, N):
 @pytest.mark.parametrize("kind", ["gauss", "uniform", "narrow", "lognormal", "cauchy", "tiny", "small_ties"])
 @pytest.mark.parametrize("N", [700, 1500])
 def test_ranks_fast_path_over_score_distributions(ops, monkeypatch, kind, N):
-    """The MSD fast path keeps ~4096 keys per bucket whatever the distribution of the scores (the bucket boundaries come from the
+    """The opt-in MSD path (MDG_RANKS_MSD=1) keeps ~4096 keys per bucket whatever the distribution of i.i.d. scores (the bucket boundaries come from the
     outcome's own histogram); same bits as the oracle and as the LSD sort, and NO outcome handed back to the LSD kernels for
     these shapes (``fallback_flags``), small tie groups included -- except "narrow", which must be handed back."""
     from helpers import set_switch
@@ -207,6 +206,7 @@ def test_ranks_fast_path_over_score_distributions(ops, monkeypatch, kind, N):
     L = 2
     s = _score_shapes(kind, np.random.default_rng(11 + N), L, N).astype(np.float32)
     dev = torch.from_numpy(s).cuda()
+    set_switch(monkeypatch, "MDG_RANKS_MSD", "1")
     flags = []
     out = ops.rank_normalize(dev, fallback_flags=flags)
     handed = sum(int((f != 0).sum()) for f in flags)
@@ -220,10 +220,12 @@ def test_ranks_fast_path_over_score_distributions(ops, monkeypatch, kind, N):
     assert torch.equal(ops.rank_normalize(dev, fallback_flags=flags2), out) and not flags2
 
 
-def test_ranks_fast_path_hands_point_masses_to_the_lsd_sort(ops):
+def test_ranks_fast_path_hands_point_masses_to_the_lsd_sort(ops, monkeypatch):
     """Outcomes the fast path cannot bucket (all scores equal; half of them on one value; 7 distinct values) are flagged per
     outcome and sorted by the LSD kernels, beside outcomes of the same call that stay on the fast path: same bits as the oracle."""
+    from helpers import set_switch
     from oracle import madrigal_oracle as O
+    set_switch(monkeypatch, "MDG_RANKS_MSD", "1")
     N = 900
     rng = np.random.default_rng(3)
     s = rng.standard_normal((6, N, N)).astype(np.float32)

@@ -184,3 +184,60 @@ def test_simclr_raw_pretraining_steps_reduce_loss_and_are_reproducible():
     assert all(np.isfinite(l1)) and min(l1[-3:]) < l1[0], l1
     assert l1 == l2
     assert run(10, host_inputs=True) == l1          # same rows in the same order, same kernels: bit-identical
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("bf16x3", 3e-4)])
+def test_contrastive_forward_at_the_stated_batch_against_the_oracle(prec, tol):
+    """BASELINE configs[2] at its stated size -- batch 2048 over the bench's KG (130 000 nodes / 8 000 000 edges), 'str_center_uni'
+    views, separate predictors, T = 0.1, mlp_dim 512 -- training-mode forward (BatchNorm batch statistics over the 2048 drugs /
+    their 53 000 atoms / the 32 768 tx rows; dropout off on both sides) against the CPU oracle, stage by stage at FULL size:
+    view 1 = uni_projector(GIN(all molecules)) for every drug; view 2 for every drug whose drawn modality is cv or a tx cell line
+    (the oracle's chemCPA encoder over all 16 x 2048 rows with batch statistics); the KG-view rows are the one stage taken from the
+    HIP side (the oracle's HGT over 8e6 edges takes minutes: it is pinned at fixture size, tests above and test_models_gpu); then
+    predictors (batch statistics over 2048 rows) and the [4096, 4095] InfoNCE loss on the HIP side's views against the oracle's on
+    the same views: every aug row and the loss."""
+    from madrigal_amd import data as D, models as M
+    from oracle import madrigal_oracle as O
+    free, _ = torch.cuda.mem_get_info()
+    if free < 30 * 2 ** 30:
+        pytest.skip("needs 30 GB of free HBM")
+    B, seed, T = 2048, 5, 0.1
+    avail, m1, m2 = _views(B, seed, p_kg=0.6, p_cv=0.3, p_tx=0.1)            # SURVEY 8(d) availability rates
+    batch, bkg = D.make_batch(B, seed, kg_nodes=130_000, kg_edges=8_000_000, masks=avail)
+    torch.manual_seed(seed)
+    model = _no_dropout(_build(M, bkg["data"], False, False, mlp_dim=512, T=T))
+    p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.cuda().train()
+    b = D.batch_to(batch, "cuda")
+    kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
+    data = (b["strs"], kgc, b["cv"], b["tx"])
+    with torch.no_grad(), M.precision(prec):
+        e1 = model.base_encoder(b["drugs"], m1.cuda(), *data, raw_encoder_output=True).cpu()
+        e2 = model.base_encoder(b["drugs"], m2.cuda(), *data, raw_encoder_output=True).cpu()
+        a1, a2, (lg, lb, loss) = model(b["drugs"], m1.cuda(), m2.cuda(), None, data)
+    assert e1.shape == (B, 128) and e2.shape == (B, 128) and a1.shape == (B, 128)
+    assert int((~m1).sum()) == B and bool((~m1)[:, 0].all()) and int((~m2).sum()) == B      # one row per drug and view
+    enc = O._sub({"encoder." + k: v for k, v in O._sub(p, "base_encoder.").items()}, "encoder.")
+    proj = lambda x: O.mlp_encoder_forward(O._sub(enc, "uni_projector."), x, 2, "ln", "relu", 0.2, "nd")
+    mols = batch["strs"]
+    with O.batch_statistics():
+        str_out = O.gin_forward(O._sub(enc, "str_encoder."), mols.node_feature, mols.edge_list, mols.edge_feature, mols.node2graph,
+                                mols.batch_size, num_layers=4, num_mlp_layer=3)["graph_feature"]
+        assert rel_err(e1, proj(str_out)) < tol                                   # view 1, all 2048 drugs
+        cv_out = O.mlp_encoder_forward(O._sub(enc, "cv_encoder."), batch["cv"], 2, None, "relu", 0.2)
+        sigs = torch.cat([batch["tx"][c]["sigs"] for c in D.CELL_LINES])
+        _, _, _, treated = O.chemcpa_predict(O._sub(enc, "tx_encoder."), sigs, torch.arange(16).repeat_interleave(B), 3, 3, with_decoder=False)
+        col = (~m2).float().argmax(dim=1)                                         # the one modality view 2 shows of each drug
+        mods = torch.stack([str_out, torch.zeros_like(str_out), cv_out] + list(treated.split(B)), dim=1)      # [B, 19, 128]; KG column unused
+        keep = col != 1
+        assert int(keep.sum()) > B // 4 and int((col == 2).sum()) > 50 and int((col >= 3).sum()) > 50
+        want2 = proj(mods[torch.arange(B), col][keep])
+        assert rel_err(e2[keep], want2) < tol                                     # view 2, every cv / tx drug
+        # predictors + InfoNCE at B = 2048 on the HIP side's views
+        r1 = O.simclr_predictor(O._sub(p, "predictor_1."), e1)
+        r2 = O.simclr_predictor(O._sub(p, "predictor_2."), e2)
+    assert rel_err(a1.cpu(), r1) < tol and rel_err(a2.cpu(), r2) < tol
+    logits, labels, loss_ref = O.info_nce(r1, r2, None, T)
+    assert tuple(lg.shape) == (2 * B, 2 * B - 1)
+    assert abs(float(loss) - float(loss_ref)) < 1e-4 * abs(float(loss_ref)), (float(loss), float(loss_ref))
+    assert rel_err(lg.cpu(), logits) < 10 * tol

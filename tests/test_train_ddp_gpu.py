@@ -52,37 +52,44 @@ def _worker(rank, world, port, ret, shard_kg=True):
         from madrigal_amd import models as M
         from madrigal_amd.optim import AdamW
         from madrigal_amd.train import FinetuneStep
-        n, L, seed = 101, 12, 21                       # odd drug count: uneven shards
+        n, L = 101, 12                                 # odd drug count: uneven shards
         M.set_precision("f32")
-        model, b, kgc, (lab, hd, tl, y), filler = _build(seed, n, L)
-        fs = FinetuneStep(model, AdamW(model.parameters(), lr=1e-4, weight_decay=0.0), rank=rank, world=world, shard_kg=shard_kg)
-        model.zero_grad(set_to_none=True)
-        loss = fs.accumulate(b, b, b["masks"], b["masks"], kgc, lab, hd, tl, y, kg_filler=filler)
-        from madrigal_amd.parallel import allreduce_gradients
-        allreduce_gradients(model.parameters())
-        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
-        bufs = {k: v.detach().clone() for k, v in model.named_buffers() if "running" in k}
-        # the same step in one process (fresh identical model)
-        ref, b2, kgc2, _, _ = _build(seed, n, L)
-        fs1 = FinetuneStep(ref, AdamW(ref.parameters(), lr=1e-4, weight_decay=0.0))
-        ref.zero_grad(set_to_none=True)
-        loss1 = fs1.accumulate(b2, b2, b2["masks"], b2["masks"], kgc2, lab, hd, tl, y, kg_filler=filler)
-        worst, worst2 = (0.0, ""), (0.0, "")
-        gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
-        for k, p in ref.named_parameters():
-            if p.grad is None:
-                continue
-            err = float((grads[k] - p.grad).abs().max()) / max(float(p.grad.abs().max()), 1e-2 * gmax)
-            worst = max(worst, (err, k))
-            # per tensor in the 2-norm: a ReLU whose pre-activation sits at rounding distance of zero flips its derivative when the
-            # SyncBatchNorm sums are formed in another order (three ranks instead of one) and moves a handful of entries by percents
-            l2 = float((grads[k] - p.grad).norm()) / max(float(p.grad.norm()), 1e-3 * gmax * p.grad.numel() ** 0.5)
-            worst2 = max(worst2, (l2, k))
-        worst = (worst[0], worst[1], worst2)
-        berr = max(float((bufs[k] - v).abs().max()) / max(float(v.abs().max()), 1e-6) for k, v in ref.named_buffers() if "running" in k)
-        kg_l2 = max(float((grads[k] - p.grad).norm()) / max(float(p.grad.norm()), 1e-30) for k, p in ref.named_parameters() if p.grad is not None and "kg_encoder" in k)
-        worst = worst + (("kg_encoder worst l2", kg_l2),)
-        ret[rank] = (abs(float(loss) - float(loss1)) / abs(float(loss1)), worst, berr, len(grads))
+        tried = []
+        # seeds in turn until one step has no ReLU at rounding distance of zero (tests/helpers.first_clean_seed explains; here the
+        # loop lives inside the ranks so that the process group is set up once)
+        for seed in (21, 22, 23, 24):
+            model, b, kgc, (lab, hd, tl, y), filler = _build(seed, n, L)
+            fs = FinetuneStep(model, AdamW(model.parameters(), lr=1e-4, weight_decay=0.0), rank=rank, world=world, shard_kg=shard_kg)
+            model.zero_grad(set_to_none=True)
+            loss = fs.accumulate(b, b, b["masks"], b["masks"], kgc, lab, hd, tl, y, kg_filler=filler)
+            from madrigal_amd.parallel import allreduce_gradients
+            allreduce_gradients(model.parameters())
+            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+            bufs = {k: v.detach().clone() for k, v in model.named_buffers() if "running" in k}
+            # the same step in one process (fresh identical model)
+            ref, b2, kgc2, _, _ = _build(seed, n, L)
+            fs1 = FinetuneStep(ref, AdamW(ref.parameters(), lr=1e-4, weight_decay=0.0))
+            ref.zero_grad(set_to_none=True)
+            loss1 = fs1.accumulate(b2, b2, b2["masks"], b2["masks"], kgc2, lab, hd, tl, y, kg_filler=filler)
+            worst, worst2 = (0.0, ""), (0.0, "")
+            gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+            for k, p in ref.named_parameters():
+                if p.grad is None:
+                    continue
+                err = float((grads[k] - p.grad).abs().max()) / max(float(p.grad.abs().max()), 1e-2 * gmax)
+                worst = max(worst, (err, k))
+                # per tensor in the 2-norm: a ReLU whose pre-activation sits at rounding distance of zero flips its derivative when the
+                # SyncBatchNorm sums are formed in another order (three ranks instead of one) and moves a handful of entries by percents
+                l2 = float((grads[k] - p.grad).norm()) / max(float(p.grad.norm()), 1e-3 * gmax * p.grad.numel() ** 0.5)
+                worst2 = max(worst2, (l2, k))
+            worst = (worst[0], worst[1], worst2)
+            berr = max(float((bufs[k] - v).abs().max()) / max(float(v.abs().max()), 1e-6) for k, v in ref.named_buffers() if "running" in k)
+            kg_l2 = max(float((grads[k] - p.grad).norm()) / max(float(p.grad.norm()), 1e-30) for k, p in ref.named_parameters() if p.grad is not None and "kg_encoder" in k)
+            worst = worst + (("kg_encoder worst l2", kg_l2),)
+            tried.append((seed, abs(float(loss) - float(loss1)) / abs(float(loss1)), worst, berr, len(grads)))
+            if worst[0] < 2e-3 and worst[2][0] < 5e-3:          # (identical on every rank: the gradients are all-reduced)
+                break
+        ret[rank] = tried
     finally:
         dist.destroy_process_group()
 
@@ -103,15 +110,18 @@ def test_two_rank_finetune_step_equals_single_process_step(world, shard_kg):
         p.join(600)
         assert p.exitcode == 0
     for r in range(world):
-        lerr, worst, berr, n_grads = ret[r]
-        assert lerr < 1e-5, (r, lerr)
-        # fp32 summation order + ReLU flips at rounding distance: at three ranks one structure-encoder pre-activation flips (the
-        # replicated and the partitioned KG variants show the identical 2.4 % / 1.1 % on the same GIN tensor), so the structure
-        # encoder gets the looser bound there; the KG encoder's own gradients agree to 4e-6 in either variant
-        assert worst[0] < (2e-3 if world == 2 else 5e-2) and worst[2][0] < (5e-3 if world == 2 else 2e-2), (r, worst)
-        assert worst[3][1] < 1e-4, (r, worst)
-        assert berr < 1e-4, (r, berr)                # BatchNorm running statistics = full-batch statistics on every rank
-        assert n_grads > 150
+        tried = ret[r]
+        for seed, lerr, worst, berr, n_grads in tried:
+            assert lerr < 1e-5, (r, seed, lerr)
+            # every seed: fp32 summation order + at most a ReLU flipped at rounding distance (a whole row of a structure-encoder
+            # weight gradient moves by one atom's contribution; an error of the exchange would show on every seed and far above)
+            assert worst[0] < 5e-2 and worst[2][0] < 2e-2, (r, seed, worst)
+            assert worst[3][1] < 1e-4, (r, seed, worst)    # the KG encoder's own gradients: 4e-6 in either variant
+            assert berr < 1e-4, (r, seed, berr)            # BatchNorm running statistics = full-batch statistics on every rank
+            assert n_grads > 150
+        # the last seed tried is flip-free and held to the strict bound at ANY world size (round 3 allowed 5e-2 at three ranks)
+        seed, lerr, worst, berr, n_grads = tried[-1]
+        assert worst[0] < 2e-3 and worst[2][0] < 5e-3, (r, tried)
 
 
 def _pretrain_worker(rank, world, port, ret):
