@@ -283,6 +283,21 @@ int mdg_rank_normalize_keys_ld(const uint32_t* keys, int64_t ldk, float* out, in
  * x_k <= 0.  inputs_host is a HOST array of K device pointers (16-byte aligned); n = elements of each tensor. */
 int mdg_gmean(const float* const* inputs_host, int K, float* out, int64_t n, void* stream);
 
+/* Parameter space of the HGT conv in training (PyG 2.3 HGTConv, madrigal/models/models.py:76-79,90-94): the composite projection
+ * weights of every projected node type from the live parameters -- rows [Wq_t | K_r V_r for every used relation r leaving t] with
+ * K_r = blockdiag_h(k_rel[h,r]^T p_rel[r][h] / sqrt(D)) Wk_t, V_r = blockdiag_h(v_rel[h,r]^T) Wv_t (biases likewise) -- and the
+ * gradients of kqv_lin / k_rel / v_rel / p_rel from the gradient of those rows.  w_ptrs / b_ptrs: DEVICE arrays of n_types float
+ * pointers (kqv weight [3F,cin], rows K | Q | V; bias [3F]); p_ptrs: device array of n_edge_types pointers ([heads] each); rel_*:
+ * per used relation its edge type, its source type (index into w_ptrs) and the first row of its K block in big_w (V block: + F);
+ * type_row: first row of each type's block.  bwd writes grads = [per type: dW (3F x cin) | db (3F)] | dk_rel | dv_rel | dp_rel
+ * [n_edge_types, heads] (zero for unused relations).  Exact fp32, fixed summation order. */
+int mdg_hgt_composite_fwd(const void* w_ptrs, const void* b_ptrs, const float* k_rel, const float* v_rel, const void* p_ptrs, const int* rel_r,
+                          const int* rel_src, const int* rel_row, int n_rel, const int* type_row, int n_types, float* big_w, float* big_b,
+                          int cin, int heads, int n_edge_types, int F, void* stream);
+int mdg_hgt_composite_bwd(const void* w_ptrs, const void* b_ptrs, const float* k_rel, const float* v_rel, const void* p_ptrs, const int* rel_r,
+                          const int* rel_src, const int* rel_row, int n_rel, const int* type_row, int n_types, const float* dbig_w,
+                          const float* dbig_b, float* grads, int cin, int heads, int n_edge_types, int F, void* stream);
+
 /* mdg_hgt_attention that also returns the softmax statistics stats [n_dst, heads, 2] = (max logit, denominator) the
  * backward pass needs; and that backward pass.  dout is the gradient at the attention output BEFORE the activation
  * (call the forward with apply_gelu = 0 and differentiate the activation separately), out_pre that forward output.

@@ -903,6 +903,62 @@ class _HgtProjectRows(Function):
         return (None, None, None, None, dw, db, *dxs)
 
 
+class _HgtComposite(Function):
+    """Composite projection weights of all projected node types of an HGT conv from the live parameters, and the parameter
+    gradients from the gradient of those rows: mdg_hgt_composite_fwd / _bwd (csrc/hgt_params.hip).  args: meta (dict of device
+    index tables + sizes, built once per conv and relation set), k_rel.weight, v_rel.weight, then the kqv weights of the projected
+    types, their biases, and the p_rel parameter of EVERY edge type (in edge-type order).  -> big_w [rows,in], big_b [rows].
+    Every parameter's gradient is a fresh view of one flat buffer (no accumulation inside: a conv's parameters enter once)."""
+
+    @staticmethod
+    def forward(ctx, meta, k_rel, v_rel, *params):
+        nt, R = meta["n_types"], meta["n_edge_types"]
+        ws, bs, ps = params[:nt], params[nt:2 * nt], params[2 * nt:]
+        assert len(ps) == R
+        for t in (k_rel, v_rel, *params):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError("hgt_composite: contiguous fp32 GPU parameters expected")
+        ptr_key = tuple(t.data_ptr() for t in params)
+        if meta.get("ptr_key") != ptr_key:                  # parameter storage moved (.to(), load_state_dict keeps it): rebuild the pointer tables
+            pin = torch.tensor(ptr_key, dtype=torch.int64).pin_memory()
+            meta["ptrs"] = pin.to(k_rel.device, non_blocking=True)
+            meta["ptr_key"], meta["ptr_pin"] = ptr_key, pin
+        ptrs = meta["ptrs"]
+        rows, cin = meta["rows"], meta["cin"]
+        big_w = torch.empty((rows, cin), dtype=torch.float32, device=k_rel.device)
+        big_b = torch.empty(rows, dtype=torch.float32, device=k_rel.device)
+        ops.hgt_composite(ptrs, k_rel, v_rel, meta, big_w, big_b)
+        ctx.meta = meta
+        ctx.save_for_backward(k_rel, v_rel, *params)
+        return big_w, big_b
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dbig_w, dbig_b):
+        meta = ctx.meta
+        k_rel, v_rel = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        params = ctx.saved_tensors[2:]
+        nt, R, F, H, cin = meta["n_types"], meta["n_edge_types"], meta["F"], meta["H"], meta["cin"]
+        D = F // H
+        per_type = 3 * F * cin + 3 * F
+        rel = H * R * D * D
+        flat = torch.empty(nt * per_type + 2 * rel + R * H, dtype=torch.float32, device=k_rel.device)
+        dbig_w = dbig_w if dbig_w.is_contiguous() else dbig_w.contiguous()
+        dbig_b = dbig_b if dbig_b.is_contiguous() else dbig_b.contiguous()
+        ops.hgt_composite_bwd(meta["ptrs"], k_rel, v_rel, meta, dbig_w, dbig_b, flat)
+        gw = [flat[i * per_type: i * per_type + 3 * F * cin].view(3 * F, cin) for i in range(nt)]
+        gb = [flat[i * per_type + 3 * F * cin: (i + 1) * per_type] for i in range(nt)]
+        base = nt * per_type
+        gk = flat[base: base + rel].view(H * R, D, D)
+        gv = flat[base + rel: base + 2 * rel].view(H * R, D, D)
+        gp = [flat[base + 2 * rel + r * H: base + 2 * rel + (r + 1) * H].view(params[2 * nt + r].shape) for r in range(R)]
+        return (None, gk, gv, *gw, *gb, *gp)
+
+
+def hgt_composite(meta, k_rel, v_rel, ws, bs, ps):
+    return _HgtComposite.apply(meta, k_rel, v_rel, *ws, *bs, *ps)
+
+
 def hgt_project_rows(layout, total_floats, precision, xs, big_w, big_b, offs):
     return _HgtProjectRows.apply(tuple(layout), total_floats, precision, tuple(offs), big_w, big_b, *xs)
 

@@ -596,6 +596,37 @@ class HGTConv(nn.Module):
         big_b = torch.cat([bq.reshape(-1), torch.stack([bK, bV], dim=1).reshape(-1)], 0).index_select(0, perm)
         return big_w, big_b, offs
 
+    def _composite_all_hip(self, types, plan: dict):
+        """``_composite_all_train`` as ONE autograd node over two kernels (autograd._HgtComposite, csrc/hgt_params.hip): the composite
+        rows q | k'_r v'_r ... of all projected types from the live kqv_lin / k_rel / v_rel / p_rel, their gradients from the rows'
+        gradient.  -> (W [rows,in], b [rows], first row per type)."""
+        F = self.out_channels
+        lins = [self.kqv_lin.lins[t] for t in types]
+        cin = lins[0].weight.shape[1]
+        dev = self.k_rel.weight.device
+        key = ("hip", tuple(types), tuple(plan["used"]))
+        meta = self.__dict__.setdefault("_rel_idx", {}).get(key)
+        if meta is None or meta["rel_r"].device != dev:
+            rel_r, rel_src, rel_row, type_row, offs, row = [], [], [], [], [], 0
+            for i, t in enumerate(types):
+                offs.append(row)
+                type_row.append(row)
+                row += F
+                for e in plan["used"]:
+                    if e[0] == t:
+                        rel_r.append(self.edge_types.index(e))
+                        rel_src.append(i)
+                        rel_row.append(row)
+                        row += 2 * F
+            offs.append(row)
+            i32 = lambda v: torch.tensor(v if v else [0], dtype=torch.int32, device=dev)
+            meta = dict(rel_r=i32(rel_r), rel_src=i32(rel_src), rel_row=i32(rel_row), type_row=i32(type_row), n_rel=len(rel_r), n_types=len(types),
+                        n_edge_types=len(self.edge_types), rows=row, cin=int(cin), F=F, H=self.heads, offs=offs)
+            self.__dict__["_rel_idx"][key] = meta
+        ps = [self.p_rel["__".join(et)] for et in self.edge_types]
+        big_w, big_b = ag.hgt_composite(meta, self.k_rel.weight, self.v_rel.weight, [l.weight for l in lins], [l.bias for l in lins], ps)
+        return big_w, big_b, meta["offs"]
+
     def _forward_train(self, x_dict, edge_index_dict, needed_types=None, shard=None):
         """Differentiated pass on the same flat projection layout as inference: one composite GEMM per node type writes
         q | k'_r v'_r ... into the flat buffer (ag.hgt_project), edge attention of all destination types reads queries, keys
@@ -622,7 +653,8 @@ class HGTConv(nn.Module):
         spec = dict(zip(types, layout))
         xs = [x_dict[t].float() for t in types]
         if types and len({x.shape[1] for x in xs}) == 1 and os.environ.get("MDG_HGT_BATCHED_WEIGHTS", "1") != "0":
-            big_w, big_b, offs = self._composite_all_train(types, plan)
+            # (MDG_HGT_COMPOSITE_TORCH=1: the same rows assembled with ~30 torch ops and torch's autograd, rounds 2-3; kept as the test's reference)
+            big_w, big_b, offs = (self._composite_all_train if os.environ.get("MDG_HGT_COMPOSITE_TORCH", "0") == "1" else self._composite_all_hip)(types, plan)
             flat = ag.hgt_project_rows(layout, plan["total_floats"], _state["precision"], xs, big_w, big_b, offs)
         else:                                                         # node types of different input width: one weight each
             mk_all, mv_all = self._relation_blocks_train()

@@ -734,6 +734,24 @@ def rank_normalize(scores: torch.Tensor, out: Optional[torch.Tensor] = None, max
     return out
 
 
+def _hgt_composite_args(ptrs, k_rel, v_rel, meta):
+    nt, R = meta["n_types"], meta["n_edge_types"]
+    base = ptrs.data_ptr()
+    return (_vp(base), _vp(base + 8 * nt), _ptr(k_rel), _ptr(v_rel), _vp(base + 16 * nt), _ptr(meta["rel_r"]), _ptr(meta["rel_src"]), _ptr(meta["rel_row"]),
+            _c(meta["n_rel"]), _ptr(meta["type_row"]), _c(nt))
+
+
+def hgt_composite(ptrs: torch.Tensor, k_rel, v_rel, meta: dict, big_w, big_b) -> None:
+    """mdg_hgt_composite_fwd (autograd._HgtComposite): ``ptrs`` = device int64 table [kqv weights | kqv biases | p_rel of every edge type]."""
+    check(lib().mdg_hgt_composite_fwd(*_hgt_composite_args(ptrs, k_rel, v_rel, meta), _ptr(big_w), _ptr(big_b), _c(meta["cin"]), _c(meta["H"]),
+                                      _c(meta["n_edge_types"]), _c(meta["F"]), _stream(big_w)), "mdg_hgt_composite_fwd")
+
+
+def hgt_composite_bwd(ptrs: torch.Tensor, k_rel, v_rel, meta: dict, dbig_w, dbig_b, grads) -> None:
+    check(lib().mdg_hgt_composite_bwd(*_hgt_composite_args(ptrs, k_rel, v_rel, meta), _ptr(dbig_w), _ptr(dbig_b), _ptr(grads), _c(meta["cin"]), _c(meta["H"]),
+                                      _c(meta["n_edge_types"]), _c(meta["F"]), _stream(grads)), "mdg_hgt_composite_bwd")
+
+
 def gmean(tensors) -> torch.Tensor:
     """Elementwise geometric mean of up to 8 equally shaped fp32 tensors (5-seed rank ensembling).  Row-pitched rank tensors
     (``empty_scores``) of one pitch are averaged in place of their padded storage: the result has the same layout."""

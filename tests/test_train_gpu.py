@@ -617,13 +617,16 @@ def test_chemcpa_predict_training_gradients_match_torch():
 
 
 # ---------------------------------------------------------------------------------------------- KG encoder
-@pytest.mark.parametrize("only_drug,batched", [(False, "1"), (True, "1"), (False, "0")])
+@pytest.mark.parametrize("only_drug,batched", [(False, "1"), (True, "1"), (False, "0"), (False, "torch"), (True, "torch")])
 def test_hgt_training_gradients_match_oracle_autograd(only_drug, batched, monkeypatch):
     """The oracle's HGT restatement is written on torch ops: in float64 with parameters that require grad it is its own
     autograd reference (PyG 2.3.1 is not in the image: the formula, not the wheel, is what is pinned here).  ``batched``:
-    composite projection weights of all node types built at once (default) or one node type at a time."""
+    composite projection weights of all node types built at once -- "1": by the two kernels of csrc/hgt_params.hip (default; every
+    gradient of kqv_lin / k_rel / v_rel / p_rel comes out of mdg_hgt_composite_bwd), "torch": by the ~30 torch ops of rounds 2-3 and
+    torch's autograd -- or one node type at a time ("0")."""
     from madrigal_amd import data, models as M
-    monkeypatch.setenv("MDG_HGT_BATCHED_WEIGHTS", batched)
+    monkeypatch.setenv("MDG_HGT_BATCHED_WEIGHTS", "0" if batched == "0" else "1")
+    monkeypatch.setenv("MDG_HGT_COMPOSITE_TORCH", "1" if batched == "torch" else "0")
     from oracle import madrigal_oracle as O
     torch.manual_seed(7)
     kg = data.make_kg(60, seed=4, n_nodes=700, n_edges=9000, n_node_types=5, n_rel_pairs=6)
