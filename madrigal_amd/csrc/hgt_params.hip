@@ -33,20 +33,9 @@ struct HgtCompositeArgs {
   int n_rel, n_types, cin, H, R, F;
 };
 
-// LDS image of one relation's matrices for all heads: m[h][a][b] (K: scaled by p_rel / sqrt(D))
-__device__ __forceinline__ void load_rel(const HgtCompositeArgs& A, int g, int kv, float* m) {
-  const int D = A.F / A.H, r = A.rel_r[g];
-  const float* rel = kv ? A.v_rel : A.k_rel;
-  for (int e = threadIdx.x; e < A.H * D * D; e += HP_TPB) {
-    const int h = e / (D * D);
-    const float s = kv ? 1.0f : A.p[r][h] / sqrtf(static_cast<float>(D));
-    m[e] = rel[(static_cast<int64_t>(h) * A.R + r) * D * D + (e - h * D * D)] * s;
-  }
-}
-
-// grid: n_types (Wq copies) + 2 * n_rel (K / V blocks)
+// grid: n_types (Wq copies) + 2 * H * n_rel (K / V blocks, one head each)
 __global__ __launch_bounds__(HP_TPB) void hgt_composite_fwd_kernel(const HgtCompositeArgs A, float* __restrict__ big_w, float* __restrict__ big_b) {
-  extern __shared__ float m[];                                    // [H][D][D]
+  extern __shared__ float m[];                                    // one head's [D][D] relation matrix
   const int F = A.F, cin = A.cin, D = F / A.H;
   const int job = blockIdx.x;
   if (job < A.n_types) {
@@ -57,31 +46,35 @@ __global__ __launch_bounds__(HP_TPB) void hgt_composite_fwd_kernel(const HgtComp
     for (int e = threadIdx.x; e < F; e += HP_TPB) big_b[A.type_row[job] + e] = b[e];
     return;
   }
-  const int g = (job - A.n_types) >> 1, kv = (job - A.n_types) & 1;
-  load_rel(A, g, kv, m);
+  const int j = job - A.n_types;
+  const int g = j / (2 * A.H), kv = (j / A.H) & 1, h = j % A.H, r = A.rel_r[g];
+  {
+    const float* rel = kv ? A.v_rel : A.k_rel;
+    const float sc = kv ? 1.0f : A.p[r][h] / sqrtf(static_cast<float>(D));
+    for (int e = threadIdx.x; e < D * D; e += HP_TPB) m[e] = rel[(static_cast<int64_t>(h) * A.R + r) * D * D + e] * sc;      // m[a][b]
+  }
   __syncthreads();
   const int src = A.rel_src[g];
-  const float* w = A.w[src] + (kv ? 2 : 0) * static_cast<int64_t>(F) * cin;      // K rows (0) or V rows (2F)
-  const float* b = A.b[src] + (kv ? 2 : 0) * F;
-  const int row0 = A.rel_row[g] + kv * F;
-  for (int o = threadIdx.x; o < F * (cin + 1); o += HP_TPB) {
-    const int row = o / (cin + 1), c = o - row * (cin + 1);
-    const int h = row / D, bb = row - h * D;
-    const float* mh = m + (h * D) * D + bb;                        // m[h][a][bb], stride D over a
+  const float* w = A.w[src] + (kv ? 2 : 0) * static_cast<int64_t>(F) * cin + static_cast<int64_t>(h * D) * cin;      // K rows (0) or V rows (2F), head h
+  const float* b = A.b[src] + (kv ? 2 : 0) * F + h * D;
+  const int row0 = A.rel_row[g] + kv * F + h * D;
+  for (int o = threadIdx.x; o < D * (cin + 1); o += HP_TPB) {
+    const int bb = o / (cin + 1), c = o - bb * (cin + 1);
+    const float* mb = m + bb;                                      // m[a][bb], stride D over a
     float acc = 0.f;
     if (c < cin) {
-      const float* wc = w + static_cast<int64_t>(h * D) * cin + c;
-      for (int a = 0; a < D; ++a) acc += mh[a * D] * wc[static_cast<int64_t>(a) * cin];
-      big_w[static_cast<int64_t>(row0 + row) * cin + c] = acc;
+      const float* wc = w + c;
+      for (int a = 0; a < D; ++a) acc += mb[a * D] * wc[static_cast<int64_t>(a) * cin];
+      big_w[static_cast<int64_t>(row0 + bb) * cin + c] = acc;
     } else {
-      for (int a = 0; a < D; ++a) acc += mh[a * D] * b[h * D + a];
-      big_b[row0 + row] = acc;
+      for (int a = 0; a < D; ++a) acc += mb[a * D] * b[a];
+      big_b[row0 + bb] = acc;
     }
   }
 }
 
 // grads: [type i: dW (3F x cin) | db (3F)] x n_types | dk_rel [H R D D] | dv_rel [H R D D] | dp_rel [R H]   (rel part zeroed by the caller)
-// grid: n_types (Q rows: copies) + 2 H n_types (K / V rows of a type's weight gradient, one head each) + 2 * n_rel (relation matrices)
+// grid: n_types (Q rows: copies) + 2 H n_types (K / V rows of a type's weight gradient, one head each) + 2 H n_rel (relation matrices, one head each)
 __global__ __launch_bounds__(HP_TPB) void hgt_composite_bwd_kernel(const HgtCompositeArgs A, const float* __restrict__ dbig_w, const float* __restrict__ dbig_b,
                                                                    float* __restrict__ grads) {
   extern __shared__ float m[];                                    // one head's [D][D] relation matrix | HP_TPB partial sums
@@ -145,41 +138,38 @@ __global__ __launch_bounds__(HP_TPB) void hgt_composite_bwd_kernel(const HgtComp
     return;
   }
   job -= 2 * H * A.n_types;
-  // relation matrices: dM[h][a][b] = sum_c W[(h,a), c] dKV[(h,b), c] + bias[(h,a)] dbKV[(h,b)]
-  const int g = job >> 1, kv = job & 1;
+  // relation matrices, one head per job: dM[a][b] = sum_c W[(h,a), c] dKV[(h,b), c] + bias[(h,a)] dbKV[(h,b)]
+  const int g = job / (2 * H), kv = (job / H) & 1, h = job % H;
   const int r = A.rel_r[g], src = A.rel_src[g];
-  const float* w = A.w[src] + (kv ? 2 : 0) * static_cast<int64_t>(F) * cin;
-  const float* b = A.b[src] + (kv ? 2 : 0) * F;
-  const int row0 = A.rel_row[g] + kv * F;
+  const float* w = A.w[src] + (kv ? 2 : 0) * static_cast<int64_t>(F) * cin + static_cast<int64_t>(h * D) * cin;
+  const float* b = A.b[src] + (kv ? 2 : 0) * F + h * D;
+  const int row0 = A.rel_row[g] + kv * F + h * D;
   const int64_t rel_elems = static_cast<int64_t>(H) * A.R * D * D;
-  float* drel = grads + A.n_types * per_type + (kv ? rel_elems : 0);
+  float* drel = grads + A.n_types * per_type + (kv ? rel_elems : 0) + (static_cast<int64_t>(h) * A.R + r) * D * D;
   float* dp = grads + A.n_types * per_type + 2 * rel_elems;
-  float* part = m;                                                 // [HP_TPB] partial sums of dp
   const float inv = 1.0f / sqrtf(static_cast<float>(D));
+  const float ph = A.p[r][h];
+  const float* krel = A.k_rel + (static_cast<int64_t>(h) * A.R + r) * D * D;
   float psum = 0.f;
-  const int per_head = D * D, tph = HP_TPB / H;                    // threads per head: thread t works for head t / tph
-  const int h = threadIdx.x / tph, lt = threadIdx.x - h * tph;
-  for (int e = lt; e < per_head; e += tph) {
+  for (int e = threadIdx.x; e < D * D; e += HP_TPB) {
     const int a = e / D, bb = e - a * D;
-    const float* wr = w + static_cast<int64_t>(h * D + a) * cin;
-    const float* dk = dbig_w + static_cast<int64_t>(row0 + h * D + bb) * cin;
-    float s = b[h * D + a] * dbig_b[row0 + h * D + bb];
+    const float* wr = w + static_cast<int64_t>(a) * cin;
+    const float* dk = dbig_w + static_cast<int64_t>(row0 + bb) * cin;
+    float s = b[a] * dbig_b[row0 + bb];
     for (int c = 0; c < cin; ++c) s += wr[c] * dk[c];
-    const int64_t idx = (static_cast<int64_t>(h) * A.R + r) * per_head + e;
     if (kv) {
-      drel[idx] = s;
+      drel[e] = s;
     } else {
-      const float ph = A.p[r][h];
-      drel[idx] = s * ph * inv;
-      psum += s * A.k_rel[idx] * inv;
+      drel[e] = s * ph * inv;
+      psum += s * krel[e] * inv;
     }
   }
-  if (!kv) {
-    part[threadIdx.x] = psum;
+  if (!kv) {                                                       // dp_rel[r][h]: the workgroup's partial sums in thread order
+    m[threadIdx.x] = psum;
     __syncthreads();
-    if (lt == 0) {
+    if (threadIdx.x == 0) {
       float tot = 0.f;
-      for (int i = 0; i < tph; ++i) tot += part[h * tph + i];      // fixed order
+      for (int i = 0; i < HP_TPB; ++i) tot += m[i];
       dp[r * H + h] = tot;
     }
   }
@@ -202,7 +192,7 @@ extern "C" int mdg_hgt_composite_fwd(const void* w_ptrs, const void* b_ptrs, con
   const HgtCompositeArgs A{static_cast<const float* const*>(w_ptrs), static_cast<const float* const*>(b_ptrs), k_rel, v_rel, static_cast<const float* const*>(p_ptrs),
                            rel_r, rel_src, rel_row, type_row, n_rel, n_types, cin, heads, n_edge_types, F};
   const int D = F / heads;
-  hipLaunchKernelGGL(hgt_composite_fwd_kernel, dim3(static_cast<unsigned>(n_types + 2 * n_rel)), dim3(HP_TPB), static_cast<size_t>(heads) * D * D * 4,
+  hipLaunchKernelGGL(hgt_composite_fwd_kernel, dim3(static_cast<unsigned>(n_types + 2 * heads * n_rel)), dim3(HP_TPB), static_cast<size_t>(D) * D * 4,
                      static_cast<hipStream_t>(stream), A, big_w, big_b);
   MDG_CHECK_LAUNCH("mdg_hgt_composite_fwd");
   return MDG_OK;
@@ -221,7 +211,7 @@ extern "C" int mdg_hgt_composite_bwd(const void* w_ptrs, const void* b_ptrs, con
   const int64_t per_type = static_cast<int64_t>(3) * F * cin + 3 * F, rel_elems = static_cast<int64_t>(heads) * n_edge_types * D * D;
   (void)hipMemsetAsync(grads + n_types * per_type, 0, static_cast<size_t>(2 * rel_elems + static_cast<int64_t>(n_edge_types) * heads) * 4, st);   // unused relations: zero
   const size_t lds = static_cast<size_t>(D) * D * 4 > HP_TPB * 4 ? static_cast<size_t>(D) * D * 4 : HP_TPB * 4;
-  hipLaunchKernelGGL(hgt_composite_bwd_kernel, dim3(static_cast<unsigned>(n_types + 2 * heads * n_types + 2 * n_rel)), dim3(HP_TPB), lds, st, A, dbig_w, dbig_b, grads);
+  hipLaunchKernelGGL(hgt_composite_bwd_kernel, dim3(static_cast<unsigned>(n_types + 2 * heads * n_types + 2 * heads * n_rel)), dim3(HP_TPB), lds, st, A, dbig_w, dbig_b, grads);
   MDG_CHECK_LAUNCH("mdg_hgt_composite_bwd");
   return MDG_OK;
 }
