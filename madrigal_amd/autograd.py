@@ -709,12 +709,12 @@ class _GatherRows(Function):
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
         dout = dout if dout.is_contiguous() else dout.contiguous()
-        if ctx.n_rows <= 128:
+        if ctx.n_rows <= 128 and idx.numel() >= 4096 and bool((idx.numel() % 4) == 0):
             # a small table (the 16 cell lines) under 10^4..10^5 lookups: one workgroup per table row would add its rows one
             # after the other; as onehot(idx)^T dout the sum is the split-reduction weight-gradient kernel (exact fp32
             # matrix cores, the rows of a split in order, the splits in order: deterministic)
             onehot = torch.zeros((idx.numel(), ctx.n_rows), dtype=torch.float32, device=dout.device)
-            onehot.scatter_(1, idx.unsqueeze(1), 1.0)
+            onehot.scatter_(1, idx.clamp_min(0).unsqueeze(1), (idx >= 0).to(torch.float32).unsqueeze(1))     # (idx < 0: _GatherRowsOr's default rows)
             return ops.grad_weight(onehot, dout), None
         # the index tensor of an embedding lookup is fixed for a run (cell-line ids of the tx stack): its sort is kept per
         # (storage, version, table size); the entry holds the tensor, so the address cannot be recycled under it
@@ -726,7 +726,7 @@ class _GatherRows(Function):
             # back to the host, which would stall the launch queue in the middle of the backward pass)
             rowptr = torch.searchsorted(idx[order], torch.arange(ctx.n_rows + 1, device=idx.device))
             hit = (key, order.contiguous(), rowptr, idx)
-            while len(_gather_plan) >= 8:                 # a handful of lookup sites per model (head / tail side, views): oldest out
+            while len(_gather_plan) >= 48:                # a dozen lookup sites per side (cell-line ids, the drug-row glue of encode): oldest out
                 _gather_plan.pop(next(iter(_gather_plan)))
             _gather_plan[key] = hit
         order, rowptr = hit[1], hit[2]
@@ -735,6 +735,28 @@ class _GatherRows(Function):
 
 def gather_rows(table, idx):
     return _GatherRows.apply(table, idx)
+
+
+class _GatherRowsOr(Function):
+    """out[d] = table[idx[d]] where idx[d] >= 0, default[d] (a constant) elsewhere: the KG rows of a drug batch, filler rows for the
+    drugs that are not in the KG (madrigal/models/models.py:734-736 does it with an indexed assignment into a filler table and an
+    indexed read: torch's backward of that pair sorts and scatters).  Backward: _GatherRows' (the sorted-index plan skips idx < 0)."""
+
+    @staticmethod
+    def forward(ctx, table, idx, default):
+        ctx.save_for_backward(idx)
+        ctx.n_rows = table.shape[0]
+        got = table.index_select(0, idx.clamp_min(0))
+        return torch.where((idx >= 0).unsqueeze(1), got, default)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        return _GatherRows.backward(ctx, dout) + (None,)
+
+
+def gather_rows_or(table, idx, default):
+    return _GatherRowsOr.apply(table, idx, default)
 
 
 # ------------------------------------------------------------------------------------------- contrastive pretraining

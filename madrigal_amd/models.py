@@ -1612,6 +1612,14 @@ class NovelDDIEncoder(nn.Module):
               "live": self.transformer.live_token_plan(kpm, src) if (compact and nf > 0) else None,
               # rows of the cell-line-major tx stack whose (drug, cell line) signature exists
               "tx_rows": (~batch_masks[:, NUM_NON_TX_MODALITIES:]).t().reshape(-1).nonzero().flatten()}
+        if rows is not None:                                          # index lists of the training path's own gather nodes (encode)
+            ar = torch.arange(len(CELL_LINES), device=dev).unsqueeze(1) * n
+            mp["tx_rows_of_multi"] = (ar + rows.unsqueeze(0)).reshape(-1)             # rows of the [16 n, D] tx stack: (cell line, multi-modal drug)
+            mp["uni_flat"] = uni_col * n + uni_rows                                    # rows of [str | kg | cv | tx stack]: the single modality of a uni-modal drug
+            perm = torch.empty(n, dtype=torch.int64, device=dev)
+            perm[rows] = torch.arange(nf, device=dev)
+            perm[uni_rows] = nf + torch.arange(n_uni, device=dev)
+            mp["merge_perm"] = perm                                                    # drug d's row in [fused rows | uni-modal rows]
         self._plan_cache = (key, mp, batch_masks)
         return mp
 
@@ -1738,6 +1746,16 @@ class NovelDDIEncoder(nn.Module):
                     kg_valid = self.kg_encoder(kg_data.x_dict, kg_data.edge_index_dict, only_types=('drug',), **kg_kw)['drug']
                 if share is not None:
                     share[key] = kg_valid
+            if train:
+                # own gather node instead of torch's indexed assignment + indexed read (their backward sorts and scatters: rocprim
+                # launches in every step): src[d] = row of drug d in the KG encoder's output, -1 for drugs outside the KG
+                gkey = (kg_map.data_ptr(), kg_map._version, batch_drugs.data_ptr(), batch_drugs._version, int(filler.shape[0]))
+                hit = self.__dict__.get("_kg_gather")
+                if hit is None or hit[0] != gkey:
+                    pos = torch.full((int(filler.shape[0]),), -1, dtype=torch.int64, device=dev)
+                    pos[kg_map] = torch.arange(kg_map.numel(), device=dev)
+                    hit = self.__dict__["_kg_gather"] = (gkey, pos[batch_drugs].contiguous(), kg_map, batch_drugs)
+                return ag.gather_rows_or(kg_valid, hit[1], filler.to(dev)[batch_drugs])
             table = filler.to(dev).clone()
             table[kg_map] = kg_valid
             return table[batch_drugs]
@@ -1834,8 +1852,8 @@ class NovelDDIEncoder(nn.Module):
         elif train:
             s_, k_, c_, t_ = str_out, kg_out, cv_out, tx_out
             if rows is not None:                         # only multi-modal drugs enter the transformer (models.py:781-790)
-                s_, k_, c_ = (v.index_select(0, rows) for v in (s_, k_, c_))
-                t_ = t_.view(len(CELL_LINES), n, Dm).index_select(1, rows).reshape(-1, Dm)
+                s_, k_, c_ = (ag.gather_rows(v, rows) for v in (s_, k_, c_))
+                t_ = ag.gather_rows(t_, mp["tx_rows_of_multi"])      # rows c * n + rows[.] of the [16 n, D] stack, cell line by cell line
             plan = mp["live"] if compact else None
             tokens = ag.assemble_tokens(s_, k_, c_, t_, bottleneck=self.tx_bottleneck_tokens if nb > 0 else None,
                                         cls=self.cls if has_cls else None, pe=self.pos_encoder.table(train=True),
@@ -1851,6 +1869,17 @@ class NovelDDIEncoder(nn.Module):
             z_f = self.transformer(seq, fusion_mask=mp["kpm"], src_mask=mp["src"])
         if self.fusion != 'transformer_uni_proj':
             return z_f
+        if train:
+            # the same merge as below through own gather nodes (no indexed assignments: their backward sorts): the single available
+            # modality of a uni-modal drug is row uni_col * n + drug of [str | kg | cv | tx (cell line by cell line)]; the fused and the
+            # uni-modal rows, one after the other, are read back in drug order
+            parts = [z_f]
+            if mp["n_uni"] > 0:
+                uni = ag.gather_rows(torch.cat([str_out, kg_out, cv_out, tx_out], dim=0), mp["uni_flat"])
+                if self.normalize:
+                    uni = norm(uni)
+                parts.append(self.uni_fuser(uni))
+            return ag.gather_rows(torch.cat(parts, dim=0) if len(parts) > 1 else z_f, mp["merge_perm"])
         z = torch.empty((n, Dm), dtype=torch.float32, device=dev)
         z[rows] = z_f
         if mp["n_uni"] > 0:
