@@ -31,25 +31,24 @@ __global__ __launch_bounds__(256) void csr_aggregate_kernel(const float* __restr
   const bool act = c < F;
   const int64_t e0 = rowptr[v], e1 = rowptr[v + 1];
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  int64_t e = e0;
-  for (; e + 4 <= e1; e += 4) {           // 4 independent gathers in flight
+  // groups of 4 edges with 4 independent gathers in flight; the last (for a molecule's atoms: the only) group is PREDICATED instead
+  // of walked edge by edge: at degree ~2 the edge-by-edge tail was a chain of col -> row -> col -> row dependent loads per atom
+  // (round 3: 1.4 TB/s on the GIN aggregation); same summation order, absent edges add 0 * 0
+  for (int64_t e = e0; e < e1; e += 4) {
     int64_t s[4];
     float ww[4];
+    bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      s[u] = col ? col[e + u] : e + u;
-      ww[u] = w ? w[e + u] : 1.f;
+      ok[u] = e + u < e1;
+      s[u] = ok[u] ? (col ? col[e + u] : e + u) : 0;
+      ww[u] = ok[u] ? (w ? w[e + u] : 1.f) : 0.f;
     }
     f32x4 r[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) r[u] = act ? *reinterpret_cast<const f32x4*>(x + s[u] * ldx + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < 4; ++u) r[u] = (act && ok[u]) ? *reinterpret_cast<const f32x4*>(x + s[u] * ldx + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc += ww[u] * r[u];
-  }
-  for (; e < e1; ++e) {
-    const int64_t s = col ? col[e] : e;
-    const float ww = w ? w[e] : 1.f;
-    if (act) acc += ww * *reinterpret_cast<const f32x4*>(x + s * ldx + c);
   }
   if (mean) {
     const float cnt = static_cast<float>(e1 - e0);

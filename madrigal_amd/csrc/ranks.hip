@@ -46,6 +46,25 @@ __device__ __forceinline__ void tri_decode(int64_t p, int& i, int& j) {
   j = static_cast<int>(p - r * (r - 1) / 2);
 }
 
+struct TriWalk {                          // wave-uniform walk along the rows of the strict lower triangle, 64 positions per step
+  int wi, wj;
+  __device__ __forceinline__ void start(int64_t p, int64_t M) {
+    int i, j;
+    tri_decode(p < M ? p : M - 1, i, j);
+    wi = __builtin_amdgcn_readfirstlane(i);
+    wj = __builtin_amdgcn_readfirstlane(j);
+  }
+  __device__ __forceinline__ void lane_pos(int lane, int& i, int& j) const {
+    i = wi;
+    j = wj + lane;
+    while (j >= i) { j -= i; ++i; }
+  }
+  __device__ __forceinline__ void step() {
+    wj += 64;
+    while (wj >= wi) { wj -= wi; ++wi; }
+  }
+};
+
 // lanes of the wave that hold the same 8-bit digit as this lane (all 64 lanes take part)
 __device__ __forceinline__ uint64_t match_digit(uint32_t dg) {
   uint64_t peers = ~0ull;
@@ -302,12 +321,23 @@ __global__ __launch_bounds__(C::TPB) void scatter_kernel(const KIN* __restrict__
   __syncthreads();
   const int64_t seg = blockIdx.y, base = static_cast<int64_t>(blockIdx.x) * TILE;
   uint32_t key[ITEMS], pay[ITEMS], rk[ITEMS];
+  // payload = (i << 16) | j of the entry (round 4; rounds 1-3 carried the triangle index p and took a double-precision square root per
+  // key to get (i, j) back in the last pass): the first pass walks the triangle's rows once per wave, as the key extraction does
+  TriWalk tw;
+  if (FIRST) tw.start(base + wave * WSPAN, M);
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     const int64_t p = base + wave * WSPAN + k * 64 + lane;
     const bool valid = p < M;
     key[k] = valid ? static_cast<uint32_t>(keys_in[seg * M + p]) : 0xFFFFFFFFu;   // padding: digit 255 in every pass, behind every real key of the tile
-    pay[k] = valid ? (FIRST ? static_cast<uint32_t>(p) : pay_in[seg * M + p]) : NO_PAY;
+    if (FIRST) {
+      int i, j;
+      tw.lane_pos(lane, i, j);
+      pay[k] = valid ? ((static_cast<uint32_t>(i) << 16) | static_cast<uint32_t>(j)) : NO_PAY;
+      tw.step();
+    } else {
+      pay[k] = valid ? pay_in[seg * M + p] : NO_PAY;
+    }
   }
   uint32_t* const status_seg = offsets ? nullptr : status + seg * static_cast<int64_t>(nblk) * 256;
   if (!offsets) {                           // (uniform) look-back: count first, publish, count again with ranks
@@ -374,8 +404,7 @@ __global__ __launch_bounds__(C::TPB) void scatter_kernel(const KIN* __restrict__
     if (pp == NO_PAY) continue;
     const uint32_t g = gofs[(kk >> shift) & 255u] + static_cast<uint32_t>(idx);
     if constexpr (LAST) {
-      int i, j;
-      tri_decode(pp, i, j);
+      const int i = static_cast<int>(pp >> 16), j = static_cast<int>(pp & 0xFFFFu);
       const float v = static_cast<float>(static_cast<double>(g + 1u) / denom);
       o[static_cast<int64_t>(i) * ldo + j] = v;
       o[static_cast<int64_t>(j) * ldo + i] = v;
@@ -485,8 +514,7 @@ __global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const KIN* __restri
     if (pay[k] == NO_PAY) continue;
     const uint32_t dg = (key[k] >> SH) & 255u;
     key[k] = gbase[dg] + cnt[wave][dg] + rk[k];
-    int i, j;
-    tri_decode(pay[k], i, j);
+    const int i = static_cast<int>(pay[k] >> 16), j = static_cast<int>(pay[k] & 0xFFFFu);
     const int bi = i >> 7, bj = j >> 7;
     blk[k] = static_cast<uint32_t>(bi * (bi + 1) / 2 + bj);
     pay[k] = static_cast<uint32_t>(((i & 127) << 7) | (j & 127));
@@ -585,29 +613,10 @@ constexpr int MSD_BSH = 32, MSD_BREGION = 20480;   // shards of a block's pair r
                                                    // room: 1.25 x the 16384 pairs of a full 128 x 128 block, cut evenly (32 shards: 640 each, 512 +- 22 used)
 constexpr int MSD_TILE = 16384;           // keys per partition tile (1024 threads x 16)
 constexpr int MSD_TIE_LIMIT = 128;        // keys per fine bin ordered in place; more: LSD fallback
-constexpr int MSD_BUCKET_TPB = 1024;      // threads of the bucket sort (two workgroups per CU: 8 waves per SIMD hide the LDS round trips)
 constexpr int MSD_MAX_BLOCKS = 1536;      // output blocks per outcome on the fast path (3 per thread of the bucket sort)
 constexpr uint32_t MSD_F_SEG = 1u, MSD_F_TOTAL = 2u, MSD_F_TIES = 4u, MSD_F_BLOCK = 8u;      // why an outcome was handed back
 constexpr uint32_t MSD_SKIP = 0xFFFFFFFFu;
 
-struct TriWalk {                          // wave-uniform walk along the rows of the strict lower triangle, 64 positions per step
-  int wi, wj;
-  __device__ __forceinline__ void start(int64_t p, int64_t M) {
-    int i, j;
-    tri_decode(p < M ? p : M - 1, i, j);
-    wi = __builtin_amdgcn_readfirstlane(i);
-    wj = __builtin_amdgcn_readfirstlane(j);
-  }
-  __device__ __forceinline__ void lane_pos(int lane, int& i, int& j) const {
-    i = wi;
-    j = wj + lane;
-    while (j >= i) { j -= i; ++i; }
-  }
-  __device__ __forceinline__ void step() {
-    wj += 64;
-    while (wj >= wi) { wj -= wi; ++wi; }
-  }
-};
 
 // hist[(outcome * MSD_SH + workgroup % MSD_SH) * MSD_NC + top 14 bits of the key]
 __global__ __launch_bounds__(1024) void msd_hist_kernel(const float* __restrict__ scores, int64_t lds, uint32_t* __restrict__ hist, int N, int64_t M,
