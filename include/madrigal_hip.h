@@ -303,8 +303,10 @@ int mdg_hgt_composite_bwd(const void* w_ptrs, const void* b_ptrs, const float* k
  * (call the forward with apply_gelu = 0 and differentiate the activation separately), out_pre that forward output.
  * Reversed edge lists (built by the caller from col / the destination of each edge): the nnz edges stably sorted by
  * key row; t_edge[e'] = forward edge id, t_dst[e'] = its destination; the n_src_rows distinct key rows t_row are cut
- * into work items (t_item_begin/end, t_item_ptr [n_src_rows+1]).  dq [n_dst,128]; dkv has the layout of kv (lddkv =
- * 128: value rows follow key rows) and only the rows of this call's key rows are written — zero-fill it first. */
+ * into work items (t_item_begin/end, t_item_ptr [n_src_rows+1]; t_item_row [n_src_items] = index into t_row of each
+ * item's key row, or null: with it a key row of ONE item is written by the gather kernel itself, not through a partial).
+ * dq [n_dst,128]; dkv has the layout of kv (lddkv = 128: value rows follow key rows) and only the rows of this call's
+ * key rows are written — zero-fill it first. */
 int mdg_hgt_attention_stats(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const int64_t* col,
                             const int64_t* item_dst, const int64_t* item_begin, const int64_t* item_end, int64_t n_items,
                             const int64_t* item_ptr, float* out, int64_t ldo, int64_t n_dst, int heads, int64_t F,
@@ -315,8 +317,8 @@ int mdg_hgt_attention_bwd(const float* q, int64_t ldq, const float* kv, int64_t 
                           const int64_t* item_ptr, int64_t n_dst, const float* dout, int64_t lddo, const float* out_pre,
                           int64_t ldp, const float* stats, int heads, const int64_t* t_edge, const int64_t* t_dst,
                           const int64_t* t_item_begin, const int64_t* t_item_end, int64_t n_src_items,
-                          const int64_t* t_item_ptr, const int64_t* t_row, int64_t n_src_rows, float* dq, int64_t lddq,
-                          float* dkv, int64_t lddkv, void* workspace, size_t workspace_bytes, void* stream);
+                          const int64_t* t_item_ptr, const int64_t* t_row, int64_t n_src_rows, const int64_t* t_item_row,
+                          float* dq, int64_t lddq, float* dkv, int64_t lddkv, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------- gathered head (finetune step) ---- */
 /* train_ddi_batch.py:285-288 computes sigmoid(model(...)) [L,N,N] and reads T (label, head, tail) entries of it.  These

@@ -85,6 +85,9 @@ struct HgtArgs {
   int H;
   const int64_t* q_off;                 // optional: float offset of each destination's query row from q (destinations of several
                                         // node types, whose rows differ in width, in ONE launch); null: row dst at q + dst * ldq
+  // a destination with ONE work item (<= CHUNK edges: nearly all of them) is finished here - normalised, activated, its softmax
+  // statistics stored - instead of going through a partial that hgt_combine_kernel would only copy
+  const int64_t* item_ptr; float* out; int64_t ldo; float* stats; int apply_gelu;
 };
 
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]); }
@@ -150,9 +153,24 @@ __global__ __launch_bounds__(256) void hgt_attention_kernel(const HgtArgs p) {
     m = mn;
   }
   if (half == 0) {
+    const int h = sub / lph;
+    if (p.item_ptr[dst + 1] - p.item_ptr[dst] == 1) {          // the same arithmetic as hgt_combine_kernel over one partial
+      if (m == -INFINITY) l = 0.f;
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (l > 0.f) o = acc / (l + 1e-16f);
+      if (p.stats && sub % lph == 0) {
+        p.stats[(dst * p.H + h) * 2 + 0] = m;
+        p.stats[(dst * p.H + h) * 2 + 1] = l + 1e-16f;
+      }
+      if (p.apply_gelu) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = mdg_gelu(o[c]);
+      }
+      *reinterpret_cast<f32x4*>(p.out + dst * p.ldo + 4 * sub) = o;
+      return;
+    }
     *reinterpret_cast<f32x4*>(p.part_acc + item * 128 + 4 * sub) = acc;
     if (sub % lph == 0) {
-      const int h = sub / lph;
       p.part_ml[(item * p.H + h) * 2 + 0] = m;
       p.part_ml[(item * p.H + h) * 2 + 1] = l;
     }
@@ -167,6 +185,7 @@ __global__ __launch_bounds__(256) void hgt_combine_kernel(const float* __restric
   if (v >= n_dst) return;
   const int h = sub / (32 / H);
   const int64_t i0 = item_ptr[v], i1 = item_ptr[v + 1];
+  if (i1 - i0 == 1) return;                      // finished by hgt_attention_kernel itself
   float m = -INFINITY, l = 0.f;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int64_t it = i0; it < i1; ++it) {
@@ -214,6 +233,7 @@ struct HgtBwdArgs {
   float* edge_alpha; float* edge_da;    // [nnz,H]
   float* part_dq;                       // [n_items,128]
   int H;
+  const int64_t* item_ptr; float* dq; int64_t lddq;     // a destination with one work item writes its dq row itself
 };
 
 __global__ __launch_bounds__(256) void hgt_attention_bwd_edge_kernel(const HgtBwdArgs p) {
@@ -230,37 +250,67 @@ __global__ __launch_bounds__(256) void hgt_attention_bwd_edge_kernel(const HgtBw
   for (int o = lph >> 1; o > 0; o >>= 1) delta += __shfl_xor(delta, o, 64);
   const float m = p.stats[(dst * p.H + h) * 2], inv = 1.0f / p.stats[(dst * p.H + h) * 2 + 1];
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t e = e0 + half; e < e1; e += 2) {
-    const float* r = p.kv + p.col[e] * p.ldkv + 4 * sub;
-    const f32x4 k = *reinterpret_cast<const f32x4*>(r), v = *reinterpret_cast<const f32x4*>(r + 128);
-    float a = dot4(q, k), da = dot4(g, v);
-    for (int o = lph >> 1; o > 0; o >>= 1) {
-      a += __shfl_xor(a, o, 64);
-      da += __shfl_xor(da, o, 64);
+  // four edges of this half in flight (8 rows of k' | v'), as in the forward kernel; the sum keeps the edge order
+  for (int64_t e = e0 + half; e < e1; e += 8) {
+    bool ok[4];
+    const float* r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ok[u] = (e + 2 * u) < e1;
+      r[u] = p.kv + p.col[ok[u] ? e + 2 * u : e] * p.ldkv + 4 * sub;
     }
-    const float alpha = expf(a - m) * inv;
-    const float ds = alpha * (da - delta);
-    acc += ds * k;
-    if (sub % lph == 0) {
-      p.edge_alpha[e * p.H + h] = alpha;
-      p.edge_da[e * p.H + h] = ds;
+    f32x4 k[4], v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      k[u] = *reinterpret_cast<const f32x4*>(r[u]);
+      v[u] = *reinterpret_cast<const f32x4*>(r[u] + 128);
+    }
+    float a[4], da[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = dot4(q, k[u]);
+      da[u] = dot4(g, v[u]);
+    }
+    for (int o = lph >> 1; o > 0; o >>= 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] += __shfl_xor(a[u], o, 64);
+        da[u] += __shfl_xor(da[u], o, 64);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float alpha = expf(a[u] - m) * inv;
+      const float ds = alpha * (da[u] - delta);
+      if (ok[u]) {
+        acc += ds * k[u];
+        if (sub % lph == 0) {
+          p.edge_alpha[(e + 2 * u) * p.H + h] = alpha;
+          p.edge_da[(e + 2 * u) * p.H + h] = ds;
+        }
+      }
     }
   }
   f32x4 other;
 #pragma unroll
   for (int c = 0; c < 4; ++c) other[c] = __shfl_xor(acc[c], 32, 64);
-  if (half == 0) *reinterpret_cast<f32x4*>(p.part_dq + item * 128 + 4 * sub) = acc + other;
+  if (half == 0) {
+    const bool single = p.item_ptr[dst + 1] - p.item_ptr[dst] == 1;
+    *reinterpret_cast<f32x4*>((single ? p.dq + dst * p.lddq : p.part_dq + item * 128) + 4 * sub) = acc + other;
+  }
 }
 
 // out[v, 0:width] = sum of part[item, 0:width] over the items of row v, in item order; rows go to out + row_index[v]*ldo
-// (row_index null = v).  width = 128 (dq) or 256 (dk' | dv' = two consecutive kv rows).
+// (row_index null = v).  width = 128 (dq) or 256 (dk' | dv' = two consecutive kv rows).  skip_single: rows with exactly one
+// item were written by the kernel that produced the partials.
 __global__ __launch_bounds__(256) void hgt_sum_items_kernel(const float* __restrict__ part, const int64_t* __restrict__ item_ptr,
                                                             const int64_t* __restrict__ row_index, float* __restrict__ out, int64_t ldo,
-                                                            int64_t n_rows, int width) {
+                                                            int64_t n_rows, int width, int skip_single) {
   const int lpr = width / 4;                      // lanes per row: 32 or 64
   const int sub = threadIdx.x % lpr;
   const int64_t v = static_cast<int64_t>(blockIdx.x) * (256 / lpr) + threadIdx.x / lpr;
   if (v >= n_rows) return;
+  if (skip_single && item_ptr[v + 1] - item_ptr[v] == 1) return;       // written by the producing kernel
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int64_t it = item_ptr[v]; it < item_ptr[v + 1]; ++it) acc += *reinterpret_cast<const f32x4*>(part + it * width + 4 * sub);
   const int64_t row = row_index ? row_index[v] : v;
@@ -276,6 +326,8 @@ struct HgtSrcArgs {
   const float* edge_alpha; const float* edge_da;
   float* part;                                     // [n_items,256]: dk' | dv'
   int H;
+  // optional (item_row non-null): a key row with one work item writes dk' | dv' itself
+  const int64_t* item_row; const int64_t* item_ptr; const int64_t* rows; float* dkv; int64_t lddkv;
 };
 
 __global__ __launch_bounds__(256) void hgt_attention_bwd_src_kernel(const HgtSrcArgs p) {
@@ -284,11 +336,34 @@ __global__ __launch_bounds__(256) void hgt_attention_bwd_src_kernel(const HgtSrc
   if (item >= p.n_items) return;
   const int h = sub / (32 / p.H);
   f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t e = p.item_begin[item] + half; e < p.item_end[item]; e += 2) {
-    const int64_t eid = p.t_edge[e], d = p.t_dst[e];
-    const float da = p.edge_da[eid * p.H + h], al = p.edge_alpha[eid * p.H + h];
-    ak += da * *reinterpret_cast<const f32x4*>(p.q + d * p.ldq + 4 * sub);
-    av += al * *reinterpret_cast<const f32x4*>(p.g + d * p.ldg + 4 * sub);
+  const int64_t e1 = p.item_end[item];
+  // four reversed edges of this half in flight: each is an (edge id, destination) -> (alpha, da), q row, g row chain
+  for (int64_t e = p.item_begin[item] + half; e < e1; e += 8) {
+    bool in[4];
+    int64_t eid[4], d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      in[u] = (e + 2 * u) < e1;
+      const int64_t eu = in[u] ? e + 2 * u : e;
+      eid[u] = p.t_edge[eu];
+      d[u] = p.t_dst[eu];
+    }
+    float da[4], al[4];
+    f32x4 qr[4], gr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      da[u] = p.edge_da[eid[u] * p.H + h];
+      al[u] = p.edge_alpha[eid[u] * p.H + h];
+      qr[u] = *reinterpret_cast<const f32x4*>(p.q + d[u] * p.ldq + 4 * sub);
+      gr[u] = *reinterpret_cast<const f32x4*>(p.g + d[u] * p.ldg + 4 * sub);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (in[u]) {
+        ak += da[u] * qr[u];
+        av += al[u] * gr[u];
+      }
+    }
   }
   f32x4 ok, ov;
 #pragma unroll
@@ -297,8 +372,13 @@ __global__ __launch_bounds__(256) void hgt_attention_bwd_src_kernel(const HgtSrc
     ov[c] = __shfl_xor(av[c], 32, 64);
   }
   if (half == 0) {
-    *reinterpret_cast<f32x4*>(p.part + item * 256 + 4 * sub) = ak + ok;
-    *reinterpret_cast<f32x4*>(p.part + item * 256 + 128 + 4 * sub) = av + ov;
+    float* o = p.part + item * 256;
+    if (p.item_row) {
+      const int64_t v = p.item_row[item];
+      if (p.item_ptr[v + 1] - p.item_ptr[v] == 1) o = p.dkv + p.rows[v] * p.lddkv;
+    }
+    *reinterpret_cast<f32x4*>(o + 4 * sub) = ak + ok;
+    *reinterpret_cast<f32x4*>(o + 128 + 4 * sub) = av + ov;
   }
 }
 
@@ -357,7 +437,7 @@ extern "C" int mdg_hgt_attention_stats(const float* q, int64_t ldq, const float*
   float* part_acc = static_cast<float*>(workspace);
   float* part_ml = part_acc ? part_acc + n_items * 128 : nullptr;
   if (n_items > 0) {
-    HgtArgs a{q, ldq, kv, ldkv, col, item_dst, item_begin, item_end, part_acc, part_ml, n_items, heads, nullptr};
+    HgtArgs a{q, ldq, kv, ldkv, col, item_dst, item_begin, item_end, part_acc, part_ml, n_items, heads, nullptr, item_ptr, out, ldo, stats, apply_gelu};
     hipLaunchKernelGGL(hgt_attention_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_items, 4))), dim3(256), 0, st, a);
   }
   hipLaunchKernelGGL(hgt_combine_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_dst, 8))), dim3(256), 0, st, part_acc, part_ml, item_ptr,
@@ -395,7 +475,7 @@ extern "C" int mdg_hgt_attention_rows(const float* q_base, const int64_t* q_off,
   float* part_acc = static_cast<float*>(workspace);
   float* part_ml = part_acc ? part_acc + n_items * 128 : nullptr;
   if (n_items > 0) {
-    HgtArgs a{q_base, 0, kv, ldkv, col, item_dst, item_begin, item_end, part_acc, part_ml, n_items, heads, q_off};
+    HgtArgs a{q_base, 0, kv, ldkv, col, item_dst, item_begin, item_end, part_acc, part_ml, n_items, heads, q_off, item_ptr, out, ldo, nullptr, apply_gelu};
     hipLaunchKernelGGL(hgt_attention_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_items, 4))), dim3(256), 0, st, a);
   }
   hipLaunchKernelGGL(hgt_combine_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_dst, 8))), dim3(256), 0, st, part_acc, part_ml, item_ptr,
@@ -414,8 +494,8 @@ extern "C" int mdg_hgt_attention_bwd(const float* q, int64_t ldq, const float* k
                                      const int64_t* item_ptr, int64_t n_dst, const float* dout, int64_t lddo, const float* out_pre,
                                      int64_t ldp, const float* stats, int heads, const int64_t* t_edge, const int64_t* t_dst,
                                      const int64_t* t_item_begin, const int64_t* t_item_end, int64_t n_src_items,
-                                     const int64_t* t_item_ptr, const int64_t* t_row, int64_t n_src_rows, float* dq, int64_t lddq,
-                                     float* dkv, int64_t lddkv, void* workspace, size_t workspace_bytes, void* stream) {
+                                     const int64_t* t_item_ptr, const int64_t* t_row, int64_t n_src_rows, const int64_t* t_item_row,
+                                     float* dq, int64_t lddq, float* dkv, int64_t lddkv, void* workspace, size_t workspace_bytes, void* stream) {
   MDG_CHECK_ARG(heads == 1 || heads == 2 || heads == 4 || heads == 8, "mdg_hgt_attention_bwd: heads must be 1, 2, 4 or 8 (got %d)", heads);
   MDG_CHECK_ARG(n_dst >= 0 && n_items >= 0 && nnz >= 0 && n_src_items >= 0 && n_src_rows >= 0, "mdg_hgt_attention_bwd: negative size");
   if (n_dst == 0) return MDG_OK;
@@ -436,16 +516,16 @@ extern "C" int mdg_hgt_attention_bwd(const float* q, int64_t ldq, const float* k
     MDG_CHECK_ARG(kv && col && item_dst && item_begin && item_end && dkv && t_edge && t_dst && t_item_begin && t_item_end && t_item_ptr && t_row,
                   "mdg_hgt_attention_bwd: null plan pointer");
     MDG_CHECK_ARG(ldkv % 4 == 0 && lddkv % 4 == 0 && ldkv >= 128 && lddkv >= 128 && mdg_aligned16(kv) && mdg_aligned16(dkv), "mdg_hgt_attention_bwd: bad kv strides");
-    HgtBwdArgs a{q, ldq, kv, ldkv, col, item_dst, item_begin, item_end, n_items, dout, lddo, out_pre, ldp, stats, edge_alpha, edge_da, part_dq, heads};
+    HgtBwdArgs a{q, ldq, kv, ldkv, col, item_dst, item_begin, item_end, n_items, dout, lddo, out_pre, ldp, stats, edge_alpha, edge_da, part_dq, heads, item_ptr, dq, lddq};
     hipLaunchKernelGGL(hgt_attention_bwd_edge_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_items, 4))), dim3(256), 0, st, a);
   }
-  hipLaunchKernelGGL(hgt_sum_items_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_dst, 8))), dim3(256), 0, st, part_dq, item_ptr, nullptr, dq, lddq, n_dst, 128);
+  hipLaunchKernelGGL(hgt_sum_items_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_dst, 8))), dim3(256), 0, st, part_dq, item_ptr, nullptr, dq, lddq, n_dst, 128, 1);
   if (n_src_items > 0) {
-    HgtSrcArgs s{q, ldq, dout, lddo, t_edge, t_dst, t_item_begin, t_item_end, n_src_items, edge_alpha, edge_da, part_src, heads};
+    HgtSrcArgs s{q, ldq, dout, lddo, t_edge, t_dst, t_item_begin, t_item_end, n_src_items, edge_alpha, edge_da, part_src, heads, t_item_row, t_item_ptr, t_row, dkv, lddkv};
     hipLaunchKernelGGL(hgt_attention_bwd_src_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_src_items, 4))), dim3(256), 0, st, s);
     // dk' and dv' of key row r are rows r and r+1 of dkv (ldkv == 128 layout): written as one 256-float row
     hipLaunchKernelGGL(hgt_sum_items_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_src_rows, 4))), dim3(256), 0, st, part_src, t_item_ptr, t_row, dkv,
-                       lddkv, n_src_rows, 256);
+                       lddkv, n_src_rows, 256, t_item_row ? 1 : 0);
   }
   MDG_CHECK_LAUNCH("mdg_hgt_attention_bwd");
   return MDG_OK;

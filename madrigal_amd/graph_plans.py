@@ -88,7 +88,7 @@ def hgt_reverse_plan(pd: dict) -> dict:
     end = torch.minimum(begin + HGT_CHUNK, rptr[item_row + 1])
     pd["rev"] = {"t_edge": order.contiguous(), "t_dst": dst[order].contiguous(), "item_begin": begin.contiguous(),
                  "item_end": end.contiguous(), "item_ptr": item_ptr, "rows": rows.contiguous(), "n_rows": n_rows,
-                 "n_items": int(item_row.numel())}
+                 "n_items": int(item_row.numel()), "item_row": item_row.contiguous()}
     return pd["rev"]
 
 

@@ -1387,8 +1387,8 @@ def hgt_attention_bwd(q: torch.Tensor, kv: torch.Tensor, plan: dict, rev: dict, 
                                       _ptr(plan["item_begin"]), _ptr(plan["item_end"]), _c64(n_items), _ptr(plan["item_ptr"]), _c64(n_dst),
                                       _ptr(dout), _c64(dout.stride(0)), _ptr(out_pre), _c64(out_pre.stride(0)), _ptr(stats), _c(heads),
                                       _ptr(rev["t_edge"]), _ptr(rev["t_dst"]), _ptr(rev["item_begin"]), _ptr(rev["item_end"]),
-                                      _c64(rev["n_items"]), _ptr(rev["item_ptr"]), _ptr(rev["rows"]), _c64(rev["n_rows"]), _ptr(dq),
-                                      _c64(dq.stride(0)), _ptr(dkv), _c64(128), _ptr(ws), ctypes.c_size_t(nbytes), _stream(q)),
+                                      _c64(rev["n_items"]), _ptr(rev["item_ptr"]), _ptr(rev["rows"]), _c64(rev["n_rows"]), _ptr(rev.get("item_row")),
+                                      _ptr(dq), _c64(dq.stride(0)), _ptr(dkv), _c64(128), _ptr(ws), ctypes.c_size_t(nbytes), _stream(q)),
           "mdg_hgt_attention_bwd")
     return dq
 

@@ -297,3 +297,52 @@ def test_hgt_attention_heavy_tail(ops, heads):
     got_g = ops.hgt_attention(q.cuda(), kvd, plan["per_dst"]["b"], heads, apply_gelu=True).cpu()
     assert float((got_g - O._act("gelu", agg)).abs().max()) < 2e-5
     assert float(got[5].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("heads", [4, 8])
+def test_hgt_attention_backward_heavy_tail(ops, heads):
+    """dq / dk' / dv' of the edge attention against float64 autograd of the same formula: a destination with > CHUNK edges and a
+    key row with > CHUNK outgoing edges (several work items: partials summed in item order), rows with exactly one item (written
+    by the gather kernels themselves), an isolated destination, key rows nobody attends to (their gradient rows stay zero)."""
+    from madrigal_amd.graph_plans import HGT_CHUNK, hgt_plan, hgt_reverse_plan
+    g = torch.Generator().manual_seed(80)
+    n_src, n_dst = 500, 300
+    hub = 2 * HGT_CHUNK + 9
+    dst = torch.cat([torch.zeros(hub, dtype=torch.int64), torch.randint(2, n_dst, (hub,), generator=g), torch.randint(2, n_dst, (900,), generator=g),
+                     torch.tensor([1])])
+    src = torch.cat([torch.randint(0, n_src - 50, (hub,), generator=g), torch.full((hub,), 7), torch.randint(0, n_src - 50, (901,), generator=g)])
+    dst[dst == 5] = 6                                    # destination 5 has no edges; key rows n_src-50.. have none either
+    plan = hgt_plan({("a", "r", "b"): torch.stack([src, dst]).cuda()}, [("a", "r", "b")], {"a": n_src, "b": n_dst}, torch.device("cuda"))
+    pd = plan["per_dst"]["b"]
+    rev = hgt_reverse_plan(pd)
+    assert int((pd["item_ptr"][1:] - pd["item_ptr"][:-1]).max()) == 3 and int((rev["item_ptr"][1:] - rev["item_ptr"][:-1]).max()) == 3
+    q = _rand((n_dst, 128), 81)
+    proj = _rand((n_src, 384), 82)
+    dout = _rand((n_dst, 128), 83)
+    D = 128 // heads
+    q64 = q.double().requires_grad_(True)
+    kv64 = proj[:, 128:].double().requires_grad_(True)
+    a = (q64[dst].view(-1, heads, D) * kv64[src, :128].view(-1, heads, D)).sum(-1)
+    amax = torch.full((n_dst, heads), float("-inf"), dtype=torch.float64).scatter_reduce(0, dst[:, None].expand(-1, heads), a.detach(), reduce="amax")
+    e = torch.exp(a - amax[dst])
+    den = torch.zeros(n_dst, heads, dtype=torch.float64).index_add(0, dst, e)
+    alpha = e / (den[dst] + 1e-16)
+    agg = torch.zeros(n_dst, heads, D, dtype=torch.float64).index_add(0, dst, kv64[src, 128:].view(-1, heads, D) * alpha[..., None]).reshape(n_dst, 128)
+    (agg * dout.double()).sum().backward()
+    buf = torch.zeros(plan["total_floats"])
+    buf[: n_src * 384] = proj.flatten()
+    kvd = buf.cuda().view(-1, 128)
+    qd = q.cuda()
+    out, stats = ops.hgt_attention_stats(qd, kvd, pd, heads)
+    assert float((out.cpu() - agg.detach().float()).abs().max()) < 2e-5
+    dkv = torch.zeros_like(kvd)
+    dq = ops.hgt_attention_bwd(qd, kvd, pd, rev, heads, dout.cuda(), out, stats, dkv)
+    scale = float(q64.grad.abs().max())
+    assert float((dq.cpu() - q64.grad.float()).abs().max()) < 2e-5 * max(scale, 1.0)
+    got = dkv.view(-1)[: n_src * 384].view(n_src, 384).cpu()
+    assert float(got[:, :128].abs().max()) == 0.0                                  # the query slots are not this call's to write
+    assert float((got[:, 128:] - kv64.grad.float()).abs().max()) < 2e-5 * max(float(kv64.grad.abs().max()), 1.0)
+    assert float(got[n_src - 50:].abs().max()) == 0.0 and float(dq[5].abs().max()) == 0.0
+    dkv2 = torch.zeros_like(kvd)
+    dq2 = ops.hgt_attention_bwd(qd, kvd, pd, rev, heads, dout.cuda(), out, stats, dkv2)
+    assert torch.equal(dq, dq2) and torch.equal(dkv, dkv2)                         # no atomics: bit-reproducible
