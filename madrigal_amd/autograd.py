@@ -7,6 +7,7 @@ structure on the CPU (the reference's backward *is* torch autograd).
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -892,15 +893,16 @@ class _HgtProjectRows(Function):
         flat = torch.zeros(max(total_floats, 128), dtype=torch.float32, device=big_w.device)      # unprojected types stay zero
         big_w = big_w if big_w.is_contiguous() else big_w.contiguous()
         big_b = big_b if big_b.is_contiguous() else big_b.contiguous()
-        xs2 = []
-        for i, ((off, rows, width), x) in enumerate(zip(layout, xs)):
-            x2 = x if x.is_contiguous() else x.contiguous()
-            xs2.append(x2)
+        xs2 = [x if x.is_contiguous() else x.contiguous() for x in xs]
+        lanes = _type_lanes(flat, len(layout), chains=True)            # one GEMM per node type into disjoint rows of ``flat``
+        for i, ((off, rows, width), x2) in enumerate(zip(layout, xs2)):
             if offs[i + 1] - offs[i] != width:
                 raise ValueError("hgt_project_rows: weight rows disagree with the projection width")
             if rows:
-                ops.linear(x2, big_w[offs[i]:offs[i + 1]], big_b[offs[i]:offs[i + 1]], precision=precision,
-                           out=flat[off:off + rows * width].view(rows, width), cache_weight=False)
+                with lanes.lane(i):
+                    ops.linear(x2, big_w[offs[i]:offs[i + 1]], big_b[offs[i]:offs[i + 1]], precision=precision,
+                               out=flat[off:off + rows * width].view(rows, width), cache_weight=False)
+        lanes.join()
         ctx.layout, ctx.precision, ctx.offs = layout, precision, offs
         ctx.save_for_backward(big_w, *xs2)
         return flat.view(-1, 128)
@@ -914,14 +916,17 @@ class _HgtProjectRows(Function):
         dw = torch.empty_like(big_w)
         db = torch.empty(big_w.shape[0], dtype=torch.float32, device=big_w.device)
         dxs = []
+        lanes = _type_lanes(dflat, len(xs), chains=True)               # per type: dx, and its rows of dw / db (disjoint)
         for i, ((off, rows, width), x) in enumerate(zip(ctx.layout, xs)):
             g = dflat[off:off + rows * width].view(rows, width)
             w = big_w[offs[i]:offs[i + 1]]
             dx = None
-            if ctx.needs_input_grad[6 + i]:
-                dx = ops.linear(g, ops.transpose(w), precision=ctx.precision, cache_weight=False)[:, :x.shape[1]] if rows else torch.zeros_like(x)
-            ops.grad_weight(g, x, ctx.precision, want_bias=True, out=(dw[offs[i]:offs[i + 1]], db[offs[i]:offs[i + 1]]))
+            with lanes.lane(i):
+                if ctx.needs_input_grad[6 + i]:
+                    dx = ops.linear(g, ops.transpose(w), precision=ctx.precision, cache_weight=False)[:, :x.shape[1]] if rows else torch.zeros_like(x)
+                ops.grad_weight(g, x, ctx.precision, want_bias=True, out=(dw[offs[i]:offs[i + 1]], db[offs[i]:offs[i + 1]]))
             dxs.append(dx)
+        lanes.join(*dxs)
         return (None, None, None, None, dw, db, *dxs)
 
 
@@ -992,13 +997,23 @@ class _type_lanes:
     """The destination types of a conv are independent launches (every type reads the shared projection buffer and writes its own
     rows / its own relations' column blocks): they are dealt to a few side streams that fork from the current stream and join it
     again, so that the small types' kernels run beside the large ones instead of in a chain of launch gaps.  MDG_HGT_LANES=1 (or a
-    stream capture in progress, or a CPU tensor) keeps the plain loop."""
+    CPU tensor) keeps the plain loop.
+    Inside a stream capture (the KG pass replayed as hipGraphs, NovelDDIEncoder._kg_graphed) the fork / join become edges of the
+    graph: parallel branches cost the replay nothing, so there the per-type CHAINS of small launches (``chains=True``: one
+    projection GEMM per node type, a type's GELU / out_lin / gated residual, their backward) are dealt out too, on
+    MDG_HGT_CHAIN_LANES (2: measured best of 1-4) branches.  Eager launches pay an event round trip per fork and join, which costs the chains more
+    than their concurrency returns (finetune step 40.5 -> 41.5 ms): outside a capture ``chains`` keeps the plain loop."""
 
-    def __init__(self, ref: torch.Tensor, n_items: int):
-        import os
-        want = int(os.environ.get("MDG_HGT_LANES", "2"))
+    def __init__(self, ref: torch.Tensor, n_items: int, chains: bool = False):
+        capturing = ref.is_cuda and torch.cuda.is_current_stream_capturing()
+        if capturing and os.environ.get("MDG_HGT_LANES_IN_GRAPH", "1") == "0":
+            want = 1
+        elif chains:
+            want = int(os.environ.get("MDG_HGT_CHAIN_LANES", "2")) if (capturing and _bn_sync["reduce"] is None) else 1
+        else:
+            want = int(os.environ.get("MDG_HGT_LANES", "2"))
         self.cur = self.lanes = None
-        if ref.is_cuda and want > 1 and n_items > 1 and not torch.cuda.is_current_stream_capturing():
+        if ref.is_cuda and want > 1 and n_items > 1:
             self.cur = torch.cuda.current_stream(ref.device)
             key = (ref.device, self.cur.cuda_stream, want)
             if key not in _hgt_lanes:
@@ -1059,6 +1074,9 @@ class _HgtAttentionFlat(Function):
                 ops.hgt_attention_bwd(q, flat, pd, rev, ctx.heads, g, o, s, dflat, dq_out=dq)
         lanes.join()
         return dflat, None, None, None
+
+
+type_lanes = _type_lanes
 
 
 def hgt_attention_flat(flat, heads, plans, qspec):

@@ -669,11 +669,17 @@ class HGTConv(nn.Module):
             return (off + rng[t][0] * width, rng[t][1] - rng[t][0], width)
         pres = ag.hgt_attention_flat(flat, H, [plan["per_dst"][t] for t in dst_types], [block(t) for t in dst_types]) if dst_types else ()
         out = {}
-        for t, pre in zip(dst_types, pres):
+        # the destination types' output stages (GELU, out_lin, gated residual: a chain of small launches per type, and as many again
+        # in the backward pass, which autograd runs on the stream of the forward): parallel branches when the pass is being captured
+        # as a hipGraph (ag.type_lanes), a plain loop otherwise
+        lanes = ag.type_lanes(flat, len(dst_types) if dst_range is None else 1, chains=True)
+        for i, (t, pre) in enumerate(zip(dst_types, pres)):
             lin = self.out_lin.lins[t]
-            o = _linT(ag.activation(pre, "gelu"), lin.weight, lin.bias)
-            xr = x_dict[t].float()
-            out[t] = ag.gated_residual(o, xr[rng[t][0]:rng[t][1]] if dst_range is not None else xr, self.skip[t]) if x_dict[t].shape[-1] == F else o
+            with lanes.lane(i):
+                o = _linT(ag.activation(pre, "gelu"), lin.weight, lin.bias)
+                xr = x_dict[t].float()
+                out[t] = ag.gated_residual(o, xr[rng[t][0]:rng[t][1]] if dst_range is not None else xr, self.skip[t]) if x_dict[t].shape[-1] == F else o
+        lanes.join(*out.values())
         if dst_range is None:
             return out
         # one exchange step for every destination type (as the inference conv): each rank's blocks back to back, gathered with a

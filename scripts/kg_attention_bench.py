@@ -14,7 +14,7 @@ ap.add_argument("--precision", default="bf16")
 ap.add_argument("--reps", type=int, default=5)
 a = ap.parse_args()
 M.set_precision(a.precision)
-batch, bkg = D.make_batch(64, 0, kg_nodes=130000, kg_edges=8000000)
+batch, bkg = D.make_batch(4096, 0, kg_nodes=130000, kg_edges=8000000)      # (the KG holds the batch's drugs: the bench shape)
 torch.manual_seed(0)
 model = configs.build_model("twosides321", bkg["data"], 8).cuda().train()
 kg = bkg["data"].to("cuda")
