@@ -306,11 +306,11 @@ int mdg_hgt_composite_bwd(const void* w_ptrs, const void* b_ptrs, const float* k
  * into work items (t_item_begin/end, t_item_ptr [n_src_rows+1]; t_item_row [n_src_items] = index into t_row of each
  * item's key row, or null: with it a key row of ONE item is written by the gather kernel itself, not through a partial).
  * dq [n_dst,128]; dkv has the layout of kv (lddkv = 128: value rows follow key rows) and only the rows of this call's
- * key rows are written — zero-fill it first. */
+ * key rows are written — zero-fill it first.  kv16: optional bf16 mirror of kv (mdg_f32_to_bf16; ldkv must be 128). */
 int mdg_hgt_attention_stats(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const int64_t* col,
                             const int64_t* item_dst, const int64_t* item_begin, const int64_t* item_end, int64_t n_items,
                             const int64_t* item_ptr, float* out, int64_t ldo, int64_t n_dst, int heads, int64_t F,
-                            int apply_gelu, float* stats, void* workspace, size_t workspace_bytes, void* stream);
+                            int apply_gelu, float* stats, const void* kv16, void* workspace, size_t workspace_bytes, void* stream);
 size_t mdg_hgt_attention_bwd_workspace_bytes(int64_t nnz, int64_t n_items, int64_t n_src_items, int heads);
 int mdg_hgt_attention_bwd(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const int64_t* col, int64_t nnz,
                           const int64_t* item_dst, const int64_t* item_begin, const int64_t* item_end, int64_t n_items,
@@ -318,7 +318,12 @@ int mdg_hgt_attention_bwd(const float* q, int64_t ldq, const float* kv, int64_t 
                           int64_t ldp, const float* stats, int heads, const int64_t* t_edge, const int64_t* t_dst,
                           const int64_t* t_item_begin, const int64_t* t_item_end, int64_t n_src_items,
                           const int64_t* t_item_ptr, const int64_t* t_row, int64_t n_src_rows, const int64_t* t_item_row,
-                          float* dq, int64_t lddq, float* dkv, int64_t lddkv, void* workspace, size_t workspace_bytes, void* stream);
+                          float* dq, int64_t lddq, float* dkv, int64_t lddkv, const void* kv16, void* workspace, size_t workspace_bytes,
+                          void* stream);
+/* fp32 -> bf16 (round to nearest even), n a multiple of 8: the 16-bit mirror of the projection buffer the two entry points above
+ * gather their k' | v' rows from when kv16 is non-null (the step's reduced-precision "bf16" mode: half the bytes per edge; q, the
+ * softmax statistics, every sum and every gradient stay fp32).  kv16 null = rows read from kv itself. */
+int mdg_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 
 /* ------------------------------------------------------- gathered head (finetune step) ---- */
 /* train_ddi_batch.py:285-288 computes sigmoid(model(...)) [L,N,N] and reads T (label, head, tail) entries of it.  These

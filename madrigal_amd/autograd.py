@@ -1041,20 +1041,24 @@ class _HgtAttentionFlat(Function):
     one gradient tensor for the whole projection buffer, no per-type scatter of dq."""
 
     @staticmethod
-    def forward(ctx, flat, heads, plans, qspec):
+    def forward(ctx, flat, heads, plans, qspec, rows16=False):
         from .graph_plans import hgt_reverse_plan
         outs, stats = [], []
         f1 = flat.view(-1)
+        # reduced-precision mode: the k' | v' rows are gathered from a bf16 mirror of the projection buffer (half the bytes per edge:
+        # the gathers ARE these kernels' time); queries, statistics, sums and gradients stay fp32
+        flat16 = ops.f32_to_bf16(flat) if (rows16 and flat.numel() % 8 == 0) else None
         lanes = _type_lanes(flat, len(plans))
         for i, (pd, (off, rows, width)) in enumerate(zip(plans, qspec)):
             q = f1[off:off + rows * width].view(rows, width)[:, 0:128]
             with lanes.lane(i):
-                o, s = ops.hgt_attention_stats(q, flat, pd, heads)
+                o, s = ops.hgt_attention_stats(q, flat, pd, heads, kv16=flat16)
             outs.append(o)
             stats.append(s)
         lanes.join(*outs, *stats)
         ctx.heads, ctx.plans, ctx.qspec, ctx.n = heads, plans, qspec, len(plans)
         ctx.revs = [hgt_reverse_plan(pd) for pd in plans]
+        ctx.flat16 = flat16
         ctx.save_for_backward(flat, *outs, *stats)
         return tuple(outs)
 
@@ -1071,13 +1075,13 @@ class _HgtAttentionFlat(Function):
             q = f1[off:off + rows * width].view(rows, width)[:, 0:128]
             dq = d1[off:off + rows * width].view(rows, width)[:, 0:128]
             with lanes.lane(i):
-                ops.hgt_attention_bwd(q, flat, pd, rev, ctx.heads, g, o, s, dflat, dq_out=dq)
+                ops.hgt_attention_bwd(q, flat, pd, rev, ctx.heads, g, o, s, dflat, dq_out=dq, kv16=ctx.flat16)
         lanes.join()
-        return dflat, None, None, None
+        return dflat, None, None, None, None
 
 
 type_lanes = _type_lanes
 
 
-def hgt_attention_flat(flat, heads, plans, qspec):
-    return _HgtAttentionFlat.apply(flat, heads, tuple(plans), tuple(qspec))
+def hgt_attention_flat(flat, heads, plans, qspec, rows16=False):
+    return _HgtAttentionFlat.apply(flat, heads, tuple(plans), tuple(qspec), bool(rows16))

@@ -74,6 +74,34 @@ __global__ __launch_bounds__(256) void csr_aggregate_kernel(const float* __restr
 // A half-wave (32 lanes x float4 = 128 floats) handles one edge; the two halves of a wave walk
 // alternate edges with 4 edges each in flight, and are merged at the end.
 // ---------------------------------------------------------------------------------------------
+// 16-bit mirror of the projection buffer (the step's "bf16" mode): the gathered k' | v' rows are what the kernels move -- 1 KB per
+// edge in fp32, half that as bf16 (the values a bf16 GEMM would have handed over anyway; q, the statistics, every sum and every
+// gradient stay fp32).  R16 kernels read row r of the mirror at element offset r * 128.
+template <bool R16>
+__device__ __forceinline__ f32x4 load_row4(const float* __restrict__ f32rows, const uint16_t* __restrict__ b16rows, int64_t elem) {
+  if constexpr (R16) {
+    const uint2 u = *reinterpret_cast<const uint2*>(b16rows + elem);
+    return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
+  } else {
+    return *reinterpret_cast<const f32x4*>(f32rows + elem);
+  }
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n8) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const f32x4 a = reinterpret_cast<const f32x4*>(x)[2 * i], b = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
+  auto rne = [](float v) -> uint32_t {                   // round to nearest even (NaN keeps a quiet payload)
+    const uint32_t u = __float_as_uint(v);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+  };
+  uint4 o;
+  o.x = rne(a[0]) | (rne(a[1]) << 16); o.y = rne(a[2]) | (rne(a[3]) << 16);
+  o.z = rne(b[0]) | (rne(b[1]) << 16); o.w = rne(b[2]) | (rne(b[3]) << 16);
+  reinterpret_cast<uint4*>(y)[i] = o;
+}
+
 struct HgtArgs {
   const float* q; int64_t ldq;          // [n_dst, >=128]
   const float* kv; int64_t ldkv;        // row col[e]: k' at +0 and v' at +128 floats (ldkv 128: v' is the next row)
@@ -88,10 +116,12 @@ struct HgtArgs {
   // a destination with ONE work item (<= CHUNK edges: nearly all of them) is finished here - normalised, activated, its softmax
   // statistics stored - instead of going through a partial that hgt_combine_kernel would only copy
   const int64_t* item_ptr; float* out; int64_t ldo; float* stats; int apply_gelu;
+  const uint16_t* kv16;                 // R16 kernels: the bf16 mirror of kv (same row numbering, 128 elements per row)
 };
 
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]); }
 
+template <bool R16>
 __global__ __launch_bounds__(256) void hgt_attention_kernel(const HgtArgs p) {
   const int lane = threadIdx.x & 63, sub = lane & 31, half = lane >> 5;
   const int64_t item = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -105,17 +135,17 @@ __global__ __launch_bounds__(256) void hgt_attention_kernel(const HgtArgs p) {
   // step is a dependent col -> row gather, so the rows in flight per wave are what hide its latency)
   for (int64_t e = e0 + half; e < e1; e += 8) {
     bool ok[4];
-    const float* r[4];
+    int64_t r[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       ok[u] = (e + 2 * u) < e1;
-      r[u] = p.kv + p.col[ok[u] ? e + 2 * u : e] * p.ldkv + 4 * sub;
+      r[u] = p.col[ok[u] ? e + 2 * u : e] * (R16 ? 128 : p.ldkv) + 4 * sub;
     }
     f32x4 k[4], v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      k[u] = *reinterpret_cast<const f32x4*>(r[u]);
-      v[u] = *reinterpret_cast<const f32x4*>(r[u] + 128);
+      k[u] = load_row4<R16>(p.kv, p.kv16, r[u]);
+      v[u] = load_row4<R16>(p.kv, p.kv16, r[u] + 128);
     }
     float a[4];
 #pragma unroll
@@ -234,8 +264,10 @@ struct HgtBwdArgs {
   float* part_dq;                       // [n_items,128]
   int H;
   const int64_t* item_ptr; float* dq; int64_t lddq;     // a destination with one work item writes its dq row itself
+  const uint16_t* kv16;
 };
 
+template <bool R16>
 __global__ __launch_bounds__(256) void hgt_attention_bwd_edge_kernel(const HgtBwdArgs p) {
   const int lane = threadIdx.x & 63, sub = lane & 31, half = lane >> 5;
   const int64_t item = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -253,17 +285,17 @@ __global__ __launch_bounds__(256) void hgt_attention_bwd_edge_kernel(const HgtBw
   // four edges of this half in flight (8 rows of k' | v'), as in the forward kernel; the sum keeps the edge order
   for (int64_t e = e0 + half; e < e1; e += 8) {
     bool ok[4];
-    const float* r[4];
+    int64_t r[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       ok[u] = (e + 2 * u) < e1;
-      r[u] = p.kv + p.col[ok[u] ? e + 2 * u : e] * p.ldkv + 4 * sub;
+      r[u] = p.col[ok[u] ? e + 2 * u : e] * (R16 ? 128 : p.ldkv) + 4 * sub;
     }
     f32x4 k[4], v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      k[u] = *reinterpret_cast<const f32x4*>(r[u]);
-      v[u] = *reinterpret_cast<const f32x4*>(r[u] + 128);
+      k[u] = load_row4<R16>(p.kv, p.kv16, r[u]);
+      v[u] = load_row4<R16>(p.kv, p.kv16, r[u] + 128);
     }
     float a[4], da[4];
 #pragma unroll
@@ -412,6 +444,16 @@ extern "C" int mdg_csr_aggregate(const float* x, int64_t ldx, const int64_t* row
   return MDG_OK;
 }
 
+extern "C" int mdg_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
+  MDG_CHECK_ARG(n >= 0 && n % 8 == 0, "mdg_f32_to_bf16: the element count must be a multiple of 8 (got %lld)", (long long)n);
+  if (n == 0) return MDG_OK;
+  MDG_CHECK_ARG(x && y && mdg_aligned16(x) && mdg_aligned16(y), "mdg_f32_to_bf16: 16-byte aligned pointers");
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n / 8, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     static_cast<uint16_t*>(y), n / 8);
+  MDG_CHECK_LAUNCH("mdg_f32_to_bf16");
+  return MDG_OK;
+}
+
 extern "C" size_t mdg_hgt_attention_workspace_bytes(int64_t n_items, int heads) {
   if (n_items <= 0) return 0;
   return static_cast<size_t>(n_items) * (128 + 2 * static_cast<size_t>(heads)) * sizeof(float);
@@ -420,8 +462,9 @@ extern "C" size_t mdg_hgt_attention_workspace_bytes(int64_t n_items, int heads) 
 extern "C" int mdg_hgt_attention_stats(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const int64_t* col,
                                        const int64_t* item_dst, const int64_t* item_begin, const int64_t* item_end, int64_t n_items,
                                        const int64_t* item_ptr, float* out, int64_t ldo, int64_t n_dst, int heads, int64_t F,
-                                       int apply_gelu, float* stats, void* workspace, size_t workspace_bytes, void* stream) {
+                                       int apply_gelu, float* stats, const void* kv16, void* workspace, size_t workspace_bytes, void* stream) {
   MDG_CHECK_ARG(F == 128, "mdg_hgt_attention: hidden size must be 128 (got %lld)", (long long)F);
+  MDG_CHECK_ARG(!kv16 || (ldkv == 128 && (reinterpret_cast<uintptr_t>(kv16) & 7u) == 0), "mdg_hgt_attention: the 16-bit mirror needs ldkv == 128 and 8-byte alignment");
   MDG_CHECK_ARG(heads == 1 || heads == 2 || heads == 4 || heads == 8, "mdg_hgt_attention: heads must be 1, 2, 4 or 8 (got %d)", heads);
   MDG_CHECK_ARG(n_dst >= 0 && n_items >= 0, "mdg_hgt_attention: negative size");
   if (n_dst == 0) return MDG_OK;
@@ -437,8 +480,10 @@ extern "C" int mdg_hgt_attention_stats(const float* q, int64_t ldq, const float*
   float* part_acc = static_cast<float*>(workspace);
   float* part_ml = part_acc ? part_acc + n_items * 128 : nullptr;
   if (n_items > 0) {
-    HgtArgs a{q, ldq, kv, ldkv, col, item_dst, item_begin, item_end, part_acc, part_ml, n_items, heads, nullptr, item_ptr, out, ldo, stats, apply_gelu};
-    hipLaunchKernelGGL(hgt_attention_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_items, 4))), dim3(256), 0, st, a);
+    HgtArgs a{q, ldq, kv, ldkv, col, item_dst, item_begin, item_end, part_acc, part_ml, n_items, heads, nullptr, item_ptr, out, ldo, stats, apply_gelu,
+              static_cast<const uint16_t*>(kv16)};
+    if (kv16) hipLaunchKernelGGL(hgt_attention_kernel<true>, dim3(static_cast<unsigned>(mdg_cdiv(n_items, 4))), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(hgt_attention_kernel<false>, dim3(static_cast<unsigned>(mdg_cdiv(n_items, 4))), dim3(256), 0, st, a);
   }
   hipLaunchKernelGGL(hgt_combine_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_dst, 8))), dim3(256), 0, st, part_acc, part_ml, item_ptr,
                      out, ldo, n_dst, heads, apply_gelu, stats);
@@ -451,7 +496,7 @@ extern "C" int mdg_hgt_attention(const float* q, int64_t ldq, const float* kv, i
                                  const int64_t* item_ptr, float* out, int64_t ldo, int64_t n_dst, int heads, int64_t F,
                                  int apply_gelu, void* workspace, size_t workspace_bytes, void* stream) {
   return mdg_hgt_attention_stats(q, ldq, kv, ldkv, col, item_dst, item_begin, item_end, n_items, item_ptr, out, ldo, n_dst, heads, F,
-                                 apply_gelu, nullptr, workspace, workspace_bytes, stream);
+                                 apply_gelu, nullptr, nullptr, workspace, workspace_bytes, stream);
 }
 
 // All destination types of a conv in one launch: destinations numbered across the types, query row of destination d at
@@ -475,8 +520,8 @@ extern "C" int mdg_hgt_attention_rows(const float* q_base, const int64_t* q_off,
   float* part_acc = static_cast<float*>(workspace);
   float* part_ml = part_acc ? part_acc + n_items * 128 : nullptr;
   if (n_items > 0) {
-    HgtArgs a{q_base, 0, kv, ldkv, col, item_dst, item_begin, item_end, part_acc, part_ml, n_items, heads, q_off, item_ptr, out, ldo, nullptr, apply_gelu};
-    hipLaunchKernelGGL(hgt_attention_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_items, 4))), dim3(256), 0, st, a);
+    HgtArgs a{q_base, 0, kv, ldkv, col, item_dst, item_begin, item_end, part_acc, part_ml, n_items, heads, q_off, item_ptr, out, ldo, nullptr, apply_gelu, nullptr};
+    hipLaunchKernelGGL(hgt_attention_kernel<false>, dim3(static_cast<unsigned>(mdg_cdiv(n_items, 4))), dim3(256), 0, st, a);
   }
   hipLaunchKernelGGL(hgt_combine_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_dst, 8))), dim3(256), 0, st, part_acc, part_ml, item_ptr,
                      out, ldo, n_dst, heads, apply_gelu, static_cast<float*>(nullptr));
@@ -495,7 +540,7 @@ extern "C" int mdg_hgt_attention_bwd(const float* q, int64_t ldq, const float* k
                                      int64_t ldp, const float* stats, int heads, const int64_t* t_edge, const int64_t* t_dst,
                                      const int64_t* t_item_begin, const int64_t* t_item_end, int64_t n_src_items,
                                      const int64_t* t_item_ptr, const int64_t* t_row, int64_t n_src_rows, const int64_t* t_item_row,
-                                     float* dq, int64_t lddq, float* dkv, int64_t lddkv, void* workspace, size_t workspace_bytes, void* stream) {
+                                     float* dq, int64_t lddq, float* dkv, int64_t lddkv, const void* kv16, void* workspace, size_t workspace_bytes, void* stream) {
   MDG_CHECK_ARG(heads == 1 || heads == 2 || heads == 4 || heads == 8, "mdg_hgt_attention_bwd: heads must be 1, 2, 4 or 8 (got %d)", heads);
   MDG_CHECK_ARG(n_dst >= 0 && n_items >= 0 && nnz >= 0 && n_src_items >= 0 && n_src_rows >= 0, "mdg_hgt_attention_bwd: negative size");
   if (n_dst == 0) return MDG_OK;
@@ -516,8 +561,11 @@ extern "C" int mdg_hgt_attention_bwd(const float* q, int64_t ldq, const float* k
     MDG_CHECK_ARG(kv && col && item_dst && item_begin && item_end && dkv && t_edge && t_dst && t_item_begin && t_item_end && t_item_ptr && t_row,
                   "mdg_hgt_attention_bwd: null plan pointer");
     MDG_CHECK_ARG(ldkv % 4 == 0 && lddkv % 4 == 0 && ldkv >= 128 && lddkv >= 128 && mdg_aligned16(kv) && mdg_aligned16(dkv), "mdg_hgt_attention_bwd: bad kv strides");
-    HgtBwdArgs a{q, ldq, kv, ldkv, col, item_dst, item_begin, item_end, n_items, dout, lddo, out_pre, ldp, stats, edge_alpha, edge_da, part_dq, heads, item_ptr, dq, lddq};
-    hipLaunchKernelGGL(hgt_attention_bwd_edge_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_items, 4))), dim3(256), 0, st, a);
+    HgtBwdArgs a{q, ldq, kv, ldkv, col, item_dst, item_begin, item_end, n_items, dout, lddo, out_pre, ldp, stats, edge_alpha, edge_da, part_dq, heads, item_ptr, dq, lddq,
+                 static_cast<const uint16_t*>(kv16)};
+    MDG_CHECK_ARG(!kv16 || (ldkv == 128 && (reinterpret_cast<uintptr_t>(kv16) & 7u) == 0), "mdg_hgt_attention_bwd: the 16-bit mirror needs ldkv == 128 and 8-byte alignment");
+    if (kv16) hipLaunchKernelGGL(hgt_attention_bwd_edge_kernel<true>, dim3(static_cast<unsigned>(mdg_cdiv(n_items, 4))), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(hgt_attention_bwd_edge_kernel<false>, dim3(static_cast<unsigned>(mdg_cdiv(n_items, 4))), dim3(256), 0, st, a);
   }
   hipLaunchKernelGGL(hgt_sum_items_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_dst, 8))), dim3(256), 0, st, part_dq, item_ptr, nullptr, dq, lddq, n_dst, 128, 1);
   if (n_src_items > 0) {

@@ -667,7 +667,8 @@ class HGTConv(nn.Module):
         def block(t):                                                  # this rank's rows of type t inside the flat buffer
             off, _, width = spec[t]
             return (off + rng[t][0] * width, rng[t][1] - rng[t][0], width)
-        pres = ag.hgt_attention_flat(flat, H, [plan["per_dst"][t] for t in dst_types], [block(t) for t in dst_types]) if dst_types else ()
+        rows16 = _state["precision"] == "bf16" and os.environ.get("MDG_HGT_ROWS16", "1") != "0"
+        pres = ag.hgt_attention_flat(flat, H, [plan["per_dst"][t] for t in dst_types], [block(t) for t in dst_types], rows16=rows16) if dst_types else ()
         out = {}
         # the destination types' output stages (GELU, out_lin, gated residual: a chain of small launches per type, and as many again
         # in the backward pass, which autograd runs on the stream of the forward): parallel branches when the pass is being captured

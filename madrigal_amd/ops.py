@@ -31,8 +31,16 @@ def _prec(p) -> int:
     return int(p)
 
 
+_raw_stream_of = torch._C._cuda_getCurrentRawStream      # the current stream's handle without building a torch.cuda.Stream (~1 000 lookups per training step)
+
+
+def _stream_handle(device) -> int:
+    idx = device.index
+    return _raw_stream_of(torch.cuda.current_device() if idx is None else idx)
+
+
 def _stream(t: torch.Tensor) -> _vp:
-    return _vp(torch.cuda.current_stream(t.device).cuda_stream)
+    return _vp(_stream_handle(t.device))
 
 
 def _ptr(t: Optional[torch.Tensor]) -> _vp:
@@ -63,7 +71,7 @@ def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
         # whatever eager op later lands on a stream with the same handle)
         return torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
     # one scratch buffer per (device, stream): ops enqueued on different streams may run concurrently
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.type, device.index, _stream_handle(device))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -1349,9 +1357,25 @@ def mul_device_scalar(x: torch.Tensor, scalar: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------- HGT attention, training
-def hgt_attention_stats(q: torch.Tensor, kv: torch.Tensor, plan: dict, heads: int):
-    """mdg_hgt_attention without the activation -> (out_pre [n_dst,128], stats [n_dst,heads,2])."""
+def f32_to_bf16(x: torch.Tensor) -> torch.Tensor:
+    """bf16 mirror (round to nearest even) of a contiguous fp32 tensor whose element count is a multiple of 8 (mdg_f32_to_bf16)."""
+    x = _f32_cuda(x, "x")
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib().mdg_f32_to_bf16(_ptr(x), _ptr(y), _c64(x.numel()), _stream(x)), "mdg_f32_to_bf16")
+    return y
+
+
+def _kv16_ok(kv: torch.Tensor, kv16: Optional[torch.Tensor]) -> None:
+    if kv16 is not None and (kv16.dtype != torch.bfloat16 or kv16.shape != kv.shape or not kv16.is_contiguous() or kv16.device != kv.device or
+                             kv.stride(0) != 128):
+        raise ValueError("kv16: the bf16 mirror of kv (same [rows,128] shape, contiguous, same device)")
+
+
+def hgt_attention_stats(q: torch.Tensor, kv: torch.Tensor, plan: dict, heads: int, kv16: Optional[torch.Tensor] = None):
+    """mdg_hgt_attention without the activation -> (out_pre [n_dst,128], stats [n_dst,heads,2]).  ``kv16``: bf16 mirror of ``kv``
+    (f32_to_bf16) to gather the k' | v' rows from -- the reduced-precision mode's half-size rows."""
     n_dst = q.shape[0]
+    _kv16_ok(kv, kv16)
     if q.dim() != 2 or q.shape[1] != 128 or q.stride(1) != 1 or not q.is_cuda or q.dtype != torch.float32:
         raise ValueError("q: expected fp32 cuda [n_dst,128] with unit inner stride")
     out = torch.empty((n_dst, 128), dtype=torch.float32, device=q.device)
@@ -1362,15 +1386,18 @@ def hgt_attention_stats(q: torch.Tensor, kv: torch.Tensor, plan: dict, heads: in
     check(lib().mdg_hgt_attention_stats(_ptr(q), _c64(q.stride(0)), _ptr(kv), _c64(0 if kv is None else kv.stride(0)), _ptr(plan["col"]),
                                         _ptr(plan["item_dst"]), _ptr(plan["item_begin"]), _ptr(plan["item_end"]), _c64(n_items),
                                         _ptr(plan["item_ptr"]), _ptr(out), _c64(128), _c64(n_dst), _c(heads), _c64(128), _c(0),
-                                        _ptr(stats), _ptr(ws), ctypes.c_size_t(nbytes), _stream(q)), "mdg_hgt_attention_stats")
+                                        _ptr(stats), _ptr(kv16), _ptr(ws), ctypes.c_size_t(nbytes), _stream(q)), "mdg_hgt_attention_stats")
     return out, stats
 
 
 def hgt_attention_bwd(q: torch.Tensor, kv: torch.Tensor, plan: dict, rev: dict, heads: int, dout: torch.Tensor, out_pre: torch.Tensor,
-                      stats: torch.Tensor, dkv: torch.Tensor, dq_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      stats: torch.Tensor, dkv: torch.Tensor, dq_out: Optional[torch.Tensor] = None,
+                      kv16: Optional[torch.Tensor] = None) -> torch.Tensor:
     """-> dq [n_dst,128]; writes this destination type's key / value gradient rows into ``dkv`` (layout of ``kv``).
-    ``dq_out``: write dq there instead (a [n_dst,128] view with unit inner stride, e.g. the query slots of ``dkv`` itself)."""
+    ``dq_out``: write dq there instead (a [n_dst,128] view with unit inner stride, e.g. the query slots of ``dkv`` itself).
+    ``kv16``: the bf16 mirror the forward pass gathered from (the same rounded rows enter dq and the softmax gradient)."""
     n_dst = q.shape[0]
+    _kv16_ok(kv, kv16)
     dout = _f32_cuda(dout, "dout", 2)
     if kv.dim() != 2 or kv.shape[1] != 128 or not kv.is_contiguous() or dkv.shape != kv.shape or not dkv.is_contiguous():
         raise ValueError("hgt_attention_bwd: kv / dkv must be contiguous [rows,128] (value rows follow key rows)")
@@ -1388,7 +1415,8 @@ def hgt_attention_bwd(q: torch.Tensor, kv: torch.Tensor, plan: dict, rev: dict, 
                                       _ptr(dout), _c64(dout.stride(0)), _ptr(out_pre), _c64(out_pre.stride(0)), _ptr(stats), _c(heads),
                                       _ptr(rev["t_edge"]), _ptr(rev["t_dst"]), _ptr(rev["item_begin"]), _ptr(rev["item_end"]),
                                       _c64(rev["n_items"]), _ptr(rev["item_ptr"]), _ptr(rev["rows"]), _c64(rev["n_rows"]), _ptr(rev.get("item_row")),
-                                      _ptr(dq), _c64(dq.stride(0)), _ptr(dkv), _c64(128), _ptr(ws), ctypes.c_size_t(nbytes), _stream(q)),
+                                      _ptr(dq), _c64(dq.stride(0)), _ptr(dkv), _c64(128), _ptr(kv16), _ptr(ws), ctypes.c_size_t(nbytes),
+                                      _stream(q)),
           "mdg_hgt_attention_bwd")
     return dq
 

@@ -16,6 +16,13 @@ from .parallel import GradientBuckets, all_gather_rows_grad, all_reduce_sum_, al
 from .pipeline import slice_batch
 
 
+def _ensure_training(model) -> None:
+    """``model.train()`` of the reference's loops (train_ddi_batch.py:231, pretrain.py:61: once per epoch there) without walking
+    the ~200 submodules in every step: the walk happens when the model, or any submodule, is not in training mode."""
+    if not model.training or not all(m.training for m in model.modules()):
+        model.train()
+
+
 def _refuse_rank_local_batchnorm(encoder, world: int) -> None:
     """Data-parallel steps synchronise BatchNorm statistics with collectives issued from inside the BatchNorm nodes, so every
     rank must run every BatchNorm-bearing module the same number of times.  GIN and the chemCPA encoder always run (every
@@ -157,7 +164,7 @@ class FinetuneStep:
             self.scheduler.step()
 
     def step(self, batch_head, batch_tail, masks_head, masks_tail, batch_kg, labels, heads, tails, targets, **kwargs) -> torch.Tensor:
-        self.model.train()
+        _ensure_training(self.model)
         self.optimizer.zero_grad(set_to_none=True)
         if self._buckets is not None:
             self._buckets.arm()
@@ -211,7 +218,7 @@ class PretrainStep:
 
     def step(self, drug_indices, mask1, mask2, too_hard_neg, batch_data) -> torch.Tensor:
         model = self.model
-        model.train()
+        _ensure_training(model)
         if self.scheduler is not None:
             self.scheduler(self.optimizer)
         self.optimizer.zero_grad(set_to_none=True)

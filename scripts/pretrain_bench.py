@@ -22,6 +22,7 @@ ap.add_argument("--kg-nodes", type=int, default=130_000)
 ap.add_argument("--kg-edges", type=int, default=8_000_000)
 ap.add_argument("--precision", default="bf16x3")
 ap.add_argument("--fusion-views", action="store_true")
+ap.add_argument("--host-profile", action="store_true", help="cProfile over the timed steps (autograd on the calling thread): where the host's issue time goes")
 ap.add_argument("--device-inputs", action="store_true", help="move the drawn masks / drug indices to the device in the loop (pageable .cuda(), as the reference does) instead of handing the step the host tensors")
 a = ap.parse_args()
 M.set_precision(a.precision)
@@ -40,9 +41,15 @@ draw = MK.StrCenterUniSampler(bank) if raw else None
 step = PretrainStep(model, AdamW(model.parameters(), lr=1e-5, weight_decay=1e-2))
 data = (b["strs"], kgc, b["cv"], b["tx"])
 losses, t_views = [], 0.0
+prof = None
 for i in range(a.warmup + a.steps):
     if i == a.warmup:
         torch.cuda.synchronize()
+        if a.host_profile:
+            import cProfile
+            torch.autograd.set_multithreading_enabled(False)
+            prof = cProfile.Profile()
+            prof.enable()
         t0 = time.perf_counter()
         t_views = 0.0
     tv = time.perf_counter()
@@ -57,6 +64,13 @@ for i in range(a.warmup + a.steps):
     t_views += time.perf_counter() - tv
     losses.append(step.step(b["drugs"] if (a.device_inputs or not raw) else batch["drugs"], m1, m2, None, data))
 host_issue = (time.perf_counter() - t0) / a.steps
+if prof is not None:
+    import io, pstats
+    prof.disable()
+    for key in ("tottime", "cumtime"):
+        buf = io.StringIO()
+        pstats.Stats(prof, stream=buf).sort_stats(key).print_stats(32)
+        print(buf.getvalue()[:7000], file=sys.stderr)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 print(json.dumps({"workload": "cl_pretrain as shipped (raw_encoder_output, str_center_uni)" if raw else "fusion-transformer views",

@@ -346,3 +346,15 @@ def test_hgt_attention_backward_heavy_tail(ops, heads):
     dkv2 = torch.zeros_like(kvd)
     dq2 = ops.hgt_attention_bwd(qd, kvd, pd, rev, heads, dout.cuda(), out, stats, dkv2)
     assert torch.equal(dq, dq2) and torch.equal(dkv, dkv2)                         # no atomics: bit-reproducible
+    # reduced-precision mode: k' | v' gathered from the bf16 mirror of the projection buffer == the fp32 kernels run on the rounded rows
+    kv16 = ops.f32_to_bf16(kvd)
+    assert torch.equal(kv16.cpu(), buf.view(-1, 128).to(torch.bfloat16))           # round to nearest even, as torch rounds
+    kvr = kv16.float()
+    out_r, stats_r = ops.hgt_attention_stats(qd, kvr, pd, heads)
+    out_h, stats_h = ops.hgt_attention_stats(qd, kvd, pd, heads, kv16=kv16)
+    assert torch.equal(out_r, out_h) and torch.equal(stats_r, stats_h)
+    dkv_r, dkv_h = torch.zeros_like(kvd), torch.zeros_like(kvd)
+    dq_r = ops.hgt_attention_bwd(qd, kvr, pd, rev, heads, dout.cuda(), out_r, stats_r, dkv_r)
+    dq_h = ops.hgt_attention_bwd(qd, kvd, pd, rev, heads, dout.cuda(), out_h, stats_h, dkv_h, kv16=kv16)
+    assert torch.equal(dq_r, dq_h) and torch.equal(dkv_r, dkv_h)
+    assert float((out_h.cpu() - agg.detach().float()).abs().max()) < 3e-2 * max(float(agg.abs().max()), 1.0)
