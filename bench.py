@@ -581,8 +581,8 @@ def pretrain_leg(model, bkg, masks_all, args, precision="bf16x3"):
     data = (b["strs"], kgc, b["cv"], b["tx"])
     losses = []
     with M.precision(precision):
-        for i in range(2 + args.pretrain_steps):
-            if i == 2:
+        for i in range(4 + args.pretrain_steps):
+            if i == 4:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
             m1, m2 = draw(range(B))                          # host tensors: the step uploads them (madrigal_amd/hostio.py)
@@ -590,7 +590,7 @@ def pretrain_leg(model, bkg, masks_all, args, precision="bf16x3"):
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.pretrain_steps
     out = {"metric": "contrastive-pretraining steps/sec", "value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "drugs_per_s": B / dt,
-           "n_gpus": 1, "steps": args.pretrain_steps, "warmup": 2, "batch": B, "dtype": "f32 via split-bf16 (bf16x3) MFMA",
+           "n_gpus": 1, "steps": args.pretrain_steps, "warmup": 4, "batch": B, "dtype": "f32 via split-bf16 (bf16x3) MFMA",
            "loss_first_last": [float(losses[0]), float(losses[-1])], "lr_last": sched.last_lr,
            "config": {"workload": "BASELINE configs[2] as shipped: SimCLR_NovelDDI(raw_encoder_output=True), 'str_center_uni' views drawn per "
                                   "iteration on the host, separate predictors, T=0.1, mlp_dim=512, AdamW with the per-iteration "
@@ -694,7 +694,7 @@ def main():
     ap.add_argument("--head-only", action="store_true", help="time the scoring stage alone (embeddings given)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-exact", action="store_true", help="skip the exact-fp32 head beside the headline's mode (N = 1)")
-    ap.add_argument("--pretrain-steps", type=int, default=5, help="contrastive-pretraining leg (BASELINE configs[2]); 0 disables; single GPU only")
+    ap.add_argument("--pretrain-steps", type=int, default=20, help="contrastive-pretraining leg (BASELINE configs[2]); 0 disables; single GPU only")
     ap.add_argument("--pretrain-batch", type=int, default=2048)
     ap.add_argument("--ddp-legs", action="store_true", help="N > 1: after the line, also run the data-parallel finetune step and the sharded cfg5 "
                     "run (untested over RCCL; results to stderr and gpurun_out/bench_ddp_legs_n<N>.json)")

@@ -1147,8 +1147,11 @@ def triple_plan(labels: torch.Tensor, heads: torch.Tensor, tails: torch.Tensor, 
     big = n_labels * max(n_head, 1) >= 2 ** 31
     key = labels * n_head + heads if big else (labels * n_head + heads).to(torch.int32)
     perm = torch.argsort(key, stable=True)
-    ls, hs, ts = labels[perm], heads[perm].contiguous(), tails[perm].contiguous()
-    counts = torch.bincount(ls, minlength=n_labels)
+    hs, ts = heads[perm].contiguous(), tails[perm].contiguous()
+    try:
+        counts = torch.bincount(labels, minlength=n_labels)
+    except RuntimeError as e:
+        raise ValueError(f"labels: value outside [0, n_labels) ({e})") from None
     if counts.numel() != n_labels:
         raise ValueError("labels: value outside [0, n_labels)")
     zero = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -1164,13 +1167,18 @@ def triple_plan(labels: torch.Tensor, heads: torch.Tensor, tails: torch.Tensor, 
     _, tile_label, tile_start = cut(32)
     chunks_per, _, chunk_start = cut(256)
     label_chunk_ptr = torch.cat([zero, torch.cumsum(chunks_per, 0)]).contiguous()
-    bounds = torch.stack([hs.max(), ts.max(), hs.min(), ts.min()]).tolist() if T else [-1, -1, 0, 0]      # one round trip
-    if bounds[0] >= n_head or bounds[1] >= n_tail or bounds[2] < 0 or bounds[3] < 0:
-        raise ValueError("heads / tails: index outside the embedding tables")
 
     def by_drug(idx, n):
+        # the range check of the drug indices rides on the histogram: bincount raises on a negative entry and returns more than n
+        # bins when one is >= n (no separate max / min reductions over the triples)
         order = torch.argsort(idx if n >= 2 ** 31 else idx.to(torch.int32), stable=True)
-        return torch.cat([zero, torch.cumsum(torch.bincount(idx, minlength=n), 0)]).contiguous(), order.contiguous()
+        try:
+            cnt = torch.bincount(idx, minlength=n)
+        except RuntimeError as e:
+            raise ValueError(f"heads / tails: index outside the embedding tables ({e})") from None
+        if cnt.numel() != n:
+            raise ValueError("heads / tails: index outside the embedding tables")
+        return torch.cat([zero, torch.cumsum(cnt, 0)]).contiguous(), order.contiguous()
 
     def pieces(ptr):
         """A drug's list can hold thousands of entries while mdg_csr_aggregate gives a row to one group of lanes: cut every
