@@ -264,6 +264,8 @@ struct LinearArgs {
   int act;
   int64_t M, N, K;
   int tiles_x, tiles_y, swizzle;   // swizzle: XCD-aware tile order (see tile_of)
+  int ty_base;                     // the launch covers tile rows ty_base .. ty_base + tiles_y - 1 of the problem (row split of one product
+                                   // over two launches: whole rounds of 256-tiles, the rest as 128-tiles; see launch_linear_core)
   int vec_y, vec_r;                // y / residual rows may be accessed 16 B at a time (alignment and row stride)
   const int64_t* tiles;            // grouped launch: [n_tiles][kGroupTileWords] tile descriptors (device), else null
   const float* a_raw;              // 128-tile kernel, 16-bit modes: x itself (fp32 rows, stride a_ldx floats, a_k valid columns) when no
@@ -533,6 +535,7 @@ __global__ __launch_bounds__(S::THREADS, 2) void linear_kernel(const LinearArgs 
   } else {
     int tx, ty;
     if (!tile_of(p, static_cast<int>(blockIdx.x), tx, ty)) return;   // workgroup-uniform
+    ty += p.ty_base;
     col0 = static_cast<int64_t>(tx) * S::BN;
     row0 = static_cast<int64_t>(ty) * S::BM;
     if (pk.ks_count > 1) {                                           // split-K: this workgroup's k range and partial result
@@ -830,6 +833,7 @@ __global__ __launch_bounds__(pp::THREADS, 2) void linear_pp_kernel(const LinearA
   if constexpr (!SK) {                                        // one tile per workgroup
     int tx, ty;
     if (!tile_of(p, static_cast<int>(blockIdx.x), tx, ty)) return;          // workgroup-uniform
+    ty += p.ty_base;
     run_piece(tx, ty, 0, nk);
     epilogue(tx, ty);
     return;
@@ -1248,6 +1252,39 @@ static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t 
     }
     const bool persistent = a.sk_tiles != 0 || (sk_sw.get() == 2 && sk_ws && sk_avail >= pp::sk_bytes());   // 2: persistent loop without shared tiles (diagnostics)
     if (persistent && !a.sk_tiles) { a.sk_ws = sk_ws; grid = dim3(static_cast<unsigned>(P)); }
+    // Row split of a product whose last round of 256-tiles would run mostly empty (one workgroup per CU; [22016, 6144]: 2064 tiles =
+    // 8 rounds + 16 tiles that cost a ninth): the tile rows that fill whole rounds go to this kernel, the remaining rows to the
+    // 128-tile kernel in a second launch (same operand images, same k order per element: the result is bit-identical to either
+    // kernel alone).  Taken when the remainder is at most half a round -- four 128-tiles per 256-tile at ~0.65 of its rate only pay
+    // below that.  MDG_LINEAR_TAIL128=0 keeps the single launch.
+    static MdgEnvInt tail_sw{"MDG_LINEAR_TAIL128", 1};
+    if (!persistent && tail_sw.get() && total > P && rem != 0 && a.tiles == nullptr) {
+      const int full_rows = (total - rem) / a.tiles_x, tail_rows = a.tiles_y - full_rows;
+      if (full_rows > 0 && tail_rows > 0 && tail_rows * a.tiles_x * 2 <= P) {
+        LinearArgs head = a, tail = a;
+        head.tiles_y = full_rows;
+        head.ty_base = 0;
+        const int n_head = head.tiles_x * head.tiles_y;
+        head.swizzle = swz_env >= 0 ? swz_env : (n_head >= 64 ? 1 : 0);
+        const dim3 ghead(static_cast<unsigned>(head.swizzle ? 8 * ((n_head + 7) / 8) : n_head));
+        if (precision == MDG_PREC_BF16X3) hipLaunchKernelGGL((linear_pp_kernel<MDG_PREC_BF16X3, false>), ghead, dim3(pp::THREADS), pp::LDS_BYTES, st, head);
+        else hipLaunchKernelGGL((linear_pp_kernel<MDG_PREC_BF16, false>), ghead, dim3(pp::THREADS), pp::LDS_BYTES, st, head);
+        using S = Small;
+        const int64_t row_base = static_cast<int64_t>(full_rows) * pp::BM;
+        tail.tiles_x = static_cast<int>(mdg_cdiv(N, S::BN));
+        tail.tiles_y = static_cast<int>(mdg_cdiv(M - row_base, S::BM));
+        tail.ty_base = static_cast<int>(row_base / S::BM);
+        const int n_tail = tail.tiles_x * tail.tiles_y;
+        tail.swizzle = swz_env >= 0 ? swz_env : (n_tail >= 64 ? 1 : 0);
+        tail.a_raw = nullptr;
+        tail.ks_count = 0;
+        const dim3 gtail(static_cast<unsigned>(tail.swizzle ? 8 * ((n_tail + 7) / 8) : n_tail));
+        const size_t lds = 2 * S::STAGE;
+        if (precision == MDG_PREC_BF16X3) hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16X3, S, 16>), gtail, dim3(S::THREADS), lds, st, tail);
+        else hipLaunchKernelGGL((linear_kernel<MDG_PREC_BF16, S, 16>), gtail, dim3(S::THREADS), lds, st, tail);
+        return;
+      }
+    }
     if (persistent) {
       if (precision == MDG_PREC_BF16X3) hipLaunchKernelGGL((linear_pp_kernel<MDG_PREC_BF16X3, true>), grid, dim3(pp::THREADS), pp::LDS_BYTES, st, a);
       else hipLaunchKernelGGL((linear_pp_kernel<MDG_PREC_BF16, true>), grid, dim3(pp::THREADS), pp::LDS_BYTES, st, a);

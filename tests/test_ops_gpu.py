@@ -263,6 +263,26 @@ def test_csr_aggregate(ops, F):
     assert float((got2 - ref2).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(22016, 1024, 512), (2700, 6144, 256), (16897, 2048, 128)])
+def test_dense_block_row_split_is_bit_identical(ops, monkeypatch, prec, M, N, K):
+    """A product whose 256-tiles fill whole rounds plus a small remainder runs as two launches (whole rounds on the 256-tile kernel,
+    the remaining rows on the 128-tile kernel: linear.hip launch_linear_core).  Same operand images, same k order per element: the
+    result equals the single launch bit for bit -- bias, activation, residual, ragged last row tile included."""
+    from helpers import set_switch
+    x, w, b = _rand((M, K), 1).cuda(), _rand((N, K), 2, 0.05).cuda(), _rand((N,), 3).cuda()
+    res = _rand((M, N), 4).cuda()
+    tiles = -(-M // 256) * -(-N // 256)
+    assert tiles > 256 and 0 < tiles % 256 <= 128                      # the shapes take the split on a 256-CU card
+    set_switch(monkeypatch, "MDG_LINEAR_TAIL128", "0")
+    one = ops.linear(x, w, b, act="gelu", residual=res, precision=prec, cache_weight=False)
+    set_switch(monkeypatch, "MDG_LINEAR_TAIL128", "1")
+    two = ops.linear(x, w, b, act="gelu", residual=res, precision=prec, cache_weight=False)
+    assert torch.equal(one, two)
+    ref = torch.nn.functional.gelu(x[-300:].double() @ w.double().t() + b.double()) + res[-300:].double()
+    assert float((two[-300:].double() - ref).abs().max()) < (3e-2 if prec == "bf16" else 1e-4) * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("heads", [4, 1, 8])
 def test_hgt_attention_heavy_tail(ops, heads):
     """Edge softmax + aggregation incl. a destination with > CHUNK edges (split into work items), an
