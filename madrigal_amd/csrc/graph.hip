@@ -260,7 +260,8 @@ struct HgtBwdArgs {
   const float* g; int64_t ldg;          // [n_dst,128] gradient at the attention output (pre-activation)
   const float* pre; int64_t ldp;        // [n_dst,128] forward output before the activation
   const float* stats;                   // [n_dst,H,2] (max, denominator)
-  float* edge_alpha; float* edge_da;    // [nnz,H]
+  float* edge_alpha; float* edge_da;    // one array [nnz][alpha: H | da: H] (edge_da = edge_alpha + H): an edge's pair shares a cache line,
+                                        // the source-side kernel's gather through the edge id touches one line per edge instead of two
   float* part_dq;                       // [n_items,128]
   int H;
   const int64_t* item_ptr; float* dq; int64_t lddq;     // a destination with one work item writes its dq row itself
@@ -317,8 +318,8 @@ __global__ __launch_bounds__(256) void hgt_attention_bwd_edge_kernel(const HgtBw
       if (ok[u]) {
         acc += ds * k[u];
         if (sub % lph == 0) {
-          p.edge_alpha[(e + 2 * u) * p.H + h] = alpha;
-          p.edge_da[(e + 2 * u) * p.H + h] = ds;
+          p.edge_alpha[(e + 2 * u) * 2 * p.H + h] = alpha;
+          p.edge_da[(e + 2 * u) * 2 * p.H + h] = ds;
         }
       }
     }
@@ -384,8 +385,8 @@ __global__ __launch_bounds__(256) void hgt_attention_bwd_src_kernel(const HgtSrc
     f32x4 qr[4], gr[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      da[u] = p.edge_da[eid[u] * p.H + h];
-      al[u] = p.edge_alpha[eid[u] * p.H + h];
+      da[u] = p.edge_da[eid[u] * 2 * p.H + h];
+      al[u] = p.edge_alpha[eid[u] * 2 * p.H + h];
       qr[u] = *reinterpret_cast<const f32x4*>(p.q + d[u] * p.ldq + 4 * sub);
       gr[u] = *reinterpret_cast<const f32x4*>(p.g + d[u] * p.ldg + 4 * sub);
     }
@@ -556,7 +557,7 @@ extern "C" int mdg_hgt_attention_bwd(const float* q, int64_t ldq, const float* k
   float* part_dq = static_cast<float*>(workspace);
   float* part_src = part_dq ? part_dq + n_items * 128 : nullptr;
   float* edge_alpha = part_src ? part_src + n_src_items * 256 : nullptr;
-  float* edge_da = edge_alpha ? edge_alpha + nnz * heads : nullptr;
+  float* edge_da = edge_alpha ? edge_alpha + heads : nullptr;                 // interleaved per edge: [alpha x heads | da x heads]
   if (n_items > 0) {
     MDG_CHECK_ARG(kv && col && item_dst && item_begin && item_end && dkv && t_edge && t_dst && t_item_begin && t_item_end && t_item_ptr && t_row,
                   "mdg_hgt_attention_bwd: null plan pointer");
