@@ -110,7 +110,8 @@ def pmc_traffic(n_drugs: int, n_outcomes: int, precision: str):
         if w.get("drugs") == n_drugs and w.get("outcomes") == n_outcomes and w.get("precision") == precision:
             for name, k in d.get("kernels", {}).items():
                 if "bilinear_allpairs" in name:
-                    return k.get("hbm_bytes_per_launch_corrected"), os.path.basename(f)
+                    # (bytes past the L2: for this kernel's write-once store stream that is the HBM traffic; older files call the field hbm_*)
+                    return k.get("past_l2_bytes_per_launch_corrected", k.get("hbm_bytes_per_launch_corrected")), os.path.basename(f)
     return None, None
 
 
