@@ -617,8 +617,9 @@ def test_chemcpa_predict_training_gradients_match_torch():
 
 
 # ---------------------------------------------------------------------------------------------- KG encoder
-@pytest.mark.parametrize("only_drug,batched", [(False, "1"), (True, "1"), (False, "0"), (False, "torch"), (True, "torch")])
-def test_hgt_training_gradients_match_oracle_autograd(only_drug, batched, monkeypatch):
+@pytest.mark.parametrize("only_drug,batched,heads", [(False, "1", 4), (True, "1", 4), (False, "0", 4), (False, "torch", 4), (True, "torch", 4),
+                                                     (False, "1", 2), (False, "1", 8)])
+def test_hgt_training_gradients_match_oracle_autograd(only_drug, batched, heads, monkeypatch):
     """The oracle's HGT restatement is written on torch ops: in float64 with parameters that require grad it is its own
     autograd reference (PyG 2.3.1 is not in the image: the formula, not the wheel, is what is pinned here).  ``batched``:
     composite projection weights of all node types built at once -- "1": by the two kernels of csrc/hgt_params.hip (default; every
@@ -630,16 +631,16 @@ def test_hgt_training_gradients_match_oracle_autograd(only_drug, batched, monkey
     from oracle import madrigal_oracle as O
     torch.manual_seed(7)
     kg = data.make_kg(60, seed=4, n_nodes=700, n_edges=9000, n_node_types=5, n_rel_pairs=6)
-    m = M.HGT(128, 128, 128, 2, 4, kg.metadata())
+    m = M.HGT(128, 128, 128, 2, heads, kg.metadata())       # (heads 2: the composite backward kernel reads its tiles in place, 4 / 8: through LDS)
     with torch.no_grad():                                   # non-trivial gates and relation priors
         for conv in m.convs:
             for p_ in conv.skip.values():
                 p_.copy_(torch.randn(1) * 0.5)
             for p_ in conv.p_rel.values():
-                p_.copy_(1.0 + 0.3 * torch.randn(1, 4))
+                p_.copy_(1.0 + 0.3 * torch.randn(1, heads))
     params = {k: v.detach().double().requires_grad_(True) for k, v in m.state_dict().items() if v.dtype.is_floating_point}
     xr = {t: x.double() for t, x in kg.x_dict.items()}
-    out_r = O.hgt_forward(params, xr, kg.edge_index_dict, kg.node_types, kg.edge_types, num_layers=2, heads=4, hidden=128)
+    out_r = O.hgt_forward(params, xr, kg.edge_index_dict, kg.node_types, kg.edge_types, num_layers=2, heads=heads, hidden=128)
     types = ["drug"] if only_drug else list(out_r.keys())
     dys = {t: _rand(*out_r[t].shape, seed=11 + i) for i, t in enumerate(types)}
     sum((out_r[t] * dys[t].double()).sum() for t in types).backward()
