@@ -1380,6 +1380,27 @@ class TransformerFusion(nn.Module):
             plan["key_rows"] = row_start[:-1].contiguous()
         return plan
 
+    def merged_live_plan(self, a: dict, b: dict) -> dict:
+        """The live-token plan of two batches laid one after the other (``a``'s drugs and token rows first): one transformer pass
+        over both (the finetune step's head side and tail side).  Row / tile / key tables are offset by ``a``'s row count; the
+        per-row bit masks are tile-local and carry over.  Kept for the last pair of plans seen."""
+        key = (id(a), id(b))
+        hit = self.__dict__.get("_merged_plan")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        assert a["S"] == b["S"] and a.get("Tk") == b.get("Tk")
+        Ra = a["R"]
+        m = {"n": a["n"] + b["n"], "S": a["S"], "R": Ra + b["R"], "n_tiles": a["n_tiles"] + b["n_tiles"],
+             "row_start": torch.cat([a["row_start"][:-1], b["row_start"] + Ra]).contiguous(),
+             "tile_start": torch.cat([a["tile_start"][:-1], b["tile_start"] + Ra]).contiguous(),
+             "row_bits": torch.cat([a["row_bits"], b["row_bits"]]).contiguous()}
+        if "key_rows" in a:
+            m["key_rows"] = torch.cat([a["key_rows"], b["key_rows"] + Ra]).contiguous()
+        if "Tk" in a:
+            m["Tk"] = a["Tk"]
+        self.__dict__["_merged_plan"] = (key, m, a, b)          # (holds a and b: their ids cannot be recycled meanwhile)
+        return m
+
     def forward_tokens(self, tokens: torch.Tensor, plan: dict) -> torch.Tensor:
         """Same result as ``forward`` on the dense sequence, computed on the live token rows only
         (tokens [R,D] in plan['token_index'] order)."""
@@ -1866,6 +1887,10 @@ class NovelDDIEncoder(nn.Module):
                                         cls=self.cls if has_cls else None, pe=self.pos_encoder.table(train=True),
                                         normalize=self.normalize, token_index=None if plan is None else plan["token_index"])
             tokens = ag.dropout(tokens, self.pos_encoder.dropout.p, self.pos_encoder.dropout.training)
+            if compact and kwargs.get('defer_fusion'):
+                # the caller runs the transformer itself -- over this side's and the other side's tokens in ONE pass
+                # (NovelDDIMultilabel.embed) -- and hands the fused rows to ``finish``
+                return PendingFusion(tokens, plan, self.transformer, lambda z_f_: self._finish_fused(z_f_, mp, n, str_out, kg_out, cv_out, tx_out, norm))
             z_f = self.transformer.forward_tokens(tokens, plan) if compact else self.transformer(tokens, fusion_mask=mp["kpm"], src_mask=mp["src"])
         elif compact:
             plan = mp["live"]
@@ -1877,16 +1902,7 @@ class NovelDDIEncoder(nn.Module):
         if self.fusion != 'transformer_uni_proj':
             return z_f
         if train:
-            # the same merge as below through own gather nodes (no indexed assignments: their backward sorts): the single available
-            # modality of a uni-modal drug is row uni_col * n + drug of [str | kg | cv | tx (cell line by cell line)]; the fused and the
-            # uni-modal rows, one after the other, are read back in drug order
-            parts = [z_f]
-            if mp["n_uni"] > 0:
-                uni = ag.gather_rows(torch.cat([str_out, kg_out, cv_out, tx_out], dim=0), mp["uni_flat"])
-                if self.normalize:
-                    uni = norm(uni)
-                parts.append(self.uni_fuser(uni))
-            return ag.gather_rows(torch.cat(parts, dim=0) if len(parts) > 1 else z_f, mp["merge_perm"])
+            return self._finish_fused(z_f, mp, n, str_out, kg_out, cv_out, tx_out, norm)
         z = torch.empty((n, Dm), dtype=torch.float32, device=dev)
         z[rows] = z_f
         if mp["n_uni"] > 0:
@@ -1897,8 +1913,45 @@ class NovelDDIEncoder(nn.Module):
             z[uni_rows] = self.uni_fuser(uni)
         return z
 
+    def _finish_fused(self, z_f, mp, n, str_out, kg_out, cv_out, tx_out, norm):
+        """Training path, after the transformer: the fused rows of the multi-modal drugs and, for 'transformer_uni_proj', the
+        projected single modality of the uni-modal ones, in drug order (models.py:781-812)."""
+        if self.fusion != 'transformer_uni_proj':
+            return z_f
+        # the merge through own gather nodes (no indexed assignments: their backward sorts): the single available modality of a
+        # uni-modal drug is row uni_col * n + drug of [str | kg | cv | tx (cell line by cell line)]; the fused and the uni-modal
+        # rows, one after the other, are read back in drug order
+        parts = [z_f]
+        if mp["n_uni"] > 0:
+            uni = ag.gather_rows(torch.cat([str_out, kg_out, cv_out, tx_out], dim=0), mp["uni_flat"])
+            if self.normalize:
+                uni = norm(uni)
+            parts.append(self.uni_fuser(uni))
+        return ag.gather_rows(torch.cat(parts, dim=0) if len(parts) > 1 else z_f, mp["merge_perm"])
+
     def forward(self, batch_drugs, batch_masks, batch_mols, batch_kg, batch_cv, batch_tx_dict, raw_encoder_output=False, **kwargs):
         return self.encode(batch_drugs, batch_masks, batch_mols, batch_kg, batch_cv, batch_tx_dict, raw_encoder_output, **kwargs)
+
+
+class PendingFusion:
+    """One side of a training step stopped in front of the fusion transformer (NovelDDIEncoder.encode(defer_fusion=True)): its
+    live tokens, their plan, and what remains to be done with the fused rows."""
+
+    def __init__(self, tokens, plan, transformer, finish):
+        self.tokens, self.plan, self.transformer, self.finish = tokens, plan, transformer, finish
+
+    def run(self):
+        return self.finish(self.transformer.forward_tokens(self.tokens, self.plan))
+
+    @staticmethod
+    def run_pair(a: "PendingFusion", b: "PendingFusion"):
+        """Both sides through the transformer in ONE pass (every op of it is per token row or per drug: the rows come out as the
+        two passes would give them, with one set of launches, and every parameter receives one gradient instead of two to add)."""
+        tr = a.transformer
+        plan = tr.merged_live_plan(a.plan, b.plan)
+        z = tr.forward_tokens(torch.cat([a.tokens, b.tokens], dim=0), plan)
+        na = a.plan["n"]
+        return a.finish(z[:na]), b.finish(z[na:])
 
 
 class NovelDDIMultilabel(nn.Module):
@@ -1930,12 +1983,21 @@ class NovelDDIMultilabel(nn.Module):
         if self.share_kg_between_sides and 'kg_share' not in kwargs:
             kwargs = dict(kwargs, kg_share={})
 
+        # training: both sides' tokens go through the fusion transformer in one pass (PendingFusion.run_pair; MDG_FUSE_SIDES=0: two)
+        defer = (self.training and torch.is_grad_enabled() and batch_head_mod_masks.is_cuda and os.environ.get("MDG_FUSE_SIDES", "1") != "0"
+                 and 'defer_fusion' not in kwargs)
+
         def enc(b, m):
-            return self.encoder(b['drugs'], m, b['strs'], batch_kg, b['cv'], b['tx'], **kwargs)
+            return self.encoder(b['drugs'], m, b['strs'], batch_kg, b['cv'], b['tx'], **(dict(kwargs, defer_fusion=True) if defer else kwargs))
         z_head = enc(batch_head, batch_head_mod_masks)
         same = (self.reuse_identical_sides and not self.training and batch_head is batch_tail and
                 (batch_head_mod_masks is batch_tail_mod_masks or torch.equal(batch_head_mod_masks, batch_tail_mod_masks)))
         z_tail = z_head if same else enc(batch_tail, batch_tail_mod_masks)
+        if isinstance(z_head, PendingFusion) and isinstance(z_tail, PendingFusion):
+            z_head, z_tail = PendingFusion.run_pair(z_head, z_tail)
+        else:
+            z_head = z_head.run() if isinstance(z_head, PendingFusion) else z_head
+            z_tail = z_tail.run() if isinstance(z_tail, PendingFusion) else z_tail
         if self.normalize:
             norm = ag.l2_normalize if ag.needs_grad(z_head, z_tail) else ops.l2_normalize
             z_head = norm(z_head)
