@@ -1825,7 +1825,7 @@ class NovelDDIEncoder(nn.Module):
                     str_out = self.str_encoder(batch_mols, batch_mols.node_feature.float())["graph_feature"]
             if share_enc:
                 share[skey] = (str_out, s_log, batch_mols)
-        cv_out = self.cv_encoder(batch_cv)
+        cv_out = kwargs['cv_out'] if kwargs.get('cv_out') is not None else self.cv_encoder(batch_cv)     # (embed() encodes both sides' rows in one pass)
         # tx embeddings of absent cell lines are masked tokens: the live-token path never reads them.  In training mode
         # every row goes through the tx encoder, as in the reference: its BatchNorm batch statistics include them.
         skip_absent = compact and not train
@@ -1987,12 +1987,20 @@ class NovelDDIMultilabel(nn.Module):
         defer = (self.training and torch.is_grad_enabled() and batch_head_mod_masks.is_cuda and os.environ.get("MDG_FUSE_SIDES", "1") != "0"
                  and 'defer_fusion' not in kwargs)
 
-        def enc(b, m):
-            return self.encoder(b['drugs'], m, b['strs'], batch_kg, b['cv'], b['tx'], **(dict(kwargs, defer_fusion=True) if defer else kwargs))
-        z_head = enc(batch_head, batch_head_mod_masks)
+        cv_pair = (None, None)
+        if defer and batch_head['cv'].shape[1:] == batch_tail['cv'].shape[1:] and \
+                not any(isinstance(m_, nn.modules.batchnorm._BatchNorm) for m_ in self.encoder.cv_encoder.modules()):
+            # the cell-viability encoder (an MLP with dropout, no batch statistics: per row) over both sides' rows at once
+            nh = batch_head['cv'].shape[0]
+            cv_both = self.encoder.cv_encoder(torch.cat([batch_head['cv'], batch_tail['cv']], dim=0))
+            cv_pair = (cv_both[:nh], cv_both[nh:])
+
+        def enc(b, m, cv=None):
+            return self.encoder(b['drugs'], m, b['strs'], batch_kg, b['cv'], b['tx'], **(dict(kwargs, defer_fusion=True, cv_out=cv) if defer else kwargs))
+        z_head = enc(batch_head, batch_head_mod_masks, cv_pair[0])
         same = (self.reuse_identical_sides and not self.training and batch_head is batch_tail and
                 (batch_head_mod_masks is batch_tail_mod_masks or torch.equal(batch_head_mod_masks, batch_tail_mod_masks)))
-        z_tail = z_head if same else enc(batch_tail, batch_tail_mod_masks)
+        z_tail = z_head if same else enc(batch_tail, batch_tail_mod_masks, cv_pair[1])
         if isinstance(z_head, PendingFusion) and isinstance(z_tail, PendingFusion):
             z_head, z_tail = PendingFusion.run_pair(z_head, z_tail)
         else:
