@@ -1857,6 +1857,8 @@ class NovelDDIEncoder(nn.Module):
                 uni = all_embeds[~batch_masks]
             if self.normalize:
                 uni = norm(uni)
+            if kwargs.get('defer_projector'):        # the caller projects both views' rows in one pass (SimCLR_NovelDDI.forward)
+                return uni
             return self.uni_projector(uni)
         if self.adapt_before_fusion:
             str_out, kg_out, cv_out, tx_out = (self.uni_projector(t) for t in (str_out, kg_out, cv_out, tx_out))

@@ -7,6 +7,9 @@ statistics) and the InfoNCE loss record a tape through madrigal_amd.autograd; fo
 """
 from __future__ import annotations
 
+import os
+
+import torch
 import torch.nn as nn
 
 from . import autograd as ag
@@ -58,10 +61,27 @@ class SimCLR_NovelDDI(nn.Module):
         # both views see the same KG and the KG encoder has neither dropout nor batch statistics: one pass serves both
         # (under autograd the two views' gradients meet in one backward pass, the sum the reference forms from two)
         share = {}
-        e1 = self.base_encoder(drug_indices, batch_mask_1, batch_mols, batch_kg, batch_cv, batch_tx_dict,
-                               raw_encoder_output=self.raw_encoder_output, kg_share=share)
-        e2 = self.base_encoder(drug_indices, batch_mask_2, batch_mols, batch_kg, batch_cv, batch_tx_dict,
-                               raw_encoder_output=self.raw_encoder_output, kg_share=share)
+        enc = self.base_encoder
+        # training, raw encoder output: the per-row stages with dropout that the reference runs once per view -- the cell-viability
+        # encoder and the uni-modal projector (LayerNorm: per row) -- run ONCE over both views' rows (independent masks for the two
+        # halves, as two passes draw them; half the launches and one gradient per parameter).  MDG_FUSE_VIEWS=0: two passes.
+        fuse = (self.raw_encoder_output and _train_path(self) and torch.is_grad_enabled() and os.environ.get("MDG_FUSE_VIEWS", "1") != "0"
+                and batch_cv.is_cuda and not any(isinstance(m, nn.modules.batchnorm._BatchNorm) for mod in (enc.cv_encoder, enc.uni_projector)
+                                                 for m in mod.modules()))
+        if fuse:
+            n = batch_cv.shape[0]
+            cv_both = enc.cv_encoder(torch.cat([batch_cv, batch_cv], dim=0))
+            u1 = enc(drug_indices, batch_mask_1, batch_mols, batch_kg, batch_cv, batch_tx_dict, raw_encoder_output=True, kg_share=share,
+                     cv_out=cv_both[:n], defer_projector=True)
+            u2 = enc(drug_indices, batch_mask_2, batch_mols, batch_kg, batch_cv, batch_tx_dict, raw_encoder_output=True, kg_share=share,
+                     cv_out=cv_both[n:], defer_projector=True)
+            e = enc.uni_projector(torch.cat([u1, u2], dim=0))
+            e1, e2 = e[:u1.shape[0]], e[u1.shape[0]:]
+        else:
+            e1 = enc(drug_indices, batch_mask_1, batch_mols, batch_kg, batch_cv, batch_tx_dict,
+                     raw_encoder_output=self.raw_encoder_output, kg_share=share)
+            e2 = enc(drug_indices, batch_mask_2, batch_mols, batch_kg, batch_cv, batch_tx_dict,
+                     raw_encoder_output=self.raw_encoder_output, kg_share=share)
         run = _run_sequential_train if (_train_path(self) or ag.needs_grad(e1, e2)) else _run_sequential
         aug_1, aug_2 = run(p1, e1), run(p2, e2)
         return aug_1, aug_2, self.contrastive_loss(aug_1, aug_2, batch_too_hard_neg_mask)
