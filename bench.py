@@ -581,15 +581,19 @@ def pretrain_leg(model, bkg, masks_all, args, precision="bf16x3"):
     step = PretrainStep(sim, AdamW(sim.parameters(), lr=1e-5, weight_decay=1e-2), scheduler=sched)
     data = (b["strs"], kgc, b["cv"], b["tx"])
     losses = []
+    import gc
     with M.precision(precision):
         for i in range(4 + args.pretrain_steps):
             if i == 4:
                 torch.cuda.synchronize()
+                gc.collect()
+                gc.freeze()                                  # the earlier legs' objects out of the collector's way: this loop is host-bound
                 t0 = time.perf_counter()
             m1, m2 = draw(range(B))                          # host tensors: the step uploads them (madrigal_amd/hostio.py)
             losses.append(step.step(batch["drugs"], m1, m2, None, data))
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.pretrain_steps
+    gc.unfreeze()
     out = {"metric": "contrastive-pretraining steps/sec", "value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "drugs_per_s": B / dt,
            "n_gpus": 1, "steps": args.pretrain_steps, "warmup": 4, "batch": B, "dtype": "f32 via split-bf16 (bf16x3) MFMA",
            "loss_first_last": [float(losses[0]), float(losses[-1])], "lr_last": sched.last_lr,
