@@ -523,7 +523,8 @@ def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend
     if rank == 0 and world == 1:
         # roofline of the step's dominant kernel, the wide fusion-transformer GEMM (linear_kernel<bf16, 256x256 tile>; 14 of the
         # 69 ms of kernel time, profiles/): one FFN-sized launch at the step's own row count, HIP events on its stream
-        live = int((~batch["masks"]).sum()) + int(model.encoder.num_tx_bottlenecks) * N            # live fusion tokens of one side
+        # live fusion tokens of BOTH sides: the step runs them through the transformer in one pass (NovelDDIMultilabel.embed)
+        live = 2 * (int((~batch["masks"]).sum()) + int(model.encoder.num_tx_bottlenecks) * N)
         d = int(model.encoder.transformer.embed2latent.weight.shape[0])
         x = torch.randn(live, d, device=dev)
         w = torch.randn(d, d, device=dev) * d ** -0.5
