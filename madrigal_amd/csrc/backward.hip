@@ -72,22 +72,30 @@ __global__ __launch_bounds__(256) void colreduce_bn_bwd_kernel(const float* __re
 
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int64_t ldp, float* __restrict__ out,
                                                            int64_t nparts, int64_t cols, float beta) {
-  // 64 columns per block, the partials interleaved over the four thread rows, combined through LDS in a fixed order
-  const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int64_t c = static_cast<int64_t>(blockIdx.x) * 64 + e;
+  // 16 columns per block, the partials interleaved over sixteen thread rows (a launch of cols / 64 blocks with four rows walked a few
+  // hundred partials per thread on 32-96 workgroups: 19 us of latency chain, 58 times per finetune step), combined through LDS in a
+  // fixed order
+  const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * 16 + e;
   float s0 = 0.f, s1 = 0.f;
   if (c < cols) {
     int64_t p = grp;
-    for (; p + 4 < nparts; p += 8) {
+    for (; p + 16 < nparts; p += 32) {
       s0 += part[p * ldp + c];
-      s1 += part[(p + 4) * ldp + c];
+      s1 += part[(p + 16) * ldp + c];
     }
-    for (; p < nparts; p += 4) s0 += part[p * ldp + c];
+    for (; p < nparts; p += 16) s0 += part[p * ldp + c];
   }
-  __shared__ float sh[4][64];
+  __shared__ float sh[16][17];
   sh[grp][e] = s0 + s1;
   __syncthreads();
-  if (grp == 0 && c < cols) out[c] = (beta != 0.f ? beta * out[c] : 0.f) + ((sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]));
+  if (grp == 0 && c < cols) {
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = sh[2 * k][e] + sh[2 * k + 1][e];
+    const float tot = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    out[c] = (beta != 0.f ? beta * out[c] : 0.f) + tot;
+  }
 }
 
 // ---- dx = dy * act'(pre) -------------------------------------------------------------------------------------
@@ -536,7 +544,7 @@ extern "C" int mdg_colsum(const float* x, int64_t ldx, float* out, int64_t rows,
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64)), static_cast<unsigned>(nparts)), dim3(256), 0, st,
                        x, ldx, static_cast<float*>(workspace), rows, cols, slab);
   }
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64))), dim3(256), 0, st,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 16))), dim3(256), 0, st,
                      static_cast<const float*>(workspace), cols, out, nparts, cols, beta);
   MDG_CHECK_LAUNCH("mdg_colsum");
   return MDG_OK;
@@ -617,7 +625,7 @@ static int colreduce(const float* x, int64_t ldx, const float* y, int64_t ldy, c
   const int64_t nparts = mdg_cdiv(rows, 256);
   hipLaunchKernelGGL(colreduce_partial_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64)), static_cast<unsigned>(nparts)), dim3(256), 0, st,
                      x, ldx, y, ldy, center, rstd, ws, rows, cols, mode);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64))), dim3(256), 0, st, static_cast<const float*>(ws), cols, out,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 16))), dim3(256), 0, st, static_cast<const float*>(ws), cols, out,
                      nparts, cols, 0.f);
   return MDG_OK;
 }
@@ -674,9 +682,9 @@ extern "C" int mdg_batchnorm_train_bwd(const float* dy, const float* x, const fl
     float* part2 = part + nparts * cols;
     hipLaunchKernelGGL(colreduce_bn_bwd_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64)), static_cast<unsigned>(nparts)), dim3(256), 0, st, dy, cols, x, cols,
                        stats, stats + cols, part, part2, rows, cols);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64))), dim3(256), 0, st, static_cast<const float*>(part), cols, dbeta, nparts,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 16))), dim3(256), 0, st, static_cast<const float*>(part), cols, dbeta, nparts,
                        cols, 0.f);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 64))), dim3(256), 0, st, static_cast<const float*>(part2), cols, dgamma, nparts,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(cols, 16))), dim3(256), 0, st, static_cast<const float*>(part2), cols, dgamma, nparts,
                        cols, 0.f);
   } else {
     colreduce(dy, cols, nullptr, 0, nullptr, nullptr, dbeta, rows, cols, 0, part, st);
@@ -728,9 +736,9 @@ static int layernorm_bwd_impl(const float* dy, int64_t lddy, const float* x, int
       hipLaunchKernelGGL(layernorm_bwd_kernel<32>, grid, dim3(256), lds, st, dy, lddy, x, ldx, gamma, dx, lddx, part, rows, di, eps, extra, ldextra);
   }
   // dgamma = sum of partial rows [nb, 2d] -> first d columns, dbeta the next d
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(d, 64))), dim3(256), 0, st, static_cast<const float*>(workspace),
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(d, 16))), dim3(256), 0, st, static_cast<const float*>(workspace),
                      2 * d, dgamma, nb, d, 0.f);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(d, 64))), dim3(256), 0, st,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(mdg_cdiv(d, 16))), dim3(256), 0, st,
                      static_cast<const float*>(workspace) + d, 2 * d, dbeta, nb, d, 0.f);
   MDG_CHECK_LAUNCH("mdg_layernorm_bwd");
   return MDG_OK;
