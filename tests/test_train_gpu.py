@@ -1414,6 +1414,50 @@ def test_sharing_dropout_free_encoders_between_sides_equals_two_passes(monkeypat
     assert any(int(v) == 2 for k, v in b0.items() if "num_batches" in k)
 
 
+def test_one_fusion_pass_for_both_sides_equals_two_passes(monkeypatch):
+    """The finetune step runs the head side's and the tail side's tokens through the fusion transformer (and the cell-viability
+    encoder) in ONE pass (NovelDDIMultilabel.embed / PendingFusion.run_pair; the reference makes two, models.py:945-946).  Every op
+    in there is per token row or per drug, so with the dropout off the embeddings of both sides equal the two-pass run BIT FOR BIT
+    (sides with different masks: different token counts, different plans) and loss / gradients agree to summation order."""
+    from madrigal_amd import data as D, models as M
+    from madrigal_amd.optim import AdamW
+    from madrigal_amd.train import FinetuneStep
+    case = ("twosides321", "transformer_uni_proj", 2, "sinusoidal", 4, 64, 256, 2, True, "x-attn", False, False)
+    n, L, seed = 80, 10, 23
+
+    def run(flag):
+        monkeypatch.setenv("MDG_FUSE_SIDES", flag)
+        model, _, batch, bkg, masks = _small_model(M, case, n, L, seed, default_init=True)
+        model = model.cuda().train()
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+        b = D.batch_to(batch, "cuda")
+        kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
+        lab, hd, tl, y = (t.cuda() for t in D.make_labelled_triples(n, L, 300, seed))
+        filler = torch.randn(n, 128, generator=torch.Generator().manual_seed(1)).cuda()
+        m_tail = b["masks"].clone()
+        m_tail[:, 3:] |= torch.rand(n, 16, generator=torch.Generator().manual_seed(2)).cuda() < 0.5
+        with M.precision("f32"):
+            zh, zt = model.embed(b, b, b["masks"], m_tail, kgc, kg_filler=filler)
+            zh, zt = zh.detach().clone(), zt.detach().clone()
+            model.zero_grad()
+            fs = FinetuneStep(model, AdamW(model.parameters(), lr=1e-4))
+            loss = fs.accumulate(b, b, b["masks"], m_tail, kgc, lab, hd, tl, y, kg_filler=filler)
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        return zh, zt, float(loss), grads
+    zh0, zt0, l0, g0 = run("0")
+    zh1, zt1, l1, g1 = run("1")
+    assert torch.equal(zh0, zh1) and torch.equal(zt0, zt1)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    assert set(g0) == set(g1)
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for k, v in g0.items():
+        assert float((g1[k] - v).abs().max()) <= 1e-5 * max(float(v.abs().max()), 1e-2 * gmax), k
+
+
 @pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
 @pytest.mark.parametrize("M,N,K", [(1000, 1300, 1280), (4097, 2048, 1024), (63, 1536, 1100)])
 def test_wide_weight_gradient_tn_product(M, N, K, prec, tol):
