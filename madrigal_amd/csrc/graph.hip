@@ -207,38 +207,66 @@ __global__ __launch_bounds__(256) void hgt_attention_kernel(const HgtArgs p) {
   }
 }
 
+// Eight destinations per workgroup, a half-wave each.  A hub (> HGT_COOP items: a drug with 3.6e4 in-edges has 286) is merged by ALL
+// eight half-waves -- half-wave g takes items g, g + 8, ... in order, the eight partial states are merged in order g = 0..7 -- instead
+// of one half-wave walking its few hundred dependent (m, l, acc) updates while the launch waits for it (the launch's duration WAS its
+// largest hub: 100 us in the inference encode's critical chain).  Fixed orders: deterministic; the branch is uniform per workgroup.
+constexpr int HGT_COOP = 16;
+
+__device__ __forceinline__ void hgt_merge(float& m, float& l, f32x4& acc, float mi, float li, const f32x4& ai) {
+  if (mi == -INFINITY) return;
+  const float mn = fmaxf(m, mi);
+  const float f = (m == -INFINITY) ? 0.f : expf(m - mn), g = expf(mi - mn);
+  l = l * f + li * g;
+  acc = acc * f + ai * g;
+  m = mn;
+}
+
 __global__ __launch_bounds__(256) void hgt_combine_kernel(const float* __restrict__ part_acc, const float* __restrict__ part_ml,
                                                           const int64_t* __restrict__ item_ptr, float* __restrict__ out, int64_t ldo,
                                                           int64_t n_dst, int H, int apply_gelu, float* __restrict__ stats) {
-  const int sub = threadIdx.x & 31;
-  const int64_t v = static_cast<int64_t>(blockIdx.x) * 8 + (threadIdx.x >> 5);
-  if (v >= n_dst) return;
+  __shared__ float sh_acc[8][128];
+  __shared__ float sh_ml[8][32][2];
+  const int sub = threadIdx.x & 31, hw = threadIdx.x >> 5;
   const int h = sub / (32 / H);
-  const int64_t i0 = item_ptr[v], i1 = item_ptr[v + 1];
-  if (i1 - i0 == 1) return;                      // finished by hgt_attention_kernel itself
-  float m = -INFINITY, l = 0.f;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t it = i0; it < i1; ++it) {
-    const float mi = part_ml[(it * H + h) * 2], li = part_ml[(it * H + h) * 2 + 1];
-    if (mi == -INFINITY) continue;
-    const f32x4 ai = *reinterpret_cast<const f32x4*>(part_acc + it * 128 + 4 * sub);
-    const float mn = fmaxf(m, mi);
-    const float f = (m == -INFINITY) ? 0.f : expf(m - mn), g = expf(mi - mn);
-    l = l * f + li * g;
-    acc = acc * f + ai * g;
-    m = mn;
-  }
-  f32x4 o = {0.f, 0.f, 0.f, 0.f};
-  if (l > 0.f) o = acc / (l + 1e-16f);          // torch_geometric.utils.softmax: exp / (sum + 1e-16)
-  if (stats && sub % (32 / H) == 0) {            // kept for the backward pass: alpha_e = exp(a_e - m) / denom
-    stats[(v * H + h) * 2 + 0] = m;
-    stats[(v * H + h) * 2 + 1] = l + 1e-16f;
-  }
-  if (apply_gelu) {
+  const int64_t v0 = static_cast<int64_t>(blockIdx.x) * 8;
+  for (int d = 0; d < 8; ++d) {
+    const int64_t v = v0 + d;
+    if (v >= n_dst) break;                         // (uniform)
+    const int64_t i0 = item_ptr[v], i1 = item_ptr[v + 1];
+    const int64_t cnt = i1 - i0;
+    if (cnt == 1) continue;                        // finished by hgt_attention_kernel itself
+    const bool coop = cnt > HGT_COOP;
+    if (!coop && hw != d) continue;
+    float m = -INFINITY, l = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t it = i0 + (coop ? hw : 0); it < i1; it += (coop ? 8 : 1))
+      hgt_merge(m, l, acc, part_ml[(it * H + h) * 2], part_ml[(it * H + h) * 2 + 1], *reinterpret_cast<const f32x4*>(part_acc + it * 128 + 4 * sub));
+    if (coop) {
+      *reinterpret_cast<f32x4*>(&sh_acc[hw][4 * sub]) = acc;
+      sh_ml[hw][sub][0] = m;
+      sh_ml[hw][sub][1] = l;
+      __syncthreads();
+      if (hw == 0) {
+        m = -INFINITY; l = 0.f; acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < 8; ++g) hgt_merge(m, l, acc, sh_ml[g][sub][0], sh_ml[g][sub][1], *reinterpret_cast<const f32x4*>(&sh_acc[g][4 * sub]));
+      }
+    }
+    if (!coop || hw == 0) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (l > 0.f) o = acc / (l + 1e-16f);          // torch_geometric.utils.softmax: exp / (sum + 1e-16)
+      if (stats && sub % (32 / H) == 0) {            // kept for the backward pass: alpha_e = exp(a_e - m) / denom
+        stats[(v * H + h) * 2 + 0] = m;
+        stats[(v * H + h) * 2 + 1] = l + 1e-16f;
+      }
+      if (apply_gelu) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) o[c] = mdg_gelu(o[c]);
+        for (int c = 0; c < 4; ++c) o[c] = mdg_gelu(o[c]);
+      }
+      *reinterpret_cast<f32x4*>(out + v * ldo + 4 * sub) = o;
+    }
+    if (coop) __syncthreads();                     // the shared partials are free again
   }
-  *reinterpret_cast<f32x4*>(out + v * ldo + 4 * sub) = o;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -291,7 +291,9 @@ def test_hgt_attention_heavy_tail(ops, heads):
     g = torch.Generator().manual_seed(70)
     n_src, n_dst = 900, 40
     e_heavy = 3 * HGT_CHUNK + 17
-    dst = torch.cat([torch.zeros(e_heavy, dtype=torch.int64), torch.randint(2, n_dst, (600,), generator=g), torch.tensor([1])])
+    e_hub = 20 * HGT_CHUNK + 5                             # > 16 work items: merged by the whole workgroup of the combine kernel
+    dst = torch.cat([torch.zeros(e_heavy, dtype=torch.int64), torch.randint(2, n_dst, (600,), generator=g), torch.tensor([1]),
+                     torch.full((e_hub,), 7, dtype=torch.int64)])
     src = torch.randint(0, n_src, (dst.numel(),), generator=g)
     dst[dst == 5] = 6                                    # destination 5 has no edges
     ei = {("a", "r", "b"): torch.stack([src, dst])}
