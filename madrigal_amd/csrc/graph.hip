@@ -240,8 +240,24 @@ __global__ __launch_bounds__(256) void hgt_combine_kernel(const float* __restric
     if (!coop && hw != d) continue;
     float m = -INFINITY, l = 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t it = i0 + (coop ? hw : 0); it < i1; it += (coop ? 8 : 1))
-      hgt_merge(m, l, acc, part_ml[(it * H + h) * 2], part_ml[(it * H + h) * 2 + 1], *reinterpret_cast<const f32x4*>(part_acc + it * 128 + 4 * sub));
+    // four partials in flight per step (each merge is a dependent exp / multiply chain: loads issued one merge at a time left the
+    // walk at a memory latency per item), merged in item order
+    const int64_t step = coop ? 8 : 1;
+    for (int64_t it = i0 + (coop ? hw : 0); it < i1; it += 4 * step) {
+      float mi[4], li[4];
+      f32x4 ai[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t iu = it + u * step;
+        const bool ok = iu < i1;
+        const int64_t ir = ok ? iu : it;
+        mi[u] = ok ? part_ml[(ir * H + h) * 2] : -INFINITY;
+        li[u] = part_ml[(ir * H + h) * 2 + 1];
+        ai[u] = *reinterpret_cast<const f32x4*>(part_acc + ir * 128 + 4 * sub);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) hgt_merge(m, l, acc, mi[u], li[u], ai[u]);
+    }
     if (coop) {
       *reinterpret_cast<f32x4*>(&sh_acc[hw][4 * sub]) = acc;
       sh_ml[hw][sub][0] = m;
@@ -364,18 +380,51 @@ __global__ __launch_bounds__(256) void hgt_attention_bwd_edge_kernel(const HgtBw
 // out[v, 0:width] = sum of part[item, 0:width] over the items of row v, in item order; rows go to out + row_index[v]*ldo
 // (row_index null = v).  width = 128 (dq) or 256 (dk' | dv' = two consecutive kv rows).  skip_single: rows with exactly one
 // item were written by the kernel that produced the partials.
+// A row with more than HGT_COOP items (a hub) is summed by all the workgroup's row groups -- group g takes items g, g + G, ... in
+// order, the G partial sums are added in order g = 0..G-1 -- as in hgt_combine_kernel.
 __global__ __launch_bounds__(256) void hgt_sum_items_kernel(const float* __restrict__ part, const int64_t* __restrict__ item_ptr,
                                                             const int64_t* __restrict__ row_index, float* __restrict__ out, int64_t ldo,
                                                             int64_t n_rows, int width, int skip_single) {
+  __shared__ float sh[8][256];                    // [group][row floats] (G * width = 1024 floats)
   const int lpr = width / 4;                      // lanes per row: 32 or 64
-  const int sub = threadIdx.x % lpr;
-  const int64_t v = static_cast<int64_t>(blockIdx.x) * (256 / lpr) + threadIdx.x / lpr;
-  if (v >= n_rows) return;
-  if (skip_single && item_ptr[v + 1] - item_ptr[v] == 1) return;       // written by the producing kernel
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t it = item_ptr[v]; it < item_ptr[v + 1]; ++it) acc += *reinterpret_cast<const f32x4*>(part + it * width + 4 * sub);
-  const int64_t row = row_index ? row_index[v] : v;
-  *reinterpret_cast<f32x4*>(out + row * ldo + 4 * sub) = acc;
+  const int G = 256 / lpr;                        // rows (= row groups) per workgroup: 8 or 4
+  const int sub = threadIdx.x % lpr, grp = threadIdx.x / lpr;
+  const int64_t v0 = static_cast<int64_t>(blockIdx.x) * G;
+  for (int d = 0; d < G; ++d) {
+    const int64_t v = v0 + d;
+    if (v >= n_rows) break;                        // (uniform)
+    const int64_t i0 = item_ptr[v], i1 = item_ptr[v + 1];
+    const int64_t cnt = i1 - i0;
+    if (skip_single && cnt == 1) continue;         // written by the producing kernel
+    const bool coop = cnt > HGT_COOP;
+    if (!coop && grp != d) continue;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int64_t step = coop ? G : 1;
+    for (int64_t it = i0 + (coop ? grp : 0); it < i1; it += 4 * step) {               // four rows in flight, added in item order
+      f32x4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t iu = it + u * step;
+        r[u] = *reinterpret_cast<const f32x4*>(part + (iu < i1 ? iu : it) * width + 4 * sub);
+        if (iu >= i1) r[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += r[u];
+    }
+    if (coop) {
+      *reinterpret_cast<f32x4*>(&sh[grp][4 * sub]) = acc;
+      __syncthreads();
+      if (grp == 0) {
+        acc = *reinterpret_cast<const f32x4*>(&sh[0][4 * sub]);
+        for (int g = 1; g < G; ++g) acc += *reinterpret_cast<const f32x4*>(&sh[g][4 * sub]);
+      }
+    }
+    if (!coop || grp == 0) {
+      const int64_t row = row_index ? row_index[v] : v;
+      *reinterpret_cast<f32x4*>(out + row * ldo + 4 * sub) = acc;
+    }
+    if (coop) __syncthreads();
+  }
 }
 
 struct HgtSrcArgs {

@@ -330,14 +330,16 @@ def test_hgt_attention_backward_heavy_tail(ops, heads):
     g = torch.Generator().manual_seed(80)
     n_src, n_dst = 500, 300
     hub = 2 * HGT_CHUNK + 9
+    big = 18 * HGT_CHUNK + 3                            # > 16 work items: summed by the whole workgroup (hgt_sum_items_kernel / hgt_combine_kernel)
     dst = torch.cat([torch.zeros(hub, dtype=torch.int64), torch.randint(2, n_dst, (hub,), generator=g), torch.randint(2, n_dst, (900,), generator=g),
-                     torch.tensor([1])])
-    src = torch.cat([torch.randint(0, n_src - 50, (hub,), generator=g), torch.full((hub,), 7), torch.randint(0, n_src - 50, (901,), generator=g)])
+                     torch.tensor([1]), torch.full((big,), 9, dtype=torch.int64), torch.randint(2, n_dst, (big,), generator=g)])
+    src = torch.cat([torch.randint(0, n_src - 50, (hub,), generator=g), torch.full((hub,), 7), torch.randint(0, n_src - 50, (901,), generator=g),
+                     torch.randint(0, n_src - 50, (big,), generator=g), torch.full((big,), 11)])
     dst[dst == 5] = 6                                    # destination 5 has no edges; key rows n_src-50.. have none either
     plan = hgt_plan({("a", "r", "b"): torch.stack([src, dst]).cuda()}, [("a", "r", "b")], {"a": n_src, "b": n_dst}, torch.device("cuda"))
     pd = plan["per_dst"]["b"]
     rev = hgt_reverse_plan(pd)
-    assert int((pd["item_ptr"][1:] - pd["item_ptr"][:-1]).max()) == 3 and int((rev["item_ptr"][1:] - rev["item_ptr"][:-1]).max()) == 3
+    assert int((pd["item_ptr"][1:] - pd["item_ptr"][:-1]).max()) == 19 and int((rev["item_ptr"][1:] - rev["item_ptr"][:-1]).max()) == 19
     q = _rand((n_dst, 128), 81)
     proj = _rand((n_src, 384), 82)
     dout = _rand((n_dst, 128), 83)
