@@ -21,7 +21,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off",       # fp32 parity: no silent fma contraction in epilogues / reductions
-         "-I", INCLUDE]
+         "-I", INCLUDE] + os.environ.get("MDG_EXTRA_HIPCC_FLAGS", "").split()      # diagnostics builds (e.g. -DMDG_RANK_STAMPS)
 
 
 def _sources():

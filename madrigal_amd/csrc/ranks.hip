@@ -424,6 +424,8 @@ __global__ __launch_bounds__(C::TPB) void scatter_kernel(const KIN* __restrict__
 // closed form, so the regions need no histogram).  A second kernel owns one block: it places the block's ranks in an LDS tile
 // and writes the rows of out[i, j] and of the mirrored out[j, i] as whole 512-byte pieces (the diagonal of out included).
 constexpr int BB = 128;                    // block edge
+constexpr int FILL_STRIDE = 32;           // words between two blocks' fill counters: one 128-byte line each (16 counters in one 64-byte line
+                                          // serialise every workgroup's atomics on that line: the bucket sort spent most of its time there)
 constexpr int MAX_BLOCKS = 8192;           // LDS budget of the sorting kernel: N <= 16256; larger N take the direct scatter
 
 // first pair slot of block (bi, bj), bj <= bi: all rows above block row bi, then the blocks left of it
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const KIN* __restri
         while (bi * (bi + 1) / 2 > t) --bi;
         while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
         const int bj = t - bi * (bi + 1) / 2;
-        bdst[t] = block_base(bi, bj, N) + atomicAdd(&fill[seg * n_blocks + t], c) - run;
+        bdst[t] = block_base(bi, bj, N) + atomicAdd(&fill[(seg * n_blocks + t) * FILL_STRIDE], c) - run;
       }
       run += c;
     }
@@ -567,152 +569,404 @@ __global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const KIN* __restri
 }
 
 // ================================================================================================================================
-// OPT-IN path (round 4, MDG_RANKS_MSD=1; OFF by default): ONE adaptive MSD partition + an in-LDS counting sort per bucket, instead of
-// four global LSD passes.  Measured on one MI355X (profiles/r04_rank_msd_experiment.txt): 184 us per 4096^2 outcome on
-// i.i.d. scores against 243 us for the LSD sort -- and SLOWER than it on the bench's own score tensor, because nearly every outcome is
-// handed back: a drug's scores sit around the drug's own level, so (i) they fill two or three of the fixed top-bit coarse bins
-// unevenly and (ii) a bucket draws its keys from the tiles of a few dozen rows, which overflows the per-tile-shard segments that
-// keep the global atomics uncontended.  Capacity-based layouts do not survive row-structured scores; the exact (count + scan)
-// layout of the LSD passes does.  Kept as a tested, bit-exact path for smooth i.i.d.-like score tensors.
+// DEFAULT path up to N = 4097 (round 5): ONE MSD partition with an EXACT layout + an in-LDS counting sort per bucket, instead of four
+// global LSD passes.  Every position in memory comes from a count and a scan -- nothing has a capacity a score tensor could overflow
+// (round 4's capacity-based layouts did, on row-structured scores: DESIGN.md 4e):
 //
-//   msd_hist_kernel      read the keys once: histogram of their top 14 bits per outcome (16 384 coarse bins: sign, exponent, 5
-//                        mantissa bits -- a bin spans 1/32 of a binade, over which any smooth score density is flat)
-//   msd_table_kernel     per outcome: prefix of the coarse counts; a coarse bin with more than Q/8 keys is cut into 2^lg equal
-//                        sub-ranges of its low bits.  bucket(key) = (prefix[c] + sub(key) * (n_c >> lg)) >> log2(Q): monotone in the
-//                        key, ~Q keys per bucket whatever the shape of the distribution (bell-shaped scores put 0.4 % of all keys
-//                        in one coarse bin), with room for 1.5 Q (CAP) keys reserved per bucket
-//   msd_partition_kernel a 16 384-key tile leaves as one run per bucket (sorted by bucket in LDS: slots handed out by LDS atomics,
-//                        no digit matching; run positions inside the bucket's segment by one global atomic per tile and bucket)
-//   msd_offsets_kernel   exclusive scan of the buckets' actual sizes = the rank of each bucket's first key
-//   msd_bucket_kernel    one bucket (<= CAP keys) per workgroup: counting sort on 2 CAP fine bins of the bucket's own key range
-//                        (one returning LDS atomic per key, ~0.5 keys per bin), keys that share a fine bin ordered by (key,
-//                        position) explicitly -- this is what makes ties stable although neither partition nor counting preserves
-//                        arrival order -- then the (rank, position) pairs binned by 128 x 128 output block exactly as the last LSD
-//                        pass did, and rank_block_write_kernel writes whole rows.
+//   msd_minmax / msd_samplehist / msd_table   (all outcomes of the call, three small launches)  a 1-in-S sample of 64-key chunks,
+//                        hashed over the whole triangle (every row and column band is seen: scores are row-structured), gives the
+//                        outcome's key range [lo, hi] and a histogram over 4096 coarse bins LINEAR IN THE KEY between lo and hi.
+//                        bucket(key) = ((keys of the sample below the key's coarse bin) + sub-range(key) * (keys per sub-range))
+//                        * buckets / samples: monotone in the key, ~4096 keys per bucket for any distribution that is smooth over
+//                        1/4096 of its own range.  The sample only steers the BALANCE; the layout below is exact for any table.
+//   msd_count_kernel     per 16 384-key tile: how many of its keys fall in each bucket (u16 counters)
+//   msd_scan_kernel      per bucket: exclusive prefix of the tile counts (= where each tile's run starts inside the bucket) + total
+//   msd_base_kernel      per outcome: exclusive prefix of the bucket totals = the rank of each bucket's first key; an outcome with a
+//                        bucket beyond the bucket sort's LDS room (a point mass of equal keys) is flagged for the LSD kernels
+//   msd_partition_kernel the tile is sorted by bucket in LDS (slots from LDS atomics, no digit matching) and leaves as one run per
+//                        bucket, (key, position) pairs, at base[b] + offs[tile][b]
+//   msd_bucket_kernel    one bucket per workgroup: counting sort on 8192 fine bins of the bucket's own key range, keys that share a
+//                        fine bin ordered by (key, position) explicitly -- this makes ties stable although neither the partition nor
+//                        the counting preserves arrival order -- then (rank, position in block) pairs binned by 128 x 128 output
+//                        block (room from one global atomic per bucket and block; a block's size is known in closed form)
+//   rank_block_write_kernel   whole rows of out[i, j] and of the mirrored block
 //
-// Bytes per key: 4 (histogram) + 4 + 8 (partition) + 8 + 8 (bucket sort) + 8 + 8 (block write) = 48, against ~80 for the four LSD
-// passes, and the kernels run on a FEW outcomes at a time (MDG_RANKS_GROUP) in a workspace that is reused, so that the 67 MB a pass
-// writes per outcome are still in the 256 MB Infinity Cache when the next pass reads them.
-//
-// The payload is q = (i << 16) | j instead of the triangle index p: the same order as p, and no square root to get back (i, j).
-//
-// What the fast path cannot sort it hands back: a bucket that overflows its segment (a point mass of equal keys, a score
-// distribution that is not smooth inside a coarse bin) or a fine bin with more than MSD_TIE_LIMIT keys raises the outcome's flag;
-// flagged outcomes are skipped by the bucket / block-write kernels and sorted by the LSD kernels (launched for every chunk, each
-// workgroup leaving at once unless its outcome is flagged).  Either way the ranks are the same bits.
-constexpr int MSD_CB = 14, MSD_NC = 1 << MSD_CB, MSD_LB = 32 - MSD_CB;
+// Bytes per key: 4 + 4 (count, partition reads) + 8 + 8 (pairs out / in) + 8 + 8 (block pairs) + 8 (ranks) = 48 + ~3 of counters,
+// against ~80 for the LSD passes.  Payload q = (i << 16) | j: ordered like the triangle index, no square root to get (i, j) back.
+// Handed to the LSD kernels (flag per outcome; same bits): a bucket with more than MSD_CAP keys, a fine bin with more than
+// MSD_TIE_LIMIT keys -- point masses, heavy ties.
+constexpr int MSD_N1 = 512, MSD_NC = 4096;   // level-1 slices and level-2 bins of the bucket function
+constexpr int MSD_HDR = 16;               // header words in front of an outcome's tables
+constexpr int MSD_TABLE_WORDS = MSD_HDR + MSD_N1 + MSD_NC;
 constexpr int MSD_NB_MAX = 2048;          // buckets per outcome: a 16 384-key tile then leaves as runs of >= 8 pairs = 64 B on average (measured,
                                           // scripts/micro/run_scatter_bw.hip: runs of 64 B and longer store at 4.7-6.4 TB/s, runs of 32 B at 1.6-2.3)
-constexpr int MSD_QLG = 12, MSD_NF = 8192;   // ~4096 keys per bucket; fine bins of the bucket sort
-// Every counter that many workgroups add to is SHARDED: returning global atomics of all tiles onto one outcome's 2048 bucket counters
-// (8 KB) or 528 block counters (2 KB) ran at the contended rate of the guide's "every workgroup into ONE row" case and WERE the
-// kernels' duration (first version: partition 60 us, bucket sort 111 us per outcome).  A bucket's segment is 8 shards (by tile
-// index), an output block's pair region 32 shards (by bucket index), the coarse histogram 8 copies (by workgroup index).
-constexpr int MSD_SH = 8, MSD_SCAP = 768, MSD_CAP = MSD_SH * MSD_SCAP;     // pairs per shard of a bucket: 8 x 768 = 6144 = 1.5 Q
-constexpr int MSD_BSH = 32, MSD_BREGION = 20480;   // shards of a block's pair region (at most; a power of two with >= 8 buckets per shard) and its
-                                                   // room: 1.25 x the 16384 pairs of a full 128 x 128 block, cut evenly (32 shards: 640 each, 512 +- 22 used)
-constexpr int MSD_TILE = 16384;           // keys per partition tile (1024 threads x 16)
+constexpr int MSD_QLG = 12;               // ~4096 keys per bucket
+constexpr int MSD_NF = 8192;              // fine bins of the bucket sort
+constexpr int MSD_CAP = 6144;             // keys a bucket may hold (LDS room of the bucket sort): 1.5 x the mean
+constexpr int MSD_TILE = 16384;           // keys per count / partition tile (1024 threads x 16)
 constexpr int MSD_TIE_LIMIT = 128;        // keys per fine bin ordered in place; more: LSD fallback
-constexpr int MSD_MAX_BLOCKS = 1536;      // output blocks per outcome on the fast path (3 per thread of the bucket sort)
-constexpr uint32_t MSD_F_SEG = 1u, MSD_F_TOTAL = 2u, MSD_F_TIES = 4u, MSD_F_BLOCK = 8u;      // why an outcome was handed back
+constexpr int MSD_MAX_BLOCKS = 1536;      // output blocks per outcome on this path
+constexpr int MSD_BWORDS = 1024;          // words of the bucket sort's block counters (two u16 per word: room for MSD_MAX_BLOCKS + the dummy block)
+constexpr int MSD_SAMPLE_CHUNKS = 4096;   // 64-key chunks sampled per outcome (262 144 keys: 128 per bucket at N = 4096)
+constexpr int MSD_SAMPLE_WGS = 32;        // 256-thread workgroups per outcome in the two sampling sweeps
+constexpr int MSD_BIG_MAX = 63, MSD_BIG_WORDS = 64;   // buckets beyond MSD_CAP keys per outcome that msd_big_bucket_kernel takes (count + ids)
+constexpr int MSD_BIG_NF = 16384, MSD_BIG_TIES = 4096;
+constexpr uint32_t MSD_F_BUCKET = 1u, MSD_F_TOTAL = 2u, MSD_F_TIES = 4u;      // why an outcome was handed back
 constexpr uint32_t MSD_SKIP = 0xFFFFFFFFu;
 
+struct MsdMap { uint32_t lo, hi, s1, e0, mul, nbt; };
 
-// hist[(outcome * MSD_SH + workgroup % MSD_SH) * MSD_NC + top 14 bits of the key]
-__global__ __launch_bounds__(1024) void msd_hist_kernel(const float* __restrict__ scores, int64_t lds, uint32_t* __restrict__ hist, int N, int64_t M,
-                                                       int64_t span, int src_is_keys) {
-  __shared__ uint32_t cnt[MSD_NC];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int c = tid; c < MSD_NC; c += 1024) cnt[c] = 0;
-  __syncthreads();
-  const int64_t seg = blockIdx.y, wspan = span / 16, base = static_cast<int64_t>(blockIdx.x) * span + wave * wspan;
-  const float* sc = scores + seg * static_cast<int64_t>(N) * lds;
-  if (base < M) {
-    TriWalk w;
-    w.start(base, M);
-    const int steps = static_cast<int>(wspan / 64);
-#pragma unroll 8
-    for (int k = 0; k < steps; ++k) {
-      const int64_t p = base + k * 64 + lane;
-      int i, j;
-      w.lane_pos(lane, i, j);
-      if (p < M) {
-        const float v = sc[static_cast<int64_t>(i) * lds + j];
-        const uint32_t key = src_is_keys ? __builtin_bit_cast(uint32_t, v) : mdg_order_key(v);
-        __hip_atomic_fetch_add(&cnt[key >> MSD_LB], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// per-outcome table: header (lo, hi, s1, multiplier, buckets, e0) | level 1 (MSD_N1 words) | level 2 (MSD_NC words)
+__device__ __forceinline__ MsdMap msd_load_map(const uint32_t* __restrict__ hdr) { return MsdMap{hdr[0], hdr[1], hdr[2], hdr[5], hdr[3], hdr[4]}; }
+
+// Level-1 bins: aligned 2^s1-key slices of the key space ((key >> s1) - (lo >> s1)), the smallest s1 that covers [lo, hi] with at
+// most MSD_N1 of them.  Scores that span many binades get s1 = 23: the slices ARE the binades, so the factor-two steps of the key
+// density at binade boundaries fall on bin boundaries; a narrow score range gets finer slices of its one or two binades.
+__device__ __forceinline__ uint32_t msd_s1_of(uint32_t lo, uint32_t hi) {
+  uint32_t s = 0;
+  while (s < 23u && (hi >> s) - (lo >> s) >= static_cast<uint32_t>(MSD_N1)) ++s;
+  return s;
+}
+
+// level 1: t1[e] = first level-2 bin of slice e | log2(level-2 bins of slice e) << 16 (a slice with many sample keys is cut finer)
+// level 2: t2[c] = (4 x sample keys in the bins before c) << 11 | (4 x sample keys per sub-range of c) << 5 | log2(sub-ranges of c)
+// bucket = (4 x sample keys below the key, taking every bin's keys as evenly spread over its sub-ranges) * buckets / (4 x samples)
+__device__ __forceinline__ uint32_t msd_coarse_of(uint32_t key, const uint32_t* t1, const MsdMap& m, uint32_t& low2, uint32_t& se) {
+  const uint32_t k = key < m.lo ? m.lo : (key > m.hi ? m.hi : key);
+  const uint32_t e1 = t1[(k >> m.s1) - m.e0];
+  se = m.s1 - (e1 >> 16);
+  const uint32_t low1 = k & ((1u << m.s1) - 1u);
+  low2 = low1 & ((1u << se) - 1u);
+  return (e1 & 0xFFFFu) + (low1 >> se);
+}
+
+__device__ __forceinline__ uint32_t msd_bucket_of(uint32_t key, const uint32_t* t1, const uint32_t* t2, const MsdMap& m) {
+  uint32_t low2, se;
+  const uint32_t ent = t2[msd_coarse_of(key, t1, m, low2, se)];
+  const uint32_t lg = ent & 31u, per = (ent >> 5) & 63u;
+  const uint32_t sub = low2 >> (se - lg);                  // lg <= se; lg = 0: low2 >> se = 0
+  const uint32_t b = __umulhi((ent >> 11) + sub * per, m.mul);
+  return b < m.nbt ? b : m.nbt - 1u;
+}
+
+__device__ __forceinline__ int64_t msd_sample_chunk(int64_t g, int64_t S, int64_t n_chunks) {
+  const uint32_t h = static_cast<uint32_t>(g) * 2654435761u;
+  const int64_t c = g * S + static_cast<int64_t>((h >> 7) % static_cast<uint32_t>(S));
+  return c < n_chunks ? c : n_chunks - 1;
+}
+
+// the sampled keys of one outcome, dealt to `n_waves` waves; eight chunk loads in flight per wave
+template <class F>
+__device__ __forceinline__ void msd_sample_sweep(const float* __restrict__ sc, int64_t lds, int64_t M, int src_is_keys, int wave_global, int n_waves,
+                                                 int lane, F&& f) {
+  const int64_t n_chunks = (M + 63) >> 6;
+  const int64_t S = (n_chunks + MSD_SAMPLE_CHUNKS - 1) / MSD_SAMPLE_CHUNKS;
+  const int64_t n_groups = (n_chunks + S - 1) / S;
+  for (int64_t g0 = wave_global; g0 < n_groups; g0 += 8 * n_waves) {
+    float v[8];
+    bool ok[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int64_t g = g0 + static_cast<int64_t>(e) * n_waves;
+      ok[e] = false;
+      v[e] = 0.f;
+      if (g < n_groups) {
+        const int64_t c = msd_sample_chunk(g, S, n_chunks);
+        TriWalk w;
+        w.start(c * 64, M);
+        int i, j;
+        w.lane_pos(lane, i, j);
+        ok[e] = c * 64 + lane < M;
+        if (ok[e]) v[e] = sc[static_cast<int64_t>(i) * lds + j];
       }
-      w.step();
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (ok[e]) f(src_is_keys ? __builtin_bit_cast(uint32_t, v[e]) : mdg_order_key(v[e]));
   }
+}
+
+// mm[2 * outcome] = ~0, mm[2 * outcome + 1] = 0
+__global__ __launch_bounds__(256) void msd_init_minmax_kernel(uint32_t* __restrict__ mm, int L) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l < L) { mm[2 * l] = 0xFFFFFFFFu; mm[2 * l + 1] = 0u; }
+}
+
+// mm[2 * outcome] = smallest sampled key, mm[2 * outcome + 1] = largest
+__global__ __launch_bounds__(256) void msd_minmax_kernel(const float* __restrict__ scores, int64_t lds, uint32_t* __restrict__ mm, int N, int64_t M,
+                                                        int src_is_keys) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t seg = blockIdx.y;
+  const float* sc = scores + seg * static_cast<int64_t>(N) * lds;
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+  msd_sample_sweep(sc, lds, M, src_is_keys, static_cast<int>(blockIdx.x) * 4 + wave, MSD_SAMPLE_WGS * 4, lane, [&](uint32_t key) {
+    kmin = kmin < key ? kmin : key;
+    kmax = kmax > key ? kmax : key;
+  });
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t a = __shfl_xor(kmin, o, 64), c = __shfl_xor(kmax, o, 64);
+    kmin = kmin < a ? kmin : a;
+    kmax = kmax > c ? kmax : c;
+  }
+  if (lane == 0 && kmin <= kmax) {
+    atomicMin(&mm[2 * seg], kmin);
+    atomicMax(&mm[2 * seg + 1], kmax);
+  }
+}
+
+// hist1[outcome * MSD_N1 + level-1 slice of the sampled key]
+__global__ __launch_bounds__(256) void msd_hist1_kernel(const float* __restrict__ scores, int64_t lds, const uint32_t* __restrict__ mm,
+                                                       uint32_t* __restrict__ hist1, int N, int64_t M, int src_is_keys) {
+  __shared__ uint32_t cnt[MSD_N1];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t seg = blockIdx.y;
+  for (int c = tid; c < MSD_N1; c += 256) cnt[c] = 0;
   __syncthreads();
-  uint32_t* h = hist + (seg * MSD_SH + (blockIdx.x % MSD_SH)) * MSD_NC;
-  for (int c = tid; c < MSD_NC; c += 1024) {
+  const float* sc = scores + seg * static_cast<int64_t>(N) * lds;
+  const uint32_t lo = mm[2 * seg], hi = mm[2 * seg + 1];
+  const uint32_t s1 = msd_s1_of(lo, hi), e0 = lo >> s1;
+  msd_sample_sweep(sc, lds, M, src_is_keys, static_cast<int>(blockIdx.x) * 4 + wave, MSD_SAMPLE_WGS * 4, lane, [&](uint32_t key) {
+    __hip_atomic_fetch_add(&cnt[(key >> s1) - e0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  });
+  __syncthreads();
+  uint32_t* h = hist1 + seg * MSD_N1;
+  for (int c = tid; c < MSD_N1; c += 256) {
     const uint32_t v = cnt[c];
     if (v) atomicAdd(&h[c], v);
   }
 }
 
-// table[c] = {keys in the coarse bins before c, (n_c >> lg) << 5 | lg}
-__global__ __launch_bounds__(1024) void msd_table_kernel(const uint32_t* __restrict__ hist, u32x2* __restrict__ table, int qlg) {
-  __shared__ uint32_t wsum[16];
+// header + level-1 table of one outcome: a slice with more than 256 sample keys is cut into 2^k level-2 bins of <= 256 sample keys
+// each (at most MSD_N1 + 2 * 262144 / 256 = 2560 <= MSD_NC bins in all)
+__global__ __launch_bounds__(MSD_N1) void msd_level1_kernel(const uint32_t* __restrict__ hist1, const uint32_t* __restrict__ mm, uint32_t* __restrict__ tables) {
+  __shared__ uint32_t wsum[MSD_N1 / 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t seg = blockIdx.x;
-  uint32_t n[16];
+  uint32_t lo = mm[2 * seg], hi = mm[2 * seg + 1];
+  if (lo > hi) lo = hi = 0u;
+  const uint32_t s1 = msd_s1_of(lo, hi);
+  const uint32_t n = hist1[seg * MSD_N1 + tid];
+  uint32_t lgb = 0;
+  if (n > 256u) {
+    lgb = 32u - static_cast<uint32_t>(__builtin_clz((n + 255u) / 256u - 1u));
+    lgb = lgb > s1 ? s1 : lgb;
+  }
+  const uint32_t bins = 1u << lgb;
+  const uint32_t inc = wave_inclusive(bins, lane);
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t run = inc - bins;
+  for (int w = 0; w < wave; ++w) run += wsum[w];
+  uint32_t* t = tables + seg * MSD_TABLE_WORDS;
+  t[MSD_HDR + tid] = run | (lgb << 16);
+  if (tid == 0) {
+    t[0] = lo;
+    t[1] = hi;
+    t[2] = s1;
+    t[5] = lo >> s1;
+  }
+}
+
+// hist2[outcome * MSD_NC + level-2 bin of the sampled key]
+__global__ __launch_bounds__(256) void msd_hist2_kernel(const float* __restrict__ scores, int64_t lds, const uint32_t* __restrict__ tables,
+                                                       uint32_t* __restrict__ hist2, int N, int64_t M, int src_is_keys) {
+  __shared__ uint32_t cnt[MSD_NC];
+  __shared__ uint32_t t1[MSD_N1];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t seg = blockIdx.y;
+  const uint32_t* t = tables + seg * MSD_TABLE_WORDS;
+  for (int c = tid; c < MSD_NC; c += 256) cnt[c] = 0;
+  for (int c = tid; c < MSD_N1; c += 256) t1[c] = t[MSD_HDR + c];
+  const MsdMap m{t[0], t[1], t[2], t[5], 0u, 0u};
+  __syncthreads();
+  const float* sc = scores + seg * static_cast<int64_t>(N) * lds;
+  msd_sample_sweep(sc, lds, M, src_is_keys, static_cast<int>(blockIdx.x) * 4 + wave, MSD_SAMPLE_WGS * 4, lane, [&](uint32_t key) {
+    uint32_t low2, se;
+    __hip_atomic_fetch_add(&cnt[msd_coarse_of(key, t1, m, low2, se)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  });
+  __syncthreads();
+  uint32_t* h = hist2 + seg * MSD_NC;
+  for (int c = tid; c < MSD_NC; c += 256) {
+    const uint32_t v = cnt[c];
+    if (v) atomicAdd(&h[c], v);
+  }
+}
+
+// level-2 table of one outcome from its sample histogram (+ the multiplier and the bucket count in the header)
+__global__ __launch_bounds__(1024) void msd_table_kernel(const uint32_t* __restrict__ hist2, uint32_t* __restrict__ tables, int nbt) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t t1[MSD_N1];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t seg = blockIdx.x;
+  uint32_t* t = tables + seg * MSD_TABLE_WORDS;
+  if (tid < MSD_N1) t1[tid] = t[MSD_HDR + tid];
+  const uint32_t s1 = t[2];
+  const u32x4 n4 = reinterpret_cast<const u32x4*>(hist2 + seg * MSD_NC)[tid];
+  const uint32_t n[4] = {n4[0], n4[1], n4[2], n4[3]};
+  const uint32_t tot = (n[0] + n[1]) + (n[2] + n[3]);
+  const uint32_t inc = wave_inclusive(tot, lane);
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t run = inc - tot, ns = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) run += wsum[w];
+    ns += wsum[w];
+  }
+  uint32_t unit = ns / static_cast<uint32_t>(nbt) / 8u;      // sub-ranges of at most an eighth of a bucket, and at most 15 sample keys
+  unit = unit < 1u ? 1u : (unit > 15u ? 15u : unit);
+  u32x4 ent;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) n[e] = 0;
-  for (int sh = 0; sh < MSD_SH; ++sh) {
-    const u32x4* h = reinterpret_cast<const u32x4*>(hist + (seg * MSD_SH + sh) * MSD_NC) + tid * 4;
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t c = 4u * static_cast<uint32_t>(tid) + static_cast<uint32_t>(e);
+    int a = 0, b = MSD_N1 - 1;                             // the level-1 slice that owns bin c: the last one whose first bin is <= c
+    while (a < b) {
+      const int mid = (a + b + 1) >> 1;
+      if ((t1[mid] & 0xFFFFu) <= c) a = mid; else b = mid - 1;
+    }
+    const uint32_t se = s1 - (t1[a] >> 16);                // key bits below bin c
+    uint32_t lg = 0;
+    if (n[e] > unit) {
+      const uint32_t parts = (n[e] + unit - 1u) / unit;
+      lg = 32u - static_cast<uint32_t>(__builtin_clz(parts - 1u));          // ceil(log2(parts)), parts >= 2
+      lg = lg > se ? se : lg;
+    }
+    uint32_t per = (4u * n[e]) >> lg;
+    per = per > 63u ? 63u : per;                           // (only when the bin ran out of key bits: heavy ties, handed back anyway)
+    ent[e] = ((4u * run) << 11) | (per << 5) | lg;
+    run += n[e];
+  }
+  reinterpret_cast<u32x4*>(t + MSD_HDR + MSD_N1)[tid] = ent;
+  if (tid == 0) {
+    t[3] = (nbt > 1 && ns > 0u) ? static_cast<uint32_t>((static_cast<uint64_t>(nbt) << 32) / (4ull * ns)) : 0u;      // bucket = umulhi(x, mul), x < 4 ns
+    t[4] = static_cast<uint32_t>(nbt);
+  }
+}
+
+// counts[(outcome * n_tiles + tile) * nbs + bucket] (u16): keys of the tile per bucket
+__global__ __launch_bounds__(1024) void msd_count_kernel(const float* __restrict__ scores, int64_t lds, const uint32_t* __restrict__ tables,
+                                                        uint16_t* __restrict__ counts, int N, int64_t M, int nbs, int src_is_keys) {
+  constexpr int TPB = 1024, ITEMS = 16;
+  __shared__ __attribute__((aligned(16))) uint32_t tab[MSD_N1 + MSD_NC];      // level 1 | level 2
+  __shared__ uint32_t cnt[MSD_NB_MAX];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t seg = blockIdx.y, base = static_cast<int64_t>(blockIdx.x) * MSD_TILE + wave * (MSD_TILE / 16);
+  const float* sc = scores + seg * static_cast<int64_t>(N) * lds;
+  const uint32_t* t = tables + seg * MSD_TABLE_WORDS;
+  float raw[ITEMS];
+  {
+    TriWalk w;
+    w.start(base, M);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const u32x4 x = h[v];
-      n[4 * v] += x[0]; n[4 * v + 1] += x[1]; n[4 * v + 2] += x[2]; n[4 * v + 3] += x[3];
+    for (int k = 0; k < ITEMS; ++k) {
+      int i, j;
+      w.lane_pos(lane, i, j);
+      raw[k] = (base + k * 64 + lane < M) ? sc[static_cast<int64_t>(i) * lds + j] : 0.f;
+      w.step();
     }
   }
-  uint32_t tot = 0;
+  for (int c = tid; c < (MSD_N1 + MSD_NC) / 4; c += TPB) reinterpret_cast<u32x4*>(tab)[c] = reinterpret_cast<const u32x4*>(t + MSD_HDR)[c];
+  const MsdMap m = msd_load_map(t);
+  for (int b = tid; b < nbs; b += TPB) cnt[b] = 0;
+  __syncthreads();
 #pragma unroll
-  for (int e = 0; e < 16; ++e) tot += n[e];
+  for (int k = 0; k < ITEMS; ++k)
+    if (base + k * 64 + lane < M) {
+      const uint32_t key = src_is_keys ? __builtin_bit_cast(uint32_t, raw[k]) : mdg_order_key(raw[k]);
+      __hip_atomic_fetch_add(&cnt[msd_bucket_of(key, tab, tab + MSD_N1, m)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  __syncthreads();
+  uint32_t* dst = reinterpret_cast<uint32_t*>(counts + (seg * gridDim.x + blockIdx.x) * static_cast<int64_t>(nbs));
+  for (int b2 = tid; b2 < nbs / 2; b2 += TPB) dst[b2] = cnt[2 * b2] | (cnt[2 * b2 + 1] << 16);
+}
+
+// offs[(outcome * n_tiles + tile) * nbs + bucket] = keys of the bucket in the tiles before; totals[outcome * nbs + bucket]
+__global__ __launch_bounds__(256) void msd_scan_kernel(const uint16_t* __restrict__ counts, uint32_t* __restrict__ offs, uint32_t* __restrict__ totals,
+                                                      int n_tiles, int nbs) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  const int64_t seg = blockIdx.y;
+  const uint16_t* c = counts + seg * n_tiles * static_cast<int64_t>(nbs) + b;
+  uint32_t* o = offs + seg * n_tiles * static_cast<int64_t>(nbs) + b;
+  uint32_t run = 0;
+  int t = 0;
+  for (; t + 8 <= n_tiles; t += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = c[static_cast<int64_t>(t + e) * nbs];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      o[static_cast<int64_t>(t + e) * nbs] = run;
+      run += v[e];
+    }
+  }
+  for (; t < n_tiles; ++t) {
+    o[static_cast<int64_t>(t) * nbs] = run;
+    run += c[static_cast<int64_t>(t) * nbs];
+  }
+  totals[seg * nbs + b] = run;
+}
+
+// base[outcome * nbs + bucket] = keys in the buckets before.  A bucket beyond the bucket sort's LDS room goes on the outcome's list for
+// msd_big_bucket_kernel (big[outcome * MSD_BIG_WORDS] = count, then the bucket ids); more than MSD_BIG_MAX of them, a bucket of 65 536
+// keys or more (a point mass of equal keys) or a total that is not M raises the outcome's flag
+__global__ __launch_bounds__(1024) void msd_base_kernel(const uint32_t* __restrict__ totals, uint32_t* __restrict__ base, uint32_t* __restrict__ flags,
+                                                       uint32_t* __restrict__ big, int nbs, int64_t M) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t nbig;
+  constexpr int BPT = MSD_NB_MAX / 1024;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t seg = blockIdx.x;
+  if (tid == 0) nbig = 0;
+  uint32_t c[BPT], tot = 0;
+#pragma unroll
+  for (int e = 0; e < BPT; ++e) {
+    const int b = BPT * tid + e;
+    c[e] = b < nbs ? totals[seg * nbs + b] : 0u;
+    tot += c[e];
+  }
   const uint32_t inc = wave_inclusive(tot, lane);
   if (lane == 63) wsum[wave] = inc;
   __syncthreads();
   uint32_t run = inc - tot;
   for (int w = 0; w < wave; ++w) run += wsum[w];
-  const uint32_t unit = 1u << (qlg - 3);                 // sub-ranges of at most Q / 8 keys
-  u32x2* t = table + seg * MSD_NC + tid * 16;
+  bool over = false;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    uint32_t lg = 0;
-    if (n[e] > unit) {
-      const uint32_t parts = (n[e] + unit - 1) >> (qlg - 3);
-      lg = 32 - __builtin_clz(parts - 1);              // ceil(log2(parts)), parts >= 2
-      if (lg > MSD_LB) lg = MSD_LB;
+  for (int e = 0; e < BPT; ++e) {
+    const int b = BPT * tid + e;
+    if (b < nbs) base[seg * nbs + b] = run;
+    run += c[e];
+    if (c[e] > static_cast<uint32_t>(MSD_CAP)) {
+      const uint32_t slot = c[e] < 65536u ? atomicAdd(&nbig, 1u) : static_cast<uint32_t>(MSD_BIG_MAX);
+      if (slot < static_cast<uint32_t>(MSD_BIG_MAX)) big[seg * MSD_BIG_WORDS + 1 + slot] = static_cast<uint32_t>(b);
+      else over = true;
     }
-    t[e] = u32x2{run, ((n[e] >> lg) << 5) | lg};
-    run += n[e];
   }
-}
-
-__device__ __forceinline__ uint32_t msd_bucket_of(uint32_t key, const u32x2* __restrict__ table, int qlg) {
-  const u32x2 ent = table[key >> MSD_LB];
-  const uint32_t lg = ent[1] & 31u;
-  const uint32_t sub = lg ? ((key << MSD_CB) >> (32 - lg)) : 0u;     // the lg bits below the coarse prefix
-  return (ent[0] + sub * (ent[1] >> 5)) >> qlg;
+  if (over) atomicOr(&flags[seg], MSD_F_BUCKET);
+  if (tid == 1023 && static_cast<int64_t>(run) != M) atomicOr(&flags[seg], MSD_F_TOTAL);
+  __syncthreads();
+  if (tid == 0) big[seg * MSD_BIG_WORDS] = nbig < static_cast<uint32_t>(MSD_BIG_MAX) ? nbig : static_cast<uint32_t>(MSD_BIG_MAX);
 }
 
 // Persistent: workgroup x of outcome y takes tiles x, x + gridDim.x, ...; the next tile's scores are in flight (registers) while
-// this one is bucketed.  fill[(outcome * MSD_SH + tile % MSD_SH) * nbs + bucket]; segs[((outcome * nb + bucket) * MSD_SH + shard) * MSD_SCAP + .]
-__global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __restrict__ scores, int64_t lds, const u32x2* __restrict__ table,
-                                                            uint32_t* __restrict__ fill, u32x2* __restrict__ segs, uint32_t* __restrict__ flags,
-                                                            int N, int64_t M, int nb, int nbs, int qlg, int n_tiles, int src_is_keys) {
+// this one is bucketed.  part[outcome * M + base[b] + offs[tile][b] + .]
+__global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __restrict__ scores, int64_t lds, const uint32_t* __restrict__ tables,
+                                                            const uint32_t* __restrict__ offs, const uint32_t* __restrict__ bases,
+                                                            u32x2* __restrict__ part, const uint32_t* __restrict__ flags, int N, int64_t M, int nbs,
+                                                            int n_tiles, int src_is_keys) {
   constexpr int TPB = 1024, ITEMS = 16, BPT = MSD_NB_MAX / TPB;
-  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];       // spair[MSD_TILE] (u32x2) | bcnt[MSD_NB_MAX]
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];       // spair[MSD_TILE] (u32x2) | tab[MSD_N1 + MSD_NC] | bcnt[MSD_NB_MAX]
   __shared__ uint32_t wsum[16];
-  u32x2* spair = reinterpret_cast<u32x2*>(dyn);
-  uint32_t* bcnt = dyn + 2 * MSD_TILE;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t seg = blockIdx.y;
+  if (flags[seg]) return;
+  u32x2* spair = reinterpret_cast<u32x2*>(dyn);
+  uint32_t* tab = dyn + 2 * MSD_TILE;
+  uint32_t* bcnt = tab + MSD_N1 + MSD_NC;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* sc = scores + seg * static_cast<int64_t>(N) * lds;
-  const u32x2* tab = table + seg * MSD_NC;
-  u32x2* dst = segs + seg * static_cast<int64_t>(nb) * MSD_CAP;
+  const uint32_t* t_hdr = tables + seg * MSD_TABLE_WORDS;
+  for (int c = tid; c < (MSD_N1 + MSD_NC) / 4; c += TPB) reinterpret_cast<u32x4*>(tab)[c] = reinterpret_cast<const u32x4*>(t_hdr + MSD_HDR)[c];
+  const MsdMap m = msd_load_map(t_hdr);
+  u32x2* dst = part + seg * M;
   float raw[ITEMS];
   const auto load_tile = [&](int t) {
     const int64_t base = static_cast<int64_t>(t) * MSD_TILE + wave * (MSD_TILE / 16);
@@ -726,13 +980,22 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
       w.step();
     }
   };
+  // where the tile's run of bucket b starts: thread tid owns buckets BPT * tid .. (loaded a tile ahead, like the scores)
+  uint32_t gpos[BPT];
+  const auto load_offsets = [&](int t) {
+#pragma unroll
+    for (int e = 0; e < BPT; ++e) {
+      const int b = BPT * tid + e;
+      gpos[e] = b < nbs ? bases[seg * nbs + b] + offs[(seg * n_tiles + t) * static_cast<int64_t>(nbs) + b] : 0u;
+    }
+  };
   int t = blockIdx.x;
-  if (t < n_tiles) load_tile(t);
+  if (t < n_tiles) { load_tile(t); load_offsets(t); }
   for (; t < n_tiles; t += gridDim.x) {
     const int64_t base = static_cast<int64_t>(t) * MSD_TILE;
-    const int shard = t % MSD_SH;
     for (int b = tid; b < MSD_NB_MAX; b += TPB) bcnt[b] = 0;
     uint32_t key[ITEMS], q[ITEMS], sb[ITEMS];             // sb = slot in the tile's run | bucket << 16
+    uint32_t gcur[BPT];
     {
       TriWalk w;                                           // the walk again, for the positions (the loads took it one tile ahead)
       w.start(base + wave * (MSD_TILE / 16), M);
@@ -744,22 +1007,22 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
         q[k] = (static_cast<uint32_t>(i) << 16) | static_cast<uint32_t>(j);
         w.step();
       }
+#pragma unroll
+      for (int e = 0; e < BPT; ++e) gcur[e] = gpos[e];
     }
-    if (t + static_cast<int>(gridDim.x) < n_tiles) load_tile(t + gridDim.x);
-    __syncthreads();                                       // bcnt zeroed (and the previous tile's copy-out done with it)
+    if (t + static_cast<int>(gridDim.x) < n_tiles) { load_tile(t + gridDim.x); load_offsets(t + gridDim.x); }
+    __syncthreads();                                       // bcnt zeroed, tab loaded (and the previous tile's copy-out done with them)
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
       const int64_t p = base + wave * (MSD_TILE / 16) + k * 64 + lane;
       sb[k] = MSD_SKIP;
       if (p < M) {
-        const uint32_t b = msd_bucket_of(key[k], tab, qlg);
+        const uint32_t b = msd_bucket_of(key[k], tab, tab + MSD_N1, m);
         sb[k] = atomicAdd(&bcnt[b], 1u) | (b << 16);
       }
     }
     __syncthreads();
-    // exclusive scan of the bucket counts, BPT per thread; room for this tile's run in every non-empty bucket's shard: the atomics
-    // are issued here and their results are needed only after the placement
-    uint32_t c4[BPT], st[BPT], old[BPT];
+    uint32_t c4[BPT], st[BPT];                             // exclusive scan of the bucket counts, BPT per thread
     {
       uint32_t tot = 0;
 #pragma unroll
@@ -774,7 +1037,6 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
         st[e] = run;
         bcnt[BPT * tid + e] = run;
         run += c4[e];
-        old[e] = c4[e] ? atomicAdd(&fill[(seg * MSD_SH + shard) * nbs + BPT * tid + e], c4[e]) : 0u;
       }
     }
     __syncthreads();
@@ -782,13 +1044,8 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
     for (int k = 0; k < ITEMS; ++k)
       if (sb[k] != MSD_SKIP) spair[bcnt[sb[k] >> 16] + (sb[k] & 0xFFFFu)] = u32x2{key[k], q[k]};
     __syncthreads();
-    // bcnt[b] becomes (position in the bucket's shard) - (position in LDS)
 #pragma unroll
-    for (int e = 0; e < BPT; ++e)
-      if (c4[e]) {
-        if (old[e] + c4[e] > static_cast<uint32_t>(MSD_SCAP)) atomicOr(&flags[seg], MSD_F_SEG);
-        bcnt[BPT * tid + e] = old[e] - st[e];
-      }
+    for (int e = 0; e < BPT; ++e) bcnt[BPT * tid + e] = gcur[e] - st[e];       // (position in the bucket) - (position in LDS)
     __syncthreads();
     const int n_valid = static_cast<int>(M - base < MSD_TILE ? M - base : MSD_TILE);
 #pragma unroll 4
@@ -796,269 +1053,420 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
       const int idx = k * TPB + tid;
       if (idx >= n_valid) break;
       const u32x2 v = spair[idx];
-      const uint32_t b = msd_bucket_of(v[0], tab, qlg);
-      const uint32_t pos = bcnt[b] + static_cast<uint32_t>(idx);
-      if (pos < static_cast<uint32_t>(MSD_SCAP)) dst[(static_cast<int64_t>(b) * MSD_SH + shard) * MSD_SCAP + pos] = v;
+      dst[bcnt[msd_bucket_of(v[0], tab, tab + MSD_N1, m)] + static_cast<uint32_t>(idx)] = v;
     }
     __syncthreads();                                       // spair / bcnt are read: the next tile may overwrite them
   }
 }
 
-// rbase[b] = keys in the buckets before b; a shard beyond its room or a total that is not M raises the flag
-__global__ __launch_bounds__(1024) void msd_offsets_kernel(const uint32_t* __restrict__ fill, uint32_t* __restrict__ rbase, uint32_t* __restrict__ flags,
-                                                          int nb, int nbs, int64_t M) {
-  __shared__ uint32_t wsum[16];
-  constexpr int BPT = MSD_NB_MAX / 1024;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t seg = blockIdx.x;
-  uint32_t c4[BPT], tot = 0;
-  bool over = false;
-#pragma unroll
-  for (int e = 0; e < BPT; ++e) {
-    const int b = BPT * tid + e;
-    c4[e] = 0;
-    if (b < nb)
-      for (int sh = 0; sh < MSD_SH; ++sh) {
-        const uint32_t c = fill[(seg * MSD_SH + sh) * nbs + b];
-        over = over || c > static_cast<uint32_t>(MSD_SCAP);
-        c4[e] += c;
-      }
-    tot += c4[e];
+// Fine bins of the bucket sorts: on the COMPOSITE (u(key) - u(lo), position).  u is the key itself -- linear in the score inside a binade,
+// logarithmic across binades, which suits the tail buckets of heavy-tailed scores -- EXCEPT in a bucket that reaches towards zero (see init);
+// the one bucket of an outcome that holds scores of both signs: it spans 2^31 keys (every binade down to the denormals, twice) with its scores at the two ends, and bins linear
+// in the key put 1 700 of its 4 000 keys in one bin.  There u is the score as a fixed-point number, round(score * 2^e) with e from the
+// bucket's largest magnitude (|u| <= 2^30): a narrow quantile slice around zero is flat in the score.  Either u is monotone in the key
+// (exact power-of-two scaling, rounding and saturating conversion are monotone; NaN keys are clamped to the largest finite score first),
+// which the ranks need; distinct keys may share a u (scores far below the bucket's largest magnitude), which only costs bin occupancy.
+// The position bits below the key part spread a tie group over several bins in position order (fp32 scores around 6 are 2^-21 apart:
+// 8.4 million of them tie in groups of 2..12), so a bin holds about half a key whatever the tie structure.
+struct MsdFine {
+  int e, sh;
+  uint32_t umin;
+  bool fixed;
+  __device__ __forceinline__ static float score_of(uint32_t key) {
+    const uint32_t kc = key < 0x00800000u ? 0x00800000u : (key > 0xFF7FFFFFu ? 0xFF7FFFFFu : key);      // -FLT_MAX .. FLT_MAX: infinities and NaNs saturate
+    return __builtin_bit_cast(float, (kc & 0x80000000u) ? (kc & 0x7FFFFFFFu) : ~kc);
   }
-  const uint32_t inc = wave_inclusive(tot, lane);
-  if (lane == 63) wsum[wave] = inc;
-  __syncthreads();
-  uint32_t run = inc - tot;
-  for (int w = 0; w < wave; ++w) run += wsum[w];
-#pragma unroll
-  for (int e = 0; e < BPT; ++e) {
-    const int b = BPT * tid + e;
-    if (b < nb) rbase[seg * nbs + b] = run;
-    run += c4[e];
+  __device__ __forceinline__ uint32_t u_of(uint32_t key) const {
+    return fixed ? static_cast<uint32_t>(__float2int_rn(ldexpf(score_of(key), e))) + 0x80000000u : key;
   }
-  if (over) atomicOr(&flags[seg], MSD_F_SEG);
-  if (tid == 1023 && static_cast<int64_t>(run) != M) atomicOr(&flags[seg], MSD_F_TOTAL);
-}
+  // mean = the bucket's mean key.  Fixed point when the bucket holds both signs, or holds one sign with its keys massed at the
+  // large-magnitude end of its key range (a slice that reaches down towards zero through many binades: flat in the score, not in its
+  // logarithm); the key itself otherwise (within a binade the two agree; a heavy tail's bucket is massed at its small-magnitude end)
+  __device__ __forceinline__ void init(uint32_t kmin, uint32_t kmax, float mean, int lgnf) {
+    const float pos = (mean - static_cast<float>(kmin)) / (static_cast<float>(kmax - kmin) + 1.f);
+    fixed = (kmin < 0x80000000u && kmax >= 0x80000000u) || (kmin >= 0x80000000u && pos > 0.6f) || (kmax < 0x80000000u && pos < 0.4f);
+    const float a = fabsf(score_of(kmin)), b = fabsf(score_of(kmax)), m = a > b ? a : b, mn = a > b ? b : a;
+    e = m > 0.f ? 29 - ilogbf(m) : 0;
+    // one sign: no finer than the smallest score's own spacing (u then steps by one between neighbouring fp32 values instead of by
+    // 64: the bins' resolution goes to the position bits, which is what spreads tie groups)
+    if (!(kmin < 0x80000000u && kmax >= 0x80000000u) && mn > 0.f && 23 - ilogbf(mn) < e) e = 23 - ilogbf(mn);
+    umin = u_of(kmin);
+    const uint64_t span = (static_cast<uint64_t>(u_of(kmax) - umin) << 26) | 0x3FFFFFFull;
+    const int bits = 64 - __builtin_clzll(span);
+    sh = bits > lgnf ? bits - lgnf : 0;                    // (span >> sh) < number of fine bins
+  }
+  __device__ __forceinline__ uint32_t operator()(uint32_t key, uint32_t qq) const {
+    const uint64_t c = (static_cast<uint64_t>(u_of(key) - umin) << 26) | (((qq >> 16) << 13) | (qq & 0x1FFFu));
+    return static_cast<uint32_t>(c >> sh);
+  }
+};
 
-// Persistent: workgroup x of outcome y takes buckets x, x + gridDim.x, ...; the next bucket's pairs are in flight (registers) while
-// this one is sorted, its shard sizes were fetched one bucket earlier still.
-// pairs[((outcome * n_blocks + block) * MSD_BSH + bucket % MSD_BSH) * MSD_BCAP + .]; blockfill[(outcome * MSD_BSH + shard) * n_blocks + block]
-template <int NF, int TPB, bool PF>
-__global__ __launch_bounds__(TPB, TPB / 128) void msd_bucket_kernel(const u32x2* __restrict__ segs, const uint32_t* __restrict__ fill, const uint32_t* __restrict__ rbase,
-                                                         u32x2* __restrict__ pairs, uint32_t* __restrict__ blockfill, uint32_t* __restrict__ flags,
-                                                         int N, int nb, int nbs, int n_blocks, int bsh) {
-  constexpr int CAP = MSD_CAP, ITEMS = CAP / TPB, WPT = NF / 2 / TPB, WAVES = TPB / 64;     // NF fine bins, two u16 counters per word
-  constexpr int LGNF = 31 - __builtin_clz(NF), BPT = (MSD_MAX_BLOCKS + TPB - 1) / TPB;
-  static_assert(CAP % TPB == 0 && (NF & (NF - 1)) == 0 && NF % (2 * TPB) == 0 && CAP < 65536, "bucket sort shape");
-  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];       // sorted[CAP] (u32x2) | fc[NF / 2] | bcnt[n_blocks] | bdst[n_blocks]
-  __shared__ uint32_t wsum[WAVES], krange[2];
+// One bucket per workgroup: ranks of its keys, then its (rank, position in block) pairs grouped by 128 x 128 output block, written
+// back CONTIGUOUSLY over the bucket's own range of the pair buffer, plus one directory row: where each block's run starts inside the
+// bucket (u16, packed in pairs; entry n_blocks = the bucket's size).  No global atomics: the first version reserved room in per-block
+// regions with one returning global atomic per bucket and block (1.08 million per outcome, 64 lanes on 64 different lines) and spent
+// a fifth of its time there; the block kernel now GATHERS its runs through the transposed directory instead.
+// Straight-line code: a thread's 12 items all take the same path -- an item behind the bucket's last key counts into a dummy fine
+// bin (NF) and a dummy block (n_blocks) that sort behind everything real -- so there are no per-item branches around the LDS atomics.
+template <int NF>
+__global__ __launch_bounds__(1024, 8) void msd_bucket_kernel(const u32x2* __restrict__ part, const uint32_t* __restrict__ bases,
+                                                           const uint32_t* __restrict__ totals, u32x2* __restrict__ grouped, uint32_t* __restrict__ dir,
+                                                           uint32_t* __restrict__ flags, int64_t M, int nbs, int n_blocks, int dw) {
+  constexpr int TPB = 1024, CAP = MSD_CAP, ITEMS = CAP / TPB, WPT = NF / 2 / TPB, WAVES = TPB / 64;     // NF fine bins, two u16 counters per word
+  constexpr int LGNF = 31 - __builtin_clz(NF), BWPT = MSD_BWORDS / TPB;
+  static_assert(CAP % TPB == 0 && (NF & (NF - 1)) == 0 && NF % (2 * TPB) == 0 && CAP < 65536 && MSD_BWORDS % TPB == 0 && 2 * MSD_BWORDS > MSD_MAX_BLOCKS + 1, "bucket sort shape");
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];       // sorted[CAP] (u32x2) | fc[NF / 2 + 32] | bc[MSD_BWORDS]
+  __shared__ __attribute__((aligned(16))) uint32_t wsum_f[WAVES], wsum_b[WAVES];
+  __shared__ uint32_t krange[2];
+  __shared__ unsigned long long ksum_sh;
+  const int64_t seg = blockIdx.y;
+  const int b = blockIdx.x;
+  if (flags[seg]) return;
+  const int n = static_cast<int>(totals[seg * nbs + b]);
+  if (n > CAP) return;                                     // msd_big_bucket_kernel's
+  const uint32_t rb = bases[seg * nbs + b];
   u32x2* sorted = reinterpret_cast<u32x2*>(dyn);
   uint32_t* fc = dyn + 2 * CAP;
-  uint32_t* bcnt = fc + NF / 2;
-  uint32_t* bdst = bcnt + n_blocks;
+  uint32_t* bc = fc + NF / 2 + 32;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t seg = blockIdx.y;
-  const int stride = gridDim.x;
-  // shard sizes of a bucket as exclusive prefix sums ps[0..SH] (ps[SH] = the bucket's size, clamped shard by shard)
-  const auto shard_sizes = [&](int b, uint32_t (&ps)[MSD_SH + 1]) {
-    ps[0] = 0;
-#pragma unroll
-    for (int sh = 0; sh < MSD_SH; ++sh) {
-      uint32_t c = b < nb ? fill[(seg * MSD_SH + sh) * nbs + b] : 0u;
-      c = c < static_cast<uint32_t>(MSD_SCAP) ? c : static_cast<uint32_t>(MSD_SCAP);
-      ps[sh + 1] = ps[sh] + c;
-    }
-  };
-  const auto load_bucket = [&](int b, const uint32_t (&ps)[MSD_SH + 1], u32x2 (&v)[ITEMS]) {
-    const u32x2* src = segs + (seg * nb + b) * static_cast<int64_t>(CAP);
+  uint32_t key[ITEMS], q[ITEMS], ss[ITEMS];
+#ifdef MDG_RANK_STAMPS
+  uint64_t stamp[10];
+  int n_stamp = 0;
+#define MDG_STAMP() do { uint64_t t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp[n_stamp++] = t_; } while (0)
+#else
+#define MDG_STAMP()
+#endif
+  MDG_STAMP();
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+  {
+    const u32x2* src = part + seg * M + rb;
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
-      const uint32_t idx = static_cast<uint32_t>(k * TPB + tid);
-      v[k] = u32x2{0u, 0u};
-      if (idx < ps[MSD_SH]) {
-        int sh = 0;
-#pragma unroll
-        for (int e = 1; e < MSD_SH; ++e) sh += idx >= ps[e] ? 1 : 0;
-        v[k] = src[sh * MSD_SCAP + (idx - ps[sh])];
-      }
+      const int idx = k * TPB + tid;
+      u32x2 v = u32x2{0xFFFFFFFFu, 0u};
+      if (idx < n) v = src[idx];
+      key[k] = v[0];
+      q[k] = v[1];
     }
-  };
-  uint32_t ps_cur[MSD_SH + 1], ps_nxt[MSD_SH + 1];
-  u32x2 cur[ITEMS];
-  int b = blockIdx.x;
-  if (b >= nb) return;
-  if constexpr (PF) {
-    shard_sizes(b, ps_cur);
-    load_bucket(b, ps_cur, cur);
-    shard_sizes(b + stride, ps_nxt);
   }
-  for (; b < nb; b += stride) {
-    if constexpr (!PF) {
-      shard_sizes(b, ps_cur);
-      load_bucket(b, ps_cur, cur);
-    }
-    const int n = static_cast<int>(ps_cur[MSD_SH]);
-    uint32_t key[ITEMS], q[ITEMS];
+  static_assert(WPT == 4 && BWPT == 1, "one 16-byte access per thread covers the fine counters");
+  reinterpret_cast<u32x4*>(fc)[tid] = u32x4{0u, 0u, 0u, 0u};
+  if (tid < 8) reinterpret_cast<u32x4*>(fc + NF / 2)[tid] = u32x4{0u, 0u, 0u, 0u};
+  bc[tid] = 0;
+  if (tid == 0) { krange[0] = 0xFFFFFFFFu; krange[1] = 0u; ksum_sh = 0ull; }
+  unsigned long long ksum = 0ull;
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k) { key[k] = cur[k][0]; q[k] = cur[k][1]; }
-    const uint32_t rb = rbase[seg * nbs + b];
-    for (int i = tid; i < NF / 2; i += TPB) fc[i] = 0;
-    for (int i = tid; i < n_blocks; i += TPB) bcnt[i] = 0;
-    if (tid == 0) { krange[0] = 0xFFFFFFFFu; krange[1] = 0u; }
+  for (int k = 0; k < ITEMS; ++k) {
+    const bool ok = k * TPB + tid < n;
+    kmin = kmin < key[k] ? kmin : key[k];                 // (an absent item's key is ~0)
+    kmax = (ok && key[k] > kmax) ? key[k] : kmax;
+    ksum += ok ? key[k] : 0u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t a = __shfl_xor(kmin, o, 64), c = __shfl_xor(kmax, o, 64);
+    kmin = kmin < a ? kmin : a;
+    kmax = kmax > c ? kmax : c;
+    ksum += __shfl_xor(ksum, o, 64);
+  }
+  MDG_STAMP();
+  __syncthreads();
+  if (lane == 0 && kmin <= kmax) { atomicMin(&krange[0], kmin); atomicMax(&krange[1], kmax); atomicAdd(&ksum_sh, ksum); }
+  __syncthreads();
+  MDG_STAMP();
+  MsdFine fine_of;
+  fine_of.init(krange[0], krange[1], n > 0 ? static_cast<float>(static_cast<double>(ksum_sh) / n) : 0.f, LGNF);
+  const auto block_of = [](uint32_t qq) -> uint32_t {
+    const uint32_t bi = qq >> 23, bj = (qq & 0xFFFFu) >> 7;
+    return bi * (bi + 1u) / 2u + bj;
+  };
+  // ---- slots: in the key's fine bin (low half of ss) and in its output block's run (high half), one returning LDS atomic each
+  // (items behind the bucket's last key take none: thousands of lanes on one dummy counter serialise)
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    ss[k] = 0u;
+    if (k * TPB + tid < n) {
+      const uint32_t fi = fine_of(key[k], q[k]), blk = block_of(q[k]);
+      const uint32_t fh = 16u * (fi & 1u), bh = 16u * (blk & 1u);
+      const uint32_t fs = (atomicAdd(&fc[fi >> 1], 1u << fh) >> fh) & 0xFFFFu;
+      const uint32_t bs = (atomicAdd(&bc[blk >> 1], 1u << bh) >> bh) & 0xFFFFu;
+      ss[k] = fs | (bs << 16);
+    }
+    if (k % 3 == 2) __builtin_amdgcn_sched_barrier(0);      // three items' atomics in flight at a time (all of them at once spilled registers)
+  }
+  __syncthreads();
+  MDG_STAMP();
+  {   // exclusive scans in place, both behind the same two barriers: fine bins (four words per thread) and blocks (one word per thread)
+    const u32x4 w = reinterpret_cast<const u32x4*>(fc)[tid];
+    const uint32_t x = bc[tid];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int e = 0; e < WPT; ++e) tot += (w[e] & 0xFFFFu) + (w[e] >> 16);
+    const uint32_t totb = (x & 0xFFFFu) + (x >> 16);
+    const uint32_t inc = wave_inclusive(tot, lane), incb = wave_inclusive(totb, lane);
+    if (lane == 63) { wsum_f[wave] = inc; wsum_b[wave] = incb; }
     __syncthreads();
-    // ---- output blocks first: their room in the pair buffer comes from global atomics whose results are needed at the very end
-    // per key: its slot in the bucket's run of its output block (low half) and, later, its slot in its fine bin (high half); the
-    // block and the fine bin themselves are recomputed from q / key where they are needed (registers: two workgroups per CU)
-    uint32_t ss[ITEMS];
-    const auto block_of = [](uint32_t qq) -> uint32_t {
-      const uint32_t bi = qq >> 23, bj = (qq & 0xFFFFu) >> 7;
-      return bi * (bi + 1u) / 2u + bj;
-    };
-    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    uint32_t run = inc - tot, runb = incb - totb;
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-      const int idx = k * TPB + tid;
-      ss[k] = 0u;
-      if (idx < n) {
-        ss[k] = atomicAdd(&bcnt[block_of(q[k])], 1u);
-        kmin = kmin < key[k] ? kmin : key[k];
-        kmax = kmax > key[k] ? kmax : key[k];
+    for (int v4 = 0; v4 < WAVES / 4; ++v4) {                // every wave total, four per LDS read (the same addresses in every lane: broadcast)
+      const u32x4 f4 = reinterpret_cast<const u32x4*>(wsum_f)[v4], b4 = reinterpret_cast<const u32x4*>(wsum_b)[v4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * v4 + e < wave) { run += f4[e]; runb += b4[e]; }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < WPT; ++e) {
+      const uint32_t c0 = w[e] & 0xFFFFu, c1 = w[e] >> 16;
+      o[e] = run | ((run + c0) << 16);
+      run += c0 + c1;
+    }
+    reinterpret_cast<u32x4*>(fc)[tid] = o;
+    bc[tid] = runb | ((runb + (x & 0xFFFFu)) << 16);
+    if (tid == 0) fc[NF / 2] = static_cast<uint32_t>(n);  // fstart(NF) = the bucket's size
+  }
+  __syncthreads();
+  MDG_STAMP();
+  const auto fstart = [&](uint32_t f) -> uint32_t { return (fc[f >> 1] >> (16u * (f & 1u))) & 0xFFFFu; };
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) asm volatile("" : "+v"(key[k]));      // recompute the fine bin per phase instead of keeping 6 more registers live (they spilled)
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    if (k * TPB + tid < n) sorted[fstart(fine_of(key[k], q[k])) + (ss[k] & 0xFFFFu)] = u32x2{key[k], q[k]};
+  }
+  __syncthreads();
+  MDG_STAMP();
+  // keys that share a fine bin: their order is (key, position); everything else is in place already.  Three bin-mates are probed
+  // unconditionally (independent LDS reads, all items' in flight together); a bin with more keeps walking
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) asm volatile("" : "+v"(key[k]));      // recompute the fine bin per phase instead of keeping 6 more registers live (they spilled)
+  bool too_many = false;
+#pragma unroll
+  for (int k0 = 0; k0 < ITEMS; k0 += 3) {                  // three items at a time: 9 probes in flight, registers within 64
+    uint32_t s0[3], c[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const int k = k0 + e;
+      const bool ok = k * TPB + tid < n;
+      const uint32_t fi = ok ? fine_of(key[k], q[k]) : 0u;
+      s0[e] = fstart(fi);
+      c[e] = ok ? fstart(fi + 1u) - s0[e] : 0u;
+    }
+    u32x2 o[3][3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+      for (int mth = 0; mth < 3; ++mth) {                  // a key alone in its bin (most are) reads nothing
+        o[e][mth] = u32x2{0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (c[e] > 1u && static_cast<uint32_t>(mth) < c[e]) o[e][mth] = sorted[s0[e] + mth];
       }
-    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const uint32_t a = __shfl_xor(kmin, o, 64), c = __shfl_xor(kmax, o, 64);
-      kmin = kmin < a ? kmin : a;
-      kmax = kmax > c ? kmax : c;
+    for (int e = 0; e < 3; ++e) {
+      const int k = k0 + e;
+      uint32_t r = 0;
+#pragma unroll
+      for (int mth = 0; mth < 3; ++mth)
+        r += (o[e][mth][0] < key[k] || (o[e][mth][0] == key[k] && o[e][mth][1] < q[k])) ? 1u : 0u;
+      if (c[e] > 3u) {
+        if (c[e] > static_cast<uint32_t>(MSD_TIE_LIMIT)) too_many = true;
+        else
+          for (uint32_t mth = 3; mth < c[e]; ++mth) {
+            const u32x2 x = sorted[s0[e] + mth];
+            r += (x[0] < key[k] || (x[0] == key[k] && x[1] < q[k])) ? 1u : 0u;
+          }
+      }
+      key[k] = rb + s0[e] + r;                             // rank - 1
     }
-    if (lane == 0 && n > 0) { atomicMin(&krange[0], kmin); atomicMax(&krange[1], kmax); }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (too_many) atomicOr(&flags[seg], MSD_F_TIES);
+  __syncthreads();                                       // `sorted` is read: the (rank, position in block) pairs go through it now
+  MDG_STAMP();
+  const auto bstart = [&](uint32_t t) -> uint32_t { return (bc[t >> 1] >> (16u * (t & 1u))) & 0xFFFFu; };
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) asm volatile("" : "+v"(q[k]));        // the same for the block index
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const uint32_t i = q[k] >> 16, j = q[k] & 0xFFFFu;
+    if (k * TPB + tid < n) sorted[bstart(block_of(q[k])) + (ss[k] >> 16)] = u32x2{key[k], ((i & 127u) << 7) | (j & 127u)};
+  }
+  __syncthreads();
+  MDG_STAMP();
+  u32x2* dst = grouped + seg * M + rb;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int idx = k * TPB + tid;
+    if (idx < n) dst[idx] = sorted[idx];
+  }
+  uint32_t* drow = dir + (seg * nbs + b) * static_cast<int64_t>(dw);
+#ifdef MDG_RANK_STAMPS
+  for (int w = tid; w < dw - 22; w += TPB) drow[w] = bc[w];
+  MDG_STAMP();
+  if (tid == 0)
+    for (int e = 0; e < n_stamp; ++e) { drow[dw - 22 + 2 * e] = static_cast<uint32_t>(stamp[e]); drow[dw - 21 + 2 * e] = static_cast<uint32_t>(stamp[e] >> 32); }
+#else
+  for (int w = tid; w < dw; w += TPB) drow[w] = bc[w];
+#endif
+#undef MDG_STAMP
+}
+
+// A bucket beyond the LDS room of msd_bucket_kernel (fewer than 65 536 keys; the bucket function's sub-ranges assume a density that is
+// flat inside a level-2 bin, which a sparse region at the edge of a score distribution is not): the same counting sort, the same
+// output (ranks, pairs grouped by output block over the bucket's own range, one directory row), with the pairs streamed through global
+// memory instead of held in registers and LDS -- sorted pairs into the bucket's range of `grouped`, the grouped (rank, position) pairs
+// back over its range of `part` (every read of the input is done by then), then copied.  One workgroup per listed bucket: a few per
+// outcome at most, so its speed does not matter.
+__global__ __launch_bounds__(1024) void msd_big_bucket_kernel(u32x2* __restrict__ part, const uint32_t* __restrict__ bases, const uint32_t* __restrict__ totals,
+                                                             u32x2* __restrict__ grouped, uint32_t* __restrict__ dir, uint32_t* __restrict__ flags,
+                                                             const uint32_t* __restrict__ big, int64_t M, int nbs, int n_blocks, int dw) {
+  constexpr int TPB = 1024, NF = MSD_BIG_NF, LGNF = 31 - __builtin_clz(NF), WPT = NF / 2 / TPB;
+  __shared__ __attribute__((aligned(16))) uint32_t fc[NF / 2 + 4];       // fine-bin counters, then starts (two u16 per word)
+  __shared__ __attribute__((aligned(16))) uint32_t cur[NF / 2 + 4];      // cursors: start + keys placed so far
+  __shared__ uint32_t bc[MSD_BWORDS], bcur[MSD_BWORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t wsum_f[16], wsum_b[16];
+  __shared__ uint32_t krange[2];
+  __shared__ unsigned long long ksum_sh;
+  const int64_t seg = blockIdx.y;
+  if (flags[seg] || blockIdx.x >= big[seg * MSD_BIG_WORDS]) return;
+  const int b = static_cast<int>(big[seg * MSD_BIG_WORDS + 1 + blockIdx.x]);
+  const int n = static_cast<int>(totals[seg * nbs + b]);
+  const uint32_t rb = bases[seg * nbs + b];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  u32x2* in = part + seg * M + rb;
+  u32x2* tmp = grouped + seg * M + rb;
+  for (int i = tid; i < NF / 2 + 4; i += TPB) fc[i] = 0;
+  bc[tid] = 0;
+  if (tid == 0) { krange[0] = 0xFFFFFFFFu; krange[1] = 0u; ksum_sh = 0ull; }
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+  unsigned long long ksum = 0ull;
+  for (int idx = tid; idx < n; idx += TPB) {
+    const uint32_t kk = in[idx][0];
+    kmin = kmin < kk ? kmin : kk;
+    kmax = kmax > kk ? kmax : kk;
+    ksum += kk;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t a = __shfl_xor(kmin, o, 64), c = __shfl_xor(kmax, o, 64);
+    kmin = kmin < a ? kmin : a;
+    kmax = kmax > c ? kmax : c;
+    ksum += __shfl_xor(ksum, o, 64);
+  }
+  __syncthreads();
+  if (lane == 0 && kmin <= kmax) { atomicMin(&krange[0], kmin); atomicMax(&krange[1], kmax); atomicAdd(&ksum_sh, ksum); }
+  __syncthreads();
+  MsdFine fine_of;
+  fine_of.init(krange[0], krange[1], static_cast<float>(static_cast<double>(ksum_sh) / n), LGNF);
+  const auto block_of = [](uint32_t qq) -> uint32_t {
+    const uint32_t bi = qq >> 23, bj = (qq & 0xFFFFu) >> 7;
+    return bi * (bi + 1u) / 2u + bj;
+  };
+  for (int idx = tid; idx < n; idx += TPB) {
+    const u32x2 v = in[idx];
+    const uint32_t fi = fine_of(v[0], v[1]), blk = block_of(v[1]);
+    atomicAdd(&fc[fi >> 1], 1u << (16u * (fi & 1u)));
+    atomicAdd(&bc[blk >> 1], 1u << (16u * (blk & 1u)));
+  }
+  __syncthreads();
+  {
+    uint32_t w[WPT], tot = 0;
+#pragma unroll
+    for (int e = 0; e < WPT; ++e) { w[e] = fc[tid * WPT + e]; tot += (w[e] & 0xFFFFu) + (w[e] >> 16); }
+    const uint32_t x = bc[tid], totb = (x & 0xFFFFu) + (x >> 16);
+    const uint32_t inc = wave_inclusive(tot, lane), incb = wave_inclusive(totb, lane);
+    if (lane == 63) { wsum_f[wave] = inc; wsum_b[wave] = incb; }
     __syncthreads();
-    uint32_t g_old[BPT], g_run[BPT], g_cnt[BPT];
-    {
-      const int a = tid * BPT;
-      uint32_t s = 0;
+    uint32_t run = inc - tot, runb = incb - totb;
+    for (int v = 0; v < wave; ++v) { run += wsum_f[v]; runb += wsum_b[v]; }
 #pragma unroll
-      for (int e = 0; e < BPT; ++e) { g_cnt[e] = a + e < n_blocks ? bcnt[a + e] : 0u; s += g_cnt[e]; }
-      const uint32_t inc = wave_inclusive(s, lane);
-      if (lane == 63) wsum[wave] = inc;
-      __syncthreads();
-      uint32_t run = inc - s;
-      for (int v = 0; v < wave; ++v) run += wsum[v];
-#pragma unroll
-      for (int e = 0; e < BPT; ++e) {
-        g_run[e] = run;
-        if (a + e < n_blocks) bcnt[a + e] = run;
-        g_old[e] = g_cnt[e] ? atomicAdd(&blockfill[(seg * MSD_BSH + (b & (bsh - 1))) * n_blocks + a + e], g_cnt[e]) : 0u;
-        run += g_cnt[e];
+    for (int e = 0; e < WPT; ++e) {
+      const uint32_t c0 = w[e] & 0xFFFFu, c1 = w[e] >> 16;
+      const uint32_t st = run | ((run + c0) << 16);        // (starts below 65 536: the bucket has fewer keys)
+      fc[tid * WPT + e] = st;
+      cur[tid * WPT + e] = st;
+      run += c0 + c1;
+    }
+    const uint32_t stb = runb | ((runb + (x & 0xFFFFu)) << 16);
+    bc[tid] = stb;
+    bcur[tid] = stb;
+  }
+  __syncthreads();
+  // sorted by fine bin into `tmp`
+  for (int idx = tid; idx < n; idx += TPB) {
+    const u32x2 v = in[idx];
+    const uint32_t fi = fine_of(v[0], v[1]), fh = 16u * (fi & 1u);
+    const uint32_t pos = (atomicAdd(&cur[fi >> 1], 1u << fh) >> fh) & 0xFFFFu;
+    tmp[pos] = v;
+  }
+  __threadfence();
+  __syncthreads();
+  __threadfence();
+  // ranks (a bin's keys ordered by (key, position) by counting), the pair into its output block's run over `in`
+  bool too_many = false;
+  for (int idx = tid; idx < n; idx += TPB) {
+    const u32x2 v = __builtin_nontemporal_load(&tmp[idx]);
+    const uint32_t fi = fine_of(v[0], v[1]);
+    const uint32_t s0 = (fc[fi >> 1] >> (16u * (fi & 1u))) & 0xFFFFu, e0 = (cur[fi >> 1] >> (16u * (fi & 1u))) & 0xFFFFu;
+    uint32_t r = 0;
+    if (e0 - s0 > static_cast<uint32_t>(MSD_BIG_TIES)) too_many = true;
+    else
+      for (uint32_t m = s0; m < e0; ++m) {
+        const u32x2 o = __builtin_nontemporal_load(&tmp[m]);
+        r += (o[0] < v[0] || (o[0] == v[0] && o[1] < v[1])) ? 1u : 0u;
       }
+    const uint32_t blk = block_of(v[1]), bh = 16u * (blk & 1u);
+    const uint32_t bpos = (atomicAdd(&bcur[blk >> 1], 1u << bh) >> bh) & 0xFFFFu;
+    const uint32_t i = v[1] >> 16, j = v[1] & 0xFFFFu;
+    in[bpos] = u32x2{rb + s0 + r, ((i & 127u) << 7) | (j & 127u)};
+  }
+  if (too_many) atomicOr(&flags[seg], MSD_F_TIES);
+  __threadfence();
+  __syncthreads();
+  __threadfence();
+  for (int idx = tid; idx < n; idx += TPB) tmp[idx] = __builtin_nontemporal_load(&in[idx]);
+  uint32_t* drow = dir + (seg * nbs + b) * static_cast<int64_t>(dw);
+  for (int w = tid; w < dw; w += TPB) drow[w] = bc[w];
+}
+
+// startT[(outcome * n_blocks + block) * nbs + bucket] = first pair of the bucket's run of that block in the pair buffer; lenT[.] = its length
+__global__ __launch_bounds__(256) void msd_dir_transpose_kernel(const uint32_t* __restrict__ dir, const uint32_t* __restrict__ bases,
+                                                               uint32_t* __restrict__ startT, uint16_t* __restrict__ lenT, const uint32_t* __restrict__ flags,
+                                                               int nbt, int nbs, int n_blocks, int dw) {
+  __shared__ uint16_t t[64][68];
+  const int64_t seg = blockIdx.z;
+  if (flags[seg]) return;
+  const int tid = threadIdx.x, k0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+  const uint16_t* d16 = reinterpret_cast<const uint16_t*>(dir);
+  for (int e = tid; e < 64 * 65; e += 256) {
+    const int rr = e / 65, kc = e - rr * 65, k = k0 + kc, bb = b0 + rr;
+    t[rr][kc] = (k <= n_blocks && bb < nbt) ? d16[(seg * nbs + bb) * static_cast<int64_t>(2 * dw) + k] : static_cast<uint16_t>(0);
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int kc = e >> 6, rr = e & 63, k = k0 + kc, bb = b0 + rr;
+    if (k < n_blocks && bb < nbt) {
+      const uint32_t s = t[rr][kc];
+      const int64_t o = (seg * n_blocks + k) * static_cast<int64_t>(nbs) + bb;
+      startT[o] = bases[seg * nbs + bb] + s;
+      lenT[o] = static_cast<uint16_t>(t[rr][kc + 1] - s);
     }
-    // ---- counting sort on the fine bins of the bucket's own key range
-    const uint32_t lo = krange[0], range = krange[1] - lo;
-    const int sh = (n > 0 && (range >> LGNF)) ? (32 - __builtin_clz(range) - LGNF) : 0;     // (range >> sh) < NF
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-      const int idx = k * TPB + tid;
-      if (idx < n) {
-        const uint32_t fi = (key[k] - lo) >> sh;
-        const int hs = 16 * (fi & 1u);
-        ss[k] |= ((atomicAdd(&fc[fi >> 1], 1u << hs) >> hs) & 0xFFFFu) << 16;
-      }
-    }
-    __syncthreads();
-    {   // exclusive scan of the NF u16 counters in place (a contiguous run of WPT words per thread): fc holds each bin's first slot
-      uint32_t w[WPT], tot = 0;
-#pragma unroll
-      for (int e = 0; e < WPT; ++e) { w[e] = fc[tid * WPT + e]; tot += (w[e] & 0xFFFFu) + (w[e] >> 16); }
-      const uint32_t inc = wave_inclusive(tot, lane);
-      if (lane == 63) wsum[wave] = inc;                    // (the block scan's readers of wsum are behind the barrier above)
-      __syncthreads();
-      uint32_t run = inc - tot;
-      for (int v = 0; v < wave; ++v) run += wsum[v];
-#pragma unroll
-      for (int e = 0; e < WPT; ++e) {
-        const uint32_t c0 = w[e] & 0xFFFFu, c1 = w[e] >> 16;
-        fc[tid * WPT + e] = run | ((run + c0) << 16);
-        run += c0 + c1;
-      }
-    }
-    __syncthreads();
-    const auto fstart = [&](uint32_t f) -> uint32_t { return f >= static_cast<uint32_t>(NF) ? static_cast<uint32_t>(n) : (fc[f >> 1] >> (16 * (f & 1u))) & 0xFFFFu; };
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-      const int idx = k * TPB + tid;
-      if (idx < n) sorted[fstart((key[k] - lo) >> sh) + (ss[k] >> 16)] = u32x2{key[k], q[k]};
-    }
-    __syncthreads();
-    // keys that share a fine bin: their order is (key, position); everything else is in place already
-    bool too_many = false;
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-      const int idx = k * TPB + tid;
-      if (idx < n) {
-        const uint32_t fi = (key[k] - lo) >> sh, s0 = fstart(fi), c = fstart(fi + 1u) - s0;
-        uint32_t r = 0;
-        if (c > 1u) {
-          if (c > static_cast<uint32_t>(MSD_TIE_LIMIT)) too_many = true;
-          else
-            for (uint32_t m = 0; m < c; ++m) {
-              const u32x2 o = sorted[s0 + m];
-              r += (o[0] < key[k] || (o[0] == key[k] && o[1] < q[k])) ? 1u : 0u;
-            }
-        }
-        key[k] = rb + s0 + r;                              // rank - 1
-      }
-    }
-    if (too_many) atomicOr(&flags[seg], MSD_F_TIES);
-    // ---- (rank, position in block) pairs, block by block, through `sorted` (free now) into the blocks' shards
-    {
-      const int a = tid * BPT;
-#pragma unroll
-      for (int e = 0; e < BPT; ++e)
-        if (g_cnt[e]) {
-          const uint32_t bcap = static_cast<uint32_t>(MSD_BREGION / bsh);
-          const bool fits = g_old[e] + g_cnt[e] <= bcap;
-          if (!fits) atomicOr(&flags[seg], MSD_F_BLOCK);
-          bdst[a + e] = fits ? static_cast<uint32_t>(a + e) * MSD_BREGION + static_cast<uint32_t>(b & (bsh - 1)) * bcap + g_old[e] - g_run[e] : MSD_SKIP;
-        }
-    }
-    __syncthreads();                                       // fix-up reads of `sorted` done; bdst written
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k)
-      if (k * TPB + tid < n) {
-        const uint32_t i = q[k] >> 16, j = q[k] & 0xFFFFu, blk = block_of(q[k]);
-        sorted[bcnt[blk] + (ss[k] & 0xFFFFu)] = u32x2{key[k], (((i & 127u) << 7) | (j & 127u)) | (blk << 14)};
-      }
-    // the per-key registers are dead: the next bucket's pairs leave now (in flight across the copy-out and the next bucket's
-    // block counting), the sizes of the bucket after it too
-    if constexpr (PF) {
-      if (b + stride < nb) load_bucket(b + stride, ps_nxt, cur);
-#pragma unroll
-      for (int e = 0; e <= MSD_SH; ++e) ps_cur[e] = ps_nxt[e];
-      shard_sizes(b + 2 * stride, ps_nxt);
-    }
-    __syncthreads();
-    u32x2* dst = pairs + seg * static_cast<int64_t>(n_blocks) * MSD_BREGION;
-#pragma unroll 4
-    for (int k = 0; k < ITEMS; ++k) {
-      const int idx = k * TPB + tid;
-      if (idx >= n) break;
-      const u32x2 v = sorted[idx];
-      const uint32_t d = bdst[v[1] >> 14];
-      if (d != MSD_SKIP) dst[d + static_cast<uint32_t>(idx)] = u32x2{v[0], v[1] & 16383u};
-    }
-    __syncthreads();                                       // sorted / bcnt / bdst are read: the next bucket may overwrite them
   }
 }
 
-// one 128 x 128 block of the lower triangle from the MSD_BSH shards of its pair region: ranks into an LDS tile, then whole rows of
-// out[i, j] and of the mirrored block (as rank_block_write_kernel)
+// one 128 x 128 block of the lower triangle, gathered from every bucket's run of it (8 lanes per run, the runs' starts and lengths from
+// the transposed directory, staged in LDS first): ranks into an LDS tile, then whole rows of out[i, j] and of the mirrored block
 template <bool VEC>
-__global__ __launch_bounds__(512) void msd_block_write_kernel(const u32x2* __restrict__ pairs, const uint32_t* __restrict__ blockfill, float* __restrict__ out,
-                                                              int64_t ldo, int N, int n_blocks, double denom, const uint32_t* __restrict__ flags, int bsh) {
+__global__ __launch_bounds__(512) void msd_block_gather_kernel(const u32x2* __restrict__ grouped, const uint32_t* __restrict__ startT,
+                                                               const uint16_t* __restrict__ lenT, float* __restrict__ out, int64_t ldo, int N, int64_t M,
+                                                               int nbt, int nbs, int n_blocks, double denom, const uint32_t* __restrict__ flags) {
   constexpr int TPB = 512;
-  __shared__ float tile[BB][BB + 1];
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];       // tile[BB][BB + 1] (float) | st[nbs] | ln[nbs] (u16)
+  float (*tile)[BB + 1] = reinterpret_cast<float (*)[BB + 1]>(dyn);
+  uint32_t* st = dyn + BB * (BB + 1);
+  uint16_t* ln = reinterpret_cast<uint16_t*>(st + nbs);
   const int64_t seg = blockIdx.y;
-  if (flags[seg]) return;                                  // handed to the LSD kernels (no writer of the flags runs beside this kernel)
+  if (flags[seg]) return;
   const int t = blockIdx.x, tid = threadIdx.x;
   int bi = static_cast<int>((sqrtf(8.0f * static_cast<float>(t) + 1.0f) - 1.0f) * 0.5f);
   while (bi * (bi + 1) / 2 > t) --bi;
@@ -1067,50 +1475,60 @@ __global__ __launch_bounds__(512) void msd_block_write_kernel(const u32x2* __res
   const int r0 = bi * BB, c0 = bj * BB;
   const int rcount = N - r0 < BB ? N - r0 : BB;
   const bool diag = bi == bj;
+  {
+    const uint32_t* s_row = startT + (seg * n_blocks + t) * static_cast<int64_t>(nbs);
+    const uint16_t* l_row = lenT + (seg * n_blocks + t) * static_cast<int64_t>(nbs);
+    for (int r = tid; r < nbt; r += TPB) { st[r] = s_row[r]; ln[r] = l_row[r]; }
+  }
   if (diag)
     for (int e = tid; e < BB; e += TPB) tile[e][e] = 0.f;
-  const u32x2* src = pairs + (seg * n_blocks + t) * static_cast<int64_t>(MSD_BREGION);
-  const int bcap = MSD_BREGION / bsh, parts = (bcap + TPB - 1) / TPB;
-  __shared__ uint32_t scnt[MSD_BSH];
-  if (tid < MSD_BSH) scnt[tid] = tid < bsh ? blockfill[(seg * MSD_BSH + tid) * n_blocks + t] : 0u;
   __syncthreads();
-  // the whole region in one flat sweep, two slots (16 B) per load and ten loads in flight per thread: a launch covers few outcomes
-  // (~2 workgroups per CU), so a thread's own loads are what hides the memory latency.  bcap is even: a load never straddles shards.
-  const u32x4* src4 = reinterpret_cast<const u32x4*>(src);
-  (void)parts;
-#pragma unroll 10
-  for (int x = tid; x < MSD_BREGION / 2; x += TPB) {
-    const int sh = (2 * x) / bcap, off = 2 * x - sh * bcap, c = static_cast<int>(scnt[sh]);
-    if (off < c) {
-      const u32x4 v = src4[x];
+  const u32x2* src = grouped + seg * M;
+  const int grp = tid >> 3, l8 = tid & 7;
+  // rank / M: both are integers below 2^24 on this path (N <= 4097), exact in fp32, and the correctly rounded fp32 quotient equals numpy's
+  // float64 quotient rounded to fp32 (|r 2^e - k M| >= 1 keeps r / M away from every fp32 rounding boundary by more than a float64 ulp)
+  const float denom_f = static_cast<float>(denom);
+  const auto put = [&](u32x2 v) {
+    const float val = static_cast<float>(v[0] + 1u) / denom_f;
+    const int r = v[1] >> 7, c = v[1] & 127;
+    tile[r][c] = val;
+    if (diag) tile[c][r] = val;
+  };
+  for (int rbase = 0; rbase < nbt; rbase += 4 * (TPB / 8)) {
+    uint32_t s[4];
+    int len[4];
+    u32x2 v[4];
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-        if (off + h < c) {
-          const float val = static_cast<float>(static_cast<double>(v[2 * h] + 1u) / denom);
-          const int r = v[2 * h + 1] >> 7, cc = v[2 * h + 1] & 127;
-          tile[r][cc] = val;
-          if (diag) tile[cc][r] = val;
-        }
+    for (int u = 0; u < 4; ++u) {
+      const int r = rbase + u * (TPB / 8) + grp;
+      len[u] = r < nbt ? static_cast<int>(ln[r]) : 0;
+      s[u] = r < nbt ? st[r] : 0u;
+      if (l8 < len[u]) v[u] = src[s[u] + l8];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (l8 < len[u]) put(v[u]);
+      for (int l = l8 + 8; l < len[u]; l += 8) put(src[s[u] + l]);
     }
   }
   __syncthreads();
   float* o = out + seg * static_cast<int64_t>(N) * ldo;
-  const int q = tid & 31, rr = tid >> 5;
+  const int qd = tid & 31, rr = tid >> 5;                  // 32 lanes x 4 columns cover a 128-wide row; 16 rows per sweep
   const int ccount = diag ? rcount : BB;
   for (int r = rr; r < rcount; r += TPB / 32) {
     float* row = o + static_cast<int64_t>(r0 + r) * ldo + c0;
-    if (VEC && 4 * q + 3 < ccount) *reinterpret_cast<f32x4*>(row + 4 * q) = f32x4{tile[r][4 * q], tile[r][4 * q + 1], tile[r][4 * q + 2], tile[r][4 * q + 3]};
+    if (VEC && 4 * qd + 3 < ccount) *reinterpret_cast<f32x4*>(row + 4 * qd) = f32x4{tile[r][4 * qd], tile[r][4 * qd + 1], tile[r][4 * qd + 2], tile[r][4 * qd + 3]};
     else
       for (int e = 0; e < 4; ++e)
-        if (4 * q + e < ccount) row[4 * q + e] = tile[r][4 * q + e];
+        if (4 * qd + e < ccount) row[4 * qd + e] = tile[r][4 * qd + e];
   }
   if (diag) return;
   for (int c = rr; c < BB; c += TPB / 32) {
     float* row = o + static_cast<int64_t>(c0 + c) * ldo + r0;
-    if (VEC && 4 * q + 3 < rcount) *reinterpret_cast<f32x4*>(row + 4 * q) = f32x4{tile[4 * q][c], tile[4 * q + 1][c], tile[4 * q + 2][c], tile[4 * q + 3][c]};
+    if (VEC && 4 * qd + 3 < rcount) *reinterpret_cast<f32x4*>(row + 4 * qd) = f32x4{tile[4 * qd][c], tile[4 * qd + 1][c], tile[4 * qd + 2][c], tile[4 * qd + 3][c]};
     else
       for (int e = 0; e < 4; ++e)
-        if (4 * q + e < rcount) row[4 * q + e] = tile[4 * q + e][c];
+        if (4 * qd + e < rcount) row[4 * qd + e] = tile[4 * qd + e][c];
   }
 }
 
@@ -1217,39 +1635,41 @@ static bool rank_use_big(int64_t N) {
   return tile_sw.get() != 8192;
 }
 
-// ---- MSD fast path: eligibility, workspace ------------------------------------------------------------------------------------
+// ---- MSD path: eligibility, workspace ------------------------------------------------------------------------------------------
 struct MsdPlan {
   bool on;
   int group;                 // outcomes per launch group (the group's buffers are reused by the next group: Infinity-Cache resident)
-  int nb, nbs, n_blocks, bsh;   // buckets per outcome; counter stride; output blocks; shards of a block's pair region
-  size_t seg_bytes, pair_bytes, hist_bytes, table_bytes, fill_bytes, rbase_bytes, blockfill_bytes;      // per outcome
-  size_t group_bytes(int g) const { return a256(g * seg_bytes) + a256(g * pair_bytes) + a256(g * table_bytes) + a256(g * rbase_bytes) + a256(g * hist_bytes) +
-                                           a256(g * fill_bytes) + a256(g * blockfill_bytes); }
+  int nbt, nbs, n_blocks, n_tiles;   // buckets per outcome; counter stride (a multiple of 256); output blocks; 16384-key tiles
+  int dw;                    // words of a directory row: n_blocks + 1 u16 entries, padded
+  size_t part_bytes, count_bytes, offs_bytes, tot_bytes, dir_bytes, start_bytes, len_bytes;      // per outcome
+  size_t group_bytes(int g) const { return 2 * a256(g * part_bytes) + a256(g * count_bytes) + a256(g * offs_bytes) + 2 * a256(g * tot_bytes) + a256(g * dir_bytes) + a256(g * start_bytes) + a256(g * len_bytes) + a256(static_cast<size_t>(g) * MSD_BIG_WORDS * 4); }
+  // per call (all outcomes): sample extremes | sample histograms (level 1, level 2) | tables
+  size_t call_bytes(int64_t L) const { return a256(static_cast<size_t>(L) * 8) + a256(static_cast<size_t>(L) * (MSD_N1 + MSD_NC) * 4) + a256(static_cast<size_t>(L) * MSD_TABLE_WORDS * 4); }
 };
 
 static MsdPlan msd_plan(int64_t n_outcomes, int64_t N) {
-  static MdgEnvInt msd_sw{"MDG_RANKS_MSD", 0};             // 1: the adaptive MSD path first, the LSD sort for what it hands back (see the header above)
-  static MdgEnvInt group_sw{"MDG_RANKS_GROUP", 8};         // measured at 4096^2: 1: 249 us per outcome, 2: 216, 8: 184, 16: 188, 32: 198 (LSD: 239)
+  static MdgEnvInt msd_sw{"MDG_RANKS_MSD", 1};             // 0: the four-pass LSD sort only (what larger N and handed-back outcomes take)
+  static MdgEnvInt group_sw{"MDG_RANKS_GROUP", 8};         // outcomes per launch group
   MsdPlan pl{};
   const int64_t M = N * (N - 1) / 2;
-  const int64_t nb = (M >> MSD_QLG) + 1;
-  pl.on = msd_sw.get() != 0 && N >= 2 && nb <= MSD_NB_MAX && rank_blocks_of(N) <= MSD_MAX_BLOCKS;
+  const int64_t nbt = mdg_cdiv(M, int64_t{1} << MSD_QLG);
+  pl.on = msd_sw.get() != 0 && N >= 2 && nbt <= MSD_NB_MAX && rank_blocks_of(N) <= MSD_MAX_BLOCKS;
   if (!pl.on) return pl;
   int g = group_sw.get();
   g = g < 1 ? 1 : g;
   pl.group = static_cast<int>(g < n_outcomes ? g : n_outcomes);
-  pl.nb = static_cast<int>(nb);
-  pl.nbs = (pl.nb + 63) & ~63;
+  pl.nbt = static_cast<int>(nbt);
+  pl.nbs = (pl.nbt + 255) & ~255;
   pl.n_blocks = static_cast<int>(rank_blocks_of(N));
-  pl.seg_bytes = static_cast<size_t>(pl.nb) * MSD_CAP * 8;
-  pl.pair_bytes = static_cast<size_t>(pl.n_blocks) * MSD_BREGION * 8;
-  pl.bsh = 1;
-  while (pl.bsh < MSD_BSH && pl.nb / (2 * pl.bsh) >= 8) pl.bsh *= 2;          // >= 8 buckets per shard of a block's pair region
-  pl.hist_bytes = static_cast<size_t>(MSD_SH) * MSD_NC * 4;
-  pl.table_bytes = static_cast<size_t>(MSD_NC) * 8;
-  pl.fill_bytes = static_cast<size_t>(MSD_SH) * pl.nbs * 4;
-  pl.rbase_bytes = static_cast<size_t>(pl.nbs) * 4;
-  pl.blockfill_bytes = static_cast<size_t>(MSD_BSH) * pl.n_blocks * 4;
+  pl.n_tiles = static_cast<int>(mdg_cdiv(M, MSD_TILE));
+  pl.part_bytes = static_cast<size_t>(M) * 8;
+  pl.count_bytes = static_cast<size_t>(pl.n_tiles) * pl.nbs * 2;
+  pl.offs_bytes = static_cast<size_t>(pl.n_tiles) * pl.nbs * 4;
+  pl.tot_bytes = static_cast<size_t>(pl.nbs) * 4;
+  pl.dw = ((pl.n_blocks + 2) / 2 + 31) & ~31;
+  pl.dir_bytes = static_cast<size_t>(pl.nbs) * pl.dw * 4;
+  pl.start_bytes = static_cast<size_t>(pl.n_blocks) * pl.nbs * 4;
+  pl.len_bytes = static_cast<size_t>(pl.n_blocks) * pl.nbs * 2;
   return pl;
 }
 
@@ -1259,17 +1679,17 @@ static size_t lsd_workspace_bytes(int64_t n_outcomes, int64_t N) {
   const size_t nblk = (M + CfgStd::TILE - 1) / CfgStd::TILE;          // the last pass always runs on 8192-key tiles (the finer table)
   // keys / payloads x 2 | per-tile digit table (histogram path: one; look-back: one status table per pass) | block fill counters | digit totals
   return 4 * a256(static_cast<size_t>(n_outcomes) * M * 4) + 4 * a256(static_cast<size_t>(n_outcomes) * 256 * nblk * 4) +
-         a256(static_cast<size_t>(n_outcomes) * static_cast<size_t>(rank_blocks_of(N)) * 4) + a256(static_cast<size_t>(n_outcomes) * 4 * 256 * 4);
+         a256(static_cast<size_t>(n_outcomes) * static_cast<size_t>(rank_blocks_of(N)) * 4 * FILL_STRIDE) + a256(static_cast<size_t>(n_outcomes) * 4 * 256 * 4);
 }
 
-// flags (one per outcome, live from the fast path to the fallback) | max(LSD scratch of all outcomes, fast-path scratch of one group)
+// flags (one per outcome, live from the MSD path to the fallback) | MSD per-call tables | max(LSD scratch of all outcomes, MSD scratch of one group)
 template <class C>
 static size_t rank_workspace_bytes(int64_t n_outcomes, int64_t N) {
   const size_t lsd = lsd_workspace_bytes<C>(n_outcomes, N);
   const MsdPlan pl = msd_plan(n_outcomes, N);
   if (!pl.on) return lsd;
   const size_t fast = pl.group_bytes(pl.group);
-  return a256(static_cast<size_t>(n_outcomes) * 4) + (lsd > fast ? lsd : fast);
+  return a256(static_cast<size_t>(n_outcomes) * 4) + pl.call_bytes(n_outcomes) + (lsd > fast ? lsd : fast);
 }
 
 extern "C" size_t mdg_rank_normalize_workspace_bytes(int64_t n_outcomes, int64_t N) {
@@ -1286,63 +1706,67 @@ extern "C" int mdg_rank_normalize(const float* scores, float* out, int64_t n_out
   return mdg_rank_normalize_ld(scores, N, out, N, n_outcomes, N, workspace, workspace_bytes, stream);
 }
 
-// the fast path over all outcomes of the call, `group` at a time; raises flags[outcome] for what it leaves to the LSD kernels
-static void msd_run(const MsdPlan& pl, const float* scores, int64_t lds, float* out, int64_t ldo, int64_t n_outcomes, int64_t N, char* ws,
+// the MSD path over all outcomes of the call, `group` at a time; raises flags[outcome] for what it leaves to the LSD kernels
+static void msd_run(const MsdPlan& pl, const float* scores, int64_t lds, float* out, int64_t ldo, int64_t n_outcomes, int64_t N, char* call_ws, char* ws,
                     uint32_t* flags, hipStream_t st, int src_is_keys) {
   const int64_t M = N * (N - 1) / 2;
   const int n_blocks = pl.n_blocks;
   const double denom = static_cast<double>(N) * static_cast<double>(N - 1) / 2.0;
   const int G = pl.group;
+  const unsigned L = static_cast<unsigned>(n_outcomes);
+  // ---- bucket function of every outcome of the call: sample extremes -> sample histogram -> table
+  char* c = call_ws;
+  uint32_t* mm = reinterpret_cast<uint32_t*>(c); c += a256(static_cast<size_t>(L) * 8);
+  uint32_t* hist1 = reinterpret_cast<uint32_t*>(c);
+  uint32_t* hist2 = hist1 + static_cast<size_t>(L) * MSD_N1; c += a256(static_cast<size_t>(L) * (MSD_N1 + MSD_NC) * 4);
+  uint32_t* tables = reinterpret_cast<uint32_t*>(c);
+  hipLaunchKernelGGL(msd_init_minmax_kernel, dim3(static_cast<unsigned>(mdg_cdiv(L, 256))), dim3(256), 0, st, mm, static_cast<int>(L));
+  (void)hipMemsetAsync(hist1, 0, static_cast<size_t>(L) * (MSD_N1 + MSD_NC) * 4, st);
+  hipLaunchKernelGGL(msd_minmax_kernel, dim3(MSD_SAMPLE_WGS, L), dim3(256), 0, st, scores, lds, mm, static_cast<int>(N), M, src_is_keys);
+  hipLaunchKernelGGL(msd_hist1_kernel, dim3(MSD_SAMPLE_WGS, L), dim3(256), 0, st, scores, lds, mm, hist1, static_cast<int>(N), M, src_is_keys);
+  hipLaunchKernelGGL(msd_level1_kernel, dim3(L), dim3(MSD_N1), 0, st, hist1, mm, tables);
+  hipLaunchKernelGGL(msd_hist2_kernel, dim3(MSD_SAMPLE_WGS, L), dim3(256), 0, st, scores, lds, tables, hist2, static_cast<int>(N), M, src_is_keys);
+  hipLaunchKernelGGL(msd_table_kernel, dim3(L), dim3(1024), 0, st, hist2, tables, pl.nbt);
+  // ---- group buffers
   char* p = ws;
-  u32x2* segs = reinterpret_cast<u32x2*>(p); p += a256(G * pl.seg_bytes);
-  u32x2* pairs = reinterpret_cast<u32x2*>(p); p += a256(G * pl.pair_bytes);
-  u32x2* table = reinterpret_cast<u32x2*>(p); p += a256(G * pl.table_bytes);
-  uint32_t* rbase = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.rbase_bytes);
-  char* zero0 = p;                                                                  // hist | fill | blockfill: zeroed per group
-  uint32_t* hist = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.hist_bytes);
-  uint32_t* fill = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.fill_bytes);
-  uint32_t* blockfill = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.blockfill_bytes);
-  const size_t zero_bytes = static_cast<size_t>(p - zero0);
-  const int n_tiles = static_cast<int>(mdg_cdiv(M, MSD_TILE));
-  static MdgEnvInt hwg_sw{"MDG_RANKS_HIST_WGS", 512};
-  // bucket sort: 2 = 512 threads, one bucket per workgroup (default: 184 us per 4096^2 outcome); 0 = 1024 threads, persistent, the next
-  // bucket prefetched (201); 1 = 512 + prefetch; 3 = 1024, one bucket per workgroup
-  static MdgEnvInt variant_sw{"MDG_RANKS_BUCKET_VARIANT", 2};
-  const size_t part_lds = static_cast<size_t>(2 * MSD_TILE + MSD_NB_MAX) * 4;
-  const size_t bucket_lds = static_cast<size_t>(2 * MSD_CAP + MSD_NF / 2 + 2 * n_blocks) * 4;
+  u32x2* part = reinterpret_cast<u32x2*>(p); p += a256(G * pl.part_bytes);
+  u32x2* pairs = reinterpret_cast<u32x2*>(p); p += a256(G * pl.part_bytes);
+  uint16_t* counts = reinterpret_cast<uint16_t*>(p); p += a256(G * pl.count_bytes);
+  uint32_t* offs = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.offs_bytes);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.tot_bytes);
+  uint32_t* bases = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.tot_bytes);
+  uint32_t* dir = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.dir_bytes);
+  uint32_t* startT = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.start_bytes);
+  uint16_t* lenT = reinterpret_cast<uint16_t*>(p); p += a256(G * pl.len_bytes);
+  uint32_t* big = reinterpret_cast<uint32_t*>(p); p += a256(static_cast<size_t>(G) * MSD_BIG_WORDS * 4);
+  const size_t part_lds = static_cast<size_t>(2 * MSD_TILE + MSD_N1 + MSD_NC + MSD_NB_MAX) * 4;
+  const size_t bucket_lds = static_cast<size_t>(2 * MSD_CAP + MSD_NF / 2 + 32 + MSD_BWORDS) * 4;
+  const size_t gather_lds = static_cast<size_t>(BB * (BB + 1) + pl.nbs + pl.nbs / 2) * 4;
   const bool vec = ldo % 4 == 0 && mdg_aligned16(out);
-  static MdgEnvInt pwg_sw{"MDG_RANKS_PART_WGS", 256}, bwg_sw{"MDG_RANKS_BUCKET_WGS", 512};   // persistent workgroups of a launch (all outcomes of the group)
+  static MdgEnvInt pwg_sw{"MDG_RANKS_PART_WGS", 256};      // persistent partition workgroups of a launch (all outcomes of the group)
   for (int64_t s0 = 0; s0 < n_outcomes; s0 += G) {
     const unsigned g = static_cast<unsigned>(n_outcomes - s0 < G ? n_outcomes - s0 : G);
     const float* sc = scores + s0 * N * lds;
     float* o = out + s0 * N * ldo;
     uint32_t* fl = flags + s0;
-    unsigned pw = static_cast<unsigned>(mdg_cdiv(pwg_sw.get(), g)), bw = static_cast<unsigned>(mdg_cdiv(bwg_sw.get(), g));
-    pw = pw < 1u ? 1u : (pw > static_cast<unsigned>(n_tiles) ? static_cast<unsigned>(n_tiles) : pw);
-    bw = bw < 1u ? 1u : (bw > static_cast<unsigned>(pl.nb) ? static_cast<unsigned>(pl.nb) : bw);
-    (void)hipMemsetAsync(zero0, 0, zero_bytes, st);
-    // two histogram workgroups per CU over the whole group: a wave keeps 8 x 256 B of scores in flight, a CU then 64 KB
-    int64_t hw = mdg_cdiv(hwg_sw.get(), g);
-    hw = hw < 1 ? 1 : (hw > mdg_cdiv(M, 1024) ? mdg_cdiv(M, 1024) : hw);
-    const int64_t span = (mdg_cdiv(M, hw) + 1023) & ~static_cast<int64_t>(1023);
-    hipLaunchKernelGGL(msd_hist_kernel, dim3(static_cast<unsigned>(hw), g), dim3(1024), 0, st, sc, lds, hist, static_cast<int>(N), M, span, src_is_keys);
-    hipLaunchKernelGGL(msd_table_kernel, dim3(g), dim3(1024), 0, st, hist, table, MSD_QLG);
-    hipLaunchKernelGGL(msd_partition_kernel, dim3(pw, g), dim3(1024), part_lds, st, sc, lds, table, fill, segs, fl, static_cast<int>(N), M, pl.nb, pl.nbs,
-                       MSD_QLG, n_tiles, src_is_keys);
-    hipLaunchKernelGGL(msd_offsets_kernel, dim3(g), dim3(1024), 0, st, fill, rbase, fl, pl.nb, pl.nbs, M);
-    switch (variant_sw.get()) {
-#define MDG_BUCKET_LAUNCH(T, P, GRID)                                                                                                                       \
-  hipLaunchKernelGGL((msd_bucket_kernel<MSD_NF, T, P>), dim3(GRID, g), dim3(T), bucket_lds, st, segs, fill, rbase, pairs, blockfill, fl, static_cast<int>(N), pl.nb, \
-                     pl.nbs, n_blocks, pl.bsh)
-      case 0: MDG_BUCKET_LAUNCH(1024, true, bw); break;
-      case 1: MDG_BUCKET_LAUNCH(512, true, bw); break;
-      case 3: MDG_BUCKET_LAUNCH(1024, false, static_cast<unsigned>(pl.nb)); break;
-      default: MDG_BUCKET_LAUNCH(512, false, static_cast<unsigned>(pl.nb)); break;
-#undef MDG_BUCKET_LAUNCH
-    }
+    const uint32_t* tb = tables + s0 * MSD_TABLE_WORDS;
+    unsigned pw = static_cast<unsigned>(mdg_cdiv(pwg_sw.get(), g));
+    pw = pw < 1u ? 1u : (pw > static_cast<unsigned>(pl.n_tiles) ? static_cast<unsigned>(pl.n_tiles) : pw);
+    hipLaunchKernelGGL(msd_count_kernel, dim3(static_cast<unsigned>(pl.n_tiles), g), dim3(1024), 0, st, sc, lds, tb, counts, static_cast<int>(N), M, pl.nbs, src_is_keys);
+    hipLaunchKernelGGL(msd_scan_kernel, dim3(static_cast<unsigned>(pl.nbs / 256), g), dim3(256), 0, st, counts, offs, totals, pl.n_tiles, pl.nbs);
+    hipLaunchKernelGGL(msd_base_kernel, dim3(g), dim3(1024), 0, st, totals, bases, fl, big, pl.nbs, M);
+    hipLaunchKernelGGL(msd_partition_kernel, dim3(pw, g), dim3(1024), part_lds, st, sc, lds, tb, offs, bases, part, fl, static_cast<int>(N), M, pl.nbs, pl.n_tiles,
+                       src_is_keys);
+    hipLaunchKernelGGL((msd_bucket_kernel<MSD_NF>), dim3(static_cast<unsigned>(pl.nbt), g), dim3(1024), bucket_lds, st, part, bases, totals, pairs, dir, fl, M,
+                       pl.nbs, n_blocks, pl.dw);
+    hipLaunchKernelGGL(msd_big_bucket_kernel, dim3(MSD_BIG_MAX, g), dim3(1024), 0, st, part, bases, totals, pairs, dir, fl, big, M, pl.nbs, n_blocks, pl.dw);
+    hipLaunchKernelGGL(msd_dir_transpose_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_blocks, 64)), static_cast<unsigned>(mdg_cdiv(pl.nbt, 64)), g), dim3(256), 0, st,
+                       dir, bases, startT, lenT, fl, pl.nbt, pl.nbs, n_blocks, pl.dw);
     const dim3 bgrid(static_cast<unsigned>(n_blocks), g);
-    if (vec) hipLaunchKernelGGL(msd_block_write_kernel<true>, bgrid, dim3(512), 0, st, pairs, blockfill, o, ldo, static_cast<int>(N), n_blocks, denom, fl, pl.bsh);
-    else hipLaunchKernelGGL(msd_block_write_kernel<false>, bgrid, dim3(512), 0, st, pairs, blockfill, o, ldo, static_cast<int>(N), n_blocks, denom, fl, pl.bsh);
+    if (vec) hipLaunchKernelGGL(msd_block_gather_kernel<true>, bgrid, dim3(512), gather_lds, st, pairs, startT, lenT, o, ldo, static_cast<int>(N), M, pl.nbt, pl.nbs,
+                                n_blocks, denom, fl);
+    else hipLaunchKernelGGL(msd_block_gather_kernel<false>, bgrid, dim3(512), gather_lds, st, pairs, startT, lenT, o, ldo, static_cast<int>(N), M, pl.nbt, pl.nbs,
+                            n_blocks, denom, fl);
   }
 }
 
@@ -1359,25 +1783,26 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
     return MDG_EWORKSPACE;
   }
   char* ws = static_cast<char*>(workspace);
-  // MSD fast path first (round 4); `only` = its per-outcome flags: the LSD kernels below then touch the flagged outcomes alone
+  // MSD path first; `only` = its per-outcome flags: the LSD kernels below then touch the flagged outcomes alone
   const uint32_t* only = nullptr;
   const MsdPlan pl = msd_plan(n_outcomes, N);
   if (pl.on) {
     static bool attr_done = false;
     if (!attr_done) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_bucket_kernel<MSD_NF, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_bucket_kernel<MSD_NF, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_bucket_kernel<MSD_NF, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_bucket_kernel<MSD_NF, 512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_bucket_kernel<MSD_NF>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_block_gather_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_block_gather_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       attr_done = true;
     }
     uint32_t* flags = reinterpret_cast<uint32_t*>(ws);
     ws += a256(static_cast<size_t>(n_outcomes) * 4);
+    char* call_ws = ws;
+    ws += pl.call_bytes(n_outcomes);
     (void)hipMemsetAsync(flags, 0, static_cast<size_t>(n_outcomes) * 4, st);
-    msd_run(pl, scores, lds, out, ldo, n_outcomes, N, ws, flags, st, src_is_keys);
+    msd_run(pl, scores, lds, out, ldo, n_outcomes, N, call_ws, ws, flags, st, src_is_keys);
     only = flags;
-    static MdgEnvInt nofb_sw{"MDG_RANKS_NO_FALLBACK", 0};   // diagnostics (timing the fast path alone): flagged outcomes are then left unranked
+    static MdgEnvInt nofb_sw{"MDG_RANKS_NO_FALLBACK", 0};   // diagnostics (timing the MSD path alone): flagged outcomes are then left unranked
     if (nofb_sw.get()) { MDG_CHECK_LAUNCH("mdg_rank_normalize"); return MDG_OK; }
   }
   const size_t kb = a256(static_cast<size_t>(n_outcomes) * M * 4);
@@ -1389,7 +1814,7 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
   const int nblk3 = static_cast<int>(mdg_cdiv(M, CfgStd::TILE));
   const size_t hb = a256(static_cast<size_t>(n_outcomes) * 256 * nblk3 * 4);       // one per-tile digit table
   uint32_t* fill = reinterpret_cast<uint32_t*>(ws + 4 * kb + 4 * hb);
-  const size_t fb = a256(static_cast<size_t>(n_outcomes) * static_cast<size_t>(rank_blocks_of(N)) * 4);
+  const size_t fb = a256(static_cast<size_t>(n_outcomes) * static_cast<size_t>(rank_blocks_of(N)) * 4 * FILL_STRIDE);
   uint32_t* ghist = reinterpret_cast<uint32_t*>(ws + 4 * kb + 4 * hb + fb);        // [4 passes][outcomes][256]
   const int64_t n_blocks = rank_blocks_of(N);
   static MdgEnvInt direct_sw{"MDG_RANKS_DIRECT", 0};        // 1: the last pass stores the ranks one by one (the large-N path) at any N
@@ -1438,7 +1863,7 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
       hipLaunchKernelGGL((scatter_kernel<C, false, false, u16, u8>), grid, dim3(TPB), 0, st, reinterpret_cast<const u16*>(kin), pin, reinterpret_cast<u8*>(kout), pout,
                          offs, out, ldo, static_cast<int>(N), M, nblk, 0, denom, stat, gcur, only);
     else if (blocked) {
-      if (!lb) (void)hipMemsetAsync(fill, 0, static_cast<size_t>(n_outcomes) * n_blocks * 4, st);
+      if (!lb) (void)hipMemsetAsync(fill, 0, static_cast<size_t>(n_outcomes) * n_blocks * 4 * FILL_STRIDE, st);
       u32x2* pairs = reinterpret_cast<u32x2*>(k0);            // pass 3 reads k1 / p1
       hipLaunchKernelGGL((rank_blocks_kernel<CfgStd, u8>), grid3, dim3(CfgStd::TPB), blocks_lds, st, reinterpret_cast<const u8*>(kin), pin, offs, pairs, fill,
                          static_cast<int>(N), M, nblk3, static_cast<int>(n_blocks), stat, gcur, only);

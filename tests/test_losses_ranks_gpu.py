@@ -210,10 +210,7 @@ def test_ranks_fast_path_over_score_distributions(ops, monkeypatch, kind, N):
     flags = []
     out = ops.rank_normalize(dev, fallback_flags=flags)
     handed = sum(int((f != 0).sum()) for f in flags)
-    # "narrow": 8 389 distinct fp32 values inside ONE coarse bin -- the equal sub-ranges of that bin's low bits are mostly empty,
-    # the rest overflow: the documented limit of the bucket function (smooth inside 1/32 of a binade; a support that ends with a
-    # dense step in the middle of such a bin is the other case); handed back, same bits
-    assert flags and handed == (L if kind == "narrow" else 0), (kind, [f.tolist() for f in flags])
+    assert flags and handed == 0, (kind, [f.tolist() for f in flags])      # (tie groups of 134 equal keys included: "narrow" at N = 1500)
     assert np.array_equal(out.cpu().numpy(), O.rank_normalize(s))
     set_switch(monkeypatch, "MDG_RANKS_MSD", "0")
     flags2 = []
