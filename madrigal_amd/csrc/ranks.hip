@@ -129,18 +129,30 @@ __device__ __forceinline__ void store_tile_histogram(const uint32_t (*cnt)[256],
   }
 }
 
+// The LSD kernels sort either every outcome of the call (only == nullptr: outcome = the grid's y / x index) or, behind the MSD path, the
+// outcomes it flagged: only[0] = how many, only[1..] = which (msd_flag_list_kernel); the grid then has one or two rows that walk the list,
+// so that a call in which nothing was flagged launches a few hundred workgroups that leave at once instead of one per tile and outcome
+// (LIST is a template parameter: without a list the body is straight-line code -- as a loop it cost the sort 17 %: registers, occupancy)
+#define MDG_SEG_BEGIN(LIST, only, IDX, STRIDE)                                                                                                         \
+  for (int64_t seg_it_ = (IDX); LIST ? seg_it_ < static_cast<int64_t>((only)[0]) : seg_it_ == static_cast<int64_t>(IDX); seg_it_ += (STRIDE)) {       \
+    const int64_t seg = LIST ? static_cast<int64_t>((only)[1 + seg_it_]) : seg_it_;
+#define MDG_SEG_END(LIST) \
+    if (LIST) __syncthreads(); \
+    else break;            \
+  }
+
 // keys of the strict lower triangle in p order + the tile histogram of the lowest digit
-template <class C>
+template <bool LIST, class C>
 __global__ __launch_bounds__(C::TPB) void extract_keys_kernel(const float* __restrict__ scores, int64_t lds, uint32_t* __restrict__ keys,
-                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ ghist, int N, int64_t M, int nblk,
-                                                           int src_is_keys, const uint32_t* __restrict__ only) {
+                                                           uint32_t* __restrict__ hist, int N, int64_t M, int nblk, int src_is_keys,
+                                                           const uint32_t* __restrict__ only) {
   MDG_RANK_USING(C);
   __shared__ uint32_t cnt[WAVES][256];
-  if (only && !only[blockIdx.y]) return;      // LSD fallback behind the MSD fast path: flagged outcomes only
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  MDG_SEG_BEGIN(LIST, only, blockIdx.y, gridDim.y)
   for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
   __syncthreads();
-  const int64_t seg = blockIdx.y, base = static_cast<int64_t>(blockIdx.x) * TILE;
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * TILE;
   const float* sc = scores + seg * static_cast<int64_t>(N) * lds;
   uint32_t key[ITEMS];
   // (i, j) of the wave's first position by the closed form, once; every later position by stepping along the rows
@@ -165,42 +177,24 @@ __global__ __launch_bounds__(C::TPB) void extract_keys_kernel(const float* __res
     wj += 64;                                              // the wave's next 64 positions (wave-uniform walk)
     while (wj >= wi) { wj -= wi; ++wi; }
   }
-  if (ghist) {
-    // look-back passes: the outcome's digit totals of ALL FOUR passes (a digit histogram does not depend on the order of the keys):
-    // wave-private counters, one atomic per tile, pass and digit.  ghist[(pass * outcomes + seg) * 256 + d]
-    const int64_t n_seg = gridDim.y;
-#pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
-      wave_digit_counts(key, 8 * pass, cnt[wave]);
-      __syncthreads();
-      if (tid < 256) {
-        uint32_t c = 0;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) { c += cnt[w][tid]; cnt[w][tid] = 0; }
-        if (tid == 255 && base + TILE > M) c -= static_cast<uint32_t>(base + TILE - M);
-        if (c) atomicAdd(&ghist[(pass * n_seg + seg) * 256 + tid], c);
-      }
-      __syncthreads();
-    }
-  } else {
-    wave_digit_counts(key, 0, cnt[wave]);
-    __syncthreads();
-    store_tile_histogram<C>(cnt, hist, seg, nblk, base, M);
-  }
+  wave_digit_counts(key, 0, cnt[wave]);
+  __syncthreads();
+  store_tile_histogram<C>(cnt, hist, seg, nblk, base, M);
+  MDG_SEG_END(LIST)
 }
 
 // KT: what the previous pass left of the key -- the bits below the current digit are sorted already and are not carried along:
 // pass 1 writes the upper 16 bits (uint16_t), pass 2 the upper 8 (uint8_t); `shift` = position of the current digit inside a KT
-template <class C, class KT>
+template <bool LIST, class C, class KT>
 __global__ __launch_bounds__(C::TPB) void histogram_kernel(const KT* __restrict__ keys, uint32_t* __restrict__ hist, int64_t M,
                                                            int nblk, int shift, const uint32_t* __restrict__ only) {
   MDG_RANK_USING(C);
   __shared__ uint32_t cnt[WAVES][256];
-  if (only && !only[blockIdx.y]) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  MDG_SEG_BEGIN(LIST, only, blockIdx.y, gridDim.y)
   for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
   __syncthreads();
-  const int64_t seg = blockIdx.y, base = static_cast<int64_t>(blockIdx.x) * TILE;
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * TILE;
   uint32_t key[ITEMS];
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
@@ -210,44 +204,7 @@ __global__ __launch_bounds__(C::TPB) void histogram_kernel(const KT* __restrict_
   wave_digit_counts(key, shift, cnt[wave]);
   __syncthreads();
   store_tile_histogram<C>(cnt, hist, seg, nblk, base, M);
-}
-
-// ---- tile offsets without the histogram / scan launches: decoupled look-back ------------------------------------------------
-// A scatter needs, per digit d, the number of keys with digit d in the tiles before it.  Instead of a histogram kernel + a scan
-// kernel per pass (a fourth of the bytes of a pass, two launches), every tile publishes its own digit counts in status[tile][d]
-// (flag AGGREGATE), walks back over its predecessors adding their counts until it meets one that already knows its inclusive
-// prefix (flag INCLUSIVE), then publishes its own inclusive prefix.  One 32-bit word carries flag and value, written and read
-// with relaxed agent-scope atomics (sc1: L2-coherent, no fence needed for a self-contained word: MI355X_MICROARCH.md, granules).
-// A tile waits only for tiles with a LOWER index of the same outcome, which were dispatched before it (blockIdx.x fastest) and wait
-// only for still lower ones; polls are bounded (a lost word must not hang the card: the result is then wrong, loudly, in the tests).
-// The digit totals of a pass (its exclusive scan over the 256 digits = where each digit's run starts) come from a global
-// histogram the PREVIOUS pass (the key extraction for pass 0) accumulates with one atomic per tile and digit.
-constexpr uint32_t LB_AGG = 1u << 30, LB_INC = 2u << 30, LB_VAL = (1u << 30) - 1;
-constexpr unsigned LB_SPIN_LIMIT = 1u << 22;
-
-// step 1, as early as the tile knows its digit counts (a cheap counting sweep in front of the ranking): successors can add them
-__device__ __forceinline__ void lookback_publish(uint32_t* __restrict__ status_seg, int blk, int d, uint32_t local) {
-  __hip_atomic_store(status_seg + static_cast<int64_t>(blk) * 256 + d, local | (blk == 0 ? LB_INC : LB_AGG), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// step 2, as late as the offsets are needed (after the ranking): by then the predecessors published long ago and most of them
-// already hold their inclusive prefix, so the walk is one or two loads deep instead of as deep as the set of co-resident tiles
-__device__ __forceinline__ uint32_t lookback_walk(uint32_t* __restrict__ status_seg, int blk, int d, uint32_t local) {
-  if (blk == 0) return 0;
-  uint32_t prefix = 0;
-  for (int t = blk - 1; t >= 0; --t) {
-    const uint32_t* theirs = status_seg + static_cast<int64_t>(t) * 256 + d;
-    uint32_t v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0;
-    while ((v >> 30) == 0 && ++spins < LB_SPIN_LIMIT) {
-      __builtin_amdgcn_s_sleep(2);
-      v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    prefix += v & LB_VAL;
-    if ((v >> 30) == 2u) break;
-  }
-  __hip_atomic_store(status_seg + static_cast<int64_t>(blk) * 256 + d, (prefix + local) | LB_INC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return prefix;
+  MDG_SEG_END(LIST)
 }
 
 // exclusive scan over the 256 digits held one per thread by threads 0..255 (4 waves): step 1 inside a wave ...
@@ -262,10 +219,11 @@ __device__ __forceinline__ uint32_t wave_inclusive(uint32_t v, int lane) {
 
 // exclusive scan of the 256*nblk counters of one outcome, in place; one workgroup per outcome, coalesced: every wave owns a
 // contiguous range and walks it 256 counters (16 bytes per lane) at a time, the next group's load issued before the scan of this one
+template <bool LIST>
 __global__ __launch_bounds__(1024) void scan_kernel(uint32_t* __restrict__ hist, int nblk, const uint32_t* __restrict__ only) {
   __shared__ uint32_t part[16];
-  if (only && !only[blockIdx.x]) return;
-  u32x4* h = reinterpret_cast<u32x4*>(hist + static_cast<int64_t>(blockIdx.x) * 256 * nblk);
+  MDG_SEG_BEGIN(LIST, only, blockIdx.x, gridDim.x)
+  u32x4* h = reinterpret_cast<u32x4*>(hist + seg * 256 * nblk);
   const int total = 64 * nblk;                                  // groups of 4 counters
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int per = ((total + 15) / 16 + 63) / 64 * 64;           // groups per wave, a multiple of 64
@@ -297,29 +255,28 @@ __global__ __launch_bounds__(1024) void scan_kernel(uint32_t* __restrict__ hist,
     if (t < b) h[t] = u32x4{e0, e0 + v[0], e0 + v[0] + v[1], e0 + v[0] + v[1] + v[2]};
     run += __shfl(inc, 63, 64);
   }
+  MDG_SEG_END(LIST)
 }
 
 // KIN / KOUT: key representation read / written (see histogram_kernel): the output drops the digit this pass sorts by when
 // KOUT is narrower than KIN (`shift` must then be 0 within KIN ... the current digit is its low byte, or bits 8..15 for pass 1)
-template <class C, bool FIRST, bool LAST, class KIN = uint32_t, class KOUT = uint32_t>
+template <bool LIST, class C, bool FIRST, bool LAST, class KIN = uint32_t, class KOUT = uint32_t>
 __global__ __launch_bounds__(C::TPB) void scatter_kernel(const KIN* __restrict__ keys_in, const uint32_t* __restrict__ pay_in,
                                                       KOUT* __restrict__ keys_out, uint32_t* __restrict__ pay_out,
                                                       const uint32_t* __restrict__ offsets, float* __restrict__ out, int64_t ldo, int N,
-                                                      int64_t M, int nblk, int shift, double denom, uint32_t* __restrict__ status,
-                                                      const uint32_t* __restrict__ ghist, const uint32_t* __restrict__ only) {
-  // offsets != null: tile offsets from the histogram + scan launches; else look-back (status, this pass's digit totals ghist)
+                                                      int64_t M, int nblk, int shift, double denom, const uint32_t* __restrict__ only) {
   MDG_RANK_USING(C);
-  if (only && !only[blockIdx.y]) return;
   __shared__ uint32_t cnt[WAVES][256];     // per-wave digit counts, then their exclusive prefix over the waves
   __shared__ uint32_t dstart[256];         // first slot of digit d in the sorted tile
   __shared__ uint32_t gofs[256];           // global position of slot 0 of digit d's run, minus dstart[d]
-  __shared__ uint32_t wsum[4], wsum2[4];
+  __shared__ uint32_t wsum[4];
   __shared__ uint32_t skey[TILE];
   __shared__ uint32_t spay[TILE];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  MDG_SEG_BEGIN(LIST, only, blockIdx.y, gridDim.y)
   for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
   __syncthreads();
-  const int64_t seg = blockIdx.y, base = static_cast<int64_t>(blockIdx.x) * TILE;
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * TILE;
   uint32_t key[ITEMS], pay[ITEMS], rk[ITEMS];
   // payload = (i << 16) | j of the entry (round 4; rounds 1-3 carried the triangle index p and took a double-precision square root per
   // key to get (i, j) back in the last pass): the first pass walks the triangle's rows once per wave, as the key extraction does
@@ -339,24 +296,9 @@ __global__ __launch_bounds__(C::TPB) void scatter_kernel(const KIN* __restrict__
       pay[k] = valid ? pay_in[seg * M + p] : NO_PAY;
     }
   }
-  uint32_t* const status_seg = offsets ? nullptr : status + seg * static_cast<int64_t>(nblk) * 256;
-  if (!offsets) {                           // (uniform) look-back: count first, publish, count again with ranks
-    wave_digit_counts(key, shift, cnt[wave]);
-    __syncthreads();
-    if (tid < 256) {
-      uint32_t c = 0;
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) c += cnt[w][tid];
-      if (tid == 255 && base + TILE > M) c -= static_cast<uint32_t>(base + TILE - M);
-      lookback_publish(status_seg, static_cast<int>(blockIdx.x), tid, c);
-    }
-    __syncthreads();
-    for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
-    __syncthreads();
-  }
   wave_digit_ranks<true, ITEMS>(key, shift, cnt[wave], lane, rk);
   __syncthreads();
-  uint32_t run = 0, gh = 0, gh_inc = 0;    // thread d < 256: the tile's count of digit d; the outcome's count of digit d
+  uint32_t run = 0;                        // thread d < 256: the tile's count of digit d
   if (tid < 256) {                         // thread d: prefix over the waves, then over the digits
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) {
@@ -367,25 +309,14 @@ __global__ __launch_bounds__(C::TPB) void scatter_kernel(const KIN* __restrict__
     const uint32_t inc = wave_inclusive(run, lane);
     if (lane == 63) wsum[wave] = inc;
     dstart[tid] = inc - run;               // exclusive within the wave's 64 digits
-    if (!offsets) {
-      gh = ghist[seg * 256 + tid];
-      gh_inc = wave_inclusive(gh, lane);
-      if (lane == 63) wsum2[wave] = gh_inc;
-    }
   }
   __syncthreads();
   if (tid < 256) {
-    uint32_t add = 0, add2 = 0;
-    for (int w = 0; w < wave; ++w) { add += wsum[w]; add2 += wsum2[w]; }
+    uint32_t add = 0;
+    for (int w = 0; w < wave; ++w) add += wsum[w];
     const uint32_t ds = dstart[tid] + add;
     dstart[tid] = ds;
-    if (offsets) {
-      gofs[tid] = offsets[(seg * 256 + tid) * nblk + blockIdx.x] - ds;
-    } else {
-      const uint32_t pad = (tid == 255 && base + TILE > M) ? static_cast<uint32_t>(base + TILE - M) : 0u;
-      const uint32_t before = lookback_walk(status_seg, static_cast<int>(blockIdx.x), tid, run - pad);
-      gofs[tid] = (gh_inc - gh + add2) + before - ds;
-    }
+    gofs[tid] = offsets[(seg * 256 + tid) * nblk + blockIdx.x] - ds;
   }
   __syncthreads();
 #pragma unroll
@@ -413,6 +344,7 @@ __global__ __launch_bounds__(C::TPB) void scatter_kernel(const KIN* __restrict__
       pay_out[seg * M + g] = pp;
     }
   }
+  MDG_SEG_END(LIST)
 }
 
 // ---- last pass, blocked: ranks delivered to 128 x 128 blocks of the lower triangle instead of one 4-byte store per entry ----
@@ -424,8 +356,7 @@ __global__ __launch_bounds__(C::TPB) void scatter_kernel(const KIN* __restrict__
 // closed form, so the regions need no histogram).  A second kernel owns one block: it places the block's ranks in an LDS tile
 // and writes the rows of out[i, j] and of the mirrored out[j, i] as whole 512-byte pieces (the diagonal of out included).
 constexpr int BB = 128;                    // block edge
-constexpr int FILL_STRIDE = 32;           // words between two blocks' fill counters: one 128-byte line each (16 counters in one 64-byte line
-                                          // serialise every workgroup's atomics on that line: the bucket sort spent most of its time there)
+constexpr int FILL_STRIDE = 1;            // words between two blocks' fill counters (one 128-byte line each, 32, was tried: 64 lanes on 64 lines are slower than the contended lines)
 constexpr int MAX_BLOCKS = 8192;           // LDS budget of the sorting kernel: N <= 16256; larger N take the direct scatter
 
 // first pair slot of block (bi, bj), bj <= bi: all rows above block row bi, then the blocks left of it
@@ -435,26 +366,25 @@ __device__ __forceinline__ uint32_t block_base(int bi, int bj, int N) {
   return static_cast<uint32_t>(r0 * (r0 - 1) / 2 + static_cast<int64_t>(bj) * rcount * BB);
 }
 
-template <class C, class KIN>
+template <bool LIST, class C, class KIN>
 __global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const KIN* __restrict__ keys_in, const uint32_t* __restrict__ pay_in,
                                                           const uint32_t* __restrict__ offsets, u32x2* __restrict__ pairs,
                                                           uint32_t* __restrict__ fill, int N, int64_t M, int nblk, int n_blocks,
-                                                          uint32_t* __restrict__ status, const uint32_t* __restrict__ ghist,
                                                           const uint32_t* __restrict__ only) {
   MDG_RANK_USING(C);
-  if (only && !only[blockIdx.y]) return;
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];            // [TILE] pairs (u32x2) | bcnt[n_blocks] | bdst[n_blocks]
   __shared__ uint32_t cnt[WAVES][256];
   __shared__ uint32_t gbase[256];
-  __shared__ uint32_t wsum[WAVES], wsum2[4];
+  __shared__ uint32_t wsum[WAVES];
   u32x2* spair = reinterpret_cast<u32x2*>(dyn);
   uint32_t* bcnt = dyn + 2 * TILE;
   uint32_t* bdst = bcnt + n_blocks;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  MDG_SEG_BEGIN(LIST, only, blockIdx.y, gridDim.y)
   for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
   for (int i = tid; i < n_blocks; i += TPB) bcnt[i] = 0;
   __syncthreads();
-  const int64_t seg = blockIdx.y, base = static_cast<int64_t>(blockIdx.x) * TILE;
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * TILE;
   uint32_t key[ITEMS], pay[ITEMS], rk[ITEMS];
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
@@ -464,49 +394,17 @@ __global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const KIN* __restri
     pay[k] = valid ? pay_in[seg * M + p] : NO_PAY;
   }
   constexpr int SH = 8 * (static_cast<int>(sizeof(KIN)) - 1);          // the last digit = the top byte of what is left of the key
-  uint32_t* const status_seg = offsets ? nullptr : status + seg * static_cast<int64_t>(nblk) * 256;
-  if (!offsets) {                           // (uniform) look-back: see scatter_kernel
-    wave_digit_counts(key, SH, cnt[wave]);
-    __syncthreads();
-    if (tid < 256) {
-      uint32_t c = 0;
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) c += cnt[w][tid];
-      if (tid == 255 && base + TILE > M) c -= static_cast<uint32_t>(base + TILE - M);
-      lookback_publish(status_seg, static_cast<int>(blockIdx.x), tid, c);
-    }
-    __syncthreads();
-    for (int i = tid; i < WAVES * 256; i += TPB) (&cnt[0][0])[i] = 0;
-    __syncthreads();
-  }
   wave_digit_ranks<true, ITEMS>(key, SH, cnt[wave], lane, rk);
   __syncthreads();
-  {
-    uint32_t run = 0, gh = 0, gh_inc = 0;
-    if (tid < 256) {
+  if (tid < 256) {
+    uint32_t run = 0;
 #pragma unroll
-      for (int w = 0; w < WAVES; ++w) {
-        const uint32_t c = cnt[w][tid];
-        cnt[w][tid] = run;
-        run += c;
-      }
-      if (offsets) {
-        gbase[tid] = offsets[(seg * 256 + tid) * nblk + blockIdx.x];
-      } else {
-        gh = ghist[seg * 256 + tid];
-        gh_inc = wave_inclusive(gh, lane);
-        if (lane == 63) wsum2[wave] = gh_inc;
-      }
+    for (int w = 0; w < WAVES; ++w) {
+      const uint32_t c = cnt[w][tid];
+      cnt[w][tid] = run;
+      run += c;
     }
-    if (!offsets) {                                        // (uniform) look-back: see scatter_kernel
-      __syncthreads();
-      if (tid < 256) {
-        uint32_t add2 = 0;
-        for (int w = 0; w < wave; ++w) add2 += wsum2[w];
-        const uint32_t pad = (tid == 255 && base + TILE > M) ? static_cast<uint32_t>(base + TILE - M) : 0u;
-        gbase[tid] = (gh_inc - gh + add2) + lookback_walk(status_seg, static_cast<int>(blockIdx.x), tid, run - pad);
-      }
-    }
+    gbase[tid] = offsets[(seg * 256 + tid) * nblk + blockIdx.x];
   }
   __syncthreads();
   uint32_t blk[ITEMS], slot[ITEMS];                       // key[] is reused for g, pay[] for the position inside the block
@@ -566,6 +464,7 @@ __global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const KIN* __restri
     const u32x2 v = spair[idx];
     dst[bdst[v[1] >> 14] + static_cast<uint32_t>(idx)] = u32x2{v[0], v[1] & 16383u};
   }
+  MDG_SEG_END(LIST)
 }
 
 // ================================================================================================================================
@@ -600,9 +499,9 @@ constexpr int MSD_HDR = 16;               // header words in front of an outcome
 constexpr int MSD_TABLE_WORDS = MSD_HDR + MSD_N1 + MSD_NC;
 constexpr int MSD_NB_MAX = 2048;          // buckets per outcome: a 16 384-key tile then leaves as runs of >= 8 pairs = 64 B on average (measured,
                                           // scripts/micro/run_scatter_bw.hip: runs of 64 B and longer store at 4.7-6.4 TB/s, runs of 32 B at 1.6-2.3)
-constexpr int MSD_QLG = 12;               // ~4096 keys per bucket
-constexpr int MSD_NF = 8192;              // fine bins of the bucket sort
-constexpr int MSD_CAP = 6144;             // keys a bucket may hold (LDS room of the bucket sort): 1.5 x the mean
+constexpr int MSD_QLG = 13;               // ~8192 keys per bucket
+constexpr int MSD_NF = 16384;             // fine bins of the bucket sort
+constexpr int MSD_CAP = 12288;            // keys a bucket may hold (LDS room of the bucket sort): 1.5 x the mean
 constexpr int MSD_TILE = 16384;           // keys per count / partition tile (1024 threads x 16)
 constexpr int MSD_TIE_LIMIT = 128;        // keys per fine bin ordered in place; more: LSD fallback
 constexpr int MSD_MAX_BLOCKS = 1536;      // output blocks per outcome on this path
@@ -1109,7 +1008,7 @@ struct MsdFine {
 // Straight-line code: a thread's 12 items all take the same path -- an item behind the bucket's last key counts into a dummy fine
 // bin (NF) and a dummy block (n_blocks) that sort behind everything real -- so there are no per-item branches around the LDS atomics.
 template <int NF>
-__global__ __launch_bounds__(1024, 8) void msd_bucket_kernel(const u32x2* __restrict__ part, const uint32_t* __restrict__ bases,
+__global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __restrict__ part, const uint32_t* __restrict__ bases,
                                                            const uint32_t* __restrict__ totals, u32x2* __restrict__ grouped, uint32_t* __restrict__ dir,
                                                            uint32_t* __restrict__ flags, int64_t M, int nbs, int n_blocks, int dw) {
   constexpr int TPB = 1024, CAP = MSD_CAP, ITEMS = CAP / TPB, WPT = NF / 2 / TPB, WAVES = TPB / 64;     // NF fine bins, two u16 counters per word
@@ -1150,8 +1049,9 @@ __global__ __launch_bounds__(1024, 8) void msd_bucket_kernel(const u32x2* __rest
       q[k] = v[1];
     }
   }
-  static_assert(WPT == 4 && BWPT == 1, "one 16-byte access per thread covers the fine counters");
-  reinterpret_cast<u32x4*>(fc)[tid] = u32x4{0u, 0u, 0u, 0u};
+  static_assert(WPT % 4 == 0 && BWPT == 1, "16-byte accesses cover the fine counters");
+#pragma unroll
+  for (int v4 = 0; v4 < WPT / 4; ++v4) reinterpret_cast<u32x4*>(fc)[tid * (WPT / 4) + v4] = u32x4{0u, 0u, 0u, 0u};
   if (tid < 8) reinterpret_cast<u32x4*>(fc + NF / 2)[tid] = u32x4{0u, 0u, 0u, 0u};
   bc[tid] = 0;
   if (tid == 0) { krange[0] = 0xFFFFFFFFu; krange[1] = 0u; ksum_sh = 0ull; }
@@ -1198,7 +1098,12 @@ __global__ __launch_bounds__(1024, 8) void msd_bucket_kernel(const u32x2* __rest
   __syncthreads();
   MDG_STAMP();
   {   // exclusive scans in place, both behind the same two barriers: fine bins (four words per thread) and blocks (one word per thread)
-    const u32x4 w = reinterpret_cast<const u32x4*>(fc)[tid];
+    uint32_t w[WPT];
+#pragma unroll
+    for (int v4 = 0; v4 < WPT / 4; ++v4) {
+      const u32x4 t4 = reinterpret_cast<const u32x4*>(fc)[tid * (WPT / 4) + v4];
+      w[4 * v4] = t4[0]; w[4 * v4 + 1] = t4[1]; w[4 * v4 + 2] = t4[2]; w[4 * v4 + 3] = t4[3];
+    }
     const uint32_t x = bc[tid];
     uint32_t tot = 0;
 #pragma unroll
@@ -1215,14 +1120,14 @@ __global__ __launch_bounds__(1024, 8) void msd_bucket_kernel(const u32x2* __rest
       for (int e = 0; e < 4; ++e)
         if (4 * v4 + e < wave) { run += f4[e]; runb += b4[e]; }
     }
-    u32x4 o;
 #pragma unroll
     for (int e = 0; e < WPT; ++e) {
       const uint32_t c0 = w[e] & 0xFFFFu, c1 = w[e] >> 16;
-      o[e] = run | ((run + c0) << 16);
+      w[e] = run | ((run + c0) << 16);
       run += c0 + c1;
     }
-    reinterpret_cast<u32x4*>(fc)[tid] = o;
+#pragma unroll
+    for (int v4 = 0; v4 < WPT / 4; ++v4) reinterpret_cast<u32x4*>(fc)[tid * (WPT / 4) + v4] = u32x4{w[4 * v4], w[4 * v4 + 1], w[4 * v4 + 2], w[4 * v4 + 3]};
     bc[tid] = runb | ((runb + (x & 0xFFFFu)) << 16);
     if (tid == 0) fc[NF / 2] = static_cast<uint32_t>(n);  // fstart(NF) = the bucket's size
   }
@@ -1242,36 +1147,38 @@ __global__ __launch_bounds__(1024, 8) void msd_bucket_kernel(const u32x2* __rest
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) asm volatile("" : "+v"(key[k]));      // recompute the fine bin per phase instead of keeping 6 more registers live (they spilled)
   bool too_many = false;
+  constexpr int PROBES = 6, GRP = 2;                       // a bin holds ~half a key: one key in 10^4 has more than six bin-mates and walks on
+  static_assert(ITEMS % GRP == 0, "tie-fix groups");
 #pragma unroll
-  for (int k0 = 0; k0 < ITEMS; k0 += 3) {                  // three items at a time: 9 probes in flight, registers within 64
-    uint32_t s0[3], c[3];
+  for (int k0 = 0; k0 < ITEMS; k0 += GRP) {                // two items at a time: 12 probes in flight, registers within 64
+    uint32_t s0[GRP], c[GRP];
 #pragma unroll
-    for (int e = 0; e < 3; ++e) {
+    for (int e = 0; e < GRP; ++e) {
       const int k = k0 + e;
       const bool ok = k * TPB + tid < n;
       const uint32_t fi = ok ? fine_of(key[k], q[k]) : 0u;
       s0[e] = fstart(fi);
       c[e] = ok ? fstart(fi + 1u) - s0[e] : 0u;
     }
-    u32x2 o[3][3];
+    u32x2 o[GRP][PROBES];
 #pragma unroll
-    for (int e = 0; e < 3; ++e)
+    for (int e = 0; e < GRP; ++e)
 #pragma unroll
-      for (int mth = 0; mth < 3; ++mth) {                  // a key alone in its bin (most are) reads nothing
+      for (int mth = 0; mth < PROBES; ++mth) {             // a key alone in its bin (most are) reads nothing
         o[e][mth] = u32x2{0xFFFFFFFFu, 0xFFFFFFFFu};
         if (c[e] > 1u && static_cast<uint32_t>(mth) < c[e]) o[e][mth] = sorted[s0[e] + mth];
       }
 #pragma unroll
-    for (int e = 0; e < 3; ++e) {
+    for (int e = 0; e < GRP; ++e) {
       const int k = k0 + e;
       uint32_t r = 0;
 #pragma unroll
-      for (int mth = 0; mth < 3; ++mth)
+      for (int mth = 0; mth < PROBES; ++mth)
         r += (o[e][mth][0] < key[k] || (o[e][mth][0] == key[k] && o[e][mth][1] < q[k])) ? 1u : 0u;
-      if (c[e] > 3u) {
+      if (c[e] > static_cast<uint32_t>(PROBES)) {
         if (c[e] > static_cast<uint32_t>(MSD_TIE_LIMIT)) too_many = true;
         else
-          for (uint32_t mth = 3; mth < c[e]; ++mth) {
+          for (uint32_t mth = PROBES; mth < c[e]; ++mth) {
             const u32x2 x = sorted[s0[e] + mth];
             r += (x[0] < key[k] || (x[0] == key[k] && x[1] < q[k])) ? 1u : 0u;
           }
@@ -1458,16 +1365,29 @@ __global__ __launch_bounds__(256) void msd_dir_transpose_kernel(const uint32_t* 
 // the transposed directory, staged in LDS first): ranks into an LDS tile, then whole rows of out[i, j] and of the mirrored block
 template <bool VEC>
 __global__ __launch_bounds__(512) void msd_block_gather_kernel(const u32x2* __restrict__ grouped, const uint32_t* __restrict__ startT,
-                                                               const uint16_t* __restrict__ lenT, float* __restrict__ out, int64_t ldo, int N, int64_t M,
+                                                               const uint16_t* lenT, float* __restrict__ out, int64_t ldo, int N, int64_t M,
                                                                int nbt, int nbs, int n_blocks, double denom, const uint32_t* __restrict__ flags) {
   constexpr int TPB = 512;
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];       // tile[BB][BB + 1] (float) | st[nbs] | ln[nbs] (u16)
   float (*tile)[BB + 1] = reinterpret_cast<float (*)[BB + 1]>(dyn);
+  uint32_t (*tile_u)[BB + 1] = reinterpret_cast<uint32_t (*)[BB + 1]>(dyn);
   uint32_t* st = dyn + BB * (BB + 1);
   uint16_t* ln = reinterpret_cast<uint16_t*>(st + nbs);
+#ifdef MDG_RANK_STAMPS
+  uint64_t stamp[8];
+  int n_stamp = 0;
+#define MDG_STAMP() do { uint64_t t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp[n_stamp++] = t_; } while (0)
+#else
+#define MDG_STAMP()
+#endif
   const int64_t seg = blockIdx.y;
   if (flags[seg]) return;
-  const int t = blockIdx.x, tid = threadIdx.x;
+  MDG_STAMP();
+  // Workgroups go to the 8 XCDs round robin (gridDim.x is a multiple of 8): XCD x takes the blocks [x * per, (x + 1) * per) in order,
+  // so that blocks t and t + 1 -- whose runs are neighbours in every bucket and share 128-byte lines -- are resident together on one
+  // XCD and the shared line is fetched into that L2 once (blockIdx order: every 64-byte run cost a whole line, 2.6 TB/s of pairs)
+  const int per = gridDim.x >> 3, t = static_cast<int>(blockIdx.x & 7u) * per + static_cast<int>(blockIdx.x >> 3), tid = threadIdx.x;
+  if (t >= n_blocks) return;
   int bi = static_cast<int>((sqrtf(8.0f * static_cast<float>(t) + 1.0f) - 1.0f) * 0.5f);
   while (bi * (bi + 1) / 2 > t) --bi;
   while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
@@ -1481,48 +1401,73 @@ __global__ __launch_bounds__(512) void msd_block_gather_kernel(const u32x2* __re
     for (int r = tid; r < nbt; r += TPB) { st[r] = s_row[r]; ln[r] = l_row[r]; }
   }
   if (diag)
-    for (int e = tid; e < BB; e += TPB) tile[e][e] = 0.f;
+    for (int e = tid; e < BB; e += TPB) tile_u[e][e] = 0u;
   __syncthreads();
+  MDG_STAMP();
   const u32x2* src = grouped + seg * M;
   const int grp = tid >> 3, l8 = tid & 7;
   // rank / M: both are integers below 2^24 on this path (N <= 4097), exact in fp32, and the correctly rounded fp32 quotient equals numpy's
   // float64 quotient rounded to fp32 (|r 2^e - k M| >= 1 keeps r / M away from every fp32 rounding boundary by more than a float64 ulp)
+  // (the tile takes the integer ranks; they are divided once per element where the rows leave, all lanes busy, not here per gathered
+  // pair with half the lanes idle)
   const float denom_f = static_cast<float>(denom);
   const auto put = [&](u32x2 v) {
-    const float val = static_cast<float>(v[0] + 1u) / denom_f;
     const int r = v[1] >> 7, c = v[1] & 127;
-    tile[r][c] = val;
-    if (diag) tile[c][r] = val;
+    tile_u[r][c] = v[0] + 1u;
+    if (diag) tile_u[c][r] = v[0] + 1u;
   };
-  for (int rbase = 0; rbase < nbt; rbase += 4 * (TPB / 8)) {
-    uint32_t s[4];
-    int len[4];
-    u32x2 v[4];
+  // eight lanes per run, two pairs per lane (a run is ~8 pairs: one in 250 is longer than 16), eight runs per lane in flight: the pair
+  // buffer of a launch group is far larger than the Infinity Cache, so every load is an HBM miss and their number in flight is the speed
+  constexpr int RU = 8;
+  for (int rbase = 0; rbase < nbt; rbase += RU * (TPB / 8)) {
+    uint32_t s[RU];
+    int len[RU];
+    u32x2 v[RU][2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < RU; ++u) {
       const int r = rbase + u * (TPB / 8) + grp;
       len[u] = r < nbt ? static_cast<int>(ln[r]) : 0;
       s[u] = r < nbt ? st[r] : 0u;
-      if (l8 < len[u]) v[u] = src[s[u] + l8];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (l8 < len[u]) put(v[u]);
-      for (int l = l8 + 8; l < len[u]; l += 8) put(src[s[u] + l]);
+    for (int u = 0; u < RU; ++u) {
+      if (l8 < len[u]) v[u][0] = src[s[u] + l8];
+      if (l8 + 8 < len[u]) v[u][1] = src[s[u] + l8 + 8];
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      if (l8 < len[u]) put(v[u][0]);
+      if (l8 + 8 < len[u]) put(v[u][1]);
+      for (int l = l8 + 16; l < len[u]; l += 8) put(src[s[u] + l]);
     }
   }
+  MDG_STAMP();
   __syncthreads();
+  MDG_STAMP();
   float* o = out + seg * static_cast<int64_t>(N) * ldo;
   const int qd = tid & 31, rr = tid >> 5;                  // 32 lanes x 4 columns cover a 128-wide row; 16 rows per sweep
   const int ccount = diag ? rcount : BB;
   for (int r = rr; r < rcount; r += TPB / 32) {
     float* row = o + static_cast<int64_t>(r0 + r) * ldo + c0;
-    if (VEC && 4 * qd + 3 < ccount) *reinterpret_cast<f32x4*>(row + 4 * qd) = f32x4{tile[r][4 * qd], tile[r][4 * qd + 1], tile[r][4 * qd + 2], tile[r][4 * qd + 3]};
+    f32x4 val;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      val[e] = static_cast<float>(tile_u[r][4 * qd + e]) / denom_f;
+      tile[r][4 * qd + e] = val[e];                        // (the same thread's own four cells: the mirrored rows below read floats)
+    }
+    if (VEC && 4 * qd + 3 < ccount) *reinterpret_cast<f32x4*>(row + 4 * qd) = val;
     else
       for (int e = 0; e < 4; ++e)
-        if (4 * qd + e < ccount) row[4 * qd + e] = tile[r][4 * qd + e];
+        if (4 * qd + e < ccount) row[4 * qd + e] = val[e];
   }
+  for (int r = rcount + rr; r < BB; r += TPB / 32)          // rows beyond a ragged N: never gathered, but the mirrored loop below reads the columns' cells
+    for (int e = 0; e < 4; ++e) tile[r][4 * qd + e] = 0.f;
+#ifdef MDG_RANK_STAMPS
+  if (!diag) {
+#else
   if (diag) return;
+#endif
+  __syncthreads();
   for (int c = rr; c < BB; c += TPB / 32) {
     float* row = o + static_cast<int64_t>(c0 + c) * ldo + r0;
     if (VEC && 4 * qd + 3 < rcount) *reinterpret_cast<f32x4*>(row + 4 * qd) = f32x4{tile[4 * qd][c], tile[4 * qd + 1][c], tile[4 * qd + 2][c], tile[4 * qd + 3][c]};
@@ -1530,16 +1475,24 @@ __global__ __launch_bounds__(512) void msd_block_gather_kernel(const u32x2* __re
       for (int e = 0; e < 4; ++e)
         if (4 * qd + e < rcount) row[4 * qd + e] = tile[4 * qd + e][c];
   }
+#ifdef MDG_RANK_STAMPS
+  }
+  MDG_STAMP();
+  if (tid == 0) {
+    uint64_t* d = reinterpret_cast<uint64_t*>(const_cast<uint16_t*>(lenT + (seg * n_blocks + t) * static_cast<int64_t>(nbs)));
+    for (int e = 0; e < n_stamp; ++e) d[e] = stamp[e];
+  }
+#endif
+#undef MDG_STAMP
 }
 
-template <bool VEC>
+template <bool LIST, bool VEC>
 __global__ __launch_bounds__(512) void rank_block_write_kernel(const u32x2* __restrict__ pairs, float* __restrict__ out, int64_t ldo, int N,
-                                                               int64_t M, int n_blocks, double denom, const uint32_t* __restrict__ flags, int want) {
+                                                               int64_t M, int n_blocks, double denom, const uint32_t* __restrict__ only) {
   constexpr int TPB = 512;
   __shared__ float tile[BB][BB + 1];
-  if (flags && (flags[blockIdx.y] != 0u) != (want != 0)) return;      // MSD fast path: unflagged outcomes; LSD fallback behind it: flagged ones
   const int t = blockIdx.x, tid = threadIdx.x;
-  const int64_t seg = blockIdx.y;
+  MDG_SEG_BEGIN(LIST, only, blockIdx.y, gridDim.y)
   int bi = static_cast<int>((sqrtf(8.0f * static_cast<float>(t) + 1.0f) - 1.0f) * 0.5f);
   while (bi * (bi + 1) / 2 > t) --bi;
   while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
@@ -1571,15 +1524,39 @@ __global__ __launch_bounds__(512) void rank_block_write_kernel(const u32x2* __re
       for (int e = 0; e < 4; ++e)
         if (4 * q + e < ccount) row[4 * q + e] = tile[r][4 * q + e];
   }
-  if (diag) return;
   // rows of the mirrored block out[j, i]
-  for (int c = rr; c < BB; c += TPB / 32) {
-    float* row = o + static_cast<int64_t>(c0 + c) * ldo + r0;
-    if (VEC && 4 * q + 3 < rcount) *reinterpret_cast<f32x4*>(row + 4 * q) = f32x4{tile[4 * q][c], tile[4 * q + 1][c], tile[4 * q + 2][c], tile[4 * q + 3][c]};
-    else
-      for (int e = 0; e < 4; ++e)
-        if (4 * q + e < rcount) row[4 * q + e] = tile[4 * q + e][c];
+  if (!diag)
+    for (int c = rr; c < BB; c += TPB / 32) {
+      float* row = o + static_cast<int64_t>(c0 + c) * ldo + r0;
+      if (VEC && 4 * q + 3 < rcount) *reinterpret_cast<f32x4*>(row + 4 * q) = f32x4{tile[4 * q][c], tile[4 * q + 1][c], tile[4 * q + 2][c], tile[4 * q + 3][c]};
+      else
+        for (int e = 0; e < 4; ++e)
+          if (4 * q + e < rcount) row[4 * q + e] = tile[4 * q + e][c];
+    }
+  MDG_SEG_END(LIST)
+}
+
+// list[0] = number of flagged outcomes, list[1..] = which (ascending)
+__global__ __launch_bounds__(1024) void msd_flag_list_kernel(const uint32_t* __restrict__ flags, uint32_t* __restrict__ list, int L) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int l0 = 0; l0 < L; l0 += 1024) {
+    const int l = l0 + tid;
+    const uint32_t f = (l < L && flags[l]) ? 1u : 0u;
+    const uint32_t inc = wave_inclusive(f, lane);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t run = carry + inc - f;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    if (f) list[1 + run] = static_cast<uint32_t>(l);
+    __syncthreads();
+    if (tid == 1023) carry = run + f;
+    __syncthreads();
   }
+  if (tid == 0) list[0] = carry;
 }
 
 __global__ __launch_bounds__(256) void zero_diag_kernel(float* __restrict__ out, int64_t ldo, int N) {
@@ -1677,9 +1654,9 @@ template <class C>
 static size_t lsd_workspace_bytes(int64_t n_outcomes, int64_t N) {
   const size_t M = static_cast<size_t>(N) * (N - 1) / 2;
   const size_t nblk = (M + CfgStd::TILE - 1) / CfgStd::TILE;          // the last pass always runs on 8192-key tiles (the finer table)
-  // keys / payloads x 2 | per-tile digit table (histogram path: one; look-back: one status table per pass) | block fill counters | digit totals
-  return 4 * a256(static_cast<size_t>(n_outcomes) * M * 4) + 4 * a256(static_cast<size_t>(n_outcomes) * 256 * nblk * 4) +
-         a256(static_cast<size_t>(n_outcomes) * static_cast<size_t>(rank_blocks_of(N)) * 4 * FILL_STRIDE) + a256(static_cast<size_t>(n_outcomes) * 4 * 256 * 4);
+  // keys / payloads x 2 | per-tile digit table | block fill counters
+  return 4 * a256(static_cast<size_t>(n_outcomes) * M * 4) + a256(static_cast<size_t>(n_outcomes) * 256 * nblk * 4) +
+         a256(static_cast<size_t>(n_outcomes) * static_cast<size_t>(rank_blocks_of(N)) * 4 * FILL_STRIDE);
 }
 
 // flags (one per outcome, live from the MSD path to the fallback) | MSD per-call tables | max(LSD scratch of all outcomes, MSD scratch of one group)
@@ -1689,7 +1666,7 @@ static size_t rank_workspace_bytes(int64_t n_outcomes, int64_t N) {
   const MsdPlan pl = msd_plan(n_outcomes, N);
   if (!pl.on) return lsd;
   const size_t fast = pl.group_bytes(pl.group);
-  return a256(static_cast<size_t>(n_outcomes) * 4) + pl.call_bytes(n_outcomes) + (lsd > fast ? lsd : fast);
+  return 2 * a256(static_cast<size_t>(n_outcomes + 1) * 4) + pl.call_bytes(n_outcomes) + (lsd > fast ? lsd : fast);      // flags | list | ...
 }
 
 extern "C" size_t mdg_rank_normalize_workspace_bytes(int64_t n_outcomes, int64_t N) {
@@ -1762,13 +1739,20 @@ static void msd_run(const MsdPlan& pl, const float* scores, int64_t lds, float* 
     hipLaunchKernelGGL(msd_big_bucket_kernel, dim3(MSD_BIG_MAX, g), dim3(1024), 0, st, part, bases, totals, pairs, dir, fl, big, M, pl.nbs, n_blocks, pl.dw);
     hipLaunchKernelGGL(msd_dir_transpose_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_blocks, 64)), static_cast<unsigned>(mdg_cdiv(pl.nbt, 64)), g), dim3(256), 0, st,
                        dir, bases, startT, lenT, fl, pl.nbt, pl.nbs, n_blocks, pl.dw);
-    const dim3 bgrid(static_cast<unsigned>(n_blocks), g);
+    const dim3 bgrid(static_cast<unsigned>(8 * mdg_cdiv(n_blocks, 8)), g);
     if (vec) hipLaunchKernelGGL(msd_block_gather_kernel<true>, bgrid, dim3(512), gather_lds, st, pairs, startT, lenT, o, ldo, static_cast<int>(N), M, pl.nbt, pl.nbs,
                                 n_blocks, denom, fl);
     else hipLaunchKernelGGL(msd_block_gather_kernel<false>, bgrid, dim3(512), gather_lds, st, pairs, startT, lenT, o, ldo, static_cast<int>(N), M, pl.nbt, pl.nbs,
                             n_blocks, denom, fl);
   }
 }
+
+#define MDG_UNPAREN(...) __VA_ARGS__
+#define MDG_LSD_LAUNCH(K, TARGS, ...)                                          \
+  do {                                                                         \
+    if (only) hipLaunchKernelGGL((K<true, MDG_UNPAREN TARGS>), __VA_ARGS__);   \
+    else hipLaunchKernelGGL((K<false, MDG_UNPAREN TARGS>), __VA_ARGS__);       \
+  } while (0)
 
 template <class C>
 static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int64_t ldo, int64_t n_outcomes, int64_t N, void* workspace,
@@ -1796,14 +1780,15 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
       attr_done = true;
     }
     uint32_t* flags = reinterpret_cast<uint32_t*>(ws);
-    ws += a256(static_cast<size_t>(n_outcomes) * 4);
+    ws += a256(static_cast<size_t>(n_outcomes + 1) * 4);
+    uint32_t* list = reinterpret_cast<uint32_t*>(ws);
+    ws += a256(static_cast<size_t>(n_outcomes + 1) * 4);
     char* call_ws = ws;
     ws += pl.call_bytes(n_outcomes);
     (void)hipMemsetAsync(flags, 0, static_cast<size_t>(n_outcomes) * 4, st);
     msd_run(pl, scores, lds, out, ldo, n_outcomes, N, call_ws, ws, flags, st, src_is_keys);
-    only = flags;
-    static MdgEnvInt nofb_sw{"MDG_RANKS_NO_FALLBACK", 0};   // diagnostics (timing the MSD path alone): flagged outcomes are then left unranked
-    if (nofb_sw.get()) { MDG_CHECK_LAUNCH("mdg_rank_normalize"); return MDG_OK; }
+    hipLaunchKernelGGL(msd_flag_list_kernel, dim3(1), dim3(1024), 0, st, flags, list, static_cast<int>(n_outcomes));
+    only = list;
   }
   const size_t kb = a256(static_cast<size_t>(n_outcomes) * M * 4);
   uint32_t* k0 = reinterpret_cast<uint32_t*>(ws);          // k0 | p0 adjacent: together they hold the last pass's (rank, position) pairs
@@ -1812,69 +1797,57 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
   uint32_t* p1 = reinterpret_cast<uint32_t*>(ws + 3 * kb);
   uint32_t* hist = reinterpret_cast<uint32_t*>(ws + 4 * kb);
   const int nblk3 = static_cast<int>(mdg_cdiv(M, CfgStd::TILE));
-  const size_t hb = a256(static_cast<size_t>(n_outcomes) * 256 * nblk3 * 4);       // one per-tile digit table
-  uint32_t* fill = reinterpret_cast<uint32_t*>(ws + 4 * kb + 4 * hb);
-  const size_t fb = a256(static_cast<size_t>(n_outcomes) * static_cast<size_t>(rank_blocks_of(N)) * 4 * FILL_STRIDE);
-  uint32_t* ghist = reinterpret_cast<uint32_t*>(ws + 4 * kb + 4 * hb + fb);        // [4 passes][outcomes][256]
+  const size_t hb = a256(static_cast<size_t>(n_outcomes) * 256 * nblk3 * 4);       // the per-tile digit table
+  uint32_t* fill = reinterpret_cast<uint32_t*>(ws + 4 * kb + hb);
   const int64_t n_blocks = rank_blocks_of(N);
-  static MdgEnvInt direct_sw{"MDG_RANKS_DIRECT", 0};        // 1: the last pass stores the ranks one by one (the large-N path) at any N
-  // Tile offsets from histogram + scan launches (default) or by decoupled look-back (1).  Measured on 4096^2 outcomes: the
-  // look-back saves the 37 us of histogram / scan launches per outcome and gives 35 us back inside the scatters (every walk step is
-  // a cross-XCD sc1 load, ~2 us, in front of the tile's write phase; 4 digit histograms in the extraction): 0.26 ms either way.
-  static MdgEnvInt lb_sw{"MDG_RANKS_LOOKBACK", 0};
-  const bool lb = lb_sw.get() != 0;
+  static MdgEnvInt direct_sw{"MDG_RANKS_DIRECT", 0};        // test hook: 1 = the last pass stores the ranks one by one (what N > 16256 takes) at any N
   // the blocked last pass on 8192-key tiles whatever the other passes use: two workgroups per CU there beat one of 16384 keys
   // (48 against 63 us per 4096^2 outcome); its histogram and scan use the same tiling
   const size_t blocks_lds = static_cast<size_t>(2 * CfgStd::TILE + 2 * n_blocks) * 4;
   const bool blocked = n_blocks <= MAX_BLOCKS && !direct_sw.get();
-  const dim3 grid3(static_cast<unsigned>(nblk3), L);
+  // behind the MSD path: two rows of workgroups walk the list of flagged outcomes (usually empty)
+  const unsigned Ly = only ? (L < 2u ? L : 2u) : L;
+  const dim3 grid3(static_cast<unsigned>(nblk3), Ly);
   const double denom = static_cast<double>(N) * static_cast<double>(N - 1) / 2.0;
-  const dim3 grid(static_cast<unsigned>(nblk), L);
-  const auto status_of = [&](int pass) { return reinterpret_cast<uint32_t*>(ws + 4 * kb + pass * hb); };
-  const auto ghist_of = [&](int pass) { return ghist + static_cast<size_t>(pass) * n_outcomes * 256; };
-  if (lb) (void)hipMemsetAsync(ws + 4 * kb, 0, 4 * hb + fb + a256(static_cast<size_t>(n_outcomes) * 4 * 256 * 4), st);   // status tables, block fill counters, digit totals
-  hipLaunchKernelGGL(extract_keys_kernel<C>, grid, dim3(TPB), 0, st, scores, lds, k0, hist, lb ? ghist : nullptr, static_cast<int>(N), M, nblk, src_is_keys, only);
+  const dim3 grid(static_cast<unsigned>(nblk), Ly);
+  MDG_LSD_LAUNCH(extract_keys_kernel, (C), grid, dim3(TPB), 0, st, scores, lds, k0, hist, static_cast<int>(N), M, nblk, src_is_keys, only);
   for (int pass = 0; pass < 4; ++pass) {
     uint32_t* kin = (pass & 1) ? k1 : k0;
     uint32_t* kout = (pass & 1) ? k0 : k1;
     uint32_t* pin = (pass & 1) ? p1 : p0;
     uint32_t* pout = (pass & 1) ? p0 : p1;
     const bool std3 = pass == 3 && blocked;
-    const uint32_t* offs = lb ? nullptr : hist;
-    uint32_t* stat = lb ? status_of(pass) : nullptr;
-    const uint32_t* gcur = lb ? ghist_of(pass) : nullptr;
     // keys narrow as the passes go: pass 0 and 1 read all 32 bits, pass 1 leaves the upper 16, pass 2 the upper 8 (the bits below
     // the current digit are sorted already): 15 of 96 bytes per key less to move
     typedef uint16_t u16;
     typedef uint8_t u8;
-    if (!lb) {
-      if (std3) hipLaunchKernelGGL((histogram_kernel<CfgStd, u8>), grid3, dim3(CfgStd::TPB), 0, st, reinterpret_cast<const u8*>(kin), hist, M, nblk3, 0, only);
-      else if (pass == 3) hipLaunchKernelGGL((histogram_kernel<C, u8>), grid, dim3(TPB), 0, st, reinterpret_cast<const u8*>(kin), hist, M, nblk, 0, only);
-      else if (pass == 2) hipLaunchKernelGGL((histogram_kernel<C, u16>), grid, dim3(TPB), 0, st, reinterpret_cast<const u16*>(kin), hist, M, nblk, 0, only);
-      else if (pass == 1) hipLaunchKernelGGL((histogram_kernel<C, uint32_t>), grid, dim3(TPB), 0, st, kin, hist, M, nblk, 8, only);
-      hipLaunchKernelGGL(scan_kernel, dim3(L), dim3(1024), 0, st, hist, std3 ? nblk3 : nblk, only);
-    }
+    if (std3) MDG_LSD_LAUNCH(histogram_kernel, (CfgStd, u8), grid3, dim3(CfgStd::TPB), 0, st, reinterpret_cast<const u8*>(kin), hist, M, nblk3, 0, only);
+    else if (pass == 3) MDG_LSD_LAUNCH(histogram_kernel, (C, u8), grid, dim3(TPB), 0, st, reinterpret_cast<const u8*>(kin), hist, M, nblk, 0, only);
+    else if (pass == 2) MDG_LSD_LAUNCH(histogram_kernel, (C, u16), grid, dim3(TPB), 0, st, reinterpret_cast<const u16*>(kin), hist, M, nblk, 0, only);
+    else if (pass == 1) MDG_LSD_LAUNCH(histogram_kernel, (C, uint32_t), grid, dim3(TPB), 0, st, kin, hist, M, nblk, 8, only);
+    if (only) hipLaunchKernelGGL(scan_kernel<true>, dim3(Ly), dim3(1024), 0, st, hist, std3 ? nblk3 : nblk, only);
+    else hipLaunchKernelGGL(scan_kernel<false>, dim3(Ly), dim3(1024), 0, st, hist, std3 ? nblk3 : nblk, only);
     if (pass == 0)
-      hipLaunchKernelGGL((scatter_kernel<C, true, false>), grid, dim3(TPB), 0, st, kin, pin, kout, pout, offs, out, ldo, static_cast<int>(N), M, nblk, 0, denom, stat, gcur, only);
+      MDG_LSD_LAUNCH(scatter_kernel, (C, true, false), grid, dim3(TPB), 0, st, kin, pin, kout, pout, hist, out, ldo, static_cast<int>(N), M, nblk, 0, denom, only);
     else if (pass == 1)
-      hipLaunchKernelGGL((scatter_kernel<C, false, false, uint32_t, u16>), grid, dim3(TPB), 0, st, kin, pin, reinterpret_cast<u16*>(kout), pout, offs, out, ldo,
-                         static_cast<int>(N), M, nblk, 8, denom, stat, gcur, only);
+      MDG_LSD_LAUNCH(scatter_kernel, (C, false, false, uint32_t, u16), grid, dim3(TPB), 0, st, kin, pin, reinterpret_cast<u16*>(kout), pout, hist, out, ldo,
+                         static_cast<int>(N), M, nblk, 8, denom, only);
     else if (pass == 2)
-      hipLaunchKernelGGL((scatter_kernel<C, false, false, u16, u8>), grid, dim3(TPB), 0, st, reinterpret_cast<const u16*>(kin), pin, reinterpret_cast<u8*>(kout), pout,
-                         offs, out, ldo, static_cast<int>(N), M, nblk, 0, denom, stat, gcur, only);
+      MDG_LSD_LAUNCH(scatter_kernel, (C, false, false, u16, u8), grid, dim3(TPB), 0, st, reinterpret_cast<const u16*>(kin), pin, reinterpret_cast<u8*>(kout), pout,
+                         hist, out, ldo, static_cast<int>(N), M, nblk, 0, denom, only);
     else if (blocked) {
-      if (!lb) (void)hipMemsetAsync(fill, 0, static_cast<size_t>(n_outcomes) * n_blocks * 4 * FILL_STRIDE, st);
+      (void)hipMemsetAsync(fill, 0, static_cast<size_t>(n_outcomes) * n_blocks * 4 * FILL_STRIDE, st);
       u32x2* pairs = reinterpret_cast<u32x2*>(k0);            // pass 3 reads k1 / p1
-      hipLaunchKernelGGL((rank_blocks_kernel<CfgStd, u8>), grid3, dim3(CfgStd::TPB), blocks_lds, st, reinterpret_cast<const u8*>(kin), pin, offs, pairs, fill,
-                         static_cast<int>(N), M, nblk3, static_cast<int>(n_blocks), stat, gcur, only);
-      const dim3 bgrid(static_cast<unsigned>(n_blocks), L);
+      MDG_LSD_LAUNCH(rank_blocks_kernel, (CfgStd, u8), grid3, dim3(CfgStd::TPB), blocks_lds, st, reinterpret_cast<const u8*>(kin), pin, hist, pairs, fill,
+                         static_cast<int>(N), M, nblk3, static_cast<int>(n_blocks), only);
+      const dim3 bgrid(static_cast<unsigned>(n_blocks), Ly);
       if (ldo % 4 == 0 && mdg_aligned16(out))
-        hipLaunchKernelGGL(rank_block_write_kernel<true>, bgrid, dim3(512), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom, only, 1);
+        MDG_LSD_LAUNCH(rank_block_write_kernel, (true), bgrid, dim3(512), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom, only);
       else
-        hipLaunchKernelGGL(rank_block_write_kernel<false>, bgrid, dim3(512), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom, only, 1);
+        MDG_LSD_LAUNCH(rank_block_write_kernel, (false), bgrid, dim3(512), 0, st, pairs, out, ldo, static_cast<int>(N), M, static_cast<int>(n_blocks), denom, only);
     } else {
-      hipLaunchKernelGGL((scatter_kernel<C, false, true, u8, u8>), grid, dim3(TPB), 0, st, reinterpret_cast<const u8*>(kin), pin, reinterpret_cast<u8*>(kout), pout, offs,
-                         out, ldo, static_cast<int>(N), M, nblk, 0, denom, stat, gcur, only);
+      MDG_LSD_LAUNCH(scatter_kernel, (C, false, true, u8, u8), grid, dim3(TPB), 0, st, reinterpret_cast<const u8*>(kin), pin, reinterpret_cast<u8*>(kout), pout, hist,
+                         out, ldo, static_cast<int>(N), M, nblk, 0, denom, only);
     }
   }
   MDG_CHECK_LAUNCH("mdg_rank_normalize");

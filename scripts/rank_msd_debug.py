@@ -79,3 +79,11 @@ if os.environ.get("DBG_STAMPS"):
     for i, nm in enumerate(names):
         print(f"   {nm:16s} mean {dt[:, i].mean():9.1f}  median {np.median(dt[:, i]):9.1f}  max {dt[:, i].max()}")
     print("   total mean", dt.sum(1).mean(), " kernel span (max end - min start):", int(t[:, :, 8].max() - t[:, :, 0][t[:, :, 0] > 0].min()))
+    # gather kernel stamps: in the (dead) lenT rows
+    off2 = off + a256(G * nbs * dw * 4) + a256(G * n_blocks * nbs * 4)
+    lt = ws[off2:off2 + G * n_blocks * nbs * 2].view(torch.int64).cpu().numpy().reshape(G, n_blocks, nbs // 4)[:, :, :5]
+    dg = np.diff(lt, axis=2).reshape(-1, 4)
+    okg = (dg >= 0).all(1) & (dg < 10_000_000).all(1)
+    dg = dg[okg]
+    print("gather kernel stamps over", dg.shape[0], "blocks: directory stage, gather loop, barrier wait, write-out")
+    print("   mean", dg.mean(0).round(0).tolist(), " median", np.median(dg, axis=0).tolist(), " total mean", dg.sum(1).mean())
