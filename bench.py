@@ -115,18 +115,31 @@ def pmc_traffic(n_drugs: int, n_outcomes: int, precision: str):
     return None, None
 
 
-def rank_pmc_traffic(n_drugs: int):
-    """HBM bytes per OUTCOME of the rank normalisation from the committed PMC passes (sum over its kernels of WRITE_SIZE + 2 x
-    FETCH_SIZE per launch, divided by the outcomes per launch), if a profile at this drug count exists under profiles/."""
+def _rank_source_sha16() -> str:
+    import hashlib
+    return hashlib.sha256(open(os.path.join(REPO, "madrigal_amd", "csrc", "ranks.hip"), "rb").read()).hexdigest()[:16]
+
+
+def rank_pmc_traffic(n_drugs: int, msd: bool):
+    """Bytes past the L2 per OUTCOME of the rank normalisation from the committed PMC passes (scripts/rank_pmc.sh: sum over its kernels of
+    WRITE_SIZE + 2 x FETCH_SIZE per launch, divided by the outcomes per launch) -- a profile of THIS build only: the file records the
+    path it measured (MSD / LSD) and the hash of csrc/ranks.hip; anything else gives (None, why)."""
     import glob
+    want = _rank_source_sha16()
+    why = "no rank PMC profile under profiles/ for this drug count"
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*rank*pmc_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("workload", {}).get("drugs") == n_drugs and d.get("hbm_bytes_per_outcome_corrected") is not None:
-            return d["hbm_bytes_per_outcome_corrected"], os.path.basename(f)
-    return None, None
+        w = d.get("workload", {})
+        if w.get("drugs") != n_drugs or d.get("hbm_bytes_per_outcome_corrected") is None:
+            continue
+        if w.get("ranks_hip_sha16") != want or bool(w.get("msd_path")) != msd:
+            why = f"{os.path.basename(f)} measured another build / path of the sort (ranks.hip {w.get('ranks_hip_sha16')}, this build {want}): not quoted"
+            continue
+        return d["hbm_bytes_per_outcome_corrected"], f"committed profile {os.path.basename(f)} (same ranks.hip, same path; separate rocprofv3 --pmc passes, not this run)"
+    return None, why
 
 
 def host_threads() -> int:
@@ -374,7 +387,7 @@ def ranks_leg(scores, args, model=None, z=None):
         passes.append(e0.elapsed_time(e1))
     ms, wall = min(passes), min(walls)
     handed = int(sum(int((f != 0).sum()) for f in flags))
-    rank_traffic, rank_traffic_src = rank_pmc_traffic(N)
+    rank_traffic, rank_traffic_src = rank_pmc_traffic(N, bool(flags))
     M = N * (N - 1) // 2
     # size-independent checks inside the run: a permutation of 1..M per outcome (sum of ranks), symmetric, zero diagonal
     denom = N * (N - 1) / 2
@@ -389,8 +402,8 @@ def ranks_leg(scores, args, model=None, z=None):
            "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": None if rank_traffic is None else rank_traffic * L, "traffic_source": rank_traffic_src,
                         "kernel": "mdg_rank_normalize (extract + 4 x 8-bit stable LSD radix passes on LDS-sorted 16384-key tiles + blocked rank store)" if not flags else
-                                  "mdg_rank_normalize, MDG_RANKS_MSD=1: adaptive MSD path (histogram -> bucket table -> one partition -> in-LDS counting sort per bucket "
-                                  "-> blocked rank store); outcomes it hands back take the LSD passes",
+                                  "mdg_rank_normalize: exact-layout MSD path (sampled bucket table -> per-tile bucket counts + scan -> one partition -> in-LDS counting "
+                                  "sort per 8192-key bucket -> output blocks gathered through a directory); outcomes it hands back (point masses) take the LSD passes",
                         "outcomes_handed_to_lsd": handed if flags else None,
                         "algorithmic_bytes_per_outcome": alg / L, "formula": "(M x 4 B keys read + N^2 x 4 B ranks written) x outcomes / launch time"}}
     del chk
@@ -471,30 +484,65 @@ def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend
         with torch.no_grad():
             model.decoder.parametrizations.weight.original.copy_(
                 torch.randn(L, 128, 128, generator=torch.Generator().manual_seed(1000)) / 128 ** 0.5)
-    # a DIFFERENT set of labelled triples every step, as in an epoch: the triple plan (sorts by label / pair / drug) is rebuilt
-    # inside every timed step; the drug batch itself is the fixed synthetic one (its molecule / mask plans are cached)
+    # What changes from step to step in the reference's loop (train_ddi_batch.py:231-354) changes here: a DIFFERENT set of labelled
+    # triples (the triple plan -- sorts by label / pair / drug -- is rebuilt inside every timed step), a DIFFERENT head batch and tail
+    # batch (distinct drug sets: other molecules, signatures, KG row orders) and freshly drawn modality masks on each side, so that no
+    # plan keyed on a batch or mask object survives from one step to the next (with one batch object on both sides every
+    # such cache always hit).  `fresh_sides = False` (the "cached_plans" figure beside the value) is round 4's step: the fixed batch.
     sets = [tuple(t.to(dev) for t in D.make_labelled_triples(N, L, args.finetune_triples, s_)) for s_ in range(3)]
     lab, hd, tl, y = sets[0]
     T = int(lab.numel())
     hp = dict(optimizer="adamw", structure_encoder_lr=1e-5, kg_encoder_lr=1e-5, perturb_encoders_lr=1e-5, fusion_lr=1e-6, decoder_lr=1e-4,
               wd=1e-2, beta1=0.9, beta2=0.999, eps=1e-8)
+    avail = batch["masks"].cpu()
+    n_var = 2 if world == 1 else 0                     # (the data-parallel leg keeps the fixed batch: its shards are cut once)
+    sides = []
+    for v_ in range(n_var):
+        pair = []
+        for side_seed in (200 + v_, 300 + v_):
+            b_, _ = D.make_batch(N, side_seed, kg=bkg["data"], masks=avail)
+            pair.append(D.batch_to(b_, dev))
+        sides.append(pair)
+    g_m = torch.Generator().manual_seed(99)
+
+    def draw_masks():
+        """A step's modality masks: every available modality but the structure dropped with probability 0.3 (the 'random_sample' family
+        of train_ddi_batch.py; True = absent)."""
+        drop = torch.rand(avail.shape, generator=g_m) < 0.3
+        drop[:, 0] = False
+        return (avail | drop).to(dev)
     fs = FinetuneStep(model, create_optimizer(model, hp), rank=rank, world=world)
     torch.manual_seed(4321 + rank)
-    with M.precision(precision):
+
+    def one_step(i_, fresh):
+        if fresh and sides:
+            hb, tb = sides[i_ % n_var]
+            return fs.step(hb, tb, draw_masks(), draw_masks(), bkg, *sets[(i_ + 1) % 3], kg_filler=filler)
+        return fs.step(batch, batch, batch["masks"], batch["masks"], bkg, *sets[(i_ + 1) % 3], kg_filler=filler)
+
+    def timed(fresh):
         # warm-up: one step per triple set -- each set has its own tensor sizes (pair counts, tile tables), whose first allocation from the
-        # device is slow (a 45-ms step then takes 60-100 ms); afterwards the caching allocator holds them.  The timed steps still build the
-        # plan of a DIFFERENT set than the step before them, every step.
-        losses = [float(fs.step(batch, batch, batch["masks"], batch["masks"], bkg, *sets[k_], kg_filler=filler)) for k_ in (1, 2, 0)][-1:]
+        # device is slow (a 45-ms step then takes 60-100 ms); afterwards the caching allocator holds them
+        ls = [float(one_step(k_, fresh)) for k_ in (0, 1, 2)][-1:]
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.finetune_steps + 1)]
-        t0 = time.perf_counter()
-        marks[0].record()
+        mk = [torch.cuda.Event(enable_timing=True) for _ in range(args.finetune_steps + 1)]
+        t_ = time.perf_counter()
+        mk[0].record()
         for i_ in range(args.finetune_steps):
-            losses.append(fs.step(batch, batch, batch["masks"], batch["masks"], bkg, *sets[(i_ + 1) % 3], kg_filler=filler))
-            marks[i_ + 1].record()                   # (no host sync: the steps stay back to back, the host queues ahead)
+            ls.append(one_step(i_, fresh))
+            mk[i_ + 1].record()                      # (no host sync: the steps stay back to back, the host queues ahead)
         torch.cuda.synchronize()
+        return ls, mk, t_
+    with M.precision(precision):
+        cached = None
+        if sides:
+            ls_c, mk_c, _ = timed(False)
+            ms_c = sorted(mk_c[i_].elapsed_time(mk_c[i_ + 1]) for i_ in range(args.finetune_steps))
+            cached = {"ms_per_step": ms_c[len(ms_c) // 2], "what": "the same step with ONE fixed batch object on both sides and fixed masks (round 4's figure): "
+                                                                   "mask / gather / molecule plans hit their caches"}
+        losses, marks, t0 = timed(bool(sides))
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -518,8 +566,12 @@ def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend
            "loss_first_last": [float(losses[0]), float(losses[-1])],
            "parallelism": "single GPU" if world == 1 else
            f"drug-sharded encoders (SyncBatchNorm), all-gather(z) / reduce-scatter(dz), triples dealt to {world} ranks, flat gradient all-reduce",
-           "work": "optimizer.zero_grad, triple plan of a fresh set of labelled triples, encode+fuse head side and tail side (training "
-                   "mode), gathered bilinear head on the labelled triples, BCE, backward through all encoders, AdamW step"}
+           "work": "optimizer.zero_grad, triple plan of a fresh set of labelled triples, encode+fuse a fresh head batch and a fresh tail batch under "
+                   "freshly drawn modality masks (training mode), gathered bilinear head on the labelled triples, BCE, backward through all "
+                   "encoders, AdamW step" if sides else
+                   "optimizer.zero_grad, triple plan of a fresh set of labelled triples, encode+fuse head side and tail side of the fixed batch (training "
+                   "mode), gathered bilinear head on the labelled triples, BCE, backward through all encoders, AdamW step",
+           "fresh_batches_and_masks_every_step": bool(sides), "cached_plans": cached}
     if rank == 0 and world == 1:
         # roofline of the step's dominant kernel, the wide fusion-transformer GEMM (linear_kernel<bf16, 256x256 tile>; 14 of the
         # 69 ms of kernel time, profiles/): one FFN-sized launch at the step's own row count, HIP events on its stream
@@ -966,7 +1018,7 @@ def main():
                 "config": {"workload": wl, "drugs": N, "outcomes_per_gpu": h["Lr"], "outcomes_total": h["L_total"], "feature_dim": 128,
                            "model": None if args.head_only else args.config, "precision": args.precision,
                            "parallelism": "single GPU" if world == 1 else
-                           f"drug-sharded encode+fuse, all-gather(z) over RCCL, outcome-sharded head x{world} ({main_mode} scaling)"},
+                           f"drug-sharded encode+fuse, all-gather(z) over {'RCCL' if backend == 'nccl' else backend}, outcome-sharded head x{world} ({main_mode} scaling)"},
                 "collective": h["collective"],
                 "roofline": roof}
         if other is not None:
@@ -986,6 +1038,26 @@ def main():
             line["finetune"] = finetune
         if pretrain is not None:
             line["pretrain"] = pretrain
+
+        def pick(d, *path):
+            for k_ in path:
+                if not isinstance(d, dict) or d.get(k_) is None:
+                    return None
+                d = d[k_]
+            return d
+        # LAST key: the driver keeps the tail of the line -- both halves of BASELINE's metric and the figures quoted beside the headline
+        line["summary"] = {"scores_per_s": line["value"], "head_frac_of_8TBs": roof.get("frac"), "encode_fuse_ms": enc_ms,
+                           "finetune_steps_per_s": pick(finetune, "value"), "finetune_ms": pick(finetune, "ms_per_step"),
+                           "finetune_ms_cached_plans": pick(finetune, "cached_plans", "ms_per_step"),
+                           "finetune_fp32_grade_ms": pick(finetune, "fp32_grade", "ms_per_step"), "dense_block_frac": pick(finetune, "roofline", "frac"),
+                           "ranks_ms_per_outcome": pick(ranks, "ms_per_outcome"), "ranks_frac": pick(ranks, "roofline", "frac"),
+                           "ranks_traffic_over_algorithmic": None if pick(ranks, "roofline", "traffic") is None else
+                           pick(ranks, "roofline", "traffic") / (pick(ranks, "roofline", "algorithmic_bytes_per_outcome") * pick(ranks, "outcomes")),
+                           "ranks_outcomes_handed_to_lsd": pick(ranks, "roofline", "outcomes_handed_to_lsd"),
+                           "f32_exact_scores_per_s": pick(f32_exact, "whole_job_scores_per_s") or pick(f32_exact, "value"),
+                           "share_within_1e-4_rel": pick(f32_exact, "headline_mode_vs_exact", "share_within_1e-4_rel"),
+                           "cfg5_frac": pick(stress, "roofline", "frac") or pick(stress, "frac"), "pretrain_ms": pick(pretrain, "ms_per_step"),
+                           "cpu_scores_per_s": pick(line.get("cpu_baseline"), "value")}
         print(json.dumps(line), flush=True)
     if world == 1:
         emit(*secondary_legs())

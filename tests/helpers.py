@@ -191,25 +191,17 @@ def gin_bias_case():
     return mols, p, b, torch.bincount(dst, minlength=6).float()
 
 
-class ReluFlip(Exception):
-    """Raised by a whole-model gradient comparison whose worst entry sits between the strict and the loose bound."""
-
-
-def first_clean_seed(run, seeds, strict, loose):
-    """Whole-model gradient comparisons between two fp32 implementations of a ReLU network (the HIP path, the CPU oracle's
-    autograd) have a failure mode that is not an error of either: a pre-activation within fp32 rounding of zero takes derivative 0
-    on one side and 1 on the other, and the affected row of a weight gradient moves by that sample's whole contribution (measured
-    on the contrastive step, scripts/pretrain_flip_probe.py: 3 of 4 seeds show ONE such unit -- worst entry 3e-3 ... 2e-2 of the
-    tensor's scale in a handful of entries -- the fourth agrees to 9e-5 everywhere; ~3e6 ReLU inputs per step make a flip likelier
-    than not).  ``run(seed)`` returns its worst relative error (and does its own exact assertions).  Acceptance: every tried seed
-    stays below ``loose`` (an arithmetic defect -- a wrong term, a wrong scale -- shows on EVERY seed and far above it), and the
-    first seed below ``strict`` ends the search; no seed below ``strict`` fails."""
-    seen = []
-    for s in seeds:
-        w = run(s)
-        seen.append((s, w))
-        err = w[0] if isinstance(w, tuple) else w
-        assert err < loose, seen
-        if err < strict:
-            return seen
-    raise AssertionError(f"no seed agrees to {strict}: {seen}")
+def assert_tensors_agree(errs, strict, loose, max_outliers=3, what=""):
+    """The acceptance rule of the whole-model gradient comparisons between two fp32 implementations of a ReLU network (the HIP path
+    against the CPU oracle's autograd; a multi-rank step against the single-process one).  ``errs`` = one (relative error, name) per
+    parameter tensor.  Such a comparison has a failure mode that is not an error of either side: a pre-activation within fp32 rounding
+    of zero takes derivative 0 on one side and 1 on the other, and ONE row of the weight gradient it feeds (and that layer's bias entry)
+    moves by that sample's whole contribution -- measured 3e-3 ... 2e-2 of the tensor's scale in a handful of entries of one or two
+    tensors (scripts/pretrain_flip_probe.py), where an arithmetic defect (a wrong term, a wrong scale, a few percent lost in a
+    reduction) moves every tensor downstream of it.  So, on EVERY seed -- no search, no seed is allowed to fail, the seeds are a fixed
+    ascending range -- all tensors but at most ``max_outliers`` sit under ``strict`` and every tensor sits under ``loose``."""
+    errs = sorted(errs, reverse=True)
+    over = [e for e in errs if e[0] >= strict]
+    assert len(over) <= max_outliers, (what, f"{len(over)} of {len(errs)} tensors beyond {strict}", over[:8])
+    assert errs[0][0] < loose, (what, errs[:4])
+    return errs[0], len(over)

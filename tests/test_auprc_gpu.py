@@ -1,0 +1,130 @@
+"""north_star's closing acceptance: "AUPRC within 1e-3 of reference on the held-out DDI split" -- of a TRAINED model.
+
+The reference trains with train_ddi_batch.py:231-354 (AdamW over the parameter groups of madrigal/utils.py:463-613) and evaluates with
+madrigal/evaluate/evaluate.py:158-196 -> madrigal/evaluate/metrics.py:87,129-191 (sklearn ``average_precision_score`` per outcome on the
+held-out triples, macro mean).  Here: one initialisation, one synthetic split with a learnable rule, N AdamW steps
+  (a) on the HIP path (``FinetuneStep``) in the ``bf16x3`` mode and in the ``bf16`` mode BASELINE configs[1] names and bench.py times,
+  (b) on the CPU oracle (torch autograd over ``oracle_pipeline`` + ``torch.optim.AdamW`` over the same groups),
+then the held-out triples scored by each trained model on its own side and sklearn's macro AUPRC of the three compared.
+Dropout 0 / eval-mode statistics on both sides (the oracle restates the eval forward), fixed masks.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASE = ("drugbank163", "transformer", 4, "learnable", 8, 64, 256, 2, True, "x-attn", True, False)
+
+
+def _split(n, L, n_pos, seed):
+    """Labelled triples whose target follows a hidden rule of the two drugs -- a per-drug effect, added over the pair, with a sign per
+    outcome and some label noise -- so that a trained model beats chance on triples it has not seen; every third triple is held out."""
+    from madrigal_amd import data as D
+    lab, hd, tl, _ = D.make_labelled_triples(n, L, n_pos, seed)
+    g = torch.Generator().manual_seed(seed + 7)
+    c = torch.randn(n, generator=g)
+    sgn = (torch.rand(L, generator=g) < 0.5).float() * 2 - 1
+    t = sgn[lab] * (c[hd] + c[tl]) + 0.3 * torch.randn(lab.numel(), generator=g)
+    y = (t > 0).float()
+    held = torch.arange(lab.numel()) % 3 == 2
+    return (lab[~held], hd[~held], tl[~held], y[~held]), (lab[held], hd[held], tl[held], y[held])
+
+
+def _macro_auprc_sklearn(pred, y, lab, L):
+    from sklearn.metrics import average_precision_score
+    vals = []
+    for l in range(L):
+        m = lab == l
+        if m.sum() and 0 < y[m].sum() < m.sum():
+            vals.append(average_precision_score(y[m], pred[m]))
+    return float(np.mean(vals)), len(vals)
+
+
+def test_held_out_auprc_of_a_trained_model_matches_the_oracle():
+    from madrigal_amd import data as D, metrics as MT, models as M, ops
+    from madrigal_amd.optim import create_optimizer
+    from madrigal_amd.train import FinetuneStep
+    from helpers import oracle_pipeline
+    from test_train_gpu import _small_model
+    n, L, steps, seed = 192, 16, 60, 41
+    hp = dict(optimizer="adamw", structure_encoder_lr=1e-3, kg_encoder_lr=1e-3, perturb_encoders_lr=1e-3, fusion_lr=5e-4, decoder_lr=2e-2,
+              wd=1e-2, beta1=0.9, beta2=0.999, eps=1e-8)
+    (lab, hd, tl, y), (hlab, hhd, htl, hy) = _split(n, L, 1500, seed)
+    filler = torch.randn(n, 128, generator=torch.Generator().manual_seed(1))
+
+    def fresh():
+        model, _, batch, bkg, masks = _small_model(M, CASE, n, L, seed, default_init=True)
+        return model, batch, bkg, masks
+
+    # ---- the reference side: oracle forward + autograd + torch.optim.AdamW over the reference's parameter groups
+    model, batch, bkg, masks = fresh()
+    p0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    p0["decoder.parametrizations.weight.original"] *= 0.1          # logits of order 0.3 at the start: the steps go into the rule, not into shrinking random scores
+    frozen = {f"{name}.{pn}" for name, mod in model.named_modules() if isinstance(mod, torch.nn.BatchNorm1d) for pn, _ in mod.named_parameters()}
+    for k, q in model.named_parameters():
+        if k in frozen:
+            q.requires_grad_(False)
+    opt0 = create_optimizer(model, hp)
+    group_of = {id(q): gi for gi, g in enumerate(opt0.param_groups) for q in g["params"]}
+    named = dict(model.named_parameters())
+    frozen |= {k for k, q in named.items() if id(q) not in group_of}
+    pr = {k: (v.clone().requires_grad_(k in named and k not in frozen) if v.dtype.is_floating_point else v) for k, v in p0.items()}
+    groups = [{"params": [], "lr": g["lr"], "weight_decay": g["weight_decay"]} for g in opt0.param_groups]
+    for k, q in named.items():
+        if k not in frozen:
+            groups[group_of[id(q)]]["params"].append(pr[k])
+    ropt = torch.optim.AdamW([g for g in groups if g["params"]], betas=(hp["beta1"], hp["beta2"]), eps=hp["eps"])
+    ref_losses = []
+    for _ in range(steps):
+        ropt.zero_grad(set_to_none=True)
+        ref = oracle_pipeline(CASE, dict(pr), batch, bkg, masks, filler)
+        loss_r = torch.nn.BCELoss()(torch.sigmoid(ref["scores"])[lab, hd, tl], y)
+        loss_r.backward()
+        for k in named:
+            if k not in frozen and pr[k].grad is None:
+                pr[k].grad = torch.zeros_like(pr[k])
+        ropt.step()
+        ref_losses.append(float(loss_r.detach()))
+    with torch.no_grad():
+        ref_scores = oracle_pipeline(CASE, {k: (v.detach() if torch.is_tensor(v) else v) for k, v in pr.items()}, batch, bkg, masks, filler)["scores"]
+    ref_pred = torch.sigmoid(ref_scores)[hlab, hhd, htl].numpy()
+    auprc_ref, n_lab = _macro_auprc_sklearn(ref_pred, hy.numpy(), hlab.numpy(), L)
+    assert n_lab >= L - 2
+
+    # ---- the HIP path, per arithmetic mode, from the same initialisation
+    out = {}
+    for prec in ("bf16x3", "bf16"):
+        model, batch, bkg, masks = fresh()
+        model.load_state_dict(p0)
+        model = model.cuda().eval()
+        for k, q in model.named_parameters():
+            if k in frozen:
+                q.requires_grad_(False)
+        opt = create_optimizer(model, hp)
+        b = D.batch_to(batch, "cuda")
+        kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
+        fs = FinetuneStep(model, opt)
+        losses = []
+        with M.precision(prec):
+            for _ in range(steps):
+                opt.zero_grad(set_to_none=True)
+                losses.append(float(fs.accumulate(b, b, b["masks"], b["masks"], kgc, lab.cuda(), hd.cuda(), tl.cuda(), y.cuda(), kg_filler=filler.cuda())))
+                fs.apply()
+            with torch.no_grad():
+                plan = ops.triple_plan(hlab.cuda(), hhd.cuda(), htl.cuda(), L, n, n)
+                s = model.score_triples(b, b, b["masks"], b["masks"], kgc, plan, kg_filler=filler.cuda())
+        pred = torch.sigmoid(s)
+        auprc, _ = _macro_auprc_sklearn(pred.cpu().numpy(), hy.numpy(), hlab.numpy(), L)
+        own, _ = MT.macro_auprc(pred, hy.cuda(), hlab.cuda(), L)                 # the device metric against sklearn on the same predictions
+        assert abs(float(own) - auprc) < 1e-9
+        out[prec] = (auprc, losses)
+    print(f"held-out macro AUPRC after {steps} AdamW steps ({int(hy.numel())} held-out triples, {n_lab} outcomes): oracle {auprc_ref:.6f}, "
+          f"bf16x3 {out['bf16x3'][0]:.6f}, bf16 {out['bf16'][0]:.6f}; training loss {ref_losses[0]:.4f} -> {ref_losses[-1]:.4f} (oracle), "
+          f"{out['bf16x3'][1][0]:.4f} -> {out['bf16x3'][1][-1]:.4f} (bf16x3), {out['bf16'][1][0]:.4f} -> {out['bf16'][1][-1]:.4f} (bf16)")
+    assert ref_losses[-1] < 0.9 * ref_losses[0]                               # it trained
+    assert auprc_ref > float(hy.mean()) + 0.10                                 # and generalises beyond the positive rate (chance level of AUPRC)
+    for a, r in zip(out["bf16x3"][1], ref_losses):
+        assert abs(a - r) < 2e-3 * abs(r), (out["bf16x3"][1], ref_losses)      # loss trajectory, every step
+    assert abs(out["bf16x3"][0] - auprc_ref) < 1e-3, (out["bf16x3"][0], auprc_ref)      # north_star's bound
+    assert abs(out["bf16"][0] - auprc_ref) < 1e-2, (out["bf16"][0], auprc_ref)          # the 16-bit step: what it actually meets, an order looser

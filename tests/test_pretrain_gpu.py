@@ -80,7 +80,7 @@ def test_simclr_raw_training_step_matches_oracle_autograd(shared, basal):
     from madrigal_amd import data as D, models as M
     from oracle import madrigal_oracle as O
     from oracle.pipeline import oracle_simclr
-    from helpers import first_clean_seed
+    from helpers import assert_tensors_agree
     n, T = 72, 0.1
 
     def run(seed):
@@ -110,7 +110,7 @@ def test_simclr_raw_training_step_matches_oracle_autograd(shared, basal):
         assert rel_err(a1.detach().cpu(), ref["aug1"].detach()) < 2e-4 and rel_err(a2.detach().cpu(), ref["aug2"].detach()) < 2e-4
         named = dict(model.named_parameters())
         gmax = max(float(v.grad.abs().max()) for v in pr.values() if torch.is_tensor(v) and v.grad is not None)
-        checked, worst = 0, (0.0, "")
+        checked, errs = 0, []
         for k, v in pr.items():
             if k not in named or not (torch.is_tensor(v) and v.requires_grad):       # buffers (GIN eps, running statistics)
                 continue
@@ -121,8 +121,7 @@ def test_simclr_raw_training_step_matches_oracle_autograd(shared, basal):
                 continue
             assert named[k].grad is not None, f"{k}: no gradient on the HIP path"
             a, r = named[k].grad.cpu().double(), v.grad.double()
-            err = float((a - r).abs().max()) / max(float(r.abs().max()), 1e-2 * gmax)
-            worst = max(worst, (err, k))
+            errs.append((float((a - r).abs().max()) / max(float(r.abs().max()), 1e-2 * gmax), k))
             checked += 1
         assert checked > 60, checked
         # parameters outside the path get no gradient at all (the reference's optimizer skips them: grad is None there)
@@ -146,11 +145,10 @@ def test_simclr_raw_training_step_matches_oracle_autograd(shared, basal):
             assert int(sd[stem + "num_batches_tracked"]) == int(p0[stem + "num_batches_tracked"]) + len(calls), k
             n_bn += len(calls) > 0
         assert n_bn >= 4 + 2 + 2                                    # GIN x4, chemCPA encoder x2, the predictors' BatchNorms
-        return worst
+        return errs
 
-    # strict: every gradient entry within 5e-4 of its tensor's scale (was 2e-3 on one hand-picked seed); see helpers.first_clean_seed
-    tried = first_clean_seed(run, (34, 33, 35, 36), strict=5e-4, loose=5e-2)
-    print("seeds tried (seed, (worst error, tensor)):", tried)
+    # every seed: all gradient tensors but a flipped unit's own (helpers.assert_tensors_agree) within 5e-4 of their scale, all within 5e-2
+    print("(seed, (worst error, tensor), tensors beyond 5e-4):", [(sd,) + assert_tensors_agree(run(sd), 5e-4, 5e-2, what=f"seed {sd}") for sd in (33, 34, 35, 36)])
 
 
 def test_simclr_raw_pretraining_steps_reduce_loss_and_are_reproducible():

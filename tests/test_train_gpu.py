@@ -1076,7 +1076,6 @@ def test_three_adamw_steps_match_oracle_autograd_plus_torch_adamw():
     from helpers import oracle_pipeline
     case = ("drugbank163", "transformer", 4, "learnable", 8, 64, 256, 2, True, "x-attn", True, False)
     n, L, steps = 96, 24, 3
-    from helpers import first_clean_seed
 
     def run(seed):
         hp = dict(optimizer="adamw", structure_encoder_lr=3e-4, kg_encoder_lr=2e-4, perturb_encoders_lr=1e-4, fusion_lr=5e-5, decoder_lr=1e-3,
@@ -1156,14 +1155,15 @@ def test_three_adamw_steps_match_oracle_autograd_plus_torch_adamw():
         assert checked > 60 and n_solid > 200_000, (checked, n_solid)
         # The comparison is between two fp32 implementations (the CPU reference's autograd sums in another order), and Adam's
         # m_hat / sqrt(v_hat) passes a gradient's relative error straight into the step: the bulk of the entries sits at SURVEY's
-        # 1e-5 of the tensor's largest delta, the tail at the fp32 backward's own noise, a handful at a flipped ReLU.
-        return max(med / 1e-5, q999 / 1e-4, worst[0] / 2e-3), (med, q99, q999, worst)
+        # 1e-5 of the tensor's largest delta, the tail at the fp32 backward's own noise, a handful at a flipped ReLU (one flipped unit
+        # moves a whole row of a weight gradient, and Adam carries it into three steps).
+        return med, q999, worst
 
-    # strict (score < 1): median < 1e-5, 99.9 % quantile < 1e-4, worst entry < 2e-3 of the tensor's largest delta, on the first seed
-    # without a flipped ReLU; every tried seed within 100x of that (helpers.first_clean_seed: one flipped unit moves a whole row of a
-    # weight gradient, and Adam's m_hat / sqrt(v_hat) carries it into three steps)
-    tried = first_clean_seed(run, (31, 32, 33, 34), strict=1.0, loose=100.0)
-    print("seeds tried:", tried)
+    # every seed of a fixed range, no search: median < 1e-5 and 99.9 % quantile < 1e-4 of the tensor's largest delta -- the bulk, which
+    # a defect anywhere in the step moves and a flipped unit does not -- and the worst single entry < 0.2
+    for seed in (31, 32, 33, 34):
+        med, q999, worst = run(seed)
+        assert med < 1e-5 and q999 < 1e-4 and worst[0] < 0.2, (seed, med, q999, worst)
 
 
 # ---------------------------------------------------------------------------------------------- dense head, drop-in loop
