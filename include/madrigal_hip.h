@@ -252,6 +252,25 @@ int mdg_gather_bce(const float* scores, int64_t n_labels, int64_t n_head, int64_
                    const int64_t* tail, const float* target, float* pred, float* term, float* loss, int64_t n, int apply_sigmoid,
                    void* stream);
 
+/* ------------------------------------------------------------------------- tuning switches ---- *
+ * Environment variables read by the library (csrc: once, re-read after mdg_tuning_reload()) or by the Python host layer.  Each
+ * changes speed or selects between paths that produce the same results within the tests' bounds; none is needed for normal use.
+ * Round 5 removed every switch whose experiment was decided (35 of them: store schedules, wave counts, stream-K, the LSD
+ * look-back, ...).  What is left, with defaults:
+ *   MDG_RANKS_MSD        [1]  0: rank normalisation by the four-pass LSD sort only (what N > 5793 and flagged outcomes take)
+ *   MDG_RANKS_GROUP      [8]  outcomes per launch group of the MSD path (its scratch is reused from group to group)
+ *   MDG_RANKS_DIRECT     [0]  test hook: the LSD sort's last pass stores ranks one by one (what N > 16256 takes) at any N
+ *   MDG_BILINEAR_SYMMETRIC [1] 0: z_head == z_tail takes the general sweep instead of the symmetric one
+ *   MDG_LINEAR_TILE      [0 = by shape]  128 / 256: force the dense block's tile shape
+ *   MDG_LINEAR_RAWX      [1]  0: the 128-tile kernel's x through an operand pre-pass instead of rounded while staged
+ *   MDG_LINEAR_TAIL128   [1]  0: no row split of a dense block's last partial round of 256-tiles
+ *   MDG_KG_GRAPH         [per step kind]  0 / 1: the KG pass of a training step eager / replayed as hipGraphs
+ *   MDG_SHARE_SIDES      [1]  0: dropout-free encoders run once per side of a step even when both sides are one batch
+ *   MDG_FUSE_SIDES       [1]  0: the two sides of a finetune step through the fusion transformer in two passes
+ *   MDG_FUSE_VIEWS       [1]  0: the two views of a contrastive step through the per-row stages in two passes
+ *   MDG_SHARD_KG         [1]  0: multi-GPU inference keeps the KG encoder replicated instead of destination-partitioned
+ * Build / bench only: MDG_EXTRA_HIPCC_FLAGS (madrigal_amd/build.py, e.g. -DMDG_RANK_STAMPS), MDG_BENCH_* (bench.py). */
+
 /* ---------------------------------------------------------------------- rank normalisation ---- */
 
 size_t mdg_rank_normalize_workspace_bytes(int64_t n_outcomes, int64_t N);

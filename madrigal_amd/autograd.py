@@ -996,22 +996,20 @@ _hgt_lanes = {}
 class _type_lanes:
     """The destination types of a conv are independent launches (every type reads the shared projection buffer and writes its own
     rows / its own relations' column blocks): they are dealt to a few side streams that fork from the current stream and join it
-    again, so that the small types' kernels run beside the large ones instead of in a chain of launch gaps.  MDG_HGT_LANES=1 (or a
+    again, so that the small types' kernels run beside the large ones instead of in a chain of launch gaps.  One lane (or a
     CPU tensor) keeps the plain loop.
     Inside a stream capture (the KG pass replayed as hipGraphs, NovelDDIEncoder._kg_graphed) the fork / join become edges of the
     graph: parallel branches cost the replay nothing, so there the per-type CHAINS of small launches (``chains=True``: one
     projection GEMM per node type, a type's GELU / out_lin / gated residual, their backward) are dealt out too, on
-    MDG_HGT_CHAIN_LANES (2: measured best of 1-4) branches.  Eager launches pay an event round trip per fork and join, which costs the chains more
+    two (measured best of 1-4) branches.  Eager launches pay an event round trip per fork and join, which costs the chains more
     than their concurrency returns (finetune step 40.5 -> 41.5 ms): outside a capture ``chains`` keeps the plain loop."""
 
     def __init__(self, ref: torch.Tensor, n_items: int, chains: bool = False):
         capturing = ref.is_cuda and torch.cuda.is_current_stream_capturing()
-        if capturing and os.environ.get("MDG_HGT_LANES_IN_GRAPH", "1") == "0":
-            want = 1
-        elif chains:
-            want = int(os.environ.get("MDG_HGT_CHAIN_LANES", "2")) if (capturing and _bn_sync["reduce"] is None) else 1
+        if chains:
+            want = 2 if (capturing and _bn_sync["reduce"] is None) else 1        # measured best of 1-4 branches
         else:
-            want = int(os.environ.get("MDG_HGT_LANES", "2"))
+            want = 2
         self.cur = self.lanes = None
         if ref.is_cuda and want > 1 and n_items > 1:
             self.cur = torch.cuda.current_stream(ref.device)

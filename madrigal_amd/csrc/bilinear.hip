@@ -1207,13 +1207,8 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
   const dim3 grid(static_cast<unsigned>(mdg_cdiv(a.n_head, 32 * NW)), static_cast<unsigned>(a.n_labels));
   const dim3 block(64 * NW);
   const size_t lds = 2 * STAGE_BYTES;
-  // MDG_BILINEAR_VARIANT: 0 = one burst of 32 dword stores per wave and stage (early / late halves), 1 = those stores spread
-  // between the MFMAs of the next tile, 2 = tile transposed through LDS, 8 x 16-byte stores spread between the MFMAs.  Read per
-  // call; changes speed only (same products, same accumulation order, same bytes stored).
-  static MdgEnvInt variant_sw{"MDG_BILINEAR_VARIANT", 0};
-  int variant = variant_sw.get();
-  if (variant < 0 || variant > 2 || a.pipeline != 0) variant = 0;
-  if (variant == 2 && ((a.ldo & 3) != 0 || a.ldo < ((a.n_tail + 3) & ~static_cast<int64_t>(3)) || !mdg_aligned16(a.out))) variant = 0;     // 16-byte stores need aligned rows
+  // (store schedule of the general sweep: one burst of 32 dword stores per wave and stage, early / late halves.  Rounds 2-3 also had
+  // the stores spread between the next tile's MFMAs and a tile transposed through LDS for 16-byte stores: neither won, removed)
   const size_t lds2 = lds + static_cast<size_t>(NW) * 8192;
   // Symmetric sweep (z_head and z_tail are the same matrix): half the matrix work, every off-diagonal tile stored twice.
   // Default for that case; MDG_BILINEAR_SYMMETRIC=0 switches it off.
@@ -1227,8 +1222,7 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
                     (long long)a.n_tail, (long long)a.ldo);
       const int nb = static_cast<int>(mdg_cdiv(a.n_tail, 256));
       const dim3 gsym(static_cast<unsigned>((nb + 1) / 2), static_cast<unsigned>(a.n_labels));
-      static MdgEnvInt sc1k_sw{"MDG_BILINEAR_SC1", -1};
-      const bool sc1 = sc1k_sw.get() >= 0 ? sc1k_sw.get() != 0 : (MODE == MDG_PREC_BF16X3);
+      const bool sc1 = MODE == MDG_PREC_BF16X3;
       if (sc1) hipLaunchKernelGGL((bilinear_allpairs_sym_kernel<MODE, MDG_EPI_TRIKEYS, 8, 1>), gsym, block, lds2, st, a);
       else hipLaunchKernelGGL((bilinear_allpairs_sym_kernel<MODE, MDG_EPI_TRIKEYS, 8, 0>), gsym, block, lds2, st, a);
       MDG_CHECK_LAUNCH("mdg_bilinear_allpairs(lower-triangle keys)");
@@ -1240,8 +1234,7 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
       const dim3 gsym(static_cast<unsigned>((nb + 1) / 2), static_cast<unsigned>(a.n_labels));
       // write-through score stores keep z_tail L2-resident (FETCH 11.3 -> 0.8 GB per launch at 4096^2 x 896); measured faster for
       // the three-product mode (11.78 -> 11.53 ms), slower for the single-product 16-bit modes (10.70 -> 11.11 ms)
-      static MdgEnvInt sc1_sw{"MDG_BILINEAR_SC1", -1};
-      const bool sc1 = sc1_sw.get() >= 0 ? sc1_sw.get() != 0 : (MODE == MDG_PREC_BF16X3);
+      const bool sc1 = MODE == MDG_PREC_BF16X3;
       if (epilogue == MDG_EPI_STORE) {
         if (sc1) hipLaunchKernelGGL((bilinear_allpairs_sym_kernel<MODE, MDG_EPI_STORE, 8, 1>), gsym, block, lds2, st, a);
         else hipLaunchKernelGGL((bilinear_allpairs_sym_kernel<MODE, MDG_EPI_STORE, 8, 0>), gsym, block, lds2, st, a);
@@ -1260,35 +1253,15 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
   }
   switch (epilogue) {
     case MDG_EPI_STORE:
-      if (variant == 2)
-        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE, NW, 1, 2>), grid, block, lds2, st, a);
-      else if (variant == 1)
-        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE, NW, 1, 1>), grid, block, lds, st, a);
-      else
-        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE, NW>), grid, block, lds, st, a);
+      hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE, NW>), grid, block, lds, st, a);
       break;
     case MDG_EPI_STORE_SIGMOID:
-      if (variant == 2)
-        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE_SIGMOID, NW, 1, 2>), grid, block, lds2, st, a);
-      else if (variant == 1)
-        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE_SIGMOID, NW, 1, 1>), grid, block, lds, st, a);
-      else
-        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE_SIGMOID, NW>), grid, block, lds, st, a);
+      hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_STORE_SIGMOID, NW>), grid, block, lds, st, a);
       break;
     case MDG_EPI_ROWSTATS: {    // three-buffer ring (prefetch distance two)
-      static MdgEnvInt rb_sw{"MDG_BILINEAR_RB", 2};
-      const int rb2 = rb_sw.get();
-      if (kSingle16<MODE> && rb2 == 2 && a.pipeline == 0) {     // 64 rows per wave: halves the LDS operand reads per MFMA
+      if constexpr (kSingle16<MODE> && NW == 8) {              // 64 rows per wave (halves the LDS operand reads per MFMA) on v_mfma_f32_16x16x32
         const dim3 grid2(static_cast<unsigned>(mdg_cdiv(a.n_head, 32 * NW * 2)), static_cast<unsigned>(a.n_labels));
-        static MdgEnvInt m16_sw{"MDG_BILINEAR_MFMA16", 1};
-        const int shape16 = m16_sw.get();
-        if constexpr (kSingle16<MODE> && NW == 8) {
-          if (shape16) {                                       // the same sweep on v_mfma_f32_16x16x32 (power-bound loop)
-            hipLaunchKernelGGL((bilinear_rowstats16_kernel<MODE>), grid2, block, 3 * STAGE_BYTES, st, a);
-            break;
-          }
-        }
-        hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_ROWSTATS, NW, (kSingle16<MODE> ? 2 : 1)>), grid2, block, 3 * STAGE_BYTES, st, a);
+        hipLaunchKernelGGL((bilinear_rowstats16_kernel<MODE>), grid2, block, 3 * STAGE_BYTES, st, a);
       } else {
         hipLaunchKernelGGL((bilinear_allpairs_kernel<MODE, MDG_EPI_ROWSTATS, NW>), grid, block, 3 * STAGE_BYTES, st, a);
       }
@@ -1302,15 +1275,10 @@ int launch_allpairs_nw(const BilinearArgs& a, int epilogue, hipStream_t st) {
   return MDG_OK;
 }
 
-// Workgroup shape.  4 waves x 128 rows lets two workgroups share a CU (2 x 64 KB LDS): they drift
-// out of lockstep, so one group's MFMA phase covers the other's store drain.  MDG_BILINEAR_WAVES
-// (4 or 8) overrides the choice for experiments; it is read per call and changes speed only.
+// Workgroup shape: 8 waves x 32 rows (4 waves x 128 rows, two workgroups per CU, was the alternative of rounds 1-2)
 template <int MODE>
 int launch_allpairs(const BilinearArgs& a, int epilogue, hipStream_t st) {
-  static MdgEnvInt nw_sw{"MDG_BILINEAR_WAVES", 8};
-  const int nw = nw_sw.get();
-  if (nw == 8 || epilogue == MDG_EPI_TRIKEYS) return launch_allpairs_nw<MODE, 8>(a, epilogue, st);
-  return launch_allpairs_nw<MODE, 4>(a, epilogue, st);
+  return launch_allpairs_nw<MODE, 8>(a, epilogue, st);
 }
 
 }  // namespace
@@ -1377,13 +1345,7 @@ extern "C" int mdg_bilinear_allpairs_ld(const float* z_head, const float* z_tail
   a.stagger = 1;
   a.stagger_waves = 1;
   a.loaders = 4;
-  static MdgEnvInt pipe_sw{"MDG_BILINEAR_PIPELINE", 0}, load_sw{"MDG_BILINEAR_LOADERS", 4}, stw_sw{"MDG_BILINEAR_STAGGER_WAVES", 1},
-      stg_sw{"MDG_BILINEAR_STAGGER", 1};
-  a.pipeline = pipe_sw.get() ? 1 : 0;
-  a.loaders = load_sw.get();
-  if (a.loaders != 1 && a.loaders != 2 && a.loaders != 4) a.loaders = 4;
-  a.stagger_waves = stw_sw.get();
-  a.stagger = stg_sw.get();
+  a.pipeline = 0;
   // diagnostics: clock stamps per workgroup, only into a buffer handed over through mdg_debug_bilinear_stamps and only when it is large enough
   {
     const int64_t wgs = mdg_cdiv(n_head, 128) * n_labels;          // the largest grid any variant launches

@@ -148,10 +148,9 @@ __global__ __launch_bounds__(256) void sum_splits_kernel(const float* __restrict
 // 16-bit form: ~2 workgroups per CU, at least 512 rows per split (a partial tile costs as much traffic as 64 rows of both operands;
 // measured: 1-tile outputs 34 -> 31 us with 512 instead of 256 rows, wide ones unchanged)
 int pick_splits16(int64_t M, int64_t N, int64_t K) {
-  static MdgEnvInt target_sw{"MDG_GW16_TARGET", 512}, minrows_sw{"MDG_GW16_MINROWS", 512};
   const int64_t tiles = mdg_cdiv(N, 128) * mdg_cdiv(K, 128);
-  int64_t s = mdg_cdiv(target_sw.get(), tiles);
-  const int64_t mr = minrows_sw.get();
+  int64_t s = mdg_cdiv(512, tiles);                       // ~2 workgroups per CU
+  const int64_t mr = 512;                                 // at least 512 rows per split
   const int64_t max_s = M / mr > 1 ? M / mr : 1;
   if (s > max_s) s = max_s;
   if (s > 4096) s = 4096;
@@ -159,8 +158,7 @@ int pick_splits16(int64_t M, int64_t N, int64_t K) {
 }
 
 bool use16(int precision, const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t N, int64_t K) {
-  static MdgEnvInt sw{"MDG_GRAD_WEIGHT_16", 1};
-  return (precision == MDG_PREC_BF16 || precision == MDG_PREC_BF16X3) && sw.get() != 0 && N % 4 == 0 && K % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0 &&
+  return (precision == MDG_PREC_BF16 || precision == MDG_PREC_BF16X3) && N % 4 == 0 && K % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0 &&
          (g == nullptr || mdg_aligned16(g)) && (x == nullptr || mdg_aligned16(x));
 }
 

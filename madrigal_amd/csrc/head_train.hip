@@ -490,8 +490,7 @@ extern "C" int mdg_bilinear_gather_bwd_prec(const float* z_head, const float* z_
   }
   if (dw) {
     MDG_CHECK_ARG(label_chunk_ptr && (n_chunks == 0 || (chunk_start && dw_partial)), "mdg_bilinear_gather_bwd: dW needs the chunk tables and scratch");
-    static MdgEnvInt dw16_sw{"MDG_HEAD_DW_16", 1};
-    if (n_chunks > 0 && precision != MDG_PREC_F32 && dw16_sw.get() != 0 && mdg_aligned16(z_head) && mdg_aligned16(z_tail)) {
+    if (n_chunks > 0 && precision != MDG_PREC_F32 && mdg_aligned16(z_head) && mdg_aligned16(z_tail)) {
       // the chunk's outer-product sum as a TN product of gathered rows on the split-bf16 matrix cores (fp32-grade: three products of
       // the hi / lo halves, fp32 accumulation) -- in every 16-bit mode of the step: the head stays fp32-grade
       GwArgs a{z_head, HD, z_tail, HD, dw_partial, nullptr, 0, 0, HD, HD, head, tail, dscore, chunk_start};
@@ -515,10 +514,7 @@ extern "C" int mdg_bilinear_matvec_rows(const float* z, const float* w, const in
   MDG_CHECK_ARG(z && w && tile_start && tile_label && rows_out && mdg_aligned16(z) && mdg_aligned16(w) && mdg_aligned16(rows_out),
                 "mdg_bilinear_matvec_rows: null / misaligned pointer");
   GatherArgs a{z, z, w, w, row_index, row_index, tile_start, tile_label, n_tiles, nullptr, nullptr, rows_out, nullptr};
-  static MdgEnvInt old_sw{"MDG_MATVEC_ROWS_OLD", 0};
-  const bool old_path = old_sw.get() != 0;
-  if (old_path) hipLaunchKernelGGL(bilinear_gather_kernel<2>, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-  else hipLaunchKernelGGL(bilinear_matvec_rows_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(bilinear_matvec_rows_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_tiles, 4))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   MDG_CHECK_LAUNCH("mdg_bilinear_matvec_rows");
   return MDG_OK;
 }
@@ -531,8 +527,7 @@ extern "C" int mdg_bilinear_matvec_rows_prec(const float* z, const float* w, int
                                              const int64_t* tile_label, int64_t n_tiles, float* rows_out, int64_t D, int precision, void* workspace,
                                              size_t workspace_bytes, void* stream) {
   MDG_CHECK_ARG(precision == MDG_PREC_F32 || precision == MDG_PREC_BF16 || precision == MDG_PREC_BF16X3, "mdg_bilinear_matvec_rows: unknown precision %d", precision);
-  static MdgEnvInt mv16_sw{"MDG_HEAD_MATVEC_16", 1};
-  if (precision == MDG_PREC_F32 || mv16_sw.get() == 0) return mdg_bilinear_matvec_rows(z, w, row_index, tile_start, tile_label, n_tiles, rows_out, D, stream);
+  if (precision == MDG_PREC_F32) return mdg_bilinear_matvec_rows(z, w, row_index, tile_start, tile_label, n_tiles, rows_out, D, stream);
   MDG_CHECK_ARG(D == HD, "mdg_bilinear_matvec_rows: D must be 128 (got %lld)", (long long)D);
   MDG_CHECK_ARG(n_tiles >= 0 && n_labels > 0, "mdg_bilinear_matvec_rows: bad sizes");
   if (n_tiles == 0) return MDG_OK;

@@ -1226,8 +1226,7 @@ static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t 
   a.vec_r = a.res && mdg_aligned16(a.res) && a.ldr % 4 == 0;
   const bool big = choose_big(precision, M, N);
   // 1-D grid; the kernel maps the linear workgroup id to a tile (XCD-aware order once there are enough tiles to matter)
-  static MdgEnvInt swz_sw{"MDG_LINEAR_SWIZZLE", -1};
-  const int swz_env = swz_sw.get();
+  constexpr int swz_env = -1;                              // XCD-aware tile order once there are 64 tiles
   const auto grid_for = [&](int bm, int bn) {
     a.tiles_x = static_cast<int>(mdg_cdiv(N, bn));
     a.tiles_y = static_cast<int>(mdg_cdiv(M, bm));
@@ -1235,9 +1234,8 @@ static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t 
     a.swizzle = swz_env >= 0 ? swz_env : (total >= 64 ? 1 : 0);
     return dim3(static_cast<unsigned>(a.swizzle ? 8 * ((total + 7) / 8) : total));
   };
-  // 16-bit modes run on the 16x16x32 MFMA unless MDG_LINEAR_MFMA=32 asks for the 32x32x16 form (128-tile kernel only)
-  static MdgEnvInt mfma_sw{"MDG_LINEAR_MFMA", 16};
-  const bool m16 = mfma_sw.get() != 32;
+  // 16-bit modes run on the 16x16x32 MFMA (the 32x32x16 form of the 128-tile kernel lost: MI355X_MICROARCH.md, DVFS give-back item 7)
+  constexpr bool m16 = true;
   if (big) {
     dim3 grid = grid_for(pp::BM, pp::BN);
     // stream-K hybrid when the last round of tiles would leave CUs idle (see the kernel): needs the slots in the workspace
@@ -1246,7 +1244,7 @@ static void launch_linear_core(LinearArgs& a, int precision, int64_t M, int64_t 
     // fill of every piece, the slot round trip -- about +11 us per 65-us tile, which is what the saved part of a round is worth
     // at these sizes ([22464, 2048] x 2048: 216-233 us plain, 251 us hybrid).  MDG_LINEAR_STREAMK=1 switches it on, 2 runs the
     // persistent loop without shared tiles.
-    static MdgEnvInt sk_sw{"MDG_LINEAR_STREAMK", 0};
+    struct { int get() const { return 0; } } sk_sw;          // the stream-K hybrid stays OFF (measured, above); its kernel variant is not dispatched
     const int total = a.tiles_x * a.tiles_y, P = resident_workgroups();
     const int rem = total % P;
     const int64_t nk = a.K / (precision == MDG_PREC_BF16 ? 64 : 32);
@@ -1509,8 +1507,7 @@ __global__ __launch_bounds__(256) void ksplit_sum_kernel(const float* __restrict
 // Weight-gradient products with few output tiles (dW [2048, 1024] over 22 016 rows: 128 tiles of 128 x 128, half the CUs idle for the
 // whole K loop): the K range is split over grid.y so that ~256 workgroups run, partial products summed afterwards.
 static int tn_splits(int precision, int64_t N, int64_t K, int64_t Mp) {
-  static MdgEnvInt sw{"MDG_LINEAR_TN_SPLITK", 1};
-  if (!sw.get() || choose_big(precision, N, K) || K % 4 != 0) return 1;
+  if (choose_big(precision, N, K) || K % 4 != 0) return 1;
   const int64_t tiles = mdg_cdiv(N, Small::BM) * mdg_cdiv(K, Small::BN);
   if (tiles >= 192 || Mp < 4096) return 1;
   int64_t s = 256 / tiles;

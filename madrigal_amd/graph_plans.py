@@ -17,7 +17,7 @@ import os
 
 # edges per work item: bounds the serial walk of one wave over a heavy-tailed KG destination (one wave walks its item 4 edges per
 # step, each step a dependent col -> row gather of ~2 us: at 512 edges the longest items ARE the kernel's duration)
-HGT_CHUNK = int(os.environ.get("MDG_HGT_CHUNK", "128"))     # 512 -> 128: encode 12.4 -> 11.8 ms, finetune step 68.7 -> 66.0 ms
+HGT_CHUNK = 128     # 512 -> 128: encode 12.4 -> 11.8 ms, finetune step 68.7 -> 66.0 ms
 
 
 def _rowptr(sorted_dst: torch.Tensor, n: int) -> torch.Tensor:

@@ -425,6 +425,8 @@ class HGTConv(nn.Module):
     edges of a node fused with the weighted value sum is mdg_hgt_attention; output projection, GELU and the
     sigmoid(skip)-gated residual are fused epilogues."""
 
+    batched_weights = True         # composite projection weights of all node types built at once (False, tests only: one node type at a time)
+
     def __init__(self, in_channels, out_channels, metadata, heads=1, group="sum", **kwargs):
         super().__init__()
         if out_channels % heads != 0:
@@ -652,9 +654,9 @@ class HGTConv(nn.Module):
         layout = [(plan["base"][t], sizes[t], plan["width"][t]) for t in types]
         spec = dict(zip(types, layout))
         xs = [x_dict[t].float() for t in types]
-        if types and len({x.shape[1] for x in xs}) == 1 and os.environ.get("MDG_HGT_BATCHED_WEIGHTS", "1") != "0":
-            # (MDG_HGT_COMPOSITE_TORCH=1: the same rows assembled with ~30 torch ops and torch's autograd, rounds 2-3; kept as the test's reference)
-            big_w, big_b, offs = (self._composite_all_train if os.environ.get("MDG_HGT_COMPOSITE_TORCH", "0") == "1" else self._composite_all_hip)(types, plan)
+        if types and len({x.shape[1] for x in xs}) == 1 and self.batched_weights:
+            # (_composite_all_train assembles the same rows with ~30 torch ops and torch's autograd, rounds 2-3: the tests' second reference)
+            big_w, big_b, offs = self._composite_all_hip(types, plan)
             flat = ag.hgt_project_rows(layout, plan["total_floats"], _state["precision"], xs, big_w, big_b, offs)
         else:                                                         # node types of different input width: one weight each
             mk_all, mv_all = self._relation_blocks_train()
@@ -667,7 +669,7 @@ class HGTConv(nn.Module):
         def block(t):                                                  # this rank's rows of type t inside the flat buffer
             off, _, width = spec[t]
             return (off + rng[t][0] * width, rng[t][1] - rng[t][0], width)
-        rows16 = _state["precision"] == "bf16" and os.environ.get("MDG_HGT_ROWS16", "1") != "0"
+        rows16 = _state["precision"] == "bf16"
         pres = ag.hgt_attention_flat(flat, H, [plan["per_dst"][t] for t in dst_types], [block(t) for t in dst_types], rows16=rows16) if dst_types else ()
         out = {}
         # the destination types' output stages (GELU, out_lin, gated residual: a chain of small launches per type, and as many again
@@ -816,7 +818,7 @@ class HGTConv(nn.Module):
             from .parallel import shard_range
             dst_range = {t: shard_range(sizes[t], shard[0], shard[1]) for t in sizes}
         plan = self._plan(edge_index_dict, sizes, dev, want, dst_range)
-        if dst_range is None and os.environ.get("MDG_HGT_GROUPED", "1") != "0":
+        if dst_range is None:
             out = self._forward_grouped(x_dict, plan, sizes, want, dev)
             if out is not None:
                 return out
@@ -1128,14 +1130,10 @@ class TransformerFusion(nn.Module):
         continue after the attention (last layer: only the pooled key tokens are ever read again)."""
         sa = L.self_attn
 
-        fused = os.environ.get("MDG_FUSED_PACK", "1") != "0"
-
         def norm(x, ln, want_fp32=True):
             """LayerNorm whose kernel also writes the output as the packed operand of the dense block that consumes it
-            (image None: fp32 mode / odd width / switched off -> the block packs its input itself).  ``want_fp32=False``:
+            (image None: fp32 mode / odd width -> the block packs its input itself).  ``want_fp32=False``:
             the fp32 rows are skipped when the image exists (pre-norm: only linear1 reads norm2's output)."""
-            if not fused:
-                return ops.layernorm(x, ln.weight, ln.bias, ln.eps), None
             return ops.layernorm_packed(x, ln.weight, ln.bias, ln.eps, _state["precision"], want_fp32)
 
         def lin_of(x, img, w, b, rows=None, **kw):
@@ -1147,7 +1145,7 @@ class TransformerFusion(nn.Module):
             row decides its own output row and nothing else): keys and values for all rows, queries for the kept rows only --
             the other rows' query slots stay unwritten and so do the outputs computed from them, which are dropped."""
             w, b = sa.in_proj_weight.detach(), sa.in_proj_bias.detach()
-            if keep_rows is None or os.environ.get("MDG_FUSION_Q_KEPT_ONLY", "1") == "0" or a.shape[0] < 4 * keep_rows.numel() // 3:
+            if keep_rows is None or a.shape[0] < 4 * keep_rows.numel() // 3:
                 return lin_of(a, img, w, b)
             d = w.shape[1]
             qkv = torch.empty((a.shape[0], 3 * d), dtype=torch.float32, device=a.device)
@@ -1244,9 +1242,7 @@ class TransformerFusion(nn.Module):
         mha = self.x_attn_mha_layer
         w, b = mha.in_proj_weight.detach(), mha.in_proj_bias.detach()
         ln = self.x_attn_kv_norm
-        img = None
-        if os.environ.get("MDG_FUSED_PACK", "1") != "0":           # the norm writes the K|V projection's packed operand itself
-            _, img = ops.layernorm_packed(h_keys, ln.weight, ln.bias, ln.eps, _state["precision"], want_fp32=False)
+        _, img = ops.layernorm_packed(h_keys, ln.weight, ln.bias, ln.eps, _state["precision"], want_fp32=False)      # the norm writes the K|V projection's packed operand itself
         if img is not None:
             kvp = ops.linear_packed(img, h_keys.shape[0], w[d:], b[d:], precision=_state["precision"])
         else:
@@ -1792,7 +1788,7 @@ class NovelDDIEncoder(nn.Module):
         # encoder's backward overlaps the other encoders' backward the same way its forward overlaps their forward
         # (measured: finetune step 115 -> 110 ms with the KG stream, -> 107 ms with the structure encoder on a third stream;
         # the tx encoder on a fourth made it slower).  Data-parallel steps keep one stream: their collectives stay in one order.
-        overlap = self.overlap_kg and (not train or (os.environ.get("MDG_TRAIN_OVERLAP_KG", "1") != "0" and ag._bn_sync["reduce"] is None))
+        overlap = self.overlap_kg and (not train or ag._bn_sync["reduce"] is None)
         if overlap:
             if self._kg_stream is None or self._kg_stream.device != dev:
                 self._kg_stream = torch.cuda.Stream(device=dev)
@@ -1809,7 +1805,7 @@ class NovelDDIEncoder(nn.Module):
         skey, tkey = ("str", id(batch_mols)), ("tx", id(batch_tx_dict))
         s_hit = share.get(skey) if share_enc else None
         # training: the structure encoder (a chain of small launches over the atoms, forward and backward) on a third stream
-        str_side = overlap and train and s_hit is None and os.environ.get("MDG_TRAIN_OVERLAP_STR", "1") != "0"
+        str_side = overlap and train and s_hit is None
         if s_hit is not None:
             str_out = s_hit[0]
             ag.replay_batchnorm(s_hit[1])

@@ -141,7 +141,7 @@ def empty_scores(L: int, Nh: int, Nt: int, device) -> torch.Tensor:
     32 floats, so that every row starts on a 128-byte line whatever Nt is (the real drug counts -- 11 607 in
     generate_embeddings.ipynb -- are not multiples of anything).  For Nt % 32 == 0 this is a plain contiguous tensor; otherwise a
     [:, :, :Nt] view of the padded storage: same values and indexing, ``.contiguous()`` compacts it."""
-    unit = int(os.environ.get("MDG_SCORE_PITCH", "32"))           # floats; 32 = one 128-byte line (experiments: scripts/head_ragged_bench.py)
+    unit = 32                                                     # floats: one 128-byte line (scripts/head_ragged_bench.py compared 4 .. 64)
     pitch = (Nt + unit - 1) // unit * unit
     return torch.empty((L, Nh, pitch), dtype=torch.float32, device=device)[:, :, :Nt]
 

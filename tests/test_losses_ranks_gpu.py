@@ -147,20 +147,18 @@ def test_rank_all_pairs_equals_ranks_of_score_all_pairs():
     assert torch.equal(mine, want.contiguous())
 
 
-@pytest.mark.parametrize("path", ["msd", "msd_group1", "msd_group5", "lsd", "lsd_tile8192", "lsd_direct"])
+@pytest.mark.parametrize("path", ["msd", "msd_group1", "msd_group5", "lsd", "lsd_direct"])
 @pytest.mark.parametrize("N,L", [(300, 5), (2, 3), (1, 2), (97, 1), (1025, 2), (1283, 1)])
 def test_ranks_vs_oracle(ops, monkeypatch, N, L, path):
     """Every path of the sort.  msd*: the default up to N = 5793 -- one exact-layout MSD partition + in-LDS bucket sort, 8 / 1 / 5 outcomes
-    per launch group.  lsd*: the four-pass LSD sort (larger N, and whatever the MSD path hands back): 16384-key tiles and 8192-key
-    tiles, the blocked last pass and the direct one (the large-N path).  Contiguous and row-pitched tensors; ragged N (not a multiple
+    per launch group.  lsd*: the four-pass LSD sort (larger N, and whatever the MSD path hands back): the blocked last pass and the
+    direct one (the large-N path).  Contiguous and row-pitched tensors; ragged N (not a multiple
     of 128 / 4)."""
     from helpers import set_switch
     from oracle import madrigal_oracle as O
     set_switch(monkeypatch, "MDG_RANKS_MSD", "0" if path.startswith("lsd") else "1")
     if path.startswith("msd_group"):
         set_switch(monkeypatch, "MDG_RANKS_GROUP", path[len("msd_group"):])
-    if path == "lsd_tile8192":
-        set_switch(monkeypatch, "MDG_RANKS_TILE", "8192")
     if path == "lsd_direct":
         set_switch(monkeypatch, "MDG_RANKS_DIRECT", "1")
     rng = np.random.default_rng(N)

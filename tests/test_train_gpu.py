@@ -626,8 +626,9 @@ def test_hgt_training_gradients_match_oracle_autograd(only_drug, batched, heads,
     gradient of kqv_lin / k_rel / v_rel / p_rel comes out of mdg_hgt_composite_bwd), "torch": by the ~30 torch ops of rounds 2-3 and
     torch's autograd -- or one node type at a time ("0")."""
     from madrigal_amd import data, models as M
-    monkeypatch.setenv("MDG_HGT_BATCHED_WEIGHTS", "0" if batched == "0" else "1")
-    monkeypatch.setenv("MDG_HGT_COMPOSITE_TORCH", "1" if batched == "torch" else "0")
+    monkeypatch.setattr(M.HGTConv, "batched_weights", batched != "0")
+    if batched == "torch":                                  # the second reference: the same composite rows from torch ops + torch's autograd
+        monkeypatch.setattr(M.HGTConv, "_composite_all_hip", M.HGTConv._composite_all_train)
     from oracle import madrigal_oracle as O
     torch.manual_seed(7)
     kg = data.make_kg(60, seed=4, n_nodes=700, n_edges=9000, n_node_types=5, n_rel_pairs=6)
