@@ -191,6 +191,20 @@ def gin_bias_case():
     return mols, p, b, torch.bincount(dst, minlength=6).float()
 
 
+def smooth_relu(model, name="gelu"):
+    """The model with every ReLU replaced by a smooth activation (nn.ReLU modules; the GIN layers' ``activation`` string): the
+    counterpart of ``oracle.relu_as`` for the whole-model gradient comparisons."""
+    import torch
+    from madrigal_amd.models import _make_act
+    for mod in list(model.modules()):
+        for cname, child in list(mod.named_children()):
+            if isinstance(child, torch.nn.ReLU):
+                setattr(mod, cname, _make_act(name))
+        if getattr(mod, "activation", None) == "relu":
+            mod.activation = name
+    return model
+
+
 def assert_tensors_agree(errs, strict, loose, max_outliers=3, what=""):
     """The acceptance rule of the whole-model gradient comparisons between two fp32 implementations of a ReLU network (the HIP path
     against the CPU oracle's autograd; a multi-rank step against the single-process one).  ``errs`` = one (relative error, name) per

@@ -47,10 +47,10 @@ def test_held_out_auprc_of_a_trained_model_matches_the_oracle():
     from madrigal_amd.train import FinetuneStep
     from helpers import oracle_pipeline
     from test_train_gpu import _small_model
-    n, L, steps, seed = 192, 16, 60, 41
-    hp = dict(optimizer="adamw", structure_encoder_lr=1e-3, kg_encoder_lr=1e-3, perturb_encoders_lr=1e-3, fusion_lr=5e-4, decoder_lr=2e-2,
+    n, L, steps, seed = 96, 8, 40, 41
+    hp = dict(optimizer="adamw", structure_encoder_lr=1e-4, kg_encoder_lr=1e-4, perturb_encoders_lr=1e-4, fusion_lr=5e-5, decoder_lr=3e-4,
               wd=1e-2, beta1=0.9, beta2=0.999, eps=1e-8)
-    (lab, hd, tl, y), (hlab, hhd, htl, hy) = _split(n, L, 1500, seed)
+    (lab, hd, tl, y), (hlab, hhd, htl, hy) = _split(n, L, 600, seed)
     filler = torch.randn(n, 128, generator=torch.Generator().manual_seed(1))
 
     def fresh():
@@ -122,8 +122,8 @@ def test_held_out_auprc_of_a_trained_model_matches_the_oracle():
     print(f"held-out macro AUPRC after {steps} AdamW steps ({int(hy.numel())} held-out triples, {n_lab} outcomes): oracle {auprc_ref:.6f}, "
           f"bf16x3 {out['bf16x3'][0]:.6f}, bf16 {out['bf16'][0]:.6f}; training loss {ref_losses[0]:.4f} -> {ref_losses[-1]:.4f} (oracle), "
           f"{out['bf16x3'][1][0]:.4f} -> {out['bf16x3'][1][-1]:.4f} (bf16x3), {out['bf16'][1][0]:.4f} -> {out['bf16'][1][-1]:.4f} (bf16)")
-    assert ref_losses[-1] < 0.9 * ref_losses[0]                               # it trained
-    assert auprc_ref > float(hy.mean()) + 0.10                                 # and generalises beyond the positive rate (chance level of AUPRC)
+    assert ref_losses[-1] < 0.6 * ref_losses[0]                               # it trained (CPU oracle alone: 0.74 -> 0.32)
+    assert auprc_ref > float(hy.mean()) + 0.25                                 # and generalises beyond the positive rate (chance level of AUPRC)
     for a, r in zip(out["bf16x3"][1], ref_losses):
         assert abs(a - r) < 2e-3 * abs(r), (out["bf16x3"][1], ref_losses)      # loss trajectory, every step
     assert abs(out["bf16x3"][0] - auprc_ref) < 1e-3, (out["bf16x3"][0], auprc_ref)      # north_star's bound

@@ -301,3 +301,92 @@ def test_gradient_buckets_beside_a_blocking_collective_and_a_rank_without_a_mid_
         assert all(outs) and n_buckets >= 3
         if not overlap:
             assert early == 0
+
+
+class _LateWork:
+    """The work handle of a non-blocking transport (RCCL): the sum lands in the buffer only when ``wait()`` is called, and until then
+    the buffer holds poison -- a reader that touches a bucket before waiting for it fails the comparison."""
+    issued = []                                         # every handle created in this process, in issue order
+    waited = []
+
+    def __init__(self, tensor, group):
+        self.tensor, self.group, self.saved = tensor, group, tensor.clone()
+        tensor.fill_(float("nan"))
+        _LateWork.issued.append(self)
+
+    def wait(self):
+        self.tensor.copy_(self.saved)
+        _REAL_ALL_REDUCE(self.tensor, group=self.group)
+        _LateWork.waited.append(self)
+        return True
+
+
+_REAL_ALL_REDUCE = dist.all_reduce
+
+
+def _late_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from madrigal_amd import parallel as P
+        torch.manual_seed(0)
+        layers = [torch.nn.Linear(12, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 4)]
+        params = [p for l in layers for p in l.parameters()]
+        x = torch.randn(8, 12, generator=torch.Generator().manual_seed(3 + rank))
+
+        def loss():
+            h = x
+            for l in layers[:-1]:
+                h = torch.relu(l(h))
+            return (layers[-1](h) ** 2).mean()
+        loss().backward()
+        P.allreduce_gradients(params)
+        want = [p.grad.clone() for p in params]
+        for p in params:
+            p.grad = None
+
+        def fake_all_reduce(tensor, op=dist.ReduceOp.SUM, group=None, async_op=False):
+            if not async_op:
+                return _REAL_ALL_REDUCE(tensor, op=op, group=group)
+            return _LateWork(tensor, group)
+        P.dist.all_reduce = fake_all_reduce               # the module's own reference to torch.distributed
+        try:
+            gb = P.GradientBuckets(params, bucket_bytes=500, overlap=True)
+            gb.arm()
+            loss().backward()
+            issued_in_backward = len(_LateWork.issued)
+            poisoned = all(bool(torch.isnan(w.tensor).all()) for w in _LateWork.issued)       # nothing has landed yet
+            gb.finish()
+        finally:
+            P.dist.all_reduce = _REAL_ALL_REDUCE
+        same = all(torch.allclose(a, p.grad, rtol=0, atol=1e-7) for a, p in zip(want, params))
+        in_order = [id(w) for w in _LateWork.waited] == [id(w) for w in _LateWork.issued]
+        ret[rank] = (same, issued_in_backward, len(_LateWork.issued), poisoned, in_order, len(gb.buckets))
+        P.destroy_bucket_groups()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_buckets_with_a_transport_whose_sums_land_late():
+    """What RCCL does and gloo on CPU tensors does not: ``all_reduce(async_op=True)`` returns at once and the sum is in the buffer only
+    after ``wait()``.  The bucket collectives are replaced by handles that poison the buffer until waited for: every bucket is issued
+    from the hooks (during backward), none is read before its wait, the waits come in issue order, the gradients equal the flat
+    all-reduce's."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_late_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(2):
+        same, early, total, poisoned, in_order, n_buckets = ret[r]
+        assert same and poisoned and in_order, (r, ret[r])
+        assert n_buckets >= 3 and total == n_buckets and early == n_buckets, (r, ret[r])      # all of them issued before backward() returned

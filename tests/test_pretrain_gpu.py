@@ -80,7 +80,7 @@ def test_simclr_raw_training_step_matches_oracle_autograd(shared, basal):
     from madrigal_amd import data as D, models as M
     from oracle import madrigal_oracle as O
     from oracle.pipeline import oracle_simclr
-    from helpers import assert_tensors_agree
+    from helpers import smooth_relu
     n, T = 72, 0.1
 
     def run(seed):
@@ -89,13 +89,13 @@ def test_simclr_raw_training_step_matches_oracle_autograd(shared, basal):
         hard = torch.rand(n, n, generator=torch.Generator().manual_seed(3)) < 0.04
         hard = (hard | hard.T) & ~torch.eye(n, dtype=torch.bool)
         torch.manual_seed(seed)
-        model = _no_dropout(_build(M, bkg["data"], shared, basal, mlp_dim=256, T=T))
+        model = smooth_relu(_no_dropout(_build(M, bkg["data"], shared, basal, mlp_dim=256, T=T)))
         p0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
         filler = torch.zeros(max(int(batch["drugs"].max()) + 1, int(bkg["drug_index_map"].max()) + 1), 128)
 
         pr = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in p0.items()}
         record = {}
-        with O.batch_statistics(record):
+        with O.batch_statistics(record), O.relu_as("gelu"):
             ref = oracle_simclr(pr, batch, bkg, m1, m2, hard, T, filler, shared_predictor=shared, use_tx_basal=basal)
         ref["loss"].backward()
 
@@ -147,8 +147,12 @@ def test_simclr_raw_training_step_matches_oracle_autograd(shared, basal):
         assert n_bn >= 4 + 2 + 2                                    # GIN x4, chemCPA encoder x2, the predictors' BatchNorms
         return errs
 
-    # every seed: all gradient tensors but a flipped unit's own (helpers.assert_tensors_agree) within 5e-4 of their scale, all within 5e-2
-    print("(seed, (worst error, tensor), tensors beyond 5e-4):", [(sd,) + assert_tensors_agree(run(sd), 5e-4, 5e-2, what=f"seed {sd}") for sd in (33, 34, 35, 36)])
+    # The comparison runs on the network with GELU in place of every ReLU (helpers.smooth_relu / oracle.relu_as; the ReLU kernels have
+    # their own forward / backward tests): every gradient entry of every tensor within 5e-4 of its tensor's scale, on EVERY seed
+    for sd in (33, 34, 35, 36):
+        worst = max(run(sd))
+        print("seed", sd, "worst (error, tensor):", worst)
+        assert worst[0] < 5e-4, (sd, worst)
 
 
 def test_simclr_raw_pretraining_steps_reduce_loss_and_are_reproducible():

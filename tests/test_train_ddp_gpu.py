@@ -32,7 +32,10 @@ def _build(seed, n, L):
     masks = D.make_masks(n, seed)
     batch, bkg = D.make_batch(n, seed, kg_nodes=700, kg_edges=9000, masks=masks)
     torch.manual_seed(seed)
-    model = build_model(M, CASE, bkg["data"], L).cuda().train()
+    from helpers import smooth_relu
+    # GELU in place of every ReLU (helpers.smooth_relu): under SyncBatchNorm's other summation order a ReLU at rounding distance of zero
+    # flips its derivative and moves every gradient upstream of it by percents -- not what these comparisons are about
+    model = smooth_relu(build_model(M, CASE, bkg["data"], L)).cuda().train()
     for mod in model.modules():                       # no dropout: the sharded and the full step are the same function
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0
@@ -81,7 +84,8 @@ def _worker(rank, world, port, ret, shard_kg=True):
                 # SyncBatchNorm sums are formed in another order (three ranks instead of one) and moves a handful of entries by percents
                 el2.append((float((grads[k] - p.grad).norm()) / max(float(p.grad.norm()), 1e-3 * gmax * p.grad.numel() ** 0.5), k))
             berr = max(float((bufs[k] - v).abs().max()) / max(float(v.abs().max()), 1e-6) for k, v in ref.named_buffers() if "running" in k)
-            kg_l2 = max(float((grads[k] - p.grad).norm()) / max(float(p.grad.norm()), 1e-30) for k, p in ref.named_parameters() if p.grad is not None and "kg_encoder" in k)
+            kg_top = max(float(p.grad.norm()) for k, p in ref.named_parameters() if p.grad is not None and "kg_encoder" in k)
+            kg_l2 = max((float((grads[k] - p.grad).norm()) / max(float(p.grad.norm()), 1e-2 * kg_top), k) for k, p in ref.named_parameters() if p.grad is not None and "kg_encoder" in k)
             tried.append((seed, abs(float(loss) - float(loss1)) / abs(float(loss1)), emax, el2, kg_l2, berr, len(grads)))
         ret[rank] = tried
     finally:
@@ -104,17 +108,13 @@ def test_two_rank_finetune_step_equals_single_process_step(world, shard_kg):
         p.join(600)
         assert p.exitcode == 0
     for r in range(world):
-        from helpers import assert_tensors_agree
         tried = ret[r]
         assert len(tried) == 3
         for seed, lerr, emax, el2, kg_l2, berr, n_grads in tried:
             assert lerr < 1e-5, (r, seed, lerr)
-            # EVERY seed, at any world size: all gradient tensors but a flipped unit's own within 2e-3 (max norm) / 5e-3 (2-norm) of the
-            # single-process step, every tensor within 5e-2 / 2e-2 (helpers.assert_tensors_agree: an error of the exchange or of a
-            # reduction moves every tensor downstream of it)
-            assert_tensors_agree(emax, 2e-3, 5e-2, what=f"rank {r} seed {seed} max norm")
-            assert_tensors_agree(el2, 5e-3, 2e-2, what=f"rank {r} seed {seed} 2-norm")
-            assert kg_l2 < 1e-4, (r, seed, kg_l2)          # the KG encoder's own gradients: 4e-6 in either variant
+            # EVERY seed, at any world size: every gradient tensor within 2e-3 (max norm) / 5e-3 (2-norm) of the single-process step
+            assert max(emax)[0] < 2e-3 and max(el2)[0] < 5e-3, (r, seed, max(emax), max(el2))
+            assert kg_l2[0] < 1e-4, (r, seed, kg_l2)       # the KG encoder's own gradients (per tensor, floored at 1 % of the largest): 4e-6 in either variant
             assert berr < 1e-4, (r, seed, berr)            # BatchNorm running statistics = full-batch statistics on every rank
             assert n_grads > 150
 
@@ -213,7 +213,8 @@ def _pretrain_raw_worker(rank, world, port, ret):
             def run(rank_, world_):
                 torch.manual_seed(seed)
                 np.random.seed(seed)
-                model = _no_dropout(_build(M, bkg0["data"], False, True, mlp_dim=256, T=0.5)).cuda().train()
+                from helpers import smooth_relu
+                model = smooth_relu(_no_dropout(_build(M, bkg0["data"], False, True, mlp_dim=256, T=0.5))).cuda().train()     # (GELU for ReLU: see _build)
                 # eps well above the gradients' rounding noise: Adam's first steps otherwise move every entry by +-lr whatever
                 # its size, so entries whose gradient is noise would take opposite steps in the two runs
                 step = PretrainStep(model, AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2, eps=1e-3), rank=rank_, world=world_)
@@ -264,16 +265,14 @@ def test_two_rank_shipped_pretraining_steps_equal_single_process_and_hold_no_bat
     for p in procs:
         p.join(900)
         assert p.exitcode == 0
-    from helpers import assert_tensors_agree
     for r in range(2):
       for si, (lerr, worst, same_set, untouched, mem) in enumerate(ret[r]):
         # the first step is the same function of the same weights (fp32 summation order only); later losses also carry the
         # three AdamW updates in between, whose per-entry normalisation amplifies rounding-level gradient differences
-        # (iterations 5 and 6 only feed the memory check below).  EVERY seed: the loss bounds, and all gradient tensors of the first step
-        # but a flipped unit's own within the strict bounds (2-norm 5e-3, max norm 5e-2), every tensor within ten times that
-        assert lerr[0] < 1e-5 and max(lerr[:4]) < 2e-2, (r, si, lerr)
-        assert_tensors_agree(worst[0], 5e-3, 5e-2, what=f"rank {r} seed #{si} 2-norm")
-        assert_tensors_agree(worst[1], 5e-2, 5e-1, what=f"rank {r} seed #{si} max norm")
+        # (iterations 5 and 6 only feed the memory check below).  EVERY seed: the loss bounds, and every gradient tensor of the first
+        # step within 5e-3 (2-norm) / 5e-2 (max norm) of the single-process step
+        assert lerr[0] < 1e-5 and max(lerr[:4]) < 2e-3, (r, si, lerr)
+        assert max(worst[0])[0] < 5e-3 and max(worst[1])[0] < 5e-2, (r, si, max(worst[0]), max(worst[1]))
         assert same_set and untouched == 0.0, (r, same_set, untouched)
         # nothing of an earlier iteration's batch stays allocated.  A rank's share of one batch is > 2 MB (tx signatures alone:
         # 34 drugs x 16 x 978 floats), so holding batches would add > 8 MB between iterations 2 and 6; what is allowed to move

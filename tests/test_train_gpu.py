@@ -1074,7 +1074,8 @@ def test_three_adamw_steps_match_oracle_autograd_plus_torch_adamw():
     from madrigal_amd import data as D, models as M
     from madrigal_amd.optim import create_optimizer
     from madrigal_amd.train import FinetuneStep
-    from helpers import oracle_pipeline
+    from helpers import oracle_pipeline, smooth_relu
+    from oracle import madrigal_oracle as O
     case = ("drugbank163", "transformer", 4, "learnable", 8, 64, 256, 2, True, "x-attn", True, False)
     n, L, steps = 96, 24, 3
 
@@ -1085,7 +1086,7 @@ def test_three_adamw_steps_match_oracle_autograd_plus_torch_adamw():
         p = {k: v.detach().clone() for k, v in model.state_dict().items()}
         filler = torch.randn(n, 128, generator=torch.Generator().manual_seed(1))
         lab, hd, tl, y = D.make_labelled_triples(n, L, 700, seed)
-        model = model.cuda().eval()
+        model = smooth_relu(model).cuda().eval()         # GELU in place of every ReLU on both sides: no derivative flips at rounding distance of zero
         frozen = set()
         for name, mod in model.named_modules():
             if isinstance(mod, torch.nn.BatchNorm1d):
@@ -1107,7 +1108,8 @@ def test_three_adamw_steps_match_oracle_autograd_plus_torch_adamw():
         ref_losses = []
         for it in range(steps):
             ropt.zero_grad(set_to_none=True)
-            ref = oracle_pipeline(case, dict(pr), batch, bkg, masks, filler)
+            with O.relu_as("gelu"):
+                ref = oracle_pipeline(case, dict(pr), batch, bkg, masks, filler)
             loss_r = torch.nn.BCELoss()(torch.sigmoid(ref["scores"])[lab, hd, tl], y)
             loss_r.backward()
             ref_losses.append(float(loss_r.detach()))
@@ -1160,11 +1162,10 @@ def test_three_adamw_steps_match_oracle_autograd_plus_torch_adamw():
         # moves a whole row of a weight gradient, and Adam carries it into three steps).
         return med, q999, worst
 
-    # every seed of a fixed range, no search: median < 1e-5 and 99.9 % quantile < 1e-4 of the tensor's largest delta -- the bulk, which
-    # a defect anywhere in the step moves and a flipped unit does not -- and the worst single entry < 0.2
+    # every seed of a fixed range, no search: median < 1e-5, 99.9 % quantile < 1e-4, worst entry < 2e-3 of the tensor's largest delta
     for seed in (31, 32, 33, 34):
         med, q999, worst = run(seed)
-        assert med < 1e-5 and q999 < 1e-4 and worst[0] < 0.2, (seed, med, q999, worst)
+        assert med < 1e-5 and q999 < 1e-4 and worst[0] < 2e-3, (seed, med, q999, worst)
 
 
 # ---------------------------------------------------------------------------------------------- dense head, drop-in loop
