@@ -503,19 +503,21 @@ def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend
             b_, _ = D.make_batch(N, side_seed, kg=bkg["data"], masks=avail)
             pair.append(D.batch_to(b_, dev))
         sides.append(pair)
-    g_m = torch.Generator().manual_seed(99)
+    g_m = torch.Generator(device=dev).manual_seed(99)
+    avail_dev = avail.to(dev)
 
     def draw_masks():
-        """A step's modality masks: every available modality but the structure dropped with probability 0.3 (the 'random_sample' family
-        of train_ddi_batch.py; True = absent)."""
-        drop = torch.rand(avail.shape, generator=g_m) < 0.3
+        """A step's modality masks, drawn on the device: every available modality but the structure dropped with probability 0.3 (the
+        'random_sample' family of train_ddi_batch.py; True = absent)."""
+        drop = torch.rand(avail_dev.shape, generator=g_m, device=dev) < 0.3
         drop[:, 0] = False
-        return (avail | drop).to(dev)
+        return avail_dev | drop
     fs = FinetuneStep(model, create_optimizer(model, hp), rank=rank, world=world)
     torch.manual_seed(4321 + rank)
-
     def one_step(i_, fresh):
         if fresh and sides:
+            # (preparing the next step's mask and triple plans on a side stream while this step runs was tried -- FinetuneStep.prefetch,
+            # round 5 -- and removed: its host round trips cost the queueing thread what they saved the device: 42.3 against 41.8 ms)
             hb, tb = sides[i_ % n_var]
             return fs.step(hb, tb, draw_masks(), draw_masks(), bkg, *sets[(i_ + 1) % 3], kg_filler=filler)
         return fs.step(batch, batch, batch["masks"], batch["masks"], bkg, *sets[(i_ + 1) % 3], kg_filler=filler)

@@ -1598,8 +1598,11 @@ class NovelDDIEncoder(nn.Module):
         """Everything that depends only on the modality masks (row partitions, token masks, live-token plan, tx rows),
         computed once per distinct mask tensor: steady-state encodes then run without a host synchronisation."""
         key = (batch_masks.data_ptr(), batch_masks._version, tuple(batch_masks.shape), str(dev), compact)
-        if self._plan_cache is not None and self._plan_cache[0] == key:
-            return self._plan_cache[1]
+        if self._plan_cache is None:
+            self._plan_cache = {}
+        hit = self._plan_cache.get(key)
+        if hit is not None and hit[1] is batch_masks:
+            return hit[0]
         n = batch_masks.shape[0]
         rows = uni_rows = uni_col = None
         masks_f, n_uni = batch_masks, 0
@@ -1644,7 +1647,10 @@ class NovelDDIEncoder(nn.Module):
             perm[rows] = torch.arange(nf, device=dev)
             perm[uni_rows] = nf + torch.arange(n_uni, device=dev)
             mp["merge_perm"] = perm                                                    # drug d's row in [fused rows | uni-modal rows]
-        self._plan_cache = (key, mp, batch_masks)
+        # a few entries, oldest out: the head and the tail side of a step carry different masks
+        while len(self._plan_cache) >= 6:
+            self._plan_cache.pop(next(iter(self._plan_cache)))
+        self._plan_cache[key] = (mp, batch_masks)          # (holds the mask tensor: its address cannot be recycled meanwhile)
         return mp
 
     def _kg_graphed(self, kg_data, dev):
@@ -1773,12 +1779,16 @@ class NovelDDIEncoder(nn.Module):
             if train:
                 # own gather node instead of torch's indexed assignment + indexed read (their backward sorts and scatters: rocprim
                 # launches in every step): src[d] = row of drug d in the KG encoder's output, -1 for drugs outside the KG
-                gkey = (kg_map.data_ptr(), kg_map._version, batch_drugs.data_ptr(), batch_drugs._version, int(filler.shape[0]))
-                hit = self.__dict__.get("_kg_gather")
-                if hit is None or hit[0] != gkey:
+                gkey = (kg_map.data_ptr(), kg_map._version, kg_map.numel(), batch_drugs.data_ptr(), batch_drugs._version, tuple(batch_drugs.shape),
+                        batch_drugs.stride(), int(filler.shape[0]))
+                cache = self.__dict__.setdefault("_kg_gather", {})
+                hit = cache.get(gkey)
+                if hit is None or hit[2] is not kg_map or hit[3] is not batch_drugs:
                     pos = torch.full((int(filler.shape[0]),), -1, dtype=torch.int64, device=dev)
                     pos[kg_map] = torch.arange(kg_map.numel(), device=dev)
-                    hit = self.__dict__["_kg_gather"] = (gkey, pos[batch_drugs].contiguous(), kg_map, batch_drugs)
+                    while len(cache) >= 4:                             # head and tail batches of a couple of steps
+                        cache.pop(next(iter(cache)))
+                    hit = cache[gkey] = (gkey, pos[batch_drugs].contiguous(), kg_map, batch_drugs)
                 return ag.gather_rows_or(kg_valid, hit[1], filler.to(dev)[batch_drugs])
             table = filler.to(dev).clone()
             table[kg_map] = kg_valid

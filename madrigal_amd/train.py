@@ -62,6 +62,7 @@ class FinetuneStep:
         self._overlapped = False
         self._plan_key = None
         self._plan = None
+        self._plans = {}                # key -> (plan, index tensors): the current and a prefetched set of triples
         self._plan_stream = None
         self._shards = {}               # side ('head' | 'tail') -> (key, sliced batch, the batch itself): ONE entry per side
 
@@ -73,10 +74,15 @@ class FinetuneStep:
         """Label-sorted tiling of the triples, rebuilt only when the index tensors change (they are fixed for a run)."""
         key = self._key_of(labels, heads, tails, n_head, n_tail)
         if self._plan_key != key:
-            n_labels = int(self.model.decoder.out_features)
-            self._plan = ops.triple_plan(labels, heads, tails, n_labels, n_head, n_tail)
+            hit = self._plans.get(key)
+            if hit is None or hit[1][0] is not labels:
+                n_labels = int(self.model.decoder.out_features)
+                hit = (ops.triple_plan(labels, heads, tails, n_labels, n_head, n_tail), (labels, heads, tails))
+                while len(self._plans) >= 3:
+                    self._plans.pop(next(iter(self._plans)))
+                self._plans[key] = hit
+            self._plan, self._pinned = hit
             self._plan_key = key
-            self._pinned = (labels, heads, tails)
         return self._plan
 
     def _shard(self, batch, masks, side):
