@@ -503,7 +503,8 @@ constexpr int MSD_QLG = 13;               // ~8192 keys per bucket
 constexpr int MSD_NF = 16384;             // fine bins of the bucket sort
 constexpr int MSD_CAP = 12288;            // keys a bucket may hold (LDS room of the bucket sort): 1.5 x the mean
 constexpr int MSD_TILE = 16384;           // keys per count / partition tile (1024 threads x 16)
-constexpr int MSD_TIE_LIMIT = 128;        // keys per fine bin ordered in place; more: LSD fallback
+constexpr int MSD_TIE_LIMIT = 1024;       // keys per fine bin ordered in place (c probes each: a bin of 170 keys -- seen in 1 to 2 % of the bench tensor's outcomes, in the
+                                          // bucket around zero -- costs 30 000 LDS reads); more: LSD fallback
 constexpr int MSD_MAX_BLOCKS = 1536;      // output blocks per outcome on this path
 constexpr int MSD_BWORDS = 1024;          // words of the bucket sort's block counters (two u16 per word: room for MSD_MAX_BLOCKS + the dummy block)
 constexpr int MSD_SAMPLE_CHUNKS = 4096;   // 64-key chunks sampled per outcome (262 144 keys: 128 per bucket at N = 4096)

@@ -102,26 +102,39 @@ if __name__ == "__main__":
         sim((3 + a + a.T + 0.03 * x)[il], name="rowstruct.03", chunk=chunk)
 
 
-def fine_bin_report(vals, N, NF=8192, cap=6144):
-    """Largest fine-bin occupancy of the bucket sort's composite (key, position) bins, per bucket (numpy model of msd_bucket_kernel)."""
+def fine_bin_report(vals, N, NF=16384, cap=12288, QLG=13):
+    """Largest fine-bin occupancy of the bucket sort's composite (u(key), position) bins, per bucket: numpy model of MsdFine in
+    csrc/ranks.hip (u = the key, or the fixed-point score where the bucket holds both signs or is massed at its large-magnitude end)."""
     k = keys_of(vals).astype(np.int64)
     il = np.tril_indices(N, -1)
     q26 = (il[0].astype(np.int64) << 13) | il[1].astype(np.int64)
-    cnt = sim(vals, verbose=False)
-    # bucket id per key: recompute through sim internals is awkward; rank keys instead (exact equi-depth buckets of the same mean size behave alike)
-    order = np.argsort(k, kind="stable")
-    nb = cnt.size
+    cnt = sim(vals, verbose=False, QLG=QLG)
+    order = np.argsort(k, kind="stable")                 # (equi-depth buckets of the model's sizes, in key order)
     edges = np.concatenate([[0], np.cumsum(cnt)])
+    v32 = np.ascontiguousarray(vals, dtype=np.float32)
     worst = []
-    for b in range(nb):
+    for b in range(cnt.size):
         idx = order[edges[b]:edges[b + 1]]
         if idx.size == 0 or idx.size > cap:
             continue
-        kk = k[idx]; lo = kk.min(); rng = int(kk.max() - lo)
-        span = (rng << 26) | 0x3FFFFFF
-        sh = max(0, span.bit_length() - 13)
-        f = (((kk - lo) << 26) | q26[idx]) >> sh
+        kk = k[idx]; kmin, kmax = int(kk.min()), int(kk.max())
+        pos = (kk.mean() - kmin) / (kmax - kmin + 1.0)
+        both = kmin < 0x80000000 <= kmax
+        fixed = both or (kmin >= 0x80000000 and pos > 0.6) or (kmax < 0x80000000 and pos < 0.4)
+        if fixed:
+            sc = v32[idx].astype(np.float64)
+            m, mn = np.abs(sc).max(), np.abs(sc).min()
+            e = 29 - int(np.floor(np.log2(m))) if m > 0 else 0
+            if not both and mn > 0:
+                e = min(e, 23 - int(np.floor(np.log2(mn))))
+            u = np.rint(np.ldexp(sc, e)).astype(np.int64)
+        else:
+            u = kk
+        u = u - u.min()
+        span = (int(u.max()) << 26) | 0x3FFFFFF
+        sh = max(0, span.bit_length() - int(np.log2(NF)))
+        f = ((u << 26) | q26[idx]) >> sh
         c = np.bincount(f, minlength=NF)
-        worst.append((int(c.max()), b, idx.size, rng, sh))
+        worst.append((int(c.max()), b, idx.size, kmax - kmin, sh, bool(fixed), round(float(pos), 3)))
     worst.sort(reverse=True)
-    return worst[:5]
+    return worst[:4]

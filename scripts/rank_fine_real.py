@@ -4,7 +4,7 @@ import numpy as np, torch
 from madrigal_amd import configs, data as D_, models as M_, ops
 from madrigal_amd.pipeline import generate_embeddings, score_all_pairs
 from rank_bucket_sim import fine_bin_report, keys_of
-L, N = 8, 4096
+L, N = 896, 4096
 batch, bkg = D_.make_batch(N, 0, kg_nodes=130_000, kg_edges=8_000_000)
 model = configs.build_model("twosides321", bkg["data"], L).cuda().eval()
 with torch.no_grad():
@@ -17,10 +17,11 @@ with torch.no_grad(), M_.precision("bf16x3"):
     s = score_all_pairs(model, z)
 flags = []
 ops.rank_normalize(s, fallback_flags=flags)
-print("flags", flags[0].tolist())
+
 il = np.tril_indices(N, -1)
-for l in range(L):
+fl = torch.cat(flags).tolist()
+print("flagged outcomes:", [i for i, f in enumerate(fl) if f])
+for l in [i for i, f in enumerate(fl) if f][:4] + [0]:
     v = s[l].cpu().numpy()[:, :N][il]
     w = fine_bin_report(v, N)
-    print(l, "worst fine bins (count, bucket, n, key range, shift):", w)
-    cnt, b0 = w[0][0], w[0][1]
+    print(l, "flag", fl[l], "worst fine bins (count, bucket, n, key range, shift, fixed-point, mean key position):", w, flush=True)
