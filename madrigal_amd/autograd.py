@@ -16,6 +16,15 @@ from torch.autograd.function import once_differentiable
 
 from . import ops
 
+# The training steps run the KG encoder and the structure encoder on side streams of their own (NovelDDIEncoder.encode: their forward, and
+# therefore -- torch runs a node's backward on the stream of its forward -- their backward, overlap the other encoders').  The gradients
+# of those encoders' parameters are thus produced on the side stream, while a parameter's AccumulateGrad node keeps the stream it was first
+# used on (the main stream, in the first steps' plan-building passes): torch orders the two with an event wait, which is exactly the join the
+# step needs before AdamW reads the gradients, and warns once per process that this "may incur unnecessary synchronization".  Intended here;
+# the warning is switched off (tests/test_train_gpu.py::test_training_steps_emit_no_stream_warnings).
+if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
 
 def needs_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)

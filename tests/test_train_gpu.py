@@ -857,6 +857,31 @@ def test_finetune_steps_reduce_loss_and_are_reproducible():
     assert int(sd1["encoder.tx_encoder.encoder.network.1.num_batches_tracked"]) == 24    # head + tail pass per step
 
 
+def test_training_steps_emit_no_stream_warnings():
+    """The finetune step runs two encoders on side streams; the AccumulateGrad stream-mismatch notice torch would print for their
+    parameters is an intended join (madrigal_amd/autograd.py) and is switched off: a step leaves no warning behind."""
+    import warnings
+    from madrigal_amd import data as D, models as M
+    from madrigal_amd.optim import create_optimizer
+    from madrigal_amd.train import FinetuneStep
+    case = ("twosides321", "transformer_uni_proj", 2, "sinusoidal", 8, 256, 1024, 2, True, "x-attn", False, False)
+    n, L = 64, 6
+    model, _, batch, bkg, masks = _small_model(M, case, n, L, 3, default_init=True)
+    model = model.cuda()
+    hp = dict(optimizer="adamw", structure_encoder_lr=1e-4, kg_encoder_lr=1e-4, perturb_encoders_lr=1e-4, fusion_lr=1e-4, decoder_lr=1e-3,
+              wd=1e-2, beta1=0.9, beta2=0.999, eps=1e-8)
+    fs = FinetuneStep(model, create_optimizer(model, hp))
+    b = D.batch_to(batch, "cuda")
+    kgc = {"data": bkg["data"].to("cuda"), "drug_index_map": bkg["drug_index_map"].cuda()}
+    lab, hd, tl, y = (t.cuda() for t in D.make_labelled_triples(n, L, 200, 3))
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        for _ in range(3):
+            fs.step(b, b, b["masks"], b["masks"], kgc, lab, hd, tl, y)
+        torch.cuda.synchronize()
+    assert not [w for w in seen if "AccumulateGrad" in str(w.message) or "stream" in str(w.message).lower()], [str(w.message)[:200] for w in seen]
+
+
 def test_inference_after_training_sees_the_updated_weights():
     """The optimizer writes parameters from a kernel; the inference path caches packed / folded / symmetrised weights keyed
     on torch's version counters — a stale cache would silently score with the old weights."""
