@@ -234,6 +234,35 @@ def test_ranks_fast_path_hands_point_masses_to_the_lsd_sort(ops, monkeypatch):
     assert np.array_equal(out, ref)
 
 
+def test_ranks_buckets_beyond_the_lds_room_take_the_streaming_kernel(ops):
+    """A dense cluster far from the bulk -- 50 000 scores inside a relative width of 2e-5, narrower than one sub-range of the sampled
+    bucket table -- lands in ONE bucket of several times the bucket sort's LDS room: msd_big_bucket_kernel sorts it (tie groups of
+    ~150 equal keys included), the outcome stays on the MSD path, same bits as the oracle.  N = 2048: the table comes from a 1-in-8
+    sample, as at full size."""
+    from oracle import madrigal_oracle as O
+    N = 2048
+    rng = np.random.default_rng(5)
+    s = rng.standard_normal((2, N, N)).astype(np.float32)
+    il = np.tril_indices(N, -1)
+    pick = rng.choice(il[0].size, 50_000, replace=False)
+    s[1, il[0][pick], il[1][pick]] = (1000.0 + rng.uniform(0, 0.02, 50_000)).astype(np.float32)
+    flags = []
+    out = ops.rank_normalize(torch.from_numpy(s).cuda(), fallback_flags=flags).cpu().numpy()
+    assert flags and torch.cat(flags).tolist() == [0, 0], [f.tolist() for f in flags]
+    assert np.array_equal(out, O.rank_normalize(s))
+
+
+def test_ranks_msd_path_beyond_4096_drugs(ops):
+    """N = 5003 (M = 1.25e7 keys: 1 528 buckets, 820 output blocks, a 1-in-48 sample): the MSD path's upper range, ragged N."""
+    from oracle import madrigal_oracle as O
+    N = 5003
+    s = (np.random.default_rng(9).standard_normal((1, N, N)) * 3 + 1).astype(np.float32)
+    flags = []
+    out = ops.rank_normalize(torch.from_numpy(s).cuda(), fallback_flags=flags).cpu().numpy()
+    assert flags and torch.cat(flags).tolist() == [0]
+    assert np.array_equal(out, O.rank_normalize(s))
+
+
 def test_ranks_ties_are_stable_in_flat_index(ops):
     from oracle import madrigal_oracle as O
     rng = np.random.default_rng(7)
