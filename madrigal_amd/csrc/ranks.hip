@@ -947,6 +947,8 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
 #pragma unroll
     for (int e = 0; e < BPT; ++e) bcnt[BPT * tid + e] = gcur[e] - st[e];       // (position in the bucket) - (position in LDS)
     __syncthreads();
+    // (copy-out by sixteen lanes per run from the bucket tables, instead of re-deriving every pair's bucket from its key, was measured:
+    // 177 against 175 us per outcome -- the idle lanes of short runs cost more than the two table reads)
     const int n_valid = static_cast<int>(M - base < MSD_TILE ? M - base : MSD_TILE);
 #pragma unroll 4
     for (int k = 0; k < ITEMS; ++k) {
@@ -1134,57 +1136,58 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
   }
   __syncthreads();
   MDG_STAMP();
-  const auto fstart = [&](uint32_t f) -> uint32_t { return (fc[f >> 1] >> (16u * (f & 1u))) & 0xFFFFu; };
+  // Where the key's fine bin starts and how many keys it holds: both bounds from one two-word read (the bins' starts are u16 pairs).  A
+  // key ALONE in its bin -- six of ten -- is in place by that alone (rank = bin start): it is neither written to `sorted` nor probed.
 #pragma unroll
-  for (int k = 0; k < ITEMS; ++k) asm volatile("" : "+v"(key[k]));      // recompute the fine bin per phase instead of keeping 6 more registers live (they spilled)
+  for (int k = 0; k < ITEMS; ++k) asm volatile("" : "+v"(key[k]));      // recompute the fine bin per phase instead of keeping 12 more registers live (they spilled)
+  uint32_t sc[ITEMS];                                      // bin start | keys in the bin << 16
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
-    if (k * TPB + tid < n) sorted[fstart(fine_of(key[k], q[k])) + (ss[k] & 0xFFFFu)] = u32x2{key[k], q[k]};
+    sc[k] = 0u;
+    if (k * TPB + tid < n) {
+      const uint32_t fi = fine_of(key[k], q[k]);
+      const uint32_t w0 = fc[fi >> 1], w1 = fc[(fi >> 1) + 1];
+      const uint32_t s0 = (fi & 1u) ? (w0 >> 16) : (w0 & 0xFFFFu), s1 = (fi & 1u) ? (w1 & 0xFFFFu) : (w0 >> 16);
+      sc[k] = s0 | ((s1 - s0) << 16);
+      if (s1 - s0 > 1u) sorted[s0 + (ss[k] & 0xFFFFu)] = u32x2{key[k], q[k]};
+    }
   }
   __syncthreads();
   MDG_STAMP();
-  // keys that share a fine bin: their order is (key, position); everything else is in place already.  Three bin-mates are probed
-  // unconditionally (independent LDS reads, all items' in flight together); a bin with more keeps walking
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) asm volatile("" : "+v"(key[k]));      // recompute the fine bin per phase instead of keeping 6 more registers live (they spilled)
+  // keys that share a fine bin: their order is (key, position).  Six bin-mates are probed with predicated, independent LDS reads (a bin
+  // holds ~half a key: one key in 10^4 has more and walks on)
   bool too_many = false;
-  constexpr int PROBES = 6, GRP = 2;                       // a bin holds ~half a key: one key in 10^4 has more than six bin-mates and walks on
+  constexpr int PROBES = 6, GRP = 2;
   static_assert(ITEMS % GRP == 0, "tie-fix groups");
 #pragma unroll
-  for (int k0 = 0; k0 < ITEMS; k0 += GRP) {                // two items at a time: 12 probes in flight, registers within 64
-    uint32_t s0[GRP], c[GRP];
-#pragma unroll
-    for (int e = 0; e < GRP; ++e) {
-      const int k = k0 + e;
-      const bool ok = k * TPB + tid < n;
-      const uint32_t fi = ok ? fine_of(key[k], q[k]) : 0u;
-      s0[e] = fstart(fi);
-      c[e] = ok ? fstart(fi + 1u) - s0[e] : 0u;
-    }
+  for (int k0 = 0; k0 < ITEMS; k0 += GRP) {                // two items at a time: 12 probes in flight
     u32x2 o[GRP][PROBES];
 #pragma unroll
-    for (int e = 0; e < GRP; ++e)
+    for (int e = 0; e < GRP; ++e) {
+      const uint32_t s0 = sc[k0 + e] & 0xFFFFu, c = sc[k0 + e] >> 16;
 #pragma unroll
-      for (int mth = 0; mth < PROBES; ++mth) {             // a key alone in its bin (most are) reads nothing
+      for (int mth = 0; mth < PROBES; ++mth) {
         o[e][mth] = u32x2{0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (c[e] > 1u && static_cast<uint32_t>(mth) < c[e]) o[e][mth] = sorted[s0[e] + mth];
+        if (c > 1u && static_cast<uint32_t>(mth) < c) o[e][mth] = sorted[s0 + mth];
       }
+    }
 #pragma unroll
     for (int e = 0; e < GRP; ++e) {
       const int k = k0 + e;
+      const uint32_t s0 = sc[k] & 0xFFFFu, c = sc[k] >> 16;
       uint32_t r = 0;
 #pragma unroll
       for (int mth = 0; mth < PROBES; ++mth)
         r += (o[e][mth][0] < key[k] || (o[e][mth][0] == key[k] && o[e][mth][1] < q[k])) ? 1u : 0u;
-      if (c[e] > static_cast<uint32_t>(PROBES)) {
-        if (c[e] > static_cast<uint32_t>(MSD_TIE_LIMIT)) too_many = true;
+      if (c > static_cast<uint32_t>(PROBES)) {
+        if (c > static_cast<uint32_t>(MSD_TIE_LIMIT)) too_many = true;
         else
-          for (uint32_t mth = PROBES; mth < c[e]; ++mth) {
-            const u32x2 x = sorted[s0[e] + mth];
+          for (uint32_t mth = PROBES; mth < c; ++mth) {
+            const u32x2 x = sorted[s0 + mth];
             r += (x[0] < key[k] || (x[0] == key[k] && x[1] < q[k])) ? 1u : 0u;
           }
       }
-      key[k] = rb + s0[e] + r;                             // rank - 1
+      key[k] = rb + s0 + r;                                // rank - 1
     }
     __builtin_amdgcn_sched_barrier(0);
   }
