@@ -502,11 +502,9 @@ constexpr int MSD_NB_MAX = 2048;          // buckets per outcome: a 16 384-key t
 constexpr int MSD_QLG = 13;               // ~8192 keys per bucket
 constexpr int MSD_NF = 16384;             // fine bins of the bucket sort
 constexpr int MSD_CAP = 12288;            // keys a bucket may hold (LDS room of the bucket sort): 1.5 x the mean
-constexpr int MSD_TILE = 16384;           // keys per count / partition tile (1024 threads x 16)
+constexpr int MSD_TILE = BB * BB;         // keys per count / partition tile: one 128 x 128 output block (1024 threads x 16)
 constexpr int MSD_TIE_LIMIT = 1024;       // keys per fine bin ordered in place (c probes each: a bin of 170 keys -- seen in 1 to 2 % of the bench tensor's outcomes, in the
                                           // bucket around zero -- costs 30 000 LDS reads); more: LSD fallback
-constexpr int MSD_MAX_BLOCKS = 1536;      // output blocks per outcome on this path
-constexpr int MSD_BWORDS = 1024;          // words of the bucket sort's block counters (two u16 per word: room for MSD_MAX_BLOCKS + the dummy block)
 constexpr int MSD_SAMPLE_CHUNKS = 4096;   // 64-key chunks sampled per outcome (262 144 keys: 128 per bucket at N = 4096)
 constexpr int MSD_SAMPLE_WGS = 32;        // 256-thread workgroups per outcome in the two sampling sweeps
 constexpr int MSD_BIG_MAX = 63, MSD_BIG_WORDS = 64;   // buckets beyond MSD_CAP keys per outcome that msd_big_bucket_kernel takes (count + ids)
@@ -743,27 +741,51 @@ __global__ __launch_bounds__(1024) void msd_table_kernel(const uint32_t* __restr
   }
 }
 
+// A count / partition TILE is one 128 x 128 block of the lower triangle -- the unit the output leaves in.  A bucket's keys therefore sit
+// in the pair buffer in runs by output block (the partition writes tile t's keys of bucket b at base[b] + offs[t][b]), and the table
+// of the exact layout -- counts / offs, one row per tile -- IS the directory the block gather reads its runs from: the bucket sort
+// neither regroups its pairs by block nor writes a directory (round 5's first version did both, with a second returning LDS atomic
+// per key, a second trip through LDS and a transposing kernel behind it).
+struct MsdTileGeom {
+  int r0, c0;
+  __device__ __forceinline__ void of(int t) {
+    int bi = static_cast<int>((sqrtf(8.0f * static_cast<float>(t) + 1.0f) - 1.0f) * 0.5f);
+    while (bi * (bi + 1) / 2 > t) --bi;
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    r0 = bi * BB;
+    c0 = (t - bi * (bi + 1) / 2) * BB;
+  }
+  // item k of thread tid (1024 threads x 16 items): row k * 8 + tid / 128, column tid % 128 -- a wave reads 256 contiguous bytes
+  __device__ __forceinline__ bool cell(int k, int tid, int N, int& i, int& j) const {
+    i = r0 + k * 8 + (tid >> 7);
+    j = c0 + (tid & 127);
+    return i < N && j < i;
+  }
+  __device__ __forceinline__ int keys(int N) const {      // cells of the tile in the strict lower triangle
+    const int rc = N - r0 < BB ? N - r0 : BB;
+    return r0 == c0 ? rc * (rc - 1) / 2 : rc * BB;
+  }
+};
+
 // counts[(outcome * n_tiles + tile) * nbs + bucket] (u16): keys of the tile per bucket
 __global__ __launch_bounds__(1024) void msd_count_kernel(const float* __restrict__ scores, int64_t lds, const uint32_t* __restrict__ tables,
-                                                        uint16_t* __restrict__ counts, int N, int64_t M, int nbs, int src_is_keys) {
+                                                        uint16_t* __restrict__ counts, int N, int nbs, int src_is_keys) {
   constexpr int TPB = 1024, ITEMS = 16;
   __shared__ __attribute__((aligned(16))) uint32_t tab[MSD_N1 + MSD_NC];      // level 1 | level 2
   __shared__ uint32_t cnt[MSD_NB_MAX];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t seg = blockIdx.y, base = static_cast<int64_t>(blockIdx.x) * MSD_TILE + wave * (MSD_TILE / 16);
+  const int tid = threadIdx.x;
+  const int64_t seg = blockIdx.y;
   const float* sc = scores + seg * static_cast<int64_t>(N) * lds;
   const uint32_t* t = tables + seg * MSD_TABLE_WORDS;
+  MsdTileGeom g;
+  g.of(static_cast<int>(blockIdx.x));
   float raw[ITEMS];
-  {
-    TriWalk w;
-    w.start(base, M);
+  bool ok[ITEMS];
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-      int i, j;
-      w.lane_pos(lane, i, j);
-      raw[k] = (base + k * 64 + lane < M) ? sc[static_cast<int64_t>(i) * lds + j] : 0.f;
-      w.step();
-    }
+  for (int k = 0; k < ITEMS; ++k) {
+    int i, j;
+    ok[k] = g.cell(k, tid, N, i, j);
+    raw[k] = ok[k] ? sc[static_cast<int64_t>(i) * lds + j] : 0.f;
   }
   for (int c = tid; c < (MSD_N1 + MSD_NC) / 4; c += TPB) reinterpret_cast<u32x4*>(tab)[c] = reinterpret_cast<const u32x4*>(t + MSD_HDR)[c];
   const MsdMap m = msd_load_map(t);
@@ -771,7 +793,7 @@ __global__ __launch_bounds__(1024) void msd_count_kernel(const float* __restrict
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k)
-    if (base + k * 64 + lane < M) {
+    if (ok[k]) {
       const uint32_t key = src_is_keys ? __builtin_bit_cast(uint32_t, raw[k]) : mdg_order_key(raw[k]);
       __hip_atomic_fetch_add(&cnt[msd_bucket_of(key, tab, tab + MSD_N1, m)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -780,16 +802,39 @@ __global__ __launch_bounds__(1024) void msd_count_kernel(const float* __restrict
   for (int b2 = tid; b2 < nbs / 2; b2 += TPB) dst[b2] = cnt[2 * b2] | (cnt[2 * b2 + 1] << 16);
 }
 
-// offs[(outcome * n_tiles + tile) * nbs + bucket] = keys of the bucket in the tiles before; totals[outcome * nbs + bucket]
-__global__ __launch_bounds__(256) void msd_scan_kernel(const uint16_t* __restrict__ counts, uint32_t* __restrict__ offs, uint32_t* __restrict__ totals,
-                                                      int n_tiles, int nbs) {
-  const int b = blockIdx.x * 256 + threadIdx.x;
+// offs[(outcome * n_tiles + tile) * nbs + bucket] = keys of the bucket in the tiles before; totals[outcome * nbs + bucket].
+// 64 buckets per workgroup, the tiles in 16 chunks of one wave each: chunk sums, their prefix through LDS, then the chunk's own walk
+// (one thread per bucket walking all ~528 tiles was 32 workgroups of dependent loads: 34 us per group of 8 outcomes)
+__global__ __launch_bounds__(1024) void msd_scan_kernel(const uint16_t* __restrict__ counts, uint32_t* __restrict__ offs, uint32_t* __restrict__ totals,
+                                                       int n_tiles, int nbs) {
+  __shared__ uint32_t csum[16][64];
+  const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
+  const int b = blockIdx.x * 64 + lane;
   const int64_t seg = blockIdx.y;
+  const int per = (n_tiles + 15) / 16, t0 = ch * per, t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
   const uint16_t* c = counts + seg * n_tiles * static_cast<int64_t>(nbs) + b;
   uint32_t* o = offs + seg * n_tiles * static_cast<int64_t>(nbs) + b;
-  uint32_t run = 0;
-  int t = 0;
-  for (; t + 8 <= n_tiles; t += 8) {
+  uint32_t sum = 0;
+  int t = t0;
+  for (; t + 8 <= t1; t += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = c[static_cast<int64_t>(t + e) * nbs];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += v[e];
+  }
+  for (; t < t1; ++t) sum += c[static_cast<int64_t>(t) * nbs];
+  csum[ch][lane] = sum;
+  __syncthreads();
+  uint32_t run = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const uint32_t v = csum[w][lane];
+    run += w < ch ? v : 0u;
+    tot += v;
+  }
+  t = t0;
+  for (; t + 8 <= t1; t += 8) {
     uint32_t v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = c[static_cast<int64_t>(t + e) * nbs];
@@ -799,11 +844,11 @@ __global__ __launch_bounds__(256) void msd_scan_kernel(const uint16_t* __restric
       run += v[e];
     }
   }
-  for (; t < n_tiles; ++t) {
+  for (; t < t1; ++t) {
     o[static_cast<int64_t>(t) * nbs] = run;
     run += c[static_cast<int64_t>(t) * nbs];
   }
-  totals[seg * nbs + b] = run;
+  if (ch == 0) totals[seg * nbs + b] = tot;
 }
 
 // base[outcome * nbs + bucket] = keys in the buckets before.  A bucket beyond the bucket sort's LDS room goes on the outcome's list for
@@ -868,16 +913,13 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
   const MsdMap m = msd_load_map(t_hdr);
   u32x2* dst = part + seg * M;
   float raw[ITEMS];
+  MsdTileGeom gnext;
   const auto load_tile = [&](int t) {
-    const int64_t base = static_cast<int64_t>(t) * MSD_TILE + wave * (MSD_TILE / 16);
-    TriWalk w;
-    w.start(base, M);
+    gnext.of(t);
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
       int i, j;
-      w.lane_pos(lane, i, j);
-      raw[k] = (base + k * 64 + lane < M) ? sc[static_cast<int64_t>(i) * lds + j] : 0.f;
-      w.step();
+      raw[k] = gnext.cell(k, tid, N, i, j) ? sc[static_cast<int64_t>(i) * lds + j] : 0.f;
     }
   };
   // where the tile's run of bucket b starts: thread tid owns buckets BPT * tid .. (loaded a tile ahead, like the scores)
@@ -892,31 +934,25 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
   int t = blockIdx.x;
   if (t < n_tiles) { load_tile(t); load_offsets(t); }
   for (; t < n_tiles; t += gridDim.x) {
-    const int64_t base = static_cast<int64_t>(t) * MSD_TILE;
+    const MsdTileGeom g = gnext;
     for (int b = tid; b < MSD_NB_MAX; b += TPB) bcnt[b] = 0;
     uint32_t key[ITEMS], q[ITEMS], sb[ITEMS];             // sb = slot in the tile's run | bucket << 16
     uint32_t gcur[BPT];
-    {
-      TriWalk w;                                           // the walk again, for the positions (the loads took it one tile ahead)
-      w.start(base + wave * (MSD_TILE / 16), M);
 #pragma unroll
-      for (int k = 0; k < ITEMS; ++k) {
-        int i, j;
-        w.lane_pos(lane, i, j);
-        key[k] = src_is_keys ? __builtin_bit_cast(uint32_t, raw[k]) : mdg_order_key(raw[k]);
-        q[k] = (static_cast<uint32_t>(i) << 16) | static_cast<uint32_t>(j);
-        w.step();
-      }
-#pragma unroll
-      for (int e = 0; e < BPT; ++e) gcur[e] = gpos[e];
+    for (int k = 0; k < ITEMS; ++k) {
+      int i, j;
+      const bool ok = g.cell(k, tid, N, i, j);
+      key[k] = src_is_keys ? __builtin_bit_cast(uint32_t, raw[k]) : mdg_order_key(raw[k]);
+      q[k] = ok ? (static_cast<uint32_t>(i) << 16) | static_cast<uint32_t>(j) : MSD_SKIP;      // (a position is never ~0: j < i)
     }
+#pragma unroll
+    for (int e = 0; e < BPT; ++e) gcur[e] = gpos[e];
     if (t + static_cast<int>(gridDim.x) < n_tiles) { load_tile(t + gridDim.x); load_offsets(t + gridDim.x); }
     __syncthreads();                                       // bcnt zeroed, tab loaded (and the previous tile's copy-out done with them)
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
-      const int64_t p = base + wave * (MSD_TILE / 16) + k * 64 + lane;
       sb[k] = MSD_SKIP;
-      if (p < M) {
+      if (q[k] != MSD_SKIP) {
         const uint32_t b = msd_bucket_of(key[k], tab, tab + MSD_N1, m);
         sb[k] = atomicAdd(&bcnt[b], 1u) | (b << 16);
       }
@@ -949,7 +985,7 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
     __syncthreads();
     // (copy-out by sixteen lanes per run from the bucket tables, instead of re-deriving every pair's bucket from its key, was measured:
     // 177 against 175 us per outcome -- the idle lanes of short runs cost more than the two table reads)
-    const int n_valid = static_cast<int>(M - base < MSD_TILE ? M - base : MSD_TILE);
+    const int n_valid = g.keys(N);
 #pragma unroll 4
     for (int k = 0; k < ITEMS; ++k) {
       const int idx = k * TPB + tid;
@@ -1003,22 +1039,20 @@ struct MsdFine {
   }
 };
 
-// One bucket per workgroup: ranks of its keys, then its (rank, position in block) pairs grouped by 128 x 128 output block, written
-// back CONTIGUOUSLY over the bucket's own range of the pair buffer, plus one directory row: where each block's run starts inside the
-// bucket (u16, packed in pairs; entry n_blocks = the bucket's size).  No global atomics: the first version reserved room in per-block
-// regions with one returning global atomic per bucket and block (1.08 million per outcome, 64 lanes on 64 different lines) and spent
-// a fifth of its time there; the block kernel now GATHERS its runs through the transposed directory instead.
-// Straight-line code: a thread's 12 items all take the same path -- an item behind the bucket's last key counts into a dummy fine
-// bin (NF) and a dummy block (n_blocks) that sort behind everything real -- so there are no per-item branches around the LDS atomics.
+// One bucket per workgroup: the rank of every key inside the bucket, written at the key's own place in the bucket's range as one word
+// -- (rank in the bucket) << 14 | (row in the output block) << 7 | (column in the output block).  The bucket's range is already in
+// runs by output block (see MsdTileGeom), so nothing is regrouped and there are no global atomics.
+// One returning LDS atomic per key (its slot in its fine bin); items behind the bucket's last key take none (thousands of lanes on one
+// dummy counter serialise).
 template <int NF>
 __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __restrict__ part, const uint32_t* __restrict__ bases,
-                                                           const uint32_t* __restrict__ totals, u32x2* __restrict__ grouped, uint32_t* __restrict__ dir,
-                                                           uint32_t* __restrict__ flags, int64_t M, int nbs, int n_blocks, int dw) {
+                                                           const uint32_t* __restrict__ totals, uint32_t* __restrict__ ranked,
+                                                           uint32_t* __restrict__ flags, int64_t M, int nbs) {
   constexpr int TPB = 1024, CAP = MSD_CAP, ITEMS = CAP / TPB, WPT = NF / 2 / TPB, WAVES = TPB / 64;     // NF fine bins, two u16 counters per word
-  constexpr int LGNF = 31 - __builtin_clz(NF), BWPT = MSD_BWORDS / TPB;
-  static_assert(CAP % TPB == 0 && (NF & (NF - 1)) == 0 && NF % (2 * TPB) == 0 && CAP < 65536 && MSD_BWORDS % TPB == 0 && 2 * MSD_BWORDS > MSD_MAX_BLOCKS + 1, "bucket sort shape");
-  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];       // sorted[CAP] (u32x2) | fc[NF / 2 + 32] | bc[MSD_BWORDS]
-  __shared__ __attribute__((aligned(16))) uint32_t wsum_f[WAVES], wsum_b[WAVES];
+  constexpr int LGNF = 31 - __builtin_clz(NF);
+  static_assert(CAP % TPB == 0 && (NF & (NF - 1)) == 0 && NF % (2 * TPB) == 0 && CAP <= 16384, "bucket sort shape");
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];       // sorted[CAP] (u32x2) | fc[NF / 2 + 32]
+  __shared__ __attribute__((aligned(16))) uint32_t wsum_f[WAVES];
   __shared__ uint32_t krange[2];
   __shared__ unsigned long long ksum_sh;
   const int64_t seg = blockIdx.y;
@@ -1029,17 +1063,8 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
   const uint32_t rb = bases[seg * nbs + b];
   u32x2* sorted = reinterpret_cast<u32x2*>(dyn);
   uint32_t* fc = dyn + 2 * CAP;
-  uint32_t* bc = fc + NF / 2 + 32;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   uint32_t key[ITEMS], q[ITEMS], ss[ITEMS];
-#ifdef MDG_RANK_STAMPS
-  uint64_t stamp[10];
-  int n_stamp = 0;
-#define MDG_STAMP() do { uint64_t t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp[n_stamp++] = t_; } while (0)
-#else
-#define MDG_STAMP()
-#endif
-  MDG_STAMP();
   uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
   {
     const u32x2* src = part + seg * M + rb;
@@ -1052,11 +1077,10 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
       q[k] = v[1];
     }
   }
-  static_assert(WPT % 4 == 0 && BWPT == 1, "16-byte accesses cover the fine counters");
+  static_assert(WPT % 4 == 0, "16-byte accesses cover the fine counters");
 #pragma unroll
   for (int v4 = 0; v4 < WPT / 4; ++v4) reinterpret_cast<u32x4*>(fc)[tid * (WPT / 4) + v4] = u32x4{0u, 0u, 0u, 0u};
   if (tid < 8) reinterpret_cast<u32x4*>(fc + NF / 2)[tid] = u32x4{0u, 0u, 0u, 0u};
-  bc[tid] = 0;
   if (tid == 0) { krange[0] = 0xFFFFFFFFu; krange[1] = 0u; ksum_sh = 0ull; }
   unsigned long long ksum = 0ull;
 #pragma unroll
@@ -1073,55 +1097,43 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
     kmax = kmax > c ? kmax : c;
     ksum += __shfl_xor(ksum, o, 64);
   }
-  MDG_STAMP();
   __syncthreads();
   if (lane == 0 && kmin <= kmax) { atomicMin(&krange[0], kmin); atomicMax(&krange[1], kmax); atomicAdd(&ksum_sh, ksum); }
   __syncthreads();
-  MDG_STAMP();
   MsdFine fine_of;
   fine_of.init(krange[0], krange[1], n > 0 ? static_cast<float>(static_cast<double>(ksum_sh) / n) : 0.f, LGNF);
-  const auto block_of = [](uint32_t qq) -> uint32_t {
-    const uint32_t bi = qq >> 23, bj = (qq & 0xFFFFu) >> 7;
-    return bi * (bi + 1u) / 2u + bj;
-  };
-  // ---- slots: in the key's fine bin (low half of ss) and in its output block's run (high half), one returning LDS atomic each
-  // (items behind the bucket's last key take none: thousands of lanes on one dummy counter serialise)
+  // ---- the key's slot in its fine bin
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     ss[k] = 0u;
     if (k * TPB + tid < n) {
-      const uint32_t fi = fine_of(key[k], q[k]), blk = block_of(q[k]);
-      const uint32_t fh = 16u * (fi & 1u), bh = 16u * (blk & 1u);
-      const uint32_t fs = (atomicAdd(&fc[fi >> 1], 1u << fh) >> fh) & 0xFFFFu;
-      const uint32_t bs = (atomicAdd(&bc[blk >> 1], 1u << bh) >> bh) & 0xFFFFu;
-      ss[k] = fs | (bs << 16);
+      const uint32_t fi = fine_of(key[k], q[k]);
+      const uint32_t fh = 16u * (fi & 1u);
+      ss[k] = (atomicAdd(&fc[fi >> 1], 1u << fh) >> fh) & 0xFFFFu;
     }
-    if (k % 3 == 2) __builtin_amdgcn_sched_barrier(0);      // three items' atomics in flight at a time (all of them at once spilled registers)
+    if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // four items' atomics in flight at a time (all of them at once spilled registers)
   }
   __syncthreads();
-  MDG_STAMP();
-  {   // exclusive scans in place, both behind the same two barriers: fine bins (four words per thread) and blocks (one word per thread)
+  {   // exclusive scan of the fine bins in place (four words per thread)
     uint32_t w[WPT];
 #pragma unroll
     for (int v4 = 0; v4 < WPT / 4; ++v4) {
       const u32x4 t4 = reinterpret_cast<const u32x4*>(fc)[tid * (WPT / 4) + v4];
       w[4 * v4] = t4[0]; w[4 * v4 + 1] = t4[1]; w[4 * v4 + 2] = t4[2]; w[4 * v4 + 3] = t4[3];
     }
-    const uint32_t x = bc[tid];
     uint32_t tot = 0;
 #pragma unroll
     for (int e = 0; e < WPT; ++e) tot += (w[e] & 0xFFFFu) + (w[e] >> 16);
-    const uint32_t totb = (x & 0xFFFFu) + (x >> 16);
-    const uint32_t inc = wave_inclusive(tot, lane), incb = wave_inclusive(totb, lane);
-    if (lane == 63) { wsum_f[wave] = inc; wsum_b[wave] = incb; }
+    const uint32_t inc = wave_inclusive(tot, lane);
+    if (lane == 63) wsum_f[wave] = inc;
     __syncthreads();
-    uint32_t run = inc - tot, runb = incb - totb;
+    uint32_t run = inc - tot;
 #pragma unroll
     for (int v4 = 0; v4 < WAVES / 4; ++v4) {                // every wave total, four per LDS read (the same addresses in every lane: broadcast)
-      const u32x4 f4 = reinterpret_cast<const u32x4*>(wsum_f)[v4], b4 = reinterpret_cast<const u32x4*>(wsum_b)[v4];
+      const u32x4 f4 = reinterpret_cast<const u32x4*>(wsum_f)[v4];
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (4 * v4 + e < wave) { run += f4[e]; runb += b4[e]; }
+        if (4 * v4 + e < wave) run += f4[e];
     }
 #pragma unroll
     for (int e = 0; e < WPT; ++e) {
@@ -1131,11 +1143,9 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
     }
 #pragma unroll
     for (int v4 = 0; v4 < WPT / 4; ++v4) reinterpret_cast<u32x4*>(fc)[tid * (WPT / 4) + v4] = u32x4{w[4 * v4], w[4 * v4 + 1], w[4 * v4 + 2], w[4 * v4 + 3]};
-    bc[tid] = runb | ((runb + (x & 0xFFFFu)) << 16);
     if (tid == 0) fc[NF / 2] = static_cast<uint32_t>(n);  // fstart(NF) = the bucket's size
   }
   __syncthreads();
-  MDG_STAMP();
   // Where the key's fine bin starts and how many keys it holds: both bounds from one two-word read (the bins' starts are u16 pairs).  A
   // key ALONE in its bin -- six of ten -- is in place by that alone (rank = bin start): it is neither written to `sorted` nor probed.
 #pragma unroll
@@ -1149,16 +1159,16 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
       const uint32_t w0 = fc[fi >> 1], w1 = fc[(fi >> 1) + 1];
       const uint32_t s0 = (fi & 1u) ? (w0 >> 16) : (w0 & 0xFFFFu), s1 = (fi & 1u) ? (w1 & 0xFFFFu) : (w0 >> 16);
       sc[k] = s0 | ((s1 - s0) << 16);
-      if (s1 - s0 > 1u) sorted[s0 + (ss[k] & 0xFFFFu)] = u32x2{key[k], q[k]};
+      if (s1 - s0 > 1u) sorted[s0 + ss[k]] = u32x2{key[k], q[k]};
     }
   }
   __syncthreads();
-  MDG_STAMP();
   // keys that share a fine bin: their order is (key, position).  Six bin-mates are probed with predicated, independent LDS reads (a bin
   // holds ~half a key: one key in 10^4 has more and walks on)
   bool too_many = false;
   constexpr int PROBES = 6, GRP = 2;
   static_assert(ITEMS % GRP == 0, "tie-fix groups");
+  uint32_t* dst = ranked + seg * M + rb;
 #pragma unroll
   for (int k0 = 0; k0 < ITEMS; k0 += GRP) {                // two items at a time: 12 probes in flight
     u32x2 o[GRP][PROBES];
@@ -1187,55 +1197,26 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
             r += (x[0] < key[k] || (x[0] == key[k] && x[1] < q[k])) ? 1u : 0u;
           }
       }
-      key[k] = rb + s0 + r;                                // rank - 1
+      const int idx = k * TPB + tid;
+      if (idx < n) dst[idx] = ((s0 + r) << 14) | (((q[k] >> 16) & 127u) << 7) | (q[k] & 127u);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
   if (too_many) atomicOr(&flags[seg], MSD_F_TIES);
-  __syncthreads();                                       // `sorted` is read: the (rank, position in block) pairs go through it now
-  MDG_STAMP();
-  const auto bstart = [&](uint32_t t) -> uint32_t { return (bc[t >> 1] >> (16u * (t & 1u))) & 0xFFFFu; };
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) asm volatile("" : "+v"(q[k]));        // the same for the block index
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) {
-    const uint32_t i = q[k] >> 16, j = q[k] & 0xFFFFu;
-    if (k * TPB + tid < n) sorted[bstart(block_of(q[k])) + (ss[k] >> 16)] = u32x2{key[k], ((i & 127u) << 7) | (j & 127u)};
-  }
-  __syncthreads();
-  MDG_STAMP();
-  u32x2* dst = grouped + seg * M + rb;
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) {
-    const int idx = k * TPB + tid;
-    if (idx < n) dst[idx] = sorted[idx];
-  }
-  uint32_t* drow = dir + (seg * nbs + b) * static_cast<int64_t>(dw);
-#ifdef MDG_RANK_STAMPS
-  for (int w = tid; w < dw - 22; w += TPB) drow[w] = bc[w];
-  MDG_STAMP();
-  if (tid == 0)
-    for (int e = 0; e < n_stamp; ++e) { drow[dw - 22 + 2 * e] = static_cast<uint32_t>(stamp[e]); drow[dw - 21 + 2 * e] = static_cast<uint32_t>(stamp[e] >> 32); }
-#else
-  for (int w = tid; w < dw; w += TPB) drow[w] = bc[w];
-#endif
-#undef MDG_STAMP
 }
 
 // A bucket beyond the LDS room of msd_bucket_kernel (fewer than 65 536 keys; the bucket function's sub-ranges assume a density that is
-// flat inside a level-2 bin, which a sparse region at the edge of a score distribution is not): the same counting sort, the same
-// output (ranks, pairs grouped by output block over the bucket's own range, one directory row), with the pairs streamed through global
-// memory instead of held in registers and LDS -- sorted pairs into the bucket's range of `grouped`, the grouped (rank, position) pairs
-// back over its range of `part` (every read of the input is done by then), then copied.  One workgroup per listed bucket: a few per
-// outcome at most, so its speed does not matter.
-__global__ __launch_bounds__(1024) void msd_big_bucket_kernel(u32x2* __restrict__ part, const uint32_t* __restrict__ bases, const uint32_t* __restrict__ totals,
-                                                             u32x2* __restrict__ grouped, uint32_t* __restrict__ dir, uint32_t* __restrict__ flags,
-                                                             const uint32_t* __restrict__ big, int64_t M, int nbs, int n_blocks, int dw) {
+// flat inside a level-2 bin, which a sparse region at the edge of a score distribution is not): the same counting sort and the same
+// output words, with the pairs streamed through global memory instead of held in registers and LDS -- sorted by fine bin into the
+// bucket's slot of `tmp` (65 536 pairs per listed bucket), then every key's bin-mates read back from there.  One workgroup per listed
+// bucket: a few per outcome at most, so its speed does not matter.
+__global__ __launch_bounds__(1024) void msd_big_bucket_kernel(const u32x2* __restrict__ part, const uint32_t* __restrict__ bases,
+                                                             const uint32_t* __restrict__ totals, uint32_t* __restrict__ ranked, u32x2* __restrict__ tmp_all,
+                                                             uint32_t* __restrict__ flags, const uint32_t* __restrict__ big, int64_t M, int nbs) {
   constexpr int TPB = 1024, NF = MSD_BIG_NF, LGNF = 31 - __builtin_clz(NF), WPT = NF / 2 / TPB;
   __shared__ __attribute__((aligned(16))) uint32_t fc[NF / 2 + 4];       // fine-bin counters, then starts (two u16 per word)
   __shared__ __attribute__((aligned(16))) uint32_t cur[NF / 2 + 4];      // cursors: start + keys placed so far
-  __shared__ uint32_t bc[MSD_BWORDS], bcur[MSD_BWORDS];
-  __shared__ __attribute__((aligned(16))) uint32_t wsum_f[16], wsum_b[16];
+  __shared__ __attribute__((aligned(16))) uint32_t wsum_f[16];
   __shared__ uint32_t krange[2];
   __shared__ unsigned long long ksum_sh;
   const int64_t seg = blockIdx.y;
@@ -1244,10 +1225,9 @@ __global__ __launch_bounds__(1024) void msd_big_bucket_kernel(u32x2* __restrict_
   const int n = static_cast<int>(totals[seg * nbs + b]);
   const uint32_t rb = bases[seg * nbs + b];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  u32x2* in = part + seg * M + rb;
-  u32x2* tmp = grouped + seg * M + rb;
+  const u32x2* in = part + seg * M + rb;
+  u32x2* tmp = tmp_all + (seg * MSD_BIG_MAX + blockIdx.x) * int64_t{65536};
   for (int i = tid; i < NF / 2 + 4; i += TPB) fc[i] = 0;
-  bc[tid] = 0;
   if (tid == 0) { krange[0] = 0xFFFFFFFFu; krange[1] = 0u; ksum_sh = 0ull; }
   uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
   unsigned long long ksum = 0ull;
@@ -1269,27 +1249,21 @@ __global__ __launch_bounds__(1024) void msd_big_bucket_kernel(u32x2* __restrict_
   __syncthreads();
   MsdFine fine_of;
   fine_of.init(krange[0], krange[1], static_cast<float>(static_cast<double>(ksum_sh) / n), LGNF);
-  const auto block_of = [](uint32_t qq) -> uint32_t {
-    const uint32_t bi = qq >> 23, bj = (qq & 0xFFFFu) >> 7;
-    return bi * (bi + 1u) / 2u + bj;
-  };
   for (int idx = tid; idx < n; idx += TPB) {
     const u32x2 v = in[idx];
-    const uint32_t fi = fine_of(v[0], v[1]), blk = block_of(v[1]);
+    const uint32_t fi = fine_of(v[0], v[1]);
     atomicAdd(&fc[fi >> 1], 1u << (16u * (fi & 1u)));
-    atomicAdd(&bc[blk >> 1], 1u << (16u * (blk & 1u)));
   }
   __syncthreads();
   {
     uint32_t w[WPT], tot = 0;
 #pragma unroll
     for (int e = 0; e < WPT; ++e) { w[e] = fc[tid * WPT + e]; tot += (w[e] & 0xFFFFu) + (w[e] >> 16); }
-    const uint32_t x = bc[tid], totb = (x & 0xFFFFu) + (x >> 16);
-    const uint32_t inc = wave_inclusive(tot, lane), incb = wave_inclusive(totb, lane);
-    if (lane == 63) { wsum_f[wave] = inc; wsum_b[wave] = incb; }
+    const uint32_t inc = wave_inclusive(tot, lane);
+    if (lane == 63) wsum_f[wave] = inc;
     __syncthreads();
-    uint32_t run = inc - tot, runb = incb - totb;
-    for (int v = 0; v < wave; ++v) { run += wsum_f[v]; runb += wsum_b[v]; }
+    uint32_t run = inc - tot;
+    for (int v = 0; v < wave; ++v) run += wsum_f[v];
 #pragma unroll
     for (int e = 0; e < WPT; ++e) {
       const uint32_t c0 = w[e] & 0xFFFFu, c1 = w[e] >> 16;
@@ -1298,9 +1272,6 @@ __global__ __launch_bounds__(1024) void msd_big_bucket_kernel(u32x2* __restrict_
       cur[tid * WPT + e] = st;
       run += c0 + c1;
     }
-    const uint32_t stb = runb | ((runb + (x & 0xFFFFu)) << 16);
-    bc[tid] = stb;
-    bcur[tid] = stb;
   }
   __syncthreads();
   // sorted by fine bin into `tmp`
@@ -1313,10 +1284,11 @@ __global__ __launch_bounds__(1024) void msd_big_bucket_kernel(u32x2* __restrict_
   __threadfence();
   __syncthreads();
   __threadfence();
-  // ranks (a bin's keys ordered by (key, position) by counting), the pair into its output block's run over `in`
+  // ranks: a bin's keys ordered by (key, position) by counting
   bool too_many = false;
+  uint32_t* dst = ranked + seg * M + rb;
   for (int idx = tid; idx < n; idx += TPB) {
-    const u32x2 v = __builtin_nontemporal_load(&tmp[idx]);
+    const u32x2 v = in[idx];
     const uint32_t fi = fine_of(v[0], v[1]);
     const uint32_t s0 = (fc[fi >> 1] >> (16u * (fi & 1u))) & 0xFFFFu, e0 = (cur[fi >> 1] >> (16u * (fi & 1u))) & 0xFFFFu;
     uint32_t r = 0;
@@ -1326,128 +1298,93 @@ __global__ __launch_bounds__(1024) void msd_big_bucket_kernel(u32x2* __restrict_
         const u32x2 o = __builtin_nontemporal_load(&tmp[m]);
         r += (o[0] < v[0] || (o[0] == v[0] && o[1] < v[1])) ? 1u : 0u;
       }
-    const uint32_t blk = block_of(v[1]), bh = 16u * (blk & 1u);
-    const uint32_t bpos = (atomicAdd(&bcur[blk >> 1], 1u << bh) >> bh) & 0xFFFFu;
-    const uint32_t i = v[1] >> 16, j = v[1] & 0xFFFFu;
-    in[bpos] = u32x2{rb + s0 + r, ((i & 127u) << 7) | (j & 127u)};
+    dst[idx] = ((s0 + r) << 14) | (((v[1] >> 16) & 127u) << 7) | (v[1] & 127u);
   }
   if (too_many) atomicOr(&flags[seg], MSD_F_TIES);
-  __threadfence();
-  __syncthreads();
-  __threadfence();
-  for (int idx = tid; idx < n; idx += TPB) tmp[idx] = __builtin_nontemporal_load(&in[idx]);
-  uint32_t* drow = dir + (seg * nbs + b) * static_cast<int64_t>(dw);
-  for (int w = tid; w < dw; w += TPB) drow[w] = bc[w];
 }
 
-// startT[(outcome * n_blocks + block) * nbs + bucket] = first pair of the bucket's run of that block in the pair buffer; lenT[.] = its length
-__global__ __launch_bounds__(256) void msd_dir_transpose_kernel(const uint32_t* __restrict__ dir, const uint32_t* __restrict__ bases,
-                                                               uint32_t* __restrict__ startT, uint16_t* __restrict__ lenT, const uint32_t* __restrict__ flags,
-                                                               int nbt, int nbs, int n_blocks, int dw) {
-  __shared__ uint16_t t[64][68];
-  const int64_t seg = blockIdx.z;
-  if (flags[seg]) return;
-  const int tid = threadIdx.x, k0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
-  const uint16_t* d16 = reinterpret_cast<const uint16_t*>(dir);
-  for (int e = tid; e < 64 * 65; e += 256) {
-    const int rr = e / 65, kc = e - rr * 65, k = k0 + kc, bb = b0 + rr;
-    t[rr][kc] = (k <= n_blocks && bb < nbt) ? d16[(seg * nbs + bb) * static_cast<int64_t>(2 * dw) + k] : static_cast<uint16_t>(0);
-  }
-  __syncthreads();
-  for (int e = tid; e < 64 * 64; e += 256) {
-    const int kc = e >> 6, rr = e & 63, k = k0 + kc, bb = b0 + rr;
-    if (k < n_blocks && bb < nbt) {
-      const uint32_t s = t[rr][kc];
-      const int64_t o = (seg * n_blocks + k) * static_cast<int64_t>(nbs) + bb;
-      startT[o] = bases[seg * nbs + bb] + s;
-      lenT[o] = static_cast<uint16_t>(t[rr][kc + 1] - s);
-    }
-  }
-}
-
-// one 128 x 128 block of the lower triangle, gathered from every bucket's run of it (8 lanes per run, the runs' starts and lengths from
-// the transposed directory, staged in LDS first): ranks into an LDS tile, then whole rows of out[i, j] and of the mirrored block
+// one 128 x 128 block of the lower triangle, gathered from every bucket's run of it (8 lanes per run; the runs' starts and lengths are
+// the block's row of the layout tables, staged in LDS first): ranks into an LDS tile, then whole rows of out[i, j] and of the mirrored block
 template <bool VEC>
-__global__ __launch_bounds__(512) void msd_block_gather_kernel(const u32x2* __restrict__ grouped, const uint32_t* __restrict__ startT,
-                                                               const uint16_t* lenT, float* __restrict__ out, int64_t ldo, int N, int64_t M,
+__global__ __launch_bounds__(512) void msd_block_gather_kernel(const uint32_t* __restrict__ ranked, const uint32_t* __restrict__ offs,
+                                                               const uint16_t* __restrict__ counts, const uint32_t* __restrict__ bases,
+                                                               float* __restrict__ out, int64_t ldo, int N, int64_t M,
                                                                int nbt, int nbs, int n_blocks, double denom, const uint32_t* __restrict__ flags) {
   constexpr int TPB = 512;
-  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];       // tile[BB][BB + 1] (float) | st[nbs] | ln[nbs] (u16)
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];       // tile[BB][BB + 1] (float) | st[nbs] | bs[nbs] | ln[nbs] (u16)
   float (*tile)[BB + 1] = reinterpret_cast<float (*)[BB + 1]>(dyn);
   uint32_t (*tile_u)[BB + 1] = reinterpret_cast<uint32_t (*)[BB + 1]>(dyn);
   uint32_t* st = dyn + BB * (BB + 1);
-  uint16_t* ln = reinterpret_cast<uint16_t*>(st + nbs);
-#ifdef MDG_RANK_STAMPS
-  uint64_t stamp[8];
-  int n_stamp = 0;
-#define MDG_STAMP() do { uint64_t t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp[n_stamp++] = t_; } while (0)
-#else
-#define MDG_STAMP()
-#endif
+  uint32_t* bs = st + nbs;
+  uint16_t* ln = reinterpret_cast<uint16_t*>(bs + nbs);
   const int64_t seg = blockIdx.y;
   if (flags[seg]) return;
-  MDG_STAMP();
   // Workgroups go to the 8 XCDs round robin (gridDim.x is a multiple of 8): XCD x takes the blocks [x * per, (x + 1) * per) in order,
   // so that blocks t and t + 1 -- whose runs are neighbours in every bucket and share 128-byte lines -- are resident together on one
   // XCD and the shared line is fetched into that L2 once (blockIdx order: every 64-byte run cost a whole line, 2.6 TB/s of pairs)
   const int per = gridDim.x >> 3, t = static_cast<int>(blockIdx.x & 7u) * per + static_cast<int>(blockIdx.x >> 3), tid = threadIdx.x;
   if (t >= n_blocks) return;
-  int bi = static_cast<int>((sqrtf(8.0f * static_cast<float>(t) + 1.0f) - 1.0f) * 0.5f);
-  while (bi * (bi + 1) / 2 > t) --bi;
-  while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-  const int bj = t - bi * (bi + 1) / 2;
-  const int r0 = bi * BB, c0 = bj * BB;
+  MsdTileGeom g;
+  g.of(t);
+  const int r0 = g.r0, c0 = g.c0;
   const int rcount = N - r0 < BB ? N - r0 : BB;
-  const bool diag = bi == bj;
+  const bool diag = r0 == c0;
   {
-    const uint32_t* s_row = startT + (seg * n_blocks + t) * static_cast<int64_t>(nbs);
-    const uint16_t* l_row = lenT + (seg * n_blocks + t) * static_cast<int64_t>(nbs);
-    for (int r = tid; r < nbt; r += TPB) { st[r] = s_row[r]; ln[r] = l_row[r]; }
+    const uint32_t* o_row = offs + (seg * n_blocks + t) * static_cast<int64_t>(nbs);
+    const uint16_t* l_row = counts + (seg * n_blocks + t) * static_cast<int64_t>(nbs);
+    const uint32_t* b_row = bases + seg * nbs;
+    for (int r = tid; r < nbt; r += TPB) {
+      const uint32_t bb = b_row[r];
+      bs[r] = bb + 1u;                                     // ranks count from 1
+      st[r] = bb + o_row[r];
+      ln[r] = l_row[r];
+    }
   }
   if (diag)
     for (int e = tid; e < BB; e += TPB) tile_u[e][e] = 0u;
   __syncthreads();
-  MDG_STAMP();
-  const u32x2* src = grouped + seg * M;
+  const uint32_t* src = ranked + seg * M;
   const int grp = tid >> 3, l8 = tid & 7;
-  // rank / M: both are integers below 2^24 on this path (N <= 4097), exact in fp32, and the correctly rounded fp32 quotient equals numpy's
+  // rank / M: both are integers below 2^24 on this path (N <= 5793), exact in fp32, and the correctly rounded fp32 quotient equals numpy's
   // float64 quotient rounded to fp32 (|r 2^e - k M| >= 1 keeps r / M away from every fp32 rounding boundary by more than a float64 ulp)
   // (the tile takes the integer ranks; they are divided once per element where the rows leave, all lanes busy, not here per gathered
-  // pair with half the lanes idle)
+  // word with half the lanes idle)
   const float denom_f = static_cast<float>(denom);
-  const auto put = [&](u32x2 v) {
-    const int r = v[1] >> 7, c = v[1] & 127;
-    tile_u[r][c] = v[0] + 1u;
-    if (diag) tile_u[c][r] = v[0] + 1u;
+  const auto put = [&](uint32_t v, uint32_t base1) {
+    const int r = (v >> 7) & 127, c = v & 127;
+    const uint32_t rank = base1 + (v >> 14);
+    tile_u[r][c] = rank;
+    if (diag) tile_u[c][r] = rank;
   };
-  // eight lanes per run, two pairs per lane (a run is ~8 pairs: one in 250 is longer than 16), eight runs per lane in flight: the pair
-  // buffer of a launch group is far larger than the Infinity Cache, so every load is an HBM miss and their number in flight is the speed
+  // eight lanes per run, two words per lane (a run is ~16 words: few are longer), eight runs per lane in flight: the word
+  // buffer of a launch group is larger than the Infinity Cache, so every load is an HBM miss and their number in flight is the speed
   constexpr int RU = 8;
   for (int rbase = 0; rbase < nbt; rbase += RU * (TPB / 8)) {
-    uint32_t s[RU];
+    uint32_t s[RU], b1[RU];
     int len[RU];
-    u32x2 v[RU][2];
+    uint32_t v[RU][3];
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
       const int r = rbase + u * (TPB / 8) + grp;
       len[u] = r < nbt ? static_cast<int>(ln[r]) : 0;
       s[u] = r < nbt ? st[r] : 0u;
+      b1[u] = r < nbt ? bs[r] : 0u;
     }
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
-      if (l8 < len[u]) v[u][0] = src[s[u] + l8];
-      if (l8 + 8 < len[u]) v[u][1] = src[s[u] + l8 + 8];
+#pragma unroll
+      for (int h = 0; h < 3; ++h)
+        if (l8 + 8 * h < len[u]) v[u][h] = src[s[u] + l8 + 8 * h];
     }
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
-      if (l8 < len[u]) put(v[u][0]);
-      if (l8 + 8 < len[u]) put(v[u][1]);
-      for (int l = l8 + 16; l < len[u]; l += 8) put(src[s[u] + l]);
+#pragma unroll
+      for (int h = 0; h < 3; ++h)
+        if (l8 + 8 * h < len[u]) put(v[u][h], b1[u]);
+      for (int l = l8 + 24; l < len[u]; l += 8) put(src[s[u] + l], b1[u]);
     }
   }
-  MDG_STAMP();
   __syncthreads();
-  MDG_STAMP();
   float* o = out + seg * static_cast<int64_t>(N) * ldo;
   const int qd = tid & 31, rr = tid >> 5;                  // 32 lanes x 4 columns cover a 128-wide row; 16 rows per sweep
   const int ccount = diag ? rcount : BB;
@@ -1466,11 +1403,7 @@ __global__ __launch_bounds__(512) void msd_block_gather_kernel(const u32x2* __re
   }
   for (int r = rcount + rr; r < BB; r += TPB / 32)          // rows beyond a ragged N: never gathered, but the mirrored loop below reads the columns' cells
     for (int e = 0; e < 4; ++e) tile[r][4 * qd + e] = 0.f;
-#ifdef MDG_RANK_STAMPS
-  if (!diag) {
-#else
   if (diag) return;
-#endif
   __syncthreads();
   for (int c = rr; c < BB; c += TPB / 32) {
     float* row = o + static_cast<int64_t>(c0 + c) * ldo + r0;
@@ -1479,15 +1412,6 @@ __global__ __launch_bounds__(512) void msd_block_gather_kernel(const u32x2* __re
       for (int e = 0; e < 4; ++e)
         if (4 * qd + e < rcount) row[4 * qd + e] = tile[4 * qd + e][c];
   }
-#ifdef MDG_RANK_STAMPS
-  }
-  MDG_STAMP();
-  if (tid == 0) {
-    uint64_t* d = reinterpret_cast<uint64_t*>(const_cast<uint16_t*>(lenT + (seg * n_blocks + t) * static_cast<int64_t>(nbs)));
-    for (int e = 0; e < n_stamp; ++e) d[e] = stamp[e];
-  }
-#endif
-#undef MDG_STAMP
 }
 
 template <bool LIST, bool VEC>
@@ -1619,10 +1543,12 @@ static bool rank_use_big(int64_t N) {
 struct MsdPlan {
   bool on;
   int group;                 // outcomes per launch group (the group's buffers are reused by the next group: Infinity-Cache resident)
-  int nbt, nbs, n_blocks, n_tiles;   // buckets per outcome; counter stride (a multiple of 256); output blocks; 16384-key tiles
-  int dw;                    // words of a directory row: n_blocks + 1 u16 entries, padded
-  size_t part_bytes, count_bytes, offs_bytes, tot_bytes, dir_bytes, start_bytes, len_bytes;      // per outcome
-  size_t group_bytes(int g) const { return 2 * a256(g * part_bytes) + a256(g * count_bytes) + a256(g * offs_bytes) + 2 * a256(g * tot_bytes) + a256(g * dir_bytes) + a256(g * start_bytes) + a256(g * len_bytes) + a256(static_cast<size_t>(g) * MSD_BIG_WORDS * 4); }
+  int nbt, nbs, n_blocks;    // buckets per outcome; counter stride (a multiple of 256); output blocks = count / partition tiles
+  size_t part_bytes, word_bytes, count_bytes, offs_bytes, tot_bytes, bigtmp_bytes;      // per outcome
+  size_t group_bytes(int g) const {
+    return a256(g * part_bytes) + a256(g * word_bytes) + a256(g * count_bytes) + a256(g * offs_bytes) + 2 * a256(g * tot_bytes) + a256(g * bigtmp_bytes) +
+           a256(static_cast<size_t>(g) * MSD_BIG_WORDS * 4);
+  }
   // per call (all outcomes): sample extremes | sample histograms (level 1, level 2) | tables
   size_t call_bytes(int64_t L) const { return a256(static_cast<size_t>(L) * 8) + a256(static_cast<size_t>(L) * (MSD_N1 + MSD_NC) * 4) + a256(static_cast<size_t>(L) * MSD_TABLE_WORDS * 4); }
 };
@@ -1633,7 +1559,7 @@ static MsdPlan msd_plan(int64_t n_outcomes, int64_t N) {
   MsdPlan pl{};
   const int64_t M = N * (N - 1) / 2;
   const int64_t nbt = mdg_cdiv(M, int64_t{1} << MSD_QLG);
-  pl.on = msd_sw.get() != 0 && N >= 2 && nbt <= MSD_NB_MAX && rank_blocks_of(N) <= MSD_MAX_BLOCKS;
+  pl.on = msd_sw.get() != 0 && N >= 2 && nbt <= MSD_NB_MAX;
   if (!pl.on) return pl;
   int g = group_sw.get();
   g = g < 1 ? 1 : g;
@@ -1641,15 +1567,12 @@ static MsdPlan msd_plan(int64_t n_outcomes, int64_t N) {
   pl.nbt = static_cast<int>(nbt);
   pl.nbs = (pl.nbt + 255) & ~255;
   pl.n_blocks = static_cast<int>(rank_blocks_of(N));
-  pl.n_tiles = static_cast<int>(mdg_cdiv(M, MSD_TILE));
   pl.part_bytes = static_cast<size_t>(M) * 8;
-  pl.count_bytes = static_cast<size_t>(pl.n_tiles) * pl.nbs * 2;
-  pl.offs_bytes = static_cast<size_t>(pl.n_tiles) * pl.nbs * 4;
+  pl.word_bytes = static_cast<size_t>(M) * 4;
+  pl.count_bytes = static_cast<size_t>(pl.n_blocks) * pl.nbs * 2;
+  pl.offs_bytes = static_cast<size_t>(pl.n_blocks) * pl.nbs * 4;
   pl.tot_bytes = static_cast<size_t>(pl.nbs) * 4;
-  pl.dw = ((pl.n_blocks + 2) / 2 + 31) & ~31;
-  pl.dir_bytes = static_cast<size_t>(pl.nbs) * pl.dw * 4;
-  pl.start_bytes = static_cast<size_t>(pl.n_blocks) * pl.nbs * 4;
-  pl.len_bytes = static_cast<size_t>(pl.n_blocks) * pl.nbs * 2;
+  pl.bigtmp_bytes = static_cast<size_t>(MSD_BIG_MAX) * 65536 * 8;
   return pl;
 }
 
@@ -1710,43 +1633,38 @@ static void msd_run(const MsdPlan& pl, const float* scores, int64_t lds, float* 
   // ---- group buffers
   char* p = ws;
   u32x2* part = reinterpret_cast<u32x2*>(p); p += a256(G * pl.part_bytes);
-  u32x2* pairs = reinterpret_cast<u32x2*>(p); p += a256(G * pl.part_bytes);
+  uint32_t* ranked = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.word_bytes);
   uint16_t* counts = reinterpret_cast<uint16_t*>(p); p += a256(G * pl.count_bytes);
   uint32_t* offs = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.offs_bytes);
   uint32_t* totals = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.tot_bytes);
   uint32_t* bases = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.tot_bytes);
-  uint32_t* dir = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.dir_bytes);
-  uint32_t* startT = reinterpret_cast<uint32_t*>(p); p += a256(G * pl.start_bytes);
-  uint16_t* lenT = reinterpret_cast<uint16_t*>(p); p += a256(G * pl.len_bytes);
+  u32x2* bigtmp = reinterpret_cast<u32x2*>(p); p += a256(G * pl.bigtmp_bytes);
   uint32_t* big = reinterpret_cast<uint32_t*>(p); p += a256(static_cast<size_t>(G) * MSD_BIG_WORDS * 4);
   const size_t part_lds = static_cast<size_t>(2 * MSD_TILE + MSD_N1 + MSD_NC + MSD_NB_MAX) * 4;
-  const size_t bucket_lds = static_cast<size_t>(2 * MSD_CAP + MSD_NF / 2 + 32 + MSD_BWORDS) * 4;
-  const size_t gather_lds = static_cast<size_t>(BB * (BB + 1) + pl.nbs + pl.nbs / 2) * 4;
+  const size_t bucket_lds = static_cast<size_t>(2 * MSD_CAP + MSD_NF / 2 + 32) * 4;
+  const size_t gather_lds = static_cast<size_t>(BB * (BB + 1) + 2 * pl.nbs + pl.nbs / 2) * 4;
   const bool vec = ldo % 4 == 0 && mdg_aligned16(out);
-  constexpr struct { int get() const { return 256; } } pwg_sw{};      // persistent partition workgroups of a launch (all outcomes of the group): one per CU
+  constexpr int part_wgs = 256;                            // persistent partition workgroups of a launch (all outcomes of the group): one per CU
   for (int64_t s0 = 0; s0 < n_outcomes; s0 += G) {
     const unsigned g = static_cast<unsigned>(n_outcomes - s0 < G ? n_outcomes - s0 : G);
     const float* sc = scores + s0 * N * lds;
     float* o = out + s0 * N * ldo;
     uint32_t* fl = flags + s0;
     const uint32_t* tb = tables + s0 * MSD_TABLE_WORDS;
-    unsigned pw = static_cast<unsigned>(mdg_cdiv(pwg_sw.get(), g));
-    pw = pw < 1u ? 1u : (pw > static_cast<unsigned>(pl.n_tiles) ? static_cast<unsigned>(pl.n_tiles) : pw);
-    hipLaunchKernelGGL(msd_count_kernel, dim3(static_cast<unsigned>(pl.n_tiles), g), dim3(1024), 0, st, sc, lds, tb, counts, static_cast<int>(N), M, pl.nbs, src_is_keys);
-    hipLaunchKernelGGL(msd_scan_kernel, dim3(static_cast<unsigned>(pl.nbs / 256), g), dim3(256), 0, st, counts, offs, totals, pl.n_tiles, pl.nbs);
+    unsigned pw = static_cast<unsigned>(mdg_cdiv(part_wgs, g));
+    pw = pw < 1u ? 1u : (pw > static_cast<unsigned>(n_blocks) ? static_cast<unsigned>(n_blocks) : pw);
+    hipLaunchKernelGGL(msd_count_kernel, dim3(static_cast<unsigned>(n_blocks), g), dim3(1024), 0, st, sc, lds, tb, counts, static_cast<int>(N), pl.nbs, src_is_keys);
+    hipLaunchKernelGGL(msd_scan_kernel, dim3(static_cast<unsigned>(pl.nbs / 64), g), dim3(1024), 0, st, counts, offs, totals, n_blocks, pl.nbs);
     hipLaunchKernelGGL(msd_base_kernel, dim3(g), dim3(1024), 0, st, totals, bases, fl, big, pl.nbs, M);
-    hipLaunchKernelGGL(msd_partition_kernel, dim3(pw, g), dim3(1024), part_lds, st, sc, lds, tb, offs, bases, part, fl, static_cast<int>(N), M, pl.nbs, pl.n_tiles,
+    hipLaunchKernelGGL(msd_partition_kernel, dim3(pw, g), dim3(1024), part_lds, st, sc, lds, tb, offs, bases, part, fl, static_cast<int>(N), M, pl.nbs, n_blocks,
                        src_is_keys);
-    hipLaunchKernelGGL((msd_bucket_kernel<MSD_NF>), dim3(static_cast<unsigned>(pl.nbt), g), dim3(1024), bucket_lds, st, part, bases, totals, pairs, dir, fl, M,
-                       pl.nbs, n_blocks, pl.dw);
-    hipLaunchKernelGGL(msd_big_bucket_kernel, dim3(MSD_BIG_MAX, g), dim3(1024), 0, st, part, bases, totals, pairs, dir, fl, big, M, pl.nbs, n_blocks, pl.dw);
-    hipLaunchKernelGGL(msd_dir_transpose_kernel, dim3(static_cast<unsigned>(mdg_cdiv(n_blocks, 64)), static_cast<unsigned>(mdg_cdiv(pl.nbt, 64)), g), dim3(256), 0, st,
-                       dir, bases, startT, lenT, fl, pl.nbt, pl.nbs, n_blocks, pl.dw);
+    hipLaunchKernelGGL((msd_bucket_kernel<MSD_NF>), dim3(static_cast<unsigned>(pl.nbt), g), dim3(1024), bucket_lds, st, part, bases, totals, ranked, fl, M, pl.nbs);
+    hipLaunchKernelGGL(msd_big_bucket_kernel, dim3(MSD_BIG_MAX, g), dim3(1024), 0, st, part, bases, totals, ranked, bigtmp, fl, big, M, pl.nbs);
     const dim3 bgrid(static_cast<unsigned>(8 * mdg_cdiv(n_blocks, 8)), g);
-    if (vec) hipLaunchKernelGGL(msd_block_gather_kernel<true>, bgrid, dim3(512), gather_lds, st, pairs, startT, lenT, o, ldo, static_cast<int>(N), M, pl.nbt, pl.nbs,
-                                n_blocks, denom, fl);
-    else hipLaunchKernelGGL(msd_block_gather_kernel<false>, bgrid, dim3(512), gather_lds, st, pairs, startT, lenT, o, ldo, static_cast<int>(N), M, pl.nbt, pl.nbs,
-                            n_blocks, denom, fl);
+    if (vec) hipLaunchKernelGGL(msd_block_gather_kernel<true>, bgrid, dim3(512), gather_lds, st, ranked, offs, counts, bases, o, ldo, static_cast<int>(N), M, pl.nbt,
+                                pl.nbs, n_blocks, denom, fl);
+    else hipLaunchKernelGGL(msd_block_gather_kernel<false>, bgrid, dim3(512), gather_lds, st, ranked, offs, counts, bases, o, ldo, static_cast<int>(N), M, pl.nbt,
+                            pl.nbs, n_blocks, denom, fl);
   }
 }
 

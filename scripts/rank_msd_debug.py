@@ -34,19 +34,19 @@ print("flags", flags[0].tolist())
 ws = max(ops._ws_cache.values(), key=lambda t: t.numel())
 a256 = lambda x: (x + 255) // 256 * 256
 M = N * (N - 1) // 2
-n_tiles = (M + 16383) // 16384
-nbt = (M + 4095) // 4096
+n_tiles = ((N + 127) // 128) * ((N + 127) // 128 + 1) // 2      # a count / partition tile is a 128 x 128 output block
+nbt = (M + 8191) // 8192                             # MSD_QLG = 13
 nbs = (nbt + 255) // 256 * 256
-off = a256(4 * G)
+off = 2 * a256(4 * (G + 1))                          # flags | list of handed-back outcomes
 mm = ws[off:off + 8 * G].view(torch.int32).cpu().numpy().view(np.uint32); off += a256(8 * G)
 hist = ws[off:off + G * (512 + 4096) * 4].view(torch.int32).cpu().numpy().view(np.uint32); off += a256(G * (512 + 4096) * 4)
 tabs = ws[off:off + G * 4624 * 4].view(torch.int32).cpu().numpy().view(np.uint32).reshape(G, 4624); off += a256(G * 4624 * 4)
-off += 2 * a256(G * M * 8)
+off += a256(G * M * 8) + a256(G * M * 4)           # pairs by bucket | rank words
 off += a256(G * n_tiles * nbs * 2)
 off += a256(G * n_tiles * nbs * 4)
 totals_all = ws[off:off + G * nbs * 4].view(torch.int32).cpu().numpy().view(np.uint32).reshape(G, nbs)
 il = np.tril_indices(N, -1)
-for which in range(G):
+for which in range(G if os.environ.get("DBG_MODEL", "1") != "0" else 0):
     v = sub[which].cpu().numpy()[:, :N][il]
     cnt = sim(v, name=f"model[{which}]")
     m = sim.last
@@ -62,28 +62,3 @@ for which in range(G):
           " equal:", np.array_equal(totals[:nbt], cnt))
     d = np.nonzero(totals[:nbt] != cnt)[0]
     print("     differing buckets:", d.size, d[:10], totals[d[:10]], cnt[d[:10]])
-if os.environ.get("DBG_STAMPS"):
-    n_blocks = ((N + 127) // 128) * ((N + 127) // 128 + 1) // 2
-    dw = ((n_blocks + 2) // 2 + 31) // 32 * 32
-    off += a256(G * nbs * 4) * 2                     # totals, bases
-    d = ws[off:off + G * nbs * dw * 4].view(torch.int32).cpu().numpy().view(np.uint32).reshape(G, nbs, dw)[:, :nbt]
-    st = d[:, :, dw - 22:dw - 22 + 20].astype(np.uint64)
-    t = st[:, :, 0::2] | (st[:, :, 1::2] << np.uint64(32))
-    print('raw stamps, outcome 3 bucket 5..7:', t[3, 5:8].tolist())
-    print('raw words:', d[3, 5, dw - 24:].tolist())
-    dt = np.diff(t.astype(np.int64)[:, :, :9], axis=2).reshape(-1, 8)
-    okr = (dt >= 0).all(1) & (dt < 10_000_000).all(1) & (t.reshape(-1, 10)[:, 0] > 0)
-    dt = dt[okr]
-    names = ["load+init", "minmax+2 barriers", "atomics", "scans", "place", "tiefix", "blockplace", "copyout"]
-    print("in-kernel stamps (s_memtime = shader cycles): mean / median per phase over", dt.shape[0], "buckets")
-    for i, nm in enumerate(names):
-        print(f"   {nm:16s} mean {dt[:, i].mean():9.1f}  median {np.median(dt[:, i]):9.1f}  max {dt[:, i].max()}")
-    print("   total mean", dt.sum(1).mean(), " kernel span (max end - min start):", int(t[:, :, 8].max() - t[:, :, 0][t[:, :, 0] > 0].min()))
-    # gather kernel stamps: in the (dead) lenT rows
-    off2 = off + a256(G * nbs * dw * 4) + a256(G * n_blocks * nbs * 4)
-    lt = ws[off2:off2 + G * n_blocks * nbs * 2].view(torch.int64).cpu().numpy().reshape(G, n_blocks, nbs // 4)[:, :, :5]
-    dg = np.diff(lt, axis=2).reshape(-1, 4)
-    okg = (dg >= 0).all(1) & (dg < 10_000_000).all(1)
-    dg = dg[okg]
-    print("gather kernel stamps over", dg.shape[0], "blocks: directory stage, gather loop, barrier wait, write-out")
-    print("   mean", dg.mean(0).round(0).tolist(), " median", np.median(dg, axis=0).tolist(), " total mean", dg.sum(1).mean())
