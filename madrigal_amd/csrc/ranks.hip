@@ -936,14 +936,14 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
   for (; t < n_tiles; t += gridDim.x) {
     const MsdTileGeom g = gnext;
     for (int b = tid; b < MSD_NB_MAX; b += TPB) bcnt[b] = 0;
-    uint32_t key[ITEMS], q[ITEMS], sb[ITEMS];             // sb = slot in the tile's run | bucket << 16
+    uint32_t key[ITEMS], sb[ITEMS];                       // sb = slot in the tile's run | bucket << 16
     uint32_t gcur[BPT];
+    uint32_t okm = 0;
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
       int i, j;
-      const bool ok = g.cell(k, tid, N, i, j);
+      okm |= g.cell(k, tid, N, i, j) ? 1u << k : 0u;
       key[k] = src_is_keys ? __builtin_bit_cast(uint32_t, raw[k]) : mdg_order_key(raw[k]);
-      q[k] = ok ? (static_cast<uint32_t>(i) << 16) | static_cast<uint32_t>(j) : MSD_SKIP;      // (a position is never ~0: j < i)
     }
 #pragma unroll
     for (int e = 0; e < BPT; ++e) gcur[e] = gpos[e];
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
       sb[k] = MSD_SKIP;
-      if (q[k] != MSD_SKIP) {
+      if ((okm >> k) & 1u) {
         const uint32_t b = msd_bucket_of(key[k], tab, tab + MSD_N1, m);
         sb[k] = atomicAdd(&bcnt[b], 1u) | (b << 16);
       }
@@ -976,22 +976,26 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
       }
     }
     __syncthreads();
+    // in LDS a pair is (key, bucket << 14 | cell of the tile): the copy-out neither re-derives the bucket from the key (two table reads
+    // and ~25 instructions per key) nor did the position have to stay in registers
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k)
-      if (sb[k] != MSD_SKIP) spair[bcnt[sb[k] >> 16] + (sb[k] & 0xFFFFu)] = u32x2{key[k], q[k]};
+      if (sb[k] != MSD_SKIP) spair[bcnt[sb[k] >> 16] + (sb[k] & 0xFFFFu)] = u32x2{key[k], ((sb[k] >> 16) << 14) | static_cast<uint32_t>(k * TPB + tid)};
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < BPT; ++e) bcnt[BPT * tid + e] = gcur[e] - st[e];       // (position in the bucket) - (position in LDS)
     __syncthreads();
-    // (copy-out by sixteen lanes per run from the bucket tables, instead of re-deriving every pair's bucket from its key, was measured:
-    // 177 against 175 us per outcome -- the idle lanes of short runs cost more than the two table reads)
+    // (copy-out by sixteen lanes per run from the bucket tables was measured: 177 against 175 us per outcome -- the idle lanes of short
+    // runs cost more than they save)
     const int n_valid = g.keys(N);
+    const uint32_t qbase = (static_cast<uint32_t>(g.r0) << 16) | static_cast<uint32_t>(g.c0);
 #pragma unroll 4
     for (int k = 0; k < ITEMS; ++k) {
       const int idx = k * TPB + tid;
       if (idx >= n_valid) break;
       const u32x2 v = spair[idx];
-      dst[bcnt[msd_bucket_of(v[0], tab, tab + MSD_N1, m)] + static_cast<uint32_t>(idx)] = v;
+      const uint32_t cellw = v[1] & 16383u;
+      dst[bcnt[v[1] >> 14] + static_cast<uint32_t>(idx)] = u32x2{v[0], qbase + ((cellw >> 7) << 16) + (cellw & 127u)};
     }
     __syncthreads();                                       // spair / bcnt are read: the next tile may overwrite them
   }
@@ -1050,7 +1054,7 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
                                                            uint32_t* __restrict__ flags, int64_t M, int nbs) {
   constexpr int TPB = 1024, CAP = MSD_CAP, ITEMS = CAP / TPB, WPT = NF / 2 / TPB, WAVES = TPB / 64;     // NF fine bins, two u16 counters per word
   constexpr int LGNF = 31 - __builtin_clz(NF);
-  static_assert(CAP % TPB == 0 && (NF & (NF - 1)) == 0 && NF % (2 * TPB) == 0 && CAP <= 16384, "bucket sort shape");
+  static_assert(CAP % TPB == 0 && (NF & (NF - 1)) == 0 && NF % (2 * TPB) == 0 && CAP <= 16384 && NF <= 65536, "bucket sort shape");
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];       // sorted[CAP] (u32x2) | fc[NF / 2 + 32]
   __shared__ __attribute__((aligned(16))) uint32_t wsum_f[WAVES];
   __shared__ uint32_t krange[2];
@@ -1109,7 +1113,7 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
     if (k * TPB + tid < n) {
       const uint32_t fi = fine_of(key[k], q[k]);
       const uint32_t fh = 16u * (fi & 1u);
-      ss[k] = (atomicAdd(&fc[fi >> 1], 1u << fh) >> fh) & 0xFFFFu;
+      ss[k] = ((atomicAdd(&fc[fi >> 1], 1u << fh) >> fh) & 0xFFFFu) | (fi << 16);      // slot in the bin | bin
     }
     if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // four items' atomics in flight at a time (all of them at once spilled registers)
   }
@@ -1148,18 +1152,16 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
   __syncthreads();
   // Where the key's fine bin starts and how many keys it holds: both bounds from one two-word read (the bins' starts are u16 pairs).  A
   // key ALONE in its bin -- six of ten -- is in place by that alone (rank = bin start): it is neither written to `sorted` nor probed.
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) asm volatile("" : "+v"(key[k]));      // recompute the fine bin per phase instead of keeping 12 more registers live (they spilled)
   uint32_t sc[ITEMS];                                      // bin start | keys in the bin << 16
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     sc[k] = 0u;
     if (k * TPB + tid < n) {
-      const uint32_t fi = fine_of(key[k], q[k]);
+      const uint32_t fi = ss[k] >> 16;
       const uint32_t w0 = fc[fi >> 1], w1 = fc[(fi >> 1) + 1];
       const uint32_t s0 = (fi & 1u) ? (w0 >> 16) : (w0 & 0xFFFFu), s1 = (fi & 1u) ? (w1 & 0xFFFFu) : (w0 >> 16);
       sc[k] = s0 | ((s1 - s0) << 16);
-      if (s1 - s0 > 1u) sorted[s0 + ss[k]] = u32x2{key[k], q[k]};
+      if (s1 - s0 > 1u) sorted[s0 + (ss[k] & 0xFFFFu)] = u32x2{key[k], q[k]};
     }
   }
   __syncthreads();

@@ -27,7 +27,7 @@ alg = (M * 4.0 + N * N * 4.0) * L
 handed = int(sum(int((f != 0).sum()) for f in flags)) if flags else None
 if handed:
     print("reasons (1 = bucket beyond its LDS room, 2 = key count, 8 = block shard full):", sorted(set(int(v) for f in flags for v in f.tolist() if v)))
-print(f"HIP (MSD={os.environ.get('MDG_RANKS_MSD', '0 (LSD)')} group={os.environ.get('MDG_RANKS_GROUP', 'default')}): {L} outcomes x {N}x{N}: {best:.2f} ms = "
+print(f"HIP (MSD={os.environ.get('MDG_RANKS_MSD', '1 (default)')} group={os.environ.get('MDG_RANKS_GROUP', 'default')}): {L} outcomes x {N}x{N}: {best:.2f} ms = "
       f"{best / L * 1e3:.1f} us per outcome, {L * N * N / best / 1e6:.2f} G scores/s, {alg / best / 1e9:.3f} TB/s of algorithmic bytes "
       f"({alg / best / 1e9 / 8.0:.3f} of 8 TB/s); outcomes handed to the LSD sort: {handed}")
 if "--no-oracle" in sys.argv or os.environ.get("MDG_AB_LIB"):
