@@ -1043,15 +1043,16 @@ struct MsdFine {
   }
 };
 
-// One bucket per workgroup: the rank of every key inside the bucket, written at the key's own place in the bucket's range as one word
-// -- (rank in the bucket) << 14 | (row in the output block) << 7 | (column in the output block).  The bucket's range is already in
-// runs by output block (see MsdTileGeom), so nothing is regrouped and there are no global atomics.
+// One bucket at a time per workgroup (persistent: workgroup x of outcome y takes buckets x, x + gridDim.x, ... with the next bucket's
+// pairs in flight in registers): the rank of every key inside the bucket, written at the key's own place in the bucket's range as one
+// word -- (rank in the bucket) << 14 | (row in the output block) << 7 | (column in the output block).  The bucket's range is already
+// in runs by output block (see MsdTileGeom), so nothing is regrouped and there are no global atomics.
 // One returning LDS atomic per key (its slot in its fine bin); items behind the bucket's last key take none (thousands of lanes on one
 // dummy counter serialise).
 template <int NF>
 __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __restrict__ part, const uint32_t* __restrict__ bases,
                                                            const uint32_t* __restrict__ totals, uint32_t* __restrict__ ranked,
-                                                           uint32_t* __restrict__ flags, int64_t M, int nbs) {
+                                                           uint32_t* __restrict__ flags, int64_t M, int nbs, int nbt) {
   constexpr int TPB = 1024, CAP = MSD_CAP, ITEMS = CAP / TPB, WPT = NF / 2 / TPB, WAVES = TPB / 64;     // NF fine bins, two u16 counters per word
   constexpr int LGNF = 31 - __builtin_clz(NF);
   static_assert(CAP % TPB == 0 && (NF & (NF - 1)) == 0 && NF % (2 * TPB) == 0 && CAP <= 16384 && NF <= 65536, "bucket sort shape");
@@ -1060,31 +1061,45 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
   __shared__ uint32_t krange[2];
   __shared__ unsigned long long ksum_sh;
   const int64_t seg = blockIdx.y;
-  const int b = blockIdx.x;
   if (flags[seg]) return;
-  const int n = static_cast<int>(totals[seg * nbs + b]);
-  if (n > CAP) return;                                     // msd_big_bucket_kernel's
-  const uint32_t rb = bases[seg * nbs + b];
   u32x2* sorted = reinterpret_cast<u32x2*>(dyn);
   uint32_t* fc = dyn + 2 * CAP;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  uint32_t key[ITEMS], q[ITEMS], ss[ITEMS];
-  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-  {
-    const u32x2* src = part + seg * M + rb;
+  // the next bucket's pairs are in flight (registers) while this one is sorted
+  uint32_t nkey[ITEMS], nq[ITEMS];
+  int nn = 0;
+  uint32_t nrb = 0;
+  const auto fetch = [&](int bb) {
+    nn = bb < nbt ? static_cast<int>(totals[seg * nbs + bb]) : 0;
+    if (nn > CAP) nn = 0;                                  // msd_big_bucket_kernel's
+    nrb = bb < nbt ? bases[seg * nbs + bb] : 0u;
+    const u32x2* src = part + seg * M + nrb;
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
       const int idx = k * TPB + tid;
       u32x2 v = u32x2{0xFFFFFFFFu, 0u};
-      if (idx < n) v = src[idx];
-      key[k] = v[0];
-      q[k] = v[1];
+      if (idx < nn) v = src[idx];
+      nkey[k] = v[0];
+      nq[k] = v[1];
     }
-  }
-  static_assert(WPT % 4 == 0, "16-byte accesses cover the fine counters");
+  };
+  fetch(static_cast<int>(blockIdx.x));
+  bool too_many = false;
+  for (int b = blockIdx.x; b < nbt; b += gridDim.x) {
+  const int n = nn;
+  const uint32_t rb = nrb;
+  uint32_t key[ITEMS], q[ITEMS], ss[ITEMS];
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
-  for (int v4 = 0; v4 < WPT / 4; ++v4) reinterpret_cast<u32x4*>(fc)[tid * (WPT / 4) + v4] = u32x4{0u, 0u, 0u, 0u};
-  if (tid < 8) reinterpret_cast<u32x4*>(fc + NF / 2)[tid] = u32x4{0u, 0u, 0u, 0u};
+  for (int k = 0; k < ITEMS; ++k) { key[k] = nkey[k]; q[k] = nq[k]; }
+  fetch(b + static_cast<int>(gridDim.x));
+  static_assert(WPT % 4 == 0, "16-byte accesses cover the fine counters");
+  uint32_t z0 = 0u;
+  asm volatile("" : "+v"(z0));                           // (a zero made here: hoisted out of the bucket loop it was spilled and reloaded)
+  const u32x4 zero4{z0, z0, z0, z0};
+#pragma unroll
+  for (int v4 = 0; v4 < WPT / 4; ++v4) reinterpret_cast<u32x4*>(fc)[tid * (WPT / 4) + v4] = zero4;
+  if (tid < 8) reinterpret_cast<u32x4*>(fc + NF / 2)[tid] = zero4;
   if (tid == 0) { krange[0] = 0xFFFFFFFFu; krange[1] = 0u; ksum_sh = 0ull; }
   unsigned long long ksum = 0ull;
 #pragma unroll
@@ -1095,7 +1110,9 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
     ksum += ok ? key[k] : 0u;
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
+  for (int o_ = 32; o_ > 0; o_ >>= 1) {
+    int o = o_;
+    asm volatile("" : "+s"(o));                          // (the shuffles' lane addresses are rebuilt here, not carried in registers across the bucket loop)
     const uint32_t a = __shfl_xor(kmin, o, 64), c = __shfl_xor(kmax, o, 64);
     kmin = kmin < a ? kmin : a;
     kmax = kmax > c ? kmax : c;
@@ -1128,7 +1145,14 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
     uint32_t tot = 0;
 #pragma unroll
     for (int e = 0; e < WPT; ++e) tot += (w[e] & 0xFFFFu) + (w[e] >> 16);
-    const uint32_t inc = wave_inclusive(tot, lane);
+    uint32_t inc = tot;
+#pragma unroll
+    for (int o_ = 1; o_ < 64; o_ <<= 1) {
+      int o = o_;
+      asm volatile("" : "+s"(o));
+      const uint32_t u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
+    }
     if (lane == 63) wsum_f[wave] = inc;
     __syncthreads();
     uint32_t run = inc - tot;
@@ -1161,51 +1185,51 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
       const uint32_t w0 = fc[fi >> 1], w1 = fc[(fi >> 1) + 1];
       const uint32_t s0 = (fi & 1u) ? (w0 >> 16) : (w0 & 0xFFFFu), s1 = (fi & 1u) ? (w1 & 0xFFFFu) : (w0 >> 16);
       sc[k] = s0 | ((s1 - s0) << 16);
-      if (s1 - s0 > 1u) sorted[s0 + (ss[k] & 0xFFFFu)] = u32x2{key[k], q[k]};
+      if (s1 - s0 > 1u) sorted[s0 + (ss[k] & 0xFFFFu)] = u32x2{q[k], key[k]};
     }
   }
   __syncthreads();
-  // keys that share a fine bin: their order is (key, position).  Six bin-mates are probed with predicated, independent LDS reads (a bin
-  // holds ~half a key: one key in 10^4 has more and walks on)
-  bool too_many = false;
-  constexpr int PROBES = 6, GRP = 2;
+  // keys that share a fine bin: their order is (key, position) -- one 64-bit compare per bin-mate (`sorted` holds position | key << 32).
+  // Four bin-mates are probed with predicated, independent LDS reads (a bin holds ~half a key: two keys in a thousand have more and walk on)
+  constexpr int PROBES = 4, GRP = 3;
   static_assert(ITEMS % GRP == 0, "tie-fix groups");
+  const unsigned long long* sorted64 = reinterpret_cast<const unsigned long long*>(sorted);
   uint32_t* dst = ranked + seg * M + rb;
 #pragma unroll
-  for (int k0 = 0; k0 < ITEMS; k0 += GRP) {                // two items at a time: 12 probes in flight
-    u32x2 o[GRP][PROBES];
+  for (int k0 = 0; k0 < ITEMS; k0 += GRP) {                // three items at a time: 12 probes in flight
+    unsigned long long o[GRP][PROBES];
 #pragma unroll
     for (int e = 0; e < GRP; ++e) {
-      const uint32_t s0 = sc[k0 + e] & 0xFFFFu, c = sc[k0 + e] >> 16;
+      const uint32_t s0 = sc[k0 + e] & 0xFFFFu, c = sc[k0 + e] >> 16, c1 = c > 1u ? c : 0u;
 #pragma unroll
       for (int mth = 0; mth < PROBES; ++mth) {
-        o[e][mth] = u32x2{0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (c > 1u && static_cast<uint32_t>(mth) < c) o[e][mth] = sorted[s0 + mth];
+        o[e][mth] = ~0ull;
+        if (static_cast<uint32_t>(mth) < c1) o[e][mth] = sorted64[s0 + mth];
       }
     }
 #pragma unroll
     for (int e = 0; e < GRP; ++e) {
       const int k = k0 + e;
       const uint32_t s0 = sc[k] & 0xFFFFu, c = sc[k] >> 16;
+      const unsigned long long me = (static_cast<unsigned long long>(key[k]) << 32) | q[k];
       uint32_t r = 0;
 #pragma unroll
-      for (int mth = 0; mth < PROBES; ++mth)
-        r += (o[e][mth][0] < key[k] || (o[e][mth][0] == key[k] && o[e][mth][1] < q[k])) ? 1u : 0u;
+      for (int mth = 0; mth < PROBES; ++mth) r += o[e][mth] < me ? 1u : 0u;
       if (c > static_cast<uint32_t>(PROBES)) {
         if (c > static_cast<uint32_t>(MSD_TIE_LIMIT)) too_many = true;
         else
-          for (uint32_t mth = PROBES; mth < c; ++mth) {
-            const u32x2 x = sorted[s0 + mth];
-            r += (x[0] < key[k] || (x[0] == key[k] && x[1] < q[k])) ? 1u : 0u;
-          }
+          for (uint32_t mth = PROBES; mth < c; ++mth) r += sorted64[s0 + mth] < me ? 1u : 0u;
       }
       const int idx = k * TPB + tid;
       if (idx < n) dst[idx] = ((s0 + r) << 14) | (((q[k] >> 16) & 127u) << 7) | (q[k] & 127u);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  __syncthreads();                                       // `sorted` and the counters are read: the next bucket may overwrite them
+  }
   if (too_many) atomicOr(&flags[seg], MSD_F_TIES);
 }
+
 
 // A bucket beyond the LDS room of msd_bucket_kernel (fewer than 65 536 keys; the bucket function's sub-ranges assume a density that is
 // flat inside a level-2 bin, which a sparse region at the edge of a score distribution is not): the same counting sort and the same
@@ -1660,7 +1684,9 @@ static void msd_run(const MsdPlan& pl, const float* scores, int64_t lds, float* 
     hipLaunchKernelGGL(msd_base_kernel, dim3(g), dim3(1024), 0, st, totals, bases, fl, big, pl.nbs, M);
     hipLaunchKernelGGL(msd_partition_kernel, dim3(pw, g), dim3(1024), part_lds, st, sc, lds, tb, offs, bases, part, fl, static_cast<int>(N), M, pl.nbs, n_blocks,
                        src_is_keys);
-    hipLaunchKernelGGL((msd_bucket_kernel<MSD_NF>), dim3(static_cast<unsigned>(pl.nbt), g), dim3(1024), bucket_lds, st, part, bases, totals, ranked, fl, M, pl.nbs);
+    unsigned bw = static_cast<unsigned>(mdg_cdiv(part_wgs, g));       // persistent, like the partition
+    bw = bw < 1u ? 1u : (bw > static_cast<unsigned>(pl.nbt) ? static_cast<unsigned>(pl.nbt) : bw);
+    hipLaunchKernelGGL((msd_bucket_kernel<MSD_NF>), dim3(bw, g), dim3(1024), bucket_lds, st, part, bases, totals, ranked, fl, M, pl.nbs, pl.nbt);
     hipLaunchKernelGGL(msd_big_bucket_kernel, dim3(MSD_BIG_MAX, g), dim3(1024), 0, st, part, bases, totals, ranked, bigtmp, fl, big, M, pl.nbs);
     const dim3 bgrid(static_cast<unsigned>(8 * mdg_cdiv(n_blocks, 8)), g);
     if (vec) hipLaunchKernelGGL(msd_block_gather_kernel<true>, bgrid, dim3(512), gather_lds, st, ranked, offs, counts, bases, o, ldo, static_cast<int>(N), M, pl.nbt,
