@@ -892,13 +892,26 @@ __global__ __launch_bounds__(1024) void msd_base_kernel(const uint32_t* __restri
   if (tid == 0) big[seg * MSD_BIG_WORDS] = nbig < static_cast<uint32_t>(MSD_BIG_MAX) ? nbig : static_cast<uint32_t>(MSD_BIG_MAX);
 }
 
+// -DMDG_RANK_STAMPS (MDG_EXTRA_HIPCC_FLAGS): shader-clock stamps at the phase boundaries of the two persistent kernels, summed per phase
+// over a workgroup's tiles / buckets and left in the (otherwise idle) big-bucket scratch; scripts/rank_msd_debug.py reads them
+#ifdef MDG_RANK_STAMPS
+#define MDG_ST_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0
+#define MDG_ST(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if ((i) > 0) st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
+#define MDG_ST_OUT(ptr) do { if (threadIdx.x == 0) for (int e_ = 0; e_ < 8; ++e_) (ptr)[e_] = st_acc[e_]; } while (0)
+#else
+#define MDG_ST_DECL
+#define MDG_ST(i)
+#define MDG_ST_OUT(ptr)
+#endif
+
 // Persistent: workgroup x of outcome y takes tiles x, x + gridDim.x, ...; the next tile's scores are in flight (registers) while
 // this one is bucketed.  part[outcome * M + base[b] + offs[tile][b] + .]
 __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __restrict__ scores, int64_t lds, const uint32_t* __restrict__ tables,
                                                             const uint32_t* __restrict__ offs, const uint32_t* __restrict__ bases,
                                                             u32x2* __restrict__ part, const uint32_t* __restrict__ flags, int N, int64_t M, int nbs,
-                                                            int n_tiles, int src_is_keys) {
+                                                            int n_tiles, int src_is_keys, unsigned long long* stamps) {
   constexpr int TPB = 1024, ITEMS = 16, BPT = MSD_NB_MAX / TPB;
+  MDG_ST_DECL;
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];       // spair[MSD_TILE] (u32x2) | tab[MSD_N1 + MSD_NC] | bcnt[MSD_NB_MAX]
   __shared__ uint32_t wsum[16];
   const int64_t seg = blockIdx.y;
@@ -935,6 +948,7 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
   if (t < n_tiles) { load_tile(t); load_offsets(t); }
   for (; t < n_tiles; t += gridDim.x) {
     const MsdTileGeom g = gnext;
+    MDG_ST(0);
     for (int b = tid; b < MSD_NB_MAX; b += TPB) bcnt[b] = 0;
     uint32_t key[ITEMS], sb[ITEMS];                       // sb = slot in the tile's run | bucket << 16
     uint32_t gcur[BPT];
@@ -949,6 +963,7 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
     for (int e = 0; e < BPT; ++e) gcur[e] = gpos[e];
     if (t + static_cast<int>(gridDim.x) < n_tiles) { load_tile(t + gridDim.x); load_offsets(t + gridDim.x); }
     __syncthreads();                                       // bcnt zeroed, tab loaded (and the previous tile's copy-out done with them)
+    MDG_ST(1);
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
       sb[k] = MSD_SKIP;
@@ -957,7 +972,9 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
         sb[k] = atomicAdd(&bcnt[b], 1u) | (b << 16);
       }
     }
+    MDG_ST(2);
     __syncthreads();
+    MDG_ST(3);
     uint32_t c4[BPT], st[BPT];                             // exclusive scan of the bucket counts, BPT per thread
     {
       uint32_t tot = 0;
@@ -976,6 +993,7 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
       }
     }
     __syncthreads();
+    MDG_ST(4);
     // in LDS a pair is (key, bucket << 14 | cell of the tile): the copy-out neither re-derives the bucket from the key (two table reads
     // and ~25 instructions per key) nor did the position have to stay in registers
 #pragma unroll
@@ -985,6 +1003,7 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
 #pragma unroll
     for (int e = 0; e < BPT; ++e) bcnt[BPT * tid + e] = gcur[e] - st[e];       // (position in the bucket) - (position in LDS)
     __syncthreads();
+    MDG_ST(5);
     // (copy-out by sixteen lanes per run from the bucket tables was measured: 177 against 175 us per outcome -- the idle lanes of short
     // runs cost more than they save)
     const int n_valid = g.keys(N);
@@ -997,8 +1016,11 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
       const uint32_t cellw = v[1] & 16383u;
       dst[bcnt[v[1] >> 14] + static_cast<uint32_t>(idx)] = u32x2{v[0], qbase + ((cellw >> 7) << 16) + (cellw & 127u)};
     }
+    MDG_ST(6);
     __syncthreads();                                       // spair / bcnt are read: the next tile may overwrite them
+    MDG_ST(7);
   }
+  MDG_ST_OUT(stamps + (blockIdx.y * gridDim.x + blockIdx.x) * 8);
 }
 
 // Fine bins of the bucket sorts: on the COMPOSITE (u(key) - u(lo), position).  u is the key itself -- linear in the score inside a binade,
@@ -1014,6 +1036,7 @@ struct MsdFine {
   int e, sh;
   uint32_t umin;
   bool fixed;
+  bool wide;                 // sh >= 26: the position bits are shifted out, the bin is (u - umin) >> (sh - 26)
   __device__ __forceinline__ static float score_of(uint32_t key) {
     const uint32_t kc = key < 0x00800000u ? 0x00800000u : (key > 0xFF7FFFFFu ? 0xFF7FFFFFu : key);      // -FLT_MAX .. FLT_MAX: infinities and NaNs saturate
     return __builtin_bit_cast(float, (kc & 0x80000000u) ? (kc & 0x7FFFFFFFu) : ~kc);
@@ -1036,10 +1059,18 @@ struct MsdFine {
     const uint64_t span = (static_cast<uint64_t>(u_of(kmax) - umin) << 26) | 0x3FFFFFFull;
     const int bits = 64 - __builtin_clzll(span);
     sh = bits > lgnf ? bits - lgnf : 0;                    // (span >> sh) < number of fine bins
+    // the same in every lane: into scalar registers (the bin function's branches are then scalar ones)
+    e = __builtin_amdgcn_readfirstlane(e);
+    sh = __builtin_amdgcn_readfirstlane(sh);
+    umin = __builtin_amdgcn_readfirstlane(umin);
+    fixed = __builtin_amdgcn_readfirstlane(fixed ? 1 : 0) != 0;
+    wide = sh >= 26;
   }
+  // ((u - umin) << 26 | position) >> sh in 32-bit pieces (sh < 26 only when u - umin has fewer than 14 bits: the shifted difference fits)
   __device__ __forceinline__ uint32_t operator()(uint32_t key, uint32_t qq) const {
-    const uint64_t c = (static_cast<uint64_t>(u_of(key) - umin) << 26) | (((qq >> 16) << 13) | (qq & 0x1FFFu));
-    return static_cast<uint32_t>(c >> sh);
+    const uint32_t d = u_of(key) - umin;
+    if (wide) return d >> (sh - 26);
+    return (d << (26 - sh)) | ((((qq >> 16) << 13) | (qq & 0x1FFFu)) >> sh);
   }
 };
 
@@ -1049,22 +1080,48 @@ struct MsdFine {
 // in runs by output block (see MsdTileGeom), so nothing is regrouped and there are no global atomics.
 // One returning LDS atomic per key (its slot in its fine bin); items behind the bucket's last key take none (thousands of lanes on one
 // dummy counter serialise).
+// wave64 inclusive scan / reduction in registers (DPP row shifts and row broadcasts: no trip through the LDS crossbar, which a
+// __shfl step is -- six dependent ones cost more than the phase they sat in).  `ident` is op's identity.
+#define MDG_DPP(old, v, ctrl, rows) static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(old), static_cast<int>(v), ctrl, rows, 0xf, false))
+template <class Op>
+__device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t v, uint32_t ident, Op op) {
+  v = op(v, MDG_DPP(ident, v, 0x111, 0xf));                // row_shr:1, :2, :4, :8 -- inclusive within each row of 16 lanes
+  v = op(v, MDG_DPP(ident, v, 0x112, 0xf));
+  v = op(v, MDG_DPP(ident, v, 0x114, 0xf));
+  v = op(v, MDG_DPP(ident, v, 0x118, 0xf));
+  v = op(v, MDG_DPP(ident, v, 0x142, 0xa));                // row_bcast:15 into rows 1 and 3
+  v = op(v, MDG_DPP(ident, v, 0x143, 0xc));                // row_bcast:31 into rows 2 and 3
+  return v;
+}
+template <class Op>
+__device__ __forceinline__ uint32_t wave_reduce_dpp(uint32_t v, uint32_t ident, Op op) {
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_scan_dpp(v, ident, op)), 63));
+}
+
 template <int NF>
 __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __restrict__ part, const uint32_t* __restrict__ bases,
                                                            const uint32_t* __restrict__ totals, uint32_t* __restrict__ ranked,
-                                                           uint32_t* __restrict__ flags, int64_t M, int nbs, int nbt) {
+                                                           uint32_t* __restrict__ flags, int64_t M, int nbs, int nbt, unsigned long long* stamps) {
+  MDG_ST_DECL;
   constexpr int TPB = 1024, CAP = MSD_CAP, ITEMS = CAP / TPB, WPT = NF / 2 / TPB, WAVES = TPB / 64;     // NF fine bins, two u16 counters per word
   constexpr int LGNF = 31 - __builtin_clz(NF);
   static_assert(CAP % TPB == 0 && (NF & (NF - 1)) == 0 && NF % (2 * TPB) == 0 && CAP <= 16384 && NF <= 65536, "bucket sort shape");
+  static_assert(WPT % 4 == 0, "16-byte accesses cover the fine counters");
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];       // sorted[CAP] (u32x2) | fc[NF / 2 + 32]
   __shared__ __attribute__((aligned(16))) uint32_t wsum_f[WAVES];
-  __shared__ uint32_t krange[2];
-  __shared__ unsigned long long ksum_sh;
+  // smallest key | largest key | sum of key >> 14 (below 2^32 for 12 288 keys: the mean key to 2^14, which is all MsdFine::init asks
+  // of it) of a bucket, double-buffered: the NEXT bucket's are gathered at the end of this bucket's last phase (its pairs have
+  // arrived by then) and are behind the closing barrier, so a bucket starts without a reduction and its two barriers
+  __shared__ uint32_t kstat[2][4];
   const int64_t seg = blockIdx.y;
   if (flags[seg]) return;
   u32x2* sorted = reinterpret_cast<u32x2*>(dyn);
   uint32_t* fc = dyn + 2 * CAP;
+  const uint16_t* fc16 = reinterpret_cast<const uint16_t*>(fc);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const auto umin_op = [](uint32_t x, uint32_t y) { return x < y ? x : y; };
+  const auto umax_op = [](uint32_t x, uint32_t y) { return x > y ? x : y; };
+  const auto add_op = [](uint32_t x, uint32_t y) { return x + y; };
   // the next bucket's pairs are in flight (registers) while this one is sorted
   uint32_t nkey[ITEMS], nq[ITEMS];
   int nn = 0;
@@ -1083,153 +1140,159 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
       nq[k] = v[1];
     }
   };
+  const auto zero_counters = [&]() {
+    uint32_t z0 = 0u;
+    asm volatile("" : "+v"(z0));                           // (a zero made here: hoisted out of the bucket loop it was spilled and reloaded)
+    const u32x4 zero4{z0, z0, z0, z0};
+#pragma unroll
+    for (int v4 = 0; v4 < WPT / 4; ++v4) reinterpret_cast<u32x4*>(fc)[tid * (WPT / 4) + v4] = zero4;
+    if (tid < 8) reinterpret_cast<u32x4*>(fc + NF / 2)[tid] = zero4;
+  };
+  // extremes and key sum of the pairs in nkey (the absent items' keys are ~0), published to kstat[slot]
+  const auto publish_stats = [&](int slot) {
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u, ksum = 0u;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const bool ok = k * TPB + tid < nn;
+      kmin = kmin < nkey[k] ? kmin : nkey[k];
+      kmax = (ok && nkey[k] > kmax) ? nkey[k] : kmax;
+      ksum += ok ? nkey[k] >> 14 : 0u;
+    }
+    kmin = wave_reduce_dpp(kmin, 0xFFFFFFFFu, umin_op);
+    kmax = wave_reduce_dpp(kmax, 0u, umax_op);
+    ksum = wave_reduce_dpp(ksum, 0u, add_op);
+    if (lane == 0 && kmin <= kmax) { atomicMin(&kstat[slot][0], kmin); atomicMax(&kstat[slot][1], kmax); atomicAdd(&kstat[slot][2], ksum); }
+  };
   fetch(static_cast<int>(blockIdx.x));
+  zero_counters();
+  if (tid < 2) { kstat[tid][0] = 0xFFFFFFFFu; kstat[tid][1] = 0u; kstat[tid][2] = 0u; }
+  __syncthreads();
+  publish_stats(0);
+  __syncthreads();
   bool too_many = false;
-  for (int b = blockIdx.x; b < nbt; b += gridDim.x) {
-  const int n = nn;
-  const uint32_t rb = nrb;
-  uint32_t key[ITEMS], q[ITEMS], ss[ITEMS];
-  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+  int par = 0;
+  for (int b = blockIdx.x; b < nbt; b += gridDim.x, par ^= 1) {
+    const int n = nn;
+    const uint32_t rb = nrb;
+    uint32_t key[ITEMS], q[ITEMS], ss[ITEMS];
 #pragma unroll
-  for (int k = 0; k < ITEMS; ++k) { key[k] = nkey[k]; q[k] = nq[k]; }
-  fetch(b + static_cast<int>(gridDim.x));
-  static_assert(WPT % 4 == 0, "16-byte accesses cover the fine counters");
-  uint32_t z0 = 0u;
-  asm volatile("" : "+v"(z0));                           // (a zero made here: hoisted out of the bucket loop it was spilled and reloaded)
-  const u32x4 zero4{z0, z0, z0, z0};
-#pragma unroll
-  for (int v4 = 0; v4 < WPT / 4; ++v4) reinterpret_cast<u32x4*>(fc)[tid * (WPT / 4) + v4] = zero4;
-  if (tid < 8) reinterpret_cast<u32x4*>(fc + NF / 2)[tid] = zero4;
-  if (tid == 0) { krange[0] = 0xFFFFFFFFu; krange[1] = 0u; ksum_sh = 0ull; }
-  unsigned long long ksum = 0ull;
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) {
-    const bool ok = k * TPB + tid < n;
-    kmin = kmin < key[k] ? kmin : key[k];                 // (an absent item's key is ~0)
-    kmax = (ok && key[k] > kmax) ? key[k] : kmax;
-    ksum += ok ? key[k] : 0u;
-  }
-#pragma unroll
-  for (int o_ = 32; o_ > 0; o_ >>= 1) {
-    int o = o_;
-    asm volatile("" : "+s"(o));                          // (the shuffles' lane addresses are rebuilt here, not carried in registers across the bucket loop)
-    const uint32_t a = __shfl_xor(kmin, o, 64), c = __shfl_xor(kmax, o, 64);
-    kmin = kmin < a ? kmin : a;
-    kmax = kmax > c ? kmax : c;
-    ksum += __shfl_xor(ksum, o, 64);
-  }
-  __syncthreads();
-  if (lane == 0 && kmin <= kmax) { atomicMin(&krange[0], kmin); atomicMax(&krange[1], kmax); atomicAdd(&ksum_sh, ksum); }
-  __syncthreads();
-  MsdFine fine_of;
-  fine_of.init(krange[0], krange[1], n > 0 ? static_cast<float>(static_cast<double>(ksum_sh) / n) : 0.f, LGNF);
-  // ---- the key's slot in its fine bin
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) {
-    ss[k] = 0u;
-    if (k * TPB + tid < n) {
-      const uint32_t fi = fine_of(key[k], q[k]);
-      const uint32_t fh = 16u * (fi & 1u);
-      ss[k] = ((atomicAdd(&fc[fi >> 1], 1u << fh) >> fh) & 0xFFFFu) | (fi << 16);      // slot in the bin | bin
+    for (int k = 0; k < ITEMS; ++k) { key[k] = nkey[k]; q[k] = nq[k]; }
+    fetch(b + static_cast<int>(gridDim.x));
+    MDG_ST(0);
+    MsdFine fine_of;
+    {
+      const uint32_t lo = kstat[par][0], hi = kstat[par][1], sm = kstat[par][2];
+      fine_of.init(lo <= hi ? lo : 0u, lo <= hi ? hi : 0u, n > 0 ? static_cast<float>(sm) / static_cast<float>(n) * 16384.f : 0.f, LGNF);
     }
-    if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // four items' atomics in flight at a time (all of them at once spilled registers)
-  }
-  __syncthreads();
-  {   // exclusive scan of the fine bins in place (four words per thread)
-    uint32_t w[WPT];
+    if (tid == 0) { kstat[par ^ 1][0] = 0xFFFFFFFFu; kstat[par ^ 1][1] = 0u; kstat[par ^ 1][2] = 0u; }      // (last read a bucket ago; published into four barriers from here)
+    MDG_ST(1);
+    // ---- the key's slot in its fine bin (the counters were zeroed in the previous bucket's last phase)
 #pragma unroll
-    for (int v4 = 0; v4 < WPT / 4; ++v4) {
-      const u32x4 t4 = reinterpret_cast<const u32x4*>(fc)[tid * (WPT / 4) + v4];
-      w[4 * v4] = t4[0]; w[4 * v4 + 1] = t4[1]; w[4 * v4 + 2] = t4[2]; w[4 * v4 + 3] = t4[3];
+    for (int k = 0; k < ITEMS; ++k) {
+      ss[k] = 0u;
+      if (k * TPB + tid < n) {
+        const uint32_t fi = fine_of(key[k], q[k]);
+        const uint32_t fh = 16u * (fi & 1u);
+        ss[k] = ((atomicAdd(&fc[fi >> 1], 1u << fh) >> fh) & 0xFFFFu) | (fi << 16);      // slot in the bin | bin
+      }
+      if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);    // four items' atomics in flight at a time (all of them at once spilled registers)
     }
-    uint32_t tot = 0;
-#pragma unroll
-    for (int e = 0; e < WPT; ++e) tot += (w[e] & 0xFFFFu) + (w[e] >> 16);
-    uint32_t inc = tot;
-#pragma unroll
-    for (int o_ = 1; o_ < 64; o_ <<= 1) {
-      int o = o_;
-      asm volatile("" : "+s"(o));
-      const uint32_t u = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += u;
-    }
-    if (lane == 63) wsum_f[wave] = inc;
+    MDG_ST(2);
     __syncthreads();
-    uint32_t run = inc - tot;
+    MDG_ST(3);
+    {   // exclusive scan of the fine bins in place (four words per thread)
+      uint32_t w[WPT];
 #pragma unroll
-    for (int v4 = 0; v4 < WAVES / 4; ++v4) {                // every wave total, four per LDS read (the same addresses in every lane: broadcast)
-      const u32x4 f4 = reinterpret_cast<const u32x4*>(wsum_f)[v4];
+      for (int v4 = 0; v4 < WPT / 4; ++v4) {
+        const u32x4 t4 = reinterpret_cast<const u32x4*>(fc)[tid * (WPT / 4) + v4];
+        w[4 * v4] = t4[0]; w[4 * v4 + 1] = t4[1]; w[4 * v4 + 2] = t4[2]; w[4 * v4 + 3] = t4[3];
+      }
+      uint32_t tot = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (4 * v4 + e < wave) run += f4[e];
+      for (int e = 0; e < WPT; ++e) tot += (w[e] & 0xFFFFu) + (w[e] >> 16);
+      const uint32_t inc = wave_scan_dpp(tot, 0u, add_op);
+      if (lane == 63) wsum_f[wave] = inc;
+      __syncthreads();
+      uint32_t run = inc - tot;
+#pragma unroll
+      for (int v4 = 0; v4 < WAVES / 4; ++v4) {              // every wave total, four per LDS read (the same addresses in every lane: broadcast)
+        const u32x4 f4 = reinterpret_cast<const u32x4*>(wsum_f)[v4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * v4 + e < wave) run += f4[e];
+      }
+#pragma unroll
+      for (int e = 0; e < WPT; ++e) {
+        const uint32_t c0 = w[e] & 0xFFFFu, c1 = w[e] >> 16;
+        w[e] = run | ((run + c0) << 16);
+        run += c0 + c1;
+      }
+#pragma unroll
+      for (int v4 = 0; v4 < WPT / 4; ++v4) reinterpret_cast<u32x4*>(fc)[tid * (WPT / 4) + v4] = u32x4{w[4 * v4], w[4 * v4 + 1], w[4 * v4 + 2], w[4 * v4 + 3]};
+      if (tid == 0) fc[NF / 2] = static_cast<uint32_t>(n);  // fstart(NF) = the bucket's size
     }
+    __syncthreads();
+    MDG_ST(4);
+    // Where the key's fine bin starts and how many keys it holds (the bins' starts are u16: two 16-bit reads).  A
+    // key ALONE in its bin -- six of ten -- is in place by that alone (rank = bin start): it is neither written to `sorted` nor probed.
+    uint32_t sc[ITEMS];                                      // bin start | keys in the bin << 16
 #pragma unroll
-    for (int e = 0; e < WPT; ++e) {
-      const uint32_t c0 = w[e] & 0xFFFFu, c1 = w[e] >> 16;
-      w[e] = run | ((run + c0) << 16);
-      run += c0 + c1;
-    }
-#pragma unroll
-    for (int v4 = 0; v4 < WPT / 4; ++v4) reinterpret_cast<u32x4*>(fc)[tid * (WPT / 4) + v4] = u32x4{w[4 * v4], w[4 * v4 + 1], w[4 * v4 + 2], w[4 * v4 + 3]};
-    if (tid == 0) fc[NF / 2] = static_cast<uint32_t>(n);  // fstart(NF) = the bucket's size
-  }
-  __syncthreads();
-  // Where the key's fine bin starts and how many keys it holds: both bounds from one two-word read (the bins' starts are u16 pairs).  A
-  // key ALONE in its bin -- six of ten -- is in place by that alone (rank = bin start): it is neither written to `sorted` nor probed.
-  uint32_t sc[ITEMS];                                      // bin start | keys in the bin << 16
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) {
-    sc[k] = 0u;
-    if (k * TPB + tid < n) {
-      const uint32_t fi = ss[k] >> 16;
-      const uint32_t w0 = fc[fi >> 1], w1 = fc[(fi >> 1) + 1];
-      const uint32_t s0 = (fi & 1u) ? (w0 >> 16) : (w0 & 0xFFFFu), s1 = (fi & 1u) ? (w1 & 0xFFFFu) : (w0 >> 16);
-      sc[k] = s0 | ((s1 - s0) << 16);
-      if (s1 - s0 > 1u) sorted[s0 + (ss[k] & 0xFFFFu)] = u32x2{q[k], key[k]};
-    }
-  }
-  __syncthreads();
-  // keys that share a fine bin: their order is (key, position) -- one 64-bit compare per bin-mate (`sorted` holds position | key << 32).
-  // Four bin-mates are probed with predicated, independent LDS reads (a bin holds ~half a key: two keys in a thousand have more and walk on)
-  constexpr int PROBES = 4, GRP = 3;
-  static_assert(ITEMS % GRP == 0, "tie-fix groups");
-  const unsigned long long* sorted64 = reinterpret_cast<const unsigned long long*>(sorted);
-  uint32_t* dst = ranked + seg * M + rb;
-#pragma unroll
-  for (int k0 = 0; k0 < ITEMS; k0 += GRP) {                // three items at a time: 12 probes in flight
-    unsigned long long o[GRP][PROBES];
-#pragma unroll
-    for (int e = 0; e < GRP; ++e) {
-      const uint32_t s0 = sc[k0 + e] & 0xFFFFu, c = sc[k0 + e] >> 16, c1 = c > 1u ? c : 0u;
-#pragma unroll
-      for (int mth = 0; mth < PROBES; ++mth) {
-        o[e][mth] = ~0ull;
-        if (static_cast<uint32_t>(mth) < c1) o[e][mth] = sorted64[s0 + mth];
+    for (int k = 0; k < ITEMS; ++k) {
+      sc[k] = 0u;
+      if (k * TPB + tid < n) {
+        const uint32_t fi = ss[k] >> 16;
+        const uint32_t s0 = fc16[fi], s1 = fc16[fi + 1];      // (two u16 reads: the halves need no selecting)
+        sc[k] = s0 | ((s1 - s0) << 16);
+        if (s1 - s0 > 1u) sorted[s0 + (ss[k] & 0xFFFFu)] = u32x2{q[k], key[k]};
       }
     }
+    MDG_ST(5);
+    __syncthreads();
+    zero_counters();                                       // for the next bucket: the counters were last read above, `sorted` is all that is read from here
+    // keys that share a fine bin: their order is (key, position) -- one 64-bit compare per bin-mate (`sorted` holds position | key << 32).
+    // Four bin-mates are probed with predicated, independent LDS reads (a bin holds ~half a key: two keys in a thousand have more and walk on)
+    constexpr int PROBES = 4, GRP = 3;
+    static_assert(ITEMS % GRP == 0, "tie-fix groups");
+    const unsigned long long* sorted64 = reinterpret_cast<const unsigned long long*>(sorted);
+    uint32_t* dst = ranked + seg * M + rb;
 #pragma unroll
-    for (int e = 0; e < GRP; ++e) {
-      const int k = k0 + e;
-      const uint32_t s0 = sc[k] & 0xFFFFu, c = sc[k] >> 16;
-      const unsigned long long me = (static_cast<unsigned long long>(key[k]) << 32) | q[k];
-      uint32_t r = 0;
+    for (int k0 = 0; k0 < ITEMS; k0 += GRP) {                // three items at a time: 12 probes in flight
+      unsigned long long o[GRP][PROBES];
 #pragma unroll
-      for (int mth = 0; mth < PROBES; ++mth) r += o[e][mth] < me ? 1u : 0u;
-      if (c > static_cast<uint32_t>(PROBES)) {
-        if (c > static_cast<uint32_t>(MSD_TIE_LIMIT)) too_many = true;
-        else
-          for (uint32_t mth = PROBES; mth < c; ++mth) r += sorted64[s0 + mth] < me ? 1u : 0u;
+      for (int e = 0; e < GRP; ++e) {
+        const uint32_t s0 = sc[k0 + e] & 0xFFFFu, c = sc[k0 + e] >> 16, c1 = c > 1u ? c : 0u;
+#pragma unroll
+        for (int mth = 0; mth < PROBES; ++mth) {
+          o[e][mth] = ~0ull;
+          if (static_cast<uint32_t>(mth) < c1) o[e][mth] = sorted64[s0 + mth];
+        }
       }
-      const int idx = k * TPB + tid;
-      if (idx < n) dst[idx] = ((s0 + r) << 14) | (((q[k] >> 16) & 127u) << 7) | (q[k] & 127u);
+#pragma unroll
+      for (int e = 0; e < GRP; ++e) {
+        const int k = k0 + e;
+        const uint32_t s0 = sc[k] & 0xFFFFu, c = sc[k] >> 16;
+        const unsigned long long me = (static_cast<unsigned long long>(key[k]) << 32) | q[k];
+        uint32_t r = 0;
+#pragma unroll
+        for (int mth = 0; mth < PROBES; ++mth) r += o[e][mth] < me ? 1u : 0u;
+        if (c > static_cast<uint32_t>(PROBES)) {
+          if (c > static_cast<uint32_t>(MSD_TIE_LIMIT)) too_many = true;
+          else
+            for (uint32_t mth = PROBES; mth < c; ++mth) r += sorted64[s0 + mth] < me ? 1u : 0u;
+        }
+        const int idx = k * TPB + tid;
+        if (idx < n) dst[idx] = ((s0 + r) << 14) | (((q[k] >> 16) & 127u) << 7) | (q[k] & 127u);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  __syncthreads();                                       // `sorted` and the counters are read: the next bucket may overwrite them
+    MDG_ST(6);
+    publish_stats(par ^ 1);                                // (waits for the next bucket's pairs: they have had this bucket's time to arrive)
+    __syncthreads();                                       // `sorted` is read, the counters are zero, the next bucket's statistics are in: it may start
+    MDG_ST(7);
   }
   if (too_many) atomicOr(&flags[seg], MSD_F_TIES);
+  MDG_ST_OUT(stamps + 8 * 4096 + (blockIdx.y * gridDim.x + blockIdx.x) * 8);
 }
-
 
 // A bucket beyond the LDS room of msd_bucket_kernel (fewer than 65 536 keys; the bucket function's sub-ranges assume a density that is
 // flat inside a level-2 bin, which a sparse region at the edge of a score distribution is not): the same counting sort and the same
@@ -1670,6 +1733,8 @@ static void msd_run(const MsdPlan& pl, const float* scores, int64_t lds, float* 
   const size_t bucket_lds = static_cast<size_t>(2 * MSD_CAP + MSD_NF / 2 + 32) * 4;
   const size_t gather_lds = static_cast<size_t>(BB * (BB + 1) + 2 * pl.nbs + pl.nbs / 2) * 4;
   const bool vec = ldo % 4 == 0 && mdg_aligned16(out);
+  // (-DMDG_RANK_STAMPS: the phase stamps go to the tail of the big-bucket scratch, its least used slot)
+  unsigned long long* stamp_buf = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(bigtmp) + G * pl.bigtmp_bytes) - 2 * 8 * 4096;
   constexpr int part_wgs = 256;                            // persistent partition workgroups of a launch (all outcomes of the group): one per CU
   for (int64_t s0 = 0; s0 < n_outcomes; s0 += G) {
     const unsigned g = static_cast<unsigned>(n_outcomes - s0 < G ? n_outcomes - s0 : G);
@@ -1683,10 +1748,10 @@ static void msd_run(const MsdPlan& pl, const float* scores, int64_t lds, float* 
     hipLaunchKernelGGL(msd_scan_kernel, dim3(static_cast<unsigned>(pl.nbs / 64), g), dim3(1024), 0, st, counts, offs, totals, n_blocks, pl.nbs);
     hipLaunchKernelGGL(msd_base_kernel, dim3(g), dim3(1024), 0, st, totals, bases, fl, big, pl.nbs, M);
     hipLaunchKernelGGL(msd_partition_kernel, dim3(pw, g), dim3(1024), part_lds, st, sc, lds, tb, offs, bases, part, fl, static_cast<int>(N), M, pl.nbs, n_blocks,
-                       src_is_keys);
+                       src_is_keys, stamp_buf);
     unsigned bw = static_cast<unsigned>(mdg_cdiv(part_wgs, g));       // persistent, like the partition
     bw = bw < 1u ? 1u : (bw > static_cast<unsigned>(pl.nbt) ? static_cast<unsigned>(pl.nbt) : bw);
-    hipLaunchKernelGGL((msd_bucket_kernel<MSD_NF>), dim3(bw, g), dim3(1024), bucket_lds, st, part, bases, totals, ranked, fl, M, pl.nbs, pl.nbt);
+    hipLaunchKernelGGL((msd_bucket_kernel<MSD_NF>), dim3(bw, g), dim3(1024), bucket_lds, st, part, bases, totals, ranked, fl, M, pl.nbs, pl.nbt, stamp_buf);
     hipLaunchKernelGGL(msd_big_bucket_kernel, dim3(MSD_BIG_MAX, g), dim3(1024), 0, st, part, bases, totals, ranked, bigtmp, fl, big, M, pl.nbs);
     const dim3 bgrid(static_cast<unsigned>(8 * mdg_cdiv(n_blocks, 8)), g);
     if (vec) hipLaunchKernelGGL(msd_block_gather_kernel<true>, bgrid, dim3(512), gather_lds, st, ranked, offs, counts, bases, o, ldo, static_cast<int>(N), M, pl.nbt,

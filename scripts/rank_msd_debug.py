@@ -62,3 +62,17 @@ for which in range(G if os.environ.get("DBG_MODEL", "1") != "0" else 0):
           " equal:", np.array_equal(totals[:nbt], cnt))
     d = np.nonzero(totals[:nbt] != cnt)[0]
     print("     differing buckets:", d.size, d[:10], totals[d[:10]], cnt[d[:10]])
+if os.environ.get("DBG_STAMPS"):
+    # phase stamps of the persistent kernels (built with MDG_EXTRA_HIPCC_FLAGS=-DMDG_RANK_STAMPS): in the big-bucket scratch
+    off += 2 * a256(G * nbs * 4)                      # totals, bases
+    off += G * 63 * 65536 * 8 - 2 * 8 * 4096 * 8       # the tail of the scratch
+    st = ws[off:off + 2 * 8 * 4096 * 8].view(torch.int64).cpu().numpy().reshape(2, 4096, 8)
+    wgs = max(1, 256 // G)
+    for name, blk, phases in (("partition", st[0], ["-", "zero+keys+prefetch issue+barrier", "atomics", "barrier", "scan (2 barriers)", "place+bcnt update (2 barriers)", "copy-out", "end barrier"]),
+                              ("bucket sort", st[1], ["-", "init", "atomics", "barrier", "scan (2 barriers)", "bounds+place", "barrier+zero+probes+stores", "next stats+end barrier"])):
+        a = blk[:G * wgs].astype(np.float64)
+        a = a[a.sum(1) > 0]
+        tot = a.sum(1)
+        print(f"{name}: {a.shape[0]} workgroups, mean cycles per workgroup {tot.mean():.0f} (= {tot.mean() / 2.4e3:.1f} us at 2.4 GHz; clock units are the s_memtime counter's)")
+        for i, ph in enumerate(phases):
+            if i: print(f"   {ph:45s} {a[:, i].mean():10.0f}  {100 * a[:, i].mean() / tot.mean():5.1f} %")
