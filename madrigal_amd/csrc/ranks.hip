@@ -507,8 +507,9 @@ constexpr int MSD_TIE_LIMIT = 1024;       // keys per fine bin ordered in place 
                                           // bucket around zero -- costs 30 000 LDS reads); more: LSD fallback
 constexpr int MSD_SAMPLE_CHUNKS = 4096;   // 64-key chunks sampled per outcome (262 144 keys: 128 per bucket at N = 4096)
 constexpr int MSD_SAMPLE_WGS = 32;        // 256-thread workgroups per outcome in the two sampling sweeps
-constexpr int MSD_BIG_MAX = 63, MSD_BIG_WORDS = 64;   // buckets beyond MSD_CAP keys per outcome that msd_big_bucket_kernel takes (count + ids)
-constexpr int MSD_BIG_NF = 16384, MSD_BIG_TIES = 4096;
+constexpr int MSD_BIG_MAX = 63, MSD_BIG_WORDS = 72;   // buckets beyond MSD_CAP keys per outcome that msd_big_bucket takes (count + ids), then
+constexpr int MSD_BIG_QUEUE = 64;                     // the counter the bucket sort's workgroups draw their buckets from
+constexpr int MSD_BIG_NF = 32768, MSD_BIG_TIES = 4096;
 constexpr uint32_t MSD_F_BUCKET = 1u, MSD_F_TOTAL = 2u, MSD_F_TIES = 4u;      // why an outcome was handed back
 constexpr uint32_t MSD_SKIP = 0xFFFFFFFFu;
 
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(1024) void msd_scan_kernel(const uint16_t* __restri
 }
 
 // base[outcome * nbs + bucket] = keys in the buckets before.  A bucket beyond the bucket sort's LDS room goes on the outcome's list for
-// msd_big_bucket_kernel (big[outcome * MSD_BIG_WORDS] = count, then the bucket ids); more than MSD_BIG_MAX of them, a bucket of 65 536
+// msd_big_bucket (big[outcome * MSD_BIG_WORDS] = count, then the bucket ids); more than MSD_BIG_MAX of them, a bucket of 65 536
 // keys or more (a point mass of equal keys) or a total that is not M raises the outcome's flag
 __global__ __launch_bounds__(1024) void msd_base_kernel(const uint32_t* __restrict__ totals, uint32_t* __restrict__ base, uint32_t* __restrict__ flags,
                                                        uint32_t* __restrict__ big, int nbs, int64_t M) {
@@ -889,7 +890,10 @@ __global__ __launch_bounds__(1024) void msd_base_kernel(const uint32_t* __restri
   if (over) atomicOr(&flags[seg], MSD_F_BUCKET);
   if (tid == 1023 && static_cast<int64_t>(run) != M) atomicOr(&flags[seg], MSD_F_TOTAL);
   __syncthreads();
-  if (tid == 0) big[seg * MSD_BIG_WORDS] = nbig < static_cast<uint32_t>(MSD_BIG_MAX) ? nbig : static_cast<uint32_t>(MSD_BIG_MAX);
+  if (tid == 0) {
+    big[seg * MSD_BIG_WORDS] = nbig < static_cast<uint32_t>(MSD_BIG_MAX) ? nbig : static_cast<uint32_t>(MSD_BIG_MAX);
+    big[seg * MSD_BIG_WORDS + MSD_BIG_QUEUE] = 0u;
+  }
 }
 
 // -DMDG_RANK_STAMPS (MDG_EXTRA_HIPCC_FLAGS): shader-clock stamps at the phase boundaries of the two persistent kernels, summed per phase
@@ -1098,10 +1102,135 @@ __device__ __forceinline__ uint32_t wave_reduce_dpp(uint32_t v, uint32_t ident, 
   return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_scan_dpp(v, ident, op)), 63));
 }
 
+// A bucket beyond the LDS room of the bucket sort proper (fewer than 65 536 keys; the bucket function's sub-ranges assume a density
+// that is flat inside a level-2 bin, which a sparse region at the edge of a score distribution is not): the same counting sort and the
+// same output words, with the pairs streamed through global memory instead of held in registers and LDS -- sorted by fine bin into
+// the bucket's slot of `tmp` (65 536 pairs per listed bucket), then every key's bin-mates read back from there.  Called by the
+// workgroups of msd_bucket_kernel before they start on the queue of ordinary buckets (a launch of its own ran with a handful of
+// workgroups on an otherwise idle chip: 79 us per group of 8 outcomes of the bench's score tensor).  lds: 2 x (NF / 2 + 4) words.
+template <int NF>
+__device__ __forceinline__ void msd_big_bucket(const u32x2* __restrict__ in, u32x2* __restrict__ tmp, uint32_t* __restrict__ dst, int n, uint32_t* lds,
+                                               uint32_t* wsum_f, uint32_t* kst, bool& too_many) {
+  constexpr int TPB = 1024, LGNF = 31 - __builtin_clz(NF), WPT = NF / 2 / TPB, U = 4;
+  uint32_t* fc = lds;                                      // fine-bin counters, then starts (two u16 per word)
+  uint32_t* cur = lds + NF / 2 + 4;                        // cursors: start + keys placed so far
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const auto umin_op = [](uint32_t x, uint32_t y) { return x < y ? x : y; };
+  const auto umax_op = [](uint32_t x, uint32_t y) { return x > y ? x : y; };
+  const auto add_op = [](uint32_t x, uint32_t y) { return x + y; };
+  for (int i = tid; i < NF / 2 + 4; i += TPB) fc[i] = 0;
+  if (tid == 0) { kst[0] = 0xFFFFFFFFu; kst[1] = 0u; kst[2] = 0u; }
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u, ksum = 0u;       // (sum of key >> 16: below 2^32 for 65 535 keys)
+  for (int i0 = tid; i0 < n; i0 += U * TPB) {
+    uint32_t kk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) kk[u] = i0 + u * TPB < n ? in[i0 + u * TPB][0] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = i0 + u * TPB < n;
+      kmin = kmin < kk[u] ? kmin : kk[u];
+      kmax = (ok && kk[u] > kmax) ? kk[u] : kmax;
+      ksum += ok ? kk[u] >> 16 : 0u;
+    }
+  }
+  kmin = wave_reduce_dpp(kmin, 0xFFFFFFFFu, umin_op);
+  kmax = wave_reduce_dpp(kmax, 0u, umax_op);
+  ksum = wave_reduce_dpp(ksum, 0u, add_op);
+  __syncthreads();
+  if (lane == 0 && kmin <= kmax) { atomicMin(&kst[0], kmin); atomicMax(&kst[1], kmax); atomicAdd(&kst[2], ksum); }
+  __syncthreads();
+  MsdFine fine_of;
+  fine_of.init(kst[0], kst[1], static_cast<float>(kst[2]) / static_cast<float>(n) * 65536.f, LGNF);
+  for (int i0 = tid; i0 < n; i0 += U * TPB) {
+    u32x2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i0 + u * TPB < n) v[u] = in[i0 + u * TPB];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i0 + u * TPB < n) {
+        const uint32_t fi = fine_of(v[u][0], v[u][1]);
+        atomicAdd(&fc[fi >> 1], 1u << (16u * (fi & 1u)));
+      }
+  }
+  __syncthreads();
+  {
+    uint32_t w[WPT], tot = 0;
+#pragma unroll
+    for (int e = 0; e < WPT; ++e) { w[e] = fc[tid * WPT + e]; tot += (w[e] & 0xFFFFu) + (w[e] >> 16); }
+    const uint32_t inc = wave_scan_dpp(tot, 0u, add_op);
+    if (lane == 63) wsum_f[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - tot;
+    for (int v = 0; v < wave; ++v) run += wsum_f[v];
+#pragma unroll
+    for (int e = 0; e < WPT; ++e) {
+      const uint32_t c0 = w[e] & 0xFFFFu, c1 = w[e] >> 16;
+      const uint32_t st = run | ((run + c0) << 16);        // (starts below 65 536: the bucket has fewer keys)
+      fc[tid * WPT + e] = st;
+      cur[tid * WPT + e] = st;
+      run += c0 + c1;
+    }
+  }
+  __syncthreads();
+  // sorted by fine bin into `tmp`
+  for (int i0 = tid; i0 < n; i0 += U * TPB) {
+    u32x2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i0 + u * TPB < n) v[u] = in[i0 + u * TPB];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i0 + u * TPB < n) {
+        const uint32_t fi = fine_of(v[u][0], v[u][1]), fh = 16u * (fi & 1u);
+        const uint32_t pos = (atomicAdd(&cur[fi >> 1], 1u << fh) >> fh) & 0xFFFFu;
+        tmp[pos] = v[u];
+      }
+  }
+  __threadfence();
+  __syncthreads();
+  __threadfence();
+  // ranks: a bin's keys ordered by (key, position) by counting (four keys' bin-mates in flight per thread)
+  for (int i0 = tid; i0 < n; i0 += U * TPB) {
+    u32x2 v[U];
+    uint32_t s0[U], cnt[U], r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      cnt[u] = 0u; s0[u] = 0u; r[u] = 0u;
+      v[u] = u32x2{0u, 0u};
+      if (i0 + u * TPB < n) v[u] = in[i0 + u * TPB];
+    }
+    uint32_t cmax = 0u;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i0 + u * TPB < n) {
+        const uint32_t fi = fine_of(v[u][0], v[u][1]);
+        s0[u] = (fc[fi >> 1] >> (16u * (fi & 1u))) & 0xFFFFu;
+        cnt[u] = ((cur[fi >> 1] >> (16u * (fi & 1u))) & 0xFFFFu) - s0[u];
+        if (cnt[u] > static_cast<uint32_t>(MSD_BIG_TIES)) { too_many = true; cnt[u] = 0u; }
+        cmax = cmax > cnt[u] ? cmax : cnt[u];
+      }
+    for (uint32_t m = 0; m < cmax; ++m) {
+      u32x2 o[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (m < cnt[u]) o[u] = __builtin_nontemporal_load(&tmp[s0[u] + m]);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (m < cnt[u]) r[u] += (o[u][0] < v[u][0] || (o[u][0] == v[u][0] && o[u][1] < v[u][1])) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i0 + u * TPB < n) dst[i0 + u * TPB] = ((s0[u] + r[u]) << 14) | (((v[u][1] >> 16) & 127u) << 7) | (v[u][1] & 127u);
+  }
+  __syncthreads();                                         // the LDS words are the caller's again
+}
+
 template <int NF>
 __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __restrict__ part, const uint32_t* __restrict__ bases,
                                                            const uint32_t* __restrict__ totals, uint32_t* __restrict__ ranked,
-                                                           uint32_t* __restrict__ flags, int64_t M, int nbs, int nbt, unsigned long long* stamps) {
+                                                           u32x2* __restrict__ tmp_all, uint32_t* __restrict__ flags, uint32_t* __restrict__ big,
+                                                           int64_t M, int nbs, int nbt, unsigned long long* stamps) {
   MDG_ST_DECL;
   constexpr int TPB = 1024, CAP = MSD_CAP, ITEMS = CAP / TPB, WPT = NF / 2 / TPB, WAVES = TPB / 64;     // NF fine bins, two u16 counters per word
   constexpr int LGNF = 31 - __builtin_clz(NF);
@@ -1113,6 +1242,7 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
   // of it) of a bucket, double-buffered: the NEXT bucket's are gathered at the end of this bucket's last phase (its pairs have
   // arrived by then) and are behind the closing barrier, so a bucket starts without a reduction and its two barriers
   __shared__ uint32_t kstat[2][4];
+  __shared__ uint32_t q_next[2];
   const int64_t seg = blockIdx.y;
   if (flags[seg]) return;
   u32x2* sorted = reinterpret_cast<u32x2*>(dyn);
@@ -1128,7 +1258,7 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
   uint32_t nrb = 0;
   const auto fetch = [&](int bb) {
     nn = bb < nbt ? static_cast<int>(totals[seg * nbs + bb]) : 0;
-    if (nn > CAP) nn = 0;                                  // msd_big_bucket_kernel's
+    if (nn > CAP) nn = 0;                                  // msd_big_bucket's
     nrb = bb < nbt ? bases[seg * nbs + bb] : 0u;
     const u32x2* src = part + seg * M + nrb;
 #pragma unroll
@@ -1163,21 +1293,44 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
     ksum = wave_reduce_dpp(ksum, 0u, add_op);
     if (lane == 0 && kmin <= kmax) { atomicMin(&kstat[slot][0], kmin); atomicMax(&kstat[slot][1], kmax); atomicAdd(&kstat[slot][2], ksum); }
   };
-  fetch(static_cast<int>(blockIdx.x));
+  bool too_many = false;
+  // ---- the outcome's big buckets first, one per workgroup (the workgroups that take one join the queue below late: it evens out)
+  {
+    const uint32_t nbig = big[seg * MSD_BIG_WORDS];
+    static_assert(2 * (MSD_BIG_NF / 2 + 4) <= 2 * CAP + NF / 2 + 32, "the big-bucket sort works in the bucket sort's LDS");
+    for (uint32_t sl = blockIdx.x; sl < nbig; sl += gridDim.x) {
+      const int bb = static_cast<int>(big[seg * MSD_BIG_WORDS + 1 + sl]);
+      const uint32_t rbb = bases[seg * nbs + bb];
+      msd_big_bucket<MSD_BIG_NF>(part + seg * M + rbb, tmp_all + (seg * MSD_BIG_MAX + sl) * int64_t{65536}, ranked + seg * M + rbb,
+                                 static_cast<int>(totals[seg * nbs + bb]), dyn, wsum_f, kstat[0], too_many);
+    }
+  }
+  // ---- then the ordinary buckets, handed out by a counter (big[.. + MSD_BIG_QUEUE], zeroed by msd_base_kernel): a workgroup that got
+  // the bucket with the long tie walks, or started late, takes fewer.  The bucket after next is drawn at the top of a bucket and read
+  // behind its closing barrier, so the draw's latency is off the path.
+  uint32_t* qctr = big + seg * MSD_BIG_WORDS + MSD_BIG_QUEUE;
+  if (tid == 0) {
+    q_next[0] = atomicAdd(qctr, 1u);
+    q_next[1] = atomicAdd(qctr, 1u);
+  }
+  __syncthreads();
+  int b = __builtin_amdgcn_readfirstlane(static_cast<int>(q_next[0])), bn = __builtin_amdgcn_readfirstlane(static_cast<int>(q_next[1]));
+  fetch(b);
   zero_counters();
   if (tid < 2) { kstat[tid][0] = 0xFFFFFFFFu; kstat[tid][1] = 0u; kstat[tid][2] = 0u; }
   __syncthreads();
   publish_stats(0);
   __syncthreads();
-  bool too_many = false;
   int par = 0;
-  for (int b = blockIdx.x; b < nbt; b += gridDim.x, par ^= 1) {
+  for (; b < nbt; par ^= 1) {
     const int n = nn;
     const uint32_t rb = nrb;
     uint32_t key[ITEMS], q[ITEMS], ss[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) { key[k] = nkey[k]; q[k] = nq[k]; }
-    fetch(b + static_cast<int>(gridDim.x));
+    fetch(bn);
+    uint32_t drawn = 0u;
+    if (tid == 0) drawn = atomicAdd(qctr, 1u);
     MDG_ST(0);
     MsdFine fine_of;
     {
@@ -1287,109 +1440,14 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
     }
     MDG_ST(6);
     publish_stats(par ^ 1);                                // (waits for the next bucket's pairs: they have had this bucket's time to arrive)
+    if (tid == 0) q_next[0] = drawn;
     __syncthreads();                                       // `sorted` is read, the counters are zero, the next bucket's statistics are in: it may start
+    b = bn;
+    bn = __builtin_amdgcn_readfirstlane(static_cast<int>(q_next[0]));
     MDG_ST(7);
   }
   if (too_many) atomicOr(&flags[seg], MSD_F_TIES);
   MDG_ST_OUT(stamps + 8 * 4096 + (blockIdx.y * gridDim.x + blockIdx.x) * 8);
-}
-
-// A bucket beyond the LDS room of msd_bucket_kernel (fewer than 65 536 keys; the bucket function's sub-ranges assume a density that is
-// flat inside a level-2 bin, which a sparse region at the edge of a score distribution is not): the same counting sort and the same
-// output words, with the pairs streamed through global memory instead of held in registers and LDS -- sorted by fine bin into the
-// bucket's slot of `tmp` (65 536 pairs per listed bucket), then every key's bin-mates read back from there.  One workgroup per listed
-// bucket: a few per outcome at most, so its speed does not matter.
-__global__ __launch_bounds__(1024) void msd_big_bucket_kernel(const u32x2* __restrict__ part, const uint32_t* __restrict__ bases,
-                                                             const uint32_t* __restrict__ totals, uint32_t* __restrict__ ranked, u32x2* __restrict__ tmp_all,
-                                                             uint32_t* __restrict__ flags, const uint32_t* __restrict__ big, int64_t M, int nbs) {
-  constexpr int TPB = 1024, NF = MSD_BIG_NF, LGNF = 31 - __builtin_clz(NF), WPT = NF / 2 / TPB;
-  __shared__ __attribute__((aligned(16))) uint32_t fc[NF / 2 + 4];       // fine-bin counters, then starts (two u16 per word)
-  __shared__ __attribute__((aligned(16))) uint32_t cur[NF / 2 + 4];      // cursors: start + keys placed so far
-  __shared__ __attribute__((aligned(16))) uint32_t wsum_f[16];
-  __shared__ uint32_t krange[2];
-  __shared__ unsigned long long ksum_sh;
-  const int64_t seg = blockIdx.y;
-  if (flags[seg] || blockIdx.x >= big[seg * MSD_BIG_WORDS]) return;
-  const int b = static_cast<int>(big[seg * MSD_BIG_WORDS + 1 + blockIdx.x]);
-  const int n = static_cast<int>(totals[seg * nbs + b]);
-  const uint32_t rb = bases[seg * nbs + b];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const u32x2* in = part + seg * M + rb;
-  u32x2* tmp = tmp_all + (seg * MSD_BIG_MAX + blockIdx.x) * int64_t{65536};
-  for (int i = tid; i < NF / 2 + 4; i += TPB) fc[i] = 0;
-  if (tid == 0) { krange[0] = 0xFFFFFFFFu; krange[1] = 0u; ksum_sh = 0ull; }
-  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-  unsigned long long ksum = 0ull;
-  for (int idx = tid; idx < n; idx += TPB) {
-    const uint32_t kk = in[idx][0];
-    kmin = kmin < kk ? kmin : kk;
-    kmax = kmax > kk ? kmax : kk;
-    ksum += kk;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t a = __shfl_xor(kmin, o, 64), c = __shfl_xor(kmax, o, 64);
-    kmin = kmin < a ? kmin : a;
-    kmax = kmax > c ? kmax : c;
-    ksum += __shfl_xor(ksum, o, 64);
-  }
-  __syncthreads();
-  if (lane == 0 && kmin <= kmax) { atomicMin(&krange[0], kmin); atomicMax(&krange[1], kmax); atomicAdd(&ksum_sh, ksum); }
-  __syncthreads();
-  MsdFine fine_of;
-  fine_of.init(krange[0], krange[1], static_cast<float>(static_cast<double>(ksum_sh) / n), LGNF);
-  for (int idx = tid; idx < n; idx += TPB) {
-    const u32x2 v = in[idx];
-    const uint32_t fi = fine_of(v[0], v[1]);
-    atomicAdd(&fc[fi >> 1], 1u << (16u * (fi & 1u)));
-  }
-  __syncthreads();
-  {
-    uint32_t w[WPT], tot = 0;
-#pragma unroll
-    for (int e = 0; e < WPT; ++e) { w[e] = fc[tid * WPT + e]; tot += (w[e] & 0xFFFFu) + (w[e] >> 16); }
-    const uint32_t inc = wave_inclusive(tot, lane);
-    if (lane == 63) wsum_f[wave] = inc;
-    __syncthreads();
-    uint32_t run = inc - tot;
-    for (int v = 0; v < wave; ++v) run += wsum_f[v];
-#pragma unroll
-    for (int e = 0; e < WPT; ++e) {
-      const uint32_t c0 = w[e] & 0xFFFFu, c1 = w[e] >> 16;
-      const uint32_t st = run | ((run + c0) << 16);        // (starts below 65 536: the bucket has fewer keys)
-      fc[tid * WPT + e] = st;
-      cur[tid * WPT + e] = st;
-      run += c0 + c1;
-    }
-  }
-  __syncthreads();
-  // sorted by fine bin into `tmp`
-  for (int idx = tid; idx < n; idx += TPB) {
-    const u32x2 v = in[idx];
-    const uint32_t fi = fine_of(v[0], v[1]), fh = 16u * (fi & 1u);
-    const uint32_t pos = (atomicAdd(&cur[fi >> 1], 1u << fh) >> fh) & 0xFFFFu;
-    tmp[pos] = v;
-  }
-  __threadfence();
-  __syncthreads();
-  __threadfence();
-  // ranks: a bin's keys ordered by (key, position) by counting
-  bool too_many = false;
-  uint32_t* dst = ranked + seg * M + rb;
-  for (int idx = tid; idx < n; idx += TPB) {
-    const u32x2 v = in[idx];
-    const uint32_t fi = fine_of(v[0], v[1]);
-    const uint32_t s0 = (fc[fi >> 1] >> (16u * (fi & 1u))) & 0xFFFFu, e0 = (cur[fi >> 1] >> (16u * (fi & 1u))) & 0xFFFFu;
-    uint32_t r = 0;
-    if (e0 - s0 > static_cast<uint32_t>(MSD_BIG_TIES)) too_many = true;
-    else
-      for (uint32_t m = s0; m < e0; ++m) {
-        const u32x2 o = __builtin_nontemporal_load(&tmp[m]);
-        r += (o[0] < v[0] || (o[0] == v[0] && o[1] < v[1])) ? 1u : 0u;
-      }
-    dst[idx] = ((s0 + r) << 14) | (((v[1] >> 16) & 127u) << 7) | (v[1] & 127u);
-  }
-  if (too_many) atomicOr(&flags[seg], MSD_F_TIES);
 }
 
 // one 128 x 128 block of the lower triangle, gathered from every bucket's run of it (8 lanes per run; the runs' starts and lengths are
@@ -1751,8 +1809,7 @@ static void msd_run(const MsdPlan& pl, const float* scores, int64_t lds, float* 
                        src_is_keys, stamp_buf);
     unsigned bw = static_cast<unsigned>(mdg_cdiv(part_wgs, g));       // persistent, like the partition
     bw = bw < 1u ? 1u : (bw > static_cast<unsigned>(pl.nbt) ? static_cast<unsigned>(pl.nbt) : bw);
-    hipLaunchKernelGGL((msd_bucket_kernel<MSD_NF>), dim3(bw, g), dim3(1024), bucket_lds, st, part, bases, totals, ranked, fl, M, pl.nbs, pl.nbt, stamp_buf);
-    hipLaunchKernelGGL(msd_big_bucket_kernel, dim3(MSD_BIG_MAX, g), dim3(1024), 0, st, part, bases, totals, ranked, bigtmp, fl, big, M, pl.nbs);
+    hipLaunchKernelGGL((msd_bucket_kernel<MSD_NF>), dim3(bw, g), dim3(1024), bucket_lds, st, part, bases, totals, ranked, bigtmp, fl, big, M, pl.nbs, pl.nbt, stamp_buf);
     const dim3 bgrid(static_cast<unsigned>(8 * mdg_cdiv(n_blocks, 8)), g);
     if (vec) hipLaunchKernelGGL(msd_block_gather_kernel<true>, bgrid, dim3(512), gather_lds, st, ranked, offs, counts, bases, o, ldo, static_cast<int>(N), M, pl.nbt,
                                 pl.nbs, n_blocks, denom, fl);
