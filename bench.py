@@ -402,8 +402,9 @@ def ranks_leg(scores, args, model=None, z=None):
            "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": None if rank_traffic is None else rank_traffic * L, "traffic_source": rank_traffic_src,
                         "kernel": "mdg_rank_normalize (extract + 4 x 8-bit stable LSD radix passes on LDS-sorted 16384-key tiles + blocked rank store)" if not flags else
-                                  "mdg_rank_normalize: exact-layout MSD path (sampled bucket table -> per-tile bucket counts + scan -> one partition -> in-LDS counting "
-                                  "sort per 8192-key bucket -> output blocks gathered through a directory); outcomes it hands back (point masses) take the LSD passes",
+                                  "mdg_rank_normalize: exact-layout MSD path (sampled bucket table -> bucket counts per 128 x 128 output block + scan -> one partition -> in-LDS "
+                                  "counting sort per 8192-key bucket, one word per key in place -> output blocks gathered through the layout tables); outcomes it hands back "
+                                  "(point masses) take the LSD passes",
                         "outcomes_handed_to_lsd": handed if flags else None,
                         "algorithmic_bytes_per_outcome": alg / L, "formula": "(M x 4 B keys read + N^2 x 4 B ranks written) x outcomes / launch time"}}
     del chk
