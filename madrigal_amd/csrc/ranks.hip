@@ -217,6 +217,25 @@ __device__ __forceinline__ uint32_t wave_inclusive(uint32_t v, int lane) {
   return v;
 }
 
+// wave64 inclusive scan / reduction in registers (DPP row shifts and row broadcasts: no trip through the LDS crossbar, which a
+// __shfl step is -- six dependent ones cost more than the phase they sat in).  `ident` is op's identity.
+#define MDG_DPP(old, v, ctrl, rows) static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(old), static_cast<int>(v), ctrl, rows, 0xf, false))
+template <class Op>
+__device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t v, uint32_t ident, Op op) {
+  v = op(v, MDG_DPP(ident, v, 0x111, 0xf));                // row_shr:1, :2, :4, :8 -- inclusive within each row of 16 lanes
+  v = op(v, MDG_DPP(ident, v, 0x112, 0xf));
+  v = op(v, MDG_DPP(ident, v, 0x114, 0xf));
+  v = op(v, MDG_DPP(ident, v, 0x118, 0xf));
+  v = op(v, MDG_DPP(ident, v, 0x142, 0xa));                // row_bcast:15 into rows 1 and 3
+  v = op(v, MDG_DPP(ident, v, 0x143, 0xc));                // row_bcast:31 into rows 2 and 3
+  return v;
+}
+template <class Op>
+__device__ __forceinline__ uint32_t wave_reduce_dpp(uint32_t v, uint32_t ident, Op op) {
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_scan_dpp(v, ident, op)), 63));
+}
+
+
 // exclusive scan of the 256*nblk counters of one outcome, in place; one workgroup per outcome, coalesced: every wave owns a
 // contiguous range and walks it 256 counters (16 bytes per lane) at a time, the next group's load issued before the scan of this one
 template <bool LIST>
@@ -1027,6 +1046,125 @@ __global__ __launch_bounds__(1024) void msd_partition_kernel(const float* __rest
   MDG_ST_OUT(stamps + (blockIdx.y * gridDim.x + blockIdx.x) * 8);
 }
 
+// The same partition with the copy-out of tile t inside the slot phase of tile t + 1 (per item: one returning LDS atomic of the new tile,
+// one LDS pair + one global store of the old one): the 256 workgroups of a launch run in lock step, so with the phases in a row every CU
+// stored in the same sixth of a tile's time (HBM saturated) and every CU sorted in LDS in the rest (HBM idle).  Needs the run offsets of
+// the old tile (gofs) beside the counters of the new one, and the counters double-buffered (zeroed a tile ahead: four barriers per tile
+// instead of six): 12 x nbs bytes of LDS beside the 128-KB tile and the 18-KB table -- nbs <= 1024, i.e. N <= 4096; the kernel above
+// takes the rest.
+__global__ __launch_bounds__(1024) void msd_partition_pipe_kernel(const float* __restrict__ scores, int64_t lds, const uint32_t* __restrict__ tables,
+                                                                 const uint32_t* __restrict__ offs, const uint32_t* __restrict__ bases,
+                                                                 u32x2* __restrict__ part, const uint32_t* __restrict__ flags, int N, int64_t M, int nbs,
+                                                                 int n_tiles, int src_is_keys, unsigned long long* stamps) {
+  constexpr int TPB = 1024, ITEMS = 16;
+  MDG_ST_DECL;
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];       // spair[MSD_TILE] (u32x2) | tab[MSD_N1 + MSD_NC] | bcnt[2][nbs] | gofs[nbs]
+  __shared__ uint32_t wsum[16];
+  const int64_t seg = blockIdx.y;
+  if (flags[seg]) return;
+  u32x2* spair = reinterpret_cast<u32x2*>(dyn);
+  uint32_t* tab = dyn + 2 * MSD_TILE;
+  uint32_t* bcnt2 = tab + MSD_N1 + MSD_NC;
+  uint32_t* gofs = bcnt2 + 2 * nbs;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const auto add_op = [](uint32_t x, uint32_t y) { return x + y; };
+  const float* sc = scores + seg * static_cast<int64_t>(N) * lds;
+  const uint32_t* t_hdr = tables + seg * MSD_TABLE_WORDS;
+  for (int c = tid; c < (MSD_N1 + MSD_NC) / 4; c += TPB) reinterpret_cast<u32x4*>(tab)[c] = reinterpret_cast<const u32x4*>(t_hdr + MSD_HDR)[c];
+  for (int b = tid; b < 2 * nbs; b += TPB) bcnt2[b] = 0;
+  const MsdMap m = msd_load_map(t_hdr);
+  u32x2* dst = part + seg * M;
+  float raw[ITEMS];
+  MsdTileGeom gnext;
+  // thread tid owns bucket tid (nbs <= 1024): its count, its start in the tile, its run's place in the pair buffer (loaded a tile ahead,
+  // like the scores; the two words are added where they are used -- added at the load, the sum waited for the scores as well)
+  uint32_t gbase = 0, goff = 0;
+  const auto load_tile = [&](int t) {
+    gnext.of(t);
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      int i, j;
+      raw[k] = gnext.cell(k, tid, N, i, j) ? sc[static_cast<int64_t>(i) * lds + j] : 0.f;
+    }
+    if (tid < nbs) {
+      gbase = bases[seg * nbs + tid];
+      goff = offs[(seg * n_tiles + t) * static_cast<int64_t>(nbs) + tid];
+    }
+  };
+  int p_valid = 0;                                         // the tile whose pairs wait in spair: its size and the position word of its first cell
+  uint32_t p_qbase = 0;
+  const auto copy_out_item = [&](int k) {
+    const int idx = k * TPB + tid;
+    if (idx < p_valid) {
+      const u32x2 v = spair[idx];
+      const uint32_t cellw = v[1] & 16383u;
+      dst[gofs[v[1] >> 14] + static_cast<uint32_t>(idx)] = u32x2{v[0], p_qbase + ((cellw >> 7) << 16) + (cellw & 127u)};
+    }
+  };
+  int t = blockIdx.x, par = 0;
+  if (t < n_tiles) load_tile(t);
+  __syncthreads();                                         // table and zeroed counters
+  for (; t < n_tiles; t += gridDim.x, par ^= 1) {
+    const MsdTileGeom g = gnext;
+    uint32_t* bcnt = bcnt2 + par * nbs;
+    MDG_ST(0);
+    uint32_t key[ITEMS], sb[ITEMS];                       // sb = slot in the tile's run | bucket << 16
+    uint32_t okm = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      int i, j;
+      okm |= g.cell(k, tid, N, i, j) ? 1u << k : 0u;
+      key[k] = src_is_keys ? __builtin_bit_cast(uint32_t, raw[k]) : mdg_order_key(raw[k]);
+    }
+    const uint32_t gcur = gbase + goff;
+    if (t + static_cast<int>(gridDim.x) < n_tiles) load_tile(t + gridDim.x);
+    MDG_ST(1);
+    // slots of this tile | pairs of the previous tile out
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      sb[k] = MSD_SKIP;
+      if ((okm >> k) & 1u) {
+        const uint32_t b = msd_bucket_of(key[k], tab, tab + MSD_N1, m);
+        sb[k] = atomicAdd(&bcnt[b], 1u) | (b << 16);
+      }
+      copy_out_item(k);
+    }
+    MDG_ST(2);
+    __syncthreads();                                       // counts complete; spair and gofs are read
+    MDG_ST(3);
+    uint32_t st = 0;                                       // exclusive scan of the bucket counts, one per thread
+    {
+      const uint32_t c = tid < nbs ? bcnt[tid] : 0u;
+      const uint32_t inc = wave_scan_dpp(c, 0u, add_op);
+      if (lane == 63) wsum[wave] = inc;
+      __syncthreads();
+      uint32_t run = inc - c;
+      for (int w = 0; w < wave; ++w) run += wsum[w];
+      st = run;
+      if (tid < nbs) bcnt[tid] = run;
+    }
+    __syncthreads();
+    MDG_ST(4);
+    // in LDS a pair is (key, bucket << 14 | cell of the tile): the copy-out neither re-derives the bucket from the key (two table reads
+    // and ~25 instructions per key) nor did the position have to stay in registers
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k)
+      if (sb[k] != MSD_SKIP) spair[bcnt[sb[k] >> 16] + (sb[k] & 0xFFFFu)] = u32x2{key[k], ((sb[k] >> 16) << 14) | static_cast<uint32_t>(k * TPB + tid)};
+    if (tid < nbs) {
+      gofs[tid] = gcur - st;                               // (position in the bucket) - (position in LDS)
+      bcnt2[(par ^ 1) * nbs + tid] = 0u;                   // the next tile's counters (last read a tile ago)
+    }
+    p_valid = g.keys(N);
+    p_qbase = (static_cast<uint32_t>(g.r0) << 16) | static_cast<uint32_t>(g.c0);
+    MDG_ST(5);
+    __syncthreads();                                       // the tile's pairs, their offsets and the zeroed counters
+    MDG_ST(6);
+  }
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) copy_out_item(k);
+  MDG_ST_OUT(stamps + (blockIdx.y * gridDim.x + blockIdx.x) * 8);
+}
+
 // Fine bins of the bucket sorts: on the COMPOSITE (u(key) - u(lo), position).  u is the key itself -- linear in the score inside a binade,
 // logarithmic across binades, which suits the tail buckets of heavy-tailed scores -- EXCEPT in a bucket that reaches towards zero (see init);
 // the one bucket of an outcome that holds scores of both signs: it spans 2^31 keys (every binade down to the denormals, twice) with its scores at the two ends, and bins linear
@@ -1084,24 +1222,6 @@ struct MsdFine {
 // in runs by output block (see MsdTileGeom), so nothing is regrouped and there are no global atomics.
 // One returning LDS atomic per key (its slot in its fine bin); items behind the bucket's last key take none (thousands of lanes on one
 // dummy counter serialise).
-// wave64 inclusive scan / reduction in registers (DPP row shifts and row broadcasts: no trip through the LDS crossbar, which a
-// __shfl step is -- six dependent ones cost more than the phase they sat in).  `ident` is op's identity.
-#define MDG_DPP(old, v, ctrl, rows) static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(old), static_cast<int>(v), ctrl, rows, 0xf, false))
-template <class Op>
-__device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t v, uint32_t ident, Op op) {
-  v = op(v, MDG_DPP(ident, v, 0x111, 0xf));                // row_shr:1, :2, :4, :8 -- inclusive within each row of 16 lanes
-  v = op(v, MDG_DPP(ident, v, 0x112, 0xf));
-  v = op(v, MDG_DPP(ident, v, 0x114, 0xf));
-  v = op(v, MDG_DPP(ident, v, 0x118, 0xf));
-  v = op(v, MDG_DPP(ident, v, 0x142, 0xa));                // row_bcast:15 into rows 1 and 3
-  v = op(v, MDG_DPP(ident, v, 0x143, 0xc));                // row_bcast:31 into rows 2 and 3
-  return v;
-}
-template <class Op>
-__device__ __forceinline__ uint32_t wave_reduce_dpp(uint32_t v, uint32_t ident, Op op) {
-  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_scan_dpp(v, ident, op)), 63));
-}
-
 // A bucket beyond the LDS room of the bucket sort proper (fewer than 65 536 keys; the bucket function's sub-ranges assume a density
 // that is flat inside a level-2 bin, which a sparse region at the edge of a score distribution is not): the same counting sort and the
 // same output words, with the pairs streamed through global memory instead of held in registers and LDS -- sorted by fine bin into
@@ -1788,6 +1908,7 @@ static void msd_run(const MsdPlan& pl, const float* scores, int64_t lds, float* 
   u32x2* bigtmp = reinterpret_cast<u32x2*>(p); p += a256(G * pl.bigtmp_bytes);
   uint32_t* big = reinterpret_cast<uint32_t*>(p); p += a256(static_cast<size_t>(G) * MSD_BIG_WORDS * 4);
   const size_t part_lds = static_cast<size_t>(2 * MSD_TILE + MSD_N1 + MSD_NC + MSD_NB_MAX) * 4;
+  const size_t pipe_lds = static_cast<size_t>(2 * MSD_TILE + MSD_N1 + MSD_NC + 3 * pl.nbs) * 4;
   const size_t bucket_lds = static_cast<size_t>(2 * MSD_CAP + MSD_NF / 2 + 32) * 4;
   const size_t gather_lds = static_cast<size_t>(BB * (BB + 1) + 2 * pl.nbs + pl.nbs / 2) * 4;
   const bool vec = ldo % 4 == 0 && mdg_aligned16(out);
@@ -1805,8 +1926,12 @@ static void msd_run(const MsdPlan& pl, const float* scores, int64_t lds, float* 
     hipLaunchKernelGGL(msd_count_kernel, dim3(static_cast<unsigned>(n_blocks), g), dim3(1024), 0, st, sc, lds, tb, counts, static_cast<int>(N), pl.nbs, src_is_keys);
     hipLaunchKernelGGL(msd_scan_kernel, dim3(static_cast<unsigned>(pl.nbs / 64), g), dim3(1024), 0, st, counts, offs, totals, n_blocks, pl.nbs);
     hipLaunchKernelGGL(msd_base_kernel, dim3(g), dim3(1024), 0, st, totals, bases, fl, big, pl.nbs, M);
-    hipLaunchKernelGGL(msd_partition_kernel, dim3(pw, g), dim3(1024), part_lds, st, sc, lds, tb, offs, bases, part, fl, static_cast<int>(N), M, pl.nbs, n_blocks,
-                       src_is_keys, stamp_buf);
+    if (pipe_lds <= size_t{160} * 1024 - 256 && pl.nbs <= 1024)
+      hipLaunchKernelGGL(msd_partition_pipe_kernel, dim3(pw, g), dim3(1024), pipe_lds, st, sc, lds, tb, offs, bases, part, fl, static_cast<int>(N), M, pl.nbs, n_blocks,
+                         src_is_keys, stamp_buf);
+    else
+      hipLaunchKernelGGL(msd_partition_kernel, dim3(pw, g), dim3(1024), part_lds, st, sc, lds, tb, offs, bases, part, fl, static_cast<int>(N), M, pl.nbs, n_blocks,
+                         src_is_keys, stamp_buf);
     unsigned bw = static_cast<unsigned>(mdg_cdiv(part_wgs, g));       // persistent, like the partition
     bw = bw < 1u ? 1u : (bw > static_cast<unsigned>(pl.nbt) ? static_cast<unsigned>(pl.nbt) : bw);
     hipLaunchKernelGGL((msd_bucket_kernel<MSD_NF>), dim3(bw, g), dim3(1024), bucket_lds, st, part, bases, totals, ranked, bigtmp, fl, big, M, pl.nbs, pl.nbt, stamp_buf);
@@ -1845,6 +1970,7 @@ static int rank_normalize_impl(const float* scores, int64_t lds, float* out, int
     static bool attr_done = false;
     if (!attr_done) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_partition_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_bucket_kernel<MSD_NF>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_block_gather_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_block_gather_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
