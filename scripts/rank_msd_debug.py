@@ -68,7 +68,7 @@ if os.environ.get("DBG_STAMPS"):
     off += G * 63 * 65536 * 8 - 2 * 8 * 4096 * 8       # the tail of the scratch
     st = ws[off:off + 2 * 8 * 4096 * 8].view(torch.int64).cpu().numpy().reshape(2, 4096, 8)
     wgs = max(1, 256 // G)
-    for name, blk, phases in (("partition", st[0], ["-", "zero+keys+prefetch issue+barrier", "atomics", "barrier", "scan (2 barriers)", "place+bcnt update (2 barriers)", "copy-out", "end barrier"]),
+    for name, blk, phases in (("partition (msd_partition_pipe_kernel)", st[0], ["-", "keys + prefetch issue", "slots of this tile | pairs of the previous tile out", "barrier", "scan (2 barriers)", "place + offsets", "end barrier", "-"]),
                               ("bucket sort", st[1], ["-", "init", "atomics", "barrier", "scan (2 barriers)", "bounds+place", "barrier+zero+probes+stores", "next stats+end barrier"])):
         a = blk[:G * wgs].astype(np.float64)
         a = a[a.sum(1) > 0]

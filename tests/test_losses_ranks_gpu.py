@@ -252,10 +252,12 @@ def test_ranks_buckets_beyond_the_lds_room_take_the_streaming_kernel(ops):
     assert np.array_equal(out, O.rank_normalize(s))
 
 
-def test_ranks_msd_path_beyond_4096_drugs(ops):
-    """N = 5003 (M = 1.25e7 keys: 1 528 buckets, 820 output blocks, a 1-in-48 sample): the MSD path's upper range, ragged N."""
+@pytest.mark.parametrize("N", [3001, 4096, 4100, 5003])
+def test_ranks_msd_path_at_every_table_width(ops, N):
+    """Bit for bit against the oracle where the bucket tables change shape: N = 3001 (550 buckets: a counter stride of 768, the partition
+    that overlaps its copy-out), 4096 (1 024: that partition's last size, BASELINE's), 4100 (1 026 buckets -> stride 1 280: the plain
+    partition), 5003 (M = 1.25e7 keys: 1 528 buckets, 820 output blocks, a 1-in-48 sample: the MSD path's upper range); ragged N."""
     from oracle import madrigal_oracle as O
-    N = 5003
     s = (np.random.default_rng(9).standard_normal((1, N, N)) * 3 + 1).astype(np.float32)
     flags = []
     out = ops.rank_normalize(torch.from_numpy(s).cuda(), fallback_flags=flags).cpu().numpy()
