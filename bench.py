@@ -116,8 +116,11 @@ def pmc_traffic(n_drugs: int, n_outcomes: int, precision: str):
 
 
 def _rank_source_sha16() -> str:
-    import hashlib
-    return hashlib.sha256(open(os.path.join(REPO, "madrigal_amd", "csrc", "ranks.hip"), "rb").read()).hexdigest()[:16]
+    """Hash of the CODE of csrc/ranks.hip: `//` comments and blank lines do not count (scripts/rank_pmc.sh records the same hash)."""
+    import hashlib, re
+    src = open(os.path.join(REPO, "madrigal_amd", "csrc", "ranks.hip"), encoding="utf-8").read()
+    code = "\n".join(l for l in (re.sub(r"\s*//.*$", "", ln).rstrip() for ln in src.splitlines()) if l.strip())
+    return hashlib.sha256(code.encode()).hexdigest()[:16]
 
 
 def rank_pmc_traffic(n_drugs: int, msd: bool):

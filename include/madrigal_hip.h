@@ -274,10 +274,11 @@ int mdg_gather_bce(const float* scores, int64_t n_labels, int64_t n_head, int64_
 /* ---------------------------------------------------------------------- rank normalisation ---- */
 
 size_t mdg_rank_normalize_workspace_bytes(int64_t n_outcomes, int64_t N);
-/* 1 when a call of this size takes the opt-in adaptive MSD path first (MDG_RANKS_MSD=1: one partition + an in-LDS sort per bucket;
- * ranks.hip), 0 when it runs the four-pass LSD sort only (the default).  On the MSD path the first n_outcomes uint32 words of the
- * workspace hold, after the call, one flag per outcome: non-zero = that outcome was handed to the LSD kernels (point masses of
- * equal scores, scores that are not smooth inside a coarse bin, row-structured tensors).  Diagnostics: the ranks are the same bits. */
+/* 1 when a call of this size takes the exact-layout MSD path first (the default up to N = 5793, MDG_RANKS_MSD=0 turns it off: one
+ * partition + an in-LDS sort per bucket; ranks.hip), 0 when it runs the four-pass LSD sort only.  On the MSD path the first
+ * n_outcomes uint32 words of the workspace hold, after the call, one flag per outcome: non-zero = that outcome was handed to the LSD
+ * kernels (point masses of equal scores: a bucket of 65 536 keys or more, or more than 1 024 keys in one fine bin).  Diagnostics:
+ * the ranks are the same bits. */
 int mdg_rank_normalize_fast_path(int64_t n_outcomes, int64_t N);
 
 /* Per outcome l: out[l,i,j] = out[l,j,i] = rank(scores[l,i,j] among the strict lower triangle i > j, ascending,

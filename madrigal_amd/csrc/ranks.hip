@@ -487,36 +487,40 @@ __global__ __launch_bounds__(C::TPB) void rank_blocks_kernel(const KIN* __restri
 }
 
 // ================================================================================================================================
-// DEFAULT path up to N = 4097 (round 5): ONE MSD partition with an EXACT layout + an in-LDS counting sort per bucket, instead of four
+// DEFAULT path up to N = 5793 (round 5): ONE MSD partition with an EXACT layout + an in-LDS counting sort per bucket, instead of four
 // global LSD passes.  Every position in memory comes from a count and a scan -- nothing has a capacity a score tensor could overflow
-// (round 4's capacity-based layouts did, on row-structured scores: DESIGN.md 4e):
+// (round 4's capacity-based layouts did, on row-structured scores: DESIGN.md 4e).  The layout is in units of the OUTPUT: a count /
+// partition tile is one 128 x 128 block of the lower triangle, so a bucket's range is already in runs by output block:
 //
-//   msd_minmax / msd_samplehist / msd_table   (all outcomes of the call, three small launches)  a 1-in-S sample of 64-key chunks,
-//                        hashed over the whole triangle (every row and column band is seen: scores are row-structured), gives the
-//                        outcome's key range [lo, hi] and a histogram over 4096 coarse bins LINEAR IN THE KEY between lo and hi.
-//                        bucket(key) = ((keys of the sample below the key's coarse bin) + sub-range(key) * (keys per sub-range))
-//                        * buckets / samples: monotone in the key, ~4096 keys per bucket for any distribution that is smooth over
-//                        1/4096 of its own range.  The sample only steers the BALANCE; the layout below is exact for any table.
-//   msd_count_kernel     per 16 384-key tile: how many of its keys fall in each bucket (u16 counters)
+//   msd_minmax / msd_hist1 / msd_level1 / msd_hist2 / msd_table   (all outcomes of the call, small launches)  a 1-in-S sample of
+//                        64-key chunks, hashed over the whole triangle (every row and column band is seen: scores are
+//                        row-structured), gives the outcome's key range and a two-level histogram: aligned slices of the key
+//                        space, cut finer where the sample is dense.  bucket(key) = ((keys of the sample below the key's bin) +
+//                        sub-range(key) * (keys per sub-range)) * buckets / samples: monotone in the key, ~8192 keys per bucket.
+//                        The sample only steers the BALANCE; the layout below is exact for any table.
+//   msd_count_kernel     per tile (= output block): how many of its keys fall in each bucket (u16 counters)
 //   msd_scan_kernel      per bucket: exclusive prefix of the tile counts (= where each tile's run starts inside the bucket) + total
-//   msd_base_kernel      per outcome: exclusive prefix of the bucket totals = the rank of each bucket's first key; an outcome with a
-//                        bucket beyond the bucket sort's LDS room (a point mass of equal keys) is flagged for the LSD kernels
-//   msd_partition_kernel the tile is sorted by bucket in LDS (slots from LDS atomics, no digit matching) and leaves as one run per
-//                        bucket, (key, position) pairs, at base[b] + offs[tile][b]
-//   msd_bucket_kernel    one bucket per workgroup: counting sort on 8192 fine bins of the bucket's own key range, keys that share a
-//                        fine bin ordered by (key, position) explicitly -- this makes ties stable although neither the partition nor
-//                        the counting preserves arrival order -- then (rank, position in block) pairs binned by 128 x 128 output
-//                        block (room from one global atomic per bucket and block; a block's size is known in closed form)
-//   rank_block_write_kernel   whole rows of out[i, j] and of the mirrored block
+//   msd_base_kernel      per outcome: exclusive prefix of the bucket totals = the rank of each bucket's first key; the list of buckets
+//                        beyond the bucket sort's LDS room; the zeroed work counter of the bucket sort; an outcome with a bucket of
+//                        65 536 keys or more (a point mass of equal keys) is flagged for the LSD kernels
+//   msd_partition_[pipe_]kernel   the tile is sorted by bucket in LDS (slots from LDS atomics, no digit matching) and leaves as one
+//                        run per bucket, (key, position) pairs, at base[b] + offs[tile][b]
+//   msd_bucket_kernel    persistent; big buckets first (msd_big_bucket, through global memory), then buckets drawn from a counter:
+//                        counting sort on 16 384 fine bins of the bucket's own key range, keys that share a fine bin ordered by
+//                        (key, position) explicitly -- this makes ties stable although neither the partition nor the counting
+//                        preserves arrival order -- and ONE WORD per key written at the key's own place: rank in bucket | cell of the block
+//   msd_block_gather_kernel   a block gathers its run of every bucket (start = base + offs[tile], length = counts[tile]), ranks into
+//                        an LDS tile, whole rows of out[i, j] and of the mirrored block
 //
-// Bytes per key: 4 + 4 (count, partition reads) + 8 + 8 (pairs out / in) + 8 + 8 (block pairs) + 8 (ranks) = 48 + ~3 of counters,
-// against ~80 for the LSD passes.  Payload q = (i << 16) | j: ordered like the triangle index, no square root to get (i, j) back.
-// Handed to the LSD kernels (flag per outcome; same bits): a bucket with more than MSD_CAP keys, a fine bin with more than
-// MSD_TIE_LIMIT keys -- point masses, heavy ties.
+// Bytes per key: 4 + 4 (count, partition reads) + 8 + 8 (pairs out / in) + 4 + 4 (words out / in) + 8 (ranks) = 40 + ~3 of tables
+// (measured past the L2: 3.65 x the algorithmic 12), against ~80 for the LSD passes.  Payload q = (i << 16) | j: ordered like the
+// triangle index, no square root to get (i, j) back.
+// Handed to the LSD kernels (flag per outcome; same bits): a bucket of 65 536 keys or more, more than MSD_BIG_MAX buckets beyond
+// MSD_CAP keys, a fine bin with more than MSD_TIE_LIMIT keys -- point masses, heavy ties.
 constexpr int MSD_N1 = 512, MSD_NC = 4096;   // level-1 slices and level-2 bins of the bucket function
 constexpr int MSD_HDR = 16;               // header words in front of an outcome's tables
 constexpr int MSD_TABLE_WORDS = MSD_HDR + MSD_N1 + MSD_NC;
-constexpr int MSD_NB_MAX = 2048;          // buckets per outcome: a 16 384-key tile then leaves as runs of >= 8 pairs = 64 B on average (measured,
+constexpr int MSD_NB_MAX = 2048;          // buckets per outcome: a 16 384-key tile then leaves as runs of >= 8 pairs = 64 B on average even at the largest N (measured,
                                           // scripts/micro/run_scatter_bw.hip: runs of 64 B and longer store at 4.7-6.4 TB/s, runs of 32 B at 1.6-2.3)
 constexpr int MSD_QLG = 13;               // ~8192 keys per bucket
 constexpr int MSD_NF = 16384;             // fine bins of the bucket sort

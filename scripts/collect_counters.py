@@ -8,7 +8,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"gpurun_out/{src}/set*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-keep = ("linear_pp_kernel", "linear_kernel", "bilinear", "fusion_attention", "prep_operands")
+keep = ("linear_pp_kernel", "linear_kernel", "bilinear", "fusion_attention", "prep_operands", "msd_")
 out = {"command": "rocprofv3 --pmc <one set per pass> --output-format csv -- python3 scripts/kernels_once.py  (scripts/pmc_kernels.sh)",
        "note": "per-launch averages summed over the chip as rocprofv3 reports them; lds_conflict_share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; "
                "lds_issue_wait_share = SQ_WAIT_INST_LDS / SQ_BUSY_CYCLES (the r02 verdict's figure); mfma_busy_share_of_simd_cycles = "

@@ -9,7 +9,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 scrip
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_w -- python3 scripts/rank_bench.py $N $L --no-oracle > $out/pmc_w.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_r -- python3 scripts/rank_bench.py $N $L --no-oracle > $out/pmc_r.log 2>&1
 python3 - $out $tag $N $L <<'PY'
-import collections, csv, glob, hashlib, json, os, shutil, sys
+import collections, csv, glob, hashlib, json, os, re, shutil, sys
+def code_sha16(path):
+    src = open(path, encoding="utf-8").read()
+    code = "\n".join(l for l in (re.sub(r"\s*//.*$", "", ln).rstrip() for ln in src.splitlines()) if l.strip())
+    return hashlib.sha256(code.encode()).hexdigest()[:16]
 root, tag, N, L = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 ktf = glob.glob(f"{root}/kt/*/*_kernel_stats.csv")[0]
 name = os.environ.get("RANK_PROFILE_NAME", "rank_normalize")
@@ -19,7 +23,7 @@ keep = ("msd_", "rank_block", "scatter_kernel", "extract_keys", "histogram_kerne
 calls_per_run = 4                                   # rank_bench.py: one warm-up call on 4 outcomes + three timed calls on L outcomes
 out = {"command": f"rocprofv3 --pmc WRITE_SIZE (and, separately, --pmc FETCH_SIZE) --output-format csv -- python3 scripts/rank_bench.py {N} {L} --no-oracle",
        "workload": {"drugs": N, "outcomes_per_call": L, "what": "ops.rank_normalize on randn scores, MDG_RANKS_MSD=" + os.environ.get("MDG_RANKS_MSD", "1 (default: the MSD path)"),
-                    "msd_path": os.environ.get("MDG_RANKS_MSD", "1") != "0", "ranks_hip_sha16": hashlib.sha256(open("madrigal_amd/csrc/ranks.hip", "rb").read()).hexdigest()[:16]},
+                    "msd_path": os.environ.get("MDG_RANKS_MSD", "1") != "0", "ranks_hip_sha16": code_sha16("madrigal_amd/csrc/ranks.hip")},      # the code only: // comments and blank lines do not count (bench.py)
        "note": "per-dispatch averages over the run (one warm-up call on 4 outcomes + three calls on L outcomes); counters in KiB; gfx950: read bytes = 2 x FETCH_SIZE "
                "(MI355X_MICROARCH.md, HBM); FETCH / WRITE count fabric requests: bytes served by the Infinity Cache are included, so this is traffic past the L2, "
                "an upper bound on HBM bytes", "kernels": {}}
