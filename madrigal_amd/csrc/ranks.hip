@@ -631,9 +631,18 @@ __global__ __launch_bounds__(256) void msd_minmax_kernel(const float* __restrict
     kmin = kmin < a ? kmin : a;
     kmax = kmax > c ? kmax : c;
   }
+  // one pair of global atomics per workgroup, not per wave (4 096 waves of an outcome on one address serialise in the L2)
+  __shared__ uint32_t wg_mm[2];
+  if (tid == 0) { wg_mm[0] = 0xFFFFFFFFu; wg_mm[1] = 0u; }
+  __syncthreads();
   if (lane == 0 && kmin <= kmax) {
-    atomicMin(&mm[2 * seg], kmin);
-    atomicMax(&mm[2 * seg + 1], kmax);
+    atomicMin(&wg_mm[0], kmin);
+    atomicMax(&wg_mm[1], kmax);
+  }
+  __syncthreads();
+  if (tid == 0 && wg_mm[0] <= wg_mm[1]) {
+    atomicMin(&mm[2 * seg], wg_mm[0]);
+    atomicMax(&mm[2 * seg + 1], wg_mm[1]);
   }
 }
 
