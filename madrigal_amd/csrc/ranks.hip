@@ -1458,6 +1458,9 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
   for (; b < nbt; par ^= 1) {
     const int n = nn;
     const uint32_t rb = nrb;
+    // item slots in use (the same in every lane: slots behind it are skipped by scalar branches -- a bucket fills 8 or 9 of its 12, and
+    // the kernel is bound by instruction issue)
+    const int used = __builtin_amdgcn_readfirstlane((n + TPB - 1) / TPB);
     uint32_t key[ITEMS], q[ITEMS], ss[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) { key[k] = nkey[k]; q[k] = nq[k]; }
@@ -1476,7 +1479,7 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
       ss[k] = 0u;
-      if (k * TPB + tid < n) {
+      if (k < used && k * TPB + tid < n) {
         const uint32_t fi = fine_of(key[k], q[k]);
         const uint32_t fh = 16u * (fi & 1u);
         ss[k] = ((atomicAdd(&fc[fi >> 1], 1u << fh) >> fh) & 0xFFFFu) | (fi << 16);      // slot in the bin | bin
@@ -1525,7 +1528,7 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
       sc[k] = 0u;
-      if (k * TPB + tid < n) {
+      if (k < used && k * TPB + tid < n) {
         const uint32_t fi = ss[k] >> 16;
         const uint32_t s0 = fc16[fi], s1 = fc16[fi + 1];      // (two u16 reads: the halves need no selecting)
         sc[k] = s0 | ((s1 - s0) << 16);
@@ -1543,31 +1546,33 @@ __global__ __launch_bounds__(1024, 4) void msd_bucket_kernel(const u32x2* __rest
     uint32_t* dst = ranked + seg * M + rb;
 #pragma unroll
     for (int k0 = 0; k0 < ITEMS; k0 += GRP) {                // three items at a time: 12 probes in flight
-      unsigned long long o[GRP][PROBES];
+      if (k0 < used) {
+        unsigned long long o[GRP][PROBES];
 #pragma unroll
-      for (int e = 0; e < GRP; ++e) {
-        const uint32_t s0 = sc[k0 + e] & 0xFFFFu, c = sc[k0 + e] >> 16, c1 = c > 1u ? c : 0u;
+        for (int e = 0; e < GRP; ++e) {
+          const uint32_t s0 = sc[k0 + e] & 0xFFFFu, c = sc[k0 + e] >> 16, c1 = c > 1u ? c : 0u;
 #pragma unroll
-        for (int mth = 0; mth < PROBES; ++mth) {
-          o[e][mth] = ~0ull;
-          if (static_cast<uint32_t>(mth) < c1) o[e][mth] = sorted64[s0 + mth];
+          for (int mth = 0; mth < PROBES; ++mth) {
+            o[e][mth] = ~0ull;
+            if (static_cast<uint32_t>(mth) < c1) o[e][mth] = sorted64[s0 + mth];
+          }
         }
-      }
 #pragma unroll
-      for (int e = 0; e < GRP; ++e) {
-        const int k = k0 + e;
-        const uint32_t s0 = sc[k] & 0xFFFFu, c = sc[k] >> 16;
-        const unsigned long long me = (static_cast<unsigned long long>(key[k]) << 32) | q[k];
-        uint32_t r = 0;
+        for (int e = 0; e < GRP; ++e) {
+          const int k = k0 + e;
+          const uint32_t s0 = sc[k] & 0xFFFFu, c = sc[k] >> 16;
+          const unsigned long long me = (static_cast<unsigned long long>(key[k]) << 32) | q[k];
+          uint32_t r = 0;
 #pragma unroll
-        for (int mth = 0; mth < PROBES; ++mth) r += o[e][mth] < me ? 1u : 0u;
-        if (c > static_cast<uint32_t>(PROBES)) {
-          if (c > static_cast<uint32_t>(MSD_TIE_LIMIT)) too_many = true;
-          else
-            for (uint32_t mth = PROBES; mth < c; ++mth) r += sorted64[s0 + mth] < me ? 1u : 0u;
+          for (int mth = 0; mth < PROBES; ++mth) r += o[e][mth] < me ? 1u : 0u;
+          if (c > static_cast<uint32_t>(PROBES)) {
+            if (c > static_cast<uint32_t>(MSD_TIE_LIMIT)) too_many = true;
+            else
+              for (uint32_t mth = PROBES; mth < c; ++mth) r += sorted64[s0 + mth] < me ? 1u : 0u;
+          }
+          const int idx = k * TPB + tid;
+          if (idx < n) dst[idx] = ((s0 + r) << 14) | (((q[k] >> 16) & 127u) << 7) | (q[k] & 127u);
         }
-        const int idx = k * TPB + tid;
-        if (idx < n) dst[idx] = ((s0 + r) << 14) | (((q[k] >> 16) & 127u) << 7) | (q[k] & 127u);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
