@@ -732,6 +732,8 @@ def rank_normalize(scores: torch.Tensor, out: Optional[torch.Tensor] = None, max
     entry = lb.mdg_rank_normalize_keys_ld if from_keys else lb.mdg_rank_normalize_ld
     per = max(lb.mdg_rank_normalize_workspace_bytes(_c64(1), _c64(N)), 1)
     chunk = int(max(1, min(L, 65535, max_workspace_bytes // per)))
+    if chunk > 8:
+        chunk -= chunk % 8                   # whole launch groups of the MSD path (8 outcomes each): no ragged group at the end of every chunk
     for lo in range(0, L, chunk):
         hi = min(L, lo + chunk)
         nbytes = lb.mdg_rank_normalize_workspace_bytes(_c64(hi - lo), _c64(N))
