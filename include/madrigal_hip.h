@@ -346,6 +346,30 @@ int mdg_hgt_attention_bwd(const float* q, int64_t ldq, const float* kv, int64_t 
 int mdg_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 
 /* ------------------------------------------------------- gathered head (finetune step) ---- */
+/* ---- index plumbing of the gathered head's plan (madrigal_amd.ops.triple_plan; the reference feeds a new batch of labelled
+ * triples to every step, train_ddi_batch.py:231-354, so the plan is rebuilt per step).  All index arrays are int64 on the device.
+ *
+ * mdg_plan_gather: for the label-sorted order perm: hs[i] = heads[perm[i]], ts[i] = tails[perm[i]], skey[i] = labels[perm[i]] * n_head
+ *   + hs[i], inv_perm[perm[i]] = i; *status |= 1 (a label outside [0, n_labels)) | 2 (a head / tail outside its table).
+ * mdg_plan_lower_bounds: out[b] = first i with vals[i] >= b * scale, b = 0 .. n_bounds - 1 (vals ascending, val_bytes = 2 / 4 / 8:
+ *   int16 / int32 / int64): CSR pointers of a sorted index list.
+ * mdg_plan_cut_count / _fill: the lists of a CSR pointer ptr[n + 1] cut into pieces of <= size entries: first[i] = pieces of the lists
+ *   before i (first[n] = totals[0] = all pieces), totals[1] = the longest list; which[j] = the list of piece j (which may be NULL),
+ *   start[j] = its first entry, start[total] = ptr[n].  (tiles of 32 and chunks of 256 / 512 triples or pairs of one label, pieces of 64 rows of one drug)
+ * mdg_plan_pair_flags: flag[i] = 1 where skey[i] != skey[i - 1] (flag[0] = 0): its inclusive prefix sum is the (label, head) pair of
+ *   every sorted triple.  mdg_plan_pair_table: pair_ptr[p] = first triple of pair p (pair_ptr[P] = T), pair_drug[p] = its head drug.
+ * mdg_plan_take: out[i] = src[idx[i]] where 0 <= idx[i] < T, else fill. */
+int mdg_plan_gather(const int64_t* perm, const int64_t* labels, const int64_t* heads, const int64_t* tails, int64_t T, int64_t n_labels,
+                    int64_t n_head, int64_t n_tail, int64_t* hs, int64_t* ts, int64_t* skey, int64_t* inv_perm, int32_t* status, void* stream);
+int mdg_plan_lower_bounds(const void* vals, int val_bytes, int64_t T, int64_t scale, int64_t n_bounds, int64_t* out, void* stream);
+int mdg_plan_cut_count(const int64_t* ptr, int64_t n, int64_t size, int64_t* first, int64_t* totals, void* stream);
+int mdg_plan_cut_fill(const int64_t* ptr, const int64_t* first, int64_t n, int64_t size, int64_t total, int64_t* which, int64_t* start,
+                      void* stream);
+int mdg_plan_pair_flags(const int64_t* skey, int64_t T, int64_t* flag, void* stream);
+int mdg_plan_pair_table(const int64_t* skey, const int64_t* pair_of, int64_t T, int64_t n_head, int64_t P, int64_t* pair_ptr,
+                        int64_t* pair_drug, void* stream);
+int mdg_plan_take(const int64_t* src, const int64_t* idx, int64_t n, int64_t T, int64_t fill, int64_t* out, void* stream);
+
 /* train_ddi_batch.py:285-288 computes sigmoid(model(...)) [L,N,N] and reads T (label, head, tail) entries of it.  These
  * entry points compute only those entries: score[t] = z_head[head[t]]^T w[label] z_tail[tail[t]].
  * The triples are sorted by label by the caller and cut into tiles of <= 32 triples of ONE label: tile_start [n_tiles+1]

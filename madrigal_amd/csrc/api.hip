@@ -30,4 +30,4 @@ extern "C" void mdg_tuning_reload(void) { g_mdg_env_generation.fetch_add(1, std:
 
 extern "C" const char* mdg_last_error(void) { return g_err; }
 extern "C" const char* mdg_build_arch(void) { return "gfx950"; }
-extern "C" int mdg_abi_version(void) { return 8; }
+extern "C" int mdg_abi_version(void) { return 9; }

@@ -1135,102 +1135,116 @@ def l2_normalize_bwd(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------- gathered head (finetune step)
 def triple_plan(labels: torch.Tensor, heads: torch.Tensor, tails: torch.Tensor, n_labels: int, n_head: int, n_tail: int) -> dict:
-    """Index plumbing for the gathered head (torch sorts / prefix sums on the device, one host round trip for the tile
-    and chunk counts): triples sorted by label, cut into tiles of <= 32 and chunks of <= 256 triples of one label;
-    CSR lists of the sorted triples per head drug and per tail drug for the gradient row sums."""
+    """Index plumbing for the gathered head: triples sorted by label (and by head drug inside a label), cut into tiles of <= 32 and
+    chunks of <= 256 triples of one label; CSR lists of the sorted triples per head drug and per tail drug for the gradient row sums;
+    the table of (label, head drug) PAIRS (the batch holds more labelled triples than pairs, and every 128 x 128 product of the head
+    depends on the pair only: bilinear_gather_pairs / _bwd).  The reference feeds a new batch of triples to every step
+    (train_ddi_batch.py:231-354), so this runs per step: the three sorts are rocprim's (torch.sort), everything between them is the
+    mdg_plan_* kernels (csrc/plan.hip) -- ~45 launches and two host reads of a few sizes, where index / scan / repeat_interleave calls
+    took ~300 launches and 5 ms of wall time.  tests/helpers.triple_plan_torch is that earlier construction, kept as the checker."""
     T = int(labels.numel())
     dev = labels.device
     for nm, t in (("labels", labels), ("heads", heads), ("tails", tails)):
         if t.dtype != torch.int64 or not t.is_cuda or t.numel() != T or t.dim() != 1:
             raise ValueError(f"{nm}: expected int64 cuda [{T}]")
+    lb, st = lib(), _stream(labels)
+    labels, heads, tails = labels.contiguous(), heads.contiguous(), tails.contiguous()
+    i64 = lambda n: torch.empty(int(n), dtype=torch.int64, device=dev)
+
+    def bounds(vals, n_vals, scale, n_bounds):
+        out = i64(n_bounds)
+        check(lb.mdg_plan_lower_bounds(_ptr(vals), _c(vals.element_size()), _c64(n_vals), _c64(scale), _c64(n_bounds), _ptr(out), st),
+              "mdg_plan_lower_bounds")
+        return out
+
+    def by_drug(idx, n):
+        """CSR pointer over the drugs + the stable order of the entries by drug (16-bit keys when they fit: half the radix passes)."""
+        cast = torch.int16 if n <= 32767 else (torch.int32 if n < 2 ** 31 else torch.int64)
+        vals, order = torch.sort(idx.to(cast), stable=True)
+        return bounds(vals, idx.numel(), 1, n + 1), order
+
+    def cut_count(ptr, n, size, totals_row):
+        first = i64(n + 1)
+        check(lb.mdg_plan_cut_count(_ptr(ptr), _c64(n), _c64(size), _ptr(first), _ptr(totals_row), st), "mdg_plan_cut_count")
+        return first
+
+    def cut_fill(ptr, first, n, size, total, want_which=True):
+        which = i64(total) if want_which else None
+        start = i64(total + 1)
+        check(lb.mdg_plan_cut_fill(_ptr(ptr), _ptr(first), _c64(n), _c64(size), _c64(total), _ptr(which), _ptr(start), st), "mdg_plan_cut_fill")
+        return which, start
+
     # ONE sort serves the label order and the (label, head drug) pair order: by label, then by head inside a label (any
     # label-sorted order will do for the tiles; a pair's triples must be consecutive for the pair-compressed head).
     # int32 keys when they fit (twice the radix-sort rate).
     big = n_labels * max(n_head, 1) >= 2 ** 31
-    key = labels * n_head + heads if big else (labels * n_head + heads).to(torch.int32)
-    perm = torch.argsort(key, stable=True)
-    hs, ts = heads[perm].contiguous(), tails[perm].contiguous()
-    try:
-        counts = torch.bincount(labels, minlength=n_labels)
-    except RuntimeError as e:
-        raise ValueError(f"labels: value outside [0, n_labels) ({e})") from None
-    if counts.numel() != n_labels:
-        raise ValueError("labels: value outside [0, n_labels)")
-    zero = torch.zeros(1, dtype=torch.int64, device=dev)
-    label_ptr = torch.cat([zero, torch.cumsum(counts, 0)])
-    lab = torch.arange(n_labels, device=dev)
-
-    def cut(size):
-        per = (counts + size - 1) // size
-        first = torch.cumsum(per, 0) - per
-        which = torch.repeat_interleave(lab, per)
-        start = label_ptr[which] + size * (torch.arange(which.numel(), device=dev) - first[which])
-        return per, which.contiguous(), torch.cat([start, torch.tensor([T], dtype=torch.int64, device=dev)]).contiguous()
-    _, tile_label, tile_start = cut(32)
-    chunks_per, _, chunk_start = cut(256)
-    label_chunk_ptr = torch.cat([zero, torch.cumsum(chunks_per, 0)]).contiguous()
-
-    def by_drug(idx, n):
-        # the range check of the drug indices rides on the histogram: bincount raises on a negative entry and returns more than n
-        # bins when one is >= n (no separate max / min reductions over the triples)
-        order = torch.argsort(idx if n >= 2 ** 31 else idx.to(torch.int32), stable=True)
-        try:
-            cnt = torch.bincount(idx, minlength=n)
-        except RuntimeError as e:
-            raise ValueError(f"heads / tails: index outside the embedding tables ({e})") from None
-        if cnt.numel() != n:
-            raise ValueError("heads / tails: index outside the embedding tables")
-        return torch.cat([zero, torch.cumsum(cnt, 0)]).contiguous(), order.contiguous()
-
-    def pieces(ptr):
-        """A drug's list can hold thousands of entries while mdg_csr_aggregate gives a row to one group of lanes: cut every
-        list into pieces of <= 64 entries -> (piece_ptr over the entries, row_ptr over the pieces) for a two-level sum
-        (_sum_rows); None when no list is long enough to matter."""
-        counts_ = ptr[1:] - ptr[:-1]
-        if counts_.numel() == 0 or int(counts_.max()) <= 256:
-            return None
-        per = (counts_ + 63) // 64
-        first = torch.cumsum(per, 0) - per
-        which = torch.repeat_interleave(torch.arange(counts_.numel(), device=dev), per)
-        start = ptr[which] + 64 * (torch.arange(which.numel(), device=dev) - first[which])
-        return (torch.cat([start, ptr[-1:]]).contiguous(), torch.cat([zero, torch.cumsum(per, 0)]).contiguous())
+    key = labels * n_head + heads
+    perm = torch.argsort(key if big else key.to(torch.int32), stable=True)
+    hs, ts, skey, inv = i64(T), i64(T), i64(T), i64(T)
+    sizes = torch.zeros((8, 2), dtype=torch.int64, device=dev)          # rows: tiles | chunks | head pieces | tail pieces | P | status
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lb.mdg_plan_gather(_ptr(perm), _ptr(labels), _ptr(heads), _ptr(tails), _c64(T), _c64(n_labels), _c64(n_head), _c64(n_tail), _ptr(hs),
+                             _ptr(ts), _ptr(skey), _ptr(inv), _ptr(status), st), "mdg_plan_gather")
+    label_ptr = bounds(skey, T, n_head, n_labels + 1)
     head_ptr, head_rows = by_drug(hs, n_head)
     tail_ptr, tail_rows = by_drug(ts, n_tail)
-    inv = torch.empty_like(perm)
-    inv[perm] = torch.arange(T, device=dev)
-    # ---- (label, head drug) PAIRS: the batch holds more labelled triples than pairs, and every 128 x 128 product of the head
-    # depends on the pair only (bilinear_gather_pairs / _bwd).  Triples re-sorted by (label, head): pair p owns the triples
-    # pair_ptr[p] .. pair_ptr[p+1] of that order.
+    tile_first = cut_count(label_ptr, n_labels, 32, sizes[0])
+    chunk_first = cut_count(label_ptr, n_labels, 256, sizes[1])
+    hp_first = cut_count(head_ptr, n_head, 64, sizes[2])
+    tp_first = cut_count(tail_ptr, n_tail, 64, sizes[3])
+    pair_of = None
+    if T:
+        flag = i64(T)
+        check(lb.mdg_plan_pair_flags(_ptr(skey), _c64(T), _ptr(flag), st), "mdg_plan_pair_flags")
+        pair_of = torch.cumsum(flag, 0)                               # sorted triple -> its pair
+        sizes[4, 0].copy_(pair_of[T - 1])
+    sizes[5, 0].copy_(status[0])
+    host = sizes.cpu()                                                # the first of two host reads
+    if int(host[5, 0]) & 1:
+        raise ValueError("labels: value outside [0, n_labels)")
+    if int(host[5, 0]) & 2:
+        raise ValueError("heads / tails: index outside the embedding tables")
+    n_tiles, n_chunks = int(host[0, 0]), int(host[1, 0])
+    tile_label, tile_start = cut_fill(label_ptr, tile_first, n_labels, 32, n_tiles)
+    _, chunk_start = cut_fill(label_ptr, chunk_first, n_labels, 256, n_chunks, want_which=False)
+
+    def pieces(ptr, first, n, total, longest):
+        """A drug's list can hold thousands of entries while mdg_csr_aggregate gives a row to one group of lanes: every list cut into
+        pieces of <= 64 entries -> (piece_ptr over the entries, row_ptr over the pieces) for a two-level sum (_sum_rows); None when
+        no list is long enough to matter."""
+        if n == 0 or longest <= 256:
+            return None
+        return cut_fill(ptr, first, n, 64, total, want_which=False)[1], first
+    head_pieces = pieces(head_ptr, hp_first, n_head, int(host[2, 0]), int(host[2, 1]))
+    tail_pieces = pieces(tail_ptr, tp_first, n_tail, int(host[3, 0]), int(host[3, 1]))
+    # ---- (label, head drug) PAIRS: the plan's triple order IS the pair order; pair p owns the triples pair_ptr[p] .. pair_ptr[p+1]
     pairs = None
     if T:
-        pkey, pcnt = torch.unique_consecutive(key[perm], return_counts=True)     # the plan's triple order IS the pair order
-        P = int(pkey.numel())
-        pkey = pkey.to(torch.int64)
-        pair_label, pair_drug = pkey // n_head, (pkey % n_head).contiguous()
-        pair_ptr = torch.cat([zero, torch.cumsum(pcnt, 0)]).contiguous()
-        pair_of_triple = torch.repeat_interleave(torch.arange(P, device=dev), pcnt)  # sorted triple -> its pair
-        pcounts = torch.bincount(pair_label, minlength=n_labels)
-        plabel_ptr = torch.cat([zero, torch.cumsum(pcounts, 0)])
-
-        def pcut(size):
-            per = (pcounts + size - 1) // size
-            first = torch.cumsum(per, 0) - per
-            which = torch.repeat_interleave(lab, per)
-            start = plabel_ptr[which] + size * (torch.arange(which.numel(), device=dev) - first[which])
-            return per, which.contiguous(), torch.cat([start, torch.tensor([P], dtype=torch.int64, device=dev)]).contiguous()
-        _, ptile_label, ptile_start = pcut(32)
-        pchunks_per, _, pchunk_start = pcut(512)          # (256: 0.82 ms, 512 / 1024: 0.75 ms, 2048: 1.05 ms for the 2.4e6 pairs of the bench step)
+        P = int(host[4, 0]) + 1
+        pair_ptr, pair_drug = i64(P + 1), i64(P)
+        check(lb.mdg_plan_pair_table(_ptr(skey), _ptr(pair_of), _c64(T), _c64(n_head), _c64(P), _ptr(pair_ptr), _ptr(pair_drug), st),
+              "mdg_plan_pair_table")
+        plabel_ptr = i64(n_labels + 1)                                  # first pair of every label (= the pair of its first triple)
+        check(lb.mdg_plan_take(_ptr(pair_of), _ptr(label_ptr), _c64(n_labels + 1), _c64(T), _c64(P), _ptr(plabel_ptr), st), "mdg_plan_take")
+        psizes = torch.zeros((4, 2), dtype=torch.int64, device=dev)     # rows: pair tiles | pair chunks | drug pieces
+        ptile_first = cut_count(plabel_ptr, n_labels, 32, psizes[0])
+        pchunk_first = cut_count(plabel_ptr, n_labels, 512, psizes[1])  # (256: 0.82 ms, 512 / 1024: 0.75 ms, 2048: 1.05 ms for the 2.4e6 pairs of the bench step)
         drug_ptr, drug_rows = by_drug(pair_drug, n_head)
+        dp_first = cut_count(drug_ptr, n_head, 64, psizes[2])
+        of_triple_by_tail = pair_of[tail_rows]
+        phost = psizes.cpu()                                            # the second host read
+        pn_tiles, pn_chunks = int(phost[0, 0]), int(phost[1, 0])
+        ptile_label, ptile_start = cut_fill(plabel_ptr, ptile_first, n_labels, 32, pn_tiles)
+        _, pchunk_start = cut_fill(plabel_ptr, pchunk_first, n_labels, 512, pn_chunks, want_which=False)
         pairs = {"P": P, "drug": pair_drug, "ptr": pair_ptr, "tails_by_pair": ts,
-                 "of_triple": pair_of_triple, "tile_start": ptile_start, "tile_label": ptile_label, "n_tiles": int(ptile_label.numel()),
-                 "chunk_start": pchunk_start, "n_chunks": int(pchunk_start.numel()) - 1,
-                 "label_chunk_ptr": torch.cat([zero, torch.cumsum(pchunks_per, 0)]).contiguous(), "drug_ptr": drug_ptr, "drug_rows": drug_rows,
-                 "of_triple_by_tail": pair_of_triple[tail_rows].contiguous(), "drug_pieces": pieces(drug_ptr)}
+                 "of_triple": pair_of, "tile_start": ptile_start, "tile_label": ptile_label, "n_tiles": pn_tiles,
+                 "chunk_start": pchunk_start, "n_chunks": pn_chunks, "label_chunk_ptr": pchunk_first, "drug_ptr": drug_ptr, "drug_rows": drug_rows,
+                 "of_triple_by_tail": of_triple_by_tail, "drug_pieces": pieces(drug_ptr, dp_first, n_head, int(phost[2, 0]), int(phost[2, 1]))}
     return {"T": T, "L": n_labels, "n_head": n_head, "n_tail": n_tail, "perm": perm, "inv_perm": inv, "heads": hs, "tails": ts, "pairs": pairs,
-            "tile_start": tile_start, "tile_label": tile_label, "n_tiles": int(tile_label.numel()), "chunk_start": chunk_start,
-            "n_chunks": int(chunk_start.numel()) - 1, "label_chunk_ptr": label_chunk_ptr, "head_ptr": head_ptr,
-            "head_rows": head_rows, "tail_ptr": tail_ptr, "tail_rows": tail_rows, "head_pieces": pieces(head_ptr),
-            "tail_pieces": pieces(tail_ptr)}
+            "tile_start": tile_start, "tile_label": tile_label, "n_tiles": n_tiles, "chunk_start": chunk_start,
+            "n_chunks": n_chunks, "label_chunk_ptr": chunk_first, "head_ptr": head_ptr,
+            "head_rows": head_rows, "tail_ptr": tail_ptr, "tail_rows": tail_rows, "head_pieces": head_pieces,
+            "tail_pieces": tail_pieces}
 
 
 def _sum_rows(x, ptr, rows, pieces, edge_weight=None):

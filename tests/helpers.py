@@ -219,3 +219,101 @@ def assert_tensors_agree(errs, strict, loose, max_outliers=3, what=""):
     assert len(over) <= max_outliers, (what, f"{len(over)} of {len(errs)} tensors beyond {strict}", over[:8])
     assert errs[0][0] < loose, (what, errs[:4])
     return errs[0], len(over)
+
+
+def triple_plan_torch(labels: torch.Tensor, heads: torch.Tensor, tails: torch.Tensor, n_labels: int, n_head: int, n_tail: int) -> dict:
+    """CHECKER for madrigal_amd.ops.triple_plan (its construction until round 5: torch sorts / index / scan calls on the device): triples sorted by label, cut into tiles of <= 32 and chunks of <= 256 triples of one label;
+    CSR lists of the sorted triples per head drug and per tail drug for the gradient row sums."""
+    T = int(labels.numel())
+    dev = labels.device
+    for nm, t in (("labels", labels), ("heads", heads), ("tails", tails)):
+        if t.dtype != torch.int64 or not t.is_cuda or t.numel() != T or t.dim() != 1:
+            raise ValueError(f"{nm}: expected int64 cuda [{T}]")
+    # ONE sort serves the label order and the (label, head drug) pair order: by label, then by head inside a label (any
+    # label-sorted order will do for the tiles; a pair's triples must be consecutive for the pair-compressed head).
+    # int32 keys when they fit (twice the radix-sort rate).
+    big = n_labels * max(n_head, 1) >= 2 ** 31
+    key = labels * n_head + heads if big else (labels * n_head + heads).to(torch.int32)
+    perm = torch.argsort(key, stable=True)
+    hs, ts = heads[perm].contiguous(), tails[perm].contiguous()
+    try:
+        counts = torch.bincount(labels, minlength=n_labels)
+    except RuntimeError as e:
+        raise ValueError(f"labels: value outside [0, n_labels) ({e})") from None
+    if counts.numel() != n_labels:
+        raise ValueError("labels: value outside [0, n_labels)")
+    zero = torch.zeros(1, dtype=torch.int64, device=dev)
+    label_ptr = torch.cat([zero, torch.cumsum(counts, 0)])
+    lab = torch.arange(n_labels, device=dev)
+
+    def cut(size):
+        per = (counts + size - 1) // size
+        first = torch.cumsum(per, 0) - per
+        which = torch.repeat_interleave(lab, per)
+        start = label_ptr[which] + size * (torch.arange(which.numel(), device=dev) - first[which])
+        return per, which.contiguous(), torch.cat([start, torch.tensor([T], dtype=torch.int64, device=dev)]).contiguous()
+    _, tile_label, tile_start = cut(32)
+    chunks_per, _, chunk_start = cut(256)
+    label_chunk_ptr = torch.cat([zero, torch.cumsum(chunks_per, 0)]).contiguous()
+
+    def by_drug(idx, n):
+        # the range check of the drug indices rides on the histogram: bincount raises on a negative entry and returns more than n
+        # bins when one is >= n (no separate max / min reductions over the triples)
+        order = torch.argsort(idx if n >= 2 ** 31 else idx.to(torch.int32), stable=True)
+        try:
+            cnt = torch.bincount(idx, minlength=n)
+        except RuntimeError as e:
+            raise ValueError(f"heads / tails: index outside the embedding tables ({e})") from None
+        if cnt.numel() != n:
+            raise ValueError("heads / tails: index outside the embedding tables")
+        return torch.cat([zero, torch.cumsum(cnt, 0)]).contiguous(), order.contiguous()
+
+    def pieces(ptr):
+        """A drug's list can hold thousands of entries while mdg_csr_aggregate gives a row to one group of lanes: cut every
+        list into pieces of <= 64 entries -> (piece_ptr over the entries, row_ptr over the pieces) for a two-level sum
+        (_sum_rows); None when no list is long enough to matter."""
+        counts_ = ptr[1:] - ptr[:-1]
+        if counts_.numel() == 0 or int(counts_.max()) <= 256:
+            return None
+        per = (counts_ + 63) // 64
+        first = torch.cumsum(per, 0) - per
+        which = torch.repeat_interleave(torch.arange(counts_.numel(), device=dev), per)
+        start = ptr[which] + 64 * (torch.arange(which.numel(), device=dev) - first[which])
+        return (torch.cat([start, ptr[-1:]]).contiguous(), torch.cat([zero, torch.cumsum(per, 0)]).contiguous())
+    head_ptr, head_rows = by_drug(hs, n_head)
+    tail_ptr, tail_rows = by_drug(ts, n_tail)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(T, device=dev)
+    # ---- (label, head drug) PAIRS: the batch holds more labelled triples than pairs, and every 128 x 128 product of the head
+    # depends on the pair only (bilinear_gather_pairs / _bwd).  Triples re-sorted by (label, head): pair p owns the triples
+    # pair_ptr[p] .. pair_ptr[p+1] of that order.
+    pairs = None
+    if T:
+        pkey, pcnt = torch.unique_consecutive(key[perm], return_counts=True)     # the plan's triple order IS the pair order
+        P = int(pkey.numel())
+        pkey = pkey.to(torch.int64)
+        pair_label, pair_drug = pkey // n_head, (pkey % n_head).contiguous()
+        pair_ptr = torch.cat([zero, torch.cumsum(pcnt, 0)]).contiguous()
+        pair_of_triple = torch.repeat_interleave(torch.arange(P, device=dev), pcnt)  # sorted triple -> its pair
+        pcounts = torch.bincount(pair_label, minlength=n_labels)
+        plabel_ptr = torch.cat([zero, torch.cumsum(pcounts, 0)])
+
+        def pcut(size):
+            per = (pcounts + size - 1) // size
+            first = torch.cumsum(per, 0) - per
+            which = torch.repeat_interleave(lab, per)
+            start = plabel_ptr[which] + size * (torch.arange(which.numel(), device=dev) - first[which])
+            return per, which.contiguous(), torch.cat([start, torch.tensor([P], dtype=torch.int64, device=dev)]).contiguous()
+        _, ptile_label, ptile_start = pcut(32)
+        pchunks_per, _, pchunk_start = pcut(512)          # (256: 0.82 ms, 512 / 1024: 0.75 ms, 2048: 1.05 ms for the 2.4e6 pairs of the bench step)
+        drug_ptr, drug_rows = by_drug(pair_drug, n_head)
+        pairs = {"P": P, "drug": pair_drug, "ptr": pair_ptr, "tails_by_pair": ts,
+                 "of_triple": pair_of_triple, "tile_start": ptile_start, "tile_label": ptile_label, "n_tiles": int(ptile_label.numel()),
+                 "chunk_start": pchunk_start, "n_chunks": int(pchunk_start.numel()) - 1,
+                 "label_chunk_ptr": torch.cat([zero, torch.cumsum(pchunks_per, 0)]).contiguous(), "drug_ptr": drug_ptr, "drug_rows": drug_rows,
+                 "of_triple_by_tail": pair_of_triple[tail_rows].contiguous(), "drug_pieces": pieces(drug_ptr)}
+    return {"T": T, "L": n_labels, "n_head": n_head, "n_tail": n_tail, "perm": perm, "inv_perm": inv, "heads": hs, "tails": ts, "pairs": pairs,
+            "tile_start": tile_start, "tile_label": tile_label, "n_tiles": int(tile_label.numel()), "chunk_start": chunk_start,
+            "n_chunks": int(chunk_start.numel()) - 1, "label_chunk_ptr": label_chunk_ptr, "head_ptr": head_ptr,
+            "head_rows": head_rows, "tail_ptr": tail_ptr, "tail_rows": tail_rows, "head_pieces": pieces(head_ptr),
+            "tail_pieces": pieces(tail_ptr)}
