@@ -520,8 +520,10 @@ def finetune_leg(model, batch, bkg, filler, N, L, args, rank=0, world=1, backend
     torch.manual_seed(4321 + rank)
     def one_step(i_, fresh):
         if fresh and sides:
-            # (preparing the next step's mask and triple plans on a side stream while this step runs was tried -- FinetuneStep.prefetch,
-            # round 5 -- and removed: its host round trips cost the queueing thread what they saved the device: 42.3 against 41.8 ms)
+            # (preparing the next step's mask and triple plans on a side stream while this step runs was tried twice in round 5 -- with
+            # the torch-built triple plan: 42.3 against 41.8 ms; masks alone, after the plan moved to csrc/plan.hip: 42.1 against 42.4 --
+            # and removed: the fresh step is bound by its kernels (41 ms of them; two different molecule batches and mask patterns per
+            # step are more work than one shared batch), not by the host reads of its plans)
             hb, tb = sides[i_ % n_var]
             return fs.step(hb, tb, draw_masks(), draw_masks(), bkg, *sets[(i_ + 1) % 3], kg_filler=filler)
         return fs.step(batch, batch, batch["masks"], batch["masks"], bkg, *sets[(i_ + 1) % 3], kg_filler=filler)
